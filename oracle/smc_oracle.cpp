@@ -1,0 +1,972 @@
+/* oracle/smc_oracle.cpp -- TEST INFRASTRUCTURE (CPU oracle), not product code.
+ *
+ * Single-threaded restatement of the smcsmc particle-filter forward sweep.  Each function
+ * cites the reference lines it follows (paths relative to /root/reference/src).
+ * PARITY STATUS: "parity unpinned" against the upstream binary (see smc_oracle.h).
+ *
+ * What is restated verbatim (arithmetic order included):
+ *   extend_ARG                 particle.cpp:743-918
+ *   calculate_likelihood       particle.cpp:625-680
+ *   trackLocalTreeBranchLength particle.cpp:699-730
+ *   update_weight_at_site      particleContainer.cpp:138-224
+ *   normalize_probability      particleContainer.cpp:420-438
+ *   resample / systematic      particleContainer.cpp:247-311, 474-504, 321-392
+ *   event records + counting   particle.cpp:193-390, coalevent.hpp:209-244, count.cpp:355-555
+ * What is reconstructed (the scrm fork is absent): the SMC' genealogy
+ * update (Forest::sampleNextGenealogy / sampleCoalescences, mirrored by particle.cpp:1266-1384):
+ * cut the local tree at a uniform point, let the floating lineage coalesce upwards at rate
+ * (#contemporaries)/(2N(t)) through time intervals delimited by node heights and epoch
+ * boundaries, with the buffered unit exponential of RandomGenerator::sampleExpoLimit.
+ *
+ * Documented representation choices (DESIGN.md "Deviations"):
+ *   D1 counter-based Philox stream per particle slot instead of one shared MersenneTwister
+ *   D2 multiplicities expanded: always Np records of multiplicity 1 (particle.cpp:831-857)
+ *   D3 canonical radix-64 reduction / scan order for sums (exact definition in canon_* below)
+ *   D4 u_j = (j+U)/N in closed form instead of the running sum of particleContainer.cpp:494
+ *   D5 ESS computed as S1*S1/S2 on the un-normalised pilot weights (scale invariant)
+ *   D6 recombination-opportunity rectangles are closed when the stretch ends instead of being
+ *      written with the sampled next_base and patched on resampling (particle.cpp:393-436);
+ *      the sums of count.cpp:495-555 are identical
+ */
+#include "smc_oracle.h"
+#include "smc_math.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace smco {
+
+static thread_local std::string g_err;
+
+enum { NMAX = 16 };
+enum { REC_RECOMB = 1, REC_COALMIGR = 2 };
+
+/* ------------------------------------------------------------------ canonical reductions */
+
+/* pairwise tree over 64 slots: identical association to a 64-lane xor-butterfly */
+static double tree64(const double* x, int64_t n) {
+    double v[64];
+    for (int i = 0; i < 64; ++i) v[i] = i < n ? x[i] : 0.0;
+    for (int m = 1; m < 64; m <<= 1)
+        for (int i = 0; i < 64; i += 2 * m) v[i] = v[i] + v[i + m];
+    return v[0];
+}
+
+/* always three radix-64 levels (supports n <= 262144) */
+static double canon_sum(const double* x, int64_t n) {
+    if (n > 262144) throw std::runtime_error("canon_sum: n too large");
+    std::vector<double> l1((n + 63) / 64);
+    for (int64_t c = 0; c < (int64_t)l1.size(); ++c) l1[c] = tree64(x + c * 64, std::min<int64_t>(64, n - c * 64));
+    std::vector<double> l2((l1.size() + 63) / 64);
+    for (int64_t c = 0; c < (int64_t)l2.size(); ++c)
+        l2[c] = tree64(l1.data() + c * 64, std::min<int64_t>(64, (int64_t)l1.size() - c * 64));
+    return tree64(l2.data(), (int64_t)l2.size());
+}
+
+/* Hillis-Steele inclusive scan of up to 64 values (the association a wave scan produces) */
+static void hs64(const double* x, double* out, int64_t n) {
+    double v[64], w[64];
+    for (int i = 0; i < 64; ++i) v[i] = i < n ? x[i] : 0.0;
+    for (int d = 1; d < 64; d <<= 1) {
+        for (int i = 0; i < 64; ++i) w[i] = i >= d ? v[i - d] + v[i] : v[i];
+        for (int i = 0; i < 64; ++i) v[i] = w[i];
+    }
+    for (int i = 0; i < n; ++i) out[i] = v[i];
+}
+
+static void canon_scan(const double* x, double* incl, int64_t n) {
+    if (n > 262144) throw std::runtime_error("canon_scan: n too large");
+    int64_t nc = (n + 63) / 64;
+    std::vector<double> l1(n), tot(nc), l2(nc);
+    for (int64_t c = 0; c < nc; ++c) {
+        int64_t m = std::min<int64_t>(64, n - c * 64);
+        hs64(x + c * 64, l1.data() + c * 64, m);
+        tot[c] = l1[c * 64 + m - 1];
+    }
+    int64_t ng = (nc + 63) / 64;
+    std::vector<double> base(ng);
+    double run = 0.0;
+    for (int64_t g = 0; g < ng; ++g) {
+        int64_t m = std::min<int64_t>(64, nc - g * 64);
+        hs64(tot.data() + g * 64, l2.data() + g * 64, m);
+        base[g] = run;
+        run = run + l2[g * 64 + m - 1];
+    }
+    for (int64_t c = 0; c < nc; ++c) {
+        double off = (c % 64 == 0) ? 0.0 : l2[c - 1];
+        double chunk_off = base[c / 64] + off;
+        int64_t m = std::min<int64_t>(64, n - c * 64);
+        for (int64_t i = 0; i < m; ++i) incl[c * 64 + i] = chunk_off + l1[c * 64 + i];
+    }
+}
+
+/* particleContainer.cpp:474-504 in closed form (D4): lo[i] = #{ j in [0,N) : (j+U)/N < cum_i } */
+static void systematic(const double* incl, int64_t n, double u, int32_t* lo) {
+    const double total = incl[n - 1];
+    const double dn = (double)n;
+    lo[0] = 0;
+    for (int64_t i = 1; i < n; ++i) {
+        double cum = incl[i - 1] / total;
+        double guess = std::floor(cum * dn - u);
+        int64_t g = guess < 0 ? 0 : (guess > dn ? n : (int64_t)guess);
+        while (g > 0 && !((((double)(g - 1)) + u) / dn < cum)) --g;
+        while (g < n && ((((double)g) + u) / dn < cum)) ++g;
+        lo[i] = (int32_t)g;
+    }
+    lo[n] = (int32_t)n;
+}
+
+/* ------------------------------------------------------------------ model */
+
+struct Model {
+    int E = 0, P = 1, n = 0;
+    bool ancestral_aware = false, dephase = false;
+    double L = 0, mu = 0, rho = 0;
+    std::vector<double> T;       /* epoch start times */
+    std::vector<double> inv2N;   /* 1/(2 N_e) */
+    std::vector<int> recflags;
+    std::vector<double> lags;
+    int epoch_of(double t) const {
+        int e = 0;
+        while (e + 1 < E && T[e + 1] <= t) ++e;
+        return e;
+    }
+    double epoch_end(int e) const { return e + 1 < E ? T[e + 1] : HUGE_VAL; }
+};
+
+/* ------------------------------------------------------------------ event records
+ * reference: coalevent.hpp:71-369 (EvolutionaryEvent), arena.cpp (allocator; here a free list) */
+
+struct Ev {
+    double t0, t1;      /* start_height, end_height */
+    double x0, x1;      /* recomb: [start_base,end_base]; coal: x0 = x1 = position */
+    Ev* parent;
+    double acc;         /* posterior_ */
+    int32_t arrived;    /* children_updated_ */
+    int32_t refs;       /* ref_counter_ */
+    int16_t weight;     /* number of contemporaries */
+    int8_t kind;        /* 0 recombination opportunity, 1 coalescence opportunity */
+    int8_t event;       /* 1 if an event sits on this record (recomb: at (x0, ev_t); coal: at t1) */
+    int8_t dead;
+    double ev_t;        /* recombination event height (coalevent.hpp:170-176) */
+};
+
+struct Pool {
+    std::vector<Ev*> blocks;
+    Ev* free_list = nullptr;
+    int64_t n_alloc = 0, n_live = 0;
+    Ev* get() {
+        if (!free_list) {
+            Ev* b = (Ev*)std::malloc(sizeof(Ev) * 65536);
+            blocks.push_back(b);
+            for (int i = 0; i < 65536; ++i) { b[i].parent = free_list; free_list = &b[i]; }
+        }
+        Ev* e = free_list;
+        free_list = e->parent;
+        ++n_alloc; ++n_live;
+        return e;
+    }
+    void put(Ev* e) { e->parent = free_list; free_list = e; --n_live; }
+    ~Pool() { for (Ev* b : blocks) std::free(b); }
+};
+
+/* ------------------------------------------------------------------ particle */
+
+struct Tree {
+    /* local tree over n leaves, internal nodes kept sorted by height:
+     * S[r] = height of the internal node of rank r; C[r][0..1] = its children,
+     * child id < n : leaf (sample index), id >= n : internal node of rank id-n. */
+    double S[NMAX - 1];
+    int8_t C[NMAX - 1][2];
+};
+
+struct Particle {
+    Tree tr;
+    double w_post, w_pilot;
+    double next_base;
+    double x_mark;          /* start of the current recombination-opportunity stretch */
+    int mark_limit;         /* max_epoch_to_record_ in force when the stretch was opened */
+    double Ltree;
+    std::vector<Ev*> head;  /* eventTrees[epoch] (particle.hpp:235) */
+    std::vector<Ev*> open;  /* the open rectangles of the current stretch (heads of their chains) */
+};
+
+struct SlotRng { uint64_t ctr; double ebuf; };
+
+struct Filter {
+    Model M;
+    int64_t Np;
+    double ess_fraction;
+    uint64_t seed;
+    std::vector<Particle> parts;
+    std::vector<SlotRng> rng;
+    Pool pool;
+    double logl = 0;
+    double cur_pos = 0;           /* site_where_weight_was_updated_ (identical for all particles) */
+    int cur_limit = 0;
+    int64_t n_resample = 0;
+    int64_t n_recomb = 0;
+    /* count model (count.hpp) */
+    std::vector<double> coal_count, coal_opp, coal_w2, rec_count, rec_opp, rec_w2, counted_to;
+    double delayed_opp = 0, delayed_count = 0;
+    /* trace */
+    std::vector<double> tr_T, tr_ess, tr_logl;
+    std::vector<int32_t> tr_flag;
+    int32_t max_trace_events;
+    std::vector<int32_t> ev_seg;
+    std::vector<std::vector<int32_t>> ev_parents;
+    int64_t seg_done = 0;
+
+    double uni(int64_t slot) { return philox_uniform(seed, (uint32_t)slot, 0, rng[slot].ctr++); }
+
+    /* ---------------- tree helpers ---------------- */
+    inline double node_h(const Tree& t, int id) const { return id < M.n ? 0.0 : t.S[id - M.n]; }
+
+    /* local tree length by time slices: sum_r (n-r) * (S[r]-S[r-1])   (Forest::getLocalTreeLength) */
+    double tree_length(const Tree& t, int nleaves) const {
+        double acc = 0.0, prev = 0.0;
+        for (int r = 0; r < nleaves - 1; ++r) {
+            acc += (double)(nleaves - r) * (t.S[r] - prev);
+            prev = t.S[r];
+        }
+        return acc;
+    }
+
+    /* enumerate the lineages of the tree (ni internal nodes stored) that cross time t, in
+     * canonical order: parent rank ascending, child 0 then child 1.  Returns the count and
+     * writes the idx-th slot to (pr, ps).  Lineages are "slots": child pointers whose child
+     * lies at or below t while the parent lies above t. */
+    int lineages_at(const Tree& t, int ni, double time, int want, int* pr, int* ps) const {
+        int R = 0;
+        while (R < ni && t.S[R] <= time) ++R;
+        int cnt = 0;
+        for (int r = R; r < ni; ++r)
+            for (int s = 0; s < 2; ++s) {
+                int id = t.C[r][s];
+                if (id < M.n || id - M.n < R) {
+                    if (cnt == want) { *pr = r; *ps = s; }
+                    ++cnt;
+                }
+            }
+        return cnt;
+    }
+
+    /* remove internal node of rank rp from a tree with ni internal nodes; its parent slot
+     * (if any) is re-pointed to `sib`.  Tracked ids *a,*b are relabelled alongside. */
+    void remove_rank(Tree& t, int ni, int rp, int sib, int* a, int* b) const {
+        const int n = M.n;
+        const int pid = n + rp;
+        for (int r = rp + 1; r < ni; ++r)
+            for (int s = 0; s < 2; ++s)
+                if (t.C[r][s] == pid) t.C[r][s] = (int8_t)sib;
+        for (int r = rp; r + 1 < ni; ++r) {
+            t.S[r] = t.S[r + 1];
+            t.C[r][0] = t.C[r + 1][0];
+            t.C[r][1] = t.C[r + 1][1];
+        }
+        for (int r = 0; r < ni - 1; ++r)
+            for (int s = 0; s < 2; ++s)
+                if (t.C[r][s] > pid) t.C[r][s] -= 1;
+        if (*a > pid) *a -= 1;
+        if (*b > pid) *b -= 1;
+    }
+
+    /* insert a new internal node at height h joining floating id `fl` and the lineage in slot
+     * (pr,ps) -- or the tree root `root_id` if pr < 0 -- into a tree with ni internal nodes. */
+    void insert_node(Tree& t, int ni, double h, int fl, int pr, int ps, int root_id) const {
+        const int n = M.n;
+        int rn = 0;
+        while (rn < ni && t.S[rn] <= h) ++rn;
+        const int nid = n + rn;
+        for (int r = 0; r < ni; ++r)
+            for (int s = 0; s < 2; ++s)
+                if (t.C[r][s] >= nid) t.C[r][s] += 1;
+        if (fl >= nid) fl += 1;
+        if (root_id >= nid) root_id += 1;
+        for (int r = ni; r > rn; --r) {
+            t.S[r] = t.S[r - 1];
+            t.C[r][0] = t.C[r - 1][0];
+            t.C[r][1] = t.C[r - 1][1];
+        }
+        int target;
+        if (pr >= 0) {
+            if (pr >= rn) pr += 1;
+            target = t.C[pr][ps];
+            t.C[pr][ps] = (int8_t)nid;
+        } else {
+            target = root_id;
+        }
+        t.S[rn] = h;
+        t.C[rn][0] = (int8_t)fl;
+        t.C[rn][1] = (int8_t)target;
+    }
+
+    /* ---------------- event recording (particle.cpp:193-390) ---------------- */
+    Ev* new_event(Particle& p, int epoch, int kind, double t0, double t1, double x0, double x1, int weight) {
+        Ev* e = pool.get();
+        e->t0 = t0; e->t1 = t1; e->x0 = x0; e->x1 = x1;
+        e->acc = 0; e->arrived = 0; e->refs = 1;
+        e->weight = (int16_t)weight; e->kind = (int8_t)kind; e->event = 0; e->dead = 0; e->ev_t = -1;
+        e->parent = p.head[epoch];      /* add_leaf_to_tree: coalevent.hpp:288-303 (takes over the head's reference) */
+        p.head[epoch] = e;
+        return e;
+    }
+    void release(Ev* e) {
+        while (e && --e->refs == 0) {
+            Ev* par = e->parent;
+            pool.put(e);
+            e = par;
+        }
+    }
+
+    /* record_recomb_extension (particle.cpp:305-357): one rectangle per (tree time-slice x epoch)
+     * with weight = number of local contemporaries; opened at x = p.x_mark, closed later (D6). */
+    void open_stretch(Particle& p, double x, int limit) {
+        p.x_mark = x;
+        p.mark_limit = limit;
+        p.open.clear();
+        const int n = M.n;
+        double prev = 0.0;
+        for (int r = 0; r < n - 1; ++r) {
+            double top = p.tr.S[r];
+            int k = n - r;
+            double t = prev;
+            int e = M.epoch_of(t);
+            while (t < top) {
+                double t1 = std::min(top, M.epoch_end(e));
+                if ((M.recflags[e] & REC_RECOMB) && e <= limit)
+                    p.open.push_back(new_event(p, e, 0, t, t1, x, HUGE_VAL, k));
+                t = t1;
+                if (t < top) ++e;
+            }
+            prev = top;
+        }
+    }
+    void close_stretch(Particle& p, double x) {
+        for (Ev* e : p.open) e->x1 = x;
+        p.open.clear();
+    }
+
+    /* ---------------- the floating-lineage coalescence (SMC') ----------------
+     * Reconstructed Forest::sampleCoalescences for one population; interval walk mirrors
+     * particle.cpp:1325-1382, rates per SURVEY 8c, exponential buffer per SURVEY A12.
+     * Sh[0..ns) are the sorted heights that delimit the lineage count k(t) = nl - #{Sh <= t}
+     * (1 above the top).  Records one coal-opportunity record per interval (record_all_event,
+     * particle.cpp:251-300) at position x, and returns the coalescence time. */
+    double coalesce_up(int64_t slot, Particle* rec_p, const double* Sh, int ns, int nl, double h, double x,
+                       int limit) {
+        SlotRng& g = rng[slot];
+        double t = h;
+        int e = M.epoch_of(t);
+        int i = 0;
+        while (i < ns && Sh[i] <= t) ++i;
+        for (;;) {
+            double tn_node = i < ns ? Sh[i] : HUGE_VAL;
+            double tn_ep = M.epoch_end(e);
+            double tn = std::min(tn_node, tn_ep);
+            int k = i < ns ? nl - i : 1;
+            double rate = (double)k * M.inv2N[e];
+            double need = (tn - t) * rate;
+            bool fire = !(g.ebuf > need);
+            double t1 = tn;
+            if (fire) t1 = t + g.ebuf / rate;
+            if (rec_p && (M.recflags[e] & REC_COALMIGR) && e <= limit) {
+                Ev* ev = new_event(*rec_p, e, 1, t, t1, x, x, k);
+                if (fire) ev->event = 1;
+            }
+            if (fire) {
+                g.ebuf = -smc_log(uni(slot));
+                return t1;
+            }
+            g.ebuf -= need;
+            t = tn;
+            if (tn_node <= tn) ++i;
+            if (tn_ep <= tn) ++e;
+        }
+    }
+
+    /* Forest::sampleNextBase via ForestState::sampleNextBase (particle.cpp:1195-1254), multiplicity 1 */
+    void sample_next_base(int64_t slot, Particle& p, double x) {
+        SlotRng& g = rng[slot];
+        double rate = M.rho * p.Ltree;
+        double limit = M.L - x;
+        double need = limit * rate;
+        if (g.ebuf > need) {
+            g.ebuf -= need;
+            p.next_base = M.L;
+        } else {
+            double nb = x + g.ebuf / rate;
+            g.ebuf = -smc_log(uni(slot));
+            if (nb == x) nb = std::nextafter(x, x * 2 + 1);   /* particle.cpp:1238-1244 */
+            if (nb > M.L) nb = M.L;
+            p.next_base = nb;
+        }
+    }
+
+    /* Forest::buildInitialTree(true) [reconstructed]: add the samples one at a time, each new
+     * leaf coalescing into the partial tree; coalescences are recorded at position 0. */
+    void build_initial_tree(int64_t slot, Particle& p) {
+        const int n = M.n;
+        Tree& t = p.tr;
+        int root = 0;
+        for (int i = 1; i < n; ++i) {
+            int ni = i - 1;
+            double tc = coalesce_up(slot, &p, t.S, ni, i, 0.0, 0.0, M.E - 1);
+            int pr = -1, ps = 0;
+            int k = lineages_at(t, ni, tc, -1, &pr, &ps);
+            bool above_root = (ni == 0) || (tc >= t.S[ni - 1]);
+            int kk = above_root ? 1 : k;
+            double u = uni(slot);
+            int idx = std::min((int)(u * (double)kk), kk - 1);
+            if (above_root) {
+                insert_node(t, ni, tc, i, -1, 0, root);
+            } else {
+                lineages_at(t, ni, tc, idx, &pr, &ps);
+                insert_node(t, ni, tc, i, pr, ps, root);
+            }
+            root = n + ni;     /* the top-ranked node is the root of the partial tree */
+        }
+        p.Ltree = tree_length(t, n);
+    }
+
+    /* One genealogy update at position x: samplePoint (particle.cpp:1060-1126, unbiased case),
+     * cut, coalesce, re-attach.  Returns the recombination height through *h_out. */
+    void genealogy_update(int64_t slot, Particle& p, double x, int limit, double* h_out) {
+        const int n = M.n;
+        Tree& t = p.tr;
+        /* --- sample the recombination point uniformly on the local tree (one uniform) --- */
+        double r = uni(slot) * p.Ltree;
+        double prev = 0.0, h = 0.0;
+        int lin = 0, slice = 0;
+        for (int ri = 0; ri < n - 1; ++ri) {
+            int k = n - ri;
+            double d = t.S[ri] - prev;
+            double seg = (double)k * d;
+            if (r < seg || ri == n - 2) {
+                double q = r / d;
+                lin = std::min((int)q, k - 1);
+                h = prev + (q - (double)lin) * d;
+                if (!(h < t.S[ri])) h = prev;
+                slice = ri;
+                break;
+            }
+            r -= seg;
+            prev = t.S[ri];
+        }
+        (void)slice;
+        int rp = 0, sb = 0;
+        lineages_at(t, n - 1, h, lin, &rp, &sb);   /* branch b = slot (rp,sb); its parent p has rank rp */
+        *h_out = h;
+        /* --- coalesce upwards against the full old tree (SMC': the cut branch's stub is a target) --- */
+        double Sold[NMAX - 1];
+        for (int i = 0; i < n - 1; ++i) Sold[i] = t.S[i];
+        double tc = coalesce_up(slot, &p, Sold, n - 1, n, h, x, limit);
+        double Sp = t.S[rp];
+        /* --- detach: remove p, sibling takes its place --- */
+        int b_id = t.C[rp][sb], s_id = t.C[rp][1 - sb];
+        bool p_was_root = (rp == n - 2);
+        remove_rank(t, n - 1, rp, s_id, &b_id, &s_id);
+        int ni = n - 2;
+        int troot = p_was_root ? s_id : n + (ni - 1);
+        /* --- target lineage: slots of the pruned tree crossing tc, then ROOT, then STUB --- */
+        int pr = -1, ps = 0;
+        int nslots = lineages_at(t, ni, tc, -1, &pr, &ps);
+        bool has_root = tc >= node_h(t, troot);
+        bool has_stub = tc < Sp;
+        int k = nslots + (has_root ? 1 : 0) + (has_stub ? 1 : 0);
+        double u = uni(slot);
+        int idx = std::min((int)(u * (double)k), k - 1);
+        if (idx < nslots) {
+            lineages_at(t, ni, tc, idx, &pr, &ps);
+            insert_node(t, ni, tc, b_id, pr, ps, troot);
+        } else if (has_root && idx == nslots) {
+            insert_node(t, ni, tc, b_id, -1, 0, troot);
+        } else {
+            /* coalesced back into its own branch above the cut: tree unchanged -> restore p */
+            if (p_was_root) {
+                insert_node(t, ni, Sp, b_id, -1, 0, troot);
+            } else {
+                /* the sibling lineage's slot at time Sp */
+                int want = -1, c = 0;
+                int R = 0;
+                while (R < ni && t.S[R] <= Sp) ++R;
+                for (int rr = R; rr < ni && want < 0; ++rr)
+                    for (int s = 0; s < 2 && want < 0; ++s) {
+                        int id = t.C[rr][s];
+                        if (id < n || id - n < R) {
+                            if (id == s_id) want = c;
+                            ++c;
+                        }
+                    }
+                lineages_at(t, ni, Sp, want, &pr, &ps);
+                insert_node(t, ni, Sp, b_id, pr, ps, troot);
+            }
+        }
+        p.Ltree = tree_length(t, n);
+        ++n_recomb;
+    }
+
+    /* record_recomb_event (particle.cpp:360-390): mark the rectangle of the new stretch whose
+     * time range contains h */
+    void record_recomb_event(Particle& p, double h, int limit) {
+        int e = M.epoch_of(h);
+        if (e > limit) return;
+        if (!(M.recflags[e] & REC_RECOMB)) return;
+        for (Ev* ev = p.head[e]; ev; ev = ev->parent) {
+            if (ev->kind == 0 && ev->t0 <= h && h <= ev->t1) {
+                if (ev->x0 == p.x_mark && !ev->event) { ev->event = 1; ev->ev_t = h; }
+                return;
+            }
+        }
+    }
+
+    /* trackLocalTreeBranchLength (particle.cpp:699-730) on the rank-sorted tree */
+    double tracked_length(const Tree& t, const int8_t* data) const {
+        const int n = M.n;
+        double stbl[2 * NMAX];
+        for (int i = 0; i < n; ++i) stbl[i] = data[i] >= 0 ? 0.0 : -1.0;
+        double total = 0.0;
+        for (int r = 0; r < n - 1; ++r) {
+            int c0 = t.C[r][0], c1 = t.C[r][1];
+            double l = stbl[c0], rr = stbl[c1];
+            if (l >= 0.0) l += t.S[r] - node_h(t, c0);
+            if (rr >= 0.0) rr += t.S[r] - node_h(t, c1);
+            double v;
+            if (l >= 0.0 && rr >= 0.0) { total = l + rr; v = total; }
+            else if (l >= 0.0) v = l;
+            else v = rr;
+            stbl[n + r] = v;
+        }
+        return total;
+    }
+
+    /* calculate_likelihood + cal_partial_likelihood_infinite (particle.cpp:625-680) */
+    double site_likelihood(const Tree& t, const int* hap) const {
+        const int n = M.n;
+        double m0[2 * NMAX], m1[2 * NMAX];
+        for (int i = 0; i < n; ++i) {
+            m0[i] = hap[i] == 1 ? 0.0 : 1.0;
+            m1[i] = hap[i] == 0 ? 0.0 : 1.0;
+        }
+        for (int r = 0; r < n - 1; ++r) {
+            int c0 = t.C[r][0], c1 = t.C[r][1];
+            double tl = t.S[r] - node_h(t, c0);
+            double trr = t.S[r] - node_h(t, c1);
+            double pl = fastexp(-tl * M.mu);
+            double pr = fastexp(-trr * M.mu);
+            m0[n + r] = (m0[c0] * pl + m1[c0] * (1 - pl)) * (m0[c1] * pr + m1[c1] * (1 - pr));
+            m1[n + r] = (m1[c0] * pl + m0[c0] * (1 - pl)) * (m1[c1] * pr + m0[c1] * (1 - pr));
+        }
+        int root = n + n - 2;
+        double p0 = M.ancestral_aware ? 1.0 : 0.5, p1 = M.ancestral_aware ? 0.0 : 0.5;
+        return m0[root] * p0 + m1[root] * p1;
+    }
+
+    /* ---------------- ParticleContainer ---------------- */
+
+    /* particleContainer.cpp:33-65 */
+    void init_prior(double initial_position) {
+        parts.assign(Np, Particle());
+        rng.assign(Np, SlotRng{0, 0.0});
+        for (int64_t i = 0; i < Np; ++i) {
+            Particle& p = parts[i];
+            p.head.assign(M.E, nullptr);
+            rng[i].ebuf = -smc_log(uni(i));
+            build_initial_tree(i, p);
+            sample_next_base(i, p, 0.0);
+            open_stretch(p, 0.0, M.E - 1);
+            p.w_post = 1.0 / (double)Np;
+            p.w_pilot = 1.0 / (double)Np;
+        }
+        cur_pos = initial_position;
+        logl = 0;
+        const int E = M.E;
+        coal_count.assign(E, 0); coal_opp.assign(E, 0); coal_w2.assign(E, 0);
+        rec_count.assign(E, 0); rec_opp.assign(E, 0); rec_w2.assign(E, 0);
+        counted_to.assign(E, 0);
+    }
+
+    /* ForestState::extend_ARG (particle.cpp:743-918), unbiased sampling, multiplicity 1 */
+    void extend_particle(int64_t slot, double extend_to, int leaf_status, const int8_t* data, int limit) {
+        Particle& p = parts[slot];
+        double updated_to = cur_pos;
+        double B;
+        switch (leaf_status) {
+            case -1: B = 0; break;
+            case 1: B = p.Ltree; break;
+            default: B = tracked_length(p.tr, data); break;
+        }
+        while (updated_to < extend_to) {
+            double new_updated_to = std::min(extend_to, p.next_base);
+            double f = fastexp(-M.mu * B * (new_updated_to - updated_to));
+            p.w_post *= f;
+            p.w_pilot *= f;
+            updated_to = new_updated_to;
+            if (updated_to < extend_to) {
+                /* a recombination has occurred (particle.cpp:828-903) */
+                close_stretch(p, updated_to);
+                double h;
+                genealogy_update(slot, p, updated_to, limit, &h);
+                if (leaf_status == 0) B = tracked_length(p.tr, data);
+                if (leaf_status == 1) B = p.Ltree;
+                sample_next_base(slot, p, updated_to);
+                open_stretch(p, updated_to, limit);
+                record_recomb_event(p, h, limit);
+            }
+        }
+    }
+
+    /* update_state_to_data (particleContainer.cpp:441-466) */
+    void update_segment(const smco_segments* sg, int64_t s) {
+        const int n = M.n;
+        const int8_t* data = sg->alleles + s * n;
+        double seg_end = sg->start[s] + sg->length[s];
+        double extend_to = std::min(seg_end, M.L);
+        int limit = sg->max_record_epoch[s];
+        cur_limit = limit;
+        /* extend_ARGs (particleContainer.cpp:98-135) */
+        int missing = 0;
+        for (int i = 0; i < n; ++i) missing += data[i] == -1;
+        int leaf_status = 0;
+        if (missing == 0) leaf_status = 1;
+        if (missing == n) leaf_status = -1;
+        for (int64_t i = 0; i < Np; ++i) extend_particle(i, extend_to, leaf_status, data, limit);
+        cur_pos = std::max(cur_pos, extend_to);
+        /* update_weight_at_site (particleContainer.cpp:187-224) */
+        if (sg->state[s] == 0) {
+            int hap[NMAX];
+            int ncfg = 1;
+            /* calculate_initial_haplotype_configuration (pc.cpp:138-160) */
+            for (int i = 0; i < n; ++i) hap[i] = data[i];
+            for (int i = 0; i + 1 < n; i += 2) {
+                bool het = (data[i] == 2) || (M.dephase && data[i] + data[i + 1] == 1);
+                if (het) { ncfg *= 2; hap[i] = 0; hap[i + 1] = 1; }
+            }
+            double norm = 1.0 / ncfg;
+            std::vector<int> h0(hap, hap + n);
+            for (int64_t pi = 0; pi < Np; ++pi) {
+                Particle& p = parts[pi];
+                for (int i = 0; i < n; ++i) hap[i] = h0[i];
+                double lik = 0;
+                for (;;) {
+                    lik += site_likelihood(p.tr, hap);
+                    if (ncfg == 1) break;
+                    /* next_haplotype (pc.cpp:163-181) */
+                    bool more = false;
+                    for (int i = 0; i + 1 < n; i += 2) {
+                        bool het = (data[i] == 2) || (M.dephase && data[i] + data[i + 1] == 1);
+                        if (!het) continue;
+                        if (hap[i] == 0) { hap[i] = 1; hap[i + 1] = 0; more = true; break; }
+                        hap[i] = 0; hap[i + 1] = 1;
+                    }
+                    if (!more) break;
+                }
+                lik *= norm;
+                p.w_post *= lik;
+                p.w_pilot *= lik;
+            }
+        }
+        normalize();
+    }
+
+    /* normalize_probability (particleContainer.cpp:420-438), canonical sum (D3) */
+    double last_T = 1;
+    void normalize() {
+        std::vector<double> w(Np);
+        for (int64_t i = 0; i < Np; ++i) w[i] = parts[i].w_post;
+        double T = canon_sum(w.data(), Np);
+        if (!(T > 0)) throw std::runtime_error("Zero or negative probabilities");
+        logl += smc_log(T);
+        double inv = 1.0 / T;
+        for (int64_t i = 0; i < Np; ++i) { parts[i].w_post *= inv; parts[i].w_pilot *= inv; }
+        last_T = T;
+    }
+
+    /* ---------------- CountModel (count.cpp:355-555) ---------------- */
+    std::vector<double> update_to;
+
+    void count_single(Ev* ev, double w, int e) {
+        /* update_all_counts_single_evolevent (count.cpp:495-555) */
+        double x_start = counted_to[e], x_end = update_to[e];
+        double ep0 = M.T[e], ep1 = M.epoch_end(e);
+        double ts = std::max(0.0, std::min(ep1, ev->t1) - std::max(ep0, ev->t0));
+        if (ev->kind == 1) {
+            if (x_start <= ev->x0 && ev->event) coal_count[e] += w;
+            double opp = ev->weight * ts;                 /* coalevent.hpp:212-214 */
+            coal_opp[e] += w * opp;
+            coal_w2[e] += w * w * opp;
+        } else {
+            bool end_seq = (M.L == x_end);
+            double xs = std::max(0.0, std::min(x_end, ev->x1) - std::max(x_start, ev->x0));
+            double opp = ev->weight * ts * xs;            /* coalevent.hpp:224-226 */
+            if (ev->event) {                              /* coalevent.hpp:231-235 */
+                bool in = (x_start <= ev->x0) && ((ev->x0 < x_end) || end_seq) && (ep0 <= ev->ev_t) && (ev->ev_t < ep1);
+                if (in) rec_count[e] += w;
+            }
+            rec_opp[e] += w * opp;
+            rec_w2[e] += w * w * opp;
+        }
+    }
+
+    /* update_all_counts (count.cpp:448-491): push posterior weight down one epoch chain */
+    void walk_chain(Ev** hp, double w, int e) {
+        Ev** pp = hp;
+        for (;;) {
+            Ev* ev = *pp;
+            if (!ev) return;
+            if (ev->dead) {           /* fully consumed earlier: unlink (purge_events/remove_event) */
+                *pp = nullptr;
+                release(ev);
+                return;
+            }
+            ev->acc += w;
+            if (++ev->arrived < ev->refs) return;      /* coalevent.hpp:305-309 */
+            w = ev->acc;
+            ev->acc = 0;
+            ev->arrived = 0;
+            double start_base = ev->x0;
+            if (start_base < update_to[e]) {
+                count_single(ev, w, e);
+                if (ev->x1 < update_to[e]) ev->dead = 1;
+            }
+            pp = &ev->parent;
+        }
+    }
+
+    /* extract_and_update_count (count.cpp:355-415) */
+    void count(double current_base, bool end_data) {
+        const int E = M.E;
+        update_to.assign(E, 0);
+        int first = E;
+        for (int e = 0; e < E; ++e) {
+            double lagging = end_data ? 0 : M.lags[e];
+            double x_end = current_base - lagging;
+            if ((x_end - counted_to[e]) < lagging * 0.1 && first > e) {
+                update_to[e] = counted_to[e];
+            } else {
+                update_to[e] = x_end;
+                first = std::min(first, e);
+            }
+        }
+        for (int64_t i = Np - 1; i >= 0; --i) {
+            Particle& p = parts[i];
+            for (int e = E - 1; e >= first; --e) walk_chain(&p.head[e], p.w_post, e);
+        }
+        delayed_opp += update_to[E - 1] - counted_to[E - 1];
+        for (int e = 0; e < E; ++e) counted_to[e] = update_to[e];
+    }
+
+    /* resample (particleContainer.cpp:247-311) + implement_resampling (321-392) */
+    int resample(double update_pos) {
+        std::vector<double> pil(Np), incl(Np), sq(Np);
+        for (int64_t i = 0; i < Np; ++i) { pil[i] = parts[i].w_pilot; sq[i] = pil[i] * pil[i]; }
+        canon_scan(pil.data(), incl.data(), Np);
+        double S1 = incl[Np - 1];
+        double S2 = canon_sum(sq.data(), Np);
+        double ess = (S1 * S1) / S2;
+        tr_ess.push_back(ess);
+        double thr = (double)Np * ess_fraction;
+        if (!(ess < thr - 1e-6)) { tr_flag.push_back(0); return 0; }
+        tr_flag.push_back(1);
+        /* systematic_resampling (particleContainer.cpp:474-504) */
+        double u = philox_uniform(seed, 0xFFFFFFFFu, 1, (uint64_t)n_resample);
+        std::vector<int32_t> lo(Np + 1);
+        systematic(incl.data(), Np, u, lo.data());
+        /* implement_resampling */
+        std::vector<Particle> np_(Np);
+        std::vector<int32_t> parents(Np);
+        for (int64_t i = 0; i < Np; ++i) {
+            int cnt = lo[i + 1] - lo[i];
+            Particle& src = parts[i];
+            if (cnt == 0) {
+                for (Ev* h : src.head) release(h);   /* ~ForestState: particle.cpp:161-187 */
+                continue;
+            }
+            double adj = S1 / ((double)Np * src.w_pilot);   /* pc.cpp:350-351 */
+            src.w_post *= adj;
+            src.w_pilot *= adj;
+            if (cnt >= 2) close_stretch(src, update_pos);
+            for (int32_t q = lo[i]; q < lo[i + 1]; ++q) {
+                parents[q] = (int32_t)i;
+                Particle& d = np_[q];
+                if (q == lo[i] && cnt == 1) { d = std::move(src); continue; }
+                d.tr = src.tr; d.w_post = src.w_post; d.w_pilot = src.w_pilot;
+                d.next_base = src.next_base; d.Ltree = src.Ltree;
+                d.head = src.head;                       /* copyEventContainers: particle.cpp:139-148 */
+                for (Ev* h : d.head) if (h) ++h->refs;
+            }
+            if (cnt >= 2) for (Ev* h : src.head) release(h);
+        }
+        parts.swap(np_);
+        /* new stretches / fresh recombination positions for copies (pc.cpp:357-368) */
+        for (int64_t i = 0; i < Np; ++i) {
+            int cnt = lo[i + 1] - lo[i];
+            if (cnt < 2) continue;
+            for (int32_t q = lo[i]; q < lo[i + 1]; ++q) {
+                Particle& d = parts[q];
+                int lim = np_[i].mark_limit;
+                if (q != lo[i] && update_pos < M.L) sample_next_base(q, d, update_pos);
+                open_stretch(d, update_pos, lim);
+            }
+        }
+        if ((int32_t)ev_parents.size() < max_trace_events) {
+            ev_seg.push_back((int32_t)seg_done);
+            ev_parents.push_back(parents);
+        }
+        ++n_resample;
+        return 1;
+    }
+
+    void finish() {
+        /* smcsmc.cpp:371-373 */
+        normalize();
+        count(M.L, true);
+    }
+};
+
+}  // namespace smco
+
+using namespace smco;
+
+#define GUARD(body)                                                  \
+    try { body }                                                     \
+    catch (const std::exception& e) { g_err = e.what(); return -1; } \
+    return 0;
+
+extern "C" {
+
+const char* smco_last_error(void) { return g_err.c_str(); }
+
+void* smco_create(const smco_model* m, const smco_params* p) {
+    try {
+        if (m->n_pops != 1) throw std::runtime_error("oracle: only n_pops == 1 is supported in this round");
+        if (m->nsam < 2 || m->nsam > NMAX) throw std::runtime_error("oracle: nsam out of range");
+        Filter* f = new Filter();
+        Model& M = f->M;
+        M.E = m->n_epochs; M.P = 1; M.n = m->nsam;
+        M.ancestral_aware = m->flags & 1; M.dephase = m->flags & 2;
+        M.L = m->loci_length; M.mu = m->mutation_rate; M.rho = m->recombination_rate;
+        M.T.assign(m->change_times, m->change_times + M.E);
+        M.inv2N.resize(M.E);
+        for (int e = 0; e < M.E; ++e) M.inv2N[e] = 1.0 / (2.0 * m->pop_sizes[e]);
+        M.recflags.assign(m->record_flags, m->record_flags + M.E);
+        M.lags.assign(m->lags, m->lags + M.E);
+        f->Np = p->np; f->ess_fraction = p->ess_fraction; f->seed = p->seed;
+        f->max_trace_events = p->max_trace_events;
+        return f;
+    } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+
+void smco_destroy(void* h) { delete (Filter*)h; }
+
+int smco_init_prior(void* h, double initial_position) { GUARD(((Filter*)h)->init_prior(initial_position);) }
+
+int smco_update_segment(void* h, const smco_segments* segs, int64_t s) {
+    GUARD(Filter* f = (Filter*)h; f->update_segment(segs, s); f->tr_T.push_back(f->last_T); f->tr_logl.push_back(f->logl);)
+}
+int smco_count(void* h, double current_base, int end_data) { GUARD(((Filter*)h)->count(current_base, end_data != 0);) }
+int smco_resample(void* h, double update_to) {
+    try { Filter* f = (Filter*)h; int r = f->resample(update_to); f->seg_done++; return r; }
+    catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int smco_finish(void* h) { GUARD(((Filter*)h)->finish();) }
+
+int smco_run(void* h, const smco_segments* sg) {
+    GUARD(
+        Filter* f = (Filter*)h;
+        for (int64_t s = 0; s < sg->n; ++s) {
+            f->update_segment(sg, s);
+            f->tr_T.push_back(f->last_T);
+            f->tr_logl.push_back(f->logl);
+            double pos = std::min(sg->start[s] + sg->length[s], f->M.L);
+            f->count(pos, false);
+            f->resample(pos);
+            f->seg_done++;
+            if (sg->start[s] + sg->length[s] >= f->M.L) break;
+        }
+        f->finish();
+    )
+}
+
+int64_t smco_num_segments_done(void* h) { return ((Filter*)h)->seg_done; }
+
+int smco_get_trace(void* h, double* T, double* ess, int32_t* resampled, double* logl, int64_t n) {
+    Filter* f = (Filter*)h;
+    int64_t m = std::min<int64_t>(n, (int64_t)f->tr_T.size());
+    for (int64_t i = 0; i < m; ++i) {
+        if (T) T[i] = f->tr_T[i];
+        if (logl) logl[i] = f->tr_logl[i];
+        if (ess) ess[i] = i < (int64_t)f->tr_ess.size() ? f->tr_ess[i] : 0;
+        if (resampled) resampled[i] = i < (int64_t)f->tr_flag.size() ? f->tr_flag[i] : 0;
+    }
+    return (int)m;
+}
+
+int smco_get_resample_events(void* h, int32_t* seg_idx, int32_t* parents, int32_t max_events) {
+    Filter* f = (Filter*)h;
+    int n = std::min<int>(max_events, (int)f->ev_parents.size());
+    for (int k = 0; k < n; ++k) {
+        if (seg_idx) seg_idx[k] = f->ev_seg[k];
+        if (parents) std::copy(f->ev_parents[k].begin(), f->ev_parents[k].end(), parents + (int64_t)k * f->Np);
+    }
+    return n;
+}
+
+int smco_get_particles(void* h, double* w_post, double* w_pilot, double* heights, int8_t* children, double* next_base) {
+    Filter* f = (Filter*)h;
+    const int n = f->M.n;
+    for (int64_t i = 0; i < f->Np; ++i) {
+        const Particle& p = f->parts[i];
+        if (w_post) w_post[i] = p.w_post;
+        if (w_pilot) w_pilot[i] = p.w_pilot;
+        if (next_base) next_base[i] = p.next_base;
+        for (int r = 0; r < n - 1; ++r) {
+            if (heights) heights[i * (n - 1) + r] = p.tr.S[r];
+            if (children) { children[(i * (n - 1) + r) * 2] = p.tr.C[r][0]; children[(i * (n - 1) + r) * 2 + 1] = p.tr.C[r][1]; }
+        }
+    }
+    return 0;
+}
+
+int smco_get_counts(void* h, double* out, int32_t n) {
+    Filter* f = (Filter*)h;
+    const int E = f->M.E;
+    if (n < SMCO_COUNTS_LEN(E)) return -1;
+    for (int e = 0; e < E; ++e) {
+        out[0 * E + e] = f->coal_count[e]; out[1 * E + e] = f->coal_opp[e]; out[2 * E + e] = f->coal_w2[e];
+        out[3 * E + e] = f->rec_count[e]; out[4 * E + e] = f->rec_opp[e]; out[5 * E + e] = f->rec_w2[e];
+    }
+    out[6 * E + 0] = f->delayed_opp; out[6 * E + 1] = f->delayed_count;
+    out[6 * E + 2] = (double)f->n_resample; out[6 * E + 3] = f->logl;
+    return 0;
+}
+
+double smco_logl(void* h) { return ((Filter*)h)->logl; }
+
+int smco_get_stats(void* h, int64_t* n_recomb, int64_t* n_alloc, int64_t* n_resamples) {
+    Filter* f = (Filter*)h;
+    if (n_recomb) *n_recomb = f->n_recomb;
+    if (n_alloc) *n_alloc = f->pool.n_alloc;
+    if (n_resamples) *n_resamples = f->n_resample;
+    return 0;
+}
+
+double smco_exp(double x) { return smc_exp(x); }
+double smco_log(double x) { return smc_log(x); }
+double smco_fastexp(double x) { return fastexp(x); }
+double smco_uniform(uint64_t seed, uint32_t slot, uint32_t stream, uint64_t draw) { return philox_uniform(seed, slot, stream, draw); }
+double smco_canon_sum(const double* x, int64_t n) { return canon_sum(x, n); }
+void smco_canon_scan(const double* x, double* incl, int64_t n) { canon_scan(x, incl, n); }
+void smco_systematic(const double* pilot, int64_t n, double u, int32_t* lo) {
+    std::vector<double> incl(n);
+    canon_scan(pilot, incl.data(), n);
+    systematic(incl.data(), n, u, lo);
+}
+
+}  // extern "C"

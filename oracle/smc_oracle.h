@@ -1,0 +1,105 @@
+/* oracle/smc_oracle.h -- TEST INFRASTRUCTURE, not product code.
+ *
+ * C API of the CPU oracle: a single-threaded restatement of the smcsmc
+ * particle-filter forward sweep (reference: /root/reference/src/particleContainer.cpp,
+ * particle.cpp, count.cpp, smcsmc.cpp:278-401).  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library.
+ *
+ * PARITY STATUS: "parity unpinned" against the upstream binary -- the reference's
+ * coalescent engine (scrm fork) is an un-vendored submodule and Boost is absent, so the
+ * reference cannot be built here, and its own tests hold no golden vectors for weights,
+ * resampling indices or log-likelihood.  The oracle is pinned
+ * (a) structurally, function by function against the cited reference lines,
+ * (b) by the reference's .seg fixtures / FormatDouble contract for the boundary, and
+ * (c) distributionally (coalescent prior expectations, known simulation truth).
+ *
+ * The struct layouts below are deliberately identical to include/smcsmc_pf.h so the
+ * parity tests can feed both sides the same buffers.
+ */
+#ifndef SMC_ORACLE_H
+#define SMC_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smco_model {
+    int32_t n_epochs;            /* E */
+    int32_t n_pops;              /* P (oracle supports P == 1 in this round) */
+    int32_t nsam;                /* number of haplotypes n (2..16) */
+    int32_t flags;               /* bit0 ancestral_aware, bit1 dephase */
+    double loci_length;          /* L, bp */
+    double mutation_rate;        /* per bp per generation */
+    double recombination_rate;   /* per bp per generation */
+    const double* change_times;  /* [E] generations, change_times[0] == 0 */
+    const double* pop_sizes;     /* [E*P] diploid N_e per epoch */
+    const double* mig_rates;     /* [E*P*P] per generation, or NULL */
+    const double* single_mig;    /* [E*P*P] -ej style probabilities, or NULL */
+    const int32_t* sample_pops;  /* [nsam] or NULL */
+    const int32_t* record_flags; /* [E] bit0 record recomb, bit1 record coal/migr (pfparam.hpp:279-281) */
+    const double* lags;          /* [E] bp (count.cpp:230-265) */
+} smco_model;
+
+typedef struct smco_params {
+    int64_t np;                  /* number of particles */
+    double ess_fraction;         /* -ESS (pfparam.cpp:323) */
+    uint64_t seed;
+    int32_t max_trace_events;    /* number of resampling events whose ancestor arrays are kept */
+    int32_t reserved;
+} smco_params;
+
+typedef struct smco_segments {
+    int64_t n;
+    const double* start;             /* [n] 0-based, relative to -startpos (segdata.cpp:200-209) */
+    const double* length;            /* [n] */
+    const int8_t* state;             /* [n] 0 INVARIANT, 1 MISSING, 2 INVARIANT_PARTIAL (segdata.hpp:84) */
+    const int8_t* alleles;           /* [n*nsam] -1 missing, 0, 1, 2 unphased het */
+    const int32_t* max_record_epoch; /* [n] smcsmc.cpp:266-275 */
+} smco_segments;
+
+/* layout of the packed count buffer (doubles), P == 1:
+ *   [0*E..1*E) coal_count  [1*E..2*E) coal_opp  [2*E..3*E) coal_weight
+ *   [3*E..4*E) rec_count   [4*E..5*E) rec_opp   [5*E..6*E) rec_weight
+ *   [6*E+0] delayed_weight_opportunity [6*E+1] delayed_weight_count
+ *   [6*E+2] resample_count [6*E+3] ln_normalization_factor
+ * (raw sums, WITHOUT the prior pseudo-counts of count.cpp:161-227; the host adds those.) */
+#define SMCO_COUNTS_LEN(E) (6 * (E) + 4)
+
+void* smco_create(const smco_model* m, const smco_params* p);
+void smco_destroy(void* h);
+const char* smco_last_error(void);
+
+int smco_init_prior(void* h, double initial_position);               /* particleContainer.cpp:33-65 */
+int smco_run(void* h, const smco_segments* segs);                    /* smcsmc.cpp:324-373 */
+/* single steps, mirroring the reference's public methods */
+int smco_update_segment(void* h, const smco_segments* segs, int64_t s);  /* pc.cpp:441-466 */
+int smco_count(void* h, double current_base, int end_data);             /* count.cpp:355-415 */
+int smco_resample(void* h, double update_to);                           /* pc.cpp:247-311; returns 1 if resampled */
+int smco_finish(void* h);                                                /* smcsmc.cpp:371-373 */
+
+int64_t smco_num_segments_done(void* h);
+int smco_get_trace(void* h, double* T, double* ess, int32_t* resampled, double* logl, int64_t n);
+int smco_get_resample_events(void* h, int32_t* seg_idx, int32_t* parents, int32_t max_events);
+int smco_get_particles(void* h, double* w_post, double* w_pilot, double* heights, int8_t* children,
+                       double* next_base);
+int smco_get_counts(void* h, double* packed, int32_t n);
+double smco_logl(void* h);
+/* work statistics for DESIGN.md / roofline bookkeeping */
+int smco_get_stats(void* h, int64_t* n_recombinations, int64_t* n_events_allocated, int64_t* n_resamples);
+
+/* exposed helpers so the tests can pin the math bit-for-bit against the HIP side */
+double smco_exp(double x);
+double smco_log(double x);
+double smco_fastexp(double x);
+double smco_uniform(uint64_t seed, uint32_t slot, uint32_t stream, uint64_t draw);
+/* canonical reductions (DESIGN.md "canonical arithmetic") */
+double smco_canon_sum(const double* x, int64_t n);
+void smco_canon_scan(const double* x, double* incl, int64_t n);
+/* systematic resampling on given weights (pc.cpp:474-504): returns offspring start indices lo[0..n] */
+void smco_systematic(const double* pilot, int64_t n, double u, int32_t* lo);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

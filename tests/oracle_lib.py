@@ -1,0 +1,204 @@
+"""ctypes binding to the CPU oracle (oracle/libsmc_oracle.so).
+
+TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+may import this module.  The product package smcsmc_amd never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_LIB = None
+
+
+class Model(C.Structure):
+    _fields_ = [
+        ("n_epochs", C.c_int32), ("n_pops", C.c_int32), ("nsam", C.c_int32), ("flags", C.c_int32),
+        ("loci_length", C.c_double), ("mutation_rate", C.c_double), ("recombination_rate", C.c_double),
+        ("change_times", C.POINTER(C.c_double)), ("pop_sizes", C.POINTER(C.c_double)),
+        ("mig_rates", C.POINTER(C.c_double)), ("single_mig", C.POINTER(C.c_double)),
+        ("sample_pops", C.POINTER(C.c_int32)), ("record_flags", C.POINTER(C.c_int32)),
+        ("lags", C.POINTER(C.c_double)),
+    ]
+
+
+class Params(C.Structure):
+    _fields_ = [("np", C.c_int64), ("ess_fraction", C.c_double), ("seed", C.c_uint64),
+                ("max_trace_events", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Segments(C.Structure):
+    _fields_ = [("n", C.c_int64), ("start", C.POINTER(C.c_double)), ("length", C.POINTER(C.c_double)),
+                ("state", C.POINTER(C.c_int8)), ("alleles", C.POINTER(C.c_int8)),
+                ("max_record_epoch", C.POINTER(C.c_int32))]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ORACLE_DIR, "libsmc_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.smco_create.restype = C.c_void_p
+        L.smco_create.argtypes = [C.POINTER(Model), C.POINTER(Params)]
+        L.smco_destroy.argtypes = [C.c_void_p]
+        L.smco_last_error.restype = C.c_char_p
+        L.smco_init_prior.argtypes = [C.c_void_p, C.c_double]
+        L.smco_run.argtypes = [C.c_void_p, C.POINTER(Segments)]
+        L.smco_update_segment.argtypes = [C.c_void_p, C.POINTER(Segments), C.c_int64]
+        L.smco_count.argtypes = [C.c_void_p, C.c_double, C.c_int]
+        L.smco_resample.argtypes = [C.c_void_p, C.c_double]
+        L.smco_finish.argtypes = [C.c_void_p]
+        L.smco_num_segments_done.restype = C.c_int64
+        L.smco_num_segments_done.argtypes = [C.c_void_p]
+        L.smco_get_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.smco_get_resample_events.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        L.smco_get_particles.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        L.smco_get_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.smco_logl.restype = C.c_double
+        L.smco_logl.argtypes = [C.c_void_p]
+        L.smco_get_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        for name in ("smco_exp", "smco_log", "smco_fastexp"):
+            getattr(L, name).restype = C.c_double
+            getattr(L, name).argtypes = [C.c_double]
+        L.smco_uniform.restype = C.c_double
+        L.smco_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]
+        L.smco_canon_sum.restype = C.c_double
+        L.smco_canon_sum.argtypes = [C.c_void_p, C.c_int64]
+        L.smco_canon_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.smco_systematic.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class PackedInputs:
+    """Owns the numpy buffers behind the C structs (same layout for oracle and product)."""
+
+    def __init__(self, model, segs, model_cls=Model, seg_cls=Segments):
+        m = model
+        self.change_times = np.ascontiguousarray(m["change_times"], dtype=np.float64)
+        E = len(self.change_times)
+        P = int(m.get("n_pops", 1))
+        self.pop_sizes = np.ascontiguousarray(m["pop_sizes"], dtype=np.float64).reshape(E * P)
+        self.record_flags = np.ascontiguousarray(m.get("record_flags", [3] * E), dtype=np.int32)
+        self.lags = np.ascontiguousarray(m["lags"], dtype=np.float64)
+        flags = (1 if m.get("ancestral_aware") else 0) | (2 if m.get("dephase") else 0)
+        self.E, self.P, self.nsam = E, P, int(m["nsam"])
+        self.model = model_cls(E, P, int(m["nsam"]), flags, float(m["loci_length"]), float(m["mutation_rate"]),
+                               float(m["recombination_rate"]), _dp(self.change_times), _dp(self.pop_sizes),
+                               None, None, None,
+                               self.record_flags.ctypes.data_as(C.POINTER(C.c_int32)), _dp(self.lags))
+        self.segs = None
+        if segs is not None:
+            self.start = np.ascontiguousarray(segs["start"], dtype=np.float64)
+            self.length = np.ascontiguousarray(segs["length"], dtype=np.float64)
+            self.state = np.ascontiguousarray(segs["state"], dtype=np.int8)
+            self.alleles = np.ascontiguousarray(segs["alleles"], dtype=np.int8).reshape(-1)
+            self.mre = np.ascontiguousarray(segs["max_record_epoch"], dtype=np.int32)
+            n = len(self.start)
+            assert len(self.alleles) == n * self.nsam
+            self.segs = seg_cls(n, _dp(self.start), _dp(self.length),
+                                self.state.ctypes.data_as(C.POINTER(C.c_int8)),
+                                self.alleles.ctypes.data_as(C.POINTER(C.c_int8)),
+                                self.mre.ctypes.data_as(C.POINTER(C.c_int32)))
+
+
+class Oracle:
+    def __init__(self, model, np_particles, ess_fraction=0.5, seed=1, max_trace_events=64):
+        self.L = lib()
+        self.inp = PackedInputs(model, None)
+        self.Np = int(np_particles)
+        self.params = Params(self.Np, float(ess_fraction), int(seed), int(max_trace_events), 0)
+        self.h = self.L.smco_create(C.byref(self.inp.model), C.byref(self.params))
+        if not self.h:
+            raise RuntimeError(self.L.smco_last_error().decode())
+        self.max_trace_events = max_trace_events
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise RuntimeError(self.L.smco_last_error().decode())
+        return rc
+
+    def close(self):
+        if self.h:
+            self.L.smco_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def init_prior(self, initial_position=0.0):
+        self._chk(self.L.smco_init_prior(self.h, float(initial_position)))
+
+    def pack_segments(self, model, segs):
+        self.seg_inp = PackedInputs(model, segs)
+        return self.seg_inp
+
+    def run(self, seg_inp):
+        self._chk(self.L.smco_run(self.h, C.byref(seg_inp.segs)))
+
+    def update_segment(self, seg_inp, s):
+        self._chk(self.L.smco_update_segment(self.h, C.byref(seg_inp.segs), s))
+
+    def count(self, pos, end_data=False):
+        self._chk(self.L.smco_count(self.h, float(pos), int(end_data)))
+
+    def resample(self, pos):
+        return self._chk(self.L.smco_resample(self.h, float(pos)))
+
+    def finish(self):
+        self._chk(self.L.smco_finish(self.h))
+
+    def trace(self):
+        n = self.L.smco_num_segments_done(self.h)
+        T = np.zeros(n); ess = np.zeros(n); flag = np.zeros(n, np.int32); logl = np.zeros(n)
+        self.L.smco_get_trace(self.h, T.ctypes.data, ess.ctypes.data, flag.ctypes.data, logl.ctypes.data, n)
+        return {"T": T, "ess": ess, "resampled": flag, "logl": logl}
+
+    def resample_events(self):
+        seg = np.zeros(self.max_trace_events, np.int32)
+        par = np.zeros((self.max_trace_events, self.Np), np.int32)
+        n = self.L.smco_get_resample_events(self.h, seg.ctypes.data, par.ctypes.data, self.max_trace_events)
+        return seg[:n], par[:n]
+
+    def particles(self):
+        n = self.inp.nsam
+        wp = np.zeros(self.Np); wq = np.zeros(self.Np); H = np.zeros((self.Np, n - 1))
+        Ch = np.zeros((self.Np, n - 1, 2), np.int8); nb = np.zeros(self.Np)
+        self.L.smco_get_particles(self.h, wp.ctypes.data, wq.ctypes.data, H.ctypes.data, Ch.ctypes.data, nb.ctypes.data)
+        return {"w_post": wp, "w_pilot": wq, "heights": H, "children": Ch, "next_base": nb}
+
+    def counts(self):
+        E = self.inp.E
+        out = np.zeros(6 * E + 4)
+        self._chk(self.L.smco_get_counts(self.h, out.ctypes.data, len(out)))
+        return unpack_counts(out, E)
+
+    def logl(self):
+        return self.L.smco_logl(self.h)
+
+    def stats(self):
+        a = C.c_int64(); b = C.c_int64(); c = C.c_int64()
+        self.L.smco_get_stats(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return {"recombinations": a.value, "events_allocated": b.value, "resamples": c.value}
+
+
+def unpack_counts(out, E):
+    return {
+        "coal_count": out[0:E].copy(), "coal_opp": out[E:2 * E].copy(), "coal_weight": out[2 * E:3 * E].copy(),
+        "rec_count": out[3 * E:4 * E].copy(), "rec_opp": out[4 * E:5 * E].copy(), "rec_weight": out[5 * E:6 * E].copy(),
+        "delayed_opp": out[6 * E], "delayed_count": out[6 * E + 1], "resample_count": out[6 * E + 2],
+        "logl": out[6 * E + 3],
+    }
