@@ -1,0 +1,123 @@
+/* include/smcsmc_pf.h -- C-ABI of the MI355X (gfx950) particle-filter layer of smcsmc_amd.
+ *
+ * This is the drop-in boundary for the hot path named in BASELINE.json:north_star: the
+ * ParticleContainer / ForestState / CountModel inner loop of the `smcsmc` binary.  The
+ * reference has no FFI for this path (it is one C++ binary); the cut is made directly under
+ * the public methods of the reference's ParticleContainer and CountModel, so each entry point
+ * below replaces one of them (paths relative to /root/reference/src):
+ *
+ *   pf_create            ParticleContainer ctor arguments + PfParam/Model tables
+ *                        (particleContainer.cpp:33-44, pfparam.cpp:321-380)
+ *   pf_init_prior        ParticleContainer::ParticleContainer body (particleContainer.cpp:46-65)
+ *   pf_load_segments     Segment buffer made resident (segdata.cpp:55-166, 182-222)
+ *   pf_update_segment    ParticleContainer::update_state_to_data (particleContainer.cpp:441-466)
+ *   pf_count             CountModel::extract_and_update_count (count.cpp:355-415)
+ *   pf_resample          ParticleContainer::resample (particleContainer.cpp:247-311)
+ *   pf_run               the do-while of pfARG_core (smcsmc.cpp:324-360) over a segment range,
+ *                        enqueued without host round trips
+ *   pf_finish            final normalize_probability + lag-free flush (smcsmc.cpp:371-373)
+ *   pf_get_counts        CountModel totals consumed by log_counts (count.cpp:66-158)
+ *   pf_logl              ParticleContainer::ln_normalization_factor (particleContainer.hpp)
+ *
+ * Conventions: extern "C", plain pointers and sizes, caller owns host buffers, callee owns
+ * device memory, one host thread per handle.  Every function returning int returns 0 on
+ * success and a negative code on failure; pf_last_error() then holds the message (the
+ * reference's convention is `Error: <what>` + exit 1, smcsmc.cpp:99-102).
+ * There is no CPU fallback: without a HIP device pf_create fails.
+ */
+#ifndef SMCSMC_PF_H
+#define SMCSMC_PF_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pf_model {
+    int32_t n_epochs;            /* E  (Model::change_times_.size()) */
+    int32_t n_pops;              /* P  (this round: 1) */
+    int32_t nsam;                /* haplotypes n, 2..16 */
+    int32_t flags;               /* bit0 -ancestral_aware, bit1 -dephase (pfparam.cpp:143-146) */
+    double loci_length;          /* Model::loci_length() */
+    double mutation_rate;        /* per bp per generation */
+    double recombination_rate;   /* per bp per generation */
+    const double* change_times;  /* [E] generations */
+    const double* pop_sizes;     /* [E*P] */
+    const double* mig_rates;     /* [E*P*P] or NULL */
+    const double* single_mig;    /* [E*P*P] or NULL */
+    const int32_t* sample_pops;  /* [nsam] or NULL */
+    const int32_t* record_flags; /* [E] PfParam::record_event_in_epoch (pfparam.hpp:279-281) */
+    const double* lags;          /* [E] CountModel::lags (count.cpp:230-265) */
+} pf_model;
+
+typedef struct pf_params {
+    int64_t np;                  /* -Np */
+    double ess_fraction;         /* -ESS */
+    uint64_t seed;               /* -seed */
+    int32_t max_trace_events;    /* resampling events whose ancestor arrays are retained for inspection */
+    int32_t reserved;
+} pf_params;
+
+typedef struct pf_segments {
+    int64_t n;
+    const double* start;             /* [n] relative to -startpos (segdata.cpp:200-209) */
+    const double* length;            /* [n] */
+    const int8_t* state;             /* [n] 0 INVARIANT, 1 MISSING, 2 INVARIANT_PARTIAL */
+    const int8_t* alleles;           /* [n*nsam] -1 . , 0, 1, 2 / */
+    const int32_t* max_record_epoch; /* [n] max_epoch_to_update (smcsmc.cpp:266-275) */
+} pf_segments;
+
+typedef struct pf_handle pf_handle;
+
+/* packed count buffer, identical to the CountModel members read by count.cpp:66-158 (P == 1):
+ *   coal_count[E] coal_opp[E] coal_weight[E] rec_count[E] rec_opp[E] rec_weight[E]
+ *   delayed_weight_opportunity, delayed_weight_count, resample_count, ln_normalization_factor
+ * raw sums without the prior pseudo-counts (count.cpp:161-227). */
+#define PF_COUNTS_LEN(E) (6 * (E) + 4)
+
+const char* pf_last_error(void);
+int pf_device_count(void);
+
+pf_handle* pf_create(const pf_model* model, const pf_params* params, int device);
+void pf_destroy(pf_handle* h);
+
+int pf_init_prior(pf_handle* h, double initial_position);
+int pf_load_segments(pf_handle* h, const pf_segments* segs);
+
+/* single steps (each enqueues on the handle's stream; pf_sync waits) */
+int pf_update_segment(pf_handle* h, int64_t s);
+int pf_count(pf_handle* h, int64_t s, int end_data);
+int pf_resample(pf_handle* h, int64_t s);
+/* the hot loop over segments [s_begin, s_end): update -> count -> resample per segment */
+int pf_run(pf_handle* h, int64_t s_begin, int64_t s_end);
+int pf_finish(pf_handle* h);
+int pf_sync(pf_handle* h);
+
+/* results */
+int64_t pf_num_segments_done(pf_handle* h);
+double pf_logl(pf_handle* h);
+int pf_get_counts(pf_handle* h, double* packed, int32_t n);
+int pf_get_trace(pf_handle* h, double* T, double* ess, int32_t* resampled, double* logl, int64_t n);
+int pf_get_resample_events(pf_handle* h, int32_t* seg_idx, int32_t* parents, int32_t max_events);
+int pf_get_particles(pf_handle* h, double* w_post, double* w_pilot, double* heights, int8_t* children,
+                     double* next_base);
+/* device-side timing of the kernels launched so far (HIP events on the handle's stream):
+ * total milliseconds and launch count for kernel class k (0 extend, 1 decide, 2 count, 3 resample) */
+int pf_get_kernel_time(pf_handle* h, int k, double* ms, int64_t* launches);
+int pf_set_timing(pf_handle* h, int enable);
+/* bookkeeping for the roofline: records appended to the event log, bytes of particle state */
+int pf_get_stats(pf_handle* h, int64_t* n_records, int64_t* state_bytes_per_particle, int64_t* n_resamples);
+
+/* unit-level entry points used by the parity tests (device implementations of the math and
+ * of the canonical reductions; each runs one small kernel on the handle-independent default stream) */
+int pf_test_math(const double* x, int64_t n, double* out_exp, double* out_log, double* out_fastexp, int device);
+int pf_test_div(const double* a, const double* b, int64_t n, double* out, int device);
+int pf_test_uniform(uint64_t seed, uint32_t slot, uint32_t stream, uint64_t first_draw, int64_t n, double* out,
+                    int device);
+int pf_test_reduce(const double* x, int64_t n, double* out_sum, double* out_incl_scan, int device);
+int pf_test_systematic(const double* pilot, int64_t n, double u, int32_t* lo, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -120,6 +120,8 @@ static void systematic(const double* incl, int64_t n, double u, int32_t* lo) {
         lo[i] = (int32_t)g;
     }
     lo[n] = (int32_t)n;
+    /* the scan is not guaranteed monotone in floating point: enforce non-decreasing offsets */
+    for (int64_t i = 1; i <= n; ++i) lo[i] = std::max(lo[i], lo[i - 1]);
 }
 
 /* ------------------------------------------------------------------ model */
@@ -676,16 +678,19 @@ struct Filter {
     }
 
     /* normalize_probability (particleContainer.cpp:420-438), canonical sum (D3) */
-    double last_T = 1;
+    double last_T = 1, last_inv = 1;
+    std::vector<double> raw_pilot;   /* pilot weights before normalisation: ESS / scan operate on these (D5) */
     void normalize() {
         std::vector<double> w(Np);
-        for (int64_t i = 0; i < Np; ++i) w[i] = parts[i].w_post;
+        raw_pilot.resize(Np);
+        for (int64_t i = 0; i < Np; ++i) { w[i] = parts[i].w_post; raw_pilot[i] = parts[i].w_pilot; }
         double T = canon_sum(w.data(), Np);
         if (!(T > 0)) throw std::runtime_error("Zero or negative probabilities");
         logl += smc_log(T);
         double inv = 1.0 / T;
         for (int64_t i = 0; i < Np; ++i) { parts[i].w_post *= inv; parts[i].w_pilot *= inv; }
         last_T = T;
+        last_inv = inv;
     }
 
     /* ---------------- CountModel (count.cpp:355-555) ---------------- */
@@ -765,7 +770,7 @@ struct Filter {
     /* resample (particleContainer.cpp:247-311) + implement_resampling (321-392) */
     int resample(double update_pos) {
         std::vector<double> pil(Np), incl(Np), sq(Np);
-        for (int64_t i = 0; i < Np; ++i) { pil[i] = parts[i].w_pilot; sq[i] = pil[i] * pil[i]; }
+        for (int64_t i = 0; i < Np; ++i) { pil[i] = raw_pilot[i]; sq[i] = pil[i] * pil[i]; }
         canon_scan(pil.data(), incl.data(), Np);
         double S1 = incl[Np - 1];
         double S2 = canon_sum(sq.data(), Np);
@@ -788,7 +793,7 @@ struct Filter {
                 for (Ev* h : src.head) release(h);   /* ~ForestState: particle.cpp:161-187 */
                 continue;
             }
-            double adj = S1 / ((double)Np * src.w_pilot);   /* pc.cpp:350-351 */
+            double adj = (S1 * last_inv) / ((double)Np * src.w_pilot);   /* pc.cpp:350-351 */
             src.w_post *= adj;
             src.w_pilot *= adj;
             if (cnt >= 2) close_stretch(src, update_pos);

@@ -1,0 +1,47 @@
+"""Builds the gfx950 HIP library in-tree (smcsmc_amd/csrc/libsmcsmc_pf.so) and the host binary.
+
+hipcc cross-compiles for gfx950 without a GPU present, so this runs in the CPU-only build
+container as well as on the MI355X box.  The built .so stays in-tree (git-ignored).
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libsmcsmc_pf.so")
+BIN = os.path.join(os.path.dirname(HERE), "bin", "smcsmc")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
+               "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built (no CPU fallback exists)")
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build_lib(force=False):
+    srcs = [os.path.join(CSRC, "pf_hip.hip"), os.path.join(CSRC, "pf_device.h"),
+            os.path.join(os.path.dirname(HERE), "include", "smcsmc_pf.h")]
+    if force or _stale(LIB, srcs):
+        cmd = [_hipcc()] + HIPCC_FLAGS + ["-shared", "-o", LIB, srcs[0]]
+        subprocess.check_call(cmd)
+    return LIB
+
+
+def build_all(force=False):
+    lib = build_lib(force)
+    host = os.path.join(CSRC, "host")
+    if os.path.isdir(host) and os.path.exists(os.path.join(host, "Makefile")):
+        subprocess.check_call(["make", "-s", "-C", host])
+    return lib

@@ -1,0 +1,288 @@
+"""ctypes binding to the HIP particle-filter library (C-ABI: include/smcsmc_pf.h).
+
+Mirrors the reference's ParticleContainer / CountModel call surface
+(/root/reference/src/particleContainer.hpp:48-70, count.hpp:52-63):
+
+    pf = ParticleFilter(model, Np, ess_fraction, seed)
+    pf.init_prior(x0)            # ParticleContainer ctor
+    pf.load_segments(segs)       # Segment buffer
+    pf.run()                     # the pfARG_core do-while (smcsmc.cpp:324-360)
+    pf.finish()                  # smcsmc.cpp:371-373
+    pf.counts(), pf.logl()
+
+Raises PfError (the reference prints "Error: ..." and exits 1) -- in particular when the HIP
+library or a GPU is missing: there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsmcsmc_pf.so")
+_LIB = None
+
+
+class PfError(RuntimeError):
+    pass
+
+
+class _Model(C.Structure):
+    _fields_ = [
+        ("n_epochs", C.c_int32), ("n_pops", C.c_int32), ("nsam", C.c_int32), ("flags", C.c_int32),
+        ("loci_length", C.c_double), ("mutation_rate", C.c_double), ("recombination_rate", C.c_double),
+        ("change_times", C.POINTER(C.c_double)), ("pop_sizes", C.POINTER(C.c_double)),
+        ("mig_rates", C.POINTER(C.c_double)), ("single_mig", C.POINTER(C.c_double)),
+        ("sample_pops", C.POINTER(C.c_int32)), ("record_flags", C.POINTER(C.c_int32)),
+        ("lags", C.POINTER(C.c_double)),
+    ]
+
+
+class _Params(C.Structure):
+    _fields_ = [("np", C.c_int64), ("ess_fraction", C.c_double), ("seed", C.c_uint64),
+                ("max_trace_events", C.c_int32), ("reserved", C.c_int32)]
+
+
+class _Segments(C.Structure):
+    _fields_ = [("n", C.c_int64), ("start", C.POINTER(C.c_double)), ("length", C.POINTER(C.c_double)),
+                ("state", C.POINTER(C.c_int8)), ("alleles", C.POINTER(C.c_int8)),
+                ("max_record_epoch", C.POINTER(C.c_int32))]
+
+
+EXPORTS = [
+    "pf_last_error", "pf_device_count", "pf_create", "pf_destroy", "pf_init_prior", "pf_load_segments",
+    "pf_update_segment", "pf_count", "pf_resample", "pf_run", "pf_finish", "pf_sync",
+    "pf_num_segments_done", "pf_logl", "pf_get_counts", "pf_get_trace", "pf_get_resample_events",
+    "pf_get_particles", "pf_get_kernel_time", "pf_set_timing", "pf_get_stats",
+    "pf_test_math", "pf_test_div", "pf_test_uniform", "pf_test_reduce", "pf_test_systematic",
+]
+
+
+def load_library(path=None):
+    """Loads the HIP library; raises PfError loudly if it has not been built."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise PfError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(there is no CPU fallback)" % path)
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.pf_last_error.restype = C.c_char_p
+    L.pf_device_count.restype = C.c_int
+    L.pf_create.restype = vp
+    L.pf_create.argtypes = [C.POINTER(_Model), C.POINTER(_Params), C.c_int]
+    L.pf_destroy.argtypes = [vp]
+    L.pf_init_prior.argtypes = [vp, C.c_double]
+    L.pf_load_segments.argtypes = [vp, C.POINTER(_Segments)]
+    L.pf_update_segment.argtypes = [vp, C.c_int64]
+    L.pf_count.argtypes = [vp, C.c_int64, C.c_int]
+    L.pf_resample.argtypes = [vp, C.c_int64]
+    L.pf_run.argtypes = [vp, C.c_int64, C.c_int64]
+    L.pf_finish.argtypes = [vp]
+    L.pf_sync.argtypes = [vp]
+    L.pf_num_segments_done.restype = C.c_int64
+    L.pf_num_segments_done.argtypes = [vp]
+    L.pf_logl.restype = C.c_double
+    L.pf_logl.argtypes = [vp]
+    L.pf_get_counts.argtypes = [vp, vp, C.c_int32]
+    L.pf_get_trace.argtypes = [vp, vp, vp, vp, vp, C.c_int64]
+    L.pf_get_resample_events.argtypes = [vp, vp, vp, C.c_int32]
+    L.pf_get_particles.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.pf_get_kernel_time.argtypes = [vp, C.c_int, vp, vp]
+    L.pf_set_timing.argtypes = [vp, C.c_int]
+    L.pf_get_stats.argtypes = [vp, vp, vp, vp]
+    L.pf_test_math.argtypes = [vp, C.c_int64, vp, vp, vp, C.c_int]
+    L.pf_test_div.argtypes = [vp, vp, C.c_int64, vp, C.c_int]
+    L.pf_test_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int64, vp, C.c_int]
+    L.pf_test_reduce.argtypes = [vp, C.c_int64, vp, vp, C.c_int]
+    L.pf_test_systematic.argtypes = [vp, C.c_int64, C.c_double, vp, C.c_int]
+    if path == LIB_PATH:
+        _LIB = L
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _err(L):
+    return (L.pf_last_error() or b"").decode()
+
+
+KERNEL_CLASSES = ("extend", "decide", "count", "resample")
+
+
+class ParticleFilter:
+    def __init__(self, model, np_particles, ess_fraction=0.5, seed=1, max_trace_events=64, device=0):
+        self.L = load_library()
+        m = model
+        self._ct = np.ascontiguousarray(m["change_times"], dtype=np.float64)
+        E = len(self._ct)
+        P = int(m.get("n_pops", 1))
+        self._ps = np.ascontiguousarray(m["pop_sizes"], dtype=np.float64).reshape(E * P)
+        self._rf = np.ascontiguousarray(m.get("record_flags", [3] * E), dtype=np.int32)
+        self._lags = np.ascontiguousarray(m["lags"], dtype=np.float64)
+        flags = (1 if m.get("ancestral_aware") else 0) | (2 if m.get("dephase") else 0)
+        self.E, self.P, self.nsam, self.Np = E, P, int(m["nsam"]), int(np_particles)
+        self.max_trace_events = int(max_trace_events)
+        self._model = _Model(E, P, self.nsam, flags, float(m["loci_length"]), float(m["mutation_rate"]),
+                             float(m["recombination_rate"]), _dp(self._ct), _dp(self._ps), None, None, None,
+                             self._rf.ctypes.data_as(C.POINTER(C.c_int32)), _dp(self._lags))
+        self._params = _Params(self.Np, float(ess_fraction), int(seed), self.max_trace_events, 0)
+        self.h = self.L.pf_create(C.byref(self._model), C.byref(self._params), int(device))
+        if not self.h:
+            raise PfError(_err(self.L))
+        self.n_segs = 0
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise PfError(_err(self.L))
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def init_prior(self, initial_position=0.0):
+        self._chk(self.L.pf_init_prior(self.h, float(initial_position)))
+
+    def load_segments(self, segs):
+        self._s0 = np.ascontiguousarray(segs["start"], dtype=np.float64)
+        self._s1 = np.ascontiguousarray(segs["length"], dtype=np.float64)
+        self._s2 = np.ascontiguousarray(segs["state"], dtype=np.int8)
+        self._s3 = np.ascontiguousarray(segs["alleles"], dtype=np.int8).reshape(-1)
+        self._s4 = np.ascontiguousarray(segs["max_record_epoch"], dtype=np.int32)
+        n = len(self._s0)
+        assert len(self._s3) == n * self.nsam
+        sg = _Segments(n, _dp(self._s0), _dp(self._s1), self._s2.ctypes.data_as(C.POINTER(C.c_int8)),
+                       self._s3.ctypes.data_as(C.POINTER(C.c_int8)), self._s4.ctypes.data_as(C.POINTER(C.c_int32)))
+        self._chk(self.L.pf_load_segments(self.h, C.byref(sg)))
+        self.n_segs = n
+
+    def run(self, s_begin=0, s_end=None):
+        self._chk(self.L.pf_run(self.h, int(s_begin), int(self.n_segs if s_end is None else s_end)))
+
+    def update_segment(self, s):
+        self._chk(self.L.pf_update_segment(self.h, int(s)))
+
+    def count(self, s, end_data=False):
+        self._chk(self.L.pf_count(self.h, int(s), int(end_data)))
+
+    def resample(self, s):
+        self._chk(self.L.pf_resample(self.h, int(s)))
+
+    def finish(self):
+        self._chk(self.L.pf_finish(self.h))
+
+    def sync(self):
+        self._chk(self.L.pf_sync(self.h))
+
+    def segments_done(self):
+        return int(self.L.pf_num_segments_done(self.h))
+
+    def logl(self):
+        return float(self.L.pf_logl(self.h))
+
+    def trace(self):
+        self.sync()
+        n = self.segments_done()
+        T = np.zeros(n); ess = np.zeros(n); flag = np.zeros(n, np.int32); logl = np.zeros(n)
+        self._chk(self.L.pf_get_trace(self.h, T.ctypes.data, ess.ctypes.data, flag.ctypes.data, logl.ctypes.data, n))
+        return {"T": T, "ess": ess, "resampled": flag, "logl": logl}
+
+    def resample_events(self):
+        seg = np.zeros(max(1, self.max_trace_events), np.int32)
+        par = np.zeros((max(1, self.max_trace_events), self.Np), np.int32)
+        n = self._chk(self.L.pf_get_resample_events(self.h, seg.ctypes.data, par.ctypes.data, self.max_trace_events))
+        return seg[:n], par[:n]
+
+    def particles(self):
+        n = self.nsam
+        wp = np.zeros(self.Np); wq = np.zeros(self.Np); H = np.zeros((self.Np, n - 1))
+        Ch = np.zeros((self.Np, n - 1, 2), np.int8); nb = np.zeros(self.Np)
+        self._chk(self.L.pf_get_particles(self.h, wp.ctypes.data, wq.ctypes.data, H.ctypes.data, Ch.ctypes.data,
+                                          nb.ctypes.data))
+        return {"w_post": wp, "w_pilot": wq, "heights": H, "children": Ch, "next_base": nb}
+
+    def counts(self):
+        E = self.E
+        out = np.zeros(6 * E + 4)
+        self._chk(self.L.pf_get_counts(self.h, out.ctypes.data, len(out)))
+        return {
+            "coal_count": out[0:E].copy(), "coal_opp": out[E:2 * E].copy(), "coal_weight": out[2 * E:3 * E].copy(),
+            "rec_count": out[3 * E:4 * E].copy(), "rec_opp": out[4 * E:5 * E].copy(),
+            "rec_weight": out[5 * E:6 * E].copy(), "delayed_opp": out[6 * E], "delayed_count": out[6 * E + 1],
+            "resample_count": out[6 * E + 2], "logl": out[6 * E + 3],
+        }
+
+    def set_timing(self, period):
+        self.L.pf_set_timing(self.h, int(period))
+
+    def kernel_times(self):
+        """{class: (total_ms_estimate, launches)} from HIP events on the handle's stream."""
+        out = {}
+        for k, name in enumerate(KERNEL_CLASSES):
+            ms = C.c_double(); n = C.c_int64()
+            self._chk(self.L.pf_get_kernel_time(self.h, k, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
+    def stats(self):
+        a = C.c_int64(); b = C.c_int64(); c = C.c_int64()
+        self._chk(self.L.pf_get_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"records": a.value, "state_bytes_per_particle": b.value, "resamples": c.value}
+
+
+# ---- unit-level device entry points (parity tests) ----
+def device_math(x, device=0):
+    L = load_library()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    e = np.zeros_like(x); l = np.zeros_like(x); f = np.zeros_like(x)
+    if L.pf_test_math(x.ctypes.data, len(x), e.ctypes.data, l.ctypes.data, f.ctypes.data, device) < 0:
+        raise PfError(_err(L))
+    return e, l, f
+
+
+def device_div(a, b, device=0):
+    L = load_library()
+    a = np.ascontiguousarray(a, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+    o = np.zeros_like(a)
+    if L.pf_test_div(a.ctypes.data, b.ctypes.data, len(a), o.ctypes.data, device) < 0:
+        raise PfError(_err(L))
+    return o
+
+
+def device_uniform(seed, slot, stream, first, n, device=0):
+    L = load_library()
+    o = np.zeros(n)
+    if L.pf_test_uniform(seed, slot, stream, first, n, o.ctypes.data, device) < 0:
+        raise PfError(_err(L))
+    return o
+
+
+def device_reduce(x, device=0):
+    L = load_library()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    s = C.c_double(); sc = np.zeros_like(x)
+    if L.pf_test_reduce(x.ctypes.data, len(x), C.byref(s), sc.ctypes.data, device) < 0:
+        raise PfError(_err(L))
+    return s.value, sc
+
+
+def device_systematic(pilot, device=0):
+    """Offspring table of the production resampler for event 0 of seed 1 (u from the resampler stream)."""
+    L = load_library()
+    x = np.ascontiguousarray(pilot, dtype=np.float64)
+    lo = np.zeros(len(x) + 1, np.int32)
+    if L.pf_test_systematic(x.ctypes.data, len(x), 0.0, lo.ctypes.data, device) < 0:
+        raise PfError(_err(L))
+    return lo

@@ -1,0 +1,63 @@
+"""Shared test inputs: models and synthetic segment sets (seeded, small enough for the oracle)."""
+import numpy as np
+
+from smcsmc_amd import segments as segmod
+from smcsmc_amd import simulate
+
+
+def make_model(n=4, E=8, L=2e5, N0=1e4, mu=2.5e-8, rho=1e-8, lag=None, sizes=None, **kw):
+    ct = simulate.default_epochs(E, 133.0, 133032.0) if E > 1 else np.array([0.0])
+    ps = np.full(E, N0) if sizes is None else np.asarray(sizes, float) * N0
+    if lag is None:
+        # the reference's uncalibrated default (count.cpp:230-247): 4 / (rho * top_t)
+        lags = [20000.0] if E == 1 else [4.0 / (rho * (ct[e + 1] if e + 1 < E else ct[-1])) for e in range(E)]
+    else:
+        lags = [float(lag)] * E
+    m = dict(change_times=ct, pop_sizes=ps, lags=np.array(lags), nsam=n, loci_length=float(L),
+             mutation_rate=mu, recombination_rate=rho)
+    m.update(kw)
+    return m
+
+
+def make_segments(model, seed=1, unphased=False, missing_block=None, max_seg_len=None, tmpdir=None):
+    """Simulated data packed exactly as the host side packs a .seg file."""
+    n = model["nsam"]
+    L = model["loci_length"]
+    seg = simulate.simulate_seg(n, L, model["mutation_rate"], model["recombination_rate"],
+                                model["change_times"], model["pop_sizes"], seed=seed)
+    al = seg["alleles"].copy()
+    if unphased:
+        for i in range(0, n - 1, 2):
+            het = (al[:, i] >= 0) & (al[:, i + 1] >= 0) & (al[:, i] != al[:, i + 1])
+            al[het, i] = 2
+            al[het, i + 1] = 2
+    if missing_block is not None:
+        a, b, cols = missing_block
+        rows = (seg["start"] >= a) & (seg["start"] < b)
+        for c in cols:
+            al[rows, c] = -1
+    seg["alleles"] = al
+    S = segmod.Segments.__new__(segmod.Segments)
+    S.file_name = "<memory>"; S.nsam = n; S.seqlen = float(L); S.data_start = 1
+    S.max_segment_length = max_seg_len or 1e99; S.empty_file = False; S._nfields = None
+    S.rows = []
+    for s, l, a in zip(seg["start"], seg["length"], seg["alleles"]):
+        s = int(s); l = int(l); end = s + l
+        while True:   # same splitting rule as Segments._prepare
+            if l > S.max_segment_length:
+                l = int(S.max_segment_length); st = segmod.SEGMENT_INVARIANT_PARTIAL
+            else:
+                st = segmod.SEGMENT_INVARIANT
+            S.rows.append((s, l, st, list(map(int, a))))
+            s += l; l = end - s
+            if not s < end:
+                break
+    return S.pack(model["lags"])
+
+
+def nodata_segments(model, seglen=1000.0):
+    L = model["loci_length"]; n = model["nsam"]
+    S = int(np.ceil(L / seglen))
+    return dict(start=np.arange(S) * seglen, length=np.full(S, seglen), state=np.full(S, 1, np.int8),
+                alleles=np.full((S, n), -1, np.int8),
+                max_record_epoch=np.full(S, -1, np.int32) * 0 + (len(model["lags"]) - 1))

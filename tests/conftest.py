@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_lib
+    oracle_lib.build()
+    return oracle_lib
+
+
+@pytest.fixture(scope="session")
+def hiplib():
+    """The HIP library must already be built in-tree (the GPU box receives the prebuilt .so)."""
+    from smcsmc_amd import build, pf
+    if not os.path.exists(pf.LIB_PATH):
+        build.build_lib()
+    return pf.load_library()
