@@ -540,7 +540,7 @@ __global__ __launch_bounds__(PF_DECIDE_BS) void k_decide(KArgs A, long long s, i
     __syncthreads();
     if (tid == 0) {
         double T = sh_T;
-        double S1 = A.chunk_off[nc - 1] + A.chunk_pil[nc - 1];
+        double S1 = A.chunk_off[nc - 1] + A.scan1[Np - 1];   // inclusive scan at the last particle (= oracle incl[N-1])
         double S2 = sh_S2;
         if (!(T > 0.0)) c->err = ERR_ZERO_PROB;
         c->logl += dlog(T);
