@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- genome segments / second of the particle-filter forward sweep on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+  * a "step" = one E-step sweep of the particle filter over one synthetic chromosome chunk
+    (the do-while of /root/reference/src/smcsmc.cpp:324-360 plus the final flush 371-373),
+    inputs (segments, model tables) already resident in HBM when the timed region starts.
+  * workload at N=1: BASELINE.json configs[2] -- 2 diploids (4 haplotypes), 100 Mb, Np=10000,
+    E=32 epochs, N0=1e4, mu=2.5e-8, rho=1e-8, data from the in-repo SMC'
+    simulator (seeded).  N>1: one such chunk per GPU (weak scaling: chunks are independent,
+    smcsmc/model.py:563-662), then one RCCL all-gather of the packed CountModel buffers summed
+    in rank order (deterministic), the functional equivalent of smcsmc/model.py:1176-1184.
+  * value = (segments processed by all ranks over K steps) / (max over ranks of the timed wall time).
+Extra objects: "roofline" for the dominant kernel (k_extend) and "cpu_baseline" (the CPU oracle,
+kind "port": the reference binary cannot be built here) timed on a bounded sample on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def build_workload(args, seed):
+    from smcsmc_amd import segments as segmod
+    from smcsmc_amd import simulate
+    n, L, E = args.nsam, float(args.length), args.epochs
+    N0, mu, rho = 1e4, 2.5e-8, 1e-8
+    ct = simulate.default_epochs(E)
+    ps = np.full(E, N0)
+    # the reference's uncalibrated per-epoch lag 4/(rho*top_t) (count.cpp:240-245); the calibrated
+    # default needs the 1e6-tree prior simulation (smcsmc.cpp:169-263), reported separately
+    lags = np.array([4.0 / (rho * (ct[e + 1] if e + 1 < E else ct[-1])) for e in range(E)]) if E > 1 else np.array([20000.0])
+    model = dict(change_times=ct, pop_sizes=ps, lags=lags, nsam=n, loci_length=L, mutation_rate=mu,
+                 recombination_rate=rho)
+    cache = "/tmp/smcsmc_bench_n%d_L%d_E%d_s%d.npz" % (n, int(L), E, seed)
+    if os.path.exists(cache):
+        z = np.load(cache)
+        seg = {k: z[k] for k in ("start", "length", "alleles")}
+    else:
+        seg = simulate.simulate_seg(n, L, mu, rho, ct, ps, seed=seed)
+        np.savez(cache, **seg)
+    max_seg_len = int(2.0 / (rho * 4 * N0))        # pfparam.cpp:364
+    S = segmod.Segments.__new__(segmod.Segments)
+    S.file_name = "<bench>"; S.nsam = n; S.seqlen = L; S.data_start = 1
+    S.max_segment_length = max_seg_len; S.empty_file = False; S._nfields = None
+    rows = []
+    for s, l, a in zip(seg["start"], seg["length"], seg["alleles"]):
+        s = int(s); l = int(l); end = s + l
+        while True:
+            if l > max_seg_len:
+                l = max_seg_len; st = segmod.SEGMENT_INVARIANT_PARTIAL
+            else:
+                st = segmod.SEGMENT_INVARIANT
+            rows.append((s, l, st, a))
+            s += l; l = end - s
+            if not s < end:
+                break
+    S.rows = rows
+    return model, S.pack(lags)
+
+
+def run_sweep(pf, segs):
+    pf.init_prior(float(segs["start"][0]))
+    pf.run()
+    pf.finish()
+
+
+def cpu_baseline(args, model, segs):
+    """The CPU oracle (restatement of the reference's single-threaded path) on a bounded prefix."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    oracle_lib.build()
+    nseg = min(args.cpu_segments, len(segs["start"]))
+    sub = {k: v[:nseg] for k, v in segs.items()}
+    o = oracle_lib.Oracle(model, args.np, ess_fraction=0.5, seed=args.seed, max_trace_events=0)
+    o.init_prior(float(sub["start"][0]))
+    si = o.pack_segments(model, sub)
+    t0 = time.perf_counter()
+    done = 0
+    for s in range(nseg):
+        o.update_segment(si, s)
+        pos = min(sub["start"][s] + sub["length"][s], model["loci_length"])
+        o.count(pos)
+        o.resample(pos)
+        done += 1
+        if time.perf_counter() - t0 > args.cpu_seconds:
+            break
+    dt = time.perf_counter() - t0
+    st = o.stats()
+    o.close()
+    return {"value": done / dt, "unit": "segments/s", "cores": 1, "kind": "port",
+            "sample": "first %d segments of the same workload (Np=%d), %.1f s, single thread, oracle/libsmc_oracle.so "
+                      "(-O3 -DNDEBUG); %d genealogy updates" % (done, args.np, dt, st["recombinations"])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--np", type=int, default=10000)
+    ap.add_argument("--nsam", type=int, default=4)
+    ap.add_argument("--length", type=float, default=1e8)
+    ap.add_argument("--epochs", type=int, default=32)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cpu-segments", type=int, default=2000)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--timing-period", type=int, default=16, help="time every k-th segment's kernels with HIP events")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from smcsmc_amd import ParticleFilter
+    from smcsmc_amd import build as pfbuild
+    from smcsmc_amd import pf as pfmod
+    if not os.path.exists(pfmod.LIB_PATH):
+        pfbuild.build_lib()
+
+    model, segs = build_workload(args, seed=args.seed + rank)     # one independent chunk per rank
+    n_segments = len(segs["start"])
+    pf = ParticleFilter(model, args.np, ess_fraction=0.5, seed=args.seed + 1000 * rank, max_trace_events=0,
+                        device=local_rank if world > 1 else 0)
+    pf.load_segments(segs)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run_sweep(pf, segs)
+    pf.sync()
+    pf.set_timing(args.timing_period)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_sweep(pf, segs)
+    pf.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    kt = pf.kernel_times()
+    st = pf.stats()
+    logl = pf.logl()
+    counts = pf.counts()
+
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt_max = float(tmax.item())
+        segs_all = torch.tensor([float(n_segments)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(segs_all, op=dist.ReduceOp.SUM)
+        total_segments = float(segs_all.item())
+        # CountModel "all-reduce": all-gather + sum in rank order (bit-identical for any arrival order)
+        packed = np.concatenate([counts[k] for k in ("coal_count", "coal_opp", "coal_weight", "rec_count", "rec_opp",
+                                                     "rec_weight")] + [[counts["delayed_opp"], counts["resample_count"], logl]])
+        mine = torch.tensor(packed, dtype=torch.float64, device="cuda")
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        reduced = gathered[0].clone()
+        for r in range(1, world):
+            reduced += gathered[r]
+        logl_sum = float(reduced[-1].item())
+    else:
+        dt_max = dt
+        total_segments = float(n_segments)
+        logl_sum = logl
+
+    if rank == 0:
+        value = total_segments * args.steps / dt_max
+        ext_ms, ext_launches = kt["extend"]
+        avg_ext_us = 1e3 * ext_ms / max(1, ext_launches)
+        rec_per_seg = st["records"] / max(1, n_segments)            # records appended per segment (last sweep)
+        state_bytes = st["state_bytes_per_particle"]
+        rec_bytes = 8 * (5 + args.nsam - 1)
+        # algorithmic bytes of one k_extend launch: every particle's state read and written once,
+        # plus the event records appended
+        alg_bytes = args.np * 2 * state_bytes + rec_per_seg * rec_bytes
+        achieved = alg_bytes / (avg_ext_us * 1e-6) / 1e9 if avg_ext_us > 0 else 0.0
+        out = {
+            "metric": "genome segments/sec per EM iteration (Np=10000, 2 diploids, 100 Mb)",
+            "value": value, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt_max / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "2 diploids (4 haplotypes), %.0f Mb, Np=%d, E=%d epochs, one chunk per GPU"
+                                   % (args.length / 1e6, args.np, args.epochs),
+                       "segments_per_chunk": n_segments, "nsam": args.nsam, "np": args.np,
+                       "sequence_length": args.length, "epochs": args.epochs,
+                       "parallelism": "chunk-per-gpu x%d" % world, "log_likelihood_sum": logl_sum},
+            "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes_per_launch": alg_bytes, "avg_launch_us": avg_ext_us,
+                         "kernel_ms_estimate": {k: v[0] for k, v in kt.items()},
+                         "kernel_launches": {k: v[1] for k, v in kt.items()}},
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, model, segs)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

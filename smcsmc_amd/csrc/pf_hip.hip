@@ -27,6 +27,7 @@
 
 #define PF_EMAX 64
 #define PF_DECIDE_BS 1024
+#define PF_LEDGER_BLOCKS 224   // extra workgroups of k_resample that maintain the ancestor ledger
 #define REC_RECOMB 1
 #define REC_COALMIGR 2
 
@@ -56,7 +57,9 @@ struct Ctrl {
     int cur;               // index of the live state buffer
     int gen;               // current generation (number of resampling events so far)
     int first_epoch;       // first epoch updated by the current count step (E = none)
-    int g_min;             // oldest generation touched by the current count step
+    int g_retain;          // oldest generation whose run list is still maintained
+    int g_lo[PF_EMAX];     // generation containing counted_to[e]
+    int g_hi[PF_EMAX];     // generation containing update_to[e] of the current count step
     int err;               // sticky error code
     int count_active;
     int end_seq;
@@ -88,7 +91,11 @@ struct KArgs {
     unsigned* gstart;              // [Gcap][Np]  widx at the start of generation g
     int* lo;                       // [Gcap][Np+1] offspring ranges of resampling event r (between gen r and r+1)
     double* gen_x0;                // [Gcap] position where generation g starts
-    double* Wgen;                  // [Gcap][Np] posterior weight pushed back to generation g
+    // run-length encoded composite ancestor maps: generation g's list maps the slots of the
+    // current generation to slots of generation g: run i covers [run_st[i], run_st[i+1]) -> run_anc[i]
+    int* run_st;                   // [Gcap][Np]
+    int* run_anc;                  // [Gcap][Np]
+    int* nruns;                    // [Gcap]
     // per-wavefront partials written by k_extend
     double* chunk_post;            // [nc]
     double* chunk_sq;
@@ -96,6 +103,10 @@ struct KArgs {
     double* scan1;                 // [Np] within-wavefront inclusive scan of the pilot weights
     double* chunk_off;             // [nc]
     double* l2scan;                // [nc]
+    double* scanp;                 // [Np] within-wavefront inclusive scan of the posterior weights
+    double* chunk_pp;              // [nc] its per-wavefront totals
+    double* chunk_offp;            // [nc] exclusive offsets of the posterior scan
+    double* l2scanp;               // [nc]
     // counting
     double* totals;                // [6][E]
     double* partial;               // [E][nbx][6]
@@ -180,7 +191,8 @@ __global__ __launch_bounds__(PF_BS) void k_init(KArgs A, double initial_position
         c->cur_pos = initial_position;
         c->logl = 0; c->inv_T = 1; c->T = 1; c->flag = 0; c->cur = 0; c->gen = 0; c->n_resample = 0;
         c->first_epoch = A.E; c->err = 0; c->delayed_opp = 0; c->count_active = 0; c->end_seq = 0;
-        for (int e = 0; e < A.E; ++e) { c->counted_to[e] = 0; c->update_to[e] = 0; }
+        c->g_retain = 0;
+        for (int e = 0; e < A.E; ++e) { c->counted_to[e] = 0; c->update_to[e] = 0; c->g_lo[e] = 0; c->g_hi[e] = 0; }
         A.gen_x0[0] = 0.0;
     }
     if (p >= A.Np) return;
@@ -485,40 +497,44 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
     double sp = wave_tree_sum(w_post);
     double sq = wave_tree_sum(w_pilot * w_pilot);
     double sc = wave_hs_scan(w_pilot, lane);
+    double scp = wave_hs_scan(w_post, lane);
     long long chunk = p >> 6;
-    if (active) A.scan1[p] = sc;
+    if (active) { A.scan1[p] = sc; A.scanp[p] = scp; }
     if (lane == 63 && chunk < (A.Np + 63) / 64) {
         A.chunk_post[chunk] = sp;
         A.chunk_sq[chunk] = sq;
         A.chunk_pil[chunk] = sc;
+        A.chunk_pp[chunk] = scp;
     }
 }
 
 // ------------------------------------------------------------------ k_decide (single workgroup)
 // normalize_probability (pc.cpp:420-438), the ESS test of resample (pc.cpp:247-283),
 // systematic_resampling (pc.cpp:474-504) and the window bookkeeping of
-// extract_and_update_count (count.cpp:355-385) + the backward weight push of update_all_counts.
+// extract_and_update_count (count.cpp:355-385).
 __global__ __launch_bounds__(PF_DECIDE_BS) void k_decide(KArgs A, long long s, int mode, int do_count, int end_data) {
-    __shared__ double l2_post[64], l2_sq[64], l2_tot[64], base[64];
+    __shared__ double l2_post[64], l2_sq[64], l2_tot[64], l2_totp[64], base[64], basep[64];
     __shared__ double sh_T, sh_S1, sh_S2, sh_inv, sh_u;
-    __shared__ int sh_flag, sh_first, sh_gmin, sh_G;
+    __shared__ int sh_flag, sh_G;
     __shared__ int wmax[PF_DECIDE_BS / 64];
     Ctrl* c = A.ctrl;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = PF_DECIDE_BS / 64;
     const long long Np = A.Np;
     const int nc = (int)((Np + 63) / 64);
     const int ng = (nc + 63) / 64;
-    // mode 0: regular segment (after k_extend).  mode 1: finish -- weights were produced by k_resample.
+    // level 2 of the canonical radix-64 reduction / scans
     for (int g = wave; g < ng; g += nwaves) {
         int ch = g * 64 + lane;
         double vp = ch < nc ? A.chunk_post[ch] : 0.0;
         double vs = ch < nc ? A.chunk_sq[ch] : 0.0;
         double vl = ch < nc ? A.chunk_pil[ch] : 0.0;
+        double vq = ch < nc ? A.chunk_pp[ch] : 0.0;
         double rp = wave_tree_sum(vp);
         double rs = wave_tree_sum(vs);
         double sc = wave_hs_scan(vl, lane);
-        if (ch < nc) A.l2scan[ch] = sc;
-        if (lane == 63) { l2_post[g] = rp; l2_sq[g] = rs; l2_tot[g] = sc; }
+        double scq = wave_hs_scan(vq, lane);
+        if (ch < nc) { A.l2scan[ch] = sc; A.l2scanp[ch] = scq; }
+        if (lane == 63) { l2_post[g] = rp; l2_sq[g] = rs; l2_tot[g] = sc; l2_totp[g] = scq; }
     }
     __syncthreads();
     if (wave == 0) {
@@ -527,8 +543,11 @@ __global__ __launch_bounds__(PF_DECIDE_BS) void k_decide(KArgs A, long long s, i
         double T = wave_tree_sum(vp);
         double S2 = wave_tree_sum(vs);
         if (lane == 0) {
-            double run = 0.0;
-            for (int g = 0; g < ng; ++g) { base[g] = run; run = run + l2_tot[g]; }
+            double run = 0.0, runp = 0.0;
+            for (int g = 0; g < ng; ++g) {
+                base[g] = run; run = run + l2_tot[g];
+                basep[g] = runp; runp = runp + l2_totp[g];
+            }
             sh_T = T; sh_S2 = S2;
         }
     }
@@ -536,6 +555,8 @@ __global__ __launch_bounds__(PF_DECIDE_BS) void k_decide(KArgs A, long long s, i
     for (int ch = tid; ch < nc; ch += PF_DECIDE_BS) {
         double off = (ch % 64 == 0) ? 0.0 : A.l2scan[ch - 1];
         A.chunk_off[ch] = base[ch / 64] + off;
+        double offp = (ch % 64 == 0) ? 0.0 : A.l2scanp[ch - 1];
+        A.chunk_offp[ch] = basep[ch / 64] + offp;
     }
     __syncthreads();
     if (tid == 0) {
@@ -560,6 +581,8 @@ __global__ __launch_bounds__(PF_DECIDE_BS) void k_decide(KArgs A, long long s, i
         }
         c->T = T; c->inv_T = inv; c->S1 = S1; c->S2 = S2; c->ess = ess; c->u = u; c->flag = flag;
         sh_S1 = S1; sh_inv = inv; sh_u = u; sh_flag = flag;
+        const int G = c->gen;
+        sh_G = G;
         // windows of this count step (count.cpp:363-385)
         int first = A.E;
         if (do_count) {
@@ -574,47 +597,21 @@ __global__ __launch_bounds__(PF_DECIDE_BS) void k_decide(KArgs A, long long s, i
                     if (e < first) first = e;
                 }
             }
-            c->end_seq = 0;
+            // generation holding the upper end of each updated window (monotone: amortised O(1))
+            for (int e = first; e < A.E; ++e) {
+                int g = c->g_hi[e];
+                if (g < c->g_lo[e]) g = c->g_lo[e];
+                while (g < G && A.gen_x0[(g + 1) % A.Gcap] < c->update_to[e]) ++g;
+                c->g_hi[e] = g;
+            }
         }
         c->first_epoch = first;
         c->count_active = first < A.E;
-        sh_first = first;
-        int G = c->gen;
-        sh_G = G;
-        int gmin = G;
-        if (first < A.E) {
-            double xmin = c->counted_to[first];
-            for (int e = first; e < A.E; ++e) xmin = c->counted_to[e] < xmin ? c->counted_to[e] : xmin;
-            while (gmin > 0 && A.gen_x0[gmin % A.Gcap] > xmin) --gmin;
-            if (G - gmin >= A.Gcap - 1) c->err = ERR_GEN_OVERFLOW;
-        }
-        c->g_min = gmin;
-        sh_gmin = gmin;
     }
     __syncthreads();
     const int flag = sh_flag;
-    const double S1 = sh_S1, inv = sh_inv;
+    const double S1 = sh_S1;
     const int G = sh_G;
-    const DState& st = A.st[c->cur];
-
-    // ---- backward push of the (normalised) posterior weights through the ancestor ledger ----
-    if (sh_first < A.E) {
-        double* Wg = A.Wgen + (size_t)(G % A.Gcap) * Np;
-        for (long long a = tid; a < Np; a += PF_DECIDE_BS) Wg[a] = st.w_post[a] * inv;
-        __syncthreads();
-        for (int g = G - 1; g >= sh_gmin; --g) {
-            const double* Wn = A.Wgen + (size_t)((g + 1) % A.Gcap) * Np;
-            double* Wo = A.Wgen + (size_t)(g % A.Gcap) * Np;
-            const int* lo = A.lo + (size_t)(g % A.Gcap) * (Np + 1);
-            for (long long a = tid; a < Np; a += PF_DECIDE_BS) {
-                double acc = 0.0;
-                int q1 = lo[a + 1];
-                for (int q = lo[a]; q < q1; ++q) acc += Wn[q];
-                Wo[a] = acc;
-            }
-            __syncthreads();
-        }
-    }
 
     // ---- offspring table lo[0..Np] of systematic resampling (closed form, monotone) ----
     if (flag) {
@@ -658,13 +655,15 @@ __global__ __launch_bounds__(PF_DECIDE_BS) void k_decide(KArgs A, long long s, i
             c->gen = G + 1;
             A.gen_x0[(G + 1) % A.Gcap] = c->cur_pos;
             c->n_resample += 1;
+            if (G + 1 - c->g_retain >= A.Gcap - 1) c->err = ERR_GEN_OVERFLOW;
         }
     }
 }
 
 // ------------------------------------------------------------------ k_count
 // update_all_counts_single_evolevent (count.cpp:495-555) evaluated from the compact per-slot
-// records: one workgroup column per epoch (blockIdx.y), one lane per slot.
+// records.  blockIdx.y = epoch; the x dimension strides over the live ancestors (runs of the
+// composite ancestor maps) of every generation whose positions intersect the epoch's window.
 struct Acc { double cc, co, cw, rc, ro, rw; };
 
 __device__ __forceinline__ double ovl(double a0, double a1, double b0, double b1) {
@@ -674,11 +673,10 @@ __device__ __forceinline__ double ovl(double a0, double a1, double b0, double b1
     return d > 0.0 ? d : 0.0;
 }
 
-// local tree length inside [T0,T1): sum over slices (n-r) * overlap
+// sum_i (nl - i) * |[S_{i-1}, S_i] n [max(T0,lo_t), min(T1,hi_t)]|, optionally including the single
+// lineage above the top node (coalescence paths)
 __device__ __forceinline__ double slice_len(const double* S, int nint, int nl, double T0, double T1, double lo_t, double hi_t,
                                             bool above_top) {
-    // sum_{i} (nl - i) * overlap([S_{i-1}, S_i], [max(T0,lo_t), min(T1,hi_t)]); optionally the
-    // single lineage above the top node (i == nint) for coalescence paths
     double a = T0 > lo_t ? T0 : lo_t;
     double b = T1 < hi_t ? T1 : hi_t;
     if (!(b > a)) return 0.0;
@@ -692,80 +690,101 @@ __device__ __forceinline__ double slice_len(const double* S, int nint, int nl, d
     return acc;
 }
 
-__device__ __forceinline__ void stretch_contrib(Acc& acc, const KArgs& A, int e, double w, double x0, double x1, const double* S,
-                                                int lim_start, double T0, double T1, double a_e, double b_e, int rf) {
-    if (!(rf & REC_RECOMB) || e > lim_start) return;
-    double xs = ovl(x0, x1, a_e, b_e);
+struct Win { int e, rf; double T0, T1, a_e, b_e; bool end_seq; };
+
+__device__ __forceinline__ void stretch_contrib(Acc& acc, const KArgs& A, const Win& W, double w, double x0, double x1,
+                                                const double* S, int lim_start) {
+    if (!(W.rf & REC_RECOMB) || W.e > lim_start) return;
+    double xs = ovl(x0, x1, W.a_e, W.b_e);
     if (!(xs > 0.0)) return;
-    double len = slice_len(S, A.n - 1, A.n, T0, T1, 0.0, PF_INF, false);
+    double len = slice_len(S, A.n - 1, A.n, W.T0, W.T1, 0.0, PF_INF, false);
     double opp = len * xs;
     acc.ro += w * opp;
     acc.rw += w * w * opp;
 }
 
+__device__ __forceinline__ void records_contrib(Acc& acc, const KArgs& A, const Win& W, double w, long long a, unsigned k0,
+                                                unsigned k1) {
+    for (unsigned k = k0; k != k1; ++k) {
+        const double* rec = rec_ptr(A, a, k);
+        double x0 = rec[0], x1 = rec[1];
+        if (x1 < W.a_e) continue;      // consumed by earlier windows
+        unsigned long long meta = (unsigned long long)__double_as_longlong(rec[4]);
+        int type = (int)(meta & 0xff);
+        int lim_start = (int)((meta >> 8) & 0xff) - 1;
+        int lim_event = (int)((meta >> 16) & 0xff) - 1;
+        int n_eff = (int)((meta >> 24) & 0xff);
+        const double* S = rec + 5;
+        if (type <= 1) stretch_contrib(acc, A, W, w, x0, x1, S, lim_start);
+        if (type == 0 || type == 2) {
+            double h = rec[2], tc = rec[3];
+            bool inwin = (W.a_e <= x1) && (x1 < W.b_e);
+            if (inwin && (W.rf & REC_COALMIGR) && W.e <= lim_event) {
+                double opp = slice_len(S, n_eff - 1, n_eff, W.T0, W.T1, h, tc, true);
+                acc.co += w * opp;
+                acc.cw += w * w * opp;
+                if (W.T0 <= tc && tc < W.T1) acc.cc += w;
+            }
+            if (type == 0) {
+                bool inwin_r = (W.a_e <= x1) && ((x1 < W.b_e) || W.end_seq);
+                if (inwin_r && (W.rf & REC_RECOMB) && W.e <= lim_event && W.T0 <= h && h < W.T1) acc.rc += w;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0) {
     __shared__ Acc red[PF_BS / 64];
-    __shared__ int sh_gmin_e;
     const Ctrl* c = A.ctrl;
     const int e = e0 + blockIdx.y;
     const int first = c->first_epoch;
     if (e < first || e >= A.E) return;
     const long long Np = A.Np;
-    const long long a = (long long)blockIdx.x * PF_BS + threadIdx.x;
-    const int G = c->count_active ? ((c->flag) ? c->gen - 1 : c->gen) : c->gen;   // generation the weights belong to
-    const double a_e = c->counted_to[e], b_e = c->update_to[e];
-    const double T0 = A.T[e], T1 = e + 1 < A.E ? A.T[e + 1] : PF_INF;
-    const int rf = A.recflags[e];
-    const bool end_seq = (A.L == b_e);
-    if (threadIdx.x == 0) {
-        int g = G;
-        while (g > c->g_min && A.gen_x0[g % A.Gcap] > a_e) --g;
-        sh_gmin_e = g;
-    }
-    __syncthreads();
-    const int gmin_e = sh_gmin_e;
+    const int n = A.n;
+    const int G = c->flag ? c->gen - 1 : c->gen;          // the generation the weights belong to
+    const DState& st = A.st[c->flag ? (c->cur ^ 1) : c->cur];
+    const double inv = c->inv_T;
+    Win W;
+    W.e = e; W.rf = A.recflags[e];
+    W.T0 = A.T[e]; W.T1 = e + 1 < A.E ? A.T[e + 1] : PF_INF;
+    W.a_e = c->counted_to[e]; W.b_e = c->update_to[e];
+    W.end_seq = (A.L == W.b_e);
+    const int g_lo = c->g_lo[e], g_hi = c->g_hi[e];
+    const long long gtid = (long long)blockIdx.x * PF_BS + threadIdx.x;
+    const long long nthreads = (long long)gridDim.x * PF_BS;
     Acc acc = {0, 0, 0, 0, 0, 0};
-    if (a < Np) {
-        const int n = A.n;
-        for (int g = G; g >= gmin_e; --g) {
-            double w = A.Wgen[(size_t)(g % A.Gcap) * Np + a];
-            if (w == 0.0) continue;
-            unsigned k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
-            unsigned k1 = (g == G) ? A.widx[a] : A.gstart[(size_t)((g + 1) % A.Gcap) * Np + a];
-            if (g == G) {
-                // the open stretch of the live particle (its rectangles are still being extended)
-                const DState& st = A.st[c->flag ? (c->cur ^ 1) : c->cur];
+    for (int g = g_hi; g >= g_lo; --g) {
+        if (g == G) {
+            // live particles: their own weight, their open stretch, the records they wrote this generation
+            for (long long a = gtid; a < Np; a += nthreads) {
+                double w = st.w_post[a] * inv;
+                if (w == 0.0) continue;
                 double S[PF_NMAX - 1];
                 for (int r = 0; r < n - 1; ++r) S[r] = st.S[(size_t)r * Np + a];
-                stretch_contrib(acc, A, e, w, st.x_mark[a], PF_INF, S, st.mark_limit[a], T0, T1, a_e, b_e, rf);
+                stretch_contrib(acc, A, W, w, st.x_mark[a], PF_INF, S, st.mark_limit[a]);
+                unsigned k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
+                unsigned k1 = A.widx[a];
+                if (k1 - k0 > A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;
+                records_contrib(acc, A, W, w, a, k0, k1);
             }
-            for (unsigned k = k0; k != k1; ++k) {
-                const double* rec = rec_ptr(A, a, k);
-                double x0 = rec[0], x1 = rec[1];
-                if (x1 < a_e) continue;      // consumed by earlier windows
-                unsigned long long meta = (unsigned long long)__double_as_longlong(rec[4]);
-                int type = (int)(meta & 0xff);
-                int lim_start = (int)((meta >> 8) & 0xff) - 1;
-                int lim_event = (int)((meta >> 16) & 0xff) - 1;
-                int n_eff = (int)((meta >> 24) & 0xff);
-                const double* S = rec + 5;
-                if (type <= 1) stretch_contrib(acc, A, e, w, x0, x1, S, lim_start, T0, T1, a_e, b_e, rf);
-                if (type == 0 || type == 2) {
-                    double h = rec[2], tc = rec[3];
-                    bool inwin = (a_e <= x1) && (x1 < b_e);
-                    if (inwin && (rf & REC_COALMIGR) && e <= lim_event) {
-                        double opp = slice_len(S, n_eff - 1, n_eff, T0, T1, h, tc, true);
-                        acc.co += w * opp;
-                        acc.cw += w * w * opp;
-                        if (T0 <= tc && tc < T1) acc.cc += w;
-                    }
-                    if (type == 0) {
-                        bool inwin_r = (a_e <= x1) && ((x1 < b_e) || end_seq);
-                        if (inwin_r && (rf & REC_RECOMB) && e <= lim_event && T0 <= h && h < T1) acc.rc += w;
-                    }
-                }
+        } else {
+            const int nr = A.nruns[g % A.Gcap];
+            const int* rst = A.run_st + (size_t)(g % A.Gcap) * Np;
+            const int* ran = A.run_anc + (size_t)(g % A.Gcap) * Np;
+            for (long long i = gtid; i < nr; i += nthreads) {
+                int q0 = rst[i];
+                int q1 = i + 1 < nr ? rst[i + 1] : (int)Np;
+                long long a = ran[i];
+                // posterior mass of the descendants of (g, a): difference of the inclusive posterior scan
+                double hi = A.chunk_offp[(q1 - 1) >> 6] + A.scanp[q1 - 1];
+                double lo = q0 > 0 ? A.chunk_offp[(q0 - 1) >> 6] + A.scanp[q0 - 1] : 0.0;
+                double w = (hi - lo) * inv;
+                if (!(w > 0.0)) continue;
+                unsigned k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
+                unsigned k1 = A.gstart[(size_t)((g + 1) % A.Gcap) * Np + a];
+                if (A.widx[a] - k0 > A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;
+                records_contrib(acc, A, W, w, a, k0, k1);
             }
-            if (k1 - k0 > A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;
         }
     }
     // deterministic workgroup reduction: butterfly per wavefront, then wavefronts in order
@@ -784,32 +803,90 @@ __global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0) {
     }
 }
 
-__global__ void k_count_fin(KArgs A) {
+__global__ void k_count_fin(KArgs A, int nbx_used) {
     Ctrl* c = A.ctrl;
     const int first = c->first_epoch;
     const int E = A.E;
+    const int G = c->flag ? c->gen - 1 : c->gen;
     for (int e = first + threadIdx.x; e < E; e += blockDim.x) {
         double t[6] = {0, 0, 0, 0, 0, 0};
-        for (int b = 0; b < A.nbx; ++b) {
+        for (int b = 0; b < nbx_used; ++b) {
             const double* in = A.partial + ((size_t)e * A.nbx + b) * 6;
             for (int k = 0; k < 6; ++k) t[k] += in[k];
         }
         for (int k = 0; k < 6; ++k) A.totals[(size_t)k * E + e] += t[k];
+        // the window's lower end moves up: advance the generation that holds it (amortised O(1))
+        int g = c->g_lo[e];
+        while (g < G && A.gen_x0[(g + 1) % A.Gcap] <= c->update_to[e]) ++g;
+        c->g_lo[e] = g;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         c->delayed_opp += c->update_to[E - 1] - c->counted_to[E - 1];
         for (int e = 0; e < E; ++e) c->counted_to[e] = c->update_to[e];
+        int gr = c->g_lo[0];
+        for (int e = 1; e < E; ++e) gr = c->g_lo[e] < gr ? c->g_lo[e] : gr;
+        c->g_retain = gr;
         c->first_epoch = E;
         c->count_active = 0;
     }
 }
 
-// ------------------------------------------------------------------ k_resample
-// No resampling: normalise in place (pc.cpp:435-437).  Resampling: implement_resampling
-// (pc.cpp:321-392) as a gather from the old buffer into the new one.
-__global__ __launch_bounds__(PF_BS) void k_resample(KArgs A, long long s) {
+// ------------------------------------------------------------------ k_resample (+ ledger blocks)
+// Blocks [0, nblocks): no resampling -> normalise in place (pc.cpp:435-437); resampling ->
+// implement_resampling (pc.cpp:321-392) as a gather from the old buffer into the new one.
+// Blocks [nblocks, gridDim.x): after a resampling, re-base the run-length encoded composite
+// ancestor maps of all retained generations onto the new slots (st' = lo[st], empty runs dropped).
+__device__ void ledger_update(const KArgs& A, int lb, int nlb) {
+    __shared__ int wcnt[PF_BS / 64];
+    __shared__ int sh_base;
     const Ctrl* c = A.ctrl;
+    const long long Np = A.Np;
+    const int G = c->gen - 1;                      // the generation that just ended
+    const int* lo = A.lo + (size_t)(G % A.Gcap) * (Np + 1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int g = c->g_retain + lb; g <= G; g += nlb) {
+        int* rst = A.run_st + (size_t)(g % A.Gcap) * Np;
+        int* ran = A.run_anc + (size_t)(g % A.Gcap) * Np;
+        const bool ident = (g == G);
+        const int nr = ident ? (int)Np : A.nruns[g % A.Gcap];
+        if (tid == 0) sh_base = 0;
+        __syncthreads();
+        for (int off = 0; off < nr; off += PF_BS) {
+            int i = off + tid;
+            bool valid = i < nr;
+            int stv = 0, nxt = 0, anc = 0;
+            if (valid) {
+                stv = ident ? i : rst[i];
+                nxt = (i + 1 < nr) ? (ident ? i + 1 : rst[i + 1]) : (int)Np;
+                anc = ident ? i : ran[i];
+            }
+            int ns = valid ? lo[stv] : 0;
+            int ne = valid ? lo[nxt] : 0;
+            bool keep = valid && ne > ns;
+            unsigned long long bal = __ballot(keep);
+            int pos = __popcll(bal & ((1ULL << lane) - 1ULL));
+            if (lane == 0) wcnt[wave] = __popcll(bal);
+            __syncthreads();                        // every read of this chunk is done
+            int wbase = 0, total = 0;
+            for (int w = 0; w < PF_BS / 64; ++w) { if (w < wave) wbase += wcnt[w]; total += wcnt[w]; }
+            int base = sh_base;
+            if (keep) { rst[base + wbase + pos] = ns; ran[base + wbase + pos] = anc; }
+            __syncthreads();
+            if (tid == 0) sh_base = base + total;
+            __syncthreads();
+        }
+        if (tid == 0) A.nruns[g % A.Gcap] = sh_base;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(PF_BS) void k_resample(KArgs A, long long s, int nblocks) {
+    const Ctrl* c = A.ctrl;
+    if ((int)blockIdx.x >= nblocks) {
+        if (c->flag) ledger_update(A, (int)blockIdx.x - nblocks, (int)gridDim.x - nblocks);
+        return;
+    }
     const long long Np = A.Np;
     const long long i = (long long)blockIdx.x * PF_BS + threadIdx.x;
     if (i >= Np) return;
@@ -891,12 +968,14 @@ __global__ __launch_bounds__(PF_BS) void k_partials(KArgs A) {
     double sp = wave_tree_sum(w_post);
     double sq = wave_tree_sum(w_pilot * w_pilot);
     double sc = wave_hs_scan(w_pilot, lane);
+    double scp = wave_hs_scan(w_post, lane);
     long long chunk = p >> 6;
-    if (active) A.scan1[p] = sc;
+    if (active) { A.scan1[p] = sc; A.scanp[p] = scp; }
     if (lane == 63 && chunk < (A.Np + 63) / 64) {
         A.chunk_post[chunk] = sp;
         A.chunk_sq[chunk] = sq;
         A.chunk_pil[chunk] = sc;
+        A.chunk_pp[chunk] = scp;
     }
 }
 
@@ -1041,10 +1120,13 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     rc |= dalloc(h, &A.gstart, (size_t)A.Gcap * Np);
     rc |= dalloc(h, &A.lo, (size_t)A.Gcap * (Np + 1));
     rc |= dalloc(h, &A.gen_x0, A.Gcap);
-    rc |= dalloc(h, &A.Wgen, (size_t)A.Gcap * Np);
+    rc |= dalloc(h, &A.run_st, (size_t)A.Gcap * Np);
+    rc |= dalloc(h, &A.run_anc, (size_t)A.Gcap * Np);
+    rc |= dalloc(h, &A.nruns, A.Gcap);
     const size_t nc = (size_t)((Np + 63) / 64);
     rc |= dalloc(h, &A.chunk_post, nc); rc |= dalloc(h, &A.chunk_sq, nc); rc |= dalloc(h, &A.chunk_pil, nc);
     rc |= dalloc(h, &A.scan1, Np); rc |= dalloc(h, &A.chunk_off, nc); rc |= dalloc(h, &A.l2scan, nc);
+    rc |= dalloc(h, &A.scanp, Np); rc |= dalloc(h, &A.chunk_pp, nc); rc |= dalloc(h, &A.chunk_offp, nc); rc |= dalloc(h, &A.l2scanp, nc);
     A.nbx = h->nblocks;
     rc |= dalloc(h, &A.totals, (size_t)6 * E);
     rc |= dalloc(h, &A.partial, (size_t)E * A.nbx * 6);
@@ -1061,7 +1143,7 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
 }
 
 pf_handle* pf_create(const pf_model* m, const pf_params* p, int device) {
-    return create_impl(m, p, device, env_ll("SMCSMC_PF_LOG_CAP", 4096), env_ll("SMCSMC_PF_GEN_CAP", 2048));
+    return create_impl(m, p, device, env_ll("SMCSMC_PF_LOG_CAP", 16384), env_ll("SMCSMC_PF_GEN_CAP", 8192));
 }
 
 void pf_destroy(pf_handle* h) {
@@ -1203,7 +1285,7 @@ static int launch_count(pf_handle* h, long long s, int first) {
     {
         Timed tm(h, 2, t);
         hipLaunchKernelGGL(k_count, dim3(h->nblocks, h->E - first), dim3(PF_BS), 0, h->stream, h->A, first);
-        hipLaunchKernelGGL(k_count_fin, dim3(1), dim3(64), 0, h->stream, h->A);
+        hipLaunchKernelGGL(k_count_fin, dim3(1), dim3(64), 0, h->stream, h->A, h->nblocks);
     }
     return check_launch("k_count");
 }
@@ -1212,7 +1294,7 @@ static int launch_resample(pf_handle* h, long long s) {
     const bool t = timing_on(h, s);
     {
         Timed tm(h, 3, t);
-        hipLaunchKernelGGL(k_resample, dim3(h->nblocks), dim3(PF_BS), 0, h->stream, h->A, s);
+        hipLaunchKernelGGL(k_resample, dim3(h->nblocks + PF_LEDGER_BLOCKS), dim3(PF_BS), 0, h->stream, h->A, s, h->nblocks);
     }
     return check_launch("k_resample");
 }
