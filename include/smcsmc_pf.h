@@ -108,6 +108,13 @@ int pf_set_timing(pf_handle* h, int enable);
 /* bookkeeping for the roofline: records appended to the event log, bytes of particle state */
 int pf_get_stats(pf_handle* h, int64_t* n_records, int64_t* state_bytes_per_particle, int64_t* n_resamples);
 
+/* calculate_median_survival_distances (smcsmc.cpp:169-263): median genomic distance until an internal
+ * node of a prior tree is removed, per epoch, from batches of prior ARGs simulated on the device
+ * (fixed Philox seed, like the reference's MersenneTwister(true, 1)); -1-entries are filled with the
+ * reference's fallbacks (smcsmc.cpp:250-258).  lags = median * lag_fraction (count.cpp:261-265). */
+int pf_median_survival(const pf_model* model, uint64_t seed, int32_t min_events, int64_t max_trees, double* median_out,
+                       int64_t* trees_used, int device);
+
 /* unit-level entry points used by the parity tests (device implementations of the math and
  * of the canonical reductions; each runs one small kernel on the handle-independent default stream) */
 int pf_test_math(const double* x, int64_t n, double* out_exp, double* out_log, double* out_fastexp, int device);

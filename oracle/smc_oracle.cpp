@@ -225,7 +225,13 @@ struct Filter {
     std::vector<std::vector<int32_t>> ev_parents;
     int64_t seg_done = 0;
 
-    double uni(int64_t slot) { return philox_uniform(seed, (uint32_t)slot, 0, rng[slot].ctr++); }
+    uint32_t stream = 0;          /* Philox stream id: 0 particle filter, 2 lag calibration */
+    bool record_events = true;
+    double last_sp = 0; bool last_changed = false;
+    int64_t slot_override = -1;   /* calibration: RNG state lives in rng[0], stream keyed by the replicate index */
+    double uni(int64_t slot) {
+        return philox_uniform(seed, (uint32_t)(slot_override >= 0 ? slot_override : slot), stream, rng[slot].ctr++);
+    }
 
     /* ---------------- tree helpers ---------------- */
     inline double node_h(const Tree& t, int id) const { return id < M.n ? 0.0 : t.S[id - M.n]; }
@@ -378,7 +384,7 @@ struct Filter {
             bool fire = !(g.ebuf > need);
             double t1 = tn;
             if (fire) t1 = t + g.ebuf / rate;
-            if (rec_p && (M.recflags[e] & REC_COALMIGR) && e <= limit) {
+            if (rec_p && record_events && (M.recflags[e] & REC_COALMIGR) && e <= limit) {
                 Ev* ev = new_event(*rec_p, e, 1, t, t1, x, x, k);
                 if (fire) ev->event = 1;
             }
@@ -484,6 +490,8 @@ struct Filter {
         int k = nslots + (has_root ? 1 : 0) + (has_stub ? 1 : 0);
         double u = uni(slot);
         int idx = std::min((int)(u * (double)k), k - 1);
+        last_sp = Sp;
+        last_changed = !(has_stub && idx == k - 1);
         if (idx < nslots) {
             lineages_at(t, ni, tc, idx, &pr, &ps);
             insert_node(t, ni, tc, b_id, pr, ps, troot);
@@ -835,6 +843,76 @@ struct Filter {
     }
 };
 
+
+/* calculate_median_survival_distances (smcsmc.cpp:169-263), batched exactly like the HIP driver:
+ * batches of CAL_BATCH independent prior ARGs (Philox stream 2, slot = replicate index) until every
+ * epoch has min_events samples or max_trees trees were used; medians + fallbacks as smcsmc.cpp:235-262 */
+enum { CAL_BATCH = 16384 };
+
+static void median_survival(const Model& M, uint64_t seed, int min_events, int64_t max_trees, double* median_out,
+                            int64_t* trees_used) {
+    const int E = M.E, n = M.n;
+    std::vector<std::vector<double>> surv(E);
+    int64_t trees = 0;
+    for (;;) {
+        int not_done = 0;
+        for (int e = 0; e < E; ++e) not_done += (int)surv[e].size() < min_events;
+        if (not_done == 0 || trees >= max_trees) break;
+        Filter f;
+        f.M = M; f.Np = 1; f.seed = seed; f.stream = 2; f.record_events = false;
+        f.rng.assign(1, SlotRng{0, 0.0});
+        for (int64_t r = 0; r < CAL_BATCH; ++r) {
+            Particle p;
+            p.head.assign(E, nullptr);
+            /* the replicate's own stream: slot = global replicate index */
+            struct Tmp { Filter& f; int64_t slot; } tmp{f, trees + r};
+            f.rng[0] = SlotRng{0, 0.0};
+            auto uni = [&]() { return philox_uniform(seed, (uint32_t)tmp.slot, 2, f.rng[0].ctr++); };
+            (void)uni;
+            f.slot_override = tmp.slot;
+            f.rng[0].ebuf = -smc_log(f.uni(0));
+            f.build_initial_tree(0, p);
+            double orig[NMAX];
+            bool alive[NMAX];
+            int nalive = n - 1;
+            for (int j = 0; j < n - 1; ++j) { orig[j] = p.tr.S[j]; alive[j] = true; }
+            int ep[NMAX];
+            for (int j = 0; j < n - 1; ++j) ep[j] = M.epoch_of(orig[j]);
+            f.sample_next_base(0, p, 0.0);
+            double stop = M.L * 0.6;
+            while (nalive > 0 && p.next_base < stop) {
+                double x = p.next_base;
+                double h;
+                f.genealogy_update(0, p, x, -1, &h);
+                if (f.last_changed) {
+                    for (int j = 0; j < n - 1; ++j)
+                        if (alive[j] && orig[j] == f.last_sp) {
+                            surv[ep[j]].push_back(x);
+                            alive[j] = false;
+                            --nalive;
+                            break;
+                        }
+                }
+                f.sample_next_base(0, p, x);
+            }
+        }
+        trees += CAL_BATCH;
+    }
+    if (trees_used) *trees_used = trees;
+    double earliest = -1;
+    for (int e = 0; e < E; ++e) {
+        std::sort(surv[e].begin(), surv[e].end());
+        int median_idx = ((int)surv[e].size() - 1) / 2;
+        if (median_idx < 10) median_out[e] = -1;
+        else {
+            median_out[e] = surv[e][median_idx];
+            if (earliest < 0) earliest = median_out[e];
+        }
+    }
+    for (int e = 0; e < E; ++e)
+        if (median_out[e] < 0) median_out[e] = e > 0 ? median_out[e - 1] : earliest;
+}
+
 }  // namespace smco
 
 using namespace smco;
@@ -960,6 +1038,21 @@ int smco_get_stats(void* h, int64_t* n_recomb, int64_t* n_alloc, int64_t* n_resa
     if (n_alloc) *n_alloc = f->pool.n_alloc;
     if (n_resamples) *n_resamples = f->n_resample;
     return 0;
+}
+
+int smco_median_survival(const smco_model* m, uint64_t seed, int32_t min_events, int64_t max_trees, double* median_out,
+                         int64_t* trees_used) {
+    GUARD(
+        Model M;
+        M.E = m->n_epochs; M.P = 1; M.n = m->nsam;
+        M.L = m->loci_length; M.mu = m->mutation_rate; M.rho = m->recombination_rate;
+        M.T.assign(m->change_times, m->change_times + M.E);
+        M.inv2N.resize(M.E);
+        for (int e = 0; e < M.E; ++e) M.inv2N[e] = 1.0 / (2.0 * m->pop_sizes[e]);
+        M.recflags.assign(M.E, 3);
+        M.lags.assign(M.E, 0.0);
+        median_survival(M, seed, min_events, max_trees, median_out, trees_used);
+    )
 }
 
 double smco_exp(double x) { return smc_exp(x); }

@@ -88,6 +88,10 @@ double smco_logl(void* h);
 /* work statistics for DESIGN.md / roofline bookkeeping */
 int smco_get_stats(void* h, int64_t* n_recombinations, int64_t* n_events_allocated, int64_t* n_resamples);
 
+/* calculate_median_survival_distances (smcsmc.cpp:169-263), batched like the HIP driver */
+int smco_median_survival(const smco_model* m, uint64_t seed, int32_t min_events, int64_t max_trees, double* median_out,
+                         int64_t* trees_used);
+
 /* exposed helpers so the tests can pin the math bit-for-bit against the HIP side */
 double smco_exp(double x);
 double smco_log(double x);

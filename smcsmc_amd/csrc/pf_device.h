@@ -181,6 +181,7 @@ struct Lane {
     double L, mu, rho;
     unsigned long long seed;
     unsigned slot;
+    unsigned stream;          // Philox stream id: 0 particle filter, 2 lag calibration
     unsigned long long ctr;   // draws consumed by this slot
     double ebuf;              // buffered unit exponential (RandomGenerator::sampleExpoLimit)
     double Ltree;
@@ -189,7 +190,7 @@ struct Lane {
 #define LS(ln, r) ((ln).S[(r) * PF_BS])
 #define LC(ln, r, s) ((ln).C[((r) * 2 + (s)) * PF_BS])
 
-__device__ __forceinline__ double uni(Lane& ln) { return philox_uniform(ln.seed, ln.slot, 0, ln.ctr++); }
+__device__ __forceinline__ double uni(Lane& ln) { return philox_uniform(ln.seed, ln.slot, ln.stream, ln.ctr++); }
 
 __device__ __forceinline__ int epoch_of(const Lane& ln, double t) {
     int e = 0;

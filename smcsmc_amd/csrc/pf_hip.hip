@@ -175,6 +175,7 @@ __device__ __forceinline__ Lane make_lane(const KArgs& A, Smem& m, long long p) 
     ln.L = A.L; ln.mu = A.mu; ln.rho = A.rho;
     ln.seed = A.seed;
     ln.slot = (unsigned)p;
+    ln.stream = 0;
     ln.ctr = 0; ln.ebuf = 0; ln.Ltree = 0;
     return ln;
 }
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(PF_BS) void k_init(KArgs A, double initial_position
 
 // One genealogy update (SMC'): sample the recombination point, coalesce the floating lineage
 // against the old tree, re-attach.  Mirrors oracle Filter::genealogy_update step by step.
-__device__ __forceinline__ void genealogy_update(Lane& ln, double* h_out, double* tc_out) {
+__device__ __forceinline__ void genealogy_update(Lane& ln, double* h_out, double* tc_out, double* sp_out, bool* changed_out) {
     const int n = ln.n;
     double r = uni(ln) * ln.Ltree;
     double prev = 0.0, h = 0.0;
@@ -286,6 +287,8 @@ __device__ __forceinline__ void genealogy_update(Lane& ln, double* h_out, double
     int k = nslots + (has_root ? 1 : 0) + (has_stub ? 1 : 0);
     double u = uni(ln);
     int idx = min((int)(u * (double)k), k - 1);
+    *sp_out = Sp;
+    *changed_out = !(has_stub && idx == k - 1);
     if (idx < nslots) {
         lineages_at(ln, ni, tc, idx, &pr, &ps);
         insert_node(ln, ni, tc, b_id, pr, ps, troot);
@@ -420,8 +423,9 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
                 rec[0] = x_mark;
                 rec[1] = updated_to;
                 for (int r = 0; r < n - 1; ++r) rec[5 + r] = LS(ln, r);
-                double h, tc;
-                genealogy_update(ln, &h, &tc);
+                double h, tc, sp_removed;
+                bool changed;
+                genealogy_update(ln, &h, &tc, &sp_removed, &changed);
                 rec[2] = h;
                 rec[3] = tc;
                 rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n));
@@ -947,7 +951,7 @@ __global__ __launch_bounds__(PF_BS) void k_resample(KArgs A, long long s, int nb
         // a copy: draw a fresh recombination position from slot q's own stream (pc.cpp:357-368)
         Lane ln;
         ln.E = A.E; ln.n = n; ln.L = A.L; ln.mu = A.mu; ln.rho = A.rho; ln.seed = A.seed;
-        ln.slot = (unsigned)q; ln.ctr = A.rng_ctr[q]; ln.ebuf = A.ebuf[q]; ln.Ltree = Lt;
+        ln.slot = (unsigned)q; ln.stream = 0; ln.ctr = A.rng_ctr[q]; ln.ebuf = A.ebuf[q]; ln.Ltree = Lt;
         ln.S = nullptr; ln.C = nullptr; ln.T = nullptr; ln.I = nullptr; ln.RF = nullptr;
         nb = sample_next_base(ln, pos);
         A.rng_ctr[q] = ln.ctr;
@@ -976,6 +980,67 @@ __global__ __launch_bounds__(PF_BS) void k_partials(KArgs A) {
         A.chunk_sq[chunk] = sq;
         A.chunk_pil[chunk] = sc;
         A.chunk_pp[chunk] = scp;
+    }
+}
+
+// ------------------------------------------------------------------ k_calibrate
+// calculate_median_survival_distances (smcsmc.cpp:169-263): one prior ARG per lane; evolve it along
+// the sequence without data until every internal node of the initial tree has been removed (or
+// 0.6 L is reached) and report, per original node, its epoch and the position where it disappeared.
+__global__ __launch_bounds__(PF_BS) void k_calibrate(KArgs A, unsigned long long seed, long long rep0, long long nrep,
+                                                     int* out_epoch, double* out_dist) {
+    extern __shared__ double smem[];
+    Smem m = carve(smem, A.n, A.E);
+    load_model(A, m);
+    __syncthreads();
+    long long r = (long long)blockIdx.x * PF_BS + threadIdx.x;
+    if (r >= nrep) return;
+    const int n = A.n;
+    Lane ln = make_lane(A, m, rep0 + r);
+    ln.seed = seed;
+    ln.stream = 2;
+    ln.ebuf = -dlog(uni(ln));
+    int root = 0;
+    for (int i = 1; i < n; ++i) {
+        int ni = i - 1;
+        double tc = coalesce_up(ln, [&](int k) { return LS(ln, k); }, ni, i, 0.0);
+        int pr = -1, ps = 0;
+        int k = lineages_at(ln, ni, tc, -1, &pr, &ps);
+        bool above_root = (ni == 0) || (tc >= LS(ln, ni - 1));
+        int kk = above_root ? 1 : k;
+        double u = uni(ln);
+        int idx = min((int)(u * (double)kk), kk - 1);
+        if (above_root) insert_node(ln, ni, tc, i, -1, 0, root);
+        else { lineages_at(ln, ni, tc, idx, &pr, &ps); insert_node(ln, ni, tc, i, pr, ps, root); }
+        root = n + ni;
+    }
+    ln.Ltree = tree_length(ln, n);
+    // original internal-node heights live in the t0 scratch column of this lane
+    double* orig = m.t0 + threadIdx.x;
+    int alive = n - 1;
+    for (int j = 0; j < n - 1; ++j) {
+        orig[j * PF_BS] = LS(ln, j);
+        out_epoch[r * (n - 1) + j] = epoch_of(ln, LS(ln, j));
+        out_dist[r * (n - 1) + j] = -1.0;
+    }
+    unsigned alive_mask = (1u << (n - 1)) - 1u;
+    double next = sample_next_base(ln, 0.0);
+    const double stop = A.L * 0.6;
+    while (alive > 0 && next < stop) {
+        double x = next;
+        double h, tc, sp;
+        bool changed;
+        genealogy_update(ln, &h, &tc, &sp, &changed);
+        if (changed) {
+            for (int j = 0; j < n - 1; ++j)
+                if (((alive_mask >> j) & 1u) && orig[j * PF_BS] == sp) {
+                    out_dist[r * (n - 1) + j] = x;
+                    alive_mask &= ~(1u << j);
+                    --alive;
+                    break;
+                }
+        }
+        next = sample_next_base(ln, x);
     }
 }
 
@@ -1556,4 +1621,68 @@ int pf_test_systematic(const double* pilot, int64_t n, double u, int32_t* lo, in
     // the production kernel draws u from the resampler stream (seed 1, event 0); the caller
     // obtains the same u through pf_test_uniform(1, 0xFFFFFFFF, 1, 0, ...)
     return test_reduce_impl(pilot, n, nullptr, nullptr, u, lo, device);
+}
+
+// ------------------------------------------------------------------ lag calibration (host driver)
+// calculate_median_survival_distances (smcsmc.cpp:169-263).  The reference grows its sample one
+// tree at a time with a shared RNG; here trees are simulated in fixed batches of PF_CAL_BATCH
+// independent Philox streams until every epoch has min_events samples (or max_trees is reached),
+// then the same median / fallback rules are applied (smcsmc.cpp:235-262).
+#define PF_CAL_BATCH 16384
+
+int pf_median_survival(const pf_model* m, uint64_t seed, int32_t min_events, int64_t max_trees, double* median_out,
+                       int64_t* trees_used, int device) {
+    if (test_setup(device)) return -1;
+    if (m->n_pops != 1 || m->nsam < 2 || m->nsam > PF_NMAX || m->n_epochs < 1 || m->n_epochs > PF_EMAX) {
+        g_err = "pf_median_survival: unsupported model";
+        return -1;
+    }
+    const int E = m->n_epochs, n = m->nsam;
+    KArgs A;
+    memset(&A, 0, sizeof(A));
+    A.E = E; A.n = n; A.L = m->loci_length; A.mu = m->mutation_rate; A.rho = m->recombination_rate;
+    double *dT, *dI; int *dRF, *dep; double* ddist;
+    HIPCHK(hipMalloc(&dT, E * 8)); HIPCHK(hipMalloc(&dI, E * 8)); HIPCHK(hipMalloc(&dRF, E * 4));
+    HIPCHK(hipMalloc(&dep, (size_t)PF_CAL_BATCH * (n - 1) * 4)); HIPCHK(hipMalloc(&ddist, (size_t)PF_CAL_BATCH * (n - 1) * 8));
+    std::vector<double> inv2N(E);
+    for (int e = 0; e < E; ++e) inv2N[e] = 1.0 / (2.0 * m->pop_sizes[e]);
+    std::vector<int> rf(E, 3);
+    HIPCHK(hipMemcpy(dT, m->change_times, E * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dI, inv2N.data(), E * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dRF, rf.data(), E * 4, hipMemcpyHostToDevice));
+    A.T = dT; A.inv2N = dI; A.recflags = dRF;
+    std::vector<std::vector<double>> surv(E);
+    std::vector<int> hep((size_t)PF_CAL_BATCH * (n - 1));
+    std::vector<double> hdist((size_t)PF_CAL_BATCH * (n - 1));
+    long long trees = 0;
+    const size_t smem = smem_bytes(n, E);
+    for (;;) {
+        int not_done = 0;
+        for (int e = 0; e < E; ++e) not_done += (int)surv[e].size() < min_events;
+        if (not_done == 0 || trees >= max_trees) break;
+        hipLaunchKernelGGL(k_calibrate, dim3(PF_CAL_BATCH / PF_BS), dim3(PF_BS), smem, 0, A, (unsigned long long)seed, trees,
+                           (long long)PF_CAL_BATCH, dep, ddist);
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(hep.data(), dep, hep.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hdist.data(), ddist, hdist.size() * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < hep.size(); ++i)
+            if (hdist[i] >= 0) surv[hep[i]].push_back(hdist[i]);
+        trees += PF_CAL_BATCH;
+    }
+    hipFree(dT); hipFree(dI); hipFree(dRF); hipFree(dep); hipFree(ddist);
+    if (trees_used) *trees_used = trees;
+    // smcsmc.cpp:235-262
+    double earliest = -1;
+    for (int e = 0; e < E; ++e) {
+        std::sort(surv[e].begin(), surv[e].end());
+        int median_idx = ((int)surv[e].size() - 1) / 2;
+        if (median_idx < 10) median_out[e] = -1;
+        else {
+            median_out[e] = surv[e][median_idx];
+            if (earliest < 0) earliest = median_out[e];
+        }
+    }
+    for (int e = 0; e < E; ++e)
+        if (median_out[e] < 0) median_out[e] = e > 0 ? median_out[e - 1] : earliest;
+    return 0;
 }

@@ -54,7 +54,7 @@ EXPORTS = [
     "pf_update_segment", "pf_count", "pf_resample", "pf_run", "pf_finish", "pf_sync",
     "pf_num_segments_done", "pf_logl", "pf_get_counts", "pf_get_trace", "pf_get_resample_events",
     "pf_get_particles", "pf_get_kernel_time", "pf_set_timing", "pf_get_stats",
-    "pf_test_math", "pf_test_div", "pf_test_uniform", "pf_test_reduce", "pf_test_systematic",
+    "pf_median_survival", "pf_test_math", "pf_test_div", "pf_test_uniform", "pf_test_reduce", "pf_test_systematic",
 ]
 
 
@@ -93,6 +93,7 @@ def load_library(path=None):
     L.pf_get_kernel_time.argtypes = [vp, C.c_int, vp, vp]
     L.pf_set_timing.argtypes = [vp, C.c_int]
     L.pf_get_stats.argtypes = [vp, vp, vp, vp]
+    L.pf_median_survival.argtypes = [C.POINTER(_Model), C.c_uint64, C.c_int32, C.c_int64, vp, vp, C.c_int]
     L.pf_test_math.argtypes = [vp, C.c_int64, vp, vp, vp, C.c_int]
     L.pf_test_div.argtypes = [vp, vp, C.c_int64, vp, C.c_int]
     L.pf_test_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int64, vp, C.c_int]
@@ -240,6 +241,36 @@ class ParticleFilter:
         a = C.c_int64(); b = C.c_int64(); c = C.c_int64()
         self._chk(self.L.pf_get_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return {"records": a.value, "state_bytes_per_particle": b.value, "resamples": c.value}
+
+
+def _pack_model(m):
+    ct = np.ascontiguousarray(m["change_times"], dtype=np.float64)
+    E = len(ct)
+    ps = np.ascontiguousarray(m["pop_sizes"], dtype=np.float64).reshape(E)
+    rf = np.ascontiguousarray(m.get("record_flags", [3] * E), dtype=np.int32)
+    lags = np.ascontiguousarray(m.get("lags", np.zeros(E)), dtype=np.float64)
+    mod = _Model(E, 1, int(m["nsam"]), 0, float(m["loci_length"]), float(m["mutation_rate"]),
+                 float(m["recombination_rate"]), _dp(ct), _dp(ps), None, None, None,
+                 rf.ctypes.data_as(C.POINTER(C.c_int32)), _dp(lags))
+    return mod, (ct, ps, rf, lags)
+
+
+def median_survival(model, seed=1, min_events=200, max_trees=1000000, device=0):
+    """calculate_median_survival_distances (smcsmc.cpp:169-263) on the device; returns (medians[E], trees)."""
+    L = load_library()
+    mod, keep = _pack_model(model)
+    out = np.zeros(mod.n_epochs)
+    trees = C.c_int64()
+    if L.pf_median_survival(C.byref(mod), int(seed), int(min_events), int(max_trees), out.ctypes.data,
+                            C.byref(trees), int(device)) < 0:
+        raise PfError(_err(L))
+    return out, trees.value
+
+
+def calibrated_lags(model, lag_fraction=2.0, seed=1, device=0):
+    """CountModel::reset_lag (count.cpp:261-265) with the calibrated survival distances."""
+    med, _ = median_survival(model, seed=seed, device=device)
+    return med * lag_fraction
 
 
 # ---- unit-level device entry points (parity tests) ----

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.json from the reference's own Python front-end.
+
+Runs ONLY in the build container (needs /root/reference); the outputs are committed so the tests
+never touch the reference at run time.  The reference package's __init__ imports tskit (absent),
+so the stdlib-only modules that build the binary's command line are imported through a stub
+package object.
+
+  cmdlines.json  core_command_line() strings (populationmodels.py:406-437) for several model
+                 shapes together with the model tables they encode -- pins the binary's flag parser.
+  outfile.json   parse_outfile() (model.py:865-911) applied to .out text -- pins the .out contract.
+"""
+import json
+import os
+import sys
+import types
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_ref():
+    pkg = types.ModuleType("smcsmc")
+    pkg.__path__ = [os.path.join(REF, "smcsmc")]
+    sys.modules["smcsmc"] = pkg
+    import importlib
+    pm = importlib.import_module("smcsmc.populationmodels")
+    return pm
+
+
+def cmdlines(pm):
+    out = []
+    shapes = [
+        dict(name="const_1pop_2hap", kw=dict(num_samples=2, sequence_length=1e6)),
+        dict(name="const_6epochs", kw=dict(num_samples=4, sequence_length=1e7,
+                                            change_points=[0, 0.01, 0.25, 0.5, 1, 1.5],
+                                            population_sizes=[[1], [1], [1], [1], [1], [1]])),
+        dict(name="bottleneck", kw=dict(num_samples=4, sequence_length=1e6, N0=14312, mutation_rate=1.25e-8,
+                                        recombination_rate=3.5e-9, change_points=[0, 0.1, 0.5],
+                                        population_sizes=[[1.5], [0.3], [2.0]])),
+        dict(name="two_pop_im", kw=dict(num_samples=8, sequence_length=1e6, num_populations=2,
+                                        sample_populations=[1, 1, 1, 1, 2, 2, 2, 2],
+                                        change_points=[0, 0.1, 0.5],
+                                        population_sizes=[[1, 1], [2, 2], [2, 2]],
+                                        migration_rates=[[[0, 1], [1, 0]], [[0, 1], [1, 0]], [[0, 0], [0, 0]]],
+                                        migration_commands=[None, None, "-ej 0.5 2 1"])),
+    ]
+    for sh in shapes:
+        pop = pm.Population(**sh["kw"])
+        for vb in (False, True):
+            line = pop.core_command_line(vb=vb)
+            out.append(dict(name=sh["name"], vb=vb, cmdline=line, N0=pop.N0, mutation_rate=pop.mutation_rate,
+                            recombination_rate=pop.recombination_rate, sequence_length=pop.sequence_length,
+                            num_samples=pop.num_samples, num_populations=pop.num_populations,
+                            change_points=list(pop.change_points), population_sizes=pop.population_sizes,
+                            migration_rates=pop.migration_rates))
+    return out
+
+
+def outfile():
+    import importlib
+    model = importlib.import_module("smcsmc.model")
+    src = os.path.join(HERE, "sample.out")
+    s = model.Smcsmc.__new__(model.Smcsmc)
+    data = model.Smcsmc.parse_outfile(s, src)
+    rows = []
+    for (key, label), val in sorted(data.items(), key=lambda kv: (str(kv[0][0]), kv[0][1])):
+        rows.append(dict(type=key[0], epoch=key[1], frm=key[2], to=key[3], clump=key[4], label=label, value=val))
+    return rows
+
+
+if __name__ == "__main__":
+    pm = load_ref()
+    json.dump(cmdlines(pm), open(os.path.join(HERE, "cmdlines.json"), "w"), indent=1)
+    if os.path.exists(os.path.join(HERE, "sample.out")):
+        json.dump(outfile(), open(os.path.join(HERE, "outfile.json"), "w"), indent=1)
+    print("golden fixtures written")

@@ -69,6 +69,7 @@ def lib():
         for name in ("smco_exp", "smco_log", "smco_fastexp"):
             getattr(L, name).restype = C.c_double
             getattr(L, name).argtypes = [C.c_double]
+        L.smco_median_survival.argtypes = [C.POINTER(Model), C.c_uint64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
         L.smco_uniform.restype = C.c_double
         L.smco_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]
         L.smco_canon_sum.restype = C.c_double
@@ -202,3 +203,14 @@ def unpack_counts(out, E):
         "delayed_opp": out[6 * E], "delayed_count": out[6 * E + 1], "resample_count": out[6 * E + 2],
         "logl": out[6 * E + 3],
     }
+
+
+def median_survival(model, seed=1, min_events=200, max_trees=1000000):
+    L = lib()
+    inp = PackedInputs(dict(model, lags=model.get("lags", np.zeros(len(model["change_times"])))), None)
+    out = np.zeros(inp.E)
+    trees = C.c_int64()
+    if L.smco_median_survival(C.byref(inp.model), int(seed), int(min_events), int(max_trees), out.ctypes.data,
+                              C.byref(trees)) < 0:
+        raise RuntimeError(L.smco_last_error().decode())
+    return out, trees.value
