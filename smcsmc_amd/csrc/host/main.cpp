@@ -1,0 +1,195 @@
+// smcsmc_amd/csrc/host/main.cpp -- the drop-in `smcsmc` binary: main + pfARG_core
+// (/root/reference/src/smcsmc.cpp:46-103, 278-401) on top of the HIP C-ABI (include/smcsmc_pf.h).
+#include <zlib.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+
+#include "../../../include/smcsmc_pf.h"
+#include "smcsmc_host.hpp"
+
+using namespace std;
+
+static void dump_model_json(const PfParam& p) {
+    const HostModel& m = p.model;
+    cout << setprecision(17);
+    cout << "{\"N0\": " << m.N0 << ", \"nsam\": " << m.nsam << ", \"npop\": " << m.npop << ", \"loci_length\": " << m.loci_length
+         << ", \"mutation_rate\": " << m.mutation_rate << ", \"recombination_rate\": " << m.recombination_rate
+         << ", \"vb\": " << (m.vb ? "true" : "false") << ", \"seed\": " << m.seed << ", \"Np\": " << p.N
+         << ", \"change_times\": [";
+    for (size_t e = 0; e < m.change_times.size(); ++e) cout << (e ? ", " : "") << m.change_times[e];
+    cout << "], \"pop_sizes\": [";
+    for (size_t e = 0; e < m.pop_sizes.size(); ++e) {
+        cout << (e ? ", [" : "[");
+        for (size_t k = 0; k < m.pop_sizes[e].size(); ++k) cout << (k ? ", " : "") << m.pop_sizes[e][k];
+        cout << "]";
+    }
+    cout << "], \"mig_rates\": [";
+    for (size_t e = 0; e < m.mig_rates.size(); ++e) {
+        cout << (e ? ", [" : "[");
+        for (size_t k = 0; k < m.mig_rates[e].size(); ++k) cout << (k ? ", " : "") << m.mig_rates[e][k];
+        cout << "]";
+    }
+    cout << "], \"single_mig\": [";
+    for (size_t e = 0; e < m.single_mig.size(); ++e) {
+        cout << (e ? ", [" : "[");
+        for (size_t k = 0; k < m.single_mig[e].size(); ++k) cout << (k ? ", " : "") << m.single_mig[e][k];
+        cout << "]";
+    }
+    cout << "], \"sample_pops\": [";
+    for (size_t k = 0; k < m.sample_pops.size(); ++k) cout << (k ? ", " : "") << m.sample_pops[k];
+    cout << "], \"record_event_in_epoch\": [";
+    for (size_t k = 0; k < p.record_event_in_epoch.size(); ++k) cout << (k ? ", " : "") << p.record_event_in_epoch[k];
+    cout << "]}" << endl;
+}
+
+static void pf_check(int rc) {
+    if (rc < 0) throw std::runtime_error(pf_last_error());
+}
+
+// pfARG_core (smcsmc.cpp:278-401): one E-step over the chunk
+static void pfARG_core(PfParam& P) {
+    HostModel& M = P.model;
+    const int E = (int)M.change_times.size();
+    if (M.npop != 1) throw Unsupported("models with more than one population (this round implements the one-population path)");
+    int device = 0;
+    if (const char* d = getenv("SMCSMC_DEVICE")) device = atoi(d);
+
+    std::vector<double> pop_sizes(E);
+    for (int e = 0; e < E; ++e) pop_sizes[e] = M.pop_sizes[e][0];
+    pf_model pm;
+    memset(&pm, 0, sizeof(pm));
+    pm.n_epochs = E; pm.n_pops = 1; pm.nsam = M.nsam;
+    pm.flags = (P.ancestral_aware ? 1 : 0) | (P.dephase ? 2 : 0);
+    pm.loci_length = M.loci_length; pm.mutation_rate = M.mutation_rate; pm.recombination_rate = M.recombination_rate;
+    pm.change_times = M.change_times.data(); pm.pop_sizes = pop_sizes.data();
+    pm.record_flags = P.record_event_in_epoch.data();
+
+    // lags: CountModel::init_lags (count.cpp:230-247) then reset_lag with the calibrated survival (261-265)
+    std::vector<double> lags(E);
+    if (E == 1) lags[0] = 20000;
+    else
+        for (int e = 0; e < E; ++e) {
+            double top_t = e == E - 1 ? M.change_times[E - 1] : M.change_times[e + 1];
+            lags[e] = P.lag > 0 ? P.lag : 4.0 / (M.recombination_rate * top_t);
+        }
+    if (P.calibrate_lag) {
+        std::vector<double> med(E);
+        int64_t trees = 0;
+        pm.lags = lags.data();
+        pf_check(pf_median_survival(&pm, 1, 200, 1000000, med.data(), &trees, device));
+        for (int e = 0; e < E; ++e) {
+            clog << " Epoch " << e << ": survival distance " << med[e] << endl;
+            lags[e] = med[e] * P.lag_fraction;
+        }
+    }
+    pm.lags = lags.data();
+    clog << "    Lags set to:";
+    for (double l : lags) clog << " " << l;
+    clog << endl;
+    clog << " Starting position: " << fixed << setprecision(0) << P.start_position << setprecision(6) << scientific << endl;
+
+    std::vector<double> start, length;
+    std::vector<int8_t> state, alleles;
+    std::vector<int32_t> mre;
+    P.Segfile->pack(lags, start, length, state, alleles, mre);
+    pf_segments sg = {(int64_t)start.size(), start.data(), length.data(), state.data(), alleles.data(), mre.data()};
+
+    pf_params pp;
+    memset(&pp, 0, sizeof(pp));
+    pp.np = (int64_t)P.N; pp.ess_fraction = P.ESS_fraction; pp.seed = M.seed_set ? M.seed : (uint64_t)time(nullptr);
+    pp.max_trace_events = 0;
+    pf_handle* h = pf_create(&pm, &pp, device);
+    if (!h) throw std::runtime_error(pf_last_error());
+    try {
+        pf_check(pf_load_segments(h, &sg));
+        pf_check(pf_init_prior(h, start.empty() ? 0.0 : start[0]));
+        const int64_t S = sg.n;
+        const int64_t step = 1000;
+        for (int64_t s0 = 0; s0 < S; s0 += step) {
+            int64_t s1 = std::min(S, s0 + step);
+            pf_check(pf_run(h, s0, s1));
+            double end = start[s1 - 1] + length[s1 - 1];
+            cout << "\r Particle filtering " << setw(4) << int((end * 100) / M.loci_length) << "% completed." << flush;
+            if (end >= M.loci_length) break;
+        }
+        pf_check(pf_finish(h));
+        cout << "\r Particle filtering step 100% completed." << endl;
+        int64_t done = pf_num_segments_done(h);
+        std::vector<double> packed(PF_COUNTS_LEN(E));
+        pf_check(pf_get_counts(h, packed.data(), (int32_t)packed.size()));
+        clog << "Got to end of sequence; resampled " << (long long)packed[6 * E + 2] << " times" << endl;
+        clog << " Inference step completed." << endl;
+        if (P.record_resample_file) {
+            std::vector<double> ess(done);
+            std::vector<int32_t> flag(done);
+            pf_check(pf_get_trace(h, nullptr, ess.data(), flag.data(), nullptr, done));
+            for (int64_t s = 0; s < done; ++s)
+                if (flag[s]) P.append_resample_file(std::min(start[s] + length[s], M.loci_length), ess[s]);
+        }
+        // <prefix>.recomb.gz (smcsmc.cpp:376-383, count.cpp:616-654): the 100-bp local recombination map is not
+        // recorded by this build; an empty table with the reference's header keeps the file contract.
+        {
+            gzFile gz = gzopen(P.recombination_map_NAME.c_str(), "ab");
+            if (gz) {
+                std::ostringstream o;
+                if (P.EMcounter == 0) {
+                    o << "iter\tlocus\tsize\topp_per_nt";
+                    for (int s = 0; s < M.nsam; ++s) o << "\t" << s + 1;
+                    o << "\ttime\tlog_time\n";
+                }
+                gzwrite(gz, o.str().data(), (unsigned)o.str().size());
+                gzclose(gz);
+            }
+        }
+        // log_counts (count.cpp:66-158) with the prior pseudo-counts of init_coal_and_recomb (count.cpp:161-193)
+        const double* cc = &packed[0]; const double* co = &packed[E]; const double* cw = &packed[2 * E];
+        const double* rc = &packed[3 * E]; const double* ro = &packed[4 * E]; const double* rw = &packed[5 * E];
+        for (int e = 0; e < E; ++e)
+            P.appendToOutFile(P.EMcounter, e, M.change_times[e], e == E - 1 ? 1e+99 : M.change_times[e + 1], "Coal", 0, -1,
+                              co[e] + 1.0, cc[e] + 1.0 / (2.0 * pop_sizes[e]), cw[e] + 1.0);
+        double ropp = 0, rcount = 0, rweight = 0;
+        for (int e = 0; e < E; ++e) {
+            ropp += ro[e] + 1.0;
+            rcount += rc[e] + M.recombination_rate;
+            rweight += rw[e] + 1.0;
+        }
+        P.appendToOutFile(P.EMcounter, -1, 0.0, 1e+99, "Recomb", -1, -1, ropp, rcount, rweight);
+        double dopp = packed[6 * E + 0], dcount = packed[6 * E + 1], nres = packed[6 * E + 2], logl = packed[6 * E + 3];
+        P.appendToOutFile(P.EMcounter, -1, 0.0, 1e+99, "Delay", -1, -1, dopp, dcount / (double)P.N, dopp);
+        P.appendToOutFile(P.EMcounter, -1, 0.0, 1e+99, "Resamp", -1, -1, dopp, nres, dopp);
+        P.appendToOutFile(P.EMcounter, -1, 0, 1e+99, "LogL", -1, -1, 1.0, logl, 1.0);   // smcsmc.cpp:391
+        clog << " Estimated log likelihood: " << logl << endl;
+    } catch (...) {
+        pf_destroy(h);
+        throw;
+    }
+    pf_destroy(h);
+}
+
+int main(int argc, char* argv[]) {
+    try {
+        PfParam P;
+        P.parse(argc, argv);
+        if (P.version()) { P.printVersion(&std::cout); return EXIT_SUCCESS; }
+        if (P.help()) { P.printHelp(); return EXIT_SUCCESS; }
+        if (P.dump_model) { dump_model_json(P); return EXIT_SUCCESS; }
+        if (P.EM_steps > 0) throw Unsupported("-EM > 0 (the in-binary M-step; the Python front-end always passes -EM 0)");
+        P.outFileHeader();
+        for (int i = 0; i <= P.EM_steps; i++) {
+            clog << "EM step " << i << endl;
+            pfARG_core(P);
+            P.EMcounter++;
+            clog << "End of EM step " << i << endl;
+        }
+        return P.log();
+    } catch (const exception& e) {
+        std::cerr << "Error: " << e.what() << std::endl;   // smcsmc.cpp:99-102
+        return EXIT_FAILURE;
+    }
+}

@@ -1,0 +1,408 @@
+// smcsmc_amd/csrc/host/pfparam.cpp -- flag system, model tables, .out/.log writers of the drop-in binary.
+// Behaviour follows /root/reference/src/pfparam.cpp (line references inline); the scrm-style part of the
+// command line is parsed by HostModel (the scrm fork itself is not available): only the
+// flags the Python front-end emits (smcsmc/populationmodels.py:300-437) are understood.
+#include "smcsmc_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <map>
+#include <sstream>
+
+using namespace std;
+
+#ifndef SMCSMC_VERSION
+#define SMCSMC_VERSION "smcsmc_amd-0.1.0"
+#endif
+
+// ------------------------------------------------------------------ helpers
+static bool is_flag(const string& s) {
+    // a token starting with '-' followed by a letter is an option (negative numbers are operands)
+    return s.size() >= 2 && s[0] == '-' && (isalpha((unsigned char)s[1]) || s[1] == '@');
+}
+
+template <class T>
+static T convert(const string& flag, const string& arg) {
+    T value;
+    std::stringstream ss(arg);
+    ss >> value;
+    if (ss.fail() || !ss.eof()) throw WrongType(arg);
+    (void)flag;
+    return value;
+}
+
+// ------------------------------------------------------------------ HostModel
+namespace {
+struct Change {
+    std::vector<double> size;     // per pop, NaN = inherit
+    std::vector<double> mig;      // P*P per generation, NaN = inherit
+    std::vector<double> single;   // P*P
+};
+}  // namespace
+
+void HostModel::parse(const std::vector<std::string>& tok) {
+    // pass 1: population structure (-I) and -N0 must be known before rates are scaled
+    size_t i = 0;
+    double theta = -1, R = -1;
+    bool have_t = false, have_r = false;
+    for (size_t k = 0; k < tok.size(); ++k) {
+        if (tok[k] == "-I") {
+            if (k + 1 >= tok.size()) throw NotEnoughArg("-I");
+            npop = convert<int>("-I", tok[k + 1]);
+        }
+    }
+    const int P = npop;
+    std::map<double, Change> changes;
+    auto at = [&](double t_gen) -> Change& {
+        Change& c = changes[t_gen];
+        if (c.size.empty()) {
+            c.size.assign(P, NAN);
+            c.mig.assign((size_t)P * P, NAN);
+            c.single.assign((size_t)P * P, 0.0);
+        }
+        return c;
+    };
+    at(0.0);
+    auto need = [&](const string& flag, size_t k) {
+        if (i + k >= tok.size()) throw NotEnoughArg(flag);
+    };
+    auto operand_follows = [&]() { return i + 1 < tok.size() && !is_flag(tok[i + 1]); };
+    sample_pops.assign(nsam, 0);
+    while (i < tok.size()) {
+        const string f = tok[i];
+        if (f == "-N0") {
+            need(f, 1); N0 = convert<double>(f, tok[++i]);
+        } else if (f == "-t") {
+            need(f, 1); theta = convert<double>(f, tok[++i]); have_t = true;
+        } else if (f == "-r") {
+            need(f, 2); R = convert<double>(f, tok[++i]); loci_length = convert<double>(f, tok[++i]); have_r = true;
+        } else if (f == "-I") {
+            need(f, 1 + (size_t)P); ++i;
+            int idx = 0, total = 0;
+            for (int p = 0; p < P; ++p) {
+                int c = convert<int>(f, tok[++i]);
+                total += c;
+                for (int k = 0; k < c && idx < nsam; ++k) sample_pops[idx++] = p;
+            }
+            if (total != nsam) throw InvalidInput("Sample sizes in -I do not add up to -nsam");
+            if (operand_follows()) {   // optional symmetric migration rate
+                double M = convert<double>(f, tok[++i]);
+                Change& c = at(0.0);
+                for (int a = 0; a < P; ++a)
+                    for (int b = 0; b < P; ++b)
+                        if (a != b) c.mig[(size_t)a * P + b] = M / (P - 1) / (4 * N0);
+            }
+        } else if (f == "-eN") {
+            need(f, 2); double t = convert<double>(f, tok[++i]) * 4 * N0; double x = convert<double>(f, tok[++i]);
+            if (vb) { need(f, 1); ++i; }
+            Change& c = at(t);
+            for (int p = 0; p < P; ++p) c.size[p] = x * N0;
+        } else if (f == "-en") {
+            need(f, 3); double t = convert<double>(f, tok[++i]) * 4 * N0; int p = convert<int>(f, tok[++i]);
+            double x = convert<double>(f, tok[++i]);
+            if (vb) { need(f, 1); ++i; }
+            if (p < 1 || p > P) throw InvalidInput("Population index out of range in -en");
+            at(t).size[p - 1] = x * N0;
+        } else if (f == "-eM") {
+            need(f, 2); double t = convert<double>(f, tok[++i]) * 4 * N0; double M = convert<double>(f, tok[++i]);
+            if (vb) { need(f, 1); ++i; }
+            Change& c = at(t);
+            for (int a = 0; a < P; ++a)
+                for (int b = 0; b < P; ++b)
+                    if (a != b) c.mig[(size_t)a * P + b] = (P > 1 ? M / (P - 1) : 0.0) / (4 * N0);
+        } else if (f == "-em") {
+            need(f, 4); double t = convert<double>(f, tok[++i]) * 4 * N0; int a = convert<int>(f, tok[++i]);
+            int b = convert<int>(f, tok[++i]); double M = convert<double>(f, tok[++i]);
+            if (vb) { need(f, 1); ++i; }
+            if (a < 1 || a > P || b < 1 || b > P) throw InvalidInput("Population index out of range in -em");
+            at(t).mig[(size_t)(a - 1) * P + (b - 1)] = M / (4 * N0);
+        } else if (f == "-ema") {
+            need(f, 1 + (size_t)P * P * (vb ? 2 : 1)); double t = convert<double>(f, tok[++i]) * 4 * N0;
+            Change& c = at(t);
+            for (int a = 0; a < P; ++a)
+                for (int b = 0; b < P; ++b) {
+                    const string& v = tok[++i];
+                    if (vb) ++i;
+                    if (a != b) c.mig[(size_t)a * P + b] = (v == "x" ? 0.0 : convert<double>(f, v)) / (4 * N0);
+                }
+        } else if (f == "-ej") {
+            need(f, 3); double t = convert<double>(f, tok[++i]) * 4 * N0; int a = convert<int>(f, tok[++i]);
+            int b = convert<int>(f, tok[++i]);
+            if (a < 1 || a > P || b < 1 || b > P) throw InvalidInput("Population index out of range in -ej");
+            Change& c = at(t);
+            c.single[(size_t)(a - 1) * P + (b - 1)] = 1.0;
+            for (int k = 0; k < P; ++k) if (k != a - 1) c.mig[(size_t)(a - 1) * P + k] = 0.0;
+        } else if (f == "-seed") {
+            need(f, 1);
+            uint64_t sd = 0; int k = 0;
+            while (k < 3 && operand_follows()) { sd = sd * 1000003ULL + (uint64_t)convert<long long>(f, tok[++i]); ++k; }
+            if (k == 0) throw NotEnoughArg(f);
+            seed = sd; seed_set = true;
+        } else if (f == "-l") {
+            need(f, 1); string v = tok[++i];
+            if (!v.empty() && v.back() == 'r') throw Unsupported("-l <n>r (recombination-count window)");
+            window_length_seq = convert<double>(f, v);
+            if (window_length_seq != 0) throw Unsupported("-l " + v + " (only the SMC' window -l 0 is implemented)");
+        } else if (f == "-vb") {
+            vb = true;
+        } else if (f == "-bias_heights") {
+            while (operand_follows()) bias_heights.push_back(convert<double>(f, tok[++i]));
+        } else if (f == "-bias_strengths") {
+            while (operand_follows()) bias_strengths.push_back(convert<double>(f, tok[++i]));
+        } else if (f == "-eI") {
+            throw Unsupported("-eI (ancient samples)");
+        } else {
+            throw UnknowArg(f);
+        }
+        ++i;
+    }
+    if (!have_r) throw std::invalid_argument("The option -r is required");     // pfparam.cpp:266-270
+    if (!have_t) throw std::invalid_argument("The option -t is required");     // pfparam.cpp:258-263
+    // Model::setMutationRate / setRecombinationRate (scrm): scaled by 4*N0, per locus
+    mutation_rate = theta / (4 * N0) / loci_length;
+    if (loci_length <= 1) throw InvalidInput("Locus length must be larger than 1");
+    recombination_rate = R / (4 * N0) / (loci_length - 1);
+    // Model::finalize: fill unset values forward in time
+    change_times.clear(); pop_sizes.clear(); mig_rates.clear(); single_mig.clear();
+    std::vector<double> cur_size(P, N0), cur_mig((size_t)P * P, 0.0);
+    for (auto& kv : changes) {
+        Change& c = kv.second;
+        for (int p = 0; p < P; ++p) if (!std::isnan(c.size[p])) cur_size[p] = c.size[p];
+        for (size_t k = 0; k < c.mig.size(); ++k) if (!std::isnan(c.mig[k])) cur_mig[k] = c.mig[k];
+        change_times.push_back(kv.first);
+        pop_sizes.push_back(cur_size);
+        mig_rates.push_back(cur_mig);
+        single_mig.push_back(c.single);
+    }
+}
+
+void HostModel::finalize() {}
+
+// ------------------------------------------------------------------ PfParam (pfparam.cpp:51-180)
+void PfParam::parse(int argc, char* argv[]) {
+    std::vector<std::string> argv_(argv + 1, argv + argc);
+    if (argv_.empty()) { help_ = true; return; }
+    cmdline = argv[0];
+    for (int i = 1; i < argc; ++i) cmdline += std::string(" ") + argv[i];
+    default_num_mut = 1e-8 * 40000 * default_loci_length;   // pfparam.cpp:195-198
+    size_t i = 0;
+    auto next = [&](const string& flag) -> const string& {
+        if (i + 1 >= argv_.size()) throw NotEnoughArg(flag);
+        return argv_[++i];
+    };
+    auto read_range = [&](const string& flag, int& last) -> int {   // pfparam.hpp readRange: "a" or "a-b"
+        const string& v = next(flag);
+        size_t dash = v.find('-', 1);
+        int first;
+        if (dash == string::npos) { first = convert<int>(flag, v); last = first; }
+        else { first = convert<int>(flag, v.substr(0, dash)); last = convert<int>(flag, v.substr(dash + 1)); }
+        return first;
+    };
+    for (; i < argv_.size(); ++i) {
+        const string a = argv_[i];
+        if (a == "-Np") N = convert<size_t>(a, next(a));
+        else if (a == "-nsam") default_nsam = convert<size_t>(a, next(a));
+        else if (a == "-ESS") {
+            const string& v = next(a);
+            ESS_fraction = convert<double>(a, v);
+            ESS_default_bool = false;
+            if (ESS_fraction > 1.0 || ESS_fraction < 0.0) throw OutOfRange("-ESS", v);
+        } else if (a == "-arg") record_trees = true;
+        else if (a == "-EM") EM_steps = convert<int>(a, next(a));
+        else if (a == "-xr" || a == "-xc") {
+            int last_epoch;
+            int first_epoch = read_range(a, last_epoch);
+            last_epoch++;
+            for (int e = 0; e < last_epoch; e++) {
+                if ((int)record_event_in_epoch.size() <= e)
+                    record_event_in_epoch.push_back(RECORD_COALMIGR_EVENT | RECORD_RECOMB_EVENT);
+                if (e >= first_epoch) {
+                    if (a == "-xc") record_event_in_epoch[e] &= ~RECORD_COALMIGR_EVENT;
+                    else record_event_in_epoch[e] &= ~RECORD_RECOMB_EVENT;
+                }
+            }
+        } else if (a == "-cap") { Ne_cap = convert<double>(a, next(a)); useCap = true; }
+        else if (a == "-tmax") top_t = convert<double>(a, next(a));
+        else if (a == "-p") pattern = next(a);
+        else if (a == "-seg") input_SegmentDataFileName = next(a);
+        else if (a == "-guide") input_RecombinationBiasFileName = next(a);
+        else if (a == "-startpos") {
+            const string& v = next(a);
+            start_position = convert<double>(a, v);
+            if (start_position < 1) throw OutOfRange("-startpos", v);
+        } else if (a == "-lag") { lag = convert<double>(a, next(a)); calibrate_lag = false; }
+        else if (a == "-calibrate_lag") {
+            const string& v = next(a);
+            calibrate_lag = true;
+            lag_fraction = convert<double>(a, v);
+            if (lag_fraction < 0.0) throw OutOfRange("-calibrate_lag", v);
+        } else if (a == "-delay") {
+            const string& v = next(a);
+            delay = convert<double>(a, v);
+            if (delay < 0.0) throw OutOfRange("-delay", v);
+        } else if (a == "-delay_coal" || a == "-delay_migr") { /* only meaningful with biased sampling */ }
+        else if (a == "-ancestral_aware") ancestral_aware = true;
+        else if (a == "-dephase") dephase = true;
+        else if (a == "-apf") {
+            const string& v = next(a);
+            auxiliary_particle_filter = convert<int>(a, v);
+            if (auxiliary_particle_filter < 0 || auxiliary_particle_filter > 4) throw OutOfRange("-apf", v);
+        } else if (a == "-o") out_NAME_prefix = next(a);
+        else if (a == "-log") log_bool = true;
+        else if (a == "-record_ess") record_resample_file = true;
+        else if (a == "-dumpmodel") dump_model = true;      // not a reference flag: prints the parsed tables as JSON
+        else if (a == "-h" || a == "-help") help_ = true;
+        else if (a == "-v" || a == "-version") version_ = true;
+        else { scrm_tokens.push_back(a); scrm_input += a + " "; }
+    }
+    if (help_ || version_) return;
+    finalize();
+    clog << "Command line:-" << endl << cmdline << endl;
+}
+
+// pfparam.cpp:321-380
+void PfParam::finalize() {
+    ESSthreshold = N * ESS_fraction;
+    outFileName = out_NAME_prefix + ".out";
+    log_NAME = out_NAME_prefix + ".log";
+    recombination_map_NAME = out_NAME_prefix + ".recomb.gz";
+    resample_NAME = out_NAME_prefix + ".resample";
+    if (!input_RecombinationBiasFileName.empty() && auxiliary_particle_filter > 0)
+        throw std::invalid_argument("Recombination guiding and auxiliary particle filters cannot currently be used together");
+    if (!dump_model) {
+        remove(outFileName.c_str());
+        remove(log_NAME.c_str());
+        remove(recombination_map_NAME.c_str());
+        if (record_resample_file) remove(resample_NAME.c_str());
+    }
+    if (!pattern.empty()) throw Unsupported("-p (the Python front-end generates epochs itself)");
+    if (!input_RecombinationBiasFileName.empty()) throw Unsupported("-guide");
+    if (auxiliary_particle_filter > 0) throw Unsupported("-apf > 0");
+    model.nsam = (int)default_nsam;
+    model.parse(scrm_tokens);
+    default_loci_length = model.loci_length;
+    if (model.change_times.back() >= top_t * 40000)
+        throw std::invalid_argument("Problem: -tmax must be larger than bottom of final epoch");
+    if (!model.bias_heights.empty() || !model.bias_strengths.empty())
+        throw Unsupported("-bias_heights / -bias_strengths (focused sampling)");
+    while (record_event_in_epoch.size() < model.change_times.size())
+        record_event_in_epoch.push_back(RECORD_COALMIGR_EVENT | RECORD_RECOMB_EVENT);
+    if (record_event_in_epoch.size() > model.change_times.size())
+        throw OutOfEpochRange(to_string(record_event_in_epoch.size() - 1), to_string(model.change_times.size() - 1));
+    int max_seg_len = (int)(max_segment_length_factor / (model.recombination_rate * 4 * model.N0));
+    if (!dump_model)
+        Segfile = new Segment(input_SegmentDataFileName, default_nsam, model.loci_length, default_num_mut,
+                              (long long)start_position, max_seg_len);
+}
+
+// ------------------------------------------------------------------ writers
+std::string format_double(double d, double scientific_bound, int precision) {   // pfparam.cpp:482-497
+    const int field_length = 14;
+    const double maxdouble = exp((field_length - precision - 1) * log(10.0));
+    std::ostringstream o;
+    if (d < maxdouble && (d > scientific_bound || d == 0.0)) o << setw(field_length) << fixed << setprecision(precision) << d;
+    else o << setw(field_length) << scientific << setprecision(field_length - 7) << d;
+    return o.str();
+}
+
+void PfParam::outFileHeader() {   // pfparam.cpp:459-479
+    ofstream f(outFileName.c_str(), ios::binary);
+    const int f1 = 6, f2 = 14;
+    f << setw(f1) << "Iter" << " " << setw(f1) << "Epoch" << " " << setw(f2) << "Start" << " " << setw(f2) << "End" << " "
+      << setw(f1) << "Type" << " " << setw(f1) << "From" << " " << setw(f1) << "To" << " " << setw(f2) << "Opp" << " "
+      << setw(f2) << "Count" << " " << setw(f2) << "Rate" << " " << setw(f2) << "Ne" << " " << setw(f2) << "ESS" << endl;
+}
+
+void PfParam::appendToOutFile(size_t EMstep, int epoch, double epochBegin, double epochEnd, string eventType, int from_pop,
+                              int to_pop, double opportunity, double count, double weight) {   // pfparam.cpp:500-527
+    ofstream f(outFileName.c_str(), ios::out | ios::app | ios::binary);
+    const int f1 = 6;
+    f << setw(f1) << EMstep << " " << setw(f1) << epoch << " " << format_double(epochBegin) << " " << format_double(epochEnd) << " "
+      << setw(f1) << eventType << " " << setw(f1) << from_pop << " " << setw(f1) << to_pop << " " << format_double(opportunity)
+      << " " << format_double(count) << " " << format_double(count / (opportunity + 1e-10)) << " "
+      << format_double((eventType == "Coal") ? (opportunity + 1e-10) / (2.0 * count) : 0.0) << " "
+      << format_double(1.0 / (weight / opportunity + 1e-10), 1.0, 3) << endl;
+}
+
+void PfParam::append_resample_file(double position, double ESS) const {   // pfparam.cpp:530-538
+    if (!record_resample_file) return;
+    ofstream f(resample_NAME.c_str(), ios::out | ios::app | ios::binary);
+    f << (int)position << "\t" << ESS << endl;
+}
+
+void PfParam::printVersion(std::ostream* o) {   // pfparam.cpp:588-592
+    (*o) << "Program was compiled on: " << __DATE__ << endl;
+    (*o) << "smcsmc version: " << SMCSMC_VERSION << endl;
+    (*o) << "scrm version:   " << "none(hip-native-smc-prime)" << endl;
+}
+
+void PfParam::printHelp() {   // pfparam.cpp:541-585
+    cout << "smcsmc (MI355X build) -- particle filter for demographic inference -- Version " << SMCSMC_VERSION << endl;
+    cout << "Options:" << endl;
+    auto opt = [](const char* f, const char* t, const string& d) {
+        cout << setw(15) << f << setw(8) << t << "  --  " << d << endl;
+    };
+    opt("-Np", "INT", "Number of particles [ 100 ]");
+    opt("-seg", "STR", "Data file in seg format [ Chrom1.seg ]");
+    opt("-o", "STR", "Prefix for output files");
+    opt("-EM", "INT", "EM iterations [ 0 ] (only 0 is supported: the front-end drives EM)");
+    opt("-startpos", "INT", "First nucleotide position to analyze [ 1 ]");
+    opt("-apf", "INT", "Use auxiliary particle filter [ 0 ] (only 0 is supported in this build)");
+    opt("-log", " ", "Generate *.log file");
+    opt("-v", " ", "Display timestamp and versions");
+    cout << endl << "Inference tuning:" << endl;
+    opt("-dephase", " ", "Dephase heterozygous sites [ false ]");
+    opt("-calibrate_lag", "FLT", "Lag before extracting events (multiple of survival time) [ 2 ]");
+    opt("-lag", "FLT", "Constant lag (bp); disables calibration");
+    opt("-tmax", "FLT", "Maximum tree height, in unit of 4N0 [ 2 ]");
+    opt("-ESS", "FLT", "Fractional ESS threshold for resampling [ 0.5 ]");
+    opt("-xr", "INT", "Epoch or epoch range to exclude from recombination EM (0-based, closed)");
+    opt("-xc", "INT", "Epoch or epoch range (e.g. 0-10) to exclude from coalescent/migration EM");
+    opt("-ancestral_aware", " ", "Ancestral allele is 0");
+    opt("-record_ess", " ", "Generate *.resample file");
+    cout << endl << "Model (scrm-style): -N0 -t -r -I -eN -en -eM -ema -ej -seed -l 0 -vb" << endl;
+}
+
+void PfParam::writeLog(ostream* w) {   // pfparam.cpp:403-456
+    (*w) << "###########################\n";
+    (*w) << "#        smcsmc log       #\n";
+    (*w) << "###########################\n";
+    printVersion(w);
+    (*w) << "smcsmc parameters: \n";
+    (*w) << "Segment Data file: " << (input_SegmentDataFileName.empty() ? "empty" : input_SegmentDataFileName.c_str()) << "\n";
+    (*w) << "Recombination bias file: " << (input_RecombinationBiasFileName.empty() ? "None" : input_RecombinationBiasFileName.c_str()) << "\n";
+    (*w) << setw(15) << " EM steps =" << setw(10) << EM_steps << "\n";
+    if (lag > 0) (*w) << setw(15) << "Constant lag =" << setw(10) << lag << "\n";
+    (*w) << setw(15) << "N =" << setw(10) << N << "\n";
+    (*w) << setw(15) << "ESS =" << setw(10) << ESS_fraction;
+    if (ESS_default_bool) (*w) << " (by default)";
+    (*w) << "\n";
+    (*w) << "scrm model parameters: \n";
+    (*w) << setw(17) << "Extract window =" << setw(10) << model.window_length_seq << "\n";
+    (*w) << setw(17) << "Sample size =" << setw(10) << model.nsam << "\n";
+    (*w) << setw(17) << "Seq length =" << setw(10) << model.loci_length << "\n";
+    (*w) << setw(17) << "mutation rate =" << setw(10) << model.mutation_rate << "\n";
+    (*w) << setw(17) << "recomb rate =" << setw(10) << model.recombination_rate << "\n";
+    (*w) << setw(17) << "Pop size (at Generation):\n";
+    for (size_t e = 0; e < model.change_times.size(); e++) {
+        (*w) << setw(3) << "(" << setw(8) << model.change_times[e] << " )";
+        for (int p = 0; p < model.npop; p++) (*w) << " | " << setw(10) << model.pop_sizes[e][p];
+        (*w) << "\n";
+    }
+    (*w) << "Out file is saved in file: " << outFileName << "\n";
+}
+
+int PfParam::log() {   // pfparam.cpp:392-400
+    if (log_bool) {
+        ofstream f(log_NAME.c_str(), ios::out | ios::app | ios::binary);
+        writeLog(&f);
+    }
+    writeLog(&std::cout);
+    return 0;
+}

@@ -1,0 +1,180 @@
+// smcsmc_amd/csrc/host/smcsmc_host.hpp -- host side of the drop-in `smcsmc` binary.
+//
+// Mirrors the reference's driver layer (paths relative to /root/reference/src):
+//   PfParam        pfparam.hpp:225-446, pfparam.cpp   (flag system, .out/.log writers)
+//   HostModel      the part of the scrm fork's Param/Model that the front-end exercises
+//                  (flags emitted by smcsmc/populationmodels.py:300-437)
+//   Segment        segdata.hpp:86-177, segdata.cpp    (.seg reader)
+// The compute path is the C-ABI of include/smcsmc_pf.h (HIP, gfx950); nothing here computes
+// particle-filter results on the CPU.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+// ---- exception taxonomy (exception.hpp:32-51, pfparam.hpp:42-93, segdata.hpp:41-81) ----
+struct InvalidInput : public std::exception {
+    std::string src, reason, throwMsg;
+    InvalidInput() : InvalidInput("") {}
+    explicit InvalidInput(std::string s) : src("\033[1;31m" + s + "\033[0m"), reason(""), throwMsg(s) {}
+    ~InvalidInput() throw() override {}
+    const char* what() const noexcept override { return throwMsg.c_str(); }
+};
+struct NotEnoughArg : InvalidInput {
+    explicit NotEnoughArg(std::string s) : InvalidInput(s) { reason = "Not enough parameters when parsing option: "; throwMsg = reason + src; }
+};
+struct UnknowArg : InvalidInput {
+    explicit UnknowArg(std::string s) : InvalidInput(s) { reason = "Unknow option: "; throwMsg = reason + src; }
+};
+struct OutOfEpochRange : InvalidInput {
+    OutOfEpochRange(std::string a, std::string b) : InvalidInput(a) {
+        reason = "Problem: epochs specified in -xr/-xc options out of range: ";
+        src = "\033[1;31m" + a + std::string(" is greater than ") + b + "\033[0m";
+        throwMsg = reason + src;
+    }
+};
+struct OutOfRange : InvalidInput {
+    OutOfRange(std::string a, std::string b) : InvalidInput(a) {
+        reason = "Flag \"";
+        throwMsg = reason + src + std::string(" ") + b + std::string("\" out of range [0, 1].");
+    }
+};
+struct WrongType : InvalidInput {
+    explicit WrongType(std::string s) : InvalidInput(s) { reason = "Wrong type for parsing: "; throwMsg = reason + src; }
+};
+struct InvalidSeg : InvalidInput {
+    explicit InvalidSeg(std::string s) : InvalidInput(s) {}
+};
+struct InvalidInputFile : InvalidSeg {
+    explicit InvalidInputFile(std::string s) : InvalidSeg(s) { reason = "Invalid input file: "; throwMsg = reason + src; }
+};
+struct WrongNumberOfEntry : InvalidSeg {
+    explicit WrongNumberOfEntry(std::string s) : InvalidSeg(s) { reason = "Number of variant site is wrong: "; throwMsg = reason + src; }
+};
+struct InvalidSegmentStartPosition : InvalidSeg {
+    InvalidSegmentStartPosition(std::string a, std::string b) : InvalidSeg(a) {
+        reason = "Segment start position at:";
+        throwMsg = reason + src + std::string(" expect ") + b;
+    }
+};
+struct NoDataError : InvalidSeg {
+    NoDataError(std::string s, long long a, long long b) : InvalidSeg(s) {
+        reason = "No data found in file ";
+        throwMsg = reason + s + " between positions " + std::to_string(a) + " and " + std::to_string(b);
+    }
+};
+struct Unsupported : InvalidInput {
+    explicit Unsupported(std::string s) : InvalidInput(s) { throwMsg = "Not supported by this build: " + s; }
+};
+
+// ---- the model tables handed to the device (what scrm's Model holds after Param::parse) ----
+struct HostModel {
+    double N0 = 10000;               // default_pop_size (-N0)
+    int nsam = 2;
+    int npop = 1;
+    double loci_length = 2e7;
+    double mutation_rate = 0;        // per bp per generation
+    double recombination_rate = 0;   // per bp per generation
+    std::vector<double> change_times;            // generations
+    std::vector<std::vector<double>> pop_sizes;  // [E][P]
+    std::vector<std::vector<double>> mig_rates;  // [E][P*P] per generation
+    std::vector<std::vector<double>> single_mig; // [E][P*P]
+    std::vector<int> sample_pops;
+    std::vector<double> bias_heights, bias_strengths;
+    bool vb = false;
+    uint64_t seed = 0;
+    bool seed_set = false;
+    double window_length_seq = 0;
+    void parse(const std::vector<std::string>& tokens);   // tokens after "nsam nloci"
+    void finalize();
+};
+
+enum Segment_State { SEGMENT_INVARIANT, SEGMENT_MISSING, SEGMENT_INVARIANT_PARTIAL };   // segdata.hpp:84
+
+struct SegDatum {
+    long long segment_start, segment_length;
+    Segment_State segment_state;
+    std::vector<int> allele_state;
+    bool all_alleles_missing() const {
+        for (int a : allele_state) if (a != -1) return false;
+        return true;
+    }
+};
+
+class Segment {   // segdata.hpp:86-177
+  public:
+    Segment(std::string file_name, size_t nsam, double seqlen, double num_of_mut, long long data_start = 1,
+            double max_segment_length = 1e99);
+    bool empty_file() const { return empty_file_; }
+    const std::vector<SegDatum>& buffer() const { return buffer_; }
+    // arrays for pf_load_segments (coordinates relative to data_start; read_new_line semantics)
+    void pack(const std::vector<double>& lags, std::vector<double>& start, std::vector<double>& length,
+              std::vector<int8_t>& state, std::vector<int8_t>& alleles, std::vector<int32_t>& max_record_epoch) const;
+  private:
+    void prepare();
+    std::vector<int> extract_field_VARIANT(const std::string& field);
+    std::string file_name_;
+    size_t nsam_;
+    long long data_start_;
+    double seqlen_, max_segment_length_;
+    bool empty_file_ = false;
+    double num_of_expected_mutations_ = 0;
+    int number_of_fields_ = -1;
+    std::vector<SegDatum> buffer_;
+};
+
+int max_epoch_to_update(const std::vector<double>& lags, double distance_to_mutation);   // smcsmc.cpp:266-275
+
+class PfParam {   // pfparam.hpp:225-446
+  public:
+    static const int RECORD_RECOMB_EVENT = 1;
+    static const int RECORD_COALMIGR_EVENT = 2;
+    void parse(int argc, char* argv[]);
+    bool help() const { return help_; }
+    bool version() const { return version_; }
+    void printHelp();
+    void printVersion(std::ostream* out);
+    void outFileHeader();
+    void appendToOutFile(size_t EMstep, int epoch, double epochBegin, double epochEnd, std::string eventType, int from_pop,
+                         int to_pop, double opportunity, double count, double weight);
+    void append_resample_file(double position, double ESS) const;
+    int log();
+    void writeLog(std::ostream* out);
+
+    size_t N = 100;
+    int EM_steps = 0;
+    double ESS_fraction = 0.5;
+    bool ESS_default_bool = true;
+    double ESSthreshold = 50;
+    double lag = 0;
+    bool calibrate_lag = true;
+    double lag_fraction = 2.0;
+    double delay = 0.5;
+    bool ancestral_aware = false, dephase = false;
+    int auxiliary_particle_filter = 0;
+    double start_position = 1;
+    double top_t = 2;
+    bool useCap = false;
+    double Ne_cap = 200000;
+    bool log_bool = true, record_resample_file = false, record_trees = false, dump_model = false;
+    size_t default_nsam = 2;
+    double default_loci_length = 2e7;
+    double default_num_mut = 0;
+    double max_segment_length_factor = 2.0;
+    std::string out_NAME_prefix = "smcsmc", input_SegmentDataFileName, input_RecombinationBiasFileName, pattern;
+    std::string outFileName, log_NAME, recombination_map_NAME, resample_NAME;
+    std::vector<int> record_event_in_epoch;
+    std::vector<std::string> scrm_tokens;
+    std::string scrm_input;
+    HostModel model;
+    Segment* Segfile = nullptr;
+    size_t EMcounter = 0;
+    std::string cmdline;
+
+  private:
+    void finalize();
+    bool help_ = false, version_ = false;
+};
+
+std::string format_double(double d, double scientific_bound = 0.1, int precision = 2);   // pfparam.cpp:482-497

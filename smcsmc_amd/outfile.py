@@ -1,0 +1,79 @@
+"""The `.out` count table: writer mirroring PfParam::outFileHeader / appendToOutFile / FormatDouble
+(/root/reference/src/pfparam.cpp:459-527) and CountModel::log_counts (count.cpp:66-158, prior
+pseudo-counts count.cpp:161-227), plus a reader equivalent to the front-end's parse_outfile
+(/root/reference/smcsmc/model.py:865-911) used to check the contract."""
+import math
+from collections import defaultdict
+
+
+def format_double(d, scientific_bound=0.1, precision=2):
+    """pfparam.cpp:482-497: fixed with `precision` decimals when scientific_bound < d < 10^(14-precision-1)
+    or d == 0, otherwise scientific with 7 decimals; always right-aligned in 14 columns."""
+    field_length = 14
+    maxdouble = math.exp((field_length - precision - 1) * math.log(10.0))
+    if d < maxdouble and (d > scientific_bound or d == 0.0):
+        return "%*.*f" % (field_length, precision, d)
+    return "%*.*e" % (field_length, field_length - 7, d)
+
+
+HEADER = ("%6s %6s %14s %14s %6s %6s %6s %14s %14s %14s %14s %14s\n"
+          % ("Iter", "Epoch", "Start", "End", "Type", "From", "To", "Opp", "Count", "Rate", "Ne", "ESS"))
+
+
+def format_row(em_step, epoch, begin, end, event_type, from_pop, to_pop, opportunity, count, weight):
+    ne = (opportunity + 1e-10) / (2.0 * count) if event_type == "Coal" else 0.0
+    return ("%6d %6d %s %s %6s %6d %6d %s %s %s %s %s\n"
+            % (em_step, epoch, format_double(begin), format_double(end), event_type, from_pop, to_pop,
+               format_double(opportunity), format_double(count), format_double(count / (opportunity + 1e-10)),
+               format_double(ne), format_double(1.0 / (weight / opportunity + 1e-10), 1.0, 3)))
+
+
+def outfile_text(model, counts, np_particles, em_step=0):
+    """The whole .out file for a one-population model from the packed counts of ParticleFilter.counts()."""
+    ct = list(model["change_times"])
+    ps = list(model["pop_sizes"])
+    E = len(ct)
+    rho = model["recombination_rate"]
+    out = [HEADER]
+    for e in range(E):
+        out.append(format_row(em_step, e, ct[e], 1e+99 if e == E - 1 else ct[e + 1], "Coal", 0, -1,
+                              counts["coal_opp"][e] + 1.0, counts["coal_count"][e] + 1.0 / (2.0 * ps[e]),
+                              counts["coal_weight"][e] + 1.0))
+    ropp = rcount = rweight = 0.0
+    for e in range(E):
+        ropp += counts["rec_opp"][e] + 1.0
+        rcount += counts["rec_count"][e] + rho
+        rweight += counts["rec_weight"][e] + 1.0
+    out.append(format_row(em_step, -1, 0.0, 1e+99, "Recomb", -1, -1, ropp, rcount, rweight))
+    dopp = counts["delayed_opp"]
+    out.append(format_row(em_step, -1, 0.0, 1e+99, "Delay", -1, -1, dopp, counts["delayed_count"] / np_particles, dopp))
+    out.append(format_row(em_step, -1, 0.0, 1e+99, "Resamp", -1, -1, dopp, counts["resample_count"], dopp))
+    out.append(format_row(em_step, -1, 0, 1e+99, "LogL", -1, -1, 1.0, counts["logl"], 1.0))
+    return "".join(out)
+
+
+def parse_outfile(path_or_text, is_text=False):
+    """Same reduction keys and the same Wt reconstruction as model.py:865-911."""
+    text = path_or_text if is_text else open(path_or_text).read()
+    lines = text.splitlines()
+    header = lines[0].split()
+    data = defaultdict(float)
+    iters = set()
+    for line in lines[1:]:
+        if not line.strip():
+            continue
+        elts = dict(zip(header, line.split()))
+        for name in ("Iter", "Epoch", "From", "To"):
+            elts[name] = int(elts[name])
+        for name in ("Start", "End", "Opp", "Count", "Rate", "Ne", "ESS"):
+            elts[name] = float(elts[name])
+        iters.add(elts["Iter"])
+        if len(iters) > 1:
+            raise ValueError("Found multiple iterations in .out file; expected only one")
+        key = (elts["Type"], elts["Epoch"], elts["From"], elts["To"], -1)
+        data[(key, "Opp")] += elts["Opp"]
+        data[(key, "Count")] += elts["Count"]
+        data[(key, "Wt")] += max(0.0, (1.0 / elts["ESS"] - 1e-10)) * elts["Opp"]
+        data[(key, "Start")] = elts["Start"]
+        data[(key, "End")] = elts["End"]
+    return data

@@ -1,0 +1,47 @@
+"""CountModel reduction across chunk ranks: the in-process replacement for the front-end's
+file-based sum over chunks (/root/reference/smcsmc/model.py:1176-1184, 903-906).
+
+One rank per GPU, each having filtered its own chromosome chunks.  The packed CountModel buffers
+(a few KB) are all-gathered (RCCL over xGMI on the GPU box, gloo in the CPU tests) and summed in
+rank order on every rank, so the result is bit-identical on all ranks and for any arrival order.
+"""
+import numpy as np
+
+COUNT_KEYS = ("coal_count", "coal_opp", "coal_weight", "rec_count", "rec_opp", "rec_weight")
+
+
+def pack_counts(counts):
+    return np.concatenate([np.asarray(counts[k], dtype=np.float64) for k in COUNT_KEYS] +
+                          [[counts["delayed_opp"], counts["delayed_count"], counts["resample_count"], counts["logl"]]])
+
+
+def unpack_counts(packed, E):
+    out = {k: np.array(packed[i * E:(i + 1) * E]) for i, k in enumerate(COUNT_KEYS)}
+    out["delayed_opp"], out["delayed_count"], out["resample_count"], out["logl"] = (float(v) for v in packed[6 * E:6 * E + 4])
+    return out
+
+
+def allreduce_counts_ordered(packed, device=None):
+    """Sum of the per-rank packed buffers in rank order (deterministic).  torch.distributed must be initialised."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    mine = torch.as_tensor(np.asarray(packed, dtype=np.float64), device=device)
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    total = gathered[0].clone()
+    for r in range(1, world):
+        total += gathered[r]
+    return total.cpu().numpy()
+
+
+def assign_chunks(chunk_lengths, world):
+    """Longest-first greedy assignment of chunks to ranks; returns rank -> [chunk ids]."""
+    order = sorted(range(len(chunk_lengths)), key=lambda c: (-chunk_lengths[c], c))
+    load = [0.0] * world
+    out = [[] for _ in range(world)]
+    for c in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        out[r].append(c)
+        load[r] += chunk_lengths[c]
+    return out

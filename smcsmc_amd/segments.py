@@ -183,6 +183,8 @@ class Segments:
         fstart = np.array([r[0] for r in self.rows], dtype=np.int64)
         flen = np.array([r[1] for r in self.rows], dtype=np.int64)
         dist = distance_to_mutation(fstart, flen, alleles)
+        if self.empty_file:
+            dist[:] = 0.0     # no-data mode never calls set_lookahead (segdata.cpp:189-191)
         mre = np.array([max_epoch_to_update(lags, d) for d in dist], np.int32)
         return {"start": start, "length": length, "state": state, "alleles": alleles,
                 "max_record_epoch": mre, "distance_to_mutation": dist}

@@ -198,3 +198,56 @@ def test_ancestral_aware_flag(oracle, hiplib):
     o, si, g = _run_both(oracle, model, segs, 300, seed=6)
     o.run(si); g.run(); g.finish()
     assert _bits([o.logl()])[0] == _bits([g.logl()])[0]
+
+
+def test_lag_calibration_parity(oracle, hiplib):
+    """calculate_median_survival_distances (smcsmc.cpp:169-263): device batches == oracle batches, bit for bit."""
+    from smcsmc_amd import pf
+    model = cases.make_model(n=4, E=8, L=1e7)
+    dm, dt = pf.median_survival(model, seed=1, min_events=50, max_trees=32768)
+    om, ot = oracle.median_survival(model, seed=1, min_events=50, max_trees=32768)
+    assert dt == ot
+    assert (_bits(dm) == _bits(om)).all()
+    lags = pf.calibrated_lags(model, lag_fraction=2.0)
+    assert (lags > 0).all() and lags[1] > lags[-1]
+
+
+def test_binary_end_to_end_matches_library_and_front_end_contract(oracle, hiplib, tmp_path):
+    """The drop-in binary on the reference's scrm data: its .out must equal, character for character, the table
+    written from the same run through the python binding, and parse with the front-end's reader."""
+    import json
+    import os
+    import subprocess
+    from smcsmc_amd import ParticleFilter, outfile, segments as segmod
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    binary = os.path.join(root, "bin", "smcsmc")
+    seg = os.path.join(root, "tests", "golden", "seg", "constpopsize_first3000.seg")
+    L = 2000000
+    core = ("-N0 10000 -t %g -r %g %d -eN 0 1 -eN 0.01 1 -eN 0.25 1 -eN 0.5 1 -eN 1 1 -eN 1.5 1"
+            % (4 * 1e4 * 2.5e-8 * L, 4 * 1e4 * 1e-8 * L, L)).split()
+    args = core + ["-nsam", "2", "-Np", "400", "-EM", "0", "-tmax", "4", "-lag", "20000", "-seed", "7", "-seg", seg,
+                   "-record_ess", "-o", str(tmp_path / "run")]
+    r = subprocess.run([binary] + args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    text = open(tmp_path / "run.out").read()
+    assert os.path.exists(tmp_path / "run.log") and os.path.exists(tmp_path / "run.recomb.gz") and os.path.exists(tmp_path / "run.resample")
+    m = json.loads(subprocess.run([binary] + core + ["-nsam", "2", "-tmax", "4", "-dumpmodel"], capture_output=True, text=True).stdout)
+    E = len(m["change_times"])
+    model = dict(change_times=np.array(m["change_times"]), pop_sizes=np.array(m["pop_sizes"])[:, 0], lags=np.full(E, 20000.0),
+                 nsam=2, loci_length=float(L), mutation_rate=m["mutation_rate"], recombination_rate=m["recombination_rate"])
+    S = segmod.Segments(seg, 2, L, max_segment_length=int(2.0 / (m["recombination_rate"] * 4 * m["N0"])))
+    segs = S.pack(model["lags"])
+    g = ParticleFilter(model, 400, seed=7, max_trace_events=0)
+    g.init_prior(segs["start"][0]); g.load_segments(segs); g.run(); g.finish()
+    assert outfile.outfile_text(model, g.counts(), 400) == text
+    data = outfile.parse_outfile(text, is_text=True)
+    assert data[(("LogL", -1, -1, -1, -1), "Count")] == pytest.approx(g.logl(), rel=1e-7)
+    # and the oracle agrees with what the binary wrote
+    o = oracle.Oracle(model, 400, seed=7); o.init_prior(segs["start"][0]); o.run(o.pack_segments(model, segs))
+    assert _bits([o.logl()])[0] == _bits([g.logl()])[0]
+    np.testing.assert_allclose(g.counts()["coal_count"], o.counts()["coal_count"], rtol=COUNT_RTOL)
+    # default (calibrated) lags also run
+    r = subprocess.run([binary] + core + ["-nsam", "2", "-Np", "200", "-EM", "0", "-tmax", "4", "-seed", "3", "-seg", seg,
+                                          "-o", str(tmp_path / "cal")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "LogL" in open(tmp_path / "cal.out").read()
