@@ -24,6 +24,7 @@
 
 #include "../../include/smcsmc_pf.h"
 #include "pf_device.h"
+#include "pf_tree_reg.h"
 
 #define PF_EMAX 64
 #define PF_DECIDE_BS 1024
@@ -63,6 +64,8 @@ struct Ctrl {
     int err;               // sticky error code
     int count_active;
     int end_seq;
+    int pending_fin;       // k_count partials of the previous step still have to be folded into the totals
+    int nbx_used;
 };
 
 struct KArgs {
@@ -91,6 +94,7 @@ struct KArgs {
     unsigned* gstart;              // [Gcap][Np]  widx at the start of generation g
     int* lo;                       // [Gcap][Np+1] offspring ranges of resampling event r (between gen r and r+1)
     double* gen_x0;                // [Gcap] position where generation g starts
+    int* parent;                   // [Np] parent slot of every new slot at the current resampling event
     // run-length encoded composite ancestor maps: generation g's list maps the slots of the
     // current generation to slots of generation g: run i covers [run_st[i], run_st[i+1]) -> run_anc[i]
     int* run_st;                   // [Gcap][Np]
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(PF_BS) void k_init(KArgs A, double initial_position
         c->cur_pos = initial_position;
         c->logl = 0; c->inv_T = 1; c->T = 1; c->flag = 0; c->cur = 0; c->gen = 0; c->n_resample = 0;
         c->first_epoch = A.E; c->err = 0; c->delayed_opp = 0; c->count_active = 0; c->end_seq = 0;
-        c->g_retain = 0;
+        c->g_retain = 0; c->pending_fin = 0; c->nbx_used = A.nbx;
         for (int e = 0; e < A.E; ++e) { c->counted_to[e] = 0; c->update_to[e] = 0; c->g_lo[e] = 0; c->g_hi[e] = 0; }
         A.gen_x0[0] = 0.0;
     }
@@ -512,13 +516,215 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
     }
 }
 
+// ------------------------------------------------------------------ k_extend_reg
+// Same computation as k_extend with the local tree held in registers (pf_tree_reg.h); used for
+// n <= 8.  LDS only carries the two epoch tables.
+template <int NM>
+__global__ __launch_bounds__(PF_BS) void k_extend_reg(KArgs A, long long s) {
+    extern __shared__ double smem[];
+    double* sT = smem;
+    double* sI = smem + A.E;
+    for (int e = threadIdx.x; e < A.E; e += blockDim.x) { sT[e] = A.T[e]; sI[e] = A.inv2N[e]; }
+    __syncthreads();
+    const Ctrl* c = A.ctrl;
+    const int n = A.n;
+    const int cur = c->cur;
+    const long long p = (long long)blockIdx.x * PF_BS + threadIdx.x;
+    const bool active = p < A.Np;
+    const int lane = threadIdx.x & 63;
+    double w_post = 0.0, w_pilot = 0.0;
+    if (active) {
+        DState& st = A.st[cur];
+        RTree<NM> t;
+#pragma unroll
+        for (int r = 0; r < RTree<NM>::NI; ++r) {
+            t.S[r] = 0.0; t.C0[r] = 0; t.C1[r] = 0;
+            if (r < n - 1) {
+                t.S[r] = st.S[(size_t)r * A.Np + p];
+                t.C0[r] = st.C[(size_t)(2 * r) * A.Np + p];
+                t.C1[r] = st.C[(size_t)(2 * r + 1) * A.Np + p];
+            }
+        }
+        RCtx cx;
+        cx.T = sT; cx.I = sI; cx.E = A.E; cx.n = n; cx.L = A.L; cx.mu = A.mu; cx.rho = A.rho;
+        cx.seed = A.seed; cx.slot = (unsigned)p; cx.stream = 0;
+        w_post = st.w_post[p];
+        w_pilot = st.w_pilot[p];
+        double next_base = st.next_base[p];
+        double x_mark = st.x_mark[p];
+        int mark_limit = st.mark_limit[p];
+        cx.Ltree = st.Ltree[p];
+        cx.ctr = A.rng_ctr[p];
+        cx.ebuf = A.ebuf[p];
+        unsigned widx = A.widx[p];
+
+        const int8_t* data = A.seg_alleles + (size_t)s * n;
+        const double seg_end = A.seg_start[s] + A.seg_len[s];
+        const double extend_to = seg_end < A.L ? seg_end : A.L;
+        const int limit = A.seg_limit[s];
+        unsigned one_mask = 0, zero_mask = 0, present_mask = 0, two_mask = 0;
+        int missing = 0;
+        for (int i = 0; i < n; ++i) {
+            int d = data[i];
+            missing += d == -1;
+            if (d == 1) one_mask |= 1u << i;
+            if (d == 0) zero_mask |= 1u << i;
+            if (d == 2) two_mask |= 1u << i;
+            if (d >= 0) present_mask |= 1u << i;
+        }
+        int leaf_status = 0;
+        if (missing == 0) leaf_status = 1;
+        if (missing == n) leaf_status = -1;
+
+        double updated_to = c->cur_pos;
+        double B;
+        if (leaf_status == -1) B = 0;
+        else if (leaf_status == 1) B = cx.Ltree;
+        else B = r_tracked_len(t, n, present_mask);
+
+        while (updated_to < extend_to) {
+            double new_to = extend_to < next_base ? extend_to : next_base;
+            double f = fastexp(-A.mu * B * (new_to - updated_to));
+            w_post *= f;
+            w_pilot *= f;
+            updated_to = new_to;
+            if (updated_to < extend_to) {
+                double* rec = rec_ptr(A, p, widx);
+                rec[0] = x_mark;
+                rec[1] = updated_to;
+#pragma unroll
+                for (int r = 0; r < RTree<NM>::NI; ++r) if (r < n - 1) rec[5 + r] = t.S[r];
+                double h, tc;
+                r_genealogy_update(cx, t, &h, &tc);
+                rec[2] = h;
+                rec[3] = tc;
+                rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n));
+                ++widx;
+                if (leaf_status == 0) B = r_tracked_len(t, n, present_mask);
+                if (leaf_status == 1) B = cx.Ltree;
+                next_base = r_sample_next_base(cx, updated_to);
+                x_mark = updated_to;
+                mark_limit = limit;
+            }
+        }
+
+        if (A.seg_state[s] == 0) {
+            const bool dephase = A.flags & 2;
+            const bool anc = A.flags & 1;
+            unsigned het_pairs = 0;
+            int ncfg = 1;
+            for (int i = 0; i + 1 < n; i += 2) {
+                bool d0_two = (two_mask >> i) & 1u;
+                bool one0 = (one_mask >> i) & 1u, one1 = (one_mask >> (i + 1)) & 1u;
+                bool zero0 = (zero_mask >> i) & 1u, zero1 = (zero_mask >> (i + 1)) & 1u;
+                bool het = d0_two || (dephase && ((one0 && zero1) || (zero0 && one1)));
+                if (het) {
+                    ncfg *= 2;
+                    het_pairs |= 1u << i;
+                    one_mask &= ~(3u << i); zero_mask &= ~(3u << i);
+                    zero_mask |= 1u << i;
+                    one_mask |= 1u << (i + 1);
+                }
+            }
+            double norm = 1.0 / (double)ncfg;
+            double lik = 0;
+            for (;;) {
+                lik += r_site_lik(t, n, A.mu, one_mask, zero_mask, anc);
+                if (ncfg == 1) break;
+                bool more = false;
+                for (int i = 0; i + 1 < n; i += 2) {
+                    if (!((het_pairs >> i) & 1)) continue;
+                    if ((zero_mask >> i) & 1) {
+                        zero_mask &= ~(1u << i); one_mask |= 1u << i;
+                        one_mask &= ~(1u << (i + 1)); zero_mask |= 1u << (i + 1);
+                        more = true;
+                        break;
+                    }
+                    one_mask &= ~(1u << i); zero_mask |= 1u << i;
+                    zero_mask &= ~(1u << (i + 1)); one_mask |= 1u << (i + 1);
+                }
+                if (!more) break;
+            }
+            lik *= norm;
+            w_post *= lik;
+            w_pilot *= lik;
+        }
+
+#pragma unroll
+        for (int r = 0; r < RTree<NM>::NI; ++r)
+            if (r < n - 1) {
+                st.S[(size_t)r * A.Np + p] = t.S[r];
+                st.C[(size_t)(2 * r) * A.Np + p] = (int8_t)t.C0[r];
+                st.C[(size_t)(2 * r + 1) * A.Np + p] = (int8_t)t.C1[r];
+            }
+        st.w_post[p] = w_post;
+        st.w_pilot[p] = w_pilot;
+        st.next_base[p] = next_base;
+        st.x_mark[p] = x_mark;
+        st.mark_limit[p] = mark_limit;
+        st.Ltree[p] = cx.Ltree;
+        A.rng_ctr[p] = cx.ctr;
+        A.ebuf[p] = cx.ebuf;
+        A.widx[p] = widx;
+    }
+    double sp = wave_tree_sum(w_post);
+    double sq = wave_tree_sum(w_pilot * w_pilot);
+    double sc = wave_hs_scan(w_pilot, lane);
+    double scp = wave_hs_scan(w_post, lane);
+    long long chunk = p >> 6;
+    if (active) { A.scan1[p] = sc; A.scanp[p] = scp; }
+    if (lane == 63 && chunk < (A.Np + 63) / 64) {
+        A.chunk_post[chunk] = sp;
+        A.chunk_sq[chunk] = sq;
+        A.chunk_pil[chunk] = sc;
+        A.chunk_pp[chunk] = scp;
+    }
+}
+
+// ------------------------------------------------------------------ count finalisation (shared)
+// Ordered reduction of the k_count partials of the previous step into the totals, then the
+// bookkeeping at the end of extract_and_update_count (count.cpp:407-414).  Called by the first
+// wavefronts of k_decide (deferred: saves a launch per row) or by k_count_fin (explicit flush).
+__device__ void finalize_counts(const KArgs& A, Ctrl* c, int tid, int nthreads) {
+    const int E = A.E;
+    const int first = c->first_epoch;
+    const int nb = c->nbx_used;
+    for (int idx = tid; idx < (E - first) * 6; idx += nthreads) {
+        int e = first + idx / 6, k = idx % 6;
+        double t = 0.0;
+        for (int b = 0; b < nb; ++b) t += A.partial[((size_t)e * A.nbx + b) * 6 + k];
+        A.totals[(size_t)k * E + e] += t;
+    }
+    __syncthreads();
+    const int G = c->gen;
+    for (int e = first + tid; e < E; e += nthreads) {
+        // the window's lower end moves up: advance the generation that holds it (amortised O(1))
+        int g = c->g_lo[e];
+        double x = c->update_to[e];
+        while (g < G && A.gen_x0[(g + 1) % A.Gcap] <= x) ++g;
+        c->g_lo[e] = g;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        c->delayed_opp += c->update_to[E - 1] - c->counted_to[E - 1];
+        for (int e = 0; e < E; ++e) c->counted_to[e] = c->update_to[e];
+        int gr = c->g_lo[0];
+        for (int e = 1; e < E; ++e) gr = c->g_lo[e] < gr ? c->g_lo[e] : gr;
+        c->g_retain = gr;
+        c->first_epoch = E;
+        c->count_active = 0;
+        c->pending_fin = 0;
+    }
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------ k_decide (single workgroup)
 // normalize_probability (pc.cpp:420-438), the ESS test of resample (pc.cpp:247-283),
 // systematic_resampling (pc.cpp:474-504) and the window bookkeeping of
 // extract_and_update_count (count.cpp:355-385).
 __global__ __launch_bounds__(PF_DECIDE_BS) void k_decide(KArgs A, long long s, int mode, int do_count, int end_data) {
     __shared__ double l2_post[64], l2_sq[64], l2_tot[64], l2_totp[64], base[64], basep[64];
-    __shared__ double sh_T, sh_S1, sh_S2, sh_inv, sh_u;
+    __shared__ double sh_T, sh_S1, sh_S2, sh_u, sh_pos;
     __shared__ int sh_flag, sh_G;
     __shared__ int wmax[PF_DECIDE_BS / 64];
     Ctrl* c = A.ctrl;
@@ -526,6 +732,7 @@ __global__ __launch_bounds__(PF_DECIDE_BS) void k_decide(KArgs A, long long s, i
     const long long Np = A.Np;
     const int nc = (int)((Np + 63) / 64);
     const int ng = (nc + 63) / 64;
+    if (c->pending_fin) finalize_counts(A, c, tid, PF_DECIDE_BS);
     // level 2 of the canonical radix-64 reduction / scans
     for (int g = wave; g < ng; g += nwaves) {
         int ch = g * 64 + lane;
@@ -558,66 +765,82 @@ __global__ __launch_bounds__(PF_DECIDE_BS) void k_decide(KArgs A, long long s, i
     __syncthreads();
     for (int ch = tid; ch < nc; ch += PF_DECIDE_BS) {
         double off = (ch % 64 == 0) ? 0.0 : A.l2scan[ch - 1];
-        A.chunk_off[ch] = base[ch / 64] + off;
+        double co = base[ch / 64] + off;
+        A.chunk_off[ch] = co;
         double offp = (ch % 64 == 0) ? 0.0 : A.l2scanp[ch - 1];
         A.chunk_offp[ch] = basep[ch / 64] + offp;
+        if (ch == nc - 1) sh_S1 = co + A.scan1[Np - 1];   // inclusive scan at the last particle (= oracle incl[N-1])
     }
     __syncthreads();
     if (tid == 0) {
         double T = sh_T;
-        double S1 = A.chunk_off[nc - 1] + A.scan1[Np - 1];   // inclusive scan at the last particle (= oracle incl[N-1])
+        double S1 = sh_S1;
         double S2 = sh_S2;
         if (!(T > 0.0)) c->err = ERR_ZERO_PROB;
-        c->logl += dlog(T);
+        double logl = c->logl + dlog(T);
+        c->logl = logl;
         double inv = 1.0 / T;
         double ess = (S1 * S1) / S2;
         int flag = 0;
         double u = 0.0;
+        double pos = A.L;
         if (mode == 0) {
             flag = ess < A.ess_threshold - 1e-6 ? 1 : 0;
             if (flag) u = philox_uniform(A.seed, 0xFFFFFFFFu, 1, (unsigned long long)c->n_resample);
             A.tr_T[s] = T;
             A.tr_ess[s] = ess;
             A.tr_flag[s] = flag;
-            A.tr_logl[s] = c->logl;
+            A.tr_logl[s] = logl;
             double seg_end = A.seg_start[s] + A.seg_len[s];
-            c->cur_pos = seg_end < A.L ? seg_end : A.L;
+            pos = seg_end < A.L ? seg_end : A.L;
+            c->cur_pos = pos;
         }
         c->T = T; c->inv_T = inv; c->S1 = S1; c->S2 = S2; c->ess = ess; c->u = u; c->flag = flag;
-        sh_S1 = S1; sh_inv = inv; sh_u = u; sh_flag = flag;
-        const int G = c->gen;
-        sh_G = G;
-        // windows of this count step (count.cpp:363-385)
-        int first = A.E;
-        if (do_count) {
-            double current_base = mode == 0 ? c->cur_pos : A.L;
-            for (int e = 0; e < A.E; ++e) {
-                double lagging = end_data ? 0.0 : A.lags[e];
-                double x_end = current_base - lagging;
-                if ((x_end - c->counted_to[e]) < lagging * 0.1 && first > e) {
-                    c->update_to[e] = c->counted_to[e];
-                } else {
-                    c->update_to[e] = x_end;
-                    if (e < first) first = e;
-                }
-            }
-            // generation holding the upper end of each updated window (monotone: amortised O(1))
-            for (int e = first; e < A.E; ++e) {
-                int g = c->g_hi[e];
-                if (g < c->g_lo[e]) g = c->g_lo[e];
-                while (g < G && A.gen_x0[(g + 1) % A.Gcap] < c->update_to[e]) ++g;
-                c->g_hi[e] = g;
-            }
-        }
-        c->first_epoch = first;
-        c->count_active = first < A.E;
+        sh_u = u; sh_flag = flag; sh_pos = pos;
+        sh_G = c->gen;
     }
     __syncthreads();
     const int flag = sh_flag;
     const double S1 = sh_S1;
     const int G = sh_G;
+    // ---- windows of this count step (count.cpp:363-385), one lane per epoch ----
+    if (wave == 0) {
+        int first = A.E;
+        if (do_count) {
+            const int e = lane;
+            const bool valid = e < A.E;
+            double lagging = 0.0, x_end = 0.0, cto = 0.0;
+            bool wants = false;
+            if (valid) {
+                lagging = end_data ? 0.0 : A.lags[e];
+                x_end = sh_pos - lagging;
+                cto = c->counted_to[e];
+                wants = !((x_end - cto) < lagging * 0.1);
+            }
+            unsigned long long bal = __ballot(wants);
+            first = bal ? (int)__ffsll((long long)bal) - 1 : A.E;
+            if (valid) {
+                bool upd = e >= first;
+                c->update_to[e] = upd ? x_end : cto;
+                if (upd) {
+                    // generation holding the upper end of the window (monotone: amortised O(1))
+                    int g = c->g_hi[e];
+                    int glo = c->g_lo[e];
+                    if (g < glo) g = glo;
+                    while (g < G && A.gen_x0[(g + 1) % A.Gcap] < x_end) ++g;
+                    c->g_hi[e] = g;
+                }
+            }
+        }
+        if (lane == 0) {
+            c->first_epoch = first;
+            c->count_active = first < A.E;
+            c->pending_fin = first < A.E;
+            c->nbx_used = A.nbx;
+        }
+    }
 
-    // ---- offspring table lo[0..Np] of systematic resampling (closed form, monotone) ----
+    // ---- offspring table lo[0..Np] of systematic resampling (closed form, monotone) + parent table ----
     if (flag) {
         int* lo = A.lo + (size_t)(G % A.Gcap) * (Np + 1);
         const double u = sh_u;
@@ -651,13 +874,18 @@ __global__ __launch_bounds__(PF_DECIDE_BS) void k_decide(KArgs A, long long s, i
         for (long long i = i0; i < i1; ++i) lo[i] = max(lo[i], prefix);
         if (tid == 0) lo[Np] = (int)Np;
         __syncthreads();
+        // parent of every new slot: offspring of i occupy [lo[i], lo[i+1])
+        for (long long i = i0; i < i1; ++i) {
+            int q1 = lo[i + 1];
+            for (int q = lo[i]; q < q1; ++q) A.parent[q] = (int)i;
+        }
         if (tid == 0) {
             // toggle buffers / open the next generation
             int ev = (int)c->n_resample;
             if (ev < A.max_trace_events) A.ev_seg[ev] = (int)s;
             c->cur ^= 1;
             c->gen = G + 1;
-            A.gen_x0[(G + 1) % A.Gcap] = c->cur_pos;
+            A.gen_x0[(G + 1) % A.Gcap] = sh_pos;
             c->n_resample += 1;
             if (G + 1 - c->g_retain >= A.Gcap - 1) c->err = ERR_GEN_OVERFLOW;
         }
@@ -807,33 +1035,9 @@ __global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0) {
     }
 }
 
-__global__ void k_count_fin(KArgs A, int nbx_used) {
+__global__ void k_count_fin(KArgs A) {
     Ctrl* c = A.ctrl;
-    const int first = c->first_epoch;
-    const int E = A.E;
-    const int G = c->flag ? c->gen - 1 : c->gen;
-    for (int e = first + threadIdx.x; e < E; e += blockDim.x) {
-        double t[6] = {0, 0, 0, 0, 0, 0};
-        for (int b = 0; b < nbx_used; ++b) {
-            const double* in = A.partial + ((size_t)e * A.nbx + b) * 6;
-            for (int k = 0; k < 6; ++k) t[k] += in[k];
-        }
-        for (int k = 0; k < 6; ++k) A.totals[(size_t)k * E + e] += t[k];
-        // the window's lower end moves up: advance the generation that holds it (amortised O(1))
-        int g = c->g_lo[e];
-        while (g < G && A.gen_x0[(g + 1) % A.Gcap] <= c->update_to[e]) ++g;
-        c->g_lo[e] = g;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        c->delayed_opp += c->update_to[E - 1] - c->counted_to[E - 1];
-        for (int e = 0; e < E; ++e) c->counted_to[e] = c->update_to[e];
-        int gr = c->g_lo[0];
-        for (int e = 1; e < E; ++e) gr = c->g_lo[e] < gr ? c->g_lo[e] : gr;
-        c->g_retain = gr;
-        c->first_epoch = E;
-        c->count_active = 0;
-    }
+    if (c->pending_fin) finalize_counts(A, c, threadIdx.x, blockDim.x);
 }
 
 // ------------------------------------------------------------------ k_resample (+ ledger blocks)
@@ -920,14 +1124,9 @@ __global__ __launch_bounds__(PF_BS) void k_resample(KArgs A, long long s, int nb
         A.widx[i] = widx;
     }
     A.gstart[(size_t)((G + 1) % A.Gcap) * Np + i] = widx;
-    // ---- role 2: new slot q = i finds its parent: largest a with lo[a] <= q ----
+    // ---- role 2: new slot q = i copies its parent (table written by k_decide) ----
     const int q = (int)i;
-    long long lo_i = 0, hi_i = Np;             // invariant: lo[lo_i] <= q < lo[hi_i]
-    while (hi_i - lo_i > 1) {
-        long long mid = (lo_i + hi_i) >> 1;
-        if (lo[mid] <= q) lo_i = mid; else hi_i = mid;
-    }
-    const long long a = lo_i;
+    const long long a = A.parent[q];
     int ev = (int)c->n_resample - 1;
     if (ev < A.max_trace_events) A.ev_parents[(size_t)ev * Np + q] = (int)a;
     for (int r = 0; r < n - 1; ++r) {
@@ -1091,6 +1290,8 @@ struct pf_handle {
     size_t smem = 0;
     int max_trace_events = 0;
     bool finished = false;
+    bool fin_pending = false;     // k_count partials not yet folded into the totals
+    bool force_lds = false;       // SMCSMC_PF_FORCE_LDS=1: use the LDS-tree kernel for every n (testing)
     // timing
     int timing_period = 0;
     struct Span { hipEvent_t a, b; int k; };
@@ -1143,6 +1344,7 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     h->nblocks = (int)((Np + PF_BS - 1) / PF_BS);
     h->smem = smem_bytes(n, E);
     h->max_trace_events = std::max(0, p->max_trace_events);
+    h->force_lds = env_ll("SMCSMC_PF_FORCE_LDS", 0) != 0;
     h->h_lags.assign(m->lags, m->lags + E);
     h->h_counted_to.assign(E, 0.0);
     h->h_L = m->loci_length;
@@ -1185,6 +1387,7 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     rc |= dalloc(h, &A.gstart, (size_t)A.Gcap * Np);
     rc |= dalloc(h, &A.lo, (size_t)A.Gcap * (Np + 1));
     rc |= dalloc(h, &A.gen_x0, A.Gcap);
+    rc |= dalloc(h, &A.parent, Np);
     rc |= dalloc(h, &A.run_st, (size_t)A.Gcap * Np);
     rc |= dalloc(h, &A.run_anc, (size_t)A.Gcap * Np);
     rc |= dalloc(h, &A.nruns, A.Gcap);
@@ -1261,6 +1464,10 @@ struct Timed {
 
 int pf_sync(pf_handle* h) {
     HIPCHK(hipSetDevice(h->device));
+    if (h->fin_pending) {
+        hipLaunchKernelGGL(k_count_fin, dim3(1), dim3(256), 0, h->stream, h->A);
+        h->fin_pending = false;
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     if (harvest_spans(h)) return -1;
     Ctrl c;
@@ -1281,6 +1488,7 @@ int pf_init_prior(pf_handle* h, double initial_position) {
     hipLaunchKernelGGL(k_init, dim3(h->nblocks), dim3(PF_BS), h->smem, h->stream, h->A, initial_position);
     if (check_launch("k_init")) return -1;
     std::fill(h->h_counted_to.begin(), h->h_counted_to.end(), 0.0);
+    h->fin_pending = false;
     h->seg_done = 0;
     h->finished = false;
     return 0;
@@ -1334,12 +1542,19 @@ static int launch_update(pf_handle* h, long long s, bool do_count) {
     const bool t = timing_on(h, s);
     {
         Timed tm(h, 0, t);
-        hipLaunchKernelGGL(k_extend, dim3(h->nblocks), dim3(PF_BS), h->smem, h->stream, h->A, s);
+        const size_t smem_reg = (size_t)2 * h->E * 8;
+        if (h->n <= 4 && !h->force_lds)
+            hipLaunchKernelGGL(k_extend_reg<4>, dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s);
+        else if (h->n <= 8 && !h->force_lds)
+            hipLaunchKernelGGL(k_extend_reg<8>, dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s);
+        else
+            hipLaunchKernelGGL(k_extend, dim3(h->nblocks), dim3(PF_BS), h->smem, h->stream, h->A, s);
     }
     if (check_launch("k_extend")) return -1;
     {
         Timed tm(h, 1, t);
         hipLaunchKernelGGL(k_decide, dim3(1), dim3(PF_DECIDE_BS), 0, h->stream, h->A, s, 0, do_count ? 1 : 0, 0);
+        h->fin_pending = false;      // k_decide folds the previous step's partials first
     }
     return check_launch("k_decide");
 }
@@ -1350,7 +1565,7 @@ static int launch_count(pf_handle* h, long long s, int first) {
     {
         Timed tm(h, 2, t);
         hipLaunchKernelGGL(k_count, dim3(h->nblocks, h->E - first), dim3(PF_BS), 0, h->stream, h->A, first);
-        hipLaunchKernelGGL(k_count_fin, dim3(1), dim3(64), 0, h->stream, h->A, h->nblocks);
+        h->fin_pending = true;
     }
     return check_launch("k_count");
 }
@@ -1416,6 +1631,7 @@ int pf_finish(pf_handle* h) {
     hipLaunchKernelGGL(k_partials, dim3(h->nblocks), dim3(PF_BS), 0, h->stream, h->A);
     int first = host_first_epoch(h, h->h_L, true, true);
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(PF_DECIDE_BS), 0, h->stream, h->A, (long long)0, 1, 1, 1);
+    h->fin_pending = false;
     if (check_launch("k_decide(final)")) return -1;
     if (launch_count(h, 0, first)) return -1;
     if (launch_resample(h, 0)) return -1;    // flag == 0 in mode 1: in-place normalisation

@@ -1,0 +1,359 @@
+// smcsmc_amd/csrc/pf_tree_reg.h -- register-resident local tree for small sample sizes.
+//
+// Same algorithms, same IEEE-754 operations in the same order as the LDS-backed versions in
+// pf_device.h (and therefore the same bits as the oracle); only the storage differs: the n-1 node
+// heights and 2(n-1) child ids live in VGPRs, every loop over ranks is fully unrolled with a
+// compile-time index, and the few genuinely run-time indices become v_cndmask select chains.
+// This removes the dependent LDS round trips (~64+ cycles each, one wavefront per SIMD, nothing to
+// hide them behind) that dominated k_extend.
+#pragma once
+#include "pf_device.h"
+
+namespace pf {
+
+template <int NM>   // NM = maximum number of haplotypes handled by this instantiation
+struct RTree {
+    static constexpr int NI = NM - 1;
+    double S[NI];
+    int C0[NI], C1[NI];
+
+    __device__ __forceinline__ double getS(int r) const {
+        double v = S[0];
+#pragma unroll
+        for (int k = 1; k < NI; ++k) v = (r == k) ? S[k] : v;
+        return v;
+    }
+    __device__ __forceinline__ void setS(int r, double x) {
+#pragma unroll
+        for (int k = 0; k < NI; ++k) S[k] = (r == k) ? x : S[k];
+    }
+    __device__ __forceinline__ int getC(int r, int s) const {
+        int v = s ? C1[0] : C0[0];
+#pragma unroll
+        for (int k = 1; k < NI; ++k) v = (r == k) ? (s ? C1[k] : C0[k]) : v;
+        return v;
+    }
+    __device__ __forceinline__ void setC(int r, int s, int x) {
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            C0[k] = (r == k && s == 0) ? x : C0[k];
+            C1[k] = (r == k && s == 1) ? x : C1[k];
+        }
+    }
+};
+
+// per-lane context that is not the tree (epoch tables stay in LDS: they are indexed by epoch)
+struct RCtx {
+    const double* T;
+    const double* I;
+    int E, n;
+    double L, mu, rho;
+    unsigned long long seed;
+    unsigned slot, stream;
+    unsigned long long ctr;
+    double ebuf;
+    double Ltree;
+};
+
+__device__ __forceinline__ double r_uni(RCtx& cx) { return philox_uniform(cx.seed, cx.slot, cx.stream, cx.ctr++); }
+__device__ __forceinline__ int r_epoch_of(const RCtx& cx, double t) {
+    int e = 0;
+    while (e + 1 < cx.E && cx.T[e + 1] <= t) ++e;
+    return e;
+}
+__device__ __forceinline__ double r_epoch_end(const RCtx& cx, int e) { return e + 1 < cx.E ? cx.T[e + 1] : PF_INF; }
+
+template <int NM>
+__device__ __forceinline__ double r_node_h(const RTree<NM>& t, int n, int id) { return id < n ? 0.0 : t.getS(id - n); }
+
+template <int NM>
+__device__ __forceinline__ double r_tree_length(const RTree<NM>& t, int n) {
+    double acc = 0.0, prev = 0.0;
+#pragma unroll
+    for (int r = 0; r < RTree<NM>::NI; ++r)
+        if (r < n - 1) {
+            double s = t.S[r];
+            acc += (double)(n - r) * (s - prev);
+            prev = s;
+        }
+    return acc;
+}
+
+template <int NM>
+__device__ __forceinline__ int r_lineages_at(const RTree<NM>& t, int n, int ni, double time, int want, int* pr, int* ps) {
+    int R = 0;
+#pragma unroll
+    for (int k = 0; k < RTree<NM>::NI; ++k) R += (k < ni && t.S[k] <= time) ? 1 : 0;   // S is sorted: a prefix count
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < RTree<NM>::NI; ++r) {
+        if (r >= R && r < ni) {
+            int id0 = t.C0[r];
+            if (id0 < n || id0 - n < R) {
+                if (cnt == want) { *pr = r; *ps = 0; }
+                ++cnt;
+            }
+            int id1 = t.C1[r];
+            if (id1 < n || id1 - n < R) {
+                if (cnt == want) { *pr = r; *ps = 1; }
+                ++cnt;
+            }
+        }
+    }
+    return cnt;
+}
+
+template <int NM>
+__device__ __forceinline__ void r_remove_rank(RTree<NM>& t, int n, int ni, int rp, int sib, int* a, int* b) {
+    const int pid = n + rp;
+#pragma unroll
+    for (int r = 0; r < RTree<NM>::NI; ++r)
+        if (r > rp && r < ni) {
+            if (t.C0[r] == pid) t.C0[r] = sib;
+            if (t.C1[r] == pid) t.C1[r] = sib;
+        }
+#pragma unroll
+    for (int r = 0; r + 1 < RTree<NM>::NI; ++r)
+        if (r >= rp && r + 1 < ni) {
+            t.S[r] = t.S[r + 1];
+            t.C0[r] = t.C0[r + 1];
+            t.C1[r] = t.C1[r + 1];
+        }
+#pragma unroll
+    for (int r = 0; r < RTree<NM>::NI; ++r)
+        if (r < ni - 1) {
+            if (t.C0[r] > pid) t.C0[r] -= 1;
+            if (t.C1[r] > pid) t.C1[r] -= 1;
+        }
+    if (*a > pid) *a -= 1;
+    if (*b > pid) *b -= 1;
+}
+
+template <int NM>
+__device__ __forceinline__ void r_insert_node(RTree<NM>& t, int n, int ni, double h, int fl, int pr, int ps, int root_id) {
+    int rn = 0;
+#pragma unroll
+    for (int k = 0; k < RTree<NM>::NI; ++k) rn += (k < ni && t.S[k] <= h) ? 1 : 0;
+    const int nid = n + rn;
+#pragma unroll
+    for (int r = 0; r < RTree<NM>::NI; ++r)
+        if (r < ni) {
+            if (t.C0[r] >= nid) t.C0[r] += 1;
+            if (t.C1[r] >= nid) t.C1[r] += 1;
+        }
+    if (fl >= nid) fl += 1;
+    if (root_id >= nid) root_id += 1;
+#pragma unroll
+    for (int r = RTree<NM>::NI - 1; r >= 1; --r)
+        if (r <= ni && r > rn) {
+            t.S[r] = t.S[r - 1];
+            t.C0[r] = t.C0[r - 1];
+            t.C1[r] = t.C1[r - 1];
+        }
+    int target;
+    if (pr >= 0) {
+        if (pr >= rn) pr += 1;
+        target = t.getC(pr, ps);
+        t.setC(pr, ps, nid);
+    } else {
+        target = root_id;
+    }
+    t.setS(rn, h);
+    t.setC(rn, 0, fl);
+    t.setC(rn, 1, target);
+}
+
+template <int NM>
+__device__ __forceinline__ double r_coalesce_up(RCtx& cx, const RTree<NM>& t, int ns, int nl, double h) {
+    double tt = h;
+    int e = r_epoch_of(cx, tt);
+    int i = 0;
+#pragma unroll
+    for (int k = 0; k < RTree<NM>::NI; ++k) i += (k < ns && t.S[k] <= tt) ? 1 : 0;
+    for (;;) {
+        double tn_node = i < ns ? t.getS(i) : PF_INF;
+        double tn_ep = r_epoch_end(cx, e);
+        double tn = tn_node < tn_ep ? tn_node : tn_ep;
+        int k = i < ns ? nl - i : 1;
+        double rate = (double)k * cx.I[e];
+        double need = (tn - tt) * rate;
+        if (!(cx.ebuf > need)) {
+            double t1 = tt + cx.ebuf / rate;
+            cx.ebuf = -dlog(r_uni(cx));
+            return t1;
+        }
+        cx.ebuf -= need;
+        tt = tn;
+        if (tn_node <= tn) ++i;
+        if (tn_ep <= tn) ++e;
+    }
+}
+
+__device__ __forceinline__ double r_sample_next_base(RCtx& cx, double x) {
+    double rate = cx.rho * cx.Ltree;
+    double limit = cx.L - x;
+    double need = limit * rate;
+    if (cx.ebuf > need) {
+        cx.ebuf -= need;
+        return cx.L;
+    }
+    double nb = x + cx.ebuf / rate;
+    cx.ebuf = -dlog(r_uni(cx));
+    if (nb == x) {
+        nb = __longlong_as_double(__double_as_longlong(x) + 1);
+        if (x == 0.0) nb = 4.9406564584124654e-324;
+    }
+    if (nb > cx.L) nb = cx.L;
+    return nb;
+}
+
+// One SMC' genealogy update; mirrors genealogy_update() in pf_hip.hip / Filter::genealogy_update in the oracle.
+template <int NM>
+__device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, double* h_out, double* tc_out) {
+    const int n = cx.n;
+    double r = r_uni(cx) * cx.Ltree;
+    double prev = 0.0, h = 0.0;
+    int lin = 0;
+    bool done = false;
+#pragma unroll
+    for (int ri = 0; ri < RTree<NM>::NI; ++ri) {
+        if (!done && ri < n - 1) {
+            int k = n - ri;
+            double sr = t.S[ri];
+            double d = sr - prev;
+            double seg = (double)k * d;
+            if (r < seg || ri == n - 2) {
+                double q = r / d;
+                lin = min((int)q, k - 1);
+                h = prev + (q - (double)lin) * d;
+                if (!(h < sr)) h = prev;
+                done = true;
+            } else {
+                r -= seg;
+                prev = sr;
+            }
+        }
+    }
+    int rp = 0, sb = 0;
+    r_lineages_at(t, n, n - 1, h, lin, &rp, &sb);
+    *h_out = h;
+    double tc = r_coalesce_up(cx, t, n - 1, n, h);
+    *tc_out = tc;
+    double Sp = t.getS(rp);
+    int b_id = t.getC(rp, sb), s_id = t.getC(rp, 1 - sb);
+    bool p_was_root = (rp == n - 2);
+    r_remove_rank(t, n, n - 1, rp, s_id, &b_id, &s_id);
+    int ni = n - 2;
+    int troot = p_was_root ? s_id : n + (ni - 1);
+    int pr = -1, ps = 0;
+    int nslots = r_lineages_at(t, n, ni, tc, -1, &pr, &ps);
+    bool has_root = tc >= r_node_h(t, n, troot);
+    bool has_stub = tc < Sp;
+    int k = nslots + (has_root ? 1 : 0) + (has_stub ? 1 : 0);
+    double u = r_uni(cx);
+    int idx = min((int)(u * (double)k), k - 1);
+    if (idx < nslots) {
+        r_lineages_at(t, n, ni, tc, idx, &pr, &ps);
+        r_insert_node(t, n, ni, tc, b_id, pr, ps, troot);
+    } else if (has_root && idx == nslots) {
+        r_insert_node(t, n, ni, tc, b_id, -1, 0, troot);
+    } else {
+        if (p_was_root) {
+            r_insert_node(t, n, ni, Sp, b_id, -1, 0, troot);
+        } else {
+            // the sibling lineage's slot at time Sp
+            int R = 0;
+#pragma unroll
+            for (int kk = 0; kk < RTree<NM>::NI; ++kk) R += (kk < ni && t.S[kk] <= Sp) ? 1 : 0;
+            int want = -1, c = 0;
+#pragma unroll
+            for (int rr = 0; rr < RTree<NM>::NI; ++rr) {
+                if (rr >= R && rr < ni) {
+                    int id0 = t.C0[rr];
+                    if (id0 < n || id0 - n < R) { if (want < 0 && id0 == s_id) want = c; ++c; }
+                    int id1 = t.C1[rr];
+                    if (id1 < n || id1 - n < R) { if (want < 0 && id1 == s_id) want = c; ++c; }
+                }
+            }
+            r_lineages_at(t, n, ni, Sp, want, &pr, &ps);
+            r_insert_node(t, n, ni, Sp, b_id, pr, ps, troot);
+        }
+    }
+    cx.Ltree = r_tree_length(t, n);
+}
+
+// particle.cpp:699-730
+template <int NM>
+__device__ __forceinline__ double r_tracked_len(const RTree<NM>& t, int n, unsigned present_mask) {
+    double val[RTree<NM>::NI];
+    double total = 0.0;
+#pragma unroll
+    for (int r = 0; r < RTree<NM>::NI; ++r) {
+        val[r] = 0.0;
+        if (r < n - 1) {
+            int c0 = t.C0[r], c1 = t.C1[r];
+            double sr = t.S[r];
+            double l, rr, h0 = 0.0, h1 = 0.0;
+            if (c0 < n) l = (present_mask >> c0) & 1u ? 0.0 : -1.0;
+            else {
+                l = val[0]; h0 = t.S[0];
+#pragma unroll
+                for (int k = 1; k < RTree<NM>::NI; ++k) if (k < r && c0 - n == k) { l = val[k]; h0 = t.S[k]; }
+            }
+            if (c1 < n) rr = (present_mask >> c1) & 1u ? 0.0 : -1.0;
+            else {
+                rr = val[0]; h1 = t.S[0];
+#pragma unroll
+                for (int k = 1; k < RTree<NM>::NI; ++k) if (k < r && c1 - n == k) { rr = val[k]; h1 = t.S[k]; }
+            }
+            if (l >= 0.0) l += sr - h0;
+            if (rr >= 0.0) rr += sr - h1;
+            double v;
+            if (l >= 0.0 && rr >= 0.0) { total = l + rr; v = total; }
+            else if (l >= 0.0) v = l;
+            else v = rr;
+            val[r] = v;
+        }
+    }
+    return total;
+}
+
+// particle.cpp:625-680
+template <int NM>
+__device__ __forceinline__ double r_site_lik(const RTree<NM>& t, int n, double mu, unsigned one_mask, unsigned zero_mask, bool anc) {
+    double m0[RTree<NM>::NI], m1[RTree<NM>::NI];
+    double res0 = 0.0, res1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < RTree<NM>::NI; ++r) {
+        m0[r] = 0.0; m1[r] = 0.0;
+        if (r < n - 1) {
+            int c0 = t.C0[r], c1 = t.C1[r];
+            double sr = t.S[r];
+            double a0, a1, b0, b1, h0 = 0.0, h1 = 0.0;
+            if (c0 < n) { a0 = (one_mask >> c0) & 1u ? 0.0 : 1.0; a1 = (zero_mask >> c0) & 1u ? 0.0 : 1.0; }
+            else {
+                a0 = m0[0]; a1 = m1[0]; h0 = t.S[0];
+#pragma unroll
+                for (int k = 1; k < RTree<NM>::NI; ++k) if (k < r && c0 - n == k) { a0 = m0[k]; a1 = m1[k]; h0 = t.S[k]; }
+            }
+            if (c1 < n) { b0 = (one_mask >> c1) & 1u ? 0.0 : 1.0; b1 = (zero_mask >> c1) & 1u ? 0.0 : 1.0; }
+            else {
+                b0 = m0[0]; b1 = m1[0]; h1 = t.S[0];
+#pragma unroll
+                for (int k = 1; k < RTree<NM>::NI; ++k) if (k < r && c1 - n == k) { b0 = m0[k]; b1 = m1[k]; h1 = t.S[k]; }
+            }
+            double tl = sr - h0;
+            double trr = sr - h1;
+            double pl = fastexp(-tl * mu);
+            double pr = fastexp(-trr * mu);
+            double v0 = (a0 * pl + a1 * (1 - pl)) * (b0 * pr + b1 * (1 - pr));
+            double v1 = (a1 * pl + a0 * (1 - pl)) * (b1 * pr + b0 * (1 - pr));
+            m0[r] = v0; m1[r] = v1;
+            if (r == n - 2) { res0 = v0; res1 = v1; }
+        }
+    }
+    double p0 = anc ? 1.0 : 0.5, p1 = anc ? 0.0 : 0.5;
+    return res0 * p0 + res1 * p1;
+}
+
+}  // namespace pf

@@ -221,6 +221,9 @@ def test_binary_end_to_end_matches_library_and_front_end_contract(oracle, hiplib
     from smcsmc_amd import ParticleFilter, outfile, segments as segmod
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     binary = os.path.join(root, "bin", "smcsmc")
+    if not os.path.exists(binary):
+        from smcsmc_amd import build
+        build.build_all()
     seg = os.path.join(root, "tests", "golden", "seg", "constpopsize_first3000.seg")
     L = 2000000
     core = ("-N0 10000 -t %g -r %g %d -eN 0 1 -eN 0.01 1 -eN 0.25 1 -eN 0.5 1 -eN 1 1 -eN 1.5 1"
