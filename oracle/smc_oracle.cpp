@@ -106,17 +106,20 @@ static void canon_scan(const double* x, double* incl, int64_t n) {
     }
 }
 
-/* particleContainer.cpp:474-504 in closed form (D4): lo[i] = #{ j in [0,N) : (j+U)/N < cum_i } */
+/* particleContainer.cpp:474-504 in closed form (D4): sample j has quantile u_j = (j+U)/N and goes to the first
+ * record whose upper partial sum exceeds it (pc.cpp:491: partial_sum[i+1]/total > u_j).  With both sides
+ * multiplied by N*total:  lo[i] = #{ j in [0,N) : (j+U) * total < N * incl[i-1] }  (no division). */
 static void systematic(const double* incl, int64_t n, double u, int32_t* lo) {
     const double total = incl[n - 1];
     const double dn = (double)n;
+    const double inv_total = 1.0 / total;
     lo[0] = 0;
     for (int64_t i = 1; i < n; ++i) {
-        double cum = incl[i - 1] / total;
-        double guess = std::floor(cum * dn - u);
+        double rhs = dn * incl[i - 1];
+        double guess = std::floor(rhs * inv_total - u);
         int64_t g = guess < 0 ? 0 : (guess > dn ? n : (int64_t)guess);
-        while (g > 0 && !((((double)(g - 1)) + u) / dn < cum)) --g;
-        while (g < n && ((((double)g) + u) / dn < cum)) ++g;
+        while (g > 0 && !((((double)(g - 1)) + u) * total < rhs)) --g;
+        while (g < n && ((((double)g) + u) * total < rhs)) ++g;
         lo[i] = (int32_t)g;
     }
     lo[n] = (int32_t)n;

@@ -28,7 +28,8 @@
 
 #define PF_EMAX 64
 #define PF_DECIDE_BS 1024
-#define PF_LEDGER_BLOCKS 224   // extra workgroups of k_resample that maintain the ancestor ledger
+#define PF_DECIDE_PER 16      // particles per k_decide thread kept in registers (fast path: Np <= 16384)
+#define PF_LEDGER_BLOCKS 192   // extra workgroups of k_resample that maintain the ancestor ledger
 #define REC_RECOMB 1
 #define REC_COALMIGR 2
 
@@ -65,6 +66,7 @@ struct Ctrl {
     int count_active;
     int end_seq;
     int pending_fin;       // k_count partials of the previous step still have to be folded into the totals
+    int gen_prev;          // generation index as of the end of the last k_resample (stable during k_decide)
     int nbx_used;
 };
 
@@ -132,6 +134,15 @@ struct KArgs {
     Ctrl* ctrl;
 };
 
+// Count windows of one step (count.cpp:363-385).  The rule depends only on segment positions and lags,
+// so the host evaluates it (host_first_epoch) and hands the result to the kernels by value.
+struct Windows {
+    int first;                 // first epoch that updates (E = none)
+    int end_data;
+    double a[PF_EMAX];         // counted_to before this step
+    double b[PF_EMAX];         // update_to of this step
+};
+
 enum { ERR_LOG_OVERFLOW = 1, ERR_GEN_OVERFLOW = 2, ERR_ZERO_PROB = 3, ERR_COUNT_MISMATCH = 4 };
 
 __device__ __forceinline__ unsigned long long make_meta(int type, int lim_start, int lim_event, int n_eff) {
@@ -196,7 +207,7 @@ __global__ __launch_bounds__(PF_BS) void k_init(KArgs A, double initial_position
         c->cur_pos = initial_position;
         c->logl = 0; c->inv_T = 1; c->T = 1; c->flag = 0; c->cur = 0; c->gen = 0; c->n_resample = 0;
         c->first_epoch = A.E; c->err = 0; c->delayed_opp = 0; c->count_active = 0; c->end_seq = 0;
-        c->g_retain = 0; c->pending_fin = 0; c->nbx_used = A.nbx;
+        c->g_retain = 0; c->pending_fin = 0; c->nbx_used = A.nbx; c->gen_prev = 0;
         for (int e = 0; e < A.E; ++e) { c->counted_to[e] = 0; c->update_to[e] = 0; c->g_lo[e] = 0; c->g_hi[e] = 0; }
         A.gen_x0[0] = 0.0;
     }
@@ -681,36 +692,45 @@ __global__ __launch_bounds__(PF_BS) void k_extend_reg(KArgs A, long long s) {
     }
 }
 
-// ------------------------------------------------------------------ count finalisation (shared)
-// Ordered reduction of the k_count partials of the previous step into the totals, then the
-// bookkeeping at the end of extract_and_update_count (count.cpp:407-414).  Called by the first
-// wavefronts of k_decide (deferred: saves a launch per row) or by k_count_fin (explicit flush).
-__device__ void finalize_counts(const KArgs& A, Ctrl* c, int tid, int nthreads) {
+// ------------------------------------------------------------------ count bookkeeping (shared)
+// Ordered reduction of the k_count partials of the previous step into the totals
+// (count.cpp:407-414).  Runs in the second workgroup of k_decide (off the critical path) or in
+// k_count_fin (explicit flush).
+#define PF_FIN_TILE_B 64       // k_count workgroup partials staged per pass
+#define PF_FIN_PAIRS 64        // (epoch, statistic) pairs staged per pass
+
+__device__ void finalize_counts(const KArgs& A, Ctrl* c, int tid, int nthreads, double* stage /* PF_FIN_PAIRS*PF_FIN_TILE_B */) {
     const int E = A.E;
     const int first = c->first_epoch;
     const int nb = c->nbx_used;
-    for (int idx = tid; idx < (E - first) * 6; idx += nthreads) {
-        int e = first + idx / 6, k = idx % 6;
-        double t = 0.0;
-        for (int b = 0; b < nb; ++b) t += A.partial[((size_t)e * A.nbx + b) * 6 + k];
-        A.totals[(size_t)k * E + e] += t;
-    }
-    __syncthreads();
-    const int G = c->gen;
-    for (int e = first + tid; e < E; e += nthreads) {
-        // the window's lower end moves up: advance the generation that holds it (amortised O(1))
-        int g = c->g_lo[e];
-        double x = c->update_to[e];
-        while (g < G && A.gen_x0[(g + 1) % A.Gcap] <= x) ++g;
-        c->g_lo[e] = g;
+    const int npairs = (E - first) * 6;
+    // All partials of a tile are fetched with independent loads (a serial load-add chain would pay the
+    // full memory latency per term), then each pair is summed in workgroup order from LDS: the result is
+    // bit-identical to the plain serial sum over workgroups.
+    for (int p0 = 0; p0 < npairs; p0 += PF_FIN_PAIRS) {
+        const int np_ = npairs - p0 < PF_FIN_PAIRS ? npairs - p0 : PF_FIN_PAIRS;
+        double run = 0.0;                                   // running sum of pair (p0 + tid), threads < np_
+        for (int b0 = 0; b0 < nb; b0 += PF_FIN_TILE_B) {
+            const int nbt = nb - b0 < PF_FIN_TILE_B ? nb - b0 : PF_FIN_TILE_B;
+            for (int idx = tid; idx < np_ * nbt; idx += nthreads) {
+                int pp = idx / nbt, b = idx % nbt;
+                int pair = p0 + pp;
+                int e = first + pair / 6, k = pair % 6;
+                stage[pp * PF_FIN_TILE_B + b] = A.partial[((size_t)e * A.nbx + b0 + b) * 6 + k];
+            }
+            __syncthreads();
+            if (tid < np_)
+                for (int b = 0; b < nbt; ++b) run += stage[tid * PF_FIN_TILE_B + b];
+            __syncthreads();
+        }
+        if (tid < np_) {
+            int pair = p0 + tid;
+            int e = first + pair / 6, k = pair % 6;
+            A.totals[(size_t)k * E + e] += run;
+        }
     }
     __syncthreads();
     if (tid == 0) {
-        c->delayed_opp += c->update_to[E - 1] - c->counted_to[E - 1];
-        for (int e = 0; e < E; ++e) c->counted_to[e] = c->update_to[e];
-        int gr = c->g_lo[0];
-        for (int e = 1; e < E; ++e) gr = c->g_lo[e] < gr ? c->g_lo[e] : gr;
-        c->g_retain = gr;
         c->first_epoch = E;
         c->count_active = 0;
         c->pending_fin = 0;
@@ -718,21 +738,56 @@ __device__ void finalize_counts(const KArgs& A, Ctrl* c, int tid, int nthreads) 
     __syncthreads();
 }
 
-// ------------------------------------------------------------------ k_decide (single workgroup)
-// normalize_probability (pc.cpp:420-438), the ESS test of resample (pc.cpp:247-283),
-// systematic_resampling (pc.cpp:474-504) and the window bookkeeping of
-// extract_and_update_count (count.cpp:355-385).
-__global__ __launch_bounds__(PF_DECIDE_BS) void k_decide(KArgs A, long long s, int mode, int do_count, int end_data) {
-    __shared__ double l2_post[64], l2_sq[64], l2_tot[64], l2_totp[64], base[64], basep[64];
-    __shared__ double sh_T, sh_S1, sh_S2, sh_u, sh_pos;
-    __shared__ int sh_flag, sh_G;
-    __shared__ int wmax[PF_DECIDE_BS / 64];
+// generation bookkeeping for the windows of the coming count step: g_lo[e] / g_hi[e] = generations
+// that hold the window ends (both monotone along the sweep: amortised O(1) per step)
+__device__ void window_generations(const KArgs& A, Ctrl* c, const Windows& W, int tid) {
+    const int E = A.E;
+    const int G = c->gen_prev;
+    if (tid < E) {
+        const int e = tid;
+        int g = c->g_lo[e];
+        while (g < G && A.gen_x0[(g + 1) % A.Gcap] <= W.a[e]) ++g;
+        c->g_lo[e] = g;
+        if (e >= W.first) {
+            int h = c->g_hi[e];
+            if (h < g) h = g;
+            while (h < G && A.gen_x0[(h + 1) % A.Gcap] < W.b[e]) ++h;
+            c->g_hi[e] = h;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int gr = c->g_lo[0];
+        for (int e = 1; e < E; ++e) gr = c->g_lo[e] < gr ? c->g_lo[e] : gr;
+        c->g_retain = gr;
+        c->delayed_opp += W.b[E - 1] - W.a[E - 1];
+        c->first_epoch = W.first;
+        c->count_active = W.first < E;
+        c->pending_fin = W.first < E;
+        c->nbx_used = A.nbx;
+    }
+}
+
+// ------------------------------------------------------------------ k_decide (2 workgroups)
+// workgroup 0: normalize_probability (pc.cpp:420-438), the ESS test of resample (pc.cpp:247-283),
+//              systematic_resampling (pc.cpp:474-504) -> offspring table + parent table
+// workgroup 1: count bookkeeping (previous step's partials, generations of the new windows)
+__global__ __launch_bounds__(PF_DECIDE_BS) void k_decide(KArgs A, long long s, int mode, Windows W) {
+    __shared__ double l2s[4096];          // level-2 inclusive scan of the per-wavefront pilot totals
+    __shared__ double l2_post[64], l2_sq[64], l2_tot[64], l2_totp[64];
+    __shared__ int wmax[PF_DECIDE_BS / 64], wmax2[PF_DECIDE_BS / 64];
+    __shared__ unsigned short l2s_u16[2 * (PF_DECIDE_BS * PF_DECIDE_PER + 8)];   // lo / parent tables (fast path)
     Ctrl* c = A.ctrl;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = PF_DECIDE_BS / 64;
+    if (blockIdx.x == 1) {
+        if (c->pending_fin) finalize_counts(A, c, tid, PF_DECIDE_BS, l2s);
+        window_generations(A, c, W, tid);
+        return;
+    }
     const long long Np = A.Np;
     const int nc = (int)((Np + 63) / 64);
     const int ng = (nc + 63) / 64;
-    if (c->pending_fin) finalize_counts(A, c, tid, PF_DECIDE_BS);
+    const double last_scan1 = A.scan1[Np - 1];
     // level 2 of the canonical radix-64 reduction / scans
     for (int g = wave; g < ng; g += nwaves) {
         int ch = g * 64 + lane;
@@ -744,149 +799,196 @@ __global__ __launch_bounds__(PF_DECIDE_BS) void k_decide(KArgs A, long long s, i
         double rs = wave_tree_sum(vs);
         double sc = wave_hs_scan(vl, lane);
         double scq = wave_hs_scan(vq, lane);
-        if (ch < nc) { A.l2scan[ch] = sc; A.l2scanp[ch] = scq; }
+        if (ch < nc) { l2s[ch] = sc; A.l2scanp[ch] = scq; }
         if (lane == 63) { l2_post[g] = rp; l2_sq[g] = rs; l2_tot[g] = sc; l2_totp[g] = scq; }
     }
     __syncthreads();
-    if (wave == 0) {
+    // level 3, redundantly in every thread (at most 64 group totals): no further barrier needed
+    double T, S2;
+    {
         double vp = lane < ng ? l2_post[lane] : 0.0;
         double vs = lane < ng ? l2_sq[lane] : 0.0;
-        double T = wave_tree_sum(vp);
-        double S2 = wave_tree_sum(vs);
-        if (lane == 0) {
-            double run = 0.0, runp = 0.0;
-            for (int g = 0; g < ng; ++g) {
-                base[g] = run; run = run + l2_tot[g];
-                basep[g] = runp; runp = runp + l2_totp[g];
-            }
-            sh_T = T; sh_S2 = S2;
-        }
+        T = wave_tree_sum(vp);
+        S2 = wave_tree_sum(vs);
     }
-    __syncthreads();
+    auto chunk_offset = [&](int ch) -> double {
+        double run = 0.0;
+        const int gq = ch / 64;
+        for (int g = 0; g < gq; ++g) run = run + l2_tot[g];
+        double off = (ch % 64 == 0) ? 0.0 : l2s[ch - 1];
+        return run + off;
+    };
     for (int ch = tid; ch < nc; ch += PF_DECIDE_BS) {
-        double off = (ch % 64 == 0) ? 0.0 : A.l2scan[ch - 1];
-        double co = base[ch / 64] + off;
-        A.chunk_off[ch] = co;
+        A.chunk_off[ch] = chunk_offset(ch);
+        double runp = 0.0;
+        for (int g = 0; g < ch / 64; ++g) runp = runp + l2_totp[g];
         double offp = (ch % 64 == 0) ? 0.0 : A.l2scanp[ch - 1];
-        A.chunk_offp[ch] = basep[ch / 64] + offp;
-        if (ch == nc - 1) sh_S1 = co + A.scan1[Np - 1];   // inclusive scan at the last particle (= oracle incl[N-1])
+        A.chunk_offp[ch] = runp + offp;
     }
-    __syncthreads();
+    const double S1 = chunk_offset(nc - 1) + last_scan1;   // inclusive scan at the last particle (= oracle incl[N-1])
+    const double ess = (S1 * S1) / S2;
+    const int flag = (mode == 0 && ess < A.ess_threshold - 1e-6) ? 1 : 0;
+    const int G = c->gen;
+    double pos = A.L;
+    if (mode == 0) {
+        double seg_end = A.seg_start[s] + A.seg_len[s];
+        pos = seg_end < A.L ? seg_end : A.L;
+    }
+    const unsigned long long n_res = (unsigned long long)c->n_resample;
+    const double u = flag ? philox_uniform(A.seed, 0xFFFFFFFFu, 1, n_res) : 0.0;
     if (tid == 0) {
-        double T = sh_T;
-        double S1 = sh_S1;
-        double S2 = sh_S2;
         if (!(T > 0.0)) c->err = ERR_ZERO_PROB;
         double logl = c->logl + dlog(T);
         c->logl = logl;
         double inv = 1.0 / T;
-        double ess = (S1 * S1) / S2;
-        int flag = 0;
-        double u = 0.0;
-        double pos = A.L;
         if (mode == 0) {
-            flag = ess < A.ess_threshold - 1e-6 ? 1 : 0;
-            if (flag) u = philox_uniform(A.seed, 0xFFFFFFFFu, 1, (unsigned long long)c->n_resample);
             A.tr_T[s] = T;
             A.tr_ess[s] = ess;
             A.tr_flag[s] = flag;
             A.tr_logl[s] = logl;
-            double seg_end = A.seg_start[s] + A.seg_len[s];
-            pos = seg_end < A.L ? seg_end : A.L;
             c->cur_pos = pos;
         }
         c->T = T; c->inv_T = inv; c->S1 = S1; c->S2 = S2; c->ess = ess; c->u = u; c->flag = flag;
-        sh_u = u; sh_flag = flag; sh_pos = pos;
-        sh_G = c->gen;
-    }
-    __syncthreads();
-    const int flag = sh_flag;
-    const double S1 = sh_S1;
-    const int G = sh_G;
-    // ---- windows of this count step (count.cpp:363-385), one lane per epoch ----
-    if (wave == 0) {
-        int first = A.E;
-        if (do_count) {
-            const int e = lane;
-            const bool valid = e < A.E;
-            double lagging = 0.0, x_end = 0.0, cto = 0.0;
-            bool wants = false;
-            if (valid) {
-                lagging = end_data ? 0.0 : A.lags[e];
-                x_end = sh_pos - lagging;
-                cto = c->counted_to[e];
-                wants = !((x_end - cto) < lagging * 0.1);
-            }
-            unsigned long long bal = __ballot(wants);
-            first = bal ? (int)__ffsll((long long)bal) - 1 : A.E;
-            if (valid) {
-                bool upd = e >= first;
-                c->update_to[e] = upd ? x_end : cto;
-                if (upd) {
-                    // generation holding the upper end of the window (monotone: amortised O(1))
-                    int g = c->g_hi[e];
-                    int glo = c->g_lo[e];
-                    if (g < glo) g = glo;
-                    while (g < G && A.gen_x0[(g + 1) % A.Gcap] < x_end) ++g;
-                    c->g_hi[e] = g;
-                }
-            }
-        }
-        if (lane == 0) {
-            c->first_epoch = first;
-            c->count_active = first < A.E;
-            c->pending_fin = first < A.E;
-            c->nbx_used = A.nbx;
-        }
     }
 
-    // ---- offspring table lo[0..Np] of systematic resampling (closed form, monotone) + parent table ----
+    // ---- offspring table lo[0..Np] of systematic resampling (closed form, monotone), parent table and
+    //      the run list of the generation that ends here (its survivors) ----
     if (flag) {
         int* lo = A.lo + (size_t)(G % A.Gcap) * (Np + 1);
-        const double u = sh_u;
+        int* rst = A.run_st + (size_t)(G % A.Gcap) * Np;
+        int* ran = A.run_anc + (size_t)(G % A.Gcap) * Np;
         const double dn = (double)Np;
         const long long per = (Np + PF_DECIDE_BS - 1) / PF_DECIDE_BS;
         const long long i0 = (long long)tid * per;
         const long long i1 = i0 + per < Np ? i0 + per : Np;
-        int run = 0;
-        for (long long i = i0; i < i1; ++i) {
-            int v = 0;
-            if (i > 0) {
-                double incl = A.chunk_off[(i - 1) >> 6] + A.scan1[i - 1];
-                double cum = incl / S1;
-                double guess = floor(cum * dn - u);
-                long long g = guess < 0 ? 0 : (guess > dn ? Np : (long long)guess);
-                while (g > 0 && !((((double)(g - 1)) + u) / dn < cum)) --g;
-                while (g < Np && ((((double)g) + u) / dn < cum)) ++g;
-                v = (int)g;
+        // lo_raw(i) = #{ j in [0,N) : (j+u) * S1 < N * incl[i-1] }  -- the comparison of pc.cpp:491 with both
+        // sides multiplied by N*S1, so that no division is needed (exact predicate, guess corrected by it)
+        const double invS1 = 1.0 / S1;
+        auto lo_raw = [&](long long i, double sc1) -> int {
+            if (i == 0) return 0;
+            double incl = chunk_offset((int)((i - 1) >> 6)) + sc1;
+            double rhs = dn * incl;
+            double guess = floor(rhs * invS1 - u);
+            long long g = guess < 0 ? 0 : (guess > dn ? Np : (long long)guess);
+            while (g > 0 && !((((double)(g - 1)) + u) * S1 < rhs)) --g;
+            while (g < Np && ((((double)g) + u) * S1 < rhs)) ++g;
+            return (int)g;
+        };
+        if (per <= PF_DECIDE_PER) {
+            // fast path: the thread's slice lives in registers; all global loads are issued up front
+            // (a load per loop iteration behind a store would serialise ~1 us of latency each)
+            double sc1[PF_DECIDE_PER];
+            int v[PF_DECIDE_PER];
+#pragma unroll
+            for (int k = 0; k < PF_DECIDE_PER; ++k) {
+                long long i = i0 + k;
+                sc1[k] = (i < i1 && i > 0) ? A.scan1[i - 1] : 0.0;
             }
-            run = v > run ? v : run;
-            lo[i] = run;      // running max inside this thread's block; fixed up below
-        }
-        // block-wide inclusive max-scan of the per-thread maxima
-        int sc = wave_max_scan_i(run, lane);
-        if (lane == 63) wmax[wave] = sc;
-        __syncthreads();
-        int prefix = 0;
-        for (int w = 0; w < wave; ++w) prefix = max(prefix, wmax[w]);
-        int before = __shfl_up(sc, 1, 64);
-        if (lane > 0) prefix = max(prefix, before);
-        for (long long i = i0; i < i1; ++i) lo[i] = max(lo[i], prefix);
-        if (tid == 0) lo[Np] = (int)Np;
-        __syncthreads();
-        // parent of every new slot: offspring of i occupy [lo[i], lo[i+1])
-        for (long long i = i0; i < i1; ++i) {
-            int q1 = lo[i + 1];
-            for (int q = lo[i]; q < q1; ++q) A.parent[q] = (int)i;
+            int run = 0;
+#pragma unroll
+            for (int k = 0; k < PF_DECIDE_PER; ++k) {
+                long long i = i0 + k;
+                int val = i < i1 ? lo_raw(i, sc1[k]) : 0;
+                run = val > run ? val : run;
+                v[k] = run;
+            }
+            int sc = wave_max_scan_i(run, lane);
+            if (lane == 63) wmax[wave] = sc;
+            __syncthreads();
+            int prefix = 0;
+            for (int w = 0; w < wave; ++w) prefix = max(prefix, wmax[w]);
+            int before = __shfl_up(sc, 1, 64);
+            if (lane > 0) prefix = max(prefix, before);
+            // the table goes through LDS (16-bit entries, Np <= 16384) so that every global store below is
+            // coalesced: uncoalesced 4-byte stores from this single workgroup were the bottleneck
+            unsigned short* lo16 = (unsigned short*)l2s_u16;
+            unsigned short* par16 = lo16 + PF_DECIDE_BS * PF_DECIDE_PER + 8;
+#pragma unroll
+            for (int k = 0; k < PF_DECIDE_PER; ++k) {
+                v[k] = max(v[k], prefix);
+                if (i0 + k < i1) lo16[i0 + k] = (unsigned short)v[k];
+            }
+            if (tid == 0) lo16[Np] = (unsigned short)Np;
+            __syncthreads();
+            // survivors of this slice -> run list of generation G (start = lo[i], ancestor = i); parents -> LDS
+            int nsurv = 0;
+#pragma unroll
+            for (int k = 0; k < PF_DECIDE_PER; ++k) {
+                long long i = i0 + k;
+                if (i < i1) {
+                    int hi = lo16[i + 1];
+                    nsurv += hi > v[k] ? 1 : 0;
+                    for (int q = v[k]; q < hi; ++q) par16[q] = (unsigned short)i;
+                }
+            }
+            int incl = nsurv;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                int o = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += o;
+            }
+            if (lane == 63) wmax2[wave] = incl;
+            __syncthreads();
+            int wbase = 0, total = 0;
+            for (int w = 0; w < nwaves; ++w) { if (w < wave) wbase += wmax2[w]; total += wmax2[w]; }
+            int pos = wbase + incl - nsurv;
+#pragma unroll
+            for (int k = 0; k < PF_DECIDE_PER; ++k) {
+                long long i = i0 + k;
+                if (i < i1) {
+                    int hi = lo16[i + 1];
+                    if (hi > v[k]) { rst[pos] = v[k]; ran[pos] = (int)i; ++pos; }
+                }
+            }
+            for (long long i = tid; i <= Np; i += PF_DECIDE_BS) lo[i] = lo16[i];
+            for (long long q = tid; q < Np; q += PF_DECIDE_BS) A.parent[q] = par16[q];
+            if (tid == 0) A.nruns[G % A.Gcap] = total;
+        } else {
+            // generic path (Np > PF_DECIDE_BS * PF_DECIDE_PER)
+            int run = 0;
+            for (long long i = i0; i < i1; ++i) {
+                int val = lo_raw(i, i > 0 ? A.scan1[i - 1] : 0.0);
+                run = val > run ? val : run;
+                lo[i] = run;
+            }
+            int sc = wave_max_scan_i(run, lane);
+            if (lane == 63) wmax[wave] = sc;
+            __syncthreads();
+            int prefix = 0;
+            for (int w = 0; w < wave; ++w) prefix = max(prefix, wmax[w]);
+            int before = __shfl_up(sc, 1, 64);
+            if (lane > 0) prefix = max(prefix, before);
+            for (long long i = i0; i < i1; ++i) lo[i] = max(lo[i], prefix);
+            if (tid == 0) lo[Np] = (int)Np;
+            __syncthreads();
+            int nsurv = 0;
+            for (long long i = i0; i < i1; ++i) nsurv += lo[i + 1] > lo[i] ? 1 : 0;
+            int incl = nsurv;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                int o = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += o;
+            }
+            if (lane == 63) wmax2[wave] = incl;
+            __syncthreads();
+            int wbase = 0, total = 0;
+            for (int w = 0; w < nwaves; ++w) { if (w < wave) wbase += wmax2[w]; total += wmax2[w]; }
+            int pos = wbase + incl - nsurv;
+            for (long long i = i0; i < i1; ++i) {
+                int q0 = lo[i], q1 = lo[i + 1];
+                if (q1 > q0) { rst[pos] = q0; ran[pos] = (int)i; ++pos; }
+                for (int q = q0; q < q1; ++q) A.parent[q] = (int)i;
+            }
+            if (tid == 0) A.nruns[G % A.Gcap] = total;
         }
         if (tid == 0) {
             // toggle buffers / open the next generation
-            int ev = (int)c->n_resample;
+            int ev = (int)n_res;
             if (ev < A.max_trace_events) A.ev_seg[ev] = (int)s;
             c->cur ^= 1;
             c->gen = G + 1;
-            A.gen_x0[(G + 1) % A.Gcap] = sh_pos;
-            c->n_resample += 1;
+            A.gen_x0[(G + 1) % A.Gcap] = pos;
+            c->n_resample = (long long)n_res + 1;
             if (G + 1 - c->g_retain >= A.Gcap - 1) c->err = ERR_GEN_OVERFLOW;
         }
     }
@@ -906,53 +1008,64 @@ __device__ __forceinline__ double ovl(double a0, double a1, double b0, double b1
 }
 
 // sum_i (nl - i) * |[S_{i-1}, S_i] n [max(T0,lo_t), min(T1,hi_t)]|, optionally including the single
-// lineage above the top node (coalescence paths)
-__device__ __forceinline__ double slice_len(const double* S, int nint, int nl, double T0, double T1, double lo_t, double hi_t,
-                                            bool above_top) {
+// lineage above the top node (coalescence paths).  S lives in registers (NI compile-time).
+template <int NI>
+__device__ __forceinline__ double slice_len(const double (&S)[NI], int nint, int nl, double T0, double T1, double lo_t,
+                                            double hi_t, bool above_top) {
     double a = T0 > lo_t ? T0 : lo_t;
     double b = T1 < hi_t ? T1 : hi_t;
     if (!(b > a)) return 0.0;
     double acc = 0.0, prev = 0.0;
-    for (int i = 0; i < nint; ++i) {
-        double top = S[i];
-        acc += (double)(nl - i) * ovl(prev, top, a, b);
-        prev = top;
-    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+        if (i < nint) {
+            double top = S[i];
+            acc += (double)(nl - i) * ovl(prev, top, a, b);
+            prev = top;
+        }
     if (above_top) acc += (double)(nl - nint) * ovl(prev, PF_INF, a, b);
     return acc;
 }
 
 struct Win { int e, rf; double T0, T1, a_e, b_e; bool end_seq; };
 
+template <int NI>
 __device__ __forceinline__ void stretch_contrib(Acc& acc, const KArgs& A, const Win& W, double w, double x0, double x1,
-                                                const double* S, int lim_start) {
+                                                const double (&S)[NI], int lim_start) {
     if (!(W.rf & REC_RECOMB) || W.e > lim_start) return;
     double xs = ovl(x0, x1, W.a_e, W.b_e);
     if (!(xs > 0.0)) return;
-    double len = slice_len(S, A.n - 1, A.n, W.T0, W.T1, 0.0, PF_INF, false);
+    double len = slice_len<NI>(S, A.n - 1, A.n, W.T0, W.T1, 0.0, PF_INF, false);
     double opp = len * xs;
     acc.ro += w * opp;
     acc.rw += w * w * opp;
 }
 
+// All fields of a record are fetched in one round of independent loads before anything is tested:
+// the kernel is bound by dependent-load latency, not by bytes.
+template <int NI>
 __device__ __forceinline__ void records_contrib(Acc& acc, const KArgs& A, const Win& W, double w, long long a, unsigned k0,
                                                 unsigned k1) {
+    const int n = A.n;
     for (unsigned k = k0; k != k1; ++k) {
         const double* rec = rec_ptr(A, a, k);
-        double x0 = rec[0], x1 = rec[1];
+        double f0 = rec[0], f1 = rec[1], f2 = rec[2], f3 = rec[3], f4 = rec[4];
+        double S[NI];
+#pragma unroll
+        for (int r = 0; r < NI; ++r) S[r] = r < n - 1 ? rec[5 + r] : 0.0;
+        double x0 = f0, x1 = f1;
         if (x1 < W.a_e) continue;      // consumed by earlier windows
-        unsigned long long meta = (unsigned long long)__double_as_longlong(rec[4]);
+        unsigned long long meta = (unsigned long long)__double_as_longlong(f4);
         int type = (int)(meta & 0xff);
         int lim_start = (int)((meta >> 8) & 0xff) - 1;
         int lim_event = (int)((meta >> 16) & 0xff) - 1;
         int n_eff = (int)((meta >> 24) & 0xff);
-        const double* S = rec + 5;
-        if (type <= 1) stretch_contrib(acc, A, W, w, x0, x1, S, lim_start);
+        if (type <= 1) stretch_contrib<NI>(acc, A, W, w, x0, x1, S, lim_start);
         if (type == 0 || type == 2) {
-            double h = rec[2], tc = rec[3];
+            double h = f2, tc = f3;
             bool inwin = (W.a_e <= x1) && (x1 < W.b_e);
             if (inwin && (W.rf & REC_COALMIGR) && W.e <= lim_event) {
-                double opp = slice_len(S, n_eff - 1, n_eff, W.T0, W.T1, h, tc, true);
+                double opp = slice_len<NI>(S, n_eff - 1, n_eff, W.T0, W.T1, h, tc, true);
                 acc.co += w * opp;
                 acc.cw += w * w * opp;
                 if (W.T0 <= tc && tc < W.T1) acc.cc += w;
@@ -965,11 +1078,35 @@ __device__ __forceinline__ void records_contrib(Acc& acc, const KArgs& A, const 
     }
 }
 
-__global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0) {
+#define PF_CNT_TILE 2048      // generations whose run counts are staged in LDS at a time
+#define PF_CNT_WIDE 128       // run lists longer than this are strided over by the whole grid column
+
+template <int NI>
+__device__ __forceinline__ void count_run(Acc& acc, const KArgs& A, const Win& W, int g, long long i, int nr, const int* rst,
+                                          const int* ran, double inv) {
+    const long long Np = A.Np;
+    int q0 = rst[i];
+    int q1 = i + 1 < nr ? rst[i + 1] : (int)Np;
+    long long a = ran[i];
+    // posterior mass of the descendants of (g, a): difference of the inclusive posterior scan
+    double hi = A.chunk_offp[(q1 - 1) >> 6] + A.scanp[q1 - 1];
+    double lo = q0 > 0 ? A.chunk_offp[(q0 - 1) >> 6] + A.scanp[q0 - 1] : 0.0;
+    double w = (hi - lo) * inv;
+    if (!(w > 0.0)) return;
+    unsigned k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
+    unsigned k1 = A.gstart[(size_t)((g + 1) % A.Gcap) * Np + a];
+    if (A.widx[a] - k0 > A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;
+    records_contrib<NI>(acc, A, W, w, a, k0, k1);
+}
+
+template <int NM>
+__global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0, Windows Wn) {
+    constexpr int NI = NM - 1;
     __shared__ Acc red[PF_BS / 64];
+    __shared__ int s_nr[PF_CNT_TILE];
     const Ctrl* c = A.ctrl;
     const int e = e0 + blockIdx.y;
-    const int first = c->first_epoch;
+    const int first = Wn.first;
     if (e < first || e >= A.E) return;
     const long long Np = A.Np;
     const int n = A.n;
@@ -979,43 +1116,51 @@ __global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0) {
     Win W;
     W.e = e; W.rf = A.recflags[e];
     W.T0 = A.T[e]; W.T1 = e + 1 < A.E ? A.T[e + 1] : PF_INF;
-    W.a_e = c->counted_to[e]; W.b_e = c->update_to[e];
+    W.a_e = Wn.a[e]; W.b_e = Wn.b[e];
     W.end_seq = (A.L == W.b_e);
     const int g_lo = c->g_lo[e], g_hi = c->g_hi[e];
+    const int lane = threadIdx.x & 63;
     const long long gtid = (long long)blockIdx.x * PF_BS + threadIdx.x;
     const long long nthreads = (long long)gridDim.x * PF_BS;
+    const int my_wave = (int)(gtid >> 6);
+    const int total_waves = (int)(nthreads >> 6);
     Acc acc = {0, 0, 0, 0, 0, 0};
-    for (int g = g_hi; g >= g_lo; --g) {
-        if (g == G) {
-            // live particles: their own weight, their open stretch, the records they wrote this generation
-            for (long long a = gtid; a < Np; a += nthreads) {
-                double w = st.w_post[a] * inv;
-                if (w == 0.0) continue;
-                double S[PF_NMAX - 1];
-                for (int r = 0; r < n - 1; ++r) S[r] = st.S[(size_t)r * Np + a];
-                stretch_contrib(acc, A, W, w, st.x_mark[a], PF_INF, S, st.mark_limit[a]);
-                unsigned k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
-                unsigned k1 = A.widx[a];
-                if (k1 - k0 > A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;
-                records_contrib(acc, A, W, w, a, k0, k1);
-            }
-        } else {
-            const int nr = A.nruns[g % A.Gcap];
-            const int* rst = A.run_st + (size_t)(g % A.Gcap) * Np;
-            const int* ran = A.run_anc + (size_t)(g % A.Gcap) * Np;
-            for (long long i = gtid; i < nr; i += nthreads) {
-                int q0 = rst[i];
-                int q1 = i + 1 < nr ? rst[i + 1] : (int)Np;
-                long long a = ran[i];
-                // posterior mass of the descendants of (g, a): difference of the inclusive posterior scan
-                double hi = A.chunk_offp[(q1 - 1) >> 6] + A.scanp[q1 - 1];
-                double lo = q0 > 0 ? A.chunk_offp[(q0 - 1) >> 6] + A.scanp[q0 - 1] : 0.0;
-                double w = (hi - lo) * inv;
-                if (!(w > 0.0)) continue;
-                unsigned k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
-                unsigned k1 = A.gstart[(size_t)((g + 1) % A.Gcap) * Np + a];
-                if (A.widx[a] - k0 > A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;
-                records_contrib(acc, A, W, w, a, k0, k1);
+    for (int tile_hi = g_hi; tile_hi >= g_lo; tile_hi -= PF_CNT_TILE) {
+        const int tile_lo = tile_hi - PF_CNT_TILE + 1 > g_lo ? tile_hi - PF_CNT_TILE + 1 : g_lo;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx <= tile_hi - tile_lo; idx += PF_BS) {
+            int g = tile_hi - idx;
+            s_nr[idx] = g == G ? -1 : A.nruns[g % A.Gcap];
+        }
+        __syncthreads();
+        for (int idx = 0; idx <= tile_hi - tile_lo; ++idx) {
+            const int g = tile_hi - idx;
+            const int nr = s_nr[idx];
+            if (nr < 0) {
+                // live particles: their own weight, their open stretch, the records they wrote this generation
+                for (long long a = gtid; a < Np; a += nthreads) {
+                    double w = st.w_post[a] * inv;
+                    double S[NI];
+#pragma unroll
+                    for (int r = 0; r < NI; ++r) S[r] = r < n - 1 ? st.S[(size_t)r * Np + a] : 0.0;
+                    double xm = st.x_mark[a];
+                    int ml = st.mark_limit[a];
+                    unsigned k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
+                    unsigned k1 = A.widx[a];
+                    if (w == 0.0) continue;
+                    stretch_contrib<NI>(acc, A, W, w, xm, PF_INF, S, ml);
+                    if (k1 - k0 > A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;
+                    records_contrib<NI>(acc, A, W, w, a, k0, k1);
+                }
+            } else if (nr > PF_CNT_WIDE) {
+                const int* rst = A.run_st + (size_t)(g % A.Gcap) * Np;
+                const int* ran = A.run_anc + (size_t)(g % A.Gcap) * Np;
+                for (long long i = gtid; i < nr; i += nthreads) count_run<NI>(acc, A, W, g, i, nr, rst, ran, inv);
+            } else if (g % total_waves == my_wave) {
+                // short list: one wavefront takes the whole generation, so a deep window costs no serial launches
+                const int* rst = A.run_st + (size_t)(g % A.Gcap) * Np;
+                const int* ran = A.run_anc + (size_t)(g % A.Gcap) * Np;
+                for (long long i = lane; i < nr; i += 64) count_run<NI>(acc, A, W, g, i, nr, rst, ran, inv);
             }
         }
     }
@@ -1036,8 +1181,9 @@ __global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0) {
 }
 
 __global__ void k_count_fin(KArgs A) {
+    __shared__ double stage[PF_FIN_PAIRS * PF_FIN_TILE_B];
     Ctrl* c = A.ctrl;
-    if (c->pending_fin) finalize_counts(A, c, threadIdx.x, blockDim.x);
+    if (c->pending_fin) finalize_counts(A, c, threadIdx.x, blockDim.x, stage);
 }
 
 // ------------------------------------------------------------------ k_resample (+ ledger blocks)
@@ -1045,52 +1191,120 @@ __global__ void k_count_fin(KArgs A) {
 // implement_resampling (pc.cpp:321-392) as a gather from the old buffer into the new one.
 // Blocks [nblocks, gridDim.x): after a resampling, re-base the run-length encoded composite
 // ancestor maps of all retained generations onto the new slots (st' = lo[st], empty runs dropped).
+#define PF_LEDGER_TILE 4096   // runs compacted per LDS tile (32 KB of staging)
+#define PF_LEDGER_PER (PF_LEDGER_TILE / PF_BS)
+#define PF_LEDGER_NEW 64      // the newest generations (long run lists) are re-based by a whole workgroup each
+
 __device__ void ledger_update(const KArgs& A, int lb, int nlb) {
     __shared__ int wcnt[PF_BS / 64];
-    __shared__ int sh_base;
+    __shared__ int stage[2 * PF_LEDGER_TILE];
+    __shared__ int stage_in[PF_BS * (PF_LEDGER_PER + 1)];
     const Ctrl* c = A.ctrl;
     const long long Np = A.Np;
     const int G = c->gen - 1;                      // the generation that just ended
     const int* lo = A.lo + (size_t)(G % A.Gcap) * (Np + 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int g = c->g_retain + lb; g <= G; g += nlb) {
+    const int g_ret = c->g_retain;
+    // ---- pass 1: workgroup per generation, newest PF_LEDGER_NEW generations (G itself: written by k_decide) ----
+    // Blocked compaction: every thread owns a contiguous slice of the run list (count, one workgroup
+    // scan, write), the survivors are staged in LDS and copied back, so a list of any length costs two
+    // barriers instead of one per 256 runs.  Loads are issued in batches of 8 independent requests.
+    for (int k = 1 + lb; k < PF_LEDGER_NEW; k += nlb) {
+        const int g = G - k;
+        if (g < g_ret) break;
         int* rst = A.run_st + (size_t)(g % A.Gcap) * Np;
         int* ran = A.run_anc + (size_t)(g % A.Gcap) * Np;
-        const bool ident = (g == G);
-        const int nr = ident ? (int)Np : A.nruns[g % A.Gcap];
-        if (tid == 0) sh_base = 0;
-        __syncthreads();
-        for (int off = 0; off < nr; off += PF_BS) {
-            int i = off + tid;
+        const int nr = A.nruns[g % A.Gcap];
+        int out_base = 0;
+        for (int tile0 = 0; tile0 < nr; tile0 += PF_LEDGER_TILE) {
+            const int tile_n = nr - tile0 < PF_LEDGER_TILE ? nr - tile0 : PF_LEDGER_TILE;
+            const int per = (tile_n + PF_BS - 1) / PF_BS;
+            const int i0 = tile0 + tid * per;
+            const int i1 = i0 + per < tile0 + tile_n ? i0 + per : tile0 + tile_n;
+            // phase A: new starts of the slice (+1 sentinel) into LDS staging, 8 loads in flight
+            int cntk = 0;
+            int* my = stage_in + (size_t)tid * (PF_LEDGER_PER + 1);
+            for (int b = i0; b <= i1; b += 8) {
+                int st8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    int i = b + j;
+                    st8[j] = i <= i1 ? (i < nr ? rst[i] : (int)Np) : 0;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    int i = b + j;
+                    if (i <= i1) my[i - i0] = lo[st8[j]];
+                }
+            }
+            for (int i = i0; i < i1; ++i) cntk += my[i - i0 + 1] > my[i - i0] ? 1 : 0;
+            int incl = cntk;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                int o = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += o;
+            }
+            if (lane == 63) wcnt[wave] = incl;
+            __syncthreads();
+            int wbase = 0, total = 0;
+            for (int w = 0; w < PF_BS / 64; ++w) { if (w < wave) wbase += wcnt[w]; total += wcnt[w]; }
+            int pos = wbase + incl - cntk;
+            for (int b = i0; b < i1; b += 8) {
+                int an8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) an8[j] = b + j < i1 ? ran[b + j] : 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    int i = b + j;
+                    if (i < i1) {
+                        int ns = my[i - i0];
+                        if (my[i - i0 + 1] > ns) { stage[2 * pos] = ns; stage[2 * pos + 1] = an8[j]; ++pos; }
+                    }
+                }
+            }
+            __syncthreads();                 // all inputs of this tile are read, survivors sit in LDS
+            for (int j = tid; j < total; j += PF_BS) {
+                rst[out_base + j] = stage[2 * j];
+                ran[out_base + j] = stage[2 * j + 1];
+            }
+            out_base += total;
+            __syncthreads();
+        }
+        if (tid == 0) A.nruns[g % A.Gcap] = out_base;
+    }
+    // ---- pass 2: wavefront per generation for everything older (short lists, no workgroup barriers) ----
+    const int wl = lb * (PF_BS / 64) + wave;
+    const int nwl = nlb * (PF_BS / 64);
+    for (int g = G - PF_LEDGER_NEW - wl; g >= g_ret; g -= nwl) {
+        int* rst = A.run_st + (size_t)(g % A.Gcap) * Np;
+        int* ran = A.run_anc + (size_t)(g % A.Gcap) * Np;
+        const int nr = A.nruns[g % A.Gcap];
+        int base = 0;
+        for (int off = 0; off < nr; off += 64) {
+            int i = off + lane;
             bool valid = i < nr;
             int stv = 0, nxt = 0, anc = 0;
             if (valid) {
-                stv = ident ? i : rst[i];
-                nxt = (i + 1 < nr) ? (ident ? i + 1 : rst[i + 1]) : (int)Np;
-                anc = ident ? i : ran[i];
+                stv = rst[i];
+                nxt = (i + 1 < nr) ? rst[i + 1] : (int)Np;
+                anc = ran[i];
             }
             int ns = valid ? lo[stv] : 0;
             int ne = valid ? lo[nxt] : 0;
             bool keep = valid && ne > ns;
             unsigned long long bal = __ballot(keep);
             int pos = __popcll(bal & ((1ULL << lane) - 1ULL));
-            if (lane == 0) wcnt[wave] = __popcll(bal);
-            __syncthreads();                        // every read of this chunk is done
-            int wbase = 0, total = 0;
-            for (int w = 0; w < PF_BS / 64; ++w) { if (w < wave) wbase += wcnt[w]; total += wcnt[w]; }
-            int base = sh_base;
-            if (keep) { rst[base + wbase + pos] = ns; ran[base + wbase + pos] = anc; }
-            __syncthreads();
-            if (tid == 0) sh_base = base + total;
-            __syncthreads();
+            // all 64 lanes loaded their inputs before anyone stores (stores depend on the ballot)
+            if (keep) { rst[base + pos] = ns; ran[base + pos] = anc; }
+            base += __popcll(bal);
         }
-        if (tid == 0) A.nruns[g % A.Gcap] = sh_base;
-        __syncthreads();
+        if (lane == 0) A.nruns[g % A.Gcap] = base;
     }
 }
 
 __global__ __launch_bounds__(PF_BS) void k_resample(KArgs A, long long s, int nblocks) {
-    const Ctrl* c = A.ctrl;
+    Ctrl* c = A.ctrl;
+    if (blockIdx.x == 0 && threadIdx.x == 0) c->gen_prev = c->gen;
     if ((int)blockIdx.x >= nblocks) {
         if (c->flag) ledger_update(A, (int)blockIdx.x - nblocks, (int)gridDim.x - nblocks);
         return;
@@ -1291,6 +1505,7 @@ struct pf_handle {
     int max_trace_events = 0;
     bool finished = false;
     bool fin_pending = false;     // k_count partials not yet folded into the totals
+    Windows step_windows;         // windows of the step being processed
     bool force_lds = false;       // SMCSMC_PF_FORCE_LDS=1: use the LDS-tree kernel for every n (testing)
     // timing
     int timing_period = 0;
@@ -1517,28 +1732,39 @@ int pf_load_segments(pf_handle* h, const pf_segments* sg) {
     return 0;
 }
 
-// host mirror of the particle-independent window rule (count.cpp:363-385): first epoch updated
-static int host_first_epoch(pf_handle* h, double current_base, bool end_data, bool commit) {
+// the particle-independent window rule of extract_and_update_count (count.cpp:363-385)
+static Windows host_windows(pf_handle* h, double current_base, bool end_data) {
     const int E = h->E;
-    int first = E;
-    std::vector<double> upd(E);
+    Windows W;
+    memset(&W, 0, sizeof(W));
+    W.first = E;
+    W.end_data = end_data ? 1 : 0;
     for (int e = 0; e < E; ++e) {
         double lagging = end_data ? 0.0 : h->h_lags[e];
         double x_end = current_base - lagging;
-        if ((x_end - h->h_counted_to[e]) < lagging * 0.1 && first > e) {
-            upd[e] = h->h_counted_to[e];
+        W.a[e] = h->h_counted_to[e];
+        if ((x_end - h->h_counted_to[e]) < lagging * 0.1 && W.first > e) {
+            W.b[e] = h->h_counted_to[e];
         } else {
-            upd[e] = x_end;
-            first = std::min(first, e);
+            W.b[e] = x_end;
+            W.first = std::min(W.first, e);
         }
     }
-    if (commit) h->h_counted_to = upd;
-    return first;
+    for (int e = 0; e < E; ++e) h->h_counted_to[e] = W.b[e];
+    return W;
 }
 
 static bool timing_on(pf_handle* h, long long s) { return h->timing_period > 0 && (s % h->timing_period) == 0; }
 
-static int launch_update(pf_handle* h, long long s, bool do_count) {
+static Windows no_windows(pf_handle* h) {
+    Windows W;
+    memset(&W, 0, sizeof(W));
+    W.first = h->E;
+    for (int e = 0; e < h->E; ++e) { W.a[e] = h->h_counted_to[e]; W.b[e] = h->h_counted_to[e]; }
+    return W;
+}
+
+static int launch_extend(pf_handle* h, long long s) {
     const bool t = timing_on(h, s);
     {
         Timed tm(h, 0, t);
@@ -1550,21 +1776,31 @@ static int launch_update(pf_handle* h, long long s, bool do_count) {
         else
             hipLaunchKernelGGL(k_extend, dim3(h->nblocks), dim3(PF_BS), h->smem, h->stream, h->A, s);
     }
-    if (check_launch("k_extend")) return -1;
+    return check_launch("k_extend");
+}
+
+static int launch_decide(pf_handle* h, long long s, int mode, const Windows& W) {
+    const bool t = timing_on(h, s);
     {
         Timed tm(h, 1, t);
-        hipLaunchKernelGGL(k_decide, dim3(1), dim3(PF_DECIDE_BS), 0, h->stream, h->A, s, 0, do_count ? 1 : 0, 0);
-        h->fin_pending = false;      // k_decide folds the previous step's partials first
+        hipLaunchKernelGGL(k_decide, dim3(2), dim3(PF_DECIDE_BS), 0, h->stream, h->A, s, mode, W);
+        h->fin_pending = false;      // workgroup 1 folds the previous step's partials
     }
     return check_launch("k_decide");
 }
 
-static int launch_count(pf_handle* h, long long s, int first) {
+static int launch_count(pf_handle* h, long long s, const Windows& W) {
+    const int first = W.first;
     if (first >= h->E) return 0;
     const bool t = timing_on(h, s);
     {
         Timed tm(h, 2, t);
-        hipLaunchKernelGGL(k_count, dim3(h->nblocks, h->E - first), dim3(PF_BS), 0, h->stream, h->A, first);
+        if (h->n <= 4)
+            hipLaunchKernelGGL(k_count<4>, dim3(h->nblocks, h->E - first), dim3(PF_BS), 0, h->stream, h->A, first, W);
+        else if (h->n <= 8)
+            hipLaunchKernelGGL(k_count<8>, dim3(h->nblocks, h->E - first), dim3(PF_BS), 0, h->stream, h->A, first, W);
+        else
+            hipLaunchKernelGGL(k_count<PF_NMAX>, dim3(h->nblocks, h->E - first), dim3(PF_BS), 0, h->stream, h->A, first, W);
         h->fin_pending = true;
     }
     return check_launch("k_count");
@@ -1583,15 +1819,19 @@ static double seg_pos(pf_handle* h, long long s) {
     return std::min(h->h_seg_start[s] + h->h_seg_len[s], h->h_L);
 }
 
+// Single steps.  update and count of one segment share the window set: pf_update_segment evaluates the
+// window rule for segment s (the bookkeeping workgroup of k_decide needs it), pf_count launches the sums.
 int pf_update_segment(pf_handle* h, int64_t s) {
     HIPCHK(hipSetDevice(h->device));
     if (s < 0 || s >= h->n_segs) { g_err = "segment index out of range"; return -1; }
-    return launch_update(h, s, true);
+    h->step_windows = host_windows(h, seg_pos(h, s), false);
+    if (launch_extend(h, s)) return -1;
+    return launch_decide(h, s, 0, h->step_windows);
 }
 int pf_count(pf_handle* h, int64_t s, int end_data) {
     HIPCHK(hipSetDevice(h->device));
-    int first = host_first_epoch(h, seg_pos(h, s), end_data != 0, true);
-    return launch_count(h, s, first);
+    (void)end_data;
+    return launch_count(h, s, h->step_windows);
 }
 int pf_resample(pf_handle* h, int64_t s) {
     HIPCHK(hipSetDevice(h->device));
@@ -1604,9 +1844,10 @@ int pf_run(pf_handle* h, int64_t s_begin, int64_t s_end) {
     HIPCHK(hipSetDevice(h->device));
     if (s_begin < 0 || s_end > h->n_segs) { g_err = "segment range out of bounds"; return -1; }
     for (long long s = s_begin; s < s_end; ++s) {
-        int first = host_first_epoch(h, seg_pos(h, s), false, true);
-        if (launch_update(h, s, true)) return -1;
-        if (launch_count(h, s, first)) return -1;
+        h->step_windows = host_windows(h, seg_pos(h, s), false);
+        if (launch_extend(h, s)) return -1;
+        if (launch_decide(h, s, 0, h->step_windows)) return -1;
+        if (launch_count(h, s, h->step_windows)) return -1;
         if (launch_resample(h, s)) return -1;
         h->seg_done = s + 1;
         if (h->h_seg_start[s] + h->h_seg_len[s] >= h->h_L) break;   // smcsmc.cpp:353-356
@@ -1629,11 +1870,9 @@ int pf_finish(pf_handle* h) {
     HIPCHK(hipSetDevice(h->device));
     // smcsmc.cpp:371: normalize_probability once more, then the lag-free flush (373)
     hipLaunchKernelGGL(k_partials, dim3(h->nblocks), dim3(PF_BS), 0, h->stream, h->A);
-    int first = host_first_epoch(h, h->h_L, true, true);
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(PF_DECIDE_BS), 0, h->stream, h->A, (long long)0, 1, 1, 1);
-    h->fin_pending = false;
-    if (check_launch("k_decide(final)")) return -1;
-    if (launch_count(h, 0, first)) return -1;
+    h->step_windows = host_windows(h, h->h_L, true);
+    if (launch_decide(h, 0, 1, h->step_windows)) return -1;
+    if (launch_count(h, 0, h->step_windows)) return -1;
     if (launch_resample(h, 0)) return -1;    // flag == 0 in mode 1: in-place normalisation
     h->finished = true;
     return pf_sync(h);
@@ -1809,7 +2048,7 @@ static int test_reduce_impl(const double* x, int64_t n, double* out_sum, double*
         hipMemcpyAsync(h->A.st[0].w_pilot, x, n * 8, hipMemcpyHostToDevice, h->stream);
         hipLaunchKernelGGL(k_partials, dim3(h->nblocks), dim3(PF_BS), 0, h->stream, h->A);
         // override u by running k_decide in mode 0 and then patching: simpler -- write u after the fact
-        hipLaunchKernelGGL(k_decide, dim3(1), dim3(PF_DECIDE_BS), 0, h->stream, h->A, (long long)0, lo ? 0 : 1, 0, 0);
+        hipLaunchKernelGGL(k_decide, dim3(2), dim3(PF_DECIDE_BS), 0, h->stream, h->A, (long long)0, lo ? 0 : 1, no_windows(h));
         hipStreamSynchronize(h->stream);
         Ctrl c;
         hipMemcpy(&c, h->A.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost);

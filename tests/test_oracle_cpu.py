@@ -79,9 +79,8 @@ def test_systematic_resampling_matches_serial_reference_walk(oracle):
         partial = np.concatenate([[0.0], incl])
         counts = np.zeros(n, int)
         j = 0
-        for k in range(n):                       # sample k has quantile (k+u)/n
-            uk = (k + u) / n
-            while j + 1 < n and not (partial[j + 1] / partial[n] > uk):
+        for k in range(n):                       # sample k has quantile (k+u)/n; pc.cpp:491 scaled by n*total
+            while j + 1 < n and not (n * partial[j + 1] > (k + u) * partial[n]):
                 j += 1
             counts[j] += 1
         assert (np.diff(lo) == counts).all()
