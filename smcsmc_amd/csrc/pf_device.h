@@ -158,6 +158,14 @@ __device__ __forceinline__ double wave_hs_scan(double v, int lane) {
     }
     return v;
 }
+__device__ __forceinline__ double wave_max_scan_d(double v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        double o = __shfl_up(v, d, 64);
+        if (lane >= d) v = o > v ? o : v;
+    }
+    return v;
+}
 __device__ __forceinline__ int wave_max_scan_i(int v, int lane) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {

@@ -27,8 +27,7 @@
 #include "pf_tree_reg.h"
 
 #define PF_EMAX 64
-#define PF_DECIDE_BS 1024
-#define PF_DECIDE_PER 16      // particles per k_decide thread kept in registers (fast path: Np <= 16384)
+#define PF_DECIDE_TAB 16384   // offspring / parent tables fit LDS (16-bit entries) up to this many particles
 #define PF_LEDGER_BLOCKS 192   // extra workgroups of k_resample that maintain the ancestor ledger
 #define REC_RECOMB 1
 #define REC_COALMIGR 2
@@ -66,6 +65,7 @@ struct Ctrl {
     int count_active;
     int end_seq;
     int pending_fin;       // k_count partials of the previous step still have to be folded into the totals
+    long long nres_prev;   // n_resample as of the end of the last k_resample (stable during k_decide)
     int gen_prev;          // generation index as of the end of the last k_resample (stable during k_decide)
     int nbx_used;
 };
@@ -97,6 +97,7 @@ struct KArgs {
     int* lo;                       // [Gcap][Np+1] offspring ranges of resampling event r (between gen r and r+1)
     double* gen_x0;                // [Gcap] position where generation g starts
     int* parent;                   // [Np] parent slot of every new slot at the current resampling event
+    int* blkcnt;                   // [nblocks] survivors per particle workgroup at the current resampling event
     // run-length encoded composite ancestor maps: generation g's list maps the slots of the
     // current generation to slots of generation g: run i covers [run_st[i], run_st[i+1]) -> run_anc[i]
     int* run_st;                   // [Gcap][Np]
@@ -110,6 +111,8 @@ struct KArgs {
     double* chunk_off;             // [nc]
     double* l2scan;                // [nc]
     double* scanp;                 // [Np] within-wavefront inclusive scan of the posterior weights
+    double* scan1m;                // [Np] running max of scan1 inside the wavefront
+    double* chunk_mx1;             // [nc] max of scan1 per wavefront
     double* chunk_pp;              // [nc] its per-wavefront totals
     double* chunk_offp;            // [nc] exclusive offsets of the posterior scan
     double* l2scanp;               // [nc]
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(PF_BS) void k_init(KArgs A, double initial_position
         c->cur_pos = initial_position;
         c->logl = 0; c->inv_T = 1; c->T = 1; c->flag = 0; c->cur = 0; c->gen = 0; c->n_resample = 0;
         c->first_epoch = A.E; c->err = 0; c->delayed_opp = 0; c->count_active = 0; c->end_seq = 0;
-        c->g_retain = 0; c->pending_fin = 0; c->nbx_used = A.nbx; c->gen_prev = 0;
+        c->g_retain = 0; c->pending_fin = 0; c->nbx_used = A.nbx; c->gen_prev = 0; c->nres_prev = 0;
         for (int e = 0; e < A.E; ++e) { c->counted_to[e] = 0; c->update_to[e] = 0; c->g_lo[e] = 0; c->g_hi[e] = 0; }
         A.gen_x0[0] = 0.0;
     }
@@ -517,13 +520,15 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
     double sq = wave_tree_sum(w_pilot * w_pilot);
     double sc = wave_hs_scan(w_pilot, lane);
     double scp = wave_hs_scan(w_post, lane);
+    double scm = wave_max_scan_d(sc, lane);     // running max of the pilot scan (a parallel FP scan need not be monotone)
     long long chunk = p >> 6;
-    if (active) { A.scan1[p] = sc; A.scanp[p] = scp; }
+    if (active) { A.scan1[p] = sc; A.scanp[p] = scp; A.scan1m[p] = scm; }
     if (lane == 63 && chunk < (A.Np + 63) / 64) {
         A.chunk_post[chunk] = sp;
         A.chunk_sq[chunk] = sq;
         A.chunk_pil[chunk] = sc;
         A.chunk_pp[chunk] = scp;
+        A.chunk_mx1[chunk] = scm;
     }
 }
 
@@ -682,13 +687,15 @@ __global__ __launch_bounds__(PF_BS) void k_extend_reg(KArgs A, long long s) {
     double sq = wave_tree_sum(w_pilot * w_pilot);
     double sc = wave_hs_scan(w_pilot, lane);
     double scp = wave_hs_scan(w_post, lane);
+    double scm = wave_max_scan_d(sc, lane);     // running max of the pilot scan (a parallel FP scan need not be monotone)
     long long chunk = p >> 6;
-    if (active) { A.scan1[p] = sc; A.scanp[p] = scp; }
+    if (active) { A.scan1[p] = sc; A.scanp[p] = scp; A.scan1m[p] = scm; }
     if (lane == 63 && chunk < (A.Np + 63) / 64) {
         A.chunk_post[chunk] = sp;
         A.chunk_sq[chunk] = sq;
         A.chunk_pil[chunk] = sc;
         A.chunk_pp[chunk] = scp;
+        A.chunk_mx1[chunk] = scm;
     }
 }
 
@@ -768,19 +775,30 @@ __device__ void window_generations(const KArgs& A, Ctrl* c, const Windows& W, in
     }
 }
 
-// ------------------------------------------------------------------ k_decide (2 workgroups)
-// workgroup 0: normalize_probability (pc.cpp:420-438), the ESS test of resample (pc.cpp:247-283),
-//              systematic_resampling (pc.cpp:474-504) -> offspring table + parent table
-// workgroup 1: count bookkeeping (previous step's partials, generations of the new windows)
-__global__ __launch_bounds__(PF_DECIDE_BS) void k_decide(KArgs A, long long s, int mode, Windows W) {
-    __shared__ double l2s[4096];          // level-2 inclusive scan of the per-wavefront pilot totals
+// ------------------------------------------------------------------ k_decide
+// normalize_probability (pc.cpp:420-438), the ESS test of resample (pc.cpp:247-283) and
+// systematic_resampling (pc.cpp:474-504) -> offspring table, parent table, survivor run list.
+//
+// Grid = one workgroup per 256 particles + one bookkeeping workgroup.  A single workgroup has four
+// SIMDs, far too few for anything per-particle, so:
+//   * every particle workgroup redundantly redoes the tiny level-2/3 part of the canonical reduction
+//     (<= 4096 per-wavefront partials): all of them obtain bit-identical T, S1, S2, ESS, flag, u without
+//     any inter-workgroup wait;
+//   * if resampling is due, each computes the final offspring offsets of its own particles (one per lane),
+//     the parent table entries of their offspring and its survivor count: no inter-workgroup wait;
+//   * the bookkeeping workgroup folds the previous step's k_count partials and advances the window
+//     generations (off the critical path).
+__global__ __launch_bounds__(PF_BS) void k_decide(KArgs A, long long s, int mode, Windows W, int nblocks) {
+    __shared__ double l2s[4096];          // level-2 inclusive scan of the per-wavefront pilot totals / finalize staging
     __shared__ double l2_post[64], l2_sq[64], l2_tot[64], l2_totp[64];
-    __shared__ int wmax[PF_DECIDE_BS / 64], wmax2[PF_DECIDE_BS / 64];
-    __shared__ unsigned short l2s_u16[2 * (PF_DECIDE_BS * PF_DECIDE_PER + 8)];   // lo / parent tables (fast path)
+    __shared__ int wred[PF_BS / 64];
+    __shared__ double wredd[PF_BS / 64];
+    __shared__ int slo[PF_BS];
+    __shared__ double pm[4096];           // exclusive prefix max over chunks of the pilot prefix sums
     Ctrl* c = A.ctrl;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = PF_DECIDE_BS / 64;
-    if (blockIdx.x == 1) {
-        if (c->pending_fin) finalize_counts(A, c, tid, PF_DECIDE_BS, l2s);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = PF_BS / 64;
+    if ((int)blockIdx.x == nblocks) {
+        if (c->pending_fin) finalize_counts(A, c, tid, PF_BS, l2s);
         window_generations(A, c, W, tid);
         return;
     }
@@ -788,6 +806,13 @@ __global__ __launch_bounds__(PF_DECIDE_BS) void k_decide(KArgs A, long long s, i
     const int nc = (int)((Np + 63) / 64);
     const int ng = (nc + 63) / 64;
     const double last_scan1 = A.scan1[Np - 1];
+    const long long i_own = (long long)blockIdx.x * PF_BS + tid;
+    const double own_scan1m = (i_own > 0 && i_own < Np) ? A.scan1m[i_own - 1] : 0.0;
+    const double next_scan1m = (i_own + 1 < Np) ? A.scan1m[i_own] : 0.0;
+    // generation / event counters as published by the previous k_resample: workgroup 0 advances the live ones
+    // at the end of this kernel while other workgroups may still be starting
+    const int G = c->gen_prev;
+    const unsigned long long n_res = (unsigned long long)c->nres_prev;
     // level 2 of the canonical radix-64 reduction / scans
     for (int g = wave; g < ng; g += nwaves) {
         int ch = g * 64 + lane;
@@ -799,7 +824,7 @@ __global__ __launch_bounds__(PF_DECIDE_BS) void k_decide(KArgs A, long long s, i
         double rs = wave_tree_sum(vs);
         double sc = wave_hs_scan(vl, lane);
         double scq = wave_hs_scan(vq, lane);
-        if (ch < nc) { l2s[ch] = sc; A.l2scanp[ch] = scq; }
+        if (ch < nc) { l2s[ch] = sc; if (blockIdx.x == 0) A.l2scanp[ch] = scq; }
         if (lane == 63) { l2_post[g] = rp; l2_sq[g] = rs; l2_tot[g] = sc; l2_totp[g] = scq; }
     }
     __syncthreads();
@@ -818,25 +843,25 @@ __global__ __launch_bounds__(PF_DECIDE_BS) void k_decide(KArgs A, long long s, i
         double off = (ch % 64 == 0) ? 0.0 : l2s[ch - 1];
         return run + off;
     };
-    for (int ch = tid; ch < nc; ch += PF_DECIDE_BS) {
-        A.chunk_off[ch] = chunk_offset(ch);
-        double runp = 0.0;
-        for (int g = 0; g < ch / 64; ++g) runp = runp + l2_totp[g];
-        double offp = (ch % 64 == 0) ? 0.0 : A.l2scanp[ch - 1];
-        A.chunk_offp[ch] = runp + offp;
+    if (blockIdx.x == 0) {
+        for (int ch = tid; ch < nc; ch += PF_BS) {
+            A.chunk_off[ch] = chunk_offset(ch);
+            double runp = 0.0;
+            for (int g = 0; g < ch / 64; ++g) runp = runp + l2_totp[g];
+            double offp = (ch % 64 == 0) ? 0.0 : A.l2scanp[ch - 1];
+            A.chunk_offp[ch] = runp + offp;
+        }
     }
     const double S1 = chunk_offset(nc - 1) + last_scan1;   // inclusive scan at the last particle (= oracle incl[N-1])
     const double ess = (S1 * S1) / S2;
     const int flag = (mode == 0 && ess < A.ess_threshold - 1e-6) ? 1 : 0;
-    const int G = c->gen;
     double pos = A.L;
     if (mode == 0) {
         double seg_end = A.seg_start[s] + A.seg_len[s];
         pos = seg_end < A.L ? seg_end : A.L;
     }
-    const unsigned long long n_res = (unsigned long long)c->n_resample;
     const double u = flag ? philox_uniform(A.seed, 0xFFFFFFFFu, 1, n_res) : 0.0;
-    if (tid == 0) {
+    if (blockIdx.x == 0 && tid == 0) {
         if (!(T > 0.0)) c->err = ERR_ZERO_PROB;
         double logl = c->logl + dlog(T);
         c->logl = logl;
@@ -850,138 +875,73 @@ __global__ __launch_bounds__(PF_DECIDE_BS) void k_decide(KArgs A, long long s, i
         }
         c->T = T; c->inv_T = inv; c->S1 = S1; c->S2 = S2; c->ess = ess; c->u = u; c->flag = flag;
     }
+    if (!flag) return;
 
-    // ---- offspring table lo[0..Np] of systematic resampling (closed form, monotone), parent table and
-    //      the run list of the generation that ends here (its survivors) ----
-    if (flag) {
-        int* lo = A.lo + (size_t)(G % A.Gcap) * (Np + 1);
-        int* rst = A.run_st + (size_t)(G % A.Gcap) * Np;
-        int* ran = A.run_anc + (size_t)(G % A.Gcap) * Np;
-        const double dn = (double)Np;
-        const long long per = (Np + PF_DECIDE_BS - 1) / PF_DECIDE_BS;
-        const long long i0 = (long long)tid * per;
-        const long long i1 = i0 + per < Np ? i0 + per : Np;
-        // lo_raw(i) = #{ j in [0,N) : (j+u) * S1 < N * incl[i-1] }  -- the comparison of pc.cpp:491 with both
-        // sides multiplied by N*S1, so that no division is needed (exact predicate, guess corrected by it)
-        const double invS1 = 1.0 / S1;
-        auto lo_raw = [&](long long i, double sc1) -> int {
-            if (i == 0) return 0;
-            double incl = chunk_offset((int)((i - 1) >> 6)) + sc1;
-            double rhs = dn * incl;
-            double guess = floor(rhs * invS1 - u);
-            long long g = guess < 0 ? 0 : (guess > dn ? Np : (long long)guess);
-            while (g > 0 && !((((double)(g - 1)) + u) * S1 < rhs)) --g;
-            while (g < Np && ((((double)g) + u) * S1 < rhs)) ++g;
-            return (int)g;
-        };
-        if (per <= PF_DECIDE_PER) {
-            // fast path: the thread's slice lives in registers; all global loads are issued up front
-            // (a load per loop iteration behind a store would serialise ~1 us of latency each)
-            double sc1[PF_DECIDE_PER];
-            int v[PF_DECIDE_PER];
-#pragma unroll
-            for (int k = 0; k < PF_DECIDE_PER; ++k) {
-                long long i = i0 + k;
-                sc1[k] = (i < i1 && i > 0) ? A.scan1[i - 1] : 0.0;
-            }
-            int run = 0;
-#pragma unroll
-            for (int k = 0; k < PF_DECIDE_PER; ++k) {
-                long long i = i0 + k;
-                int val = i < i1 ? lo_raw(i, sc1[k]) : 0;
-                run = val > run ? val : run;
-                v[k] = run;
-            }
-            int sc = wave_max_scan_i(run, lane);
-            if (lane == 63) wmax[wave] = sc;
-            __syncthreads();
-            int prefix = 0;
-            for (int w = 0; w < wave; ++w) prefix = max(prefix, wmax[w]);
-            int before = __shfl_up(sc, 1, 64);
-            if (lane > 0) prefix = max(prefix, before);
-            // the table goes through LDS (16-bit entries, Np <= 16384) so that every global store below is
-            // coalesced: uncoalesced 4-byte stores from this single workgroup were the bottleneck
-            unsigned short* lo16 = (unsigned short*)l2s_u16;
-            unsigned short* par16 = lo16 + PF_DECIDE_BS * PF_DECIDE_PER + 8;
-#pragma unroll
-            for (int k = 0; k < PF_DECIDE_PER; ++k) {
-                v[k] = max(v[k], prefix);
-                if (i0 + k < i1) lo16[i0 + k] = (unsigned short)v[k];
-            }
-            if (tid == 0) lo16[Np] = (unsigned short)Np;
-            __syncthreads();
-            // survivors of this slice -> run list of generation G (start = lo[i], ancestor = i); parents -> LDS
-            int nsurv = 0;
-#pragma unroll
-            for (int k = 0; k < PF_DECIDE_PER; ++k) {
-                long long i = i0 + k;
-                if (i < i1) {
-                    int hi = lo16[i + 1];
-                    nsurv += hi > v[k] ? 1 : 0;
-                    for (int q = v[k]; q < hi; ++q) par16[q] = (unsigned short)i;
-                }
-            }
-            int incl = nsurv;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                int o = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += o;
-            }
-            if (lane == 63) wmax2[wave] = incl;
-            __syncthreads();
-            int wbase = 0, total = 0;
-            for (int w = 0; w < nwaves; ++w) { if (w < wave) wbase += wmax2[w]; total += wmax2[w]; }
-            int pos = wbase + incl - nsurv;
-#pragma unroll
-            for (int k = 0; k < PF_DECIDE_PER; ++k) {
-                long long i = i0 + k;
-                if (i < i1) {
-                    int hi = lo16[i + 1];
-                    if (hi > v[k]) { rst[pos] = v[k]; ran[pos] = (int)i; ++pos; }
-                }
-            }
-            for (long long i = tid; i <= Np; i += PF_DECIDE_BS) lo[i] = lo16[i];
-            for (long long q = tid; q < Np; q += PF_DECIDE_BS) A.parent[q] = par16[q];
-            if (tid == 0) A.nruns[G % A.Gcap] = total;
-        } else {
-            // generic path (Np > PF_DECIDE_BS * PF_DECIDE_PER)
-            int run = 0;
-            for (long long i = i0; i < i1; ++i) {
-                int val = lo_raw(i, i > 0 ? A.scan1[i - 1] : 0.0);
-                run = val > run ? val : run;
-                lo[i] = run;
-            }
-            int sc = wave_max_scan_i(run, lane);
-            if (lane == 63) wmax[wave] = sc;
-            __syncthreads();
-            int prefix = 0;
-            for (int w = 0; w < wave; ++w) prefix = max(prefix, wmax[w]);
-            int before = __shfl_up(sc, 1, 64);
-            if (lane > 0) prefix = max(prefix, before);
-            for (long long i = i0; i < i1; ++i) lo[i] = max(lo[i], prefix);
-            if (tid == 0) lo[Np] = (int)Np;
-            __syncthreads();
-            int nsurv = 0;
-            for (long long i = i0; i < i1; ++i) nsurv += lo[i + 1] > lo[i] ? 1 : 0;
-            int incl = nsurv;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                int o = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += o;
-            }
-            if (lane == 63) wmax2[wave] = incl;
-            __syncthreads();
-            int wbase = 0, total = 0;
-            for (int w = 0; w < nwaves; ++w) { if (w < wave) wbase += wmax2[w]; total += wmax2[w]; }
-            int pos = wbase + incl - nsurv;
-            for (long long i = i0; i < i1; ++i) {
-                int q0 = lo[i], q1 = lo[i + 1];
-                if (q1 > q0) { rst[pos] = q0; ran[pos] = (int)i; ++pos; }
-                for (int q = q0; q < q1; ++q) A.parent[q] = (int)i;
-            }
-            if (tid == 0) A.nruns[G % A.Gcap] = total;
+    // ---- systematic resampling (pc.cpp:474-504) in closed form, one particle per lane, no inter-workgroup wait ----
+    // lo[i] = max_{j<=i} lo_raw(incl[j-1]),  lo_raw(x) = #{ j in [0,N) : (j+u) * S1 < N * x }  (pc.cpp:491 scaled by
+    // N*S1: no division).  lo_raw is monotone in x, so the running max can be taken on the prefix sums instead:
+    // max_{j<=m} incl[j] = max( max_{c'<c} (chunk_off[c'] + mx1[c']),  chunk_off[c] + runmax(scan1)[m] ), which every
+    // workgroup derives from the per-wavefront summaries alone.
+    const double dn = (double)Np;
+    const double invS1 = 1.0 / S1;
+    {
+        const int perc = (nc + PF_BS - 1) / PF_BS;
+        const int c0 = tid * perc, c1 = c0 + perc < nc ? c0 + perc : nc;
+        double run = 0.0;
+        for (int ch = c0; ch < c1; ++ch) { double vch = chunk_offset(ch) + A.chunk_mx1[ch]; run = vch > run ? vch : run; }
+        double scd = wave_max_scan_d(run, lane);
+        if (lane == 63) wredd[wave] = scd;
+        __syncthreads();
+        double pre = 0.0;
+        for (int w = 0; w < wave; ++w) pre = wredd[w] > pre ? wredd[w] : pre;
+        double before = __shfl_up(scd, 1, 64);
+        if (lane > 0) pre = before > pre ? before : pre;
+        run = pre;                           // exclusive prefix for this thread's first chunk
+        for (int ch = c0; ch < c1; ++ch) {
+            pm[ch] = run;
+            double vch = chunk_offset(ch) + A.chunk_mx1[ch];
+            run = vch > run ? vch : run;
         }
-        if (tid == 0) {
+        __syncthreads();
+    }
+    auto lo_at = [&](long long i, double s1m) -> int {      // final offspring offset of particle i (0 < i < Np)
+        const int ch = (int)((i - 1) >> 6);
+        double incl = chunk_offset(ch) + s1m;
+        double pmx = pm[ch];
+        incl = pmx > incl ? pmx : incl;
+        double rhs = dn * incl;
+        double guess = floor(rhs * invS1 - u);
+        long long g = guess < 0 ? 0 : (guess > dn ? Np : (long long)guess);
+        while (g > 0 && !((((double)(g - 1)) + u) * S1 < rhs)) --g;
+        while (g < Np && ((((double)g) + u) * S1 < rhs)) ++g;
+        return (int)g;
+    };
+    int* lo = A.lo + (size_t)(G % A.Gcap) * (Np + 1);
+    int lo_i = 0, lo_n = 0;
+    const bool act = i_own < Np;
+    if (act) {
+        lo_i = i_own > 0 ? lo_at(i_own, own_scan1m) : 0;
+        lo[i_own] = lo_i;
+        slo[tid] = lo_i;
+    }
+    __syncthreads();
+    int cnt = 0;
+    if (act) {
+        if (i_own + 1 >= Np) { lo_n = (int)Np; lo[Np] = (int)Np; }
+        else if (tid + 1 < PF_BS) lo_n = slo[tid + 1];
+        else lo_n = lo_at(i_own + 1, next_scan1m);          // first particle of the next workgroup (recomputed)
+        cnt = lo_n - lo_i;
+        for (int q = lo_i; q < lo_n; ++q) A.parent[q] = (int)i_own;
+    }
+    // survivors per workgroup (k_resample turns them into the run list of the ending generation)
+    unsigned long long bal = __ballot(cnt > 0);
+    if (lane == 0) wred[wave] = __popcll(bal);
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int w = 0; w < nwaves; ++w) tot += wred[w];
+        A.blkcnt[blockIdx.x] = tot;
+        if (blockIdx.x == 0) {
             // toggle buffers / open the next generation
             int ev = (int)n_res;
             if (ev < A.max_trace_events) A.ev_seg[ev] = (int)s;
@@ -1304,21 +1264,50 @@ __device__ void ledger_update(const KArgs& A, int lb, int nlb) {
 
 __global__ __launch_bounds__(PF_BS) void k_resample(KArgs A, long long s, int nblocks) {
     Ctrl* c = A.ctrl;
-    if (blockIdx.x == 0 && threadIdx.x == 0) c->gen_prev = c->gen;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { c->gen_prev = c->gen; c->nres_prev = c->n_resample; }
     if ((int)blockIdx.x >= nblocks) {
         if (c->flag) ledger_update(A, (int)blockIdx.x - nblocks, (int)gridDim.x - nblocks);
         return;
     }
     const long long Np = A.Np;
     const long long i = (long long)blockIdx.x * PF_BS + threadIdx.x;
-    if (i >= Np) return;
     const double inv = c->inv_T;
     if (!c->flag) {
+        if (i >= Np) return;
         DState& st = A.st[c->cur];
         st.w_post[i] *= inv;
         st.w_pilot[i] *= inv;
         return;
     }
+    {
+        // run list of the generation that ends here: its survivors, in slot order (start = lo[a], ancestor = a).
+        // Position = survivors in earlier workgroups (k_decide's blkcnt) + rank inside this workgroup.
+        __shared__ int wsum[PF_BS / 64];
+        const int Gx = c->gen - 1;
+        const int* lox = A.lo + (size_t)(Gx % A.Gcap) * (Np + 1);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        int l0 = 0, l1 = 0;
+        if (i < Np) { l0 = lox[i]; l1 = lox[i + 1]; }
+        const bool surv = l1 > l0;
+        unsigned long long bal = __ballot(surv);
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __shared__ int sblk[1024];
+        for (int b = threadIdx.x; b < nblocks; b += PF_BS) sblk[b] = A.blkcnt[b];
+        __syncthreads();
+        int base = 0;
+        for (int b = 0; b < (int)blockIdx.x; ++b) base += sblk[b];
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        if (surv) {
+            int pos = base + __popcll(bal & ((1ULL << lane) - 1ULL));
+            A.run_st[(size_t)(Gx % A.Gcap) * Np + pos] = l0;
+            A.run_anc[(size_t)(Gx % A.Gcap) * Np + pos] = (int)i;
+        }
+        if (blockIdx.x == (unsigned)nblocks - 1 && threadIdx.x == PF_BS - 1) {
+            int tot = base + __popcll(bal);           // base already holds the earlier wavefronts of this workgroup
+            A.nruns[Gx % A.Gcap] = tot;
+        }
+    }
+    if (i >= Np) return;
     const int n = A.n;
     const int G = c->gen - 1;                  // the generation that ends here (k_decide already advanced gen)
     const DState& src = A.st[c->cur ^ 1];
@@ -1386,13 +1375,15 @@ __global__ __launch_bounds__(PF_BS) void k_partials(KArgs A) {
     double sq = wave_tree_sum(w_pilot * w_pilot);
     double sc = wave_hs_scan(w_pilot, lane);
     double scp = wave_hs_scan(w_post, lane);
+    double scm = wave_max_scan_d(sc, lane);     // running max of the pilot scan (a parallel FP scan need not be monotone)
     long long chunk = p >> 6;
-    if (active) { A.scan1[p] = sc; A.scanp[p] = scp; }
+    if (active) { A.scan1[p] = sc; A.scanp[p] = scp; A.scan1m[p] = scm; }
     if (lane == 63 && chunk < (A.Np + 63) / 64) {
         A.chunk_post[chunk] = sp;
         A.chunk_sq[chunk] = sq;
         A.chunk_pil[chunk] = sc;
         A.chunk_pp[chunk] = scp;
+        A.chunk_mx1[chunk] = scm;
     }
 }
 
@@ -1603,12 +1594,14 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     rc |= dalloc(h, &A.lo, (size_t)A.Gcap * (Np + 1));
     rc |= dalloc(h, &A.gen_x0, A.Gcap);
     rc |= dalloc(h, &A.parent, Np);
+    rc |= dalloc(h, &A.blkcnt, (size_t)h->nblocks);
     rc |= dalloc(h, &A.run_st, (size_t)A.Gcap * Np);
     rc |= dalloc(h, &A.run_anc, (size_t)A.Gcap * Np);
     rc |= dalloc(h, &A.nruns, A.Gcap);
     const size_t nc = (size_t)((Np + 63) / 64);
     rc |= dalloc(h, &A.chunk_post, nc); rc |= dalloc(h, &A.chunk_sq, nc); rc |= dalloc(h, &A.chunk_pil, nc);
     rc |= dalloc(h, &A.scan1, Np); rc |= dalloc(h, &A.chunk_off, nc); rc |= dalloc(h, &A.l2scan, nc);
+    rc |= dalloc(h, &A.scan1m, Np); rc |= dalloc(h, &A.chunk_mx1, nc);
     rc |= dalloc(h, &A.scanp, Np); rc |= dalloc(h, &A.chunk_pp, nc); rc |= dalloc(h, &A.chunk_offp, nc); rc |= dalloc(h, &A.l2scanp, nc);
     A.nbx = h->nblocks;
     rc |= dalloc(h, &A.totals, (size_t)6 * E);
@@ -1783,7 +1776,7 @@ static int launch_decide(pf_handle* h, long long s, int mode, const Windows& W) 
     const bool t = timing_on(h, s);
     {
         Timed tm(h, 1, t);
-        hipLaunchKernelGGL(k_decide, dim3(2), dim3(PF_DECIDE_BS), 0, h->stream, h->A, s, mode, W);
+        hipLaunchKernelGGL(k_decide, dim3(h->nblocks + 1), dim3(PF_BS), 0, h->stream, h->A, s, mode, W, h->nblocks);
         h->fin_pending = false;      // workgroup 1 folds the previous step's partials
     }
     return check_launch("k_decide");
@@ -2048,7 +2041,7 @@ static int test_reduce_impl(const double* x, int64_t n, double* out_sum, double*
         hipMemcpyAsync(h->A.st[0].w_pilot, x, n * 8, hipMemcpyHostToDevice, h->stream);
         hipLaunchKernelGGL(k_partials, dim3(h->nblocks), dim3(PF_BS), 0, h->stream, h->A);
         // override u by running k_decide in mode 0 and then patching: simpler -- write u after the fact
-        hipLaunchKernelGGL(k_decide, dim3(2), dim3(PF_DECIDE_BS), 0, h->stream, h->A, (long long)0, lo ? 0 : 1, no_windows(h));
+        hipLaunchKernelGGL(k_decide, dim3(h->nblocks + 1), dim3(PF_BS), 0, h->stream, h->A, (long long)0, lo ? 0 : 1, no_windows(h), h->nblocks);
         hipStreamSynchronize(h->stream);
         Ctrl c;
         hipMemcpy(&c, h->A.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost);
