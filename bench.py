@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--timing-period", type=int, default=16, help="time every k-th segment's kernels with HIP events")
+    ap.add_argument("--chunks-per-gpu", type=int, default=1,
+                    help="independent chunks filtered concurrently on each GPU (one host thread + stream each); "
+                         "1 = the headline single-chunk configuration")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -132,32 +135,56 @@ def main():
     if not os.path.exists(pfmod.LIB_PATH):
         pfbuild.build_lib()
 
-    model, segs = build_workload(args, seed=args.seed + rank)     # one independent chunk per rank
-    n_segments = len(segs["start"])
-    pf = ParticleFilter(model, args.np, ess_fraction=0.5, seed=args.seed + 1000 * rank, max_trace_events=0,
-                        device=local_rank if world > 1 else 0)
-    pf.load_segments(segs)
+    import threading
+    C = max(1, args.chunks_per_gpu)
+    dev = local_rank if world > 1 else 0
+    chunks = []
+    for k in range(C):
+        model, segs = build_workload(args, seed=args.seed + rank * C + k)     # independent chunks
+        f = ParticleFilter(model, args.np, ess_fraction=0.5, seed=args.seed + 1000 * (rank * C + k), max_trace_events=0,
+                           device=dev)
+        f.load_segments(segs)
+        chunks.append((f, segs))
+    pf, segs = chunks[0]
+    n_segments = sum(len(sg["start"]) for _, sg in chunks)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def sweep_all():
+        if C == 1:
+            run_sweep(pf, segs)
+            return
+        th = [threading.Thread(target=run_sweep, args=(f, sg)) for f, sg in chunks]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+
     for _ in range(args.warmup):
-        run_sweep(pf, segs)
-    pf.sync()
+        sweep_all()
+    for f, _ in chunks:
+        f.sync()
     pf.set_timing(args.timing_period)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        run_sweep(pf, segs)
-    pf.sync()
+        sweep_all()
+    for f, _ in chunks:
+        f.sync()
     barrier()
     dt = time.perf_counter() - t0
     kt = pf.kernel_times()
     st = pf.stats()
-    logl = pf.logl()
+    logl = sum(f.logl() for f, _ in chunks)
     counts = pf.counts()
+    for f, _ in chunks[1:]:
+        cc = f.counts()
+        for kk in counts:
+            counts[kk] = counts[kk] + cc[kk]
+    n_seg0 = len(segs["start"])
 
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -185,7 +212,7 @@ def main():
         value = total_segments * args.steps / dt_max
         ext_ms, ext_launches = kt["extend"]
         avg_ext_us = 1e3 * ext_ms / max(1, ext_launches)
-        rec_per_seg = st["records"] / max(1, n_segments)            # records appended per segment (last sweep)
+        rec_per_seg = st["records"] / max(1, n_seg0)                # records appended per segment (last sweep, chunk 0)
         state_bytes = st["state_bytes_per_particle"]
         rec_bytes = 8 * (5 + args.nsam - 1)
         # algorithmic bytes of one k_extend launch: every particle's state read and written once,
@@ -201,7 +228,7 @@ def main():
                                    % (args.length / 1e6, args.np, args.epochs),
                        "segments_per_chunk": n_segments, "nsam": args.nsam, "np": args.np,
                        "sequence_length": args.length, "epochs": args.epochs,
-                       "parallelism": "chunk-per-gpu x%d" % world, "log_likelihood_sum": logl_sum},
+                       "parallelism": "%d chunk(s) per gpu x %d gpu(s)" % (C, world), "log_likelihood_sum": logl_sum},
             "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_us": avg_ext_us,

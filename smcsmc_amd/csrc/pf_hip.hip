@@ -1063,7 +1063,8 @@ template <int NM>
 __global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0, Windows Wn) {
     constexpr int NI = NM - 1;
     __shared__ Acc red[PF_BS / 64];
-    __shared__ int s_nr[PF_CNT_TILE];
+    __shared__ int s_off[PF_CNT_TILE + 1];
+    __shared__ int s_wsum[PF_BS / 64];
     const Ctrl* c = A.ctrl;
     const int e = e0 + blockIdx.y;
     const int first = Wn.first;
@@ -1085,42 +1086,77 @@ __global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0, Windows Wn) {
     const int my_wave = (int)(gtid >> 6);
     const int total_waves = (int)(nthreads >> 6);
     Acc acc = {0, 0, 0, 0, 0, 0};
+    // Work = all (generation, run) pairs of the window plus the live particles, flattened into one task index
+    // space with an LDS prefix sum of the run counts: every thread takes tasks gtid, gtid+nthreads, ... so deep
+    // windows are spread over the grid column instead of being walked generation by generation.
     for (int tile_hi = g_hi; tile_hi >= g_lo; tile_hi -= PF_CNT_TILE) {
         const int tile_lo = tile_hi - PF_CNT_TILE + 1 > g_lo ? tile_hi - PF_CNT_TILE + 1 : g_lo;
+        const int ntile = tile_hi - tile_lo + 1;
         __syncthreads();
-        for (int idx = threadIdx.x; idx <= tile_hi - tile_lo; idx += PF_BS) {
-            int g = tile_hi - idx;
-            s_nr[idx] = g == G ? -1 : A.nruns[g % A.Gcap];
-        }
-        __syncthreads();
-        for (int idx = 0; idx <= tile_hi - tile_lo; ++idx) {
-            const int g = tile_hi - idx;
-            const int nr = s_nr[idx];
-            if (nr < 0) {
-                // live particles: their own weight, their open stretch, the records they wrote this generation
-                for (long long a = gtid; a < Np; a += nthreads) {
-                    double w = st.w_post[a] * inv;
-                    double S[NI];
+        // stage run counts (live generation: Np tasks) and their exclusive prefix sum
+        constexpr int PER = PF_CNT_TILE / PF_BS;
+        int loc[PER];
+        int lsum = 0;
 #pragma unroll
-                    for (int r = 0; r < NI; ++r) S[r] = r < n - 1 ? st.S[(size_t)r * Np + a] : 0.0;
-                    double xm = st.x_mark[a];
-                    int ml = st.mark_limit[a];
-                    unsigned k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
-                    unsigned k1 = A.widx[a];
-                    if (w == 0.0) continue;
-                    stretch_contrib<NI>(acc, A, W, w, xm, PF_INF, S, ml);
-                    if (k1 - k0 > A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;
-                    records_contrib<NI>(acc, A, W, w, a, k0, k1);
-                }
-            } else if (nr > PF_CNT_WIDE) {
+        for (int k = 0; k < PER; ++k) {
+            int idx = threadIdx.x * PER + k;
+            int v = 0;
+            if (idx < ntile) {
+                int g = tile_hi - idx;
+                v = g == G ? (int)Np : A.nruns[g % A.Gcap];
+            }
+            loc[k] = v;
+            lsum += v;
+        }
+        int incl = lsum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) s_wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += s_wsum[w];
+        int run = base + incl - lsum;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            int idx = threadIdx.x * PER + k;
+            if (idx <= ntile) s_off[idx] = run;
+            run += loc[k];
+        }
+        if (threadIdx.x == PF_BS - 1) s_off[ntile] = run;      // total (idx == ntile is only reached when ntile == TILE)
+        __syncthreads();
+        const long long T = s_off[ntile];
+        for (long long t = gtid; t < T; t += nthreads) {
+            // generation of task t: last idx with s_off[idx] <= t
+            int lo_i = 0, hi_i = ntile;
+            while (hi_i - lo_i > 1) {
+                int mid = (lo_i + hi_i) >> 1;
+                if ((long long)s_off[mid] <= t) lo_i = mid; else hi_i = mid;
+            }
+            const int g = tile_hi - lo_i;
+            const long long i = t - s_off[lo_i];
+            if (g == G) {
+                // live particle: its own weight, its open stretch, the records it wrote this generation
+                const long long a = i;
+                double w = st.w_post[a] * inv;
+                double S[NI];
+#pragma unroll
+                for (int r = 0; r < NI; ++r) S[r] = r < n - 1 ? st.S[(size_t)r * Np + a] : 0.0;
+                double xm = st.x_mark[a];
+                int ml = st.mark_limit[a];
+                unsigned k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
+                unsigned k1 = A.widx[a];
+                if (w == 0.0) continue;
+                stretch_contrib<NI>(acc, A, W, w, xm, PF_INF, S, ml);
+                if (k1 - k0 > A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;
+                records_contrib<NI>(acc, A, W, w, a, k0, k1);
+            } else {
+                const int nr = s_off[lo_i + 1] - s_off[lo_i];
                 const int* rst = A.run_st + (size_t)(g % A.Gcap) * Np;
                 const int* ran = A.run_anc + (size_t)(g % A.Gcap) * Np;
-                for (long long i = gtid; i < nr; i += nthreads) count_run<NI>(acc, A, W, g, i, nr, rst, ran, inv);
-            } else if (g % total_waves == my_wave) {
-                // short list: one wavefront takes the whole generation, so a deep window costs no serial launches
-                const int* rst = A.run_st + (size_t)(g % A.Gcap) * Np;
-                const int* ran = A.run_anc + (size_t)(g % A.Gcap) * Np;
-                for (long long i = lane; i < nr; i += 64) count_run<NI>(acc, A, W, g, i, nr, rst, ran, inv);
+                count_run<NI>(acc, A, W, g, i, nr, rst, ran, inv);
             }
         }
     }
