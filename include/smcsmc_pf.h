@@ -48,6 +48,13 @@ typedef struct pf_model {
     const int32_t* sample_pops;  /* [nsam] or NULL */
     const int32_t* record_flags; /* [E] PfParam::record_event_in_epoch (pfparam.hpp:279-281) */
     const double* lags;          /* [E] CountModel::lags (count.cpp:230-265) */
+    /* focused sampling + delayed importance weights (particle.cpp:866-891, 1020-1126; particle.hpp:59-101, 185-209);
+     * n_bias_heights == 0 switches it off */
+    int32_t n_bias_heights;      /* k interior band boundaries (-bias_heights, generations) */
+    int32_t delay_type;          /* PfParam::ResampleDelayType: 0 recombination, 1 coalescence, 2 coal/migr */
+    const double* bias_heights;  /* [k] */
+    const double* bias_strengths;/* [k+1] */
+    const double* application_delays; /* [E] Model::application_delays (smcsmc.cpp:306-307) */
 } pf_model;
 
 typedef struct pf_params {

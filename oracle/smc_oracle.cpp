@@ -45,6 +45,7 @@ namespace smco {
 static thread_local std::string g_err;
 
 enum { NMAX = 16 };
+enum { DCAP = 32 };   /* capacity of the per-particle delayed-factor store (the reference's heap is unbounded) */
 enum { REC_RECOMB = 1, REC_COALMIGR = 2 };
 
 /* ------------------------------------------------------------------ canonical reductions */
@@ -137,6 +138,12 @@ struct Model {
     std::vector<double> inv2N;   /* 1/(2 N_e) */
     std::vector<int> recflags;
     std::vector<double> lags;
+    /* focused sampling (Model::bias_heights / bias_strengths of the scrm fork; particle.cpp:1020-1050) */
+    bool biased = false;
+    std::vector<double> bias_H;      /* 0, h1..hk, +inf */
+    std::vector<double> bias_S;      /* k+1 strengths */
+    std::vector<double> app_delays;  /* Model::application_delays (smcsmc.cpp:306-307) */
+    int delay_type = 0;              /* PfParam::ResampleDelayType: 0 recombination height, 1 coalescence, 2 coal/migr */
     int epoch_of(double t) const {
         int e = 0;
         while (e + 1 < E && T[e + 1] <= t) ++e;
@@ -198,6 +205,10 @@ struct Particle {
     double x_mark;          /* start of the current recombination-opportunity stretch */
     int mark_limit;         /* max_epoch_to_record_ in force when the stretch was opened */
     double Ltree;
+    double total_delayed = 1.0;              /* total_delayed_adjustment_ */
+    int dcount = 0;                          /* pending DelayedFactors (particle.hpp:248) */
+    double dpos[DCAP], dfac[DCAP], ddelta[DCAP];
+    int dk[DCAP];
     std::vector<Ev*> head;  /* eventTrees[epoch] (particle.hpp:235) */
     std::vector<Ev*> open;  /* the open rectangles of the current stretch (heads of their chains) */
 };
@@ -231,6 +242,7 @@ struct Filter {
     uint32_t stream = 0;          /* Philox stream id: 0 particle filter, 2 lag calibration */
     bool record_events = true;
     double last_sp = 0; bool last_changed = false;
+    double last_iw = 1.0, last_tc = 0.0;
     int64_t slot_override = -1;   /* calibration: RNG state lives in rng[0], stream keyed by the replicate index */
     double uni(int64_t slot) {
         return philox_uniform(seed, (uint32_t)(slot_override >= 0 ? slot_override : slot), stream, rng[slot].ctr++);
@@ -451,24 +463,87 @@ struct Filter {
     void genealogy_update(int64_t slot, Particle& p, double x, int limit, double* h_out) {
         const int n = M.n;
         Tree& t = p.tr;
-        /* --- sample the recombination point uniformly on the local tree (one uniform) --- */
-        double r = uni(slot) * p.Ltree;
+        /* --- sample the recombination point on the (possibly height-weighted) local tree (one uniform) --- */
         double prev = 0.0, h = 0.0;
         int lin = 0, slice = 0;
-        for (int ri = 0; ri < n - 1; ++ri) {
-            int k = n - ri;
-            double d = t.S[ri] - prev;
-            double seg = (double)k * d;
-            if (r < seg || ri == n - 2) {
-                double q = r / d;
-                lin = std::min((int)q, k - 1);
-                h = prev + (q - (double)lin) * d;
-                if (!(h < t.S[ri])) h = prev;
-                slice = ri;
-                break;
+        last_iw = 1.0;
+        if (!M.biased) {
+            double r = uni(slot) * p.Ltree;
+            for (int ri = 0; ri < n - 1; ++ri) {
+                int k = n - ri;
+                double d = t.S[ri] - prev;
+                double seg = (double)k * d;
+                if (r < seg || ri == n - 2) {
+                    double q = r / d;
+                    lin = std::min((int)q, k - 1);
+                    h = prev + (q - (double)lin) * d;
+                    if (!(h < t.S[ri])) h = prev;
+                    slice = ri;
+                    break;
+                }
+                r -= seg;
+                prev = t.S[ri];
             }
-            r -= seg;
-            prev = t.S[ri];
+        } else {
+            /* samplePoint / accumulateBranchLengths (particle.cpp:1020-1126): branch length in height band b
+             * counts bias_S[b]-fold.  Pieces = (time slice) x (band), ascending in height. */
+            const int nb = (int)M.bias_S.size();
+            double Lw = 0.0;
+            {
+                double pv = 0.0;
+                int b = 0;
+                for (int ri = 0; ri < n - 1; ++ri) {
+                    int k = n - ri;
+                    double top = t.S[ri];
+                    while (b + 1 < nb && M.bias_H[b + 1] <= pv) ++b;
+                    int bb = b;
+                    for (;;) {
+                        double lo_ = std::max(pv, M.bias_H[bb]);
+                        double hi_ = std::min(top, M.bias_H[bb + 1]);
+                        if (hi_ > lo_) Lw += ((double)k * M.bias_S[bb]) * (hi_ - lo_);
+                        if (M.bias_H[bb + 1] >= top || bb + 1 >= nb) break;
+                        ++bb;
+                    }
+                    pv = top;
+                }
+            }
+            double r = uni(slot) * Lw;
+            double wloc = 1.0;
+            double l_lo = 0, l_hi = 0, l_str = 1; int l_k = 1;   /* last piece (fallback against rounding) */
+            bool sel = false;
+            double pv = 0.0;
+            int b = 0;
+            for (int ri = 0; ri < n - 1 && !sel; ++ri) {
+                int k = n - ri;
+                double top = t.S[ri];
+                while (b + 1 < nb && M.bias_H[b + 1] <= pv) ++b;
+                int bb = b;
+                for (;;) {
+                    double lo_ = std::max(pv, M.bias_H[bb]);
+                    double hi_ = std::min(top, M.bias_H[bb + 1]);
+                    if (hi_ > lo_) {
+                        double wlen = ((double)k * M.bias_S[bb]) * (hi_ - lo_);
+                        l_lo = lo_; l_hi = hi_; l_str = M.bias_S[bb]; l_k = k; slice = ri;
+                        if (r < wlen) { sel = true; break; }
+                        r -= wlen;
+                    }
+                    if (M.bias_H[bb + 1] >= top || bb + 1 >= nb) break;
+                    ++bb;
+                }
+                pv = top;
+            }
+            {
+                double q = r / (l_str * (l_hi - l_lo));
+                lin = std::min((int)q, l_k - 1);
+                if (lin < 0) lin = 0;
+                h = l_lo + (q - (double)lin) * (l_hi - l_lo);
+                if (!(h < l_hi)) h = l_lo;
+                wloc = l_str;
+            }
+            /* importance weight (particle.cpp:1106-1108): target density 1/L over sampled density w/Lw */
+            double sampled = wloc / Lw;
+            double target = 1.0 / p.Ltree;
+            last_iw = target / sampled;
         }
         (void)slice;
         int rp = 0, sb = 0;
@@ -478,6 +553,7 @@ struct Filter {
         double Sold[NMAX - 1];
         for (int i = 0; i < n - 1; ++i) Sold[i] = t.S[i];
         double tc = coalesce_up(slot, &p, Sold, n - 1, n, h, x, limit);
+        last_tc = tc;
         double Sp = t.S[rp];
         /* --- detach: remove p, sibling takes its place --- */
         int b_id = t.C[rp][sb], s_id = t.C[rp][1 - sb];
@@ -628,10 +704,69 @@ struct Filter {
                 genealogy_update(slot, p, updated_to, limit, &h);
                 if (leaf_status == 0) B = tracked_length(p.tr, data);
                 if (leaf_status == 1) B = p.Ltree;
+                if (M.biased) {
+                    /* particle.cpp:866-891: immediate vs delayed application of the importance weight */
+                    double iw = last_iw;
+                    double rbiw = last_iw;                         /* no guide: both weights coincide */
+                    double delay_height = M.delay_type == 0 ? h : last_tc;
+                    int idx = 0;
+                    while (idx + 1 < (int)M.bias_H.size() && M.bias_H[idx + 1] < delay_height) ++idx;
+                    if (idx >= (int)M.bias_S.size()) idx = (int)M.bias_S.size() - 1;
+                    if (M.bias_S[idx] == 1.0) {
+                        p.w_post *= rbiw; p.w_pilot *= rbiw;
+                        iw /= rbiw;
+                    }
+                    double delay = M.app_delays[M.epoch_of(delay_height)];   /* find_delay, particle.cpp:733-740 */
+                    adjust_with_delay(p, iw, delay, updated_to);
+                }
                 sample_next_base(slot, p, updated_to);
                 open_stretch(p, updated_to, limit);
                 record_recomb_event(p, h, limit);
             }
+        }
+        if (M.biased) apply_due(p, extend_to);
+    }
+
+    /* adjustWeightsWithDelay(adjustment, delay, k = 3) (particle.hpp:189-198) with DelayedFactor (59-77):
+     * the factor is applied to the pilot weight in three equal parts at cur+d/7, cur+3d/7, cur+d */
+    void adjust_with_delay(Particle& p, double adj, double delay, double cur) {
+        p.w_post *= adj;
+        if ((adj > 0.99 && adj < 1.01) || (delay <= 1)) {
+            p.w_pilot *= adj;
+            return;
+        }
+        if (p.dcount == DCAP) apply_earliest(p);        /* bounded store: make room (the reference's heap is unbounded) */
+        p.total_delayed *= adj;
+        double final_pos = cur + delay;
+        double delta = (final_pos - cur) / 7.0;
+        int i = p.dcount++;
+        p.dpos[i] = cur + delta;
+        p.dfac[i] = smc_exp(smc_log(adj) * (1.0 / 3));   /* pow(factor, 1.0/k), libm-free */
+        p.ddelta[i] = delta;
+        p.dk[i] = 3;
+    }
+    /* applyDelayedAdjustment (particle.hpp:199-209); the entry with the smallest position (ties: lowest index) */
+    void apply_earliest(Particle& p) {
+        int m = 0;
+        for (int i = 1; i < p.dcount; ++i) if (p.dpos[i] < p.dpos[m]) m = i;
+        p.w_pilot *= p.dfac[m];
+        p.total_delayed /= p.dfac[m];
+        if (p.dk[m] > 1) {
+            p.dpos[m] = p.dpos[m] + 2 * p.ddelta[m];
+            p.ddelta[m] = 2 * p.ddelta[m];
+            p.dk[m] -= 1;
+        } else {
+            int last = --p.dcount;
+            p.dpos[m] = p.dpos[last]; p.dfac[m] = p.dfac[last]; p.ddelta[m] = p.ddelta[last]; p.dk[m] = p.dk[last];
+        }
+    }
+    void apply_due(Particle& p, double extend_to) {      /* particle.cpp:910-916 */
+        for (;;) {
+            if (p.dcount == 0) return;
+            int m = 0;
+            for (int i = 1; i < p.dcount; ++i) if (p.dpos[i] < p.dpos[m]) m = i;
+            if (!(p.dpos[m] < extend_to)) return;
+            apply_earliest(p);
         }
     }
 
@@ -772,6 +907,7 @@ struct Filter {
         }
         for (int64_t i = Np - 1; i >= 0; --i) {
             Particle& p = parts[i];
+            if (p.dcount > 0) delayed_count += update_to[E - 1] - counted_to[E - 1];   /* count.cpp:395-397 */
             for (int e = E - 1; e >= first; --e) walk_chain(&p.head[e], p.w_post, e);
         }
         delayed_opp += update_to[E - 1] - counted_to[E - 1];
@@ -814,6 +950,8 @@ struct Filter {
                 if (q == lo[i] && cnt == 1) { d = std::move(src); continue; }
                 d.tr = src.tr; d.w_post = src.w_post; d.w_pilot = src.w_pilot;
                 d.next_base = src.next_base; d.Ltree = src.Ltree;
+                d.total_delayed = src.total_delayed; d.dcount = src.dcount;
+                for (int k = 0; k < src.dcount; ++k) { d.dpos[k] = src.dpos[k]; d.dfac[k] = src.dfac[k]; d.ddelta[k] = src.ddelta[k]; d.dk[k] = src.dk[k]; }
                 d.head = src.head;                       /* copyEventContainers: particle.cpp:139-148 */
                 for (Ev* h : d.head) if (h) ++h->refs;
             }
@@ -943,6 +1081,15 @@ void* smco_create(const smco_model* m, const smco_params* p) {
         for (int e = 0; e < M.E; ++e) M.inv2N[e] = 1.0 / (2.0 * m->pop_sizes[e]);
         M.recflags.assign(m->record_flags, m->record_flags + M.E);
         M.lags.assign(m->lags, m->lags + M.E);
+        if (m->n_bias_heights > 0) {
+            M.biased = true;
+            M.bias_H.push_back(0.0);
+            for (int k = 0; k < m->n_bias_heights; ++k) M.bias_H.push_back(m->bias_heights[k]);
+            M.bias_H.push_back(HUGE_VAL);
+            M.bias_S.assign(m->bias_strengths, m->bias_strengths + m->n_bias_heights + 1);
+            M.app_delays.assign(m->application_delays, m->application_delays + M.E);
+            M.delay_type = m->delay_type;
+        }
         f->Np = p->np; f->ess_fraction = p->ess_fraction; f->seed = p->seed;
         f->max_trace_events = p->max_trace_events;
         return f;

@@ -39,6 +39,12 @@ typedef struct smco_model {
     const int32_t* sample_pops;  /* [nsam] or NULL */
     const int32_t* record_flags; /* [E] bit0 record recomb, bit1 record coal/migr (pfparam.hpp:279-281) */
     const double* lags;          /* [E] bp (count.cpp:230-265) */
+    /* focused sampling + delayed importance weights (optional; n_bias_heights == 0 switches it off) */
+    int32_t n_bias_heights;      /* k interior band boundaries (-bias_heights, generations) */
+    int32_t delay_type;          /* 0 recombination height, 1 first coalescence, 2 first coal/migr (pfparam.hpp) */
+    const double* bias_heights;  /* [k] */
+    const double* bias_strengths;/* [k+1] */
+    const double* application_delays; /* [E] bp (smcsmc.cpp:306-307) */
 } smco_model;
 
 typedef struct smco_params {

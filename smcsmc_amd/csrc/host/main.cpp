@@ -78,15 +78,28 @@ static void pfARG_core(PfParam& P) {
             double top_t = e == E - 1 ? M.change_times[E - 1] : M.change_times[e + 1];
             lags[e] = P.lag > 0 ? P.lag : 4.0 / (M.recombination_rate * top_t);
         }
-    if (P.calibrate_lag) {
-        std::vector<double> med(E);
+    // calculate_median_survival_distances is always run by the reference (smcsmc.cpp:287); its result feeds the
+    // lags (when calibrating) and the application delays of the importance weights (smcsmc.cpp:306-307)
+    const bool biased = !M.bias_heights.empty();
+    std::vector<double> med(E, 0.0), app_delays(E, 0.0);
+    if (P.calibrate_lag || biased) {
         int64_t trees = 0;
         pm.lags = lags.data();
         pf_check(pf_median_survival(&pm, 1, 200, 1000000, med.data(), &trees, device));
+        for (int e = 0; e < E; ++e) clog << " Epoch " << e << ": survival distance " << med[e] << endl;
+    }
+    if (P.calibrate_lag)
+        for (int e = 0; e < E; ++e) lags[e] = med[e] * P.lag_fraction;      // reset_lag, count.cpp:261-265
+    if (biased) {
         for (int e = 0; e < E; ++e) {
-            clog << " Epoch " << e << ": survival distance " << med[e] << endl;
-            lags[e] = med[e] * P.lag_fraction;
+            app_delays[e] = med[e] * P.delay;                                 // Model::lags_to_application_delays
+            if (P.delay > 0) clog << " Application delay for epoch " << e << " set to " << app_delays[e] << endl;
         }
+        pm.n_bias_heights = (int32_t)M.bias_heights.size();
+        pm.delay_type = P.delay_type;
+        pm.bias_heights = M.bias_heights.data();
+        pm.bias_strengths = M.bias_strengths.data();
+        pm.application_delays = app_delays.data();
     }
     pm.lags = lags.data();
     clog << "    Lags set to:";

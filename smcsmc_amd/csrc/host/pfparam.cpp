@@ -246,7 +246,8 @@ void PfParam::parse(int argc, char* argv[]) {
             const string& v = next(a);
             delay = convert<double>(a, v);
             if (delay < 0.0) throw OutOfRange("-delay", v);
-        } else if (a == "-delay_coal" || a == "-delay_migr") { /* only meaningful with biased sampling */ }
+        } else if (a == "-delay_coal") delay_type = 1;      // RESAMPLE_DELAY_COAL
+        else if (a == "-delay_migr") delay_type = 2;       // RESAMPLE_DELAY_COALMIGR
         else if (a == "-ancestral_aware") ancestral_aware = true;
         else if (a == "-dephase") dephase = true;
         else if (a == "-apf") {
@@ -289,8 +290,11 @@ void PfParam::finalize() {
     default_loci_length = model.loci_length;
     if (model.change_times.back() >= top_t * 40000)
         throw std::invalid_argument("Problem: -tmax must be larger than bottom of final epoch");
-    if (!model.bias_heights.empty() || !model.bias_strengths.empty())
-        throw Unsupported("-bias_heights / -bias_strengths (focused sampling)");
+    if (!model.bias_heights.empty() || !model.bias_strengths.empty()) {
+        if (model.bias_strengths.size() != model.bias_heights.size() + 1)
+            throw std::invalid_argument("-bias_strengths should have one more value than -bias_heights");
+        if (model.bias_heights.size() > 8) throw Unsupported("more than 8 bias heights");
+    }
     while (record_event_in_epoch.size() < model.change_times.size())
         record_event_in_epoch.push_back(RECORD_COALMIGR_EVENT | RECORD_RECOMB_EVENT);
     if (record_event_in_epoch.size() > model.change_times.size())

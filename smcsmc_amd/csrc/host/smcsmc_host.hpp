@@ -151,6 +151,7 @@ class PfParam {   // pfparam.hpp:225-446
     bool calibrate_lag = true;
     double lag_fraction = 2.0;
     double delay = 0.5;
+    int delay_type = 0;          // ResampleDelayType: 0 recombination (default), 1 coalescence, 2 coal/migr
     bool ancestral_aware = false, dephase = false;
     int auxiliary_particle_filter = 0;
     double start_position = 1;

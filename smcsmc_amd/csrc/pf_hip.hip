@@ -27,6 +27,8 @@
 #include "pf_tree_reg.h"
 
 #define PF_EMAX 64
+#define PF_DCAP 32            // pending delayed factors per particle (the reference's heap is unbounded)
+#define PF_BIAS_MAX 8         // interior bias heights
 #define PF_DECIDE_TAB 16384   // offspring / parent tables fit LDS (16-bit entries) up to this many particles
 #define PF_LEDGER_BLOCKS 192   // extra workgroups of k_resample that maintain the ancestor ledger
 #define REC_RECOMB 1
@@ -44,6 +46,13 @@ struct DState {
     double* x_mark;
     double* Ltree;
     int* mark_limit;
+    // delayed importance factors (particle.hpp:59-101, 185-209); allocated only with focused sampling
+    double* total_delayed;   // [Np]
+    int* dcount;             // [Np]
+    double* dpos;            // [PF_DCAP][Np] application positions
+    double* dfac;            // [PF_DCAP][Np]
+    double* ddelta;          // [PF_DCAP][Np]
+    int* dk;                 // [PF_DCAP][Np]
 };
 
 struct Ctrl {
@@ -51,6 +60,7 @@ struct Ctrl {
     double logl;           // ln_normalization_factor_
     double inv_T, T, S1, S2, ess, u;
     double delayed_opp;
+    double delayed_count;
     double counted_to[PF_EMAX];
     double update_to[PF_EMAX];
     long long n_resample;
@@ -82,6 +92,13 @@ struct KArgs {
     long long Np;
     double ess_threshold;
     unsigned long long seed;
+    // focused sampling
+    int n_bias, delay_type;
+    double bias_H[PF_BIAS_MAX + 2];
+    double bias_S[PF_BIAS_MAX + 1];
+    const double* app_delays;
+    int* chunk_dpend;              // [nc] particles with pending delayed factors, per wavefront
+    double delayed_count_unused;
     // state
     DState st[2];
     unsigned long long* rng_ctr;   // slot-owned
@@ -209,7 +226,7 @@ __global__ __launch_bounds__(PF_BS) void k_init(KArgs A, double initial_position
         Ctrl* c = A.ctrl;
         c->cur_pos = initial_position;
         c->logl = 0; c->inv_T = 1; c->T = 1; c->flag = 0; c->cur = 0; c->gen = 0; c->n_resample = 0;
-        c->first_epoch = A.E; c->err = 0; c->delayed_opp = 0; c->count_active = 0; c->end_seq = 0;
+        c->first_epoch = A.E; c->err = 0; c->delayed_opp = 0; c->delayed_count = 0; c->count_active = 0; c->end_seq = 0;
         c->g_retain = 0; c->pending_fin = 0; c->nbx_used = A.nbx; c->gen_prev = 0; c->nres_prev = 0;
         for (int e = 0; e < A.E; ++e) { c->counted_to[e] = 0; c->update_to[e] = 0; c->g_lo[e] = 0; c->g_hi[e] = 0; }
         A.gen_x0[0] = 0.0;
@@ -259,6 +276,7 @@ __global__ __launch_bounds__(PF_BS) void k_init(KArgs A, double initial_position
     st.x_mark[p] = 0.0;
     st.Ltree[p] = ln.Ltree;
     st.mark_limit[p] = A.E - 1;
+    if (A.n_bias > 0) { st.total_delayed[p] = 1.0; st.dcount[p] = 0; }
     A.rng_ctr[p] = ln.ctr;
     A.ebuf[p] = ln.ebuf;
     A.widx[p] = widx;
@@ -535,12 +553,60 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
 // ------------------------------------------------------------------ k_extend_reg
 // Same computation as k_extend with the local tree held in registers (pf_tree_reg.h); used for
 // n <= 8.  LDS only carries the two epoch tables.
-template <int NM>
+// delayed importance weights: adjustWeightsWithDelay / applyDelayedAdjustment (particle.hpp:185-209)
+struct DStore {
+    double* pos; double* fac; double* delta; int* k;   // column of this particle: element i at [i * Np]
+    long long Np;
+    int count;
+    double total;
+};
+__device__ __forceinline__ void d_apply_earliest(DStore& d, double& w_pilot) {
+    int m = 0;
+    double pm = d.pos[0];
+    for (int i = 1; i < d.count; ++i) { double pi = d.pos[(size_t)i * d.Np]; if (pi < pm) { pm = pi; m = i; } }
+    double f = d.fac[(size_t)m * d.Np];
+    w_pilot *= f;
+    d.total /= f;
+    int km = d.k[(size_t)m * d.Np];
+    if (km > 1) {
+        double dl = d.delta[(size_t)m * d.Np];
+        d.pos[(size_t)m * d.Np] = pm + 2 * dl;
+        d.delta[(size_t)m * d.Np] = 2 * dl;
+        d.k[(size_t)m * d.Np] = km - 1;
+    } else {
+        int last = --d.count;
+        d.pos[(size_t)m * d.Np] = d.pos[(size_t)last * d.Np];
+        d.fac[(size_t)m * d.Np] = d.fac[(size_t)last * d.Np];
+        d.delta[(size_t)m * d.Np] = d.delta[(size_t)last * d.Np];
+        d.k[(size_t)m * d.Np] = d.k[(size_t)last * d.Np];
+    }
+}
+__device__ __forceinline__ void d_adjust_with_delay(DStore& d, double& w_post, double& w_pilot, double adj, double delay, double cur) {
+    w_post *= adj;
+    if ((adj > 0.99 && adj < 1.01) || (delay <= 1)) { w_pilot *= adj; return; }
+    if (d.count == PF_DCAP) d_apply_earliest(d, w_pilot);
+    d.total *= adj;
+    double final_pos = cur + delay;
+    double delta = (final_pos - cur) / 7.0;
+    int i = d.count++;
+    d.pos[(size_t)i * d.Np] = cur + delta;
+    d.fac[(size_t)i * d.Np] = dexp(dlog(adj) * (1.0 / 3));
+    d.delta[(size_t)i * d.Np] = delta;
+    d.k[(size_t)i * d.Np] = 3;
+}
+
+template <int NM, bool BIASED>
 __global__ __launch_bounds__(PF_BS) void k_extend_reg(KArgs A, long long s) {
     extern __shared__ double smem[];
     double* sT = smem;
     double* sI = smem + A.E;
+    double* sBH = sI + A.E;                       // bias band boundaries / strengths (focused sampling)
+    double* sBS = sBH + (PF_BIAS_MAX + 2);
     for (int e = threadIdx.x; e < A.E; e += blockDim.x) { sT[e] = A.T[e]; sI[e] = A.inv2N[e]; }
+    if (BIASED && threadIdx.x < PF_BIAS_MAX + 2) {
+        sBH[threadIdx.x] = A.bias_H[threadIdx.x];
+        if (threadIdx.x < PF_BIAS_MAX + 1) sBS[threadIdx.x] = A.bias_S[threadIdx.x];
+    }
     __syncthreads();
     const Ctrl* c = A.ctrl;
     const int n = A.n;
@@ -549,6 +615,7 @@ __global__ __launch_bounds__(PF_BS) void k_extend_reg(KArgs A, long long s) {
     const bool active = p < A.Np;
     const int lane = threadIdx.x & 63;
     double w_post = 0.0, w_pilot = 0.0;
+    bool has_pending = false;
     if (active) {
         DState& st = A.st[cur];
         RTree<NM> t;
@@ -564,6 +631,12 @@ __global__ __launch_bounds__(PF_BS) void k_extend_reg(KArgs A, long long s) {
         RCtx cx;
         cx.T = sT; cx.I = sI; cx.E = A.E; cx.n = n; cx.L = A.L; cx.mu = A.mu; cx.rho = A.rho;
         cx.seed = A.seed; cx.slot = (unsigned)p; cx.stream = 0;
+        cx.nb = A.n_bias + 1; cx.bH = sBH; cx.bS = sBS; cx.last_iw = 1.0;
+        DStore ds;
+        if (BIASED) {
+            ds.pos = st.dpos + p; ds.fac = st.dfac + p; ds.delta = st.ddelta + p; ds.k = st.dk + p; ds.Np = A.Np;
+            ds.count = st.dcount[p]; ds.total = st.total_delayed[p];
+        }
         w_post = st.w_post[p];
         w_pilot = st.w_pilot[p];
         double next_base = st.next_base[p];
@@ -611,19 +684,43 @@ __global__ __launch_bounds__(PF_BS) void k_extend_reg(KArgs A, long long s) {
 #pragma unroll
                 for (int r = 0; r < RTree<NM>::NI; ++r) if (r < n - 1) rec[5 + r] = t.S[r];
                 double h, tc;
-                r_genealogy_update(cx, t, &h, &tc);
+                r_genealogy_update<NM, BIASED>(cx, t, &h, &tc);
                 rec[2] = h;
                 rec[3] = tc;
                 rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n));
                 ++widx;
                 if (leaf_status == 0) B = r_tracked_len(t, n, present_mask);
                 if (leaf_status == 1) B = cx.Ltree;
+                if (BIASED) {
+                    // particle.cpp:866-891: immediate vs delayed application of the importance weight
+                    double iw = cx.last_iw, rbiw = cx.last_iw;
+                    double delay_height = A.delay_type == 0 ? h : tc;
+                    int idx = 0;
+                    while (idx + 1 < cx.nb + 1 && sBH[idx + 1] < delay_height) ++idx;
+                    if (idx >= cx.nb) idx = cx.nb - 1;
+                    if (sBS[idx] == 1.0) { w_post *= rbiw; w_pilot *= rbiw; iw /= rbiw; }
+                    double delay = A.app_delays[r_epoch_of(cx, delay_height)];
+                    d_adjust_with_delay(ds, w_post, w_pilot, iw, delay, updated_to);
+                }
                 next_base = r_sample_next_base(cx, updated_to);
                 x_mark = updated_to;
                 mark_limit = limit;
             }
         }
 
+        if (BIASED) {
+            // apply the factors that fell due during this extension (particle.cpp:910-916)
+            for (;;) {
+                if (ds.count == 0) break;
+                double pm = ds.pos[0];
+                for (int i = 1; i < ds.count; ++i) { double pi = ds.pos[(size_t)i * ds.Np]; if (pi < pm) pm = pi; }
+                if (!(pm < extend_to)) break;
+                d_apply_earliest(ds, w_pilot);
+            }
+            st.dcount[p] = ds.count;
+            st.total_delayed[p] = ds.total;
+            has_pending = ds.count > 0;
+        }
         if (A.seg_state[s] == 0) {
             const bool dephase = A.flags & 2;
             const bool anc = A.flags & 1;
@@ -697,6 +794,10 @@ __global__ __launch_bounds__(PF_BS) void k_extend_reg(KArgs A, long long s) {
         A.chunk_pp[chunk] = scp;
         A.chunk_mx1[chunk] = scm;
     }
+    if (BIASED) {
+        unsigned long long pend = __ballot(has_pending);
+        if (lane == 0 && chunk < (A.Np + 63) / 64) A.chunk_dpend[chunk] = __popcll(pend);
+    }
 }
 
 // ------------------------------------------------------------------ count bookkeeping (shared)
@@ -768,6 +869,13 @@ __device__ void window_generations(const KArgs& A, Ctrl* c, const Windows& W, in
         for (int e = 1; e < E; ++e) gr = c->g_lo[e] < gr ? c->g_lo[e] : gr;
         c->g_retain = gr;
         c->delayed_opp += W.b[E - 1] - W.a[E - 1];
+        if (A.n_bias > 0) {
+            // update_delayed_weight_count (count.cpp:395-397): particles that carry pending factors
+            long long npend = 0;
+            const int ncq = (int)((A.Np + 63) / 64);
+            for (int q = 0; q < ncq; ++q) npend += A.chunk_dpend[q];
+            c->delayed_count += (double)npend * (W.b[E - 1] - W.a[E - 1]);
+        }
         c->first_epoch = W.first;
         c->count_active = W.first < E;
         c->pending_fin = W.first < E;
@@ -1384,6 +1492,18 @@ __global__ __launch_bounds__(PF_BS) void k_resample(KArgs A, long long s, int nb
     dst.Ltree[q] = Lt;
     dst.x_mark[q] = pos;
     dst.mark_limit[q] = src.mark_limit[a];
+    if (A.n_bias > 0) {
+        // the copy constructor copies the pending factors (particle.cpp:122-123)
+        int dc = src.dcount[a];
+        dst.dcount[q] = dc;
+        dst.total_delayed[q] = src.total_delayed[a];
+        for (int k = 0; k < dc; ++k) {
+            dst.dpos[(size_t)k * Np + q] = src.dpos[(size_t)k * Np + a];
+            dst.dfac[(size_t)k * Np + q] = src.dfac[(size_t)k * Np + a];
+            dst.ddelta[(size_t)k * Np + q] = src.ddelta[(size_t)k * Np + a];
+            dst.dk[(size_t)k * Np + q] = src.dk[(size_t)k * Np + a];
+        }
+    }
     double nb = src.next_base[a];
     if (q != lo[a] && pos < A.L) {
         // a copy: draw a fresh recombination position from slot q's own stream (pc.cpp:357-368)
@@ -1576,6 +1696,10 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     if (m->nsam < 2 || m->nsam > PF_NMAX) return fail("pf_create: nsam must be in 2..16");
     if (m->n_epochs < 1 || m->n_epochs > PF_EMAX) return fail("pf_create: n_epochs must be in 1..64");
     if (p->np < 1 || p->np > 262144) return fail("pf_create: np must be in 1..262144");
+    if (m->n_bias_heights < 0 || m->n_bias_heights > PF_BIAS_MAX) return fail("pf_create: at most 8 bias heights are supported");
+    if (m->n_bias_heights > 0 && m->nsam > 8) return fail("pf_create: focused sampling is implemented for nsam <= 8");
+    if (m->n_bias_heights > 0 && (!m->bias_heights || !m->bias_strengths || !m->application_delays))
+        return fail("pf_create: bias_heights, bias_strengths and application_delays must all be given");
     pf_handle* h = new pf_handle();
     h->device = device;
     if (hipSetDevice(device) != hipSuccess) { delete h; return fail("hipSetDevice failed"); }
@@ -1609,6 +1733,19 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     hipMemcpyAsync(dRF, m->record_flags, E * 4, hipMemcpyHostToDevice, h->stream);
     hipStreamSynchronize(h->stream);
     A.T = dT; A.inv2N = dI; A.lags = dlag; A.recflags = dRF;
+    A.n_bias = m->n_bias_heights;
+    A.delay_type = m->delay_type;
+    for (int k = 0; k < PF_BIAS_MAX + 2; ++k) A.bias_H[k] = HUGE_VAL;
+    for (int k = 0; k < PF_BIAS_MAX + 1; ++k) A.bias_S[k] = 1.0;
+    A.bias_H[0] = 0.0;
+    if (A.n_bias > 0) {
+        for (int k = 0; k < A.n_bias; ++k) A.bias_H[k + 1] = m->bias_heights[k];
+        for (int k = 0; k <= A.n_bias; ++k) A.bias_S[k] = m->bias_strengths[k];
+        double* dad;
+        if (dalloc(h, &dad, E)) { pf_destroy(h); return nullptr; }
+        hipMemcpy(dad, m->application_delays, E * 8, hipMemcpyHostToDevice);
+        A.app_delays = dad;
+    }
     for (int b = 0; b < 2; ++b) {
         rc |= dalloc(h, &A.st[b].S, (size_t)(n - 1) * Np);
         rc |= dalloc(h, &A.st[b].C, (size_t)2 * (n - 1) * Np);
@@ -1618,6 +1755,14 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
         rc |= dalloc(h, &A.st[b].x_mark, Np);
         rc |= dalloc(h, &A.st[b].Ltree, Np);
         rc |= dalloc(h, &A.st[b].mark_limit, Np);
+        if (m->n_bias_heights > 0) {
+            rc |= dalloc(h, &A.st[b].total_delayed, Np);
+            rc |= dalloc(h, &A.st[b].dcount, Np);
+            rc |= dalloc(h, &A.st[b].dpos, (size_t)PF_DCAP * Np);
+            rc |= dalloc(h, &A.st[b].dfac, (size_t)PF_DCAP * Np);
+            rc |= dalloc(h, &A.st[b].ddelta, (size_t)PF_DCAP * Np);
+            rc |= dalloc(h, &A.st[b].dk, (size_t)PF_DCAP * Np);
+        }
     }
     rc |= dalloc(h, &A.rng_ctr, Np);
     rc |= dalloc(h, &A.ebuf, Np);
@@ -1638,6 +1783,7 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     rc |= dalloc(h, &A.chunk_post, nc); rc |= dalloc(h, &A.chunk_sq, nc); rc |= dalloc(h, &A.chunk_pil, nc);
     rc |= dalloc(h, &A.scan1, Np); rc |= dalloc(h, &A.chunk_off, nc); rc |= dalloc(h, &A.l2scan, nc);
     rc |= dalloc(h, &A.scan1m, Np); rc |= dalloc(h, &A.chunk_mx1, nc);
+    rc |= dalloc(h, &A.chunk_dpend, nc);
     rc |= dalloc(h, &A.scanp, Np); rc |= dalloc(h, &A.chunk_pp, nc); rc |= dalloc(h, &A.chunk_offp, nc); rc |= dalloc(h, &A.l2scanp, nc);
     A.nbx = h->nblocks;
     rc |= dalloc(h, &A.totals, (size_t)6 * E);
@@ -1797,11 +1943,16 @@ static int launch_extend(pf_handle* h, long long s) {
     const bool t = timing_on(h, s);
     {
         Timed tm(h, 0, t);
-        const size_t smem_reg = (size_t)2 * h->E * 8;
-        if (h->n <= 4 && !h->force_lds)
-            hipLaunchKernelGGL(k_extend_reg<4>, dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s);
+        const size_t smem_reg = (size_t)(2 * h->E + 2 * PF_BIAS_MAX + 3) * 8;
+        const bool biased = h->A.n_bias > 0;
+        if (h->n <= 4 && biased)
+            hipLaunchKernelGGL((k_extend_reg<4, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s);
+        else if (h->n <= 8 && biased)
+            hipLaunchKernelGGL((k_extend_reg<8, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s);
+        else if (h->n <= 4 && !h->force_lds)
+            hipLaunchKernelGGL((k_extend_reg<4, false>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s);
         else if (h->n <= 8 && !h->force_lds)
-            hipLaunchKernelGGL(k_extend_reg<8>, dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s);
+            hipLaunchKernelGGL((k_extend_reg<8, false>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s);
         else
             hipLaunchKernelGGL(k_extend, dim3(h->nblocks), dim3(PF_BS), h->smem, h->stream, h->A, s);
     }
@@ -1924,7 +2075,7 @@ int pf_get_counts(pf_handle* h, double* out, int32_t n) {
     Ctrl c;
     HIPCHK(hipMemcpy(&c, h->A.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
     out[6 * E + 0] = c.delayed_opp;
-    out[6 * E + 1] = 0.0;
+    out[6 * E + 1] = c.delayed_count;
     out[6 * E + 2] = (double)c.n_resample;
     out[6 * E + 3] = c.logl;
     return 0;

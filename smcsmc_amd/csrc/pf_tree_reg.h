@@ -53,6 +53,11 @@ struct RCtx {
     unsigned long long ctr;
     double ebuf;
     double Ltree;
+    // focused sampling (particle.cpp:1020-1126): nb bands, band b = [H[b], H[b+1]) weighs S[b]
+    int nb;
+    const double* bH;
+    const double* bS;
+    double last_iw;
 };
 
 __device__ __forceinline__ double r_uni(RCtx& cx) { return philox_uniform(cx.seed, cx.slot, cx.stream, cx.ctr++); }
@@ -207,30 +212,101 @@ __device__ __forceinline__ double r_sample_next_base(RCtx& cx, double x) {
     return nb;
 }
 
-// One SMC' genealogy update; mirrors genealogy_update() in pf_hip.hip / Filter::genealogy_update in the oracle.
+// samplePoint with height-band weights (particle.cpp:1020-1126); pieces = (time slice) x (band), ascending in
+// height; same operation order as the oracle's biased branch of Filter::genealogy_update.
 template <int NM>
+__device__ __forceinline__ void r_sample_point_biased(RCtx& cx, const RTree<NM>& t, double* h_out, int* lin_out) {
+    const int n = cx.n;
+    const int nb = cx.nb;
+    double Lw = 0.0;
+    {
+        double pv = 0.0;
+        int b = 0;
+#pragma unroll
+        for (int ri = 0; ri < RTree<NM>::NI; ++ri)
+            if (ri < n - 1) {
+                int k = n - ri;
+                double top = t.S[ri];
+                while (b + 1 < nb && cx.bH[b + 1] <= pv) ++b;
+                int bb = b;
+                for (;;) {
+                    double lo_ = pv > cx.bH[bb] ? pv : cx.bH[bb];
+                    double hi_ = top < cx.bH[bb + 1] ? top : cx.bH[bb + 1];
+                    if (hi_ > lo_) Lw += ((double)k * cx.bS[bb]) * (hi_ - lo_);
+                    if (cx.bH[bb + 1] >= top || bb + 1 >= nb) break;
+                    ++bb;
+                }
+                pv = top;
+            }
+    }
+    double r = r_uni(cx) * Lw;
+    double l_lo = 0, l_hi = 0, l_str = 1;
+    int l_k = 1;
+    bool sel = false;
+    double pv = 0.0;
+    int b = 0;
+#pragma unroll
+    for (int ri = 0; ri < RTree<NM>::NI; ++ri)
+        if (ri < n - 1 && !sel) {
+            int k = n - ri;
+            double top = t.S[ri];
+            while (b + 1 < nb && cx.bH[b + 1] <= pv) ++b;
+            int bb = b;
+            for (;;) {
+                double lo_ = pv > cx.bH[bb] ? pv : cx.bH[bb];
+                double hi_ = top < cx.bH[bb + 1] ? top : cx.bH[bb + 1];
+                if (hi_ > lo_) {
+                    double wlen = ((double)k * cx.bS[bb]) * (hi_ - lo_);
+                    l_lo = lo_; l_hi = hi_; l_str = cx.bS[bb]; l_k = k;
+                    if (r < wlen) { sel = true; break; }
+                    r -= wlen;
+                }
+                if (cx.bH[bb + 1] >= top || bb + 1 >= nb) break;
+                ++bb;
+            }
+            pv = top;
+        }
+    double q = r / (l_str * (l_hi - l_lo));
+    int lin = min((int)q, l_k - 1);
+    if (lin < 0) lin = 0;
+    double h = l_lo + (q - (double)lin) * (l_hi - l_lo);
+    if (!(h < l_hi)) h = l_lo;
+    double sampled = l_str / Lw;
+    double target = 1.0 / cx.Ltree;
+    cx.last_iw = target / sampled;
+    *h_out = h;
+    *lin_out = lin;
+}
+
+// One SMC' genealogy update; mirrors genealogy_update() in pf_hip.hip / Filter::genealogy_update in the oracle.
+template <int NM, bool BIASED>
 __device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, double* h_out, double* tc_out) {
     const int n = cx.n;
-    double r = r_uni(cx) * cx.Ltree;
-    double prev = 0.0, h = 0.0;
+    double h = 0.0;
     int lin = 0;
-    bool done = false;
+    if (BIASED) {
+        r_sample_point_biased(cx, t, &h, &lin);
+    } else {
+        double r = r_uni(cx) * cx.Ltree;
+        double prev = 0.0;
+        bool done = false;
 #pragma unroll
-    for (int ri = 0; ri < RTree<NM>::NI; ++ri) {
-        if (!done && ri < n - 1) {
-            int k = n - ri;
-            double sr = t.S[ri];
-            double d = sr - prev;
-            double seg = (double)k * d;
-            if (r < seg || ri == n - 2) {
-                double q = r / d;
-                lin = min((int)q, k - 1);
-                h = prev + (q - (double)lin) * d;
-                if (!(h < sr)) h = prev;
-                done = true;
-            } else {
-                r -= seg;
-                prev = sr;
+        for (int ri = 0; ri < RTree<NM>::NI; ++ri) {
+            if (!done && ri < n - 1) {
+                int k = n - ri;
+                double sr = t.S[ri];
+                double d = sr - prev;
+                double seg = (double)k * d;
+                if (r < seg || ri == n - 2) {
+                    double q = r / d;
+                    lin = min((int)q, k - 1);
+                    h = prev + (q - (double)lin) * d;
+                    if (!(h < sr)) h = prev;
+                    done = true;
+                } else {
+                    r -= seg;
+                    prev = sr;
+                }
             }
         }
     }

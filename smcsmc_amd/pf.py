@@ -35,6 +35,9 @@ class _Model(C.Structure):
         ("mig_rates", C.POINTER(C.c_double)), ("single_mig", C.POINTER(C.c_double)),
         ("sample_pops", C.POINTER(C.c_int32)), ("record_flags", C.POINTER(C.c_int32)),
         ("lags", C.POINTER(C.c_double)),
+        ("n_bias_heights", C.c_int32), ("delay_type", C.c_int32),
+        ("bias_heights", C.POINTER(C.c_double)), ("bias_strengths", C.POINTER(C.c_double)),
+        ("application_delays", C.POINTER(C.c_double)),
     ]
 
 
@@ -112,6 +115,25 @@ def _err(L):
     return (L.pf_last_error() or b"").decode()
 
 
+def _attach_bias(owner, cmodel, m):
+    """Focused sampling (-bias_heights / -bias_strengths) and the application delays of the delayed
+    importance weights; absent keys switch the feature off."""
+    bh = m.get("bias_heights")
+    if bh is None or len(bh) == 0:
+        cmodel.n_bias_heights = 0
+        return
+    owner._bh = np.ascontiguousarray(bh, dtype=np.float64)
+    owner._bs = np.ascontiguousarray(m["bias_strengths"], dtype=np.float64)
+    owner._ad = np.ascontiguousarray(m["application_delays"], dtype=np.float64)
+    if len(owner._bs) != len(owner._bh) + 1 or len(owner._ad) != cmodel.n_epochs:
+        raise PfError("bias_strengths needs one more entry than bias_heights; application_delays one per epoch")
+    cmodel.n_bias_heights = len(owner._bh)
+    cmodel.delay_type = int(m.get("delay_type", 0))
+    cmodel.bias_heights = _dp(owner._bh)
+    cmodel.bias_strengths = _dp(owner._bs)
+    cmodel.application_delays = _dp(owner._ad)
+
+
 KERNEL_CLASSES = ("extend", "decide", "count", "resample")
 
 
@@ -131,6 +153,7 @@ class ParticleFilter:
         self._model = _Model(E, P, self.nsam, flags, float(m["loci_length"]), float(m["mutation_rate"]),
                              float(m["recombination_rate"]), _dp(self._ct), _dp(self._ps), None, None, None,
                              self._rf.ctypes.data_as(C.POINTER(C.c_int32)), _dp(self._lags))
+        _attach_bias(self, self._model, m)
         self._params = _Params(self.Np, float(ess_fraction), int(seed), self.max_trace_events, 0)
         self.h = self.L.pf_create(C.byref(self._model), C.byref(self._params), int(device))
         if not self.h:

@@ -22,6 +22,9 @@ class Model(C.Structure):
         ("mig_rates", C.POINTER(C.c_double)), ("single_mig", C.POINTER(C.c_double)),
         ("sample_pops", C.POINTER(C.c_int32)), ("record_flags", C.POINTER(C.c_int32)),
         ("lags", C.POINTER(C.c_double)),
+        ("n_bias_heights", C.c_int32), ("delay_type", C.c_int32),
+        ("bias_heights", C.POINTER(C.c_double)), ("bias_strengths", C.POINTER(C.c_double)),
+        ("application_delays", C.POINTER(C.c_double)),
     ]
 
 
@@ -84,6 +87,23 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def attach_bias(owner, cmodel, m):
+    """Optional focused-sampling fields of the model struct (kept alive on `owner`)."""
+    bh = m.get("bias_heights")
+    if bh is None or len(bh) == 0:
+        cmodel.n_bias_heights = 0
+        return
+    owner._bh = np.ascontiguousarray(bh, dtype=np.float64)
+    owner._bs = np.ascontiguousarray(m["bias_strengths"], dtype=np.float64)
+    owner._ad = np.ascontiguousarray(m["application_delays"], dtype=np.float64)
+    assert len(owner._bs) == len(owner._bh) + 1 and len(owner._ad) == cmodel.n_epochs
+    cmodel.n_bias_heights = len(owner._bh)
+    cmodel.delay_type = int(m.get("delay_type", 0))
+    cmodel.bias_heights = _dp(owner._bh)
+    cmodel.bias_strengths = _dp(owner._bs)
+    cmodel.application_delays = _dp(owner._ad)
+
+
 class PackedInputs:
     """Owns the numpy buffers behind the C structs (same layout for oracle and product)."""
 
@@ -101,6 +121,7 @@ class PackedInputs:
                                float(m["recombination_rate"]), _dp(self.change_times), _dp(self.pop_sizes),
                                None, None, None,
                                self.record_flags.ctypes.data_as(C.POINTER(C.c_int32)), _dp(self.lags))
+        attach_bias(self, self.model, m)
         self.segs = None
         if segs is not None:
             self.start = np.ascontiguousarray(segs["start"], dtype=np.float64)

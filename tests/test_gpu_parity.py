@@ -254,3 +254,49 @@ def test_binary_end_to_end_matches_library_and_front_end_contract(oracle, hiplib
                                           "-o", str(tmp_path / "cal")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "LogL" in open(tmp_path / "cal.out").read()
+    # the reference's regression configuration: focused sampling with delayed importance weights
+    # (test/old/newtests/test_const_pop_size.py:29-37: lag 2, Np 1000, bias_heights [400], bias_strengths [3,1], tmax 4)
+    r = subprocess.run([binary] + core + ["-nsam", "2", "-Np", "1000", "-EM", "0", "-tmax", "4", "-calibrate_lag", "2", "-seed", "1",
+                                          "-bias_heights", "400", "-bias_strengths", "3", "1", "-seg", seg,
+                                          "-o", str(tmp_path / "bias")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    d = outfile.parse_outfile(str(tmp_path / "bias.out"))
+    rec = d[(("Recomb", -1, -1, -1, -1), "Count")] / d[(("Recomb", -1, -1, -1, -1), "Opp")]
+    assert 0.8e-8 < rec < 1.2e-8                      # truth 1e-8
+    assert d[(("Delay", -1, -1, -1, -1), "Count")] > 0
+
+
+@pytest.mark.parametrize("n,delay_type", [(4, 0), (2, 1), (6, 0)])
+def test_focused_sampling_and_delayed_importance_weights(oracle, hiplib, n, delay_type):
+    """-bias_heights / -bias_strengths with delayed application of the importance weights
+    (particle.cpp:866-891, 1020-1126; particle.hpp:59-101, 185-209): the configuration of the reference's own
+    regression tests (test_const_pop_size.py:34-35: bias_heights [400], bias_strengths [3, 1])."""
+    model = cases.make_model(n=n, E=8, L=1.2e5)
+    model.update(bias_heights=[400.0], bias_strengths=[3.0, 1.0], delay_type=delay_type,
+                 application_delays=np.array(model["lags"]) * 0.25)
+    segs = cases.make_segments(model, seed=17 + n, max_seg_len=5000)
+    o, si, g = _run_both(oracle, model, segs, 700, seed=5)
+    o.run(si); g.run(); g.finish()
+    to, tg = o.trace(), g.trace()
+    assert (to["resampled"] == tg["resampled"]).all() and to["resampled"].sum() > 0
+    for k in ("T", "ess", "logl"):
+        assert (_bits(to[k]) == _bits(tg[k])).all(), k
+    so, po_ = o.resample_events(); sg, pg_ = g.resample_events()
+    assert (so == sg).all() and (po_ == pg_).all()
+    _assert_state_equal(o, g)
+    co, cg = o.counts(), g.counts()
+    _assert_counts_close(co, cg)
+    assert co["delayed_count"] > 0 and cg["delayed_count"] == pytest.approx(co["delayed_count"], rel=1e-12)
+    # pilot and posterior weights differ while factors are pending
+    p = g.particles()
+    assert not np.allclose(p["w_post"], p["w_pilot"])
+
+
+def test_three_bias_bands(oracle, hiplib):
+    model = cases.make_model(n=4, E=6, L=8e4)
+    model.update(bias_heights=[300.0, 5000.0], bias_strengths=[4.0, 1.0, 0.5], application_delays=np.full(6, 3000.0))
+    segs = cases.make_segments(model, seed=44, max_seg_len=5000)
+    o, si, g = _run_both(oracle, model, segs, 300, seed=9)
+    o.run(si); g.run(); g.finish()
+    assert (_bits(o.trace()["logl"]) == _bits(g.trace()["logl"])).all()
+    _assert_counts_close(o.counts(), g.counts())
