@@ -76,6 +76,8 @@ struct Ctrl {
     int end_seq;
     int pending_fin;       // k_count partials of the previous step still have to be folded into the totals
     long long nres_prev;   // n_resample as of the end of the last k_resample (stable during k_decide)
+    // what the counting stream needs to know about a step, double-buffered by step parity
+    struct StepInfo { double inv_T; int G; int flag; } step[2];
     int gen_prev;          // generation index as of the end of the last k_resample (stable during k_decide)
     int nbx_used;
 };
@@ -127,11 +129,19 @@ struct KArgs {
     double* scan1;                 // [Np] within-wavefront inclusive scan of the pilot weights
     double* chunk_off;             // [nc]
     double* l2scan;                // [nc]
-    double* scanp;                 // [Np] within-wavefront inclusive scan of the posterior weights
+    double* scanp2[2];             // [Np] within-wavefront inclusive scan of the posterior weights (by step parity)
+    // snapshot of what k_count needs from the live particles of a step (by step parity): the counting stream
+    // runs concurrently with k_resample / the next k_extend, which rewrite the live state
+    double* snap_w[2];             // [Np] raw posterior weight
+    double* snap_S[2];             // [(n-1)][Np]
+    double* snap_xm[2];            // [Np] x_mark
+    int* snap_ml[2];               // [Np] mark_limit
+    unsigned* snap_widx[2];        // [Np]
+    int sp;                        // parity of the step this launch belongs to (set by the host per launch)
     double* scan1m;                // [Np] running max of scan1 inside the wavefront
     double* chunk_mx1;             // [nc] max of scan1 per wavefront
     double* chunk_pp;              // [nc] its per-wavefront totals
-    double* chunk_offp;            // [nc] exclusive offsets of the posterior scan
+    double* chunk_offp2[2];        // [nc] exclusive offsets of the posterior scan (by step parity)
     double* l2scanp;               // [nc]
     // counting
     double* totals;                // [6][E]
@@ -532,6 +542,8 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
         A.rng_ctr[p] = ln.ctr;
         A.ebuf[p] = ln.ebuf;
         A.widx[p] = widx;
+        for (int r = 0; r < n - 1; ++r) A.snap_S[A.sp][(size_t)r * A.Np + p] = LS(ln, r);
+        A.snap_w[A.sp][p] = w_post; A.snap_xm[A.sp][p] = x_mark; A.snap_ml[A.sp][p] = mark_limit; A.snap_widx[A.sp][p] = widx;
     }
     // per-wavefront canonical partials (level 1 of the radix-64 reduction / scan)
     double sp = wave_tree_sum(w_post);
@@ -540,7 +552,7 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
     double scp = wave_hs_scan(w_post, lane);
     double scm = wave_max_scan_d(sc, lane);     // running max of the pilot scan (a parallel FP scan need not be monotone)
     long long chunk = p >> 6;
-    if (active) { A.scan1[p] = sc; A.scanp[p] = scp; A.scan1m[p] = scm; }
+    if (active) { A.scan1[p] = sc; A.scanp2[A.sp][p] = scp; A.scan1m[p] = scm; }
     if (lane == 63 && chunk < (A.Np + 63) / 64) {
         A.chunk_post[chunk] = sp;
         A.chunk_sq[chunk] = sq;
@@ -779,6 +791,9 @@ __global__ __launch_bounds__(PF_BS) void k_extend_reg(KArgs A, long long s) {
         A.rng_ctr[p] = cx.ctr;
         A.ebuf[p] = cx.ebuf;
         A.widx[p] = widx;
+#pragma unroll
+        for (int r = 0; r < RTree<NM>::NI; ++r) if (r < n - 1) A.snap_S[A.sp][(size_t)r * A.Np + p] = t.S[r];
+        A.snap_w[A.sp][p] = w_post; A.snap_xm[A.sp][p] = x_mark; A.snap_ml[A.sp][p] = mark_limit; A.snap_widx[A.sp][p] = widx;
     }
     double sp = wave_tree_sum(w_post);
     double sq = wave_tree_sum(w_pilot * w_pilot);
@@ -786,7 +801,7 @@ __global__ __launch_bounds__(PF_BS) void k_extend_reg(KArgs A, long long s) {
     double scp = wave_hs_scan(w_post, lane);
     double scm = wave_max_scan_d(sc, lane);     // running max of the pilot scan (a parallel FP scan need not be monotone)
     long long chunk = p >> 6;
-    if (active) { A.scan1[p] = sc; A.scanp[p] = scp; A.scan1m[p] = scm; }
+    if (active) { A.scan1[p] = sc; A.scanp2[A.sp][p] = scp; A.scan1m[p] = scm; }
     if (lane == 63 && chunk < (A.Np + 63) / 64) {
         A.chunk_post[chunk] = sp;
         A.chunk_sq[chunk] = sq;
@@ -957,7 +972,7 @@ __global__ __launch_bounds__(PF_BS) void k_decide(KArgs A, long long s, int mode
             double runp = 0.0;
             for (int g = 0; g < ch / 64; ++g) runp = runp + l2_totp[g];
             double offp = (ch % 64 == 0) ? 0.0 : A.l2scanp[ch - 1];
-            A.chunk_offp[ch] = runp + offp;
+            A.chunk_offp2[A.sp][ch] = runp + offp;
         }
     }
     const double S1 = chunk_offset(nc - 1) + last_scan1;   // inclusive scan at the last particle (= oracle incl[N-1])
@@ -982,6 +997,7 @@ __global__ __launch_bounds__(PF_BS) void k_decide(KArgs A, long long s, int mode
             c->cur_pos = pos;
         }
         c->T = T; c->inv_T = inv; c->S1 = S1; c->S2 = S2; c->ess = ess; c->u = u; c->flag = flag;
+        c->step[A.sp].inv_T = inv; c->step[A.sp].G = G; c->step[A.sp].flag = flag;
     }
     if (!flag) return;
 
@@ -1157,8 +1173,10 @@ __device__ __forceinline__ void count_run(Acc& acc, const KArgs& A, const Win& W
     int q1 = i + 1 < nr ? rst[i + 1] : (int)Np;
     long long a = ran[i];
     // posterior mass of the descendants of (g, a): difference of the inclusive posterior scan
-    double hi = A.chunk_offp[(q1 - 1) >> 6] + A.scanp[q1 - 1];
-    double lo = q0 > 0 ? A.chunk_offp[(q0 - 1) >> 6] + A.scanp[q0 - 1] : 0.0;
+    const double* offp = A.chunk_offp2[A.sp];
+    const double* scp_ = A.scanp2[A.sp];
+    double hi = offp[(q1 - 1) >> 6] + scp_[q1 - 1];
+    double lo = q0 > 0 ? offp[(q0 - 1) >> 6] + scp_[q0 - 1] : 0.0;
     double w = (hi - lo) * inv;
     if (!(w > 0.0)) return;
     unsigned k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
@@ -1179,9 +1197,8 @@ __global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0, Windows Wn) {
     if (e < first || e >= A.E) return;
     const long long Np = A.Np;
     const int n = A.n;
-    const int G = c->flag ? c->gen - 1 : c->gen;          // the generation the weights belong to
-    const DState& st = A.st[c->flag ? (c->cur ^ 1) : c->cur];
-    const double inv = c->inv_T;
+    const int G = c->step[A.sp].G;                        // the generation the weights belong to
+    const double inv = c->step[A.sp].inv_T;
     Win W;
     W.e = e; W.rf = A.recflags[e];
     W.T0 = A.T[e]; W.T1 = e + 1 < A.E ? A.T[e + 1] : PF_INF;
@@ -1248,14 +1265,14 @@ __global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0, Windows Wn) {
             if (g == G) {
                 // live particle: its own weight, its open stretch, the records it wrote this generation
                 const long long a = i;
-                double w = st.w_post[a] * inv;
+                double w = A.snap_w[A.sp][a] * inv;
                 double S[NI];
 #pragma unroll
-                for (int r = 0; r < NI; ++r) S[r] = r < n - 1 ? st.S[(size_t)r * Np + a] : 0.0;
-                double xm = st.x_mark[a];
-                int ml = st.mark_limit[a];
+                for (int r = 0; r < NI; ++r) S[r] = r < n - 1 ? A.snap_S[A.sp][(size_t)r * Np + a] : 0.0;
+                double xm = A.snap_xm[A.sp][a];
+                int ml = A.snap_ml[A.sp][a];
                 unsigned k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
-                unsigned k1 = A.widx[a];
+                unsigned k1 = A.snap_widx[A.sp][a];
                 if (w == 0.0) continue;
                 stretch_contrib<NI>(acc, A, W, w, xm, PF_INF, S, ml);
                 if (k1 - k0 > A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;
@@ -1299,13 +1316,12 @@ __global__ void k_count_fin(KArgs A) {
 #define PF_LEDGER_PER (PF_LEDGER_TILE / PF_BS)
 #define PF_LEDGER_NEW 64      // the newest generations (long run lists) are re-based by a whole workgroup each
 
-__device__ void ledger_update(const KArgs& A, int lb, int nlb) {
+__device__ void ledger_update(const KArgs& A, int lb, int nlb, int G) {
     __shared__ int wcnt[PF_BS / 64];
     __shared__ int stage[2 * PF_LEDGER_TILE];
     __shared__ int stage_in[PF_BS * (PF_LEDGER_PER + 1)];
     const Ctrl* c = A.ctrl;
     const long long Np = A.Np;
-    const int G = c->gen - 1;                      // the generation that just ended
     const int* lo = A.lo + (size_t)(G % A.Gcap) * (Np + 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g_ret = c->g_retain;
@@ -1406,28 +1422,25 @@ __device__ void ledger_update(const KArgs& A, int lb, int nlb) {
     }
 }
 
-__global__ __launch_bounds__(PF_BS) void k_resample(KArgs A, long long s, int nblocks) {
-    Ctrl* c = A.ctrl;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { c->gen_prev = c->gen; c->nres_prev = c->n_resample; }
+// ------------------------------------------------------------------ k_ledger (counting stream)
+// After a resampling: workgroups [0, nblocks) write the run list of the generation that ended (its survivors,
+// in slot order: start = lo[a], ancestor = a); the others re-base the run-length encoded composite ancestor
+// maps of all retained generations onto the new slots (st' = lo[st], empty runs dropped).  Only k_count reads
+// these lists, so the whole maintenance lives on the counting stream, off the filter's critical path.
+__global__ __launch_bounds__(PF_BS) void k_ledger(KArgs A, int nblocks) {
+    const Ctrl* c = A.ctrl;
+    if (!c->step[A.sp].flag) return;
+    const int Gx = c->step[A.sp].G;
     if ((int)blockIdx.x >= nblocks) {
-        if (c->flag) ledger_update(A, (int)blockIdx.x - nblocks, (int)gridDim.x - nblocks);
+        ledger_update(A, (int)blockIdx.x - nblocks, (int)gridDim.x - nblocks, Gx);
         return;
     }
     const long long Np = A.Np;
     const long long i = (long long)blockIdx.x * PF_BS + threadIdx.x;
-    const double inv = c->inv_T;
-    if (!c->flag) {
-        if (i >= Np) return;
-        DState& st = A.st[c->cur];
-        st.w_post[i] *= inv;
-        st.w_pilot[i] *= inv;
-        return;
-    }
     {
         // run list of the generation that ends here: its survivors, in slot order (start = lo[a], ancestor = a).
         // Position = survivors in earlier workgroups (k_decide's blkcnt) + rank inside this workgroup.
         __shared__ int wsum[PF_BS / 64];
-        const int Gx = c->gen - 1;
         const int* lox = A.lo + (size_t)(Gx % A.Gcap) * (Np + 1);
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         int l0 = 0, l1 = 0;
@@ -1450,6 +1463,21 @@ __global__ __launch_bounds__(PF_BS) void k_resample(KArgs A, long long s, int nb
             int tot = base + __popcll(bal);           // base already holds the earlier wavefronts of this workgroup
             A.nruns[Gx % A.Gcap] = tot;
         }
+    }
+}
+
+__global__ __launch_bounds__(PF_BS) void k_resample(KArgs A, long long s, int nblocks) {
+    Ctrl* c = A.ctrl;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { c->gen_prev = c->gen; c->nres_prev = c->n_resample; }
+    const long long Np = A.Np;
+    const long long i = (long long)blockIdx.x * PF_BS + threadIdx.x;
+    const double inv = c->inv_T;
+    if (!c->flag) {
+        if (i >= Np) return;
+        DState& st = A.st[c->cur];
+        st.w_post[i] *= inv;
+        st.w_pilot[i] *= inv;
+        return;
     }
     if (i >= Np) return;
     const int n = A.n;
@@ -1527,13 +1555,18 @@ __global__ __launch_bounds__(PF_BS) void k_partials(KArgs A) {
     const DState& st = A.st[c->cur];
     double w_post = active ? st.w_post[p] : 0.0;
     double w_pilot = active ? st.w_pilot[p] : 0.0;
+    if (active) {
+        for (int r = 0; r < A.n - 1; ++r) A.snap_S[A.sp][(size_t)r * A.Np + p] = st.S[(size_t)r * A.Np + p];
+        A.snap_w[A.sp][p] = w_post; A.snap_xm[A.sp][p] = st.x_mark[p]; A.snap_ml[A.sp][p] = st.mark_limit[p];
+        A.snap_widx[A.sp][p] = A.widx[p];
+    }
     double sp = wave_tree_sum(w_post);
     double sq = wave_tree_sum(w_pilot * w_pilot);
     double sc = wave_hs_scan(w_pilot, lane);
     double scp = wave_hs_scan(w_post, lane);
     double scm = wave_max_scan_d(sc, lane);     // running max of the pilot scan (a parallel FP scan need not be monotone)
     long long chunk = p >> 6;
-    if (active) { A.scan1[p] = sc; A.scanp[p] = scp; A.scan1m[p] = scm; }
+    if (active) { A.scan1[p] = sc; A.scanp2[A.sp][p] = scp; A.scan1m[p] = scm; }
     if (lane == 63 && chunk < (A.Np + 63) / 64) {
         A.chunk_post[chunk] = sp;
         A.chunk_sq[chunk] = sq;
@@ -1637,7 +1670,11 @@ const char* pf_last_error(void) { return g_err.c_str(); }
 
 struct pf_handle {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // filter stream: k_extend, k_decide, k_resample
+    hipStream_t cstream = nullptr;     // counting stream: k_count, k_ledger (off the critical path)
+    std::vector<hipEvent_t> sync_ev;   // ring of events ordering the two streams
+    size_t sync_next = 0;
+    hipEvent_t ev_dec = nullptr, ev_cnt = nullptr;   // last decide / last count+ledger
     KArgs A;
     std::vector<void*> allocs;
     std::vector<double> h_lags, h_counted_to;
@@ -1704,6 +1741,9 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     h->device = device;
     if (hipSetDevice(device) != hipSuccess) { delete h; return fail("hipSetDevice failed"); }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail("hipStreamCreate failed"); }
+    if (hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail("hipStreamCreate failed"); }
+    h->sync_ev.resize(512);
+    for (auto& e : h->sync_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) { delete h; return fail("hipEventCreate failed"); }
     const int E = m->n_epochs, n = m->nsam;
     const long long Np = p->np;
     h->E = E; h->n = n; h->Np = Np;
@@ -1784,7 +1824,12 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     rc |= dalloc(h, &A.scan1, Np); rc |= dalloc(h, &A.chunk_off, nc); rc |= dalloc(h, &A.l2scan, nc);
     rc |= dalloc(h, &A.scan1m, Np); rc |= dalloc(h, &A.chunk_mx1, nc);
     rc |= dalloc(h, &A.chunk_dpend, nc);
-    rc |= dalloc(h, &A.scanp, Np); rc |= dalloc(h, &A.chunk_pp, nc); rc |= dalloc(h, &A.chunk_offp, nc); rc |= dalloc(h, &A.l2scanp, nc);
+    rc |= dalloc(h, &A.chunk_pp, nc); rc |= dalloc(h, &A.l2scanp, nc);
+    for (int b = 0; b < 2; ++b) {
+        rc |= dalloc(h, &A.scanp2[b], Np); rc |= dalloc(h, &A.chunk_offp2[b], nc);
+        rc |= dalloc(h, &A.snap_w[b], Np); rc |= dalloc(h, &A.snap_S[b], (size_t)(n - 1) * Np);
+        rc |= dalloc(h, &A.snap_xm[b], Np); rc |= dalloc(h, &A.snap_ml[b], Np); rc |= dalloc(h, &A.snap_widx[b], Np);
+    }
     A.nbx = h->nblocks;
     rc |= dalloc(h, &A.totals, (size_t)6 * E);
     rc |= dalloc(h, &A.partial, (size_t)E * A.nbx * 6);
@@ -1808,7 +1853,10 @@ void pf_destroy(pf_handle* h) {
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->cstream) hipStreamSynchronize(h->cstream);
     for (void* p : h->allocs) hipFree(p);
+    for (auto e : h->sync_ev) if (e) hipEventDestroy(e);
+    if (h->cstream) hipStreamDestroy(h->cstream);
     for (auto& sp : h->spans) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
     for (auto e : h->ev_pool) hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -1842,18 +1890,25 @@ static hipEvent_t get_event(pf_handle* h) {
 }
 
 struct Timed {
-    pf_handle* h; int k; bool on; hipEvent_t a, b;
-    Timed(pf_handle* h_, int k_, bool on_) : h(h_), k(k_), on(on_) {
+    pf_handle* h; int k; bool on; hipEvent_t a, b; hipStream_t st;
+    Timed(pf_handle* h_, int k_, bool on_, hipStream_t st_ = nullptr) : h(h_), k(k_), on(on_), st(st_ ? st_ : h_->stream) {
         h->k_launches[k] += 1;
-        if (on) { a = get_event(h); b = get_event(h); hipEventRecord(a, h->stream); }
+        if (on) { a = get_event(h); b = get_event(h); hipEventRecord(a, st); }
     }
     ~Timed() {
-        if (on) { hipEventRecord(b, h->stream); h->spans.push_back({a, b, k}); }
+        if (on) { hipEventRecord(b, st); h->spans.push_back({a, b, k}); }
     }
 };
 
+static hipEvent_t next_sync_event(pf_handle* h) {
+    hipEvent_t e = h->sync_ev[h->sync_next];
+    h->sync_next = (h->sync_next + 1) % h->sync_ev.size();
+    return e;
+}
+
 int pf_sync(pf_handle* h) {
     HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->cstream));
     if (h->fin_pending) {
         hipLaunchKernelGGL(k_count_fin, dim3(1), dim3(256), 0, h->stream, h->A);
         h->fin_pending = false;
@@ -1879,6 +1934,7 @@ int pf_init_prior(pf_handle* h, double initial_position) {
     if (check_launch("k_init")) return -1;
     std::fill(h->h_counted_to.begin(), h->h_counted_to.end(), 0.0);
     h->fin_pending = false;
+    h->ev_dec = nullptr; h->ev_cnt = nullptr;
     h->seg_done = 0;
     h->finished = false;
     return 0;
@@ -1961,11 +2017,16 @@ static int launch_extend(pf_handle* h, long long s) {
 
 static int launch_decide(pf_handle* h, long long s, int mode, const Windows& W) {
     const bool t = timing_on(h, s);
+    // k_decide folds the previous step's k_count partials and rewrites what k_count / k_ledger read
+    // (window generations, offspring tables): it must not start before the counting stream is done with them
+    if (h->ev_cnt) hipStreamWaitEvent(h->stream, h->ev_cnt, 0);
     {
         Timed tm(h, 1, t);
         hipLaunchKernelGGL(k_decide, dim3(h->nblocks + 1), dim3(PF_BS), 0, h->stream, h->A, s, mode, W, h->nblocks);
-        h->fin_pending = false;      // workgroup 1 folds the previous step's partials
+        h->fin_pending = false;      // the bookkeeping workgroup folds the previous step's partials
     }
+    h->ev_dec = next_sync_event(h);
+    hipEventRecord(h->ev_dec, h->stream);
     return check_launch("k_decide");
 }
 
@@ -1973,24 +2034,35 @@ static int launch_count(pf_handle* h, long long s, const Windows& W) {
     const int first = W.first;
     if (first >= h->E) return 0;
     const bool t = timing_on(h, s);
+    if (h->ev_dec) hipStreamWaitEvent(h->cstream, h->ev_dec, 0);
     {
-        Timed tm(h, 2, t);
+        Timed tm(h, 2, t, h->cstream);
         if (h->n <= 4)
-            hipLaunchKernelGGL(k_count<4>, dim3(h->nblocks, h->E - first), dim3(PF_BS), 0, h->stream, h->A, first, W);
+            hipLaunchKernelGGL(k_count<4>, dim3(h->nblocks, h->E - first), dim3(PF_BS), 0, h->cstream, h->A, first, W);
         else if (h->n <= 8)
-            hipLaunchKernelGGL(k_count<8>, dim3(h->nblocks, h->E - first), dim3(PF_BS), 0, h->stream, h->A, first, W);
+            hipLaunchKernelGGL(k_count<8>, dim3(h->nblocks, h->E - first), dim3(PF_BS), 0, h->cstream, h->A, first, W);
         else
-            hipLaunchKernelGGL(k_count<PF_NMAX>, dim3(h->nblocks, h->E - first), dim3(PF_BS), 0, h->stream, h->A, first, W);
+            hipLaunchKernelGGL(k_count<PF_NMAX>, dim3(h->nblocks, h->E - first), dim3(PF_BS), 0, h->cstream, h->A, first, W);
         h->fin_pending = true;
     }
     return check_launch("k_count");
+}
+
+// ancestor-ledger maintenance of this step (no-op unless the step resampled); closes the step on the counting stream
+static int launch_ledger(pf_handle* h, long long s) {
+    (void)s;
+    if (h->ev_dec) hipStreamWaitEvent(h->cstream, h->ev_dec, 0);
+    hipLaunchKernelGGL(k_ledger, dim3(h->nblocks + PF_LEDGER_BLOCKS), dim3(PF_BS), 0, h->cstream, h->A, h->nblocks);
+    h->ev_cnt = next_sync_event(h);
+    hipEventRecord(h->ev_cnt, h->cstream);
+    return check_launch("k_ledger");
 }
 
 static int launch_resample(pf_handle* h, long long s) {
     const bool t = timing_on(h, s);
     {
         Timed tm(h, 3, t);
-        hipLaunchKernelGGL(k_resample, dim3(h->nblocks + PF_LEDGER_BLOCKS), dim3(PF_BS), 0, h->stream, h->A, s, h->nblocks);
+        hipLaunchKernelGGL(k_resample, dim3(h->nblocks), dim3(PF_BS), 0, h->stream, h->A, s, h->nblocks);
     }
     return check_launch("k_resample");
 }
@@ -2005,6 +2077,7 @@ int pf_update_segment(pf_handle* h, int64_t s) {
     HIPCHK(hipSetDevice(h->device));
     if (s < 0 || s >= h->n_segs) { g_err = "segment index out of range"; return -1; }
     h->step_windows = host_windows(h, seg_pos(h, s), false);
+    h->A.sp = (int)(s & 1);
     if (launch_extend(h, s)) return -1;
     return launch_decide(h, s, 0, h->step_windows);
 }
@@ -2016,6 +2089,7 @@ int pf_count(pf_handle* h, int64_t s, int end_data) {
 int pf_resample(pf_handle* h, int64_t s) {
     HIPCHK(hipSetDevice(h->device));
     int rc = launch_resample(h, s);
+    if (!rc) rc = launch_ledger(h, s);
     h->seg_done = std::max<long long>(h->seg_done, s + 1);
     return rc;
 }
@@ -2025,10 +2099,12 @@ int pf_run(pf_handle* h, int64_t s_begin, int64_t s_end) {
     if (s_begin < 0 || s_end > h->n_segs) { g_err = "segment range out of bounds"; return -1; }
     for (long long s = s_begin; s < s_end; ++s) {
         h->step_windows = host_windows(h, seg_pos(h, s), false);
+        h->A.sp = (int)(s & 1);
         if (launch_extend(h, s)) return -1;
         if (launch_decide(h, s, 0, h->step_windows)) return -1;
-        if (launch_count(h, s, h->step_windows)) return -1;
         if (launch_resample(h, s)) return -1;
+        if (launch_count(h, s, h->step_windows)) return -1;
+        if (launch_ledger(h, s)) return -1;
         h->seg_done = s + 1;
         if (h->h_seg_start[s] + h->h_seg_len[s] >= h->h_L) break;   // smcsmc.cpp:353-356
         if ((s & 1023) == 1023 && !h->spans.empty()) {
@@ -2049,11 +2125,14 @@ int pf_run(pf_handle* h, int64_t s_begin, int64_t s_end) {
 int pf_finish(pf_handle* h) {
     HIPCHK(hipSetDevice(h->device));
     // smcsmc.cpp:371: normalize_probability once more, then the lag-free flush (373)
+    h->A.sp = (int)(h->seg_done & 1);
+    if (h->ev_cnt) hipStreamWaitEvent(h->stream, h->ev_cnt, 0);     // k_partials rewrites the parity buffers
     hipLaunchKernelGGL(k_partials, dim3(h->nblocks), dim3(PF_BS), 0, h->stream, h->A);
     h->step_windows = host_windows(h, h->h_L, true);
     if (launch_decide(h, 0, 1, h->step_windows)) return -1;
-    if (launch_count(h, 0, h->step_windows)) return -1;
     if (launch_resample(h, 0)) return -1;    // flag == 0 in mode 1: in-place normalisation
+    if (launch_count(h, 0, h->step_windows)) return -1;
+    if (launch_ledger(h, 0)) return -1;
     h->finished = true;
     return pf_sync(h);
 }
