@@ -35,7 +35,7 @@ extern "C" {
 
 typedef struct pf_model {
     int32_t n_epochs;            /* E  (Model::change_times_.size()) */
-    int32_t n_pops;              /* P  (this round: 1) */
+    int32_t n_pops;              /* P  (1..4; scrm -I) */
     int32_t nsam;                /* haplotypes n, 2..16 */
     int32_t flags;               /* bit0 -ancestral_aware, bit1 -dephase (pfparam.cpp:143-146) */
     double loci_length;          /* Model::loci_length() */
@@ -43,8 +43,8 @@ typedef struct pf_model {
     double recombination_rate;   /* per bp per generation */
     const double* change_times;  /* [E] generations */
     const double* pop_sizes;     /* [E*P] */
-    const double* mig_rates;     /* [E*P*P] or NULL */
-    const double* single_mig;    /* [E*P*P] or NULL */
+    const double* mig_rates;     /* [E*P*P] backward migration rate p -> q per generation (scrm -eM/-ema), or NULL */
+    const double* single_mig;    /* [E*P*P] fixed-time moves at the start of the epoch (scrm -ej: 0 or 1), or NULL */
     const int32_t* sample_pops;  /* [nsam] or NULL */
     const int32_t* record_flags; /* [E] PfParam::record_event_in_epoch (pfparam.hpp:279-281) */
     const double* lags;          /* [E] CountModel::lags (count.cpp:230-265) */
@@ -81,6 +81,10 @@ typedef struct pf_handle pf_handle;
  *   delayed_weight_opportunity, delayed_weight_count, resample_count, ln_normalization_factor
  * raw sums without the prior pseudo-counts (count.cpp:161-227). */
 #define PF_COUNTS_LEN(E) (6 * (E) + 4)
+/* structured models (P > 1), CountModel members of count.hpp:95-110:
+ *   coal_count[E][P] coal_opp[E][P] coal_weight[E][P]  rec_count[E] rec_opp[E] rec_weight[E]
+ *   mig_count[E][P][P] mig_opp[E][P] mig_weight[E][P]  and the same four scalars */
+#define PF_COUNTS_LEN2(E, P) ((P) == 1 ? PF_COUNTS_LEN(E) : (3 * (E) * (P) + 3 * (E) + (E) * (P) * (P) + 2 * (E) * (P) + 4))
 
 const char* pf_last_error(void);
 int pf_device_count(void);
@@ -106,6 +110,11 @@ double pf_logl(pf_handle* h);
 int pf_get_counts(pf_handle* h, double* packed, int32_t n);
 int pf_get_trace(pf_handle* h, double* T, double* ess, int32_t* resampled, double* logl, int64_t n);
 int pf_get_resample_events(pf_handle* h, int32_t* seg_idx, int32_t* parents, int32_t max_events);
+/* structured models: the migration events on every particle's local tree ([np*cap], sorted by time; event k sits
+ * on the branch above node id branch[k] and moves the lineage to newpop[k]) and the population of every
+ * coalescent node ([np*(nsam-1)]); scrm keeps these as migrating unary nodes (Node::is_migrating) */
+int pf_get_migrations(pf_handle* h, int32_t* n_events, double* times, int8_t* branch, int8_t* newpop, int8_t* node_pops,
+                      int32_t cap);
 int pf_get_particles(pf_handle* h, double* w_post, double* w_pilot, double* heights, int8_t* children,
                      double* next_base);
 /* device-side timing of the kernels launched so far (HIP events on the handle's stream):

@@ -45,6 +45,7 @@ namespace smco {
 static thread_local std::string g_err;
 
 enum { NMAX = 16 };
+enum { MMAX = 24 };   /* migration events kept per local tree (multi-population models) */
 enum { DCAP = 32 };   /* capacity of the per-particle delayed-factor store (the reference's heap is unbounded) */
 enum { REC_RECOMB = 1, REC_COALMIGR = 2 };
 
@@ -138,6 +139,13 @@ struct Model {
     std::vector<double> inv2N;   /* 1/(2 N_e) */
     std::vector<int> recflags;
     std::vector<double> lags;
+    /* structured models (P > 1): per-epoch, per-population tables (scrm Model::population_size,
+     * migration_rate, single_mig_pop) */
+    std::vector<double> inv2Np;      /* [E*P]   1/(2 N_e,p) */
+    std::vector<double> Mrate;       /* [E*P*P] backward migration rate p -> q per generation */
+    std::vector<double> Mtot;        /* [E*P]   sum_q Mrate[e][p][q], summed q ascending */
+    std::vector<int> jmap;           /* [E*P]   population after the fixed-time moves at the start of epoch e (-ej) */
+    std::vector<int> sample_pop;     /* [n] */
     /* focused sampling (Model::bias_heights / bias_strengths of the scrm fork; particle.cpp:1020-1050) */
     bool biased = false;
     std::vector<double> bias_H;      /* 0, h1..hk, +inf */
@@ -164,8 +172,10 @@ struct Ev {
     int32_t refs;       /* ref_counter_ */
     int16_t weight;     /* number of contemporaries */
     int8_t kind;        /* 0 recombination opportunity, 1 coalescence opportunity */
-    int8_t event;       /* 1 if an event sits on this record (recomb: at (x0, ev_t); coal: at t1) */
+    int8_t event;       /* 1 if an event sits on this record (recomb: at (x0, ev_t); coal: at t1); 2 migration at t1 */
     int8_t dead;
+    int8_t pop;         /* coal/migr records: population of the active lineage */
+    int8_t mig_to;      /* event == 2: destination population of the migration event */
     double ev_t;        /* recombination event height (coalevent.hpp:170-176) */
 };
 
@@ -196,6 +206,15 @@ struct Tree {
      * child id < n : leaf (sample index), id >= n : internal node of rank id-n. */
     double S[NMAX - 1];
     int8_t C[NMAX - 1][2];
+    /* structured models: population in which each coalescence happened, and the migration events on the
+     * branches of the local tree, sorted by time.  Event m sits on the branch above node id Mb[m] (the
+     * child end of the branch) and moves the lineage to population Mq[m] at time Mt[m].  scrm keeps
+     * these as unary "migrating" nodes (Node::is_migrating); a list keeps the rank-sorted binary tree
+     * -- and with it likelihood / branch-length code -- untouched. */
+    int8_t Pn[NMAX - 1];
+    int nm = 0;
+    double Mt[MMAX];
+    int8_t Mb[MMAX], Mq[MMAX];
 };
 
 struct Particle {
@@ -229,7 +248,10 @@ struct Filter {
     int64_t n_resample = 0;
     int64_t n_recomb = 0;
     /* count model (count.hpp) */
-    std::vector<double> coal_count, coal_opp, coal_w2, rec_count, rec_opp, rec_w2, counted_to;
+    std::vector<double> coal_count, coal_opp, coal_w2;   /* [E*P] */
+    std::vector<double> rec_count, rec_opp, rec_w2, counted_to;
+    std::vector<double> mig_count;                       /* [E*P*P] */
+    std::vector<double> mig_opp, mig_w2;                 /* [E*P] */
     double delayed_opp = 0, delayed_count = 0;
     /* trace */
     std::vector<double> tr_T, tr_ess, tr_logl;
@@ -335,7 +357,7 @@ struct Filter {
         Ev* e = pool.get();
         e->t0 = t0; e->t1 = t1; e->x0 = x0; e->x1 = x1;
         e->acc = 0; e->arrived = 0; e->refs = 1;
-        e->weight = (int16_t)weight; e->kind = (int8_t)kind; e->event = 0; e->dead = 0; e->ev_t = -1;
+        e->weight = (int16_t)weight; e->kind = (int8_t)kind; e->event = 0; e->dead = 0; e->ev_t = -1; e->pop = 0; e->mig_to = 0;
         e->parent = p.head[epoch];      /* add_leaf_to_tree: coalevent.hpp:288-303 (takes over the head's reference) */
         p.head[epoch] = e;
         return e;
@@ -346,6 +368,304 @@ struct Filter {
             pool.put(e);
             e = par;
         }
+    }
+
+    /* ================= structured models (P > 1) =================
+     * Reconstructed from the control flow of particle.cpp:1266-1521 (sampleNextGenealogyWithoutImplementing and
+     * its dontImplement* helpers, which mirror the scrm fork's implementing versions) with the rates of
+     * an active lineage in population p coalesces at rate #contemporaries(p)/(2 N_p), migrates to q
+     * at rate M[p][q]; two active lineages in the same population coalesce pairwise at rate 1/(2 N_p);
+     * fixed-time moves (-ej) are applied when an active lineage crosses the epoch boundary
+     * (dontImplementFixedTimeEvent, particle.cpp:1387-1418; deterministic moves only). */
+
+    int pop_base(const Tree& t, int id) const { return id < M.n ? M.sample_pop[id] : t.Pn[id - M.n]; }
+    /* population of the lineage above node `id` at time `time` */
+    int pop_at(const Tree& t, int id, double time) const {
+        int pop = pop_base(t, id);
+        for (int m = 0; m < t.nm; ++m)
+            if (t.Mb[m] == id && t.Mt[m] <= time) pop = t.Mq[m];
+        return pop;
+    }
+    /* lineages_at restricted to the lineages that are in population `pop` at `time` */
+    int lineages_in_pop(const Tree& t, int ni, double time, int pop, int want, int* pr, int* ps) const {
+        int R = 0;
+        while (R < ni && t.S[R] <= time) ++R;
+        int cnt = 0;
+        for (int r = R; r < ni; ++r)
+            for (int s = 0; s < 2; ++s) {
+                int id = t.C[r][s];
+                if ((id < M.n || id - M.n < R) && pop_at(t, id, time) == pop) {
+                    if (cnt == want) { *pr = r; *ps = s; }
+                    ++cnt;
+                }
+            }
+        return cnt;
+    }
+    void ev_insert(Tree& t, double time, int branch, int newpop) const {
+        if (t.nm >= MMAX) throw std::runtime_error("too many migration events on one local tree");
+        int m = t.nm;
+        while (m > 0 && t.Mt[m - 1] > time) {
+            t.Mt[m] = t.Mt[m - 1]; t.Mb[m] = t.Mb[m - 1]; t.Mq[m] = t.Mq[m - 1];
+            --m;
+        }
+        t.Mt[m] = time; t.Mb[m] = (int8_t)branch; t.Mq[m] = (int8_t)newpop;
+        ++t.nm;
+    }
+    /* drop the events on branch `id` later than `tmin` */
+    void ev_drop_above(Tree& t, int id, double tmin) const {
+        int o = 0;
+        for (int m = 0; m < t.nm; ++m) {
+            if (t.Mb[m] == id && t.Mt[m] > tmin) continue;
+            t.Mt[o] = t.Mt[m]; t.Mb[o] = t.Mb[m]; t.Mq[o] = t.Mq[m];
+            ++o;
+        }
+        t.nm = o;
+    }
+    /* remove_rank that also maintains node populations and the migration list: the events on the
+     * removed node's own branch pass to the sibling lineage that takes its place */
+    void mp_remove_rank(Tree& t, int ni, int rp, int sib, int* a, int* b) const {
+        const int pid = M.n + rp;
+        for (int m = 0; m < t.nm; ++m) {
+            if (t.Mb[m] == pid) t.Mb[m] = (int8_t)sib;
+            if (t.Mb[m] > pid) t.Mb[m] -= 1;
+        }
+        for (int r = rp; r + 1 < ni; ++r) t.Pn[r] = t.Pn[r + 1];
+        remove_rank(t, ni, rp, sib, a, b);
+    }
+    /* insert_node that also maintains node populations and the migration list: the part of the target
+     * branch above the new node becomes the new node's branch (or vanishes above a new root) */
+    void mp_insert_node(Tree& t, int ni, double h, int* fl, int pr, int ps, int root_id, int node_pop) const {
+        const int n = M.n;
+        int rn = 0;
+        while (rn < ni && t.S[rn] <= h) ++rn;
+        const int nid = n + rn;
+        int target = pr >= 0 ? t.C[pr][ps] : root_id;
+        for (int m = 0; m < t.nm; ++m)
+            if (t.Mb[m] >= nid) t.Mb[m] += 1;
+        if (target >= nid) target += 1;
+        if (pr >= 0) {
+            for (int m = 0; m < t.nm; ++m)
+                if (t.Mb[m] == target && t.Mt[m] > h) t.Mb[m] = (int8_t)nid;
+        } else {
+            ev_drop_above(t, target, h);
+        }
+        for (int r = ni; r > rn; --r) t.Pn[r] = t.Pn[r - 1];
+        t.Pn[rn] = (int8_t)node_pop;
+        insert_node(t, ni, h, *fl, pr, ps, root_id);
+        if (*fl >= nid) *fl += 1;
+    }
+
+    struct Walk {
+        double tc;
+        int pf, pr;                       /* populations of the floating / root lineage at tc */
+        int npath, nrpath;
+        double pt[MMAX], rt[MMAX];        /* migration events picked up on the way: floating / root lineage */
+        int8_t pq[MMAX], rq[MMAX];
+        int weight;                       /* coalescence partners at tc (consistency check) */
+    };
+
+    /* The floating lineage starts at height h in population pf0 and moves up through the tree `t`
+     * (ni internal nodes; root_id its top node, or the single leaf).  Above the root the root's own
+     * lineage is the second active lineage.  One unit exponential is consumed across the intervals
+     * (sampleExpoLimit), the kind of event is drawn with one uniform. */
+    void mp_coalesce(int64_t slot, Particle* rec_p, const Tree& t, int ni, int root_id, double h, int pf0,
+                     double x, int limit, Walk& W) {
+        SlotRng& g = rng[slot];
+        const int P = M.P;
+        const double Hr = node_h(t, root_id);
+        double tt = h;
+        int e = M.epoch_of(tt);
+        int i = 0, j = 0;
+        while (i < ni && t.S[i] <= tt) ++i;
+        while (j < t.nm && t.Mt[j] <= tt) ++j;
+        int pf = pf0, pr = pop_base(t, root_id);
+        W.npath = W.nrpath = 0;
+        for (;;) {
+            const bool root_active = tt >= Hr;
+            double tn_node = i < ni ? t.S[i] : HUGE_VAL;
+            double tn_mig = j < t.nm ? t.Mt[j] : HUGE_VAL;
+            double tn_ep = M.epoch_end(e);
+            double tn = std::min(std::min(tn_node, tn_mig), tn_ep);
+            int dummy_r = 0, dummy_s = 0;
+            int k = lineages_in_pop(t, ni, tt, pf, -1, &dummy_r, &dummy_s);
+            int weight = k + ((root_active && pr == pf) ? 1 : 0);      /* particle.cpp:255-260, 277 */
+            double rc = (double)weight * M.inv2Np[e * P + pf];
+            double rmf = M.Mtot[e * P + pf];
+            double rmr = root_active ? M.Mtot[e * P + pr] : 0.0;
+            double lam = (rc + rmf) + rmr;
+            if (lam == 0.0 && !(tn < HUGE_VAL)) throw std::logic_error("No final coalescence event was sampled!");
+            double need = (tn - tt) * lam;
+            bool fire = !(g.ebuf > need);
+            double t1 = fire ? tt + g.ebuf / lam : tn;
+            int kind = 0, to = 0;          /* 1 coalescence, 2 floating lineage migrates, 3 root lineage migrates */
+            if (fire) {
+                double v = uni(slot) * lam;
+                if (v < rc || (rmf == 0.0 && rmr == 0.0)) kind = 1;
+                else {
+                    v -= rc;
+                    int from;
+                    if (v < rmf || rmr == 0.0) { kind = 2; from = pf; }
+                    else { kind = 3; from = pr; v -= rmf; }
+                    to = -1;
+                    for (int q = 0; q < P; ++q) {
+                        double m = M.Mrate[(e * P + from) * P + q];
+                        if (q == from || m == 0.0) continue;
+                        to = q;
+                        if (v < m) break;
+                        v -= m;
+                    }
+                }
+            }
+            if (rec_p && record_events && (M.recflags[e] & REC_COALMIGR) && e <= limit) {
+                Ev* ev = new_event(*rec_p, e, 1, tt, t1, x, x, weight);
+                ev->pop = (int8_t)pf;
+                if (kind == 1) ev->event = 1;
+                if (kind == 2) { ev->event = 2; ev->mig_to = (int8_t)to; }
+                if (root_active) {
+                    /* second active node: no contemporaries above the root, migration opportunity only */
+                    Ev* ev2 = new_event(*rec_p, e, 1, tt, t1, x, x, 0);
+                    ev2->pop = (int8_t)pr;
+                    if (kind == 3) { ev2->event = 2; ev2->mig_to = (int8_t)to; }
+                }
+            }
+            if (fire) {
+                g.ebuf = -smc_log(uni(slot));
+                if (kind == 1) {
+                    W.tc = t1; W.pf = pf; W.pr = pr; W.weight = weight;
+                    return;
+                }
+                if (kind == 2) {
+                    if (W.npath >= MMAX) throw std::runtime_error("too many migration events on one local tree");
+                    W.pt[W.npath] = t1; W.pq[W.npath] = (int8_t)to; ++W.npath;
+                    pf = to;
+                } else {
+                    if (W.nrpath >= MMAX) throw std::runtime_error("too many migration events on one local tree");
+                    W.rt[W.nrpath] = t1; W.rq[W.nrpath] = (int8_t)to; ++W.nrpath;
+                    pr = to;
+                }
+                tt = t1;
+                continue;
+            }
+            g.ebuf -= need;
+            tt = tn;
+            while (i < ni && t.S[i] <= tt) ++i;
+            while (j < t.nm && t.Mt[j] <= tt) ++j;
+            if (tn_ep <= tn) {
+                ++e;
+                /* fixed-time moves at the start of epoch e */
+                int q = M.jmap[e * P + pf];
+                if (q != pf) {
+                    if (W.npath >= MMAX) throw std::runtime_error("too many migration events on one local tree");
+                    W.pt[W.npath] = tt; W.pq[W.npath] = (int8_t)q; ++W.npath;
+                    pf = q;
+                }
+                if (tt >= Hr) {
+                    int qr = M.jmap[e * P + pr];
+                    if (qr != pr) {
+                        if (W.nrpath >= MMAX) throw std::runtime_error("too many migration events on one local tree");
+                        W.rt[W.nrpath] = tt; W.rq[W.nrpath] = (int8_t)qr; ++W.nrpath;
+                        pr = qr;
+                    }
+                }
+            }
+        }
+    }
+
+    void mp_build_initial_tree(int64_t slot, Particle& p) {
+        const int n = M.n;
+        Tree& t = p.tr;
+        t.nm = 0;
+        int root = 0;
+        for (int i = 1; i < n; ++i) {
+            int ni = i - 1;
+            Walk W;
+            mp_coalesce(slot, &p, t, ni, root, 0.0, M.sample_pop[i], 0.0, M.E - 1, W);
+            double tc = W.tc;
+            for (int m = 0; m < W.nrpath; ++m) ev_insert(t, W.rt[m], root, W.rq[m]);
+            int pr = -1, ps = 0;
+            int nslots = lineages_in_pop(t, ni, tc, W.pf, -1, &pr, &ps);
+            bool has_root = tc >= node_h(t, root) && pop_at(t, root, tc) == W.pf;
+            int k = nslots + (has_root ? 1 : 0);
+            if (k != W.weight) throw std::logic_error("initial tree: coalescence partners inconsistent");
+            double u = uni(slot);
+            int idx = std::min((int)(u * (double)k), k - 1);
+            int fl = i;
+            if (idx < nslots) {
+                lineages_in_pop(t, ni, tc, W.pf, idx, &pr, &ps);
+                mp_insert_node(t, ni, tc, &fl, pr, ps, root, W.pf);
+            } else {
+                mp_insert_node(t, ni, tc, &fl, -1, 0, root, W.pf);
+            }
+            for (int m = 0; m < W.npath; ++m) ev_insert(t, W.pt[m], fl, W.pq[m]);
+            root = n + ni;
+        }
+        p.Ltree = tree_length(t, n);
+    }
+
+    /* the part of genealogy_update after the recombination point (slot (rp,sb), height h) is known */
+    void mp_genealogy_rest(int64_t slot, Particle& p, double x, int limit, int rp, int sb, double h) {
+        const int n = M.n;
+        Tree& t = p.tr;
+        int b_id = t.C[rp][sb], s_id = t.C[rp][1 - sb];
+        const int pf0 = pop_at(t, b_id, h);
+        Walk W;
+        mp_coalesce(slot, &p, t, n - 1, n + n - 2, h, pf0, x, limit, W);
+        const double tc = W.tc;
+        last_tc = tc;
+        const double Sp = t.S[rp];
+        const int p_pop = t.Pn[rp];
+        const bool p_was_root = (rp == n - 2);
+        /* the stub: what remains of the cut branch above the cut, with its migration events */
+        int nstub = 0; double st_t[MMAX]; int8_t st_q[MMAX];
+        for (int m = 0; m < t.nm; ++m)
+            if (t.Mb[m] == b_id && t.Mt[m] > h) { st_t[nstub] = t.Mt[m]; st_q[nstub] = t.Mq[m]; ++nstub; }
+        ev_drop_above(t, b_id, h);
+        mp_remove_rank(t, n - 1, rp, s_id, &b_id, &s_id);
+        int ni = n - 2;
+        int troot = p_was_root ? s_id : n + (ni - 1);
+        for (int m = 0; m < W.nrpath; ++m) ev_insert(t, W.rt[m], troot, W.rq[m]);
+        int pr = -1, ps = 0;
+        int nslots = lineages_in_pop(t, ni, tc, W.pf, -1, &pr, &ps);
+        bool has_root = tc >= node_h(t, troot) && pop_at(t, troot, tc) == W.pf;
+        int stub_pop = pf0;
+        for (int m = 0; m < nstub; ++m) if (st_t[m] <= tc) stub_pop = st_q[m];
+        bool has_stub = tc < Sp && stub_pop == W.pf;
+        int k = nslots + (has_root ? 1 : 0) + (has_stub ? 1 : 0);
+        if (k != W.weight) throw std::logic_error("genealogy update: coalescence partners inconsistent");
+        double u = uni(slot);
+        int idx = std::min((int)(u * (double)k), k - 1);
+        last_sp = Sp;
+        last_changed = !(has_stub && idx == k - 1);
+        if (idx < nslots) {
+            lineages_in_pop(t, ni, tc, W.pf, idx, &pr, &ps);
+            mp_insert_node(t, ni, tc, &b_id, pr, ps, troot, W.pf);
+        } else if (has_root && idx == nslots) {
+            mp_insert_node(t, ni, tc, &b_id, -1, 0, troot, W.pf);
+        } else {
+            /* back into its own stub: the tree keeps its shape, the cut branch swaps the events between the
+             * cut and tc for the ones picked up on the way */
+            if (p_was_root) {
+                mp_insert_node(t, ni, Sp, &b_id, -1, 0, troot, p_pop);
+            } else {
+                int want = -1, c = 0, R = 0;
+                while (R < ni && t.S[R] <= Sp) ++R;
+                int fr = -1, fs = 0;
+                for (int rr = R; rr < ni && want < 0; ++rr)
+                    for (int s = 0; s < 2 && want < 0; ++s) {
+                        int id = t.C[rr][s];
+                        if (id < n || id - n < R) {
+                            if (id == s_id) { want = c; fr = rr; fs = s; }
+                            ++c;
+                        }
+                    }
+                mp_insert_node(t, ni, Sp, &b_id, fr, fs, troot, p_pop);
+            }
+            for (int m = 0; m < nstub; ++m) if (st_t[m] > tc) ev_insert(t, st_t[m], b_id, st_q[m]);
+        }
+        for (int m = 0; m < W.npath; ++m) ev_insert(t, W.pt[m], b_id, W.pq[m]);
+        ev_drop_above(t, n + n - 2, -1.0);      /* nothing is kept above the root of the local tree */
+        p.Ltree = tree_length(t, n);
+        ++n_recomb;
     }
 
     /* record_recomb_extension (particle.cpp:305-357): one rectangle per (tree time-slice x epoch)
@@ -435,6 +755,7 @@ struct Filter {
     /* Forest::buildInitialTree(true) [reconstructed]: add the samples one at a time, each new
      * leaf coalescing into the partial tree; coalescences are recorded at position 0. */
     void build_initial_tree(int64_t slot, Particle& p) {
+        if (M.P > 1) { mp_build_initial_tree(slot, p); return; }
         const int n = M.n;
         Tree& t = p.tr;
         int root = 0;
@@ -549,6 +870,7 @@ struct Filter {
         int rp = 0, sb = 0;
         lineages_at(t, n - 1, h, lin, &rp, &sb);   /* branch b = slot (rp,sb); its parent p has rank rp */
         *h_out = h;
+        if (M.P > 1) { mp_genealogy_rest(slot, p, x, limit, rp, sb, h); return; }
         /* --- coalesce upwards against the full old tree (SMC': the cut branch's stub is a target) --- */
         double Sold[NMAX - 1];
         for (int i = 0; i < n - 1; ++i) Sold[i] = t.S[i];
@@ -676,7 +998,9 @@ struct Filter {
         cur_pos = initial_position;
         logl = 0;
         const int E = M.E;
-        coal_count.assign(E, 0); coal_opp.assign(E, 0); coal_w2.assign(E, 0);
+        const int P = M.P;
+        coal_count.assign(E * P, 0); coal_opp.assign(E * P, 0); coal_w2.assign(E * P, 0);
+        mig_count.assign(E * P * P, 0); mig_opp.assign(E * P, 0); mig_w2.assign(E * P, 0);
         rec_count.assign(E, 0); rec_opp.assign(E, 0); rec_w2.assign(E, 0);
         counted_to.assign(E, 0);
     }
@@ -848,10 +1172,16 @@ struct Filter {
         double ep0 = M.T[e], ep1 = M.epoch_end(e);
         double ts = std::max(0.0, std::min(ep1, ev->t1) - std::max(ep0, ev->t0));
         if (ev->kind == 1) {
-            if (x_start <= ev->x0 && ev->event) coal_count[e] += w;
+            const int P = M.P, ep = e * P + ev->pop;
+            if (x_start <= ev->x0 && ev->event == 1) coal_count[ep] += w;
+            if (x_start <= ev->x0 && ev->event == 2) mig_count[ep * P + ev->mig_to] += w;
             double opp = ev->weight * ts;                 /* coalevent.hpp:212-214 */
-            coal_opp[e] += w * opp;
-            coal_w2[e] += w * w * opp;
+            coal_opp[ep] += w * opp;
+            coal_w2[ep] += w * w * opp;
+            if (P > 1) {                                  /* coalevent.hpp:215-220, count.cpp:521-526 */
+                mig_opp[ep] += w * ts;
+                mig_w2[ep] += w * w * ts;
+            }
         } else {
             bool end_seq = (M.L == x_end);
             double xs = std::max(0.0, std::min(x_end, ev->x1) - std::max(x_start, ev->x0));
@@ -1067,18 +1397,56 @@ extern "C" {
 
 const char* smco_last_error(void) { return g_err.c_str(); }
 
+static void fill_model(Model& M, const smco_model* m) {
+    if (m->n_pops < 1 || m->n_pops > 8) throw std::runtime_error("oracle: n_pops out of range");
+    if (m->nsam < 2 || m->nsam > NMAX) throw std::runtime_error("oracle: nsam out of range");
+    M.E = m->n_epochs; M.P = m->n_pops; M.n = m->nsam;
+    const int E = M.E, P = M.P;
+    M.ancestral_aware = m->flags & 1; M.dephase = m->flags & 2;
+    M.L = m->loci_length; M.mu = m->mutation_rate; M.rho = m->recombination_rate;
+    M.T.assign(m->change_times, m->change_times + E);
+    M.inv2N.resize(E);
+    for (int e = 0; e < E; ++e) M.inv2N[e] = 1.0 / (2.0 * m->pop_sizes[e * P]);
+    M.inv2Np.resize(E * P);
+    for (int i = 0; i < E * P; ++i) M.inv2Np[i] = 1.0 / (2.0 * m->pop_sizes[i]);
+    M.Mrate.assign(E * P * P, 0.0);
+    if (m->mig_rates) M.Mrate.assign(m->mig_rates, m->mig_rates + E * P * P);
+    M.Mtot.assign(E * P, 0.0);
+    for (int e = 0; e < E; ++e)
+        for (int a = 0; a < P; ++a) {
+            double sum = 0.0;
+            for (int b = 0; b < P; ++b) if (b != a) sum += M.Mrate[(e * P + a) * P + b];
+            M.Mtot[e * P + a] = sum;
+        }
+    /* fixed-time moves: deterministic only (single_mig_pop in {0,1}), chains resolved here
+     * (dontImplementFixedTimeEvent, particle.cpp:1387-1418) */
+    M.jmap.resize(E * P);
+    for (int e = 0; e < E; ++e)
+        for (int a = 0; a < P; ++a) {
+            int cur = a;
+            for (int step = 0; step <= P && m->single_mig; ++step) {
+                int nxt = cur;
+                for (int b = 0; b < P; ++b) {
+                    double pr = m->single_mig[(e * P + cur) * P + b];
+                    if (pr != 0.0 && pr != 1.0) throw std::runtime_error("oracle: partial single migration events are not supported");
+                    if (pr == 1.0 && b != cur) { nxt = b; break; }
+                }
+                if (nxt == cur) break;
+                if (step == P) throw std::logic_error("Cycle detected when moving individuals between populations");
+                cur = nxt;
+            }
+            M.jmap[e * P + a] = cur;
+        }
+    M.sample_pop.assign(M.n, 0);
+    if (m->sample_pops) M.sample_pop.assign(m->sample_pops, m->sample_pops + M.n);
+    for (int v : M.sample_pop) if (v < 0 || v >= P) throw std::runtime_error("oracle: sample population out of range");
+}
+
 void* smco_create(const smco_model* m, const smco_params* p) {
     try {
-        if (m->n_pops != 1) throw std::runtime_error("oracle: only n_pops == 1 is supported in this round");
-        if (m->nsam < 2 || m->nsam > NMAX) throw std::runtime_error("oracle: nsam out of range");
         Filter* f = new Filter();
         Model& M = f->M;
-        M.E = m->n_epochs; M.P = 1; M.n = m->nsam;
-        M.ancestral_aware = m->flags & 1; M.dephase = m->flags & 2;
-        M.L = m->loci_length; M.mu = m->mutation_rate; M.rho = m->recombination_rate;
-        M.T.assign(m->change_times, m->change_times + M.E);
-        M.inv2N.resize(M.E);
-        for (int e = 0; e < M.E; ++e) M.inv2N[e] = 1.0 / (2.0 * m->pop_sizes[e]);
+        fill_model(M, m);
         M.recflags.assign(m->record_flags, m->record_flags + M.E);
         M.lags.assign(m->lags, m->lags + M.E);
         if (m->n_bias_heights > 0) {
@@ -1169,14 +1537,43 @@ int smco_get_particles(void* h, double* w_post, double* w_pilot, double* heights
 
 int smco_get_counts(void* h, double* out, int32_t n) {
     Filter* f = (Filter*)h;
-    const int E = f->M.E;
-    if (n < SMCO_COUNTS_LEN(E)) return -1;
-    for (int e = 0; e < E; ++e) {
-        out[0 * E + e] = f->coal_count[e]; out[1 * E + e] = f->coal_opp[e]; out[2 * E + e] = f->coal_w2[e];
-        out[3 * E + e] = f->rec_count[e]; out[4 * E + e] = f->rec_opp[e]; out[5 * E + e] = f->rec_w2[e];
+    const int E = f->M.E, P = f->M.P;
+    if (n < SMCO_COUNTS_LEN2(E, P)) return -1;
+    double* o = out;
+    for (int i = 0; i < E * P; ++i) o[i] = f->coal_count[i];
+    o += E * P;
+    for (int i = 0; i < E * P; ++i) o[i] = f->coal_opp[i];
+    o += E * P;
+    for (int i = 0; i < E * P; ++i) o[i] = f->coal_w2[i];
+    o += E * P;
+    for (int e = 0; e < E; ++e) { o[e] = f->rec_count[e]; o[E + e] = f->rec_opp[e]; o[2 * E + e] = f->rec_w2[e]; }
+    o += 3 * E;
+    if (P > 1) {
+        for (int i = 0; i < E * P * P; ++i) o[i] = f->mig_count[i];
+        o += E * P * P;
+        for (int i = 0; i < E * P; ++i) o[i] = f->mig_opp[i];
+        o += E * P;
+        for (int i = 0; i < E * P; ++i) o[i] = f->mig_w2[i];
+        o += E * P;
     }
-    out[6 * E + 0] = f->delayed_opp; out[6 * E + 1] = f->delayed_count;
-    out[6 * E + 2] = (double)f->n_resample; out[6 * E + 3] = f->logl;
+    o[0] = f->delayed_opp; o[1] = f->delayed_count;
+    o[2] = (double)f->n_resample; o[3] = f->logl;
+    return 0;
+}
+
+int smco_get_migrations(void* h, int32_t* nm, double* times, int8_t* branch, int8_t* newpop, int8_t* node_pops, int32_t cap) {
+    Filter* f = (Filter*)h;
+    const int n = f->M.n;
+    for (int64_t i = 0; i < f->Np; ++i) {
+        const Tree& t = f->parts[i].tr;
+        if (nm) nm[i] = t.nm;
+        for (int m = 0; m < cap; ++m) {
+            if (times) times[i * cap + m] = m < t.nm ? t.Mt[m] : 0.0;
+            if (branch) branch[i * cap + m] = m < t.nm ? t.Mb[m] : 0;
+            if (newpop) newpop[i * cap + m] = m < t.nm ? t.Mq[m] : 0;
+        }
+        if (node_pops) for (int r = 0; r < n - 1; ++r) node_pops[i * (n - 1) + r] = f->M.P > 1 ? t.Pn[r] : 0;
+    }
     return 0;
 }
 
@@ -1194,11 +1591,7 @@ int smco_median_survival(const smco_model* m, uint64_t seed, int32_t min_events,
                          int64_t* trees_used) {
     GUARD(
         Model M;
-        M.E = m->n_epochs; M.P = 1; M.n = m->nsam;
-        M.L = m->loci_length; M.mu = m->mutation_rate; M.rho = m->recombination_rate;
-        M.T.assign(m->change_times, m->change_times + M.E);
-        M.inv2N.resize(M.E);
-        for (int e = 0; e < M.E; ++e) M.inv2N[e] = 1.0 / (2.0 * m->pop_sizes[e]);
+        fill_model(M, m);
         M.recflags.assign(M.E, 3);
         M.lags.assign(M.E, 0.0);
         median_survival(M, seed, min_events, max_trees, median_out, trees_used);

@@ -26,7 +26,7 @@ extern "C" {
 
 typedef struct smco_model {
     int32_t n_epochs;            /* E */
-    int32_t n_pops;              /* P (oracle supports P == 1 in this round) */
+    int32_t n_pops;              /* P (1..8) */
     int32_t nsam;                /* number of haplotypes n (2..16) */
     int32_t flags;               /* bit0 ancestral_aware, bit1 dephase */
     double loci_length;          /* L, bp */
@@ -71,6 +71,9 @@ typedef struct smco_segments {
  *   [6*E+2] resample_count [6*E+3] ln_normalization_factor
  * (raw sums, WITHOUT the prior pseudo-counts of count.cpp:161-227; the host adds those.) */
 #define SMCO_COUNTS_LEN(E) (6 * (E) + 4)
+/* P > 1:  coal_count[E][P] coal_opp[E][P] coal_weight[E][P]  rec_count[E] rec_opp[E] rec_weight[E]
+ *         mig_count[E][P][P] mig_opp[E][P] mig_weight[E][P]  and the same four scalars (count.hpp:95-110) */
+#define SMCO_COUNTS_LEN2(E, P) ((P) == 1 ? SMCO_COUNTS_LEN(E) : (3 * (E) * (P) + 3 * (E) + (E) * (P) * (P) + 2 * (E) * (P) + 4))
 
 void* smco_create(const smco_model* m, const smco_params* p);
 void smco_destroy(void* h);
@@ -90,6 +93,10 @@ int smco_get_resample_events(void* h, int32_t* seg_idx, int32_t* parents, int32_
 int smco_get_particles(void* h, double* w_post, double* w_pilot, double* heights, int8_t* children,
                        double* next_base);
 int smco_get_counts(void* h, double* packed, int32_t n);
+/* structured models: migration events kept on each particle's local tree ([np*cap], sorted by time) and the
+ * population of every coalescent node ([np*(nsam-1)]) */
+int smco_get_migrations(void* h, int32_t* n_events, double* times, int8_t* branch, int8_t* newpop, int8_t* node_pops,
+                        int32_t cap);
 double smco_logl(void* h);
 /* work statistics for DESIGN.md / roofline bookkeeping */
 int smco_get_stats(void* h, int64_t* n_recombinations, int64_t* n_events_allocated, int64_t* n_resamples);

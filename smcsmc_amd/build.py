@@ -31,8 +31,8 @@ def _stale(target, sources):
 
 
 def build_lib(force=False):
-    srcs = [os.path.join(CSRC, "pf_hip.hip"), os.path.join(CSRC, "pf_device.h"),
-            os.path.join(os.path.dirname(HERE), "include", "smcsmc_pf.h")]
+    srcs = [os.path.join(CSRC, "pf_hip.hip"), os.path.join(CSRC, "pf_device.h"), os.path.join(CSRC, "pf_tree_reg.h"),
+            os.path.join(CSRC, "pf_mp.h"), os.path.join(os.path.dirname(HERE), "include", "smcsmc_pf.h")]
     if force or _stale(LIB, srcs):
         cmd = [_hipcc()] + HIPCC_FLAGS + ["-shared", "-o", LIB, srcs[0]]
         subprocess.check_call(cmd)

@@ -25,6 +25,7 @@
 #include "../../include/smcsmc_pf.h"
 #include "pf_device.h"
 #include "pf_tree_reg.h"
+#include "pf_mp.h"
 
 #define PF_EMAX 64
 #define PF_DCAP 32            // pending delayed factors per particle (the reference's heap is unbounded)
@@ -53,6 +54,12 @@ struct DState {
     double* dfac;            // [PF_DCAP][Np]
     double* ddelta;          // [PF_DCAP][Np]
     int* dk;                 // [PF_DCAP][Np]
+    // structured models (pf_mp.h); allocated only when P > 1
+    int8_t* Pn;              // [(n-1)][Np] population of every coalescent node
+    int* nm;                 // [Np] migration events on the local tree
+    double* Mt;              // [PF_MMAX][Np]
+    int8_t* Mb;              // [PF_MMAX][Np]
+    int8_t* Mq;              // [PF_MMAX][Np]
 };
 
 struct Ctrl {
@@ -90,6 +97,16 @@ struct KArgs {
     const double* inv2N;
     const double* lags;
     const int* recflags;
+    // structured models: P populations
+    int P, ncol;                   // ncol = statistics per epoch (6 when P == 1)
+    const double* inv2Np;          // [E*P]
+    const double* mig_rate;        // [E*P*P]
+    const double* mig_tot;         // [E*P]
+    const int* join_map;           // [E*P]
+    const int* sample_pop;         // [n]
+    double* plog;                  // coal/migr opportunity pieces: plog[(p*pcap + k%pcap)*3 .. +3)
+    unsigned pcap;
+    unsigned* pidx;                // slot-owned: pieces ever written by this slot
     // run parameters
     long long Np;
     double ess_threshold;
@@ -173,7 +190,8 @@ struct Windows {
     double b[PF_EMAX];         // update_to of this step
 };
 
-enum { ERR_LOG_OVERFLOW = 1, ERR_GEN_OVERFLOW = 2, ERR_ZERO_PROB = 3, ERR_COUNT_MISMATCH = 4 };
+enum { ERR_LOG_OVERFLOW = 1, ERR_GEN_OVERFLOW = 2, ERR_ZERO_PROB = 3, ERR_COUNT_MISMATCH = 4, ERR_MIG_OVERFLOW = 5,
+       ERR_MP_INTERNAL = 6, ERR_NO_COALESCENCE = 7 };
 
 __device__ __forceinline__ unsigned long long make_meta(int type, int lim_start, int lim_event, int n_eff) {
     return (unsigned long long)(type & 0xff) | ((unsigned long long)((lim_start + 1) & 0xff) << 8) |
@@ -199,7 +217,7 @@ __device__ __forceinline__ Smem carve(double* base, int n, int E) {
     m.C = (int8_t*)(m.RF + E + (E & 1));
     return m;
 }
-static size_t smem_bytes(int n, int E) {
+__host__ __device__ static size_t smem_bytes(int n, int E) {
     return (size_t)3 * (n - 1) * PF_BS * 8 + (size_t)2 * E * 8 + (size_t)(E + (E & 1)) * 4 + (size_t)2 * (n - 1) * PF_BS;
 }
 
@@ -295,7 +313,7 @@ __global__ __launch_bounds__(PF_BS) void k_init(KArgs A, double initial_position
 
 // One genealogy update (SMC'): sample the recombination point, coalesce the floating lineage
 // against the old tree, re-attach.  Mirrors oracle Filter::genealogy_update step by step.
-__device__ __forceinline__ void genealogy_update(Lane& ln, double* h_out, double* tc_out, double* sp_out, bool* changed_out) {
+__device__ __forceinline__ void sample_point(Lane& ln, int* rp_out, int* sb_out, double* h_out) {
     const int n = ln.n;
     double r = uni(ln) * ln.Ltree;
     double prev = 0.0, h = 0.0;
@@ -315,8 +333,15 @@ __device__ __forceinline__ void genealogy_update(Lane& ln, double* h_out, double
         r -= seg;
         prev = sr;
     }
+    lineages_at(ln, n - 1, h, lin, rp_out, sb_out);
+    *h_out = h;
+}
+
+__device__ __forceinline__ void genealogy_update(Lane& ln, double* h_out, double* tc_out, double* sp_out, bool* changed_out) {
+    const int n = ln.n;
     int rp = 0, sb = 0;
-    lineages_at(ln, n - 1, h, lin, &rp, &sb);
+    double h;
+    sample_point(ln, &rp, &sb, &h);
     *h_out = h;
     double tc = coalesce_up(ln, [&](int k) { return LS(ln, k); }, n - 1, n, h);
     *tc_out = tc;
@@ -551,6 +576,290 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
     double sc = wave_hs_scan(w_pilot, lane);
     double scp = wave_hs_scan(w_post, lane);
     double scm = wave_max_scan_d(sc, lane);     // running max of the pilot scan (a parallel FP scan need not be monotone)
+    long long chunk = p >> 6;
+    if (active) { A.scan1[p] = sc; A.scanp2[A.sp][p] = scp; A.scan1m[p] = scm; }
+    if (lane == 63 && chunk < (A.Np + 63) / 64) {
+        A.chunk_post[chunk] = sp;
+        A.chunk_sq[chunk] = sq;
+        A.chunk_pil[chunk] = sc;
+        A.chunk_pp[chunk] = scp;
+        A.chunk_mx1[chunk] = scm;
+    }
+}
+
+// ------------------------------------------------------------------ structured models (P > 1): LDS-tree kernels
+// Same structure as k_init / k_extend / k_calibrate with the migration-aware genealogy update of pf_mp.h.
+struct SmemMP { double* I2; double* MR; double* MT; double* Mt; int* JM; int* SP; int8_t* Pn; int8_t* Mb; int8_t* Mq; };
+__host__ __device__ static size_t smem_mp_extra(int n, int E, int P) {
+    size_t dbl = (size_t)E * P * 2 + (size_t)E * P * P + (size_t)PF_MMAX * PF_BS;
+    size_t ints = (size_t)E * P + (size_t)((n + 1) & ~1) + (size_t)((E * P) & 1);
+    size_t bytes = (size_t)(n - 1) * PF_BS + (size_t)2 * PF_MMAX * PF_BS;
+    return dbl * 8 + ints * 4 + bytes;
+}
+static size_t smem_bytes_mp(int n, int E, int P) { return smem_bytes(n, E) + smem_mp_extra(n, E, P); }
+__device__ __forceinline__ SmemMP carve_mp(double* base, int n, int E, int P) {
+    SmemMP m;
+    m.I2 = (double*)((char*)base + smem_bytes(n, E));
+    m.MR = m.I2 + (size_t)E * P;
+    m.MT = m.MR + (size_t)E * P * P;
+    m.Mt = m.MT + (size_t)E * P;
+    m.JM = (int*)(m.Mt + (size_t)PF_MMAX * PF_BS);
+    m.SP = m.JM + (size_t)E * P + ((E * P) & 1);
+    m.Pn = (int8_t*)(m.SP + ((n + 1) & ~1));
+    m.Mb = m.Pn + (size_t)(n - 1) * PF_BS;
+    m.Mq = m.Mb + (size_t)PF_MMAX * PF_BS;
+    return m;
+}
+__device__ __forceinline__ void load_model_mp(const KArgs& A, SmemMP& m) {
+    const int EP = A.E * A.P;
+    for (int i = threadIdx.x; i < EP; i += blockDim.x) { m.I2[i] = A.inv2Np[i]; m.MT[i] = A.mig_tot[i]; m.JM[i] = A.join_map[i]; }
+    for (int i = threadIdx.x; i < EP * A.P; i += blockDim.x) m.MR[i] = A.mig_rate[i];
+    for (int i = threadIdx.x; i < A.n; i += blockDim.x) m.SP[i] = A.sample_pop[i];
+}
+__device__ __forceinline__ MLane make_mlane(const KArgs& A, SmemMP& m) {
+    MLane ml;
+    ml.Pn = m.Pn + threadIdx.x; ml.Mt = m.Mt + threadIdx.x; ml.Mb = m.Mb + threadIdx.x; ml.Mq = m.Mq + threadIdx.x;
+    ml.nm = 0; ml.P = A.P;
+    ml.I2 = m.I2; ml.MR = m.MR; ml.MT = m.MT; ml.JM = m.JM; ml.SP = m.SP;
+    ml.err = 0;
+    return ml;
+}
+__device__ __forceinline__ void mp_report(const KArgs& A, const MLane& ml) {
+    if (ml.err == 1) A.ctrl->err = ERR_MIG_OVERFLOW;
+    if (ml.err == 2) A.ctrl->err = ERR_MP_INTERNAL;
+    if (ml.err == 3) A.ctrl->err = ERR_NO_COALESCENCE;
+}
+__device__ __forceinline__ double piece_ref(unsigned pstart, unsigned npieces) {
+    return __longlong_as_double((long long)((unsigned long long)pstart | ((unsigned long long)npieces << 32)));
+}
+__device__ __forceinline__ void store_mp_state(const KArgs& A, DState& st, const Lane& ln, const MLane& ml, long long p) {
+    const int n = A.n;
+    for (int r = 0; r < n - 1; ++r) st.Pn[(size_t)r * A.Np + p] = LPn(ml, r);
+    st.nm[p] = ml.nm;
+    for (int m = 0; m < ml.nm; ++m) {
+        st.Mt[(size_t)m * A.Np + p] = LMt(ml, m);
+        st.Mb[(size_t)m * A.Np + p] = LMb(ml, m);
+        st.Mq[(size_t)m * A.Np + p] = LMq(ml, m);
+    }
+}
+
+__global__ __launch_bounds__(PF_BS) void k_init_mp(KArgs A, double initial_position) {
+    extern __shared__ double smem[];
+    Smem m = carve(smem, A.n, A.E);
+    SmemMP mm = carve_mp(smem, A.n, A.E, A.P);
+    load_model(A, m);
+    load_model_mp(A, mm);
+    __syncthreads();
+    long long p = (long long)blockIdx.x * PF_BS + threadIdx.x;
+    if (p == 0) {
+        Ctrl* c = A.ctrl;
+        c->cur_pos = initial_position;
+        c->logl = 0; c->inv_T = 1; c->T = 1; c->flag = 0; c->cur = 0; c->gen = 0; c->n_resample = 0;
+        c->first_epoch = A.E; c->err = 0; c->delayed_opp = 0; c->delayed_count = 0; c->count_active = 0; c->end_seq = 0;
+        c->g_retain = 0; c->pending_fin = 0; c->nbx_used = A.nbx; c->gen_prev = 0; c->nres_prev = 0;
+        for (int e = 0; e < A.E; ++e) { c->counted_to[e] = 0; c->update_to[e] = 0; c->g_lo[e] = 0; c->g_hi[e] = 0; }
+        A.gen_x0[0] = 0.0;
+    }
+    if (p >= A.Np) return;
+    const int n = A.n;
+    Lane ln = make_lane(A, m, p);
+    MLane ml = make_mlane(A, mm);
+    ln.ebuf = -dlog(uni(ln));
+    unsigned widx = 0;
+    PLog pl;
+    pl.base = A.plog + (size_t)p * A.pcap * 3; pl.cap = A.pcap; pl.idx = 0; pl.on = true; pl.fopen = false; pl.ropen = false;
+    // every coalescence of the initial tree is logged as a type-2 record at position 0 (particle.cpp:251-300)
+    mp_build_initial_tree(ln, ml, &pl, [&](int i, unsigned p0, unsigned np_, double tc) {
+        double* rec = rec_ptr(A, p, widx);
+        rec[0] = 0.0; rec[1] = 0.0; rec[2] = 0.0;
+        rec[3] = piece_ref(p0, np_);
+        rec[4] = __longlong_as_double((long long)make_meta(2, A.E - 1, A.E - 1, i));
+        for (int r = 0; r < n - 1; ++r) rec[5 + r] = 0.0;
+        (void)tc;
+        ++widx;
+    });
+    mp_report(A, ml);
+    double nb = sample_next_base(ln, 0.0);
+    DState& st = A.st[0];
+    for (int r = 0; r < n - 1; ++r) {
+        st.S[(size_t)r * A.Np + p] = LS(ln, r);
+        st.C[(size_t)(2 * r) * A.Np + p] = LC(ln, r, 0);
+        st.C[(size_t)(2 * r + 1) * A.Np + p] = LC(ln, r, 1);
+    }
+    store_mp_state(A, st, ln, ml, p);
+    st.w_post[p] = 1.0 / (double)A.Np;
+    st.w_pilot[p] = 1.0 / (double)A.Np;
+    st.next_base[p] = nb;
+    st.x_mark[p] = 0.0;
+    st.Ltree[p] = ln.Ltree;
+    st.mark_limit[p] = A.E - 1;
+    A.rng_ctr[p] = ln.ctr;
+    A.ebuf[p] = ln.ebuf;
+    A.widx[p] = widx;
+    A.pidx[p] = pl.idx;
+    A.gstart[p] = 0;
+}
+
+__global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
+    extern __shared__ double smem[];
+    Smem m = carve(smem, A.n, A.E);
+    SmemMP mm = carve_mp(smem, A.n, A.E, A.P);
+    load_model(A, m);
+    load_model_mp(A, mm);
+    __syncthreads();
+    const Ctrl* c = A.ctrl;
+    const int n = A.n;
+    const int cur = c->cur;
+    const long long p = (long long)blockIdx.x * PF_BS + threadIdx.x;
+    const bool active = p < A.Np;
+    const int lane = threadIdx.x & 63;
+    double w_post = 0.0, w_pilot = 0.0;
+    if (active) {
+        DState& st = A.st[cur];
+        Lane ln = make_lane(A, m, p);
+        MLane ml = make_mlane(A, mm);
+        for (int r = 0; r < n - 1; ++r) {
+            LS(ln, r) = st.S[(size_t)r * A.Np + p];
+            LC(ln, r, 0) = st.C[(size_t)(2 * r) * A.Np + p];
+            LC(ln, r, 1) = st.C[(size_t)(2 * r + 1) * A.Np + p];
+            LPn(ml, r) = st.Pn[(size_t)r * A.Np + p];
+        }
+        ml.nm = st.nm[p];
+        for (int q = 0; q < ml.nm; ++q) {
+            LMt(ml, q) = st.Mt[(size_t)q * A.Np + p];
+            LMb(ml, q) = st.Mb[(size_t)q * A.Np + p];
+            LMq(ml, q) = st.Mq[(size_t)q * A.Np + p];
+        }
+        w_post = st.w_post[p];
+        w_pilot = st.w_pilot[p];
+        double next_base = st.next_base[p];
+        double x_mark = st.x_mark[p];
+        int mark_limit = st.mark_limit[p];
+        ln.Ltree = st.Ltree[p];
+        ln.ctr = A.rng_ctr[p];
+        ln.ebuf = A.ebuf[p];
+        unsigned widx = A.widx[p];
+        PLog pl;
+        pl.base = A.plog + (size_t)p * A.pcap * 3; pl.cap = A.pcap; pl.idx = A.pidx[p]; pl.on = true;
+        pl.fopen = false; pl.ropen = false;
+        double* tmp0 = m.t0 + threadIdx.x;
+        double* tmp1 = m.t1 + threadIdx.x;
+
+        const int8_t* data = A.seg_alleles + (size_t)s * n;
+        const double seg_end = A.seg_start[s] + A.seg_len[s];
+        const double extend_to = seg_end < A.L ? seg_end : A.L;
+        const int limit = A.seg_limit[s];
+        int missing = 0;
+        for (int i = 0; i < n; ++i) missing += data[i] == -1;
+        int leaf_status = 0;
+        if (missing == 0) leaf_status = 1;
+        if (missing == n) leaf_status = -1;
+
+        double updated_to = c->cur_pos;
+        double B;
+        if (leaf_status == -1) B = 0;
+        else if (leaf_status == 1) B = ln.Ltree;
+        else B = tracked_len_lane(ln, data, tmp0);
+
+        while (updated_to < extend_to) {
+            double new_to = extend_to < next_base ? extend_to : next_base;
+            double f = fastexp(-A.mu * B * (new_to - updated_to));
+            w_post *= f;
+            w_pilot *= f;
+            updated_to = new_to;
+            if (updated_to < extend_to) {
+                double* rec = rec_ptr(A, p, widx);
+                rec[0] = x_mark;
+                rec[1] = updated_to;
+                for (int r = 0; r < n - 1; ++r) rec[5 + r] = LS(ln, r);
+                int rp = 0, sb = 0;
+                double h, tc, sp_removed;
+                bool changed;
+                sample_point(ln, &rp, &sb, &h);
+                unsigned p0 = pl.idx;
+                mp_genealogy_rest(ln, ml, &pl, limit, rp, sb, h, &tc, &sp_removed, &changed);
+                rec[2] = h;
+                rec[3] = piece_ref(p0, pl.idx - p0);
+                rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n));
+                ++widx;
+                if (ml.err) break;
+                if (leaf_status == 0) B = tracked_len_lane(ln, data, tmp0);
+                if (leaf_status == 1) B = ln.Ltree;
+                next_base = sample_next_base(ln, updated_to);
+                x_mark = updated_to;
+                mark_limit = limit;
+            }
+        }
+        mp_report(A, ml);
+
+        if (A.seg_state[s] == 0) {
+            // update_weight_at_site: marginalise over phasings of unphased hets (pc.cpp:138-224)
+            const bool dephase = A.flags & 2;
+            const bool anc = A.flags & 1;
+            unsigned one_mask = 0, zero_mask = 0, het_pairs = 0;
+            int ncfg = 1;
+            for (int i = 0; i < n; ++i) {
+                if (data[i] == 1) one_mask |= 1u << i;
+                if (data[i] == 0) zero_mask |= 1u << i;
+            }
+            for (int i = 0; i + 1 < n; i += 2) {
+                bool het = (data[i] == 2) || (dephase && data[i] + data[i + 1] == 1);
+                if (het) {
+                    ncfg *= 2;
+                    het_pairs |= 1u << i;
+                    one_mask &= ~(3u << i); zero_mask &= ~(3u << i);
+                    zero_mask |= 1u << i;
+                    one_mask |= 1u << (i + 1);
+                }
+            }
+            double norm = 1.0 / (double)ncfg;
+            double lik = 0;
+            for (;;) {
+                lik += site_lik_lane(ln, one_mask, zero_mask, anc, tmp0, tmp1);
+                if (ncfg == 1) break;
+                bool more = false;
+                for (int i = 0; i + 1 < n; i += 2) {
+                    if (!((het_pairs >> i) & 1)) continue;
+                    if ((zero_mask >> i) & 1) {
+                        zero_mask &= ~(1u << i); one_mask |= 1u << i;
+                        one_mask &= ~(1u << (i + 1)); zero_mask |= 1u << (i + 1);
+                        more = true;
+                        break;
+                    }
+                    one_mask &= ~(1u << i); zero_mask |= 1u << i;
+                    zero_mask &= ~(1u << (i + 1)); one_mask |= 1u << (i + 1);
+                }
+                if (!more) break;
+            }
+            lik *= norm;
+            w_post *= lik;
+            w_pilot *= lik;
+        }
+
+        for (int r = 0; r < n - 1; ++r) {
+            st.S[(size_t)r * A.Np + p] = LS(ln, r);
+            st.C[(size_t)(2 * r) * A.Np + p] = LC(ln, r, 0);
+            st.C[(size_t)(2 * r + 1) * A.Np + p] = LC(ln, r, 1);
+        }
+        store_mp_state(A, st, ln, ml, p);
+        st.w_post[p] = w_post;
+        st.w_pilot[p] = w_pilot;
+        st.next_base[p] = next_base;
+        st.x_mark[p] = x_mark;
+        st.mark_limit[p] = mark_limit;
+        st.Ltree[p] = ln.Ltree;
+        A.rng_ctr[p] = ln.ctr;
+        A.ebuf[p] = ln.ebuf;
+        A.widx[p] = widx;
+        A.pidx[p] = pl.idx;
+        for (int r = 0; r < n - 1; ++r) A.snap_S[A.sp][(size_t)r * A.Np + p] = LS(ln, r);
+        A.snap_w[A.sp][p] = w_post; A.snap_xm[A.sp][p] = x_mark; A.snap_ml[A.sp][p] = mark_limit; A.snap_widx[A.sp][p] = widx;
+    }
+    double sp = wave_tree_sum(w_post);
+    double sq = wave_tree_sum(w_pilot * w_pilot);
+    double sc = wave_hs_scan(w_pilot, lane);
+    double scp = wave_hs_scan(w_post, lane);
+    double scm = wave_max_scan_d(sc, lane);
     long long chunk = p >> 6;
     if (active) { A.scan1[p] = sc; A.scanp2[A.sp][p] = scp; A.scan1m[p] = scm; }
     if (lane == 63 && chunk < (A.Np + 63) / 64) {
@@ -826,7 +1135,8 @@ __device__ void finalize_counts(const KArgs& A, Ctrl* c, int tid, int nthreads, 
     const int E = A.E;
     const int first = c->first_epoch;
     const int nb = c->nbx_used;
-    const int npairs = (E - first) * 6;
+    const int NC = A.ncol;
+    const int npairs = (E - first) * NC;
     // All partials of a tile are fetched with independent loads (a serial load-add chain would pay the
     // full memory latency per term), then each pair is summed in workgroup order from LDS: the result is
     // bit-identical to the plain serial sum over workgroups.
@@ -838,8 +1148,8 @@ __device__ void finalize_counts(const KArgs& A, Ctrl* c, int tid, int nthreads, 
             for (int idx = tid; idx < np_ * nbt; idx += nthreads) {
                 int pp = idx / nbt, b = idx % nbt;
                 int pair = p0 + pp;
-                int e = first + pair / 6, k = pair % 6;
-                stage[pp * PF_FIN_TILE_B + b] = A.partial[((size_t)e * A.nbx + b0 + b) * 6 + k];
+                int e = first + pair / NC, k = pair % NC;
+                stage[pp * PF_FIN_TILE_B + b] = A.partial[((size_t)e * A.nbx + b0 + b) * NC + k];
             }
             __syncthreads();
             if (tid < np_)
@@ -848,7 +1158,7 @@ __device__ void finalize_counts(const KArgs& A, Ctrl* c, int tid, int nthreads, 
         }
         if (tid < np_) {
             int pair = p0 + tid;
-            int e = first + pair / 6, k = pair % 6;
+            int e = first + pair / NC, k = pair % NC;
             A.totals[(size_t)k * E + e] += run;
         }
     }
@@ -1082,7 +1392,15 @@ __global__ __launch_bounds__(PF_BS) void k_decide(KArgs A, long long s, int mode
 // update_all_counts_single_evolevent (count.cpp:495-555) evaluated from the compact per-slot
 // records.  blockIdx.y = epoch; the x dimension strides over the live ancestors (runs of the
 // composite ancestor maps) of every generation whose positions intersect the epoch's window.
-struct Acc { double cc, co, cw, rc, ro, rw; };
+// per-thread statistics of one epoch: [coal count, opp, weight][P], recomb count, opp, weight and -- for
+// structured models -- [migration count][P][P], [migration opp, weight][P]  (count.hpp:95-110)
+template <int P>
+struct AccT {
+    static constexpr int NC = P == 1 ? 6 : 3 * P + 3 + P * P + 2 * P;
+    static constexpr int CC = 0, CO = P, CW = 2 * P, RC = 3 * P, RO = 3 * P + 1, RW = 3 * P + 2;
+    static constexpr int MC = 3 * P + 3, MO = 3 * P + 3 + P * P, MW = 3 * P + 3 + P * P + P;
+    double v[NC];
+};
 
 __device__ __forceinline__ double ovl(double a0, double a1, double b0, double b1) {
     double lo = a0 > b0 ? a0 : b0;
@@ -1113,23 +1431,24 @@ __device__ __forceinline__ double slice_len(const double (&S)[NI], int nint, int
 
 struct Win { int e, rf; double T0, T1, a_e, b_e; bool end_seq; };
 
-template <int NI>
-__device__ __forceinline__ void stretch_contrib(Acc& acc, const KArgs& A, const Win& W, double w, double x0, double x1,
+template <int NI, int P>
+__device__ __forceinline__ void stretch_contrib(AccT<P>& acc, const KArgs& A, const Win& W, double w, double x0, double x1,
                                                 const double (&S)[NI], int lim_start) {
     if (!(W.rf & REC_RECOMB) || W.e > lim_start) return;
     double xs = ovl(x0, x1, W.a_e, W.b_e);
     if (!(xs > 0.0)) return;
     double len = slice_len<NI>(S, A.n - 1, A.n, W.T0, W.T1, 0.0, PF_INF, false);
     double opp = len * xs;
-    acc.ro += w * opp;
-    acc.rw += w * w * opp;
+    acc.v[AccT<P>::RO] += w * opp;
+    acc.v[AccT<P>::RW] += w * w * opp;
 }
 
 // All fields of a record are fetched in one round of independent loads before anything is tested:
 // the kernel is bound by dependent-load latency, not by bytes.
-template <int NI>
-__device__ __forceinline__ void records_contrib(Acc& acc, const KArgs& A, const Win& W, double w, long long a, unsigned k0,
+template <int NI, int P>
+__device__ __forceinline__ void records_contrib(AccT<P>& acc, const KArgs& A, const Win& W, double w, long long a, unsigned k0,
                                                 unsigned k1) {
+    using AC = AccT<P>;
     const int n = A.n;
     for (unsigned k = k0; k != k1; ++k) {
         const double* rec = rec_ptr(A, a, k);
@@ -1144,19 +1463,52 @@ __device__ __forceinline__ void records_contrib(Acc& acc, const KArgs& A, const 
         int lim_start = (int)((meta >> 8) & 0xff) - 1;
         int lim_event = (int)((meta >> 16) & 0xff) - 1;
         int n_eff = (int)((meta >> 24) & 0xff);
-        if (type <= 1) stretch_contrib<NI>(acc, A, W, w, x0, x1, S, lim_start);
+        if (type <= 1) stretch_contrib<NI, P>(acc, A, W, w, x0, x1, S, lim_start);
         if (type == 0 || type == 2) {
-            double h = f2, tc = f3;
+            double h = f2;
             bool inwin = (W.a_e <= x1) && (x1 < W.b_e);
-            if (inwin && (W.rf & REC_COALMIGR) && W.e <= lim_event) {
-                double opp = slice_len<NI>(S, n_eff - 1, n_eff, W.T0, W.T1, h, tc, true);
-                acc.co += w * opp;
-                acc.cw += w * w * opp;
-                if (W.T0 <= tc && tc < W.T1) acc.cc += w;
+            if constexpr (P == 1) {
+                double tc = f3;
+                if (inwin && (W.rf & REC_COALMIGR) && W.e <= lim_event) {
+                    double opp = slice_len<NI>(S, n_eff - 1, n_eff, W.T0, W.T1, h, tc, true);
+                    acc.v[AC::CO] += w * opp;
+                    acc.v[AC::CW] += w * w * opp;
+                    if (W.T0 <= tc && tc < W.T1) acc.v[AC::CC] += w;
+                }
+            } else {
+                // structured models: the coal/migr opportunities were integrated when the update was simulated
+                // (pieces of pf_mp.h; the record flags and the epoch limit were applied there)
+                (void)n_eff;
+                if (inwin) {
+                    unsigned long long ref = (unsigned long long)__double_as_longlong(f3);
+                    unsigned pstart = (unsigned)(ref & 0xffffffffu), np_ = (unsigned)(ref >> 32);
+                    if (A.pidx[a] - pstart > A.pcap) A.ctrl->err = ERR_LOG_OVERFLOW;
+                    for (unsigned j = 0; j < np_; ++j) {
+                        const double* q = A.plog + ((size_t)a * A.pcap + ((pstart + j) % A.pcap)) * 3;
+                        long long tag = __double_as_longlong(q[0]);
+                        double co = q[1], mo = q[2];
+                        if ((int)(tag & 0xff) != W.e) continue;
+                        int pop = (int)((tag >> 8) & 0xff), kind = (int)((tag >> 16) & 0xff), to = (int)((tag >> 24) & 0xff);
+#pragma unroll
+                        for (int pp = 0; pp < P; ++pp)
+                            if (pp == pop) {
+                                acc.v[AC::CO + pp] += w * co;
+                                acc.v[AC::CW + pp] += w * w * co;
+                                acc.v[AC::MO + pp] += w * mo;
+                                acc.v[AC::MW + pp] += w * w * mo;
+                                if (kind & 1) acc.v[AC::CC + pp] += w;
+                                if (kind & 2) {
+#pragma unroll
+                                    for (int qq = 0; qq < P; ++qq)
+                                        if (qq == to) acc.v[AC::MC + pp * P + qq] += w;
+                                }
+                            }
+                    }
+                }
             }
             if (type == 0) {
                 bool inwin_r = (W.a_e <= x1) && ((x1 < W.b_e) || W.end_seq);
-                if (inwin_r && (W.rf & REC_RECOMB) && W.e <= lim_event && W.T0 <= h && h < W.T1) acc.rc += w;
+                if (inwin_r && (W.rf & REC_RECOMB) && W.e <= lim_event && W.T0 <= h && h < W.T1) acc.v[AC::RC] += w;
             }
         }
     }
@@ -1165,8 +1517,8 @@ __device__ __forceinline__ void records_contrib(Acc& acc, const KArgs& A, const 
 #define PF_CNT_TILE 2048      // generations whose run counts are staged in LDS at a time
 #define PF_CNT_WIDE 128       // run lists longer than this are strided over by the whole grid column
 
-template <int NI>
-__device__ __forceinline__ void count_run(Acc& acc, const KArgs& A, const Win& W, int g, long long i, int nr, const int* rst,
+template <int NI, int P>
+__device__ __forceinline__ void count_run(AccT<P>& acc, const KArgs& A, const Win& W, int g, long long i, int nr, const int* rst,
                                           const int* ran, double inv) {
     const long long Np = A.Np;
     int q0 = rst[i];
@@ -1182,13 +1534,14 @@ __device__ __forceinline__ void count_run(Acc& acc, const KArgs& A, const Win& W
     unsigned k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
     unsigned k1 = A.gstart[(size_t)((g + 1) % A.Gcap) * Np + a];
     if (A.widx[a] - k0 > A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;
-    records_contrib<NI>(acc, A, W, w, a, k0, k1);
+    records_contrib<NI, P>(acc, A, W, w, a, k0, k1);
 }
 
-template <int NM>
+template <int NM, int P>
 __global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0, Windows Wn) {
     constexpr int NI = NM - 1;
-    __shared__ Acc red[PF_BS / 64];
+    using AC = AccT<P>;
+    __shared__ AC red[PF_BS / 64];
     __shared__ int s_off[PF_CNT_TILE + 1];
     __shared__ int s_wsum[PF_BS / 64];
     const Ctrl* c = A.ctrl;
@@ -1210,7 +1563,9 @@ __global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0, Windows Wn) {
     const long long nthreads = (long long)gridDim.x * PF_BS;
     const int my_wave = (int)(gtid >> 6);
     const int total_waves = (int)(nthreads >> 6);
-    Acc acc = {0, 0, 0, 0, 0, 0};
+    AC acc;
+#pragma unroll
+    for (int k = 0; k < AC::NC; ++k) acc.v[k] = 0.0;
     // Work = all (generation, run) pairs of the window plus the live particles, flattened into one task index
     // space with an LDS prefix sum of the run counts: every thread takes tasks gtid, gtid+nthreads, ... so deep
     // windows are spread over the grid column instead of being walked generation by generation.
@@ -1274,30 +1629,27 @@ __global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0, Windows Wn) {
                 unsigned k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
                 unsigned k1 = A.snap_widx[A.sp][a];
                 if (w == 0.0) continue;
-                stretch_contrib<NI>(acc, A, W, w, xm, PF_INF, S, ml);
+                stretch_contrib<NI, P>(acc, A, W, w, xm, PF_INF, S, ml);
                 if (k1 - k0 > A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;
-                records_contrib<NI>(acc, A, W, w, a, k0, k1);
+                records_contrib<NI, P>(acc, A, W, w, a, k0, k1);
             } else {
                 const int nr = s_off[lo_i + 1] - s_off[lo_i];
                 const int* rst = A.run_st + (size_t)(g % A.Gcap) * Np;
                 const int* ran = A.run_anc + (size_t)(g % A.Gcap) * Np;
-                count_run<NI>(acc, A, W, g, i, nr, rst, ran, inv);
+                count_run<NI, P>(acc, A, W, g, i, nr, rst, ran, inv);
             }
         }
     }
     // deterministic workgroup reduction: butterfly per wavefront, then wavefronts in order
-    acc.cc = wave_tree_sum(acc.cc); acc.co = wave_tree_sum(acc.co); acc.cw = wave_tree_sum(acc.cw);
-    acc.rc = wave_tree_sum(acc.rc); acc.ro = wave_tree_sum(acc.ro); acc.rw = wave_tree_sum(acc.rw);
+#pragma unroll
+    for (int k = 0; k < AC::NC; ++k) acc.v[k] = wave_tree_sum(acc.v[k]);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        Acc t = red[0];
-        for (int w = 1; w < PF_BS / 64; ++w) {
-            t.cc += red[w].cc; t.co += red[w].co; t.cw += red[w].cw;
-            t.rc += red[w].rc; t.ro += red[w].ro; t.rw += red[w].rw;
-        }
-        double* out = A.partial + ((size_t)e * A.nbx + blockIdx.x) * 6;
-        out[0] = t.cc; out[1] = t.co; out[2] = t.cw; out[3] = t.rc; out[4] = t.ro; out[5] = t.rw;
+    if (threadIdx.x < AC::NC) {
+        const int k = threadIdx.x;
+        double t = red[0].v[k];
+        for (int w = 1; w < PF_BS / 64; ++w) t += red[w].v[k];
+        A.partial[((size_t)e * A.nbx + blockIdx.x) * AC::NC + k] = t;
     }
 }
 
@@ -1509,6 +1861,16 @@ __global__ __launch_bounds__(PF_BS) void k_resample(KArgs A, long long s, int nb
         dst.C[(size_t)(2 * r) * Np + q] = src.C[(size_t)(2 * r) * Np + a];
         dst.C[(size_t)(2 * r + 1) * Np + q] = src.C[(size_t)(2 * r + 1) * Np + a];
     }
+    if (A.P > 1) {
+        for (int r = 0; r < n - 1; ++r) dst.Pn[(size_t)r * Np + q] = src.Pn[(size_t)r * Np + a];
+        const int nmv = src.nm[a];
+        dst.nm[q] = nmv;
+        for (int k = 0; k < nmv; ++k) {
+            dst.Mt[(size_t)k * Np + q] = src.Mt[(size_t)k * Np + a];
+            dst.Mb[(size_t)k * Np + q] = src.Mb[(size_t)k * Np + a];
+            dst.Mq[(size_t)k * Np + q] = src.Mq[(size_t)k * Np + a];
+        }
+    }
     // weights: normalise, then adjustment = sum / (N * pilot)   (pc.cpp:350-351)
     double wp = src.w_post[a] * inv;
     double wq = src.w_pilot[a] * inv;
@@ -1637,6 +1999,55 @@ __global__ __launch_bounds__(PF_BS) void k_calibrate(KArgs A, unsigned long long
     }
 }
 
+__global__ __launch_bounds__(PF_BS) void k_calibrate_mp(KArgs A, unsigned long long seed, long long rep0, long long nrep,
+                                                        int* out_epoch, double* out_dist, int* out_err) {
+    extern __shared__ double smem[];
+    Smem m = carve(smem, A.n, A.E);
+    SmemMP mm = carve_mp(smem, A.n, A.E, A.P);
+    load_model(A, m);
+    load_model_mp(A, mm);
+    __syncthreads();
+    long long r = (long long)blockIdx.x * PF_BS + threadIdx.x;
+    if (r >= nrep) return;
+    const int n = A.n;
+    Lane ln = make_lane(A, m, rep0 + r);
+    MLane ml = make_mlane(A, mm);
+    ln.seed = seed;
+    ln.stream = 2;
+    ln.ebuf = -dlog(uni(ln));
+    mp_build_initial_tree(ln, ml, (PLog*)nullptr, [&](int, unsigned, unsigned, double) {});
+    double* orig = m.t0 + threadIdx.x;
+    int alive = n - 1;
+    for (int j = 0; j < n - 1; ++j) {
+        orig[j * PF_BS] = LS(ln, j);
+        out_epoch[r * (n - 1) + j] = epoch_of(ln, LS(ln, j));
+        out_dist[r * (n - 1) + j] = -1.0;
+    }
+    unsigned alive_mask = (1u << (n - 1)) - 1u;
+    double next = ml.err ? A.L : sample_next_base(ln, 0.0);
+    const double stop = A.L * 0.6;
+    while (alive > 0 && next < stop && !ml.err) {
+        double x = next;
+        int rp = 0, sb = 0;
+        double h, tc, sp;
+        bool changed;
+        sample_point(ln, &rp, &sb, &h);
+        mp_genealogy_rest(ln, ml, (PLog*)nullptr, -1, rp, sb, h, &tc, &sp, &changed);
+        if (ml.err) break;
+        if (changed) {
+            for (int j = 0; j < n - 1; ++j)
+                if (((alive_mask >> j) & 1u) && orig[j * PF_BS] == sp) {
+                    out_dist[r * (n - 1) + j] = x;
+                    alive_mask &= ~(1u << j);
+                    --alive;
+                    break;
+                }
+        }
+        next = sample_next_base(ln, x);
+    }
+    if (ml.err) *out_err = ml.err;
+}
+
 // ------------------------------------------------------------------ unit-test kernels
 __global__ void k_test_math(const double* x, long long n, double* oe, double* ol, double* of) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1682,7 +2093,7 @@ struct pf_handle {
     std::vector<double> h_seg_start, h_seg_len;
     long long n_segs = 0;
     long long seg_done = 0;
-    int E = 0, n = 0;
+    int E = 0, n = 0, P = 1;
     long long Np = 0;
     int nblocks = 0;
     size_t smem = 0;
@@ -1724,12 +2135,71 @@ static long long env_ll(const char* name, long long dflt) {
     return v ? atoll(v) : dflt;
 }
 
+// per-epoch, per-population tables of a structured model (scrm Model::population_size / migration_rate /
+// single_mig_pop), prepared exactly as the oracle's fill_model does
+struct MpTables {
+    std::vector<double> inv2Np, mrate, mtot;
+    std::vector<int> jmap, spop;
+};
+static int build_mp_tables(const pf_model* m, MpTables& t) {
+    const int E = m->n_epochs, P = m->n_pops, n = m->nsam;
+    t.inv2Np.resize((size_t)E * P);
+    for (int i = 0; i < E * P; ++i) t.inv2Np[i] = 1.0 / (2.0 * m->pop_sizes[i]);
+    t.mrate.assign((size_t)E * P * P, 0.0);
+    if (m->mig_rates) t.mrate.assign(m->mig_rates, m->mig_rates + (size_t)E * P * P);
+    t.mtot.assign((size_t)E * P, 0.0);
+    for (int e = 0; e < E; ++e)
+        for (int a = 0; a < P; ++a) {
+            double sum = 0.0;
+            for (int b = 0; b < P; ++b) if (b != a) sum += t.mrate[((size_t)e * P + a) * P + b];
+            t.mtot[(size_t)e * P + a] = sum;
+        }
+    t.jmap.resize((size_t)E * P);
+    for (int e = 0; e < E; ++e)
+        for (int a = 0; a < P; ++a) {
+            int cur = a;
+            for (int step = 0; step <= P && m->single_mig; ++step) {
+                int nxt = cur;
+                for (int b = 0; b < P; ++b) {
+                    double pr = m->single_mig[((size_t)e * P + cur) * P + b];
+                    if (pr != 0.0 && pr != 1.0) { g_err = "partial single migration events (-es/-eps style) are not supported"; return -1; }
+                    if (pr == 1.0 && b != cur) { nxt = b; break; }
+                }
+                if (nxt == cur) break;
+                if (step == P) { g_err = "Cycle detected when moving individuals between populations"; return -1; }
+                cur = nxt;
+            }
+            t.jmap[(size_t)e * P + a] = cur;
+        }
+    t.spop.assign(n, 0);
+    if (m->sample_pops) t.spop.assign(m->sample_pops, m->sample_pops + n);
+    for (int v : t.spop) if (v < 0 || v >= P) { g_err = "sample population out of range"; return -1; }
+    return 0;
+}
+
+static int upload_mp_tables(const MpTables& t, KArgs& A, std::vector<void*>& allocs) {
+    double *d1, *d2, *d3; int *i1, *i2;
+    HIPCHK(hipMalloc(&d1, t.inv2Np.size() * 8)); allocs.push_back(d1);
+    HIPCHK(hipMalloc(&d2, t.mrate.size() * 8)); allocs.push_back(d2);
+    HIPCHK(hipMalloc(&d3, t.mtot.size() * 8)); allocs.push_back(d3);
+    HIPCHK(hipMalloc(&i1, t.jmap.size() * 4)); allocs.push_back(i1);
+    HIPCHK(hipMalloc(&i2, t.spop.size() * 4)); allocs.push_back(i2);
+    HIPCHK(hipMemcpy(d1, t.inv2Np.data(), t.inv2Np.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d2, t.mrate.data(), t.mrate.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d3, t.mtot.data(), t.mtot.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(i1, t.jmap.data(), t.jmap.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(i2, t.spop.data(), t.spop.size() * 4, hipMemcpyHostToDevice));
+    A.inv2Np = d1; A.mig_rate = d2; A.mig_tot = d3; A.join_map = i1; A.sample_pop = i2;
+    return 0;
+}
+
 static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device, long long log_cap, long long gen_cap) {
     auto fail = [&](const std::string& msg) -> pf_handle* { g_err = msg; return nullptr; };
     int ndev = pf_device_count();
     if (ndev <= 0) return fail("pf_create: no HIP device available (there is no CPU fallback)");
     if (device < 0 || device >= ndev) return fail("pf_create: device index out of range");
-    if (m->n_pops != 1) return fail("pf_create: n_pops != 1 is not supported in this round");
+    if (m->n_pops < 1 || m->n_pops > PF_PMAX) return fail("pf_create: n_pops must be in 1..4");
+    if (m->n_pops > 1 && m->n_bias_heights > 0) return fail("pf_create: focused sampling is implemented for one population");
     if (m->nsam < 2 || m->nsam > PF_NMAX) return fail("pf_create: nsam must be in 2..16");
     if (m->n_epochs < 1 || m->n_epochs > PF_EMAX) return fail("pf_create: n_epochs must be in 1..64");
     if (p->np < 1 || p->np > 262144) return fail("pf_create: np must be in 1..262144");
@@ -1746,9 +2216,10 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     for (auto& e : h->sync_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) { delete h; return fail("hipEventCreate failed"); }
     const int E = m->n_epochs, n = m->nsam;
     const long long Np = p->np;
-    h->E = E; h->n = n; h->Np = Np;
+    const int P = m->n_pops;
+    h->E = E; h->n = n; h->Np = Np; h->P = P;
     h->nblocks = (int)((Np + PF_BS - 1) / PF_BS);
-    h->smem = smem_bytes(n, E);
+    h->smem = P > 1 ? smem_bytes_mp(n, E, P) : smem_bytes(n, E);
     h->max_trace_events = std::max(0, p->max_trace_events);
     h->force_lds = env_ll("SMCSMC_PF_FORCE_LDS", 0) != 0;
     h->h_lags.assign(m->lags, m->lags + E);
@@ -1766,7 +2237,16 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     rc |= dalloc(h, &dT, E); rc |= dalloc(h, &dI, E); rc |= dalloc(h, &dlag, E); rc |= dalloc(h, &dRF, E);
     if (rc) { pf_destroy(h); return nullptr; }
     std::vector<double> inv2N(E);
-    for (int e = 0; e < E; ++e) inv2N[e] = 1.0 / (2.0 * m->pop_sizes[e]);
+    for (int e = 0; e < E; ++e) inv2N[e] = 1.0 / (2.0 * m->pop_sizes[(size_t)e * P]);
+    A.P = P;
+    {
+        const int PT = P <= 2 ? P : PF_PMAX;     // k_count is instantiated for 1, 2 and PF_PMAX populations
+        A.ncol = PT == 1 ? 6 : 3 * PT + 3 + PT * PT + 2 * PT;
+    }
+    if (P > 1) {
+        MpTables tb;
+        if (build_mp_tables(m, tb) || upload_mp_tables(tb, A, h->allocs)) { pf_destroy(h); return nullptr; }
+    }
     hipMemcpyAsync(dT, m->change_times, E * 8, hipMemcpyHostToDevice, h->stream);
     hipMemcpyAsync(dI, inv2N.data(), E * 8, hipMemcpyHostToDevice, h->stream);
     hipMemcpyAsync(dlag, m->lags, E * 8, hipMemcpyHostToDevice, h->stream);
@@ -1795,6 +2275,13 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
         rc |= dalloc(h, &A.st[b].x_mark, Np);
         rc |= dalloc(h, &A.st[b].Ltree, Np);
         rc |= dalloc(h, &A.st[b].mark_limit, Np);
+        if (P > 1) {
+            rc |= dalloc(h, &A.st[b].Pn, (size_t)(n - 1) * Np);
+            rc |= dalloc(h, &A.st[b].nm, Np);
+            rc |= dalloc(h, &A.st[b].Mt, (size_t)PF_MMAX * Np);
+            rc |= dalloc(h, &A.st[b].Mb, (size_t)PF_MMAX * Np);
+            rc |= dalloc(h, &A.st[b].Mq, (size_t)PF_MMAX * Np);
+        }
         if (m->n_bias_heights > 0) {
             rc |= dalloc(h, &A.st[b].total_delayed, Np);
             rc |= dalloc(h, &A.st[b].dcount, Np);
@@ -1811,6 +2298,12 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     A.RS = 5 + (n - 1);
     A.Gcap = (int)gen_cap;
     rc |= dalloc(h, &A.log, (size_t)Np * A.cap * A.RS);
+    if (P > 1) {
+        // a genealogy update leaves one piece per (epoch, population) stretch of its path: a handful per record
+        A.pcap = (unsigned)env_ll("SMCSMC_PF_PIECE_CAP", 4 * log_cap);
+        rc |= dalloc(h, &A.plog, (size_t)Np * A.pcap * 3);
+        rc |= dalloc(h, &A.pidx, Np);
+    }
     rc |= dalloc(h, &A.gstart, (size_t)A.Gcap * Np);
     rc |= dalloc(h, &A.lo, (size_t)A.Gcap * (Np + 1));
     rc |= dalloc(h, &A.gen_x0, A.Gcap);
@@ -1831,8 +2324,8 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
         rc |= dalloc(h, &A.snap_xm[b], Np); rc |= dalloc(h, &A.snap_ml[b], Np); rc |= dalloc(h, &A.snap_widx[b], Np);
     }
     A.nbx = h->nblocks;
-    rc |= dalloc(h, &A.totals, (size_t)6 * E);
-    rc |= dalloc(h, &A.partial, (size_t)E * A.nbx * 6);
+    rc |= dalloc(h, &A.totals, (size_t)A.ncol * E);
+    rc |= dalloc(h, &A.partial, (size_t)E * A.nbx * A.ncol);
     A.max_trace_events = h->max_trace_events;
     rc |= dalloc(h, &A.ev_seg, (size_t)std::max(1, h->max_trace_events));
     rc |= dalloc(h, &A.ev_parents, (size_t)std::max(1, h->max_trace_events) * Np);
@@ -1841,7 +2334,10 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     if (h->smem > 64 * 1024) {
         hipFuncSetAttribute((const void*)k_extend, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem);
         hipFuncSetAttribute((const void*)k_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem);
+        hipFuncSetAttribute((const void*)k_extend_mp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem);
+        hipFuncSetAttribute((const void*)k_init_mp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem);
     }
+    if (h->smem > 160 * 1024) { pf_destroy(h); return fail("pf_create: the local-tree state does not fit the LDS of one workgroup"); }
     return h;
 }
 
@@ -1922,6 +2418,9 @@ int pf_sync(pf_handle* h) {
         if (c.err == ERR_LOG_OVERFLOW) msg = "event log ring overflow (raise SMCSMC_PF_LOG_CAP)";
         if (c.err == ERR_GEN_OVERFLOW) msg = "generation ledger overflow (raise SMCSMC_PF_GEN_CAP)";
         if (c.err == ERR_ZERO_PROB) msg = "Zero or negative probabilities";   /* pc.cpp:428-429 */
+        if (c.err == ERR_MIG_OVERFLOW) msg = "too many migration events on one local tree";
+        if (c.err == ERR_MP_INTERNAL) msg = "structured-model genealogy update: coalescence partners inconsistent";
+        if (c.err == ERR_NO_COALESCENCE) msg = "No final coalescence event was sampled!";   /* particle.cpp:1383 */
         g_err = msg;
         return -2;
     }
@@ -1930,7 +2429,10 @@ int pf_sync(pf_handle* h) {
 
 int pf_init_prior(pf_handle* h, double initial_position) {
     HIPCHK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_init, dim3(h->nblocks), dim3(PF_BS), h->smem, h->stream, h->A, initial_position);
+    if (h->P > 1)
+        hipLaunchKernelGGL(k_init_mp, dim3(h->nblocks), dim3(PF_BS), h->smem, h->stream, h->A, initial_position);
+    else
+        hipLaunchKernelGGL(k_init, dim3(h->nblocks), dim3(PF_BS), h->smem, h->stream, h->A, initial_position);
     if (check_launch("k_init")) return -1;
     std::fill(h->h_counted_to.begin(), h->h_counted_to.end(), 0.0);
     h->fin_pending = false;
@@ -2001,7 +2503,9 @@ static int launch_extend(pf_handle* h, long long s) {
         Timed tm(h, 0, t);
         const size_t smem_reg = (size_t)(2 * h->E + 2 * PF_BIAS_MAX + 3) * 8;
         const bool biased = h->A.n_bias > 0;
-        if (h->n <= 4 && biased)
+        if (h->P > 1)
+            hipLaunchKernelGGL(k_extend_mp, dim3(h->nblocks), dim3(PF_BS), h->smem, h->stream, h->A, s);
+        else if (h->n <= 4 && biased)
             hipLaunchKernelGGL((k_extend_reg<4, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s);
         else if (h->n <= 8 && biased)
             hipLaunchKernelGGL((k_extend_reg<8, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s);
@@ -2037,12 +2541,22 @@ static int launch_count(pf_handle* h, long long s, const Windows& W) {
     if (h->ev_dec) hipStreamWaitEvent(h->cstream, h->ev_dec, 0);
     {
         Timed tm(h, 2, t, h->cstream);
-        if (h->n <= 4)
-            hipLaunchKernelGGL(k_count<4>, dim3(h->nblocks, h->E - first), dim3(PF_BS), 0, h->cstream, h->A, first, W);
-        else if (h->n <= 8)
-            hipLaunchKernelGGL(k_count<8>, dim3(h->nblocks, h->E - first), dim3(PF_BS), 0, h->cstream, h->A, first, W);
-        else
-            hipLaunchKernelGGL(k_count<PF_NMAX>, dim3(h->nblocks, h->E - first), dim3(PF_BS), 0, h->cstream, h->A, first, W);
+        const dim3 grid(h->nblocks, h->E - first), blk(PF_BS);
+#define PF_LAUNCH_COUNT(NMV, PV) hipLaunchKernelGGL((k_count<NMV, PV>), grid, blk, 0, h->cstream, h->A, first, W)
+        const int P = h->P;
+        if (P == 1) {
+            if (h->n <= 4) PF_LAUNCH_COUNT(4, 1);
+            else if (h->n <= 8) PF_LAUNCH_COUNT(8, 1);
+            else PF_LAUNCH_COUNT(PF_NMAX, 1);
+        } else if (P == 2) {
+            if (h->n <= 4) PF_LAUNCH_COUNT(4, 2);
+            else if (h->n <= 8) PF_LAUNCH_COUNT(8, 2);
+            else PF_LAUNCH_COUNT(PF_NMAX, 2);
+        } else {
+            if (h->n <= 8) PF_LAUNCH_COUNT(8, PF_PMAX);
+            else PF_LAUNCH_COUNT(PF_NMAX, PF_PMAX);
+        }
+#undef PF_LAUNCH_COUNT
         h->fin_pending = true;
     }
     return check_launch("k_count");
@@ -2148,15 +2662,74 @@ double pf_logl(pf_handle* h) {
 
 int pf_get_counts(pf_handle* h, double* out, int32_t n) {
     if (pf_sync(h)) return -1;
-    const int E = h->E;
-    if (n < PF_COUNTS_LEN(E)) { g_err = "count buffer too small"; return -1; }
-    HIPCHK(hipMemcpy(out, h->A.totals, (size_t)6 * E * 8, hipMemcpyDeviceToHost));
+    const int E = h->E, P = h->P;
+    if (n < PF_COUNTS_LEN2(E, P)) { g_err = "count buffer too small"; return -1; }
     Ctrl c;
     HIPCHK(hipMemcpy(&c, h->A.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
-    out[6 * E + 0] = c.delayed_opp;
-    out[6 * E + 1] = c.delayed_count;
-    out[6 * E + 2] = (double)c.n_resample;
-    out[6 * E + 3] = c.logl;
+    double* tail;
+    if (P == 1) {
+        HIPCHK(hipMemcpy(out, h->A.totals, (size_t)6 * E * 8, hipMemcpyDeviceToHost));
+        tail = out + 6 * E;
+    } else {
+        // device layout: totals[column][epoch]; columns as AccT<P>.  A kernel compiled for PF_PMAX populations
+        // (P == 3) still uses the column numbering of its template parameter.
+        const int PT = P == 2 ? 2 : PF_PMAX;
+        const int ncol = h->A.ncol;
+        std::vector<double> tot((size_t)ncol * E);
+        HIPCHK(hipMemcpy(tot.data(), h->A.totals, tot.size() * 8, hipMemcpyDeviceToHost));
+        auto col = [&](int k, int e) { return tot[(size_t)k * E + e]; };
+        double* o = out;
+        for (int stat = 0; stat < 3; ++stat) {                 // coal count, opp, weight [E][P]
+            for (int e = 0; e < E; ++e) for (int a = 0; a < P; ++a) o[e * P + a] = col(stat * PT + a, e);
+            o += E * P;
+        }
+        for (int stat = 0; stat < 3; ++stat) {                 // recomb count, opp, weight [E]
+            for (int e = 0; e < E; ++e) o[e] = col(3 * PT + stat, e);
+            o += E;
+        }
+        for (int e = 0; e < E; ++e) for (int a = 0; a < P; ++a) for (int b = 0; b < P; ++b)
+            o[(e * P + a) * P + b] = col(3 * PT + 3 + a * PT + b, e);
+        o += E * P * P;
+        for (int e = 0; e < E; ++e) for (int a = 0; a < P; ++a) o[e * P + a] = col(3 * PT + 3 + PT * PT + a, e);
+        o += E * P;
+        for (int e = 0; e < E; ++e) for (int a = 0; a < P; ++a) o[e * P + a] = col(3 * PT + 3 + PT * PT + PT + a, e);
+        o += E * P;
+        tail = o;
+    }
+    tail[0] = c.delayed_opp;
+    tail[1] = c.delayed_count;
+    tail[2] = (double)c.n_resample;
+    tail[3] = c.logl;
+    return 0;
+}
+
+int pf_get_migrations(pf_handle* h, int32_t* n_events, double* times, int8_t* branch, int8_t* newpop, int8_t* node_pops,
+                      int32_t cap) {
+    if (pf_sync(h)) return -1;
+    if (h->P < 2) { g_err = "pf_get_migrations: the model has one population"; return -1; }
+    Ctrl c;
+    HIPCHK(hipMemcpy(&c, h->A.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
+    const DState& st = h->A.st[c.cur];
+    const long long Np = h->Np;
+    const int n = h->n;
+    std::vector<int> nm(Np);
+    HIPCHK(hipMemcpy(nm.data(), st.nm, Np * 4, hipMemcpyDeviceToHost));
+    std::vector<double> mt((size_t)PF_MMAX * Np);
+    std::vector<int8_t> mb((size_t)PF_MMAX * Np), mq((size_t)PF_MMAX * Np), pn((size_t)(n - 1) * Np);
+    HIPCHK(hipMemcpy(mt.data(), st.Mt, mt.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(mb.data(), st.Mb, mb.size(), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(mq.data(), st.Mq, mq.size(), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(pn.data(), st.Pn, pn.size(), hipMemcpyDeviceToHost));
+    for (long long p = 0; p < Np; ++p) {
+        if (n_events) n_events[p] = nm[p];
+        for (int k = 0; k < cap; ++k) {
+            bool ok = k < nm[p] && k < PF_MMAX;
+            if (times) times[p * cap + k] = ok ? mt[(size_t)k * Np + p] : 0.0;
+            if (branch) branch[p * cap + k] = ok ? mb[(size_t)k * Np + p] : 0;
+            if (newpop) newpop[p * cap + k] = ok ? mq[(size_t)k * Np + p] : 0;
+        }
+        if (node_pops) for (int r = 0; r < n - 1; ++r) node_pops[p * (n - 1) + r] = pn[(size_t)r * Np + p];
+    }
     return 0;
 }
 
@@ -2347,43 +2920,66 @@ int pf_test_systematic(const double* pilot, int64_t n, double u, int32_t* lo, in
 int pf_median_survival(const pf_model* m, uint64_t seed, int32_t min_events, int64_t max_trees, double* median_out,
                        int64_t* trees_used, int device) {
     if (test_setup(device)) return -1;
-    if (m->n_pops != 1 || m->nsam < 2 || m->nsam > PF_NMAX || m->n_epochs < 1 || m->n_epochs > PF_EMAX) {
+    if (m->n_pops < 1 || m->n_pops > PF_PMAX || m->nsam < 2 || m->nsam > PF_NMAX || m->n_epochs < 1 || m->n_epochs > PF_EMAX) {
         g_err = "pf_median_survival: unsupported model";
         return -1;
     }
-    const int E = m->n_epochs, n = m->nsam;
+    const int E = m->n_epochs, n = m->nsam, P = m->n_pops;
     KArgs A;
     memset(&A, 0, sizeof(A));
-    A.E = E; A.n = n; A.L = m->loci_length; A.mu = m->mutation_rate; A.rho = m->recombination_rate;
-    double *dT, *dI; int *dRF, *dep; double* ddist;
-    HIPCHK(hipMalloc(&dT, E * 8)); HIPCHK(hipMalloc(&dI, E * 8)); HIPCHK(hipMalloc(&dRF, E * 4));
+    A.E = E; A.n = n; A.P = P; A.L = m->loci_length; A.mu = m->mutation_rate; A.rho = m->recombination_rate;
+    double *dT, *dI; int *dRF, *dep, *derr; double* ddist;
+    std::vector<void*> mp_allocs;
+    HIPCHK(hipMalloc(&dT, E * 8)); HIPCHK(hipMalloc(&dI, E * 8)); HIPCHK(hipMalloc(&dRF, E * 4)); HIPCHK(hipMalloc(&derr, 4));
+    HIPCHK(hipMemset(derr, 0, 4));
     HIPCHK(hipMalloc(&dep, (size_t)PF_CAL_BATCH * (n - 1) * 4)); HIPCHK(hipMalloc(&ddist, (size_t)PF_CAL_BATCH * (n - 1) * 8));
     std::vector<double> inv2N(E);
-    for (int e = 0; e < E; ++e) inv2N[e] = 1.0 / (2.0 * m->pop_sizes[e]);
+    for (int e = 0; e < E; ++e) inv2N[e] = 1.0 / (2.0 * m->pop_sizes[(size_t)e * P]);
     std::vector<int> rf(E, 3);
     HIPCHK(hipMemcpy(dT, m->change_times, E * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dI, inv2N.data(), E * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dRF, rf.data(), E * 4, hipMemcpyHostToDevice));
     A.T = dT; A.inv2N = dI; A.recflags = dRF;
+    if (P > 1) {
+        MpTables tb;
+        if (build_mp_tables(m, tb) || upload_mp_tables(tb, A, mp_allocs)) return -1;
+    }
     std::vector<std::vector<double>> surv(E);
     std::vector<int> hep((size_t)PF_CAL_BATCH * (n - 1));
     std::vector<double> hdist((size_t)PF_CAL_BATCH * (n - 1));
     long long trees = 0;
-    const size_t smem = smem_bytes(n, E);
+    const size_t smem = P > 1 ? smem_bytes_mp(n, E, P) : smem_bytes(n, E);
+    if (smem > 64 * 1024) {
+        hipFuncSetAttribute((const void*)k_calibrate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)k_calibrate_mp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    }
+    int cal_err = 0;
     for (;;) {
         int not_done = 0;
         for (int e = 0; e < E; ++e) not_done += (int)surv[e].size() < min_events;
         if (not_done == 0 || trees >= max_trees) break;
-        hipLaunchKernelGGL(k_calibrate, dim3(PF_CAL_BATCH / PF_BS), dim3(PF_BS), smem, 0, A, (unsigned long long)seed, trees,
-                           (long long)PF_CAL_BATCH, dep, ddist);
+        if (P > 1)
+            hipLaunchKernelGGL(k_calibrate_mp, dim3(PF_CAL_BATCH / PF_BS), dim3(PF_BS), smem, 0, A, (unsigned long long)seed, trees,
+                               (long long)PF_CAL_BATCH, dep, ddist, derr);
+        else
+            hipLaunchKernelGGL(k_calibrate, dim3(PF_CAL_BATCH / PF_BS), dim3(PF_BS), smem, 0, A, (unsigned long long)seed, trees,
+                               (long long)PF_CAL_BATCH, dep, ddist);
         HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(&cal_err, derr, 4, hipMemcpyDeviceToHost));
+        if (cal_err) break;
         HIPCHK(hipMemcpy(hep.data(), dep, hep.size() * 4, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(hdist.data(), ddist, hdist.size() * 8, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < hep.size(); ++i)
             if (hdist[i] >= 0) surv[hep[i]].push_back(hdist[i]);
         trees += PF_CAL_BATCH;
     }
-    hipFree(dT); hipFree(dI); hipFree(dRF); hipFree(dep); hipFree(ddist);
+    hipFree(dT); hipFree(dI); hipFree(dRF); hipFree(dep); hipFree(ddist); hipFree(derr);
+    for (void* q : mp_allocs) hipFree(q);
+    if (cal_err) {
+        g_err = cal_err == 1 ? "too many migration events on one local tree"
+              : cal_err == 3 ? "No final coalescence event was sampled!" : "structured-model genealogy update failed";
+        return -1;
+    }
     if (trees_used) *trees_used = trees;
     // smcsmc.cpp:235-262
     double earliest = -1;

@@ -1,0 +1,376 @@
+// smcsmc_amd/csrc/pf_mp.h -- structured models (more than one population): migration, population-specific
+// coalescence rates and fixed-time population moves for the per-lane local tree held in LDS.
+//
+// Reference: the scrm fork's Forest::sampleCoalescences is absent; the control flow follows its
+// mirror in /root/reference/src/particle.cpp:1266-1521 (sampleNextGenealogyWithoutImplementing + dontImplement*),
+// the event records particle.cpp:251-300.  Same arithmetic, draw order and enumeration order as the CPU oracle
+// restatement under oracle/ ("structured models"), which the parity tests compare against.
+//
+// Representation: the rank-sorted binary tree of pf_device.h is kept as it is; every coalescent node also
+// stores the population it happened in (Pn), and the migration events of the local tree live in one list
+// sorted by time: event m sits on the branch above node id Mb[m] and moves that lineage to population Mq[m]
+// at time Mt[m].  Likelihood, branch-length and recombination-opportunity code never see the events.
+// While a genealogy update is in flight, the events picked up by the floating lineage, by the root's own
+// lineage and the events of the cut branch's stub carry the temporary branch tags below.
+#pragma once
+#include "pf_device.h"
+
+#define PF_PMAX 4             // populations supported by the HIP path
+#define PF_MMAX 24            // migration events kept per local tree
+#define PF_TAG_PATH 120       // picked up by the floating lineage during this update
+#define PF_TAG_RPATH 121      // picked up by the root's lineage above the root
+#define PF_TAG_STUB 122       // on the cut branch above the cut
+#define PF_TAG_MIN 120
+
+namespace pf {
+
+struct MLane {
+    int8_t* Pn;        // &sPn[tid]   population of coalescent node r at Pn[r*PF_BS]
+    double* Mt;        // &sMt[tid]
+    int8_t* Mb;        // &sMb[tid]
+    int8_t* Mq;        // &sMq[tid]
+    int nm;
+    int P;
+    const double* I2;  // [E*P]   1/(2 N_e,p)                 (LDS)
+    const double* MR;  // [E*P*P] migration rates p -> q      (LDS)
+    const double* MT;  // [E*P]   total emigration rate       (LDS)
+    const int* JM;     // [E*P]   fixed-time moves at the start of epoch e (LDS)
+    const int* SP;     // [n]     sample populations          (LDS)
+    int err;           // 1 list overflow, 2 partner count inconsistent, 3 no final coalescence possible
+};
+
+#define LPn(ml, r) ((ml).Pn[(r) * PF_BS])
+#define LMt(ml, m) ((ml).Mt[(m) * PF_BS])
+#define LMb(ml, m) ((ml).Mb[(m) * PF_BS])
+#define LMq(ml, m) ((ml).Mq[(m) * PF_BS])
+
+// coal/migr opportunity pieces of one genealogy update, written to the slot's piece ring (three words each):
+//   tag = epoch | pop << 8 | kind << 16 | to << 24   (kind bit0: coalescence at the end, bit1: migration to `to`)
+//   coal opportunity = sum over the merged intervals of weight * dt,  migration opportunity = sum of dt
+struct PLog {
+    double* base;            // ring of this slot
+    unsigned cap;
+    unsigned idx;            // pieces ever written by this slot
+    bool on;
+    int fe, fp, re, rp;
+    double fco, fmo, rmo;
+    bool fopen, ropen;
+};
+
+__device__ __forceinline__ void plog_write(PLog& pl, int e, int pop, int kind, int to, double co, double mo) {
+    double* q = pl.base + (size_t)(pl.idx % pl.cap) * 3;
+    long long tag = (long long)(e & 0xff) | ((long long)(pop & 0xff) << 8) | ((long long)(kind & 0xff) << 16) |
+                    ((long long)(to & 0xff) << 24);
+    q[0] = __longlong_as_double(tag);
+    q[1] = co;
+    q[2] = mo;
+    ++pl.idx;
+}
+__device__ __forceinline__ void plog_flush_f(PLog& pl, int kind, int to) {
+    if (pl.fopen) plog_write(pl, pl.fe, pl.fp, kind, to, pl.fco, pl.fmo);
+    pl.fopen = false;
+}
+__device__ __forceinline__ void plog_flush_r(PLog& pl, int kind, int to) {
+    if (pl.ropen) plog_write(pl, pl.re, pl.rp, kind, to, 0.0, pl.rmo);
+    pl.ropen = false;
+}
+
+__device__ __forceinline__ int mp_pop_base(const Lane& ln, const MLane& ml, int id) {
+    return id < ln.n ? ml.SP[id] : (int)LPn(ml, id - ln.n);
+}
+__device__ __forceinline__ int mp_pop_at(const Lane& ln, const MLane& ml, int id, double time) {
+    int pop = mp_pop_base(ln, ml, id);
+    for (int m = 0; m < ml.nm; ++m)
+        if (LMb(ml, m) == id && LMt(ml, m) <= time) pop = LMq(ml, m);
+    return pop;
+}
+__device__ __forceinline__ int mp_lineages_in_pop(const Lane& ln, const MLane& ml, int ni, double time, int pop, int want,
+                                                  int* pr, int* ps) {
+    int R = 0;
+    while (R < ni && LS(ln, R) <= time) ++R;
+    int cnt = 0;
+    for (int r = R; r < ni; ++r)
+        for (int s = 0; s < 2; ++s) {
+            int id = LC(ln, r, s);
+            if ((id < ln.n || id - ln.n < R) && mp_pop_at(ln, ml, id, time) == pop) {
+                if (cnt == want) { *pr = r; *ps = s; }
+                ++cnt;
+            }
+        }
+    return cnt;
+}
+__device__ __forceinline__ void mp_ev_insert(MLane& ml, double time, int branch, int newpop) {
+    if (ml.nm >= PF_MMAX) { ml.err = 1; return; }
+    int m = ml.nm;
+    while (m > 0 && LMt(ml, m - 1) > time) {
+        LMt(ml, m) = LMt(ml, m - 1); LMb(ml, m) = LMb(ml, m - 1); LMq(ml, m) = LMq(ml, m - 1);
+        --m;
+    }
+    LMt(ml, m) = time; LMb(ml, m) = (int8_t)branch; LMq(ml, m) = (int8_t)newpop;
+    ++ml.nm;
+}
+// drop the events on branch `id` later than tmin
+__device__ __forceinline__ void mp_ev_drop_above(MLane& ml, int id, double tmin) {
+    int o = 0;
+    for (int m = 0; m < ml.nm; ++m) {
+        int b = LMb(ml, m);
+        double t = LMt(ml, m);
+        if (b == id && t > tmin) continue;
+        if (o != m) { LMt(ml, o) = t; LMb(ml, o) = (int8_t)b; LMq(ml, o) = LMq(ml, m); }
+        ++o;
+    }
+    ml.nm = o;
+}
+__device__ __forceinline__ void mp_remove_rank(Lane& ln, MLane& ml, int ni, int rp, int sib, int* a, int* b) {
+    const int pid = ln.n + rp;
+    for (int m = 0; m < ml.nm; ++m) {
+        int v = LMb(ml, m);
+        if (v == pid) v = sib;
+        if (v > pid && v < PF_TAG_MIN) v -= 1;
+        LMb(ml, m) = (int8_t)v;
+    }
+    for (int r = rp; r + 1 < ni; ++r) LPn(ml, r) = LPn(ml, r + 1);
+    remove_rank(ln, ni, rp, sib, a, b);
+}
+__device__ __forceinline__ void mp_insert_node(Lane& ln, MLane& ml, int ni, double h, int* fl, int pr, int ps, int root_id,
+                                               int node_pop) {
+    int rn = 0;
+    while (rn < ni && LS(ln, rn) <= h) ++rn;
+    const int nid = ln.n + rn;
+    int target = pr >= 0 ? (int)LC(ln, pr, ps) : root_id;
+    for (int m = 0; m < ml.nm; ++m) {
+        int v = LMb(ml, m);
+        if (v >= nid && v < PF_TAG_MIN) LMb(ml, m) = (int8_t)(v + 1);
+    }
+    if (target >= nid) target += 1;
+    if (pr >= 0) {
+        for (int m = 0; m < ml.nm; ++m)
+            if (LMb(ml, m) == target && LMt(ml, m) > h) LMb(ml, m) = (int8_t)nid;
+    } else {
+        mp_ev_drop_above(ml, target, h);
+    }
+    for (int r = ni; r > rn; --r) LPn(ml, r) = LPn(ml, r - 1);
+    LPn(ml, rn) = (int8_t)node_pop;
+    insert_node(ln, ni, h, *fl, pr, ps, root_id);
+    if (*fl >= nid) *fl += 1;
+}
+
+struct MWalk { double tc; int pf, pr, weight; };
+
+// The floating lineage starts at height h in population pf0 and moves up through the stored tree (ni internal
+// nodes, root_id its top node or the single leaf); above the root the root's own lineage is the second active
+// lineage.  Migration events picked up on the way enter the list under PF_TAG_PATH / PF_TAG_RPATH.
+__device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int root_id, double h, int pf0, PLog* pl,
+                                            int limit, MWalk& W) {
+    const int P = ml.P;
+    const double Hr = node_h(ln, root_id);
+    double tt = h;
+    int e = epoch_of(ln, tt);
+    int i = 0, j = 0;
+    while (i < ni && LS(ln, i) <= tt) ++i;
+    while (j < ml.nm && LMt(ml, j) <= tt) ++j;
+    int pf = pf0, pr = mp_pop_base(ln, ml, root_id);
+    if (pl) { pl->fopen = false; pl->ropen = false; }
+    for (int guard = 0; guard < 100000; ++guard) {
+        const bool root_active = tt >= Hr;
+        double tn_node = i < ni ? LS(ln, i) : PF_INF;
+        double tn_mig = j < ml.nm ? LMt(ml, j) : PF_INF;
+        double tn_ep = epoch_end(ln, e);
+        double tn = tn_node < tn_mig ? tn_node : tn_mig;
+        tn = tn < tn_ep ? tn : tn_ep;
+        int dr = 0, dsl = 0;
+        int k = mp_lineages_in_pop(ln, ml, ni, tt, pf, -1, &dr, &dsl);
+        int weight = k + ((root_active && pr == pf) ? 1 : 0);
+        double rc = (double)weight * ml.I2[e * P + pf];
+        double rmf = ml.MT[e * P + pf];
+        double rmr = root_active ? ml.MT[e * P + pr] : 0.0;
+        double lam = (rc + rmf) + rmr;
+        if (lam == 0.0 && !(tn < PF_INF)) { ml.err = 3; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
+        double need = (tn - tt) * lam;
+        bool fire = !(ln.ebuf > need);
+        double t1 = fire ? tt + ln.ebuf / lam : tn;
+        int kind = 0, to = 0;
+        if (fire) {
+            double v = uni(ln) * lam;
+            if (v < rc || (rmf == 0.0 && rmr == 0.0)) kind = 1;
+            else {
+                v -= rc;
+                int from;
+                if (v < rmf || rmr == 0.0) { kind = 2; from = pf; }
+                else { kind = 3; from = pr; v -= rmf; }
+                to = -1;
+                for (int q = 0; q < P; ++q) {
+                    double mr = ml.MR[(e * P + from) * P + q];
+                    if (q == from || mr == 0.0) continue;
+                    to = q;
+                    if (v < mr) break;
+                    v -= mr;
+                }
+            }
+        }
+        if (pl && pl->on && (ln.RF[e] & 2) && e <= limit) {
+            double dt = t1 - tt;
+            if (pl->fopen && (pl->fe != e || pl->fp != pf)) plog_flush_f(*pl, 0, 0);
+            if (!pl->fopen) { pl->fopen = true; pl->fe = e; pl->fp = pf; pl->fco = 0.0; pl->fmo = 0.0; }
+            pl->fco += (double)weight * dt;
+            pl->fmo += dt;
+            if (kind == 1) plog_flush_f(*pl, 1, 0);
+            if (kind == 2) plog_flush_f(*pl, 2, to);
+            if (root_active) {
+                if (pl->ropen && (pl->re != e || pl->rp != pr)) plog_flush_r(*pl, 0, 0);
+                if (!pl->ropen) { pl->ropen = true; pl->re = e; pl->rp = pr; pl->rmo = 0.0; }
+                pl->rmo += dt;
+                if (kind == 3) plog_flush_r(*pl, 2, to);
+            }
+        }
+        if (fire) {
+            ln.ebuf = -dlog(uni(ln));
+            if (kind == 1) {
+                if (pl) { plog_flush_f(*pl, 0, 0); plog_flush_r(*pl, 0, 0); }
+                W.tc = t1; W.pf = pf; W.pr = pr; W.weight = weight;
+                return;
+            }
+            if (kind == 2) { mp_ev_insert(ml, t1, PF_TAG_PATH, to); pf = to; }
+            else { mp_ev_insert(ml, t1, PF_TAG_RPATH, to); pr = to; }
+            if (ml.err) { W.tc = t1; W.pf = pf; W.pr = pr; W.weight = 0; return; }
+            tt = t1;
+            while (j < ml.nm && LMt(ml, j) <= tt) ++j;
+            continue;
+        }
+        ln.ebuf -= need;
+        tt = tn;
+        while (i < ni && LS(ln, i) <= tt) ++i;
+        while (j < ml.nm && LMt(ml, j) <= tt) ++j;
+        if (tn_ep <= tn) {
+            ++e;
+            int q = ml.JM[e * P + pf];
+            if (q != pf) { mp_ev_insert(ml, tt, PF_TAG_PATH, q); pf = q; }
+            if (tt >= Hr) {
+                int qr = ml.JM[e * P + pr];
+                if (qr != pr) { mp_ev_insert(ml, tt, PF_TAG_RPATH, qr); pr = qr; }
+            }
+            if (ml.err) { W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
+            while (j < ml.nm && LMt(ml, j) <= tt) ++j;
+        }
+    }
+    ml.err = 3;
+    W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0;
+}
+
+__device__ __forceinline__ void mp_retag(MLane& ml, int from, int to) {
+    for (int m = 0; m < ml.nm; ++m)
+        if (LMb(ml, m) == from) LMb(ml, m) = (int8_t)to;
+}
+
+// Forest::buildInitialTree(true) for a structured model.  `emit(i, pstart, npieces, tc)` logs the record of leaf i.
+template <class Emit>
+__device__ __forceinline__ void mp_build_initial_tree(Lane& ln, MLane& ml, PLog* pl, Emit emit) {
+    const int n = ln.n;
+    ml.nm = 0;
+    int root = 0;
+    for (int i = 1; i < n; ++i) {
+        int ni = i - 1;
+        MWalk W;
+        unsigned p0 = pl ? pl->idx : 0u;
+        mp_coalesce(ln, ml, ni, root, 0.0, ml.SP[i], pl, ln.E - 1, W);
+        if (ml.err) return;
+        emit(i, p0, pl ? pl->idx - p0 : 0u, W.tc);
+        double tc = W.tc;
+        mp_retag(ml, PF_TAG_RPATH, root);
+        int pr = -1, ps = 0;
+        int nslots = mp_lineages_in_pop(ln, ml, ni, tc, W.pf, -1, &pr, &ps);
+        bool has_root = tc >= node_h(ln, root) && mp_pop_at(ln, ml, root, tc) == W.pf;
+        int k = nslots + (has_root ? 1 : 0);
+        if (k != W.weight || k < 1) { ml.err = 2; return; }
+        double u = uni(ln);
+        int idx = min((int)(u * (double)k), k - 1);
+        int fl = i;
+        if (idx < nslots) {
+            mp_lineages_in_pop(ln, ml, ni, tc, W.pf, idx, &pr, &ps);
+            mp_insert_node(ln, ml, ni, tc, &fl, pr, ps, root, W.pf);
+        } else {
+            mp_insert_node(ln, ml, ni, tc, &fl, -1, 0, root, W.pf);
+        }
+        mp_retag(ml, PF_TAG_PATH, fl);
+        root = n + ni;
+    }
+    ln.Ltree = tree_length(ln, n);
+}
+
+// the part of a genealogy update after the recombination point (slot (rp,sb), height h) has been sampled
+__device__ __forceinline__ void mp_genealogy_rest(Lane& ln, MLane& ml, PLog* pl, int limit, int rp, int sb, double h,
+                                                  double* tc_out, double* sp_out, bool* changed_out) {
+    const int n = ln.n;
+    int b_id = LC(ln, rp, sb), s_id = LC(ln, rp, 1 - sb);
+    const int pf0 = mp_pop_at(ln, ml, b_id, h);
+    MWalk W;
+    mp_coalesce(ln, ml, n - 1, n + n - 2, h, pf0, pl, limit, W);
+    const double tc = W.tc;
+    *tc_out = tc;
+    const double Sp = LS(ln, rp);
+    *sp_out = Sp;
+    *changed_out = true;
+    if (ml.err) return;
+    const int p_pop = LPn(ml, rp);
+    const bool p_was_root = (rp == n - 2);
+    // the stub: what remains of the cut branch above the cut
+    for (int m = 0; m < ml.nm; ++m)
+        if (LMb(ml, m) == b_id && LMt(ml, m) > h) LMb(ml, m) = (int8_t)PF_TAG_STUB;
+    mp_remove_rank(ln, ml, n - 1, rp, s_id, &b_id, &s_id);
+    int ni = n - 2;
+    int troot = p_was_root ? s_id : n + (ni - 1);
+    mp_retag(ml, PF_TAG_RPATH, troot);
+    int pr = -1, ps = 0;
+    int nslots = mp_lineages_in_pop(ln, ml, ni, tc, W.pf, -1, &pr, &ps);
+    bool has_root = tc >= node_h(ln, troot) && mp_pop_at(ln, ml, troot, tc) == W.pf;
+    int stub_pop = pf0;
+    for (int m = 0; m < ml.nm; ++m)
+        if (LMb(ml, m) == PF_TAG_STUB && LMt(ml, m) <= tc) stub_pop = LMq(ml, m);
+    bool has_stub = tc < Sp && stub_pop == W.pf;
+    int k = nslots + (has_root ? 1 : 0) + (has_stub ? 1 : 0);
+    if (k != W.weight || k < 1) { ml.err = 2; return; }
+    double u = uni(ln);
+    int idx = min((int)(u * (double)k), k - 1);
+    *changed_out = !(has_stub && idx == k - 1);
+    if (idx < nslots) {
+        mp_lineages_in_pop(ln, ml, ni, tc, W.pf, idx, &pr, &ps);
+        mp_insert_node(ln, ml, ni, tc, &b_id, pr, ps, troot, W.pf);
+        mp_ev_drop_above(ml, PF_TAG_STUB, -1.0);
+    } else if (has_root && idx == nslots) {
+        mp_insert_node(ln, ml, ni, tc, &b_id, -1, 0, troot, W.pf);
+        mp_ev_drop_above(ml, PF_TAG_STUB, -1.0);
+    } else {
+        // back into its own stub: the tree keeps its shape; the cut branch swaps the events between the cut
+        // and tc for the ones picked up on the way
+        if (p_was_root) {
+            mp_insert_node(ln, ml, ni, Sp, &b_id, -1, 0, troot, p_pop);
+        } else {
+            int fr = -1, fs = 0, R = 0;
+            while (R < ni && LS(ln, R) <= Sp) ++R;
+            for (int rr = R; rr < ni && fr < 0; ++rr)
+                for (int s = 0; s < 2 && fr < 0; ++s) {
+                    int id = LC(ln, rr, s);
+                    if ((id < n || id - n < R) && id == s_id) { fr = rr; fs = s; }
+                }
+            mp_insert_node(ln, ml, ni, Sp, &b_id, fr, fs, troot, p_pop);
+        }
+        // stub events at or before tc vanish, later ones return to the branch
+        int o = 0;
+        for (int m = 0; m < ml.nm; ++m) {
+            int bb = LMb(ml, m);
+            double t = LMt(ml, m);
+            if (bb == PF_TAG_STUB) {
+                if (!(t > tc)) continue;
+                bb = b_id;
+            }
+            LMt(ml, o) = t; LMb(ml, o) = (int8_t)bb; LMq(ml, o) = LMq(ml, m);
+            ++o;
+        }
+        ml.nm = o;
+    }
+    mp_retag(ml, PF_TAG_PATH, b_id);
+    mp_ev_drop_above(ml, n + n - 2, -1.0);      // nothing is kept above the root of the local tree
+    ln.Ltree = tree_length(ln, n);
+}
+
+}  // namespace pf

@@ -56,7 +56,7 @@ EXPORTS = [
     "pf_last_error", "pf_device_count", "pf_create", "pf_destroy", "pf_init_prior", "pf_load_segments",
     "pf_update_segment", "pf_count", "pf_resample", "pf_run", "pf_finish", "pf_sync",
     "pf_num_segments_done", "pf_logl", "pf_get_counts", "pf_get_trace", "pf_get_resample_events",
-    "pf_get_particles", "pf_get_kernel_time", "pf_set_timing", "pf_get_stats",
+    "pf_get_particles", "pf_get_migrations", "pf_get_kernel_time", "pf_set_timing", "pf_get_stats",
     "pf_median_survival", "pf_test_math", "pf_test_div", "pf_test_uniform", "pf_test_reduce", "pf_test_systematic",
 ]
 
@@ -93,6 +93,7 @@ def load_library(path=None):
     L.pf_get_trace.argtypes = [vp, vp, vp, vp, vp, C.c_int64]
     L.pf_get_resample_events.argtypes = [vp, vp, vp, C.c_int32]
     L.pf_get_particles.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.pf_get_migrations.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int32]
     L.pf_get_kernel_time.argtypes = [vp, C.c_int, vp, vp]
     L.pf_set_timing.argtypes = [vp, C.c_int]
     L.pf_get_stats.argtypes = [vp, vp, vp, vp]
@@ -134,6 +135,49 @@ def _attach_bias(owner, cmodel, m):
     cmodel.application_delays = _dp(owner._ad)
 
 
+def _attach_structure(owner, cmodel, m, E, P):
+    """Structured models (scrm -I / -eM / -ema / -ej): migration matrix [E][P][P] (backward rate p -> q per
+    generation), fixed-time moves [E][P][P] applied at the start of an epoch, and the samples' populations."""
+    if m.get("mig_rates") is not None:
+        owner._mig = np.ascontiguousarray(m["mig_rates"], dtype=np.float64).reshape(E * P * P)
+        cmodel.mig_rates = _dp(owner._mig)
+    if m.get("single_mig") is not None:
+        owner._smig = np.ascontiguousarray(m["single_mig"], dtype=np.float64).reshape(E * P * P)
+        cmodel.single_mig = _dp(owner._smig)
+    if m.get("sample_pops") is not None:
+        owner._spop = np.ascontiguousarray(m["sample_pops"], dtype=np.int32)
+        if len(owner._spop) != cmodel.nsam:
+            raise PfError("sample_pops needs one entry per sample")
+        cmodel.sample_pops = owner._spop.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def counts_len(E, P=1):
+    """PF_COUNTS_LEN2 of include/smcsmc_pf.h"""
+    return 6 * E + 4 if P == 1 else 3 * E * P + 3 * E + E * P * P + 2 * E * P + 4
+
+
+def unpack_counts(out, E, P=1):
+    """Packed count buffer -> dict of the CountModel members (count.hpp:95-110)."""
+    if P == 1:
+        return {
+            "coal_count": out[0:E].copy(), "coal_opp": out[E:2 * E].copy(), "coal_weight": out[2 * E:3 * E].copy(),
+            "rec_count": out[3 * E:4 * E].copy(), "rec_opp": out[4 * E:5 * E].copy(),
+            "rec_weight": out[5 * E:6 * E].copy(), "delayed_opp": out[6 * E], "delayed_count": out[6 * E + 1],
+            "resample_count": out[6 * E + 2], "logl": out[6 * E + 3],
+        }
+    o = 0
+    d = {}
+    for k in ("coal_count", "coal_opp", "coal_weight"):
+        d[k] = out[o:o + E * P].reshape(E, P).copy(); o += E * P
+    for k in ("rec_count", "rec_opp", "rec_weight"):
+        d[k] = out[o:o + E].copy(); o += E
+    d["mig_count"] = out[o:o + E * P * P].reshape(E, P, P).copy(); o += E * P * P
+    for k in ("mig_opp", "mig_weight"):
+        d[k] = out[o:o + E * P].reshape(E, P).copy(); o += E * P
+    d["delayed_opp"], d["delayed_count"], d["resample_count"], d["logl"] = (float(v) for v in out[o:o + 4])
+    return d
+
+
 KERNEL_CLASSES = ("extend", "decide", "count", "resample")
 
 
@@ -154,6 +198,7 @@ class ParticleFilter:
                              float(m["recombination_rate"]), _dp(self._ct), _dp(self._ps), None, None, None,
                              self._rf.ctypes.data_as(C.POINTER(C.c_int32)), _dp(self._lags))
         _attach_bias(self, self._model, m)
+        _attach_structure(self, self._model, m, E, P)
         self._params = _Params(self.Np, float(ess_fraction), int(seed), self.max_trace_events, 0)
         self.h = self.L.pf_create(C.byref(self._model), C.byref(self._params), int(device))
         if not self.h:
@@ -238,15 +283,18 @@ class ParticleFilter:
         return {"w_post": wp, "w_pilot": wq, "heights": H, "children": Ch, "next_base": nb}
 
     def counts(self):
-        E = self.E
-        out = np.zeros(6 * E + 4)
+        out = np.zeros(counts_len(self.E, self.P))
         self._chk(self.L.pf_get_counts(self.h, out.ctypes.data, len(out)))
-        return {
-            "coal_count": out[0:E].copy(), "coal_opp": out[E:2 * E].copy(), "coal_weight": out[2 * E:3 * E].copy(),
-            "rec_count": out[3 * E:4 * E].copy(), "rec_opp": out[4 * E:5 * E].copy(),
-            "rec_weight": out[5 * E:6 * E].copy(), "delayed_opp": out[6 * E], "delayed_count": out[6 * E + 1],
-            "resample_count": out[6 * E + 2], "logl": out[6 * E + 3],
-        }
+        return unpack_counts(out, self.E, self.P)
+
+    def migrations(self, cap=24):
+        """Migration events on every particle's local tree and the population of every coalescent node."""
+        n = self.nsam
+        nm = np.zeros(self.Np, np.int32); t = np.zeros((self.Np, cap)); b = np.zeros((self.Np, cap), np.int8)
+        q = np.zeros((self.Np, cap), np.int8); npop = np.zeros((self.Np, n - 1), np.int8)
+        self._chk(self.L.pf_get_migrations(self.h, nm.ctypes.data, t.ctypes.data, b.ctypes.data, q.ctypes.data,
+                                           npop.ctypes.data, cap))
+        return {"n_events": nm, "times": t, "branch": b, "newpop": q, "node_pops": npop}
 
     def set_timing(self, period):
         self.L.pf_set_timing(self.h, int(period))
@@ -266,16 +314,25 @@ class ParticleFilter:
         return {"records": a.value, "state_bytes_per_particle": b.value, "resamples": c.value}
 
 
+class _PackedModel:
+    """Owns the buffers behind a _Model used outside a ParticleFilter (lag calibration)."""
+
+    def __init__(self, m):
+        self.ct = np.ascontiguousarray(m["change_times"], dtype=np.float64)
+        E = len(self.ct)
+        P = int(m.get("n_pops", 1))
+        self.ps = np.ascontiguousarray(m["pop_sizes"], dtype=np.float64).reshape(E * P)
+        self.rf = np.ascontiguousarray(m.get("record_flags", [3] * E), dtype=np.int32)
+        self.lags = np.ascontiguousarray(m.get("lags", np.zeros(E)), dtype=np.float64)
+        self.model = _Model(E, P, int(m["nsam"]), 0, float(m["loci_length"]), float(m["mutation_rate"]),
+                            float(m["recombination_rate"]), _dp(self.ct), _dp(self.ps), None, None, None,
+                            self.rf.ctypes.data_as(C.POINTER(C.c_int32)), _dp(self.lags))
+        _attach_structure(self, self.model, m, E, P)
+
+
 def _pack_model(m):
-    ct = np.ascontiguousarray(m["change_times"], dtype=np.float64)
-    E = len(ct)
-    ps = np.ascontiguousarray(m["pop_sizes"], dtype=np.float64).reshape(E)
-    rf = np.ascontiguousarray(m.get("record_flags", [3] * E), dtype=np.int32)
-    lags = np.ascontiguousarray(m.get("lags", np.zeros(E)), dtype=np.float64)
-    mod = _Model(E, 1, int(m["nsam"]), 0, float(m["loci_length"]), float(m["mutation_rate"]),
-                 float(m["recombination_rate"]), _dp(ct), _dp(ps), None, None, None,
-                 rf.ctypes.data_as(C.POINTER(C.c_int32)), _dp(lags))
-    return mod, (ct, ps, rf, lags)
+    pm = _PackedModel(m)
+    return pm.model, pm
 
 
 def median_survival(model, seed=1, min_events=200, max_trees=1000000, device=0):

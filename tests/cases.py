@@ -61,3 +61,29 @@ def nodata_segments(model, seglen=1000.0):
     return dict(start=np.arange(S) * seglen, length=np.full(S, seglen), state=np.full(S, 1, np.int8),
                 alleles=np.full((S, n), -1, np.int8),
                 max_record_epoch=np.full(S, -1, np.int32) * 0 + (len(model["lags"]) - 1))
+
+
+def make_structured(model, P=2, split_epoch=None, mig=1.0, N0=1e4, sample_pops=None, sizes=None):
+    """Turns a single-population model into an isolation-with-migration model with P populations:
+    symmetric migration 4*N0*m = `mig` between all pairs until the epoch `split_epoch`, at whose start every
+    population joins population 0 (scrm -ej).  Shape of the reference's test_two_pops.py:54-72."""
+    m = dict(model)
+    E = len(m["change_times"])
+    n = m["nsam"]
+    split_epoch = E - 2 if split_epoch is None else split_epoch
+    base = np.asarray(m["pop_sizes"], float).reshape(E)
+    ps = np.repeat(base[:, None], P, axis=1)
+    if sizes is not None:
+        ps = ps * np.asarray(sizes, float)[None, :]
+    mr = np.zeros((E, P, P)); sm = np.zeros((E, P, P))
+    for e in range(E):
+        if e < split_epoch:
+            for a in range(P):
+                for b in range(P):
+                    if a != b:
+                        mr[e, a, b] = mig / (4.0 * N0)
+    for a in range(1, P):
+        sm[split_epoch, a, 0] = 1.0
+    m.update(n_pops=P, pop_sizes=ps, mig_rates=mr, single_mig=sm,
+             sample_pops=list(sample_pops) if sample_pops is not None else [i * P // n for i in range(n)])
+    return m

@@ -66,6 +66,7 @@ def lib():
         L.smco_get_resample_events.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
         L.smco_get_particles.argtypes = [C.c_void_p] + [C.c_void_p] * 5
         L.smco_get_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.smco_get_migrations.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int32]
         L.smco_logl.restype = C.c_double
         L.smco_logl.argtypes = [C.c_void_p]
         L.smco_get_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -104,6 +105,20 @@ def attach_bias(owner, cmodel, m):
     cmodel.application_delays = _dp(owner._ad)
 
 
+def attach_structure(owner, cmodel, m, E, P):
+    """Per-epoch migration matrix [E][P][P], fixed-time moves [E][P][P] and the samples' populations."""
+    if m.get("mig_rates") is not None:
+        owner._mig = np.ascontiguousarray(m["mig_rates"], dtype=np.float64).reshape(E * P * P)
+        cmodel.mig_rates = _dp(owner._mig)
+    if m.get("single_mig") is not None:
+        owner._smig = np.ascontiguousarray(m["single_mig"], dtype=np.float64).reshape(E * P * P)
+        cmodel.single_mig = _dp(owner._smig)
+    if m.get("sample_pops") is not None:
+        owner._spop = np.ascontiguousarray(m["sample_pops"], dtype=np.int32)
+        assert len(owner._spop) == cmodel.nsam
+        cmodel.sample_pops = owner._spop.ctypes.data_as(C.POINTER(C.c_int32))
+
+
 class PackedInputs:
     """Owns the numpy buffers behind the C structs (same layout for oracle and product)."""
 
@@ -121,6 +136,7 @@ class PackedInputs:
                                float(m["recombination_rate"]), _dp(self.change_times), _dp(self.pop_sizes),
                                None, None, None,
                                self.record_flags.ctypes.data_as(C.POINTER(C.c_int32)), _dp(self.lags))
+        attach_structure(self, self.model, m, E, P)
         attach_bias(self, self.model, m)
         self.segs = None
         if segs is not None:
@@ -203,10 +219,18 @@ class Oracle:
         return {"w_post": wp, "w_pilot": wq, "heights": H, "children": Ch, "next_base": nb}
 
     def counts(self):
-        E = self.inp.E
-        out = np.zeros(6 * E + 4)
+        E, P = self.inp.E, self.inp.P
+        out = np.zeros(counts_len(E, P))
         self._chk(self.L.smco_get_counts(self.h, out.ctypes.data, len(out)))
-        return unpack_counts(out, E)
+        return unpack_counts(out, E, P)
+
+    def migrations(self, cap=24):
+        n = self.inp.nsam
+        nm = np.zeros(self.Np, np.int32); t = np.zeros((self.Np, cap)); b = np.zeros((self.Np, cap), np.int8)
+        q = np.zeros((self.Np, cap), np.int8); npop = np.zeros((self.Np, n - 1), np.int8)
+        self.L.smco_get_migrations(self.h, nm.ctypes.data, t.ctypes.data, b.ctypes.data, q.ctypes.data,
+                                   npop.ctypes.data, cap)
+        return {"n_events": nm, "times": t, "branch": b, "newpop": q, "node_pops": npop}
 
     def logl(self):
         return self.L.smco_logl(self.h)
@@ -217,13 +241,30 @@ class Oracle:
         return {"recombinations": a.value, "events_allocated": b.value, "resamples": c.value}
 
 
-def unpack_counts(out, E):
-    return {
-        "coal_count": out[0:E].copy(), "coal_opp": out[E:2 * E].copy(), "coal_weight": out[2 * E:3 * E].copy(),
-        "rec_count": out[3 * E:4 * E].copy(), "rec_opp": out[4 * E:5 * E].copy(), "rec_weight": out[5 * E:6 * E].copy(),
-        "delayed_opp": out[6 * E], "delayed_count": out[6 * E + 1], "resample_count": out[6 * E + 2],
-        "logl": out[6 * E + 3],
-    }
+def counts_len(E, P=1):
+    return 6 * E + 4 if P == 1 else 3 * E * P + 3 * E + E * P * P + 2 * E * P + 4
+
+
+def unpack_counts(out, E, P=1):
+    """Packed count buffer -> dict (layout: include/smcsmc_pf.h PF_COUNTS_LEN / PF_COUNTS_LEN2)."""
+    if P == 1:
+        return {
+            "coal_count": out[0:E].copy(), "coal_opp": out[E:2 * E].copy(), "coal_weight": out[2 * E:3 * E].copy(),
+            "rec_count": out[3 * E:4 * E].copy(), "rec_opp": out[4 * E:5 * E].copy(), "rec_weight": out[5 * E:6 * E].copy(),
+            "delayed_opp": out[6 * E], "delayed_count": out[6 * E + 1], "resample_count": out[6 * E + 2],
+            "logl": out[6 * E + 3],
+        }
+    o = 0
+    d = {}
+    for k in ("coal_count", "coal_opp", "coal_weight"):
+        d[k] = out[o:o + E * P].reshape(E, P).copy(); o += E * P
+    for k in ("rec_count", "rec_opp", "rec_weight"):
+        d[k] = out[o:o + E].copy(); o += E
+    d["mig_count"] = out[o:o + E * P * P].reshape(E, P, P).copy(); o += E * P * P
+    for k in ("mig_opp", "mig_weight"):
+        d[k] = out[o:o + E * P].reshape(E, P).copy(); o += E * P
+    d["delayed_opp"], d["delayed_count"], d["resample_count"], d["logl"] = out[o:o + 4]
+    return d
 
 
 def median_survival(model, seed=1, min_events=200, max_trees=1000000):
