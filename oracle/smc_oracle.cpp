@@ -45,7 +45,7 @@ namespace smco {
 static thread_local std::string g_err;
 
 enum { NMAX = 16 };
-enum { MMAX = 24 };   /* migration events kept per local tree (multi-population models) */
+enum { MMAX = 96 };   /* migration events kept per local tree (multi-population models) */
 enum { DCAP = 32 };   /* capacity of the per-particle delayed-factor store (the reference's heap is unbounded) */
 enum { REC_RECOMB = 1, REC_COALMIGR = 2 };
 

@@ -31,10 +31,12 @@ def _stale(target, sources):
 
 
 def build_lib(force=False):
-    srcs = [os.path.join(CSRC, "pf_hip.hip"), os.path.join(CSRC, "pf_device.h"), os.path.join(CSRC, "pf_tree_reg.h"),
-            os.path.join(CSRC, "pf_mp.h"), os.path.join(os.path.dirname(HERE), "include", "smcsmc_pf.h")]
-    if force or _stale(LIB, srcs):
-        cmd = [_hipcc()] + HIPCC_FLAGS + ["-shared", "-o", LIB, srcs[0]]
+    units = [os.path.join(CSRC, "pf_hip.hip"), os.path.join(CSRC, "pf_mp.hip")]
+    deps = [os.path.join(CSRC, f) for f in ("pf_device.h", "pf_types.h", "pf_lane.h", "pf_tree_reg.h", "pf_mp.h",
+                                            "pf_mp_host.h")]
+    deps.append(os.path.join(os.path.dirname(HERE), "include", "smcsmc_pf.h"))
+    if force or _stale(LIB, units + deps):
+        cmd = [_hipcc()] + HIPCC_FLAGS + ["-shared", "-o", LIB] + units
         subprocess.check_call(cmd)
     return LIB
 

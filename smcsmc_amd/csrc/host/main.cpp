@@ -56,15 +56,25 @@ static void pf_check(int rc) {
 static void pfARG_core(PfParam& P) {
     HostModel& M = P.model;
     const int E = (int)M.change_times.size();
-    if (M.npop != 1) throw Unsupported("models with more than one population (this round implements the one-population path)");
+    const int NP = M.npop;
+    if (NP > 4) throw Unsupported("models with more than four populations");
     int device = 0;
     if (const char* d = getenv("SMCSMC_DEVICE")) device = atoi(d);
 
-    std::vector<double> pop_sizes(E);
-    for (int e = 0; e < E; ++e) pop_sizes[e] = M.pop_sizes[e][0];
+    std::vector<double> pop_sizes((size_t)E * NP), mig_rates((size_t)E * NP * NP), single_mig((size_t)E * NP * NP);
+    for (int e = 0; e < E; ++e)
+        for (int a = 0; a < NP; ++a) {
+            pop_sizes[(size_t)e * NP + a] = M.pop_sizes[e][a];
+            for (int b = 0; b < NP; ++b) {
+                mig_rates[((size_t)e * NP + a) * NP + b] = M.mig_rates[e][(size_t)a * NP + b];
+                single_mig[((size_t)e * NP + a) * NP + b] = M.single_mig[e][(size_t)a * NP + b];
+            }
+        }
+    std::vector<int32_t> sample_pops(M.sample_pops.begin(), M.sample_pops.end());
     pf_model pm;
     memset(&pm, 0, sizeof(pm));
-    pm.n_epochs = E; pm.n_pops = 1; pm.nsam = M.nsam;
+    pm.n_epochs = E; pm.n_pops = NP; pm.nsam = M.nsam;
+    if (NP > 1) { pm.mig_rates = mig_rates.data(); pm.single_mig = single_mig.data(); pm.sample_pops = sample_pops.data(); }
     pm.flags = (P.ancestral_aware ? 1 : 0) | (P.dephase ? 2 : 0);
     pm.loci_length = M.loci_length; pm.mutation_rate = M.mutation_rate; pm.recombination_rate = M.recombination_rate;
     pm.change_times = M.change_times.data(); pm.pop_sizes = pop_sizes.data();
@@ -134,9 +144,10 @@ static void pfARG_core(PfParam& P) {
         pf_check(pf_finish(h));
         cout << "\r Particle filtering step 100% completed." << endl;
         int64_t done = pf_num_segments_done(h);
-        std::vector<double> packed(PF_COUNTS_LEN(E));
+        std::vector<double> packed(PF_COUNTS_LEN2(E, NP));
         pf_check(pf_get_counts(h, packed.data(), (int32_t)packed.size()));
-        clog << "Got to end of sequence; resampled " << (long long)packed[6 * E + 2] << " times" << endl;
+        const double* tail = &packed[packed.size() - 4];
+        clog << "Got to end of sequence; resampled " << (long long)tail[2] << " times" << endl;
         clog << " Inference step completed." << endl;
         if (P.record_resample_file) {
             std::vector<double> ess(done);
@@ -161,11 +172,17 @@ static void pfARG_core(PfParam& P) {
             }
         }
         // log_counts (count.cpp:66-158) with the prior pseudo-counts of init_coal_and_recomb (count.cpp:161-193)
-        const double* cc = &packed[0]; const double* co = &packed[E]; const double* cw = &packed[2 * E];
-        const double* rc = &packed[3 * E]; const double* ro = &packed[4 * E]; const double* rw = &packed[5 * E];
+        const size_t EP = (size_t)E * NP;
+        const double* cc = &packed[0]; const double* co = &packed[EP]; const double* cw = &packed[2 * EP];
+        const double* rc = &packed[3 * EP]; const double* ro = &packed[3 * EP + E]; const double* rw = &packed[3 * EP + 2 * E];
+        auto epoch_end = [&](int e) { return e == E - 1 ? 1e+99 : M.change_times[e + 1]; };
         for (int e = 0; e < E; ++e)
-            P.appendToOutFile(P.EMcounter, e, M.change_times[e], e == E - 1 ? 1e+99 : M.change_times[e + 1], "Coal", 0, -1,
-                              co[e] + 1.0, cc[e] + 1.0 / (2.0 * pop_sizes[e]), cw[e] + 1.0);
+            for (int a = 0; a < NP; ++a) {
+                const size_t k = (size_t)e * NP + a;
+                P.appendToOutFile(P.EMcounter, e, M.change_times[e], epoch_end(e), "Coal", a, -1, co[k] + 1.0,
+                                  cc[k] + 1.0 / (2.0 * pop_sizes[k]), cw[k] + 1.0);
+            }
+        // recombination is booked on population 0 only (count.cpp:534-539); the report sums the epochs (84-113)
         double ropp = 0, rcount = 0, rweight = 0;
         for (int e = 0; e < E; ++e) {
             ropp += ro[e] + 1.0;
@@ -173,7 +190,19 @@ static void pfARG_core(PfParam& P) {
             rweight += rw[e] + 1.0;
         }
         P.appendToOutFile(P.EMcounter, -1, 0.0, 1e+99, "Recomb", -1, -1, ropp, rcount, rweight);
-        double dopp = packed[6 * E + 0], dcount = packed[6 * E + 1], nres = packed[6 * E + 2], logl = packed[6 * E + 3];
+        if (NP > 1) {
+            // migration rows with the pseudo-counts of init_migr (count.cpp:196-227)
+            const double* mc = &packed[3 * EP + 3 * E]; const double* mo = mc + EP * NP; const double* mw = mo + EP;
+            for (int e = 0; e < E; ++e)
+                for (int a = 0; a < NP; ++a)
+                    for (int b = 0; b < NP; ++b)
+                        if (a != b) {
+                            const size_t k = (size_t)e * NP + a;
+                            P.appendToOutFile(P.EMcounter, e, M.change_times[e], epoch_end(e), "Migr", a, b, mo[k] + 1.0,
+                                              mc[k * NP + b] + mig_rates[k * NP + b], mw[k] + 1.0);
+                        }
+        }
+        double dopp = tail[0], dcount = tail[1], nres = tail[2], logl = tail[3];
         P.appendToOutFile(P.EMcounter, -1, 0.0, 1e+99, "Delay", -1, -1, dopp, dcount / (double)P.N, dopp);
         P.appendToOutFile(P.EMcounter, -1, 0.0, 1e+99, "Resamp", -1, -1, dopp, nres, dopp);
         P.appendToOutFile(P.EMcounter, -1, 0, 1e+99, "LogL", -1, -1, 1.0, logl, 1.0);   // smcsmc.cpp:391

@@ -137,7 +137,9 @@ void HostModel::parse(const std::vector<std::string>& tok) {
             if (a < 1 || a > P || b < 1 || b > P) throw InvalidInput("Population index out of range in -ej");
             Change& c = at(t);
             c.single[(size_t)(a - 1) * P + (b - 1)] = 1.0;
-            for (int k = 0; k < P; ++k) if (k != a - 1) c.mig[(size_t)(a - 1) * P + k] = 0.0;
+            // scrm -ej: every line of population a moves to b, and no line may enter a from then on
+            for (int k = 0; k < P; ++k)
+                if (k != a - 1) { c.mig[(size_t)k * P + (a - 1)] = 0.0; c.mig[(size_t)(a - 1) * P + k] = 0.0; }
         } else if (f == "-seed") {
             need(f, 1);
             uint64_t sd = 0; int k = 0;

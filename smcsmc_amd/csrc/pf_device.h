@@ -15,7 +15,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define PF_BS 256          // threads per workgroup of the per-particle kernels (4 wavefronts)
+#ifndef PF_BS
+#define PF_BS 256          // threads per workgroup of the per-particle kernels (4 wavefronts) = LDS stride of per-lane columns
+#endif
 #define PF_NMAX 16         // maximum number of haplotypes
 #define PF_INF (__longlong_as_double(0x7ff0000000000000LL))
 

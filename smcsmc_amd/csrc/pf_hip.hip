@@ -24,224 +24,12 @@
 
 #include "../../include/smcsmc_pf.h"
 #include "pf_device.h"
+#include "pf_types.h"
+#include "pf_lane.h"
 #include "pf_tree_reg.h"
-#include "pf_mp.h"
-
-#define PF_EMAX 64
-#define PF_DCAP 32            // pending delayed factors per particle (the reference's heap is unbounded)
-#define PF_BIAS_MAX 8         // interior bias heights
-#define PF_DECIDE_TAB 16384   // offspring / parent tables fit LDS (16-bit entries) up to this many particles
-#define PF_LEDGER_BLOCKS 192   // extra workgroups of k_resample that maintain the ancestor ledger
-#define REC_RECOMB 1
-#define REC_COALMIGR 2
+#include "pf_mp_host.h"
 
 using namespace pf;
-
-// ------------------------------------------------------------------ device-visible structures
-struct DState {
-    double* S;        // [(n-1)][Np]
-    int8_t* C;        // [2(n-1)][Np]
-    double* w_post;   // [Np]
-    double* w_pilot;
-    double* next_base;
-    double* x_mark;
-    double* Ltree;
-    int* mark_limit;
-    // delayed importance factors (particle.hpp:59-101, 185-209); allocated only with focused sampling
-    double* total_delayed;   // [Np]
-    int* dcount;             // [Np]
-    double* dpos;            // [PF_DCAP][Np] application positions
-    double* dfac;            // [PF_DCAP][Np]
-    double* ddelta;          // [PF_DCAP][Np]
-    int* dk;                 // [PF_DCAP][Np]
-    // structured models (pf_mp.h); allocated only when P > 1
-    int8_t* Pn;              // [(n-1)][Np] population of every coalescent node
-    int* nm;                 // [Np] migration events on the local tree
-    double* Mt;              // [PF_MMAX][Np]
-    int8_t* Mb;              // [PF_MMAX][Np]
-    int8_t* Mq;              // [PF_MMAX][Np]
-};
-
-struct Ctrl {
-    double cur_pos;        // site_where_weight_was_updated_ (same for every particle)
-    double logl;           // ln_normalization_factor_
-    double inv_T, T, S1, S2, ess, u;
-    double delayed_opp;
-    double delayed_count;
-    double counted_to[PF_EMAX];
-    double update_to[PF_EMAX];
-    long long n_resample;
-    int flag;              // resample at this segment?
-    int cur;               // index of the live state buffer
-    int gen;               // current generation (number of resampling events so far)
-    int first_epoch;       // first epoch updated by the current count step (E = none)
-    int g_retain;          // oldest generation whose run list is still maintained
-    int g_lo[PF_EMAX];     // generation containing counted_to[e]
-    int g_hi[PF_EMAX];     // generation containing update_to[e] of the current count step
-    int err;               // sticky error code
-    int count_active;
-    int end_seq;
-    int pending_fin;       // k_count partials of the previous step still have to be folded into the totals
-    long long nres_prev;   // n_resample as of the end of the last k_resample (stable during k_decide)
-    // what the counting stream needs to know about a step, double-buffered by step parity
-    struct StepInfo { double inv_T; int G; int flag; } step[2];
-    int gen_prev;          // generation index as of the end of the last k_resample (stable during k_decide)
-    int nbx_used;
-};
-
-struct KArgs {
-    // model
-    int E, n, flags;
-    double L, mu, rho;
-    const double* T;
-    const double* inv2N;
-    const double* lags;
-    const int* recflags;
-    // structured models: P populations
-    int P, ncol;                   // ncol = statistics per epoch (6 when P == 1)
-    const double* inv2Np;          // [E*P]
-    const double* mig_rate;        // [E*P*P]
-    const double* mig_tot;         // [E*P]
-    const int* join_map;           // [E*P]
-    const int* sample_pop;         // [n]
-    double* plog;                  // coal/migr opportunity pieces: plog[(p*pcap + k%pcap)*3 .. +3)
-    unsigned pcap;
-    unsigned* pidx;                // slot-owned: pieces ever written by this slot
-    // run parameters
-    long long Np;
-    double ess_threshold;
-    unsigned long long seed;
-    // focused sampling
-    int n_bias, delay_type;
-    double bias_H[PF_BIAS_MAX + 2];
-    double bias_S[PF_BIAS_MAX + 1];
-    const double* app_delays;
-    int* chunk_dpend;              // [nc] particles with pending delayed factors, per wavefront
-    double delayed_count_unused;
-    // state
-    DState st[2];
-    unsigned long long* rng_ctr;   // slot-owned
-    double* ebuf;                  // slot-owned
-    unsigned* widx;                // slot-owned: records ever appended by this slot
-    // event log: rec[(p*cap + k%cap)*RS .. +RS)
-    double* log;
-    unsigned cap;
-    int RS;
-    // ancestor ledger (rings of Gcap generations)
-    int Gcap;
-    unsigned* gstart;              // [Gcap][Np]  widx at the start of generation g
-    int* lo;                       // [Gcap][Np+1] offspring ranges of resampling event r (between gen r and r+1)
-    double* gen_x0;                // [Gcap] position where generation g starts
-    int* parent;                   // [Np] parent slot of every new slot at the current resampling event
-    int* blkcnt;                   // [nblocks] survivors per particle workgroup at the current resampling event
-    // run-length encoded composite ancestor maps: generation g's list maps the slots of the
-    // current generation to slots of generation g: run i covers [run_st[i], run_st[i+1]) -> run_anc[i]
-    int* run_st;                   // [Gcap][Np]
-    int* run_anc;                  // [Gcap][Np]
-    int* nruns;                    // [Gcap]
-    // per-wavefront partials written by k_extend
-    double* chunk_post;            // [nc]
-    double* chunk_sq;
-    double* chunk_pil;
-    double* scan1;                 // [Np] within-wavefront inclusive scan of the pilot weights
-    double* chunk_off;             // [nc]
-    double* l2scan;                // [nc]
-    double* scanp2[2];             // [Np] within-wavefront inclusive scan of the posterior weights (by step parity)
-    // snapshot of what k_count needs from the live particles of a step (by step parity): the counting stream
-    // runs concurrently with k_resample / the next k_extend, which rewrite the live state
-    double* snap_w[2];             // [Np] raw posterior weight
-    double* snap_S[2];             // [(n-1)][Np]
-    double* snap_xm[2];            // [Np] x_mark
-    int* snap_ml[2];               // [Np] mark_limit
-    unsigned* snap_widx[2];        // [Np]
-    int sp;                        // parity of the step this launch belongs to (set by the host per launch)
-    double* scan1m;                // [Np] running max of scan1 inside the wavefront
-    double* chunk_mx1;             // [nc] max of scan1 per wavefront
-    double* chunk_pp;              // [nc] its per-wavefront totals
-    double* chunk_offp2[2];        // [nc] exclusive offsets of the posterior scan (by step parity)
-    double* l2scanp;               // [nc]
-    // counting
-    double* totals;                // [6][E]
-    double* partial;               // [E][nbx][6]
-    int nbx;
-    // segments
-    const double* seg_start;
-    const double* seg_len;
-    const int8_t* seg_state;
-    const int8_t* seg_alleles;
-    const int* seg_limit;
-    // traces
-    double* tr_T;
-    double* tr_ess;
-    double* tr_logl;
-    int* tr_flag;
-    int* ev_seg;
-    int* ev_parents;
-    int max_trace_events;
-    Ctrl* ctrl;
-};
-
-// Count windows of one step (count.cpp:363-385).  The rule depends only on segment positions and lags,
-// so the host evaluates it (host_first_epoch) and hands the result to the kernels by value.
-struct Windows {
-    int first;                 // first epoch that updates (E = none)
-    int end_data;
-    double a[PF_EMAX];         // counted_to before this step
-    double b[PF_EMAX];         // update_to of this step
-};
-
-enum { ERR_LOG_OVERFLOW = 1, ERR_GEN_OVERFLOW = 2, ERR_ZERO_PROB = 3, ERR_COUNT_MISMATCH = 4, ERR_MIG_OVERFLOW = 5,
-       ERR_MP_INTERNAL = 6, ERR_NO_COALESCENCE = 7 };
-
-__device__ __forceinline__ unsigned long long make_meta(int type, int lim_start, int lim_event, int n_eff) {
-    return (unsigned long long)(type & 0xff) | ((unsigned long long)((lim_start + 1) & 0xff) << 8) |
-           ((unsigned long long)((lim_event + 1) & 0xff) << 16) | ((unsigned long long)(n_eff & 0xff) << 24);
-}
-
-__device__ __forceinline__ double* rec_ptr(const KArgs& A, long long p, unsigned k) {
-    return A.log + ((size_t)p * A.cap + (k % A.cap)) * A.RS;
-}
-
-// LDS carve-up shared by k_init / k_extend
-struct Smem {
-    double* S; double* t0; double* t1; double* T; double* I; int* RF; int8_t* C;
-};
-__device__ __forceinline__ Smem carve(double* base, int n, int E) {
-    Smem m;
-    m.S = base;
-    m.t0 = m.S + (size_t)(n - 1) * PF_BS;
-    m.t1 = m.t0 + (size_t)(n - 1) * PF_BS;
-    m.T = m.t1 + (size_t)(n - 1) * PF_BS;
-    m.I = m.T + E;
-    m.RF = (int*)(m.I + E);
-    m.C = (int8_t*)(m.RF + E + (E & 1));
-    return m;
-}
-__host__ __device__ static size_t smem_bytes(int n, int E) {
-    return (size_t)3 * (n - 1) * PF_BS * 8 + (size_t)2 * E * 8 + (size_t)(E + (E & 1)) * 4 + (size_t)2 * (n - 1) * PF_BS;
-}
-
-__device__ __forceinline__ void load_model(const KArgs& A, Smem& m) {
-    for (int e = threadIdx.x; e < A.E; e += blockDim.x) {
-        m.T[e] = A.T[e];
-        m.I[e] = A.inv2N[e];
-        m.RF[e] = A.recflags[e];
-    }
-}
-
-__device__ __forceinline__ Lane make_lane(const KArgs& A, Smem& m, long long p) {
-    Lane ln;
-    ln.S = m.S + threadIdx.x;
-    ln.C = m.C + threadIdx.x;
-    ln.T = m.T; ln.I = m.I; ln.RF = m.RF;
-    ln.E = A.E; ln.n = A.n;
-    ln.L = A.L; ln.mu = A.mu; ln.rho = A.rho;
-    ln.seed = A.seed;
-    ln.slot = (unsigned)p;
-    ln.stream = 0;
-    ln.ctr = 0; ln.ebuf = 0; ln.Ltree = 0;
-    return ln;
-}
 
 // ------------------------------------------------------------------ k_init  (particleContainer.cpp:33-65)
 __global__ __launch_bounds__(PF_BS) void k_init(KArgs A, double initial_position) {
@@ -309,126 +97,6 @@ __global__ __launch_bounds__(PF_BS) void k_init(KArgs A, double initial_position
     A.ebuf[p] = ln.ebuf;
     A.widx[p] = widx;
     A.gstart[p] = 0;   // generation 0 starts with an empty log (the init records belong to it)
-}
-
-// One genealogy update (SMC'): sample the recombination point, coalesce the floating lineage
-// against the old tree, re-attach.  Mirrors oracle Filter::genealogy_update step by step.
-__device__ __forceinline__ void sample_point(Lane& ln, int* rp_out, int* sb_out, double* h_out) {
-    const int n = ln.n;
-    double r = uni(ln) * ln.Ltree;
-    double prev = 0.0, h = 0.0;
-    int lin = 0;
-    for (int ri = 0; ri < n - 1; ++ri) {
-        int k = n - ri;
-        double sr = LS(ln, ri);
-        double d = sr - prev;
-        double seg = (double)k * d;
-        if (r < seg || ri == n - 2) {
-            double q = r / d;
-            lin = min((int)q, k - 1);
-            h = prev + (q - (double)lin) * d;
-            if (!(h < sr)) h = prev;
-            break;
-        }
-        r -= seg;
-        prev = sr;
-    }
-    lineages_at(ln, n - 1, h, lin, rp_out, sb_out);
-    *h_out = h;
-}
-
-__device__ __forceinline__ void genealogy_update(Lane& ln, double* h_out, double* tc_out, double* sp_out, bool* changed_out) {
-    const int n = ln.n;
-    int rp = 0, sb = 0;
-    double h;
-    sample_point(ln, &rp, &sb, &h);
-    *h_out = h;
-    double tc = coalesce_up(ln, [&](int k) { return LS(ln, k); }, n - 1, n, h);
-    *tc_out = tc;
-    double Sp = LS(ln, rp);
-    int b_id = LC(ln, rp, sb), s_id = LC(ln, rp, 1 - sb);
-    bool p_was_root = (rp == n - 2);
-    remove_rank(ln, n - 1, rp, s_id, &b_id, &s_id);
-    int ni = n - 2;
-    int troot = p_was_root ? s_id : n + (ni - 1);
-    int pr = -1, ps = 0;
-    int nslots = lineages_at(ln, ni, tc, -1, &pr, &ps);
-    bool has_root = tc >= node_h(ln, troot);
-    bool has_stub = tc < Sp;
-    int k = nslots + (has_root ? 1 : 0) + (has_stub ? 1 : 0);
-    double u = uni(ln);
-    int idx = min((int)(u * (double)k), k - 1);
-    *sp_out = Sp;
-    *changed_out = !(has_stub && idx == k - 1);
-    if (idx < nslots) {
-        lineages_at(ln, ni, tc, idx, &pr, &ps);
-        insert_node(ln, ni, tc, b_id, pr, ps, troot);
-    } else if (has_root && idx == nslots) {
-        insert_node(ln, ni, tc, b_id, -1, 0, troot);
-    } else {
-        if (p_was_root) {
-            insert_node(ln, ni, Sp, b_id, -1, 0, troot);
-        } else {
-            int want = -1, c = 0;
-            int R = 0;
-            while (R < ni && LS(ln, R) <= Sp) ++R;
-            for (int rr = R; rr < ni && want < 0; ++rr)
-                for (int s = 0; s < 2 && want < 0; ++s) {
-                    int id = LC(ln, rr, s);
-                    if (id < n || id - n < R) {
-                        if (id == s_id) want = c;
-                        ++c;
-                    }
-                }
-            lineages_at(ln, ni, Sp, want, &pr, &ps);
-            insert_node(ln, ni, Sp, b_id, pr, ps, troot);
-        }
-    }
-    ln.Ltree = tree_length(ln, n);
-}
-
-__device__ __forceinline__ double tracked_len_lane(const Lane& ln, const int8_t* data, double* tmp) {
-    // particle.cpp:699-730; tmp holds the per-internal-node values (stride PF_BS)
-    const int n = ln.n;
-    double total = 0.0;
-    for (int r = 0; r < n - 1; ++r) {
-        int c0 = LC(ln, r, 0), c1 = LC(ln, r, 1);
-        double sr = LS(ln, r);
-        double l = c0 < n ? (data[c0] >= 0 ? 0.0 : -1.0) : tmp[(c0 - n) * PF_BS];
-        double rr = c1 < n ? (data[c1] >= 0 ? 0.0 : -1.0) : tmp[(c1 - n) * PF_BS];
-        if (l >= 0.0) l += sr - node_h(ln, c0);
-        if (rr >= 0.0) rr += sr - node_h(ln, c1);
-        double v;
-        if (l >= 0.0 && rr >= 0.0) { total = l + rr; v = total; }
-        else if (l >= 0.0) v = l;
-        else v = rr;
-        tmp[r * PF_BS] = v;
-    }
-    return total;
-}
-
-__device__ __forceinline__ double site_lik_lane(const Lane& ln, unsigned one_mask, unsigned zero_mask, bool anc,
-                                                double* t0, double* t1) {
-    // particle.cpp:625-680.  Leaf i: L0 = (state==1 ? 0 : 1), L1 = (state==0 ? 0 : 1);
-    // one_mask bit i <=> state==1, zero_mask bit i <=> state==0 (missing: neither).
-    const int n = ln.n;
-    for (int r = 0; r < n - 1; ++r) {
-        int c0 = LC(ln, r, 0), c1 = LC(ln, r, 1);
-        double sr = LS(ln, r);
-        double tl = sr - node_h(ln, c0);
-        double trr = sr - node_h(ln, c1);
-        double pl = fastexp(-tl * ln.mu);
-        double pr = fastexp(-trr * ln.mu);
-        double a0, a1, b0, b1;
-        if (c0 < n) { a0 = (one_mask >> c0) & 1 ? 0.0 : 1.0; a1 = (zero_mask >> c0) & 1 ? 0.0 : 1.0; }
-        else { a0 = t0[(c0 - n) * PF_BS]; a1 = t1[(c0 - n) * PF_BS]; }
-        if (c1 < n) { b0 = (one_mask >> c1) & 1 ? 0.0 : 1.0; b1 = (zero_mask >> c1) & 1 ? 0.0 : 1.0; }
-        else { b0 = t0[(c1 - n) * PF_BS]; b1 = t1[(c1 - n) * PF_BS]; }
-        t0[r * PF_BS] = (a0 * pl + a1 * (1 - pl)) * (b0 * pr + b1 * (1 - pr));
-        t1[r * PF_BS] = (a1 * pl + a0 * (1 - pl)) * (b1 * pr + b0 * (1 - pr));
-    }
-    double p0 = anc ? 1.0 : 0.5, p1 = anc ? 0.0 : 0.5;
-    return t0[(n - 2) * PF_BS] * p0 + t1[(n - 2) * PF_BS] * p1;
 }
 
 // ------------------------------------------------------------------ k_extend
@@ -576,290 +244,6 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
     double sc = wave_hs_scan(w_pilot, lane);
     double scp = wave_hs_scan(w_post, lane);
     double scm = wave_max_scan_d(sc, lane);     // running max of the pilot scan (a parallel FP scan need not be monotone)
-    long long chunk = p >> 6;
-    if (active) { A.scan1[p] = sc; A.scanp2[A.sp][p] = scp; A.scan1m[p] = scm; }
-    if (lane == 63 && chunk < (A.Np + 63) / 64) {
-        A.chunk_post[chunk] = sp;
-        A.chunk_sq[chunk] = sq;
-        A.chunk_pil[chunk] = sc;
-        A.chunk_pp[chunk] = scp;
-        A.chunk_mx1[chunk] = scm;
-    }
-}
-
-// ------------------------------------------------------------------ structured models (P > 1): LDS-tree kernels
-// Same structure as k_init / k_extend / k_calibrate with the migration-aware genealogy update of pf_mp.h.
-struct SmemMP { double* I2; double* MR; double* MT; double* Mt; int* JM; int* SP; int8_t* Pn; int8_t* Mb; int8_t* Mq; };
-__host__ __device__ static size_t smem_mp_extra(int n, int E, int P) {
-    size_t dbl = (size_t)E * P * 2 + (size_t)E * P * P + (size_t)PF_MMAX * PF_BS;
-    size_t ints = (size_t)E * P + (size_t)((n + 1) & ~1) + (size_t)((E * P) & 1);
-    size_t bytes = (size_t)(n - 1) * PF_BS + (size_t)2 * PF_MMAX * PF_BS;
-    return dbl * 8 + ints * 4 + bytes;
-}
-static size_t smem_bytes_mp(int n, int E, int P) { return smem_bytes(n, E) + smem_mp_extra(n, E, P); }
-__device__ __forceinline__ SmemMP carve_mp(double* base, int n, int E, int P) {
-    SmemMP m;
-    m.I2 = (double*)((char*)base + smem_bytes(n, E));
-    m.MR = m.I2 + (size_t)E * P;
-    m.MT = m.MR + (size_t)E * P * P;
-    m.Mt = m.MT + (size_t)E * P;
-    m.JM = (int*)(m.Mt + (size_t)PF_MMAX * PF_BS);
-    m.SP = m.JM + (size_t)E * P + ((E * P) & 1);
-    m.Pn = (int8_t*)(m.SP + ((n + 1) & ~1));
-    m.Mb = m.Pn + (size_t)(n - 1) * PF_BS;
-    m.Mq = m.Mb + (size_t)PF_MMAX * PF_BS;
-    return m;
-}
-__device__ __forceinline__ void load_model_mp(const KArgs& A, SmemMP& m) {
-    const int EP = A.E * A.P;
-    for (int i = threadIdx.x; i < EP; i += blockDim.x) { m.I2[i] = A.inv2Np[i]; m.MT[i] = A.mig_tot[i]; m.JM[i] = A.join_map[i]; }
-    for (int i = threadIdx.x; i < EP * A.P; i += blockDim.x) m.MR[i] = A.mig_rate[i];
-    for (int i = threadIdx.x; i < A.n; i += blockDim.x) m.SP[i] = A.sample_pop[i];
-}
-__device__ __forceinline__ MLane make_mlane(const KArgs& A, SmemMP& m) {
-    MLane ml;
-    ml.Pn = m.Pn + threadIdx.x; ml.Mt = m.Mt + threadIdx.x; ml.Mb = m.Mb + threadIdx.x; ml.Mq = m.Mq + threadIdx.x;
-    ml.nm = 0; ml.P = A.P;
-    ml.I2 = m.I2; ml.MR = m.MR; ml.MT = m.MT; ml.JM = m.JM; ml.SP = m.SP;
-    ml.err = 0;
-    return ml;
-}
-__device__ __forceinline__ void mp_report(const KArgs& A, const MLane& ml) {
-    if (ml.err == 1) A.ctrl->err = ERR_MIG_OVERFLOW;
-    if (ml.err == 2) A.ctrl->err = ERR_MP_INTERNAL;
-    if (ml.err == 3) A.ctrl->err = ERR_NO_COALESCENCE;
-}
-__device__ __forceinline__ double piece_ref(unsigned pstart, unsigned npieces) {
-    return __longlong_as_double((long long)((unsigned long long)pstart | ((unsigned long long)npieces << 32)));
-}
-__device__ __forceinline__ void store_mp_state(const KArgs& A, DState& st, const Lane& ln, const MLane& ml, long long p) {
-    const int n = A.n;
-    for (int r = 0; r < n - 1; ++r) st.Pn[(size_t)r * A.Np + p] = LPn(ml, r);
-    st.nm[p] = ml.nm;
-    for (int m = 0; m < ml.nm; ++m) {
-        st.Mt[(size_t)m * A.Np + p] = LMt(ml, m);
-        st.Mb[(size_t)m * A.Np + p] = LMb(ml, m);
-        st.Mq[(size_t)m * A.Np + p] = LMq(ml, m);
-    }
-}
-
-__global__ __launch_bounds__(PF_BS) void k_init_mp(KArgs A, double initial_position) {
-    extern __shared__ double smem[];
-    Smem m = carve(smem, A.n, A.E);
-    SmemMP mm = carve_mp(smem, A.n, A.E, A.P);
-    load_model(A, m);
-    load_model_mp(A, mm);
-    __syncthreads();
-    long long p = (long long)blockIdx.x * PF_BS + threadIdx.x;
-    if (p == 0) {
-        Ctrl* c = A.ctrl;
-        c->cur_pos = initial_position;
-        c->logl = 0; c->inv_T = 1; c->T = 1; c->flag = 0; c->cur = 0; c->gen = 0; c->n_resample = 0;
-        c->first_epoch = A.E; c->err = 0; c->delayed_opp = 0; c->delayed_count = 0; c->count_active = 0; c->end_seq = 0;
-        c->g_retain = 0; c->pending_fin = 0; c->nbx_used = A.nbx; c->gen_prev = 0; c->nres_prev = 0;
-        for (int e = 0; e < A.E; ++e) { c->counted_to[e] = 0; c->update_to[e] = 0; c->g_lo[e] = 0; c->g_hi[e] = 0; }
-        A.gen_x0[0] = 0.0;
-    }
-    if (p >= A.Np) return;
-    const int n = A.n;
-    Lane ln = make_lane(A, m, p);
-    MLane ml = make_mlane(A, mm);
-    ln.ebuf = -dlog(uni(ln));
-    unsigned widx = 0;
-    PLog pl;
-    pl.base = A.plog + (size_t)p * A.pcap * 3; pl.cap = A.pcap; pl.idx = 0; pl.on = true; pl.fopen = false; pl.ropen = false;
-    // every coalescence of the initial tree is logged as a type-2 record at position 0 (particle.cpp:251-300)
-    mp_build_initial_tree(ln, ml, &pl, [&](int i, unsigned p0, unsigned np_, double tc) {
-        double* rec = rec_ptr(A, p, widx);
-        rec[0] = 0.0; rec[1] = 0.0; rec[2] = 0.0;
-        rec[3] = piece_ref(p0, np_);
-        rec[4] = __longlong_as_double((long long)make_meta(2, A.E - 1, A.E - 1, i));
-        for (int r = 0; r < n - 1; ++r) rec[5 + r] = 0.0;
-        (void)tc;
-        ++widx;
-    });
-    mp_report(A, ml);
-    double nb = sample_next_base(ln, 0.0);
-    DState& st = A.st[0];
-    for (int r = 0; r < n - 1; ++r) {
-        st.S[(size_t)r * A.Np + p] = LS(ln, r);
-        st.C[(size_t)(2 * r) * A.Np + p] = LC(ln, r, 0);
-        st.C[(size_t)(2 * r + 1) * A.Np + p] = LC(ln, r, 1);
-    }
-    store_mp_state(A, st, ln, ml, p);
-    st.w_post[p] = 1.0 / (double)A.Np;
-    st.w_pilot[p] = 1.0 / (double)A.Np;
-    st.next_base[p] = nb;
-    st.x_mark[p] = 0.0;
-    st.Ltree[p] = ln.Ltree;
-    st.mark_limit[p] = A.E - 1;
-    A.rng_ctr[p] = ln.ctr;
-    A.ebuf[p] = ln.ebuf;
-    A.widx[p] = widx;
-    A.pidx[p] = pl.idx;
-    A.gstart[p] = 0;
-}
-
-__global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
-    extern __shared__ double smem[];
-    Smem m = carve(smem, A.n, A.E);
-    SmemMP mm = carve_mp(smem, A.n, A.E, A.P);
-    load_model(A, m);
-    load_model_mp(A, mm);
-    __syncthreads();
-    const Ctrl* c = A.ctrl;
-    const int n = A.n;
-    const int cur = c->cur;
-    const long long p = (long long)blockIdx.x * PF_BS + threadIdx.x;
-    const bool active = p < A.Np;
-    const int lane = threadIdx.x & 63;
-    double w_post = 0.0, w_pilot = 0.0;
-    if (active) {
-        DState& st = A.st[cur];
-        Lane ln = make_lane(A, m, p);
-        MLane ml = make_mlane(A, mm);
-        for (int r = 0; r < n - 1; ++r) {
-            LS(ln, r) = st.S[(size_t)r * A.Np + p];
-            LC(ln, r, 0) = st.C[(size_t)(2 * r) * A.Np + p];
-            LC(ln, r, 1) = st.C[(size_t)(2 * r + 1) * A.Np + p];
-            LPn(ml, r) = st.Pn[(size_t)r * A.Np + p];
-        }
-        ml.nm = st.nm[p];
-        for (int q = 0; q < ml.nm; ++q) {
-            LMt(ml, q) = st.Mt[(size_t)q * A.Np + p];
-            LMb(ml, q) = st.Mb[(size_t)q * A.Np + p];
-            LMq(ml, q) = st.Mq[(size_t)q * A.Np + p];
-        }
-        w_post = st.w_post[p];
-        w_pilot = st.w_pilot[p];
-        double next_base = st.next_base[p];
-        double x_mark = st.x_mark[p];
-        int mark_limit = st.mark_limit[p];
-        ln.Ltree = st.Ltree[p];
-        ln.ctr = A.rng_ctr[p];
-        ln.ebuf = A.ebuf[p];
-        unsigned widx = A.widx[p];
-        PLog pl;
-        pl.base = A.plog + (size_t)p * A.pcap * 3; pl.cap = A.pcap; pl.idx = A.pidx[p]; pl.on = true;
-        pl.fopen = false; pl.ropen = false;
-        double* tmp0 = m.t0 + threadIdx.x;
-        double* tmp1 = m.t1 + threadIdx.x;
-
-        const int8_t* data = A.seg_alleles + (size_t)s * n;
-        const double seg_end = A.seg_start[s] + A.seg_len[s];
-        const double extend_to = seg_end < A.L ? seg_end : A.L;
-        const int limit = A.seg_limit[s];
-        int missing = 0;
-        for (int i = 0; i < n; ++i) missing += data[i] == -1;
-        int leaf_status = 0;
-        if (missing == 0) leaf_status = 1;
-        if (missing == n) leaf_status = -1;
-
-        double updated_to = c->cur_pos;
-        double B;
-        if (leaf_status == -1) B = 0;
-        else if (leaf_status == 1) B = ln.Ltree;
-        else B = tracked_len_lane(ln, data, tmp0);
-
-        while (updated_to < extend_to) {
-            double new_to = extend_to < next_base ? extend_to : next_base;
-            double f = fastexp(-A.mu * B * (new_to - updated_to));
-            w_post *= f;
-            w_pilot *= f;
-            updated_to = new_to;
-            if (updated_to < extend_to) {
-                double* rec = rec_ptr(A, p, widx);
-                rec[0] = x_mark;
-                rec[1] = updated_to;
-                for (int r = 0; r < n - 1; ++r) rec[5 + r] = LS(ln, r);
-                int rp = 0, sb = 0;
-                double h, tc, sp_removed;
-                bool changed;
-                sample_point(ln, &rp, &sb, &h);
-                unsigned p0 = pl.idx;
-                mp_genealogy_rest(ln, ml, &pl, limit, rp, sb, h, &tc, &sp_removed, &changed);
-                rec[2] = h;
-                rec[3] = piece_ref(p0, pl.idx - p0);
-                rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n));
-                ++widx;
-                if (ml.err) break;
-                if (leaf_status == 0) B = tracked_len_lane(ln, data, tmp0);
-                if (leaf_status == 1) B = ln.Ltree;
-                next_base = sample_next_base(ln, updated_to);
-                x_mark = updated_to;
-                mark_limit = limit;
-            }
-        }
-        mp_report(A, ml);
-
-        if (A.seg_state[s] == 0) {
-            // update_weight_at_site: marginalise over phasings of unphased hets (pc.cpp:138-224)
-            const bool dephase = A.flags & 2;
-            const bool anc = A.flags & 1;
-            unsigned one_mask = 0, zero_mask = 0, het_pairs = 0;
-            int ncfg = 1;
-            for (int i = 0; i < n; ++i) {
-                if (data[i] == 1) one_mask |= 1u << i;
-                if (data[i] == 0) zero_mask |= 1u << i;
-            }
-            for (int i = 0; i + 1 < n; i += 2) {
-                bool het = (data[i] == 2) || (dephase && data[i] + data[i + 1] == 1);
-                if (het) {
-                    ncfg *= 2;
-                    het_pairs |= 1u << i;
-                    one_mask &= ~(3u << i); zero_mask &= ~(3u << i);
-                    zero_mask |= 1u << i;
-                    one_mask |= 1u << (i + 1);
-                }
-            }
-            double norm = 1.0 / (double)ncfg;
-            double lik = 0;
-            for (;;) {
-                lik += site_lik_lane(ln, one_mask, zero_mask, anc, tmp0, tmp1);
-                if (ncfg == 1) break;
-                bool more = false;
-                for (int i = 0; i + 1 < n; i += 2) {
-                    if (!((het_pairs >> i) & 1)) continue;
-                    if ((zero_mask >> i) & 1) {
-                        zero_mask &= ~(1u << i); one_mask |= 1u << i;
-                        one_mask &= ~(1u << (i + 1)); zero_mask |= 1u << (i + 1);
-                        more = true;
-                        break;
-                    }
-                    one_mask &= ~(1u << i); zero_mask |= 1u << i;
-                    zero_mask &= ~(1u << (i + 1)); one_mask |= 1u << (i + 1);
-                }
-                if (!more) break;
-            }
-            lik *= norm;
-            w_post *= lik;
-            w_pilot *= lik;
-        }
-
-        for (int r = 0; r < n - 1; ++r) {
-            st.S[(size_t)r * A.Np + p] = LS(ln, r);
-            st.C[(size_t)(2 * r) * A.Np + p] = LC(ln, r, 0);
-            st.C[(size_t)(2 * r + 1) * A.Np + p] = LC(ln, r, 1);
-        }
-        store_mp_state(A, st, ln, ml, p);
-        st.w_post[p] = w_post;
-        st.w_pilot[p] = w_pilot;
-        st.next_base[p] = next_base;
-        st.x_mark[p] = x_mark;
-        st.mark_limit[p] = mark_limit;
-        st.Ltree[p] = ln.Ltree;
-        A.rng_ctr[p] = ln.ctr;
-        A.ebuf[p] = ln.ebuf;
-        A.widx[p] = widx;
-        A.pidx[p] = pl.idx;
-        for (int r = 0; r < n - 1; ++r) A.snap_S[A.sp][(size_t)r * A.Np + p] = LS(ln, r);
-        A.snap_w[A.sp][p] = w_post; A.snap_xm[A.sp][p] = x_mark; A.snap_ml[A.sp][p] = mark_limit; A.snap_widx[A.sp][p] = widx;
-    }
-    double sp = wave_tree_sum(w_post);
-    double sq = wave_tree_sum(w_pilot * w_pilot);
-    double sc = wave_hs_scan(w_pilot, lane);
-    double scp = wave_hs_scan(w_post, lane);
-    double scm = wave_max_scan_d(sc, lane);
     long long chunk = p >> 6;
     if (active) { A.scan1[p] = sc; A.scanp2[A.sp][p] = scp; A.scan1m[p] = scm; }
     if (lane == 63 && chunk < (A.Np + 63) / 64) {
@@ -1999,55 +1383,6 @@ __global__ __launch_bounds__(PF_BS) void k_calibrate(KArgs A, unsigned long long
     }
 }
 
-__global__ __launch_bounds__(PF_BS) void k_calibrate_mp(KArgs A, unsigned long long seed, long long rep0, long long nrep,
-                                                        int* out_epoch, double* out_dist, int* out_err) {
-    extern __shared__ double smem[];
-    Smem m = carve(smem, A.n, A.E);
-    SmemMP mm = carve_mp(smem, A.n, A.E, A.P);
-    load_model(A, m);
-    load_model_mp(A, mm);
-    __syncthreads();
-    long long r = (long long)blockIdx.x * PF_BS + threadIdx.x;
-    if (r >= nrep) return;
-    const int n = A.n;
-    Lane ln = make_lane(A, m, rep0 + r);
-    MLane ml = make_mlane(A, mm);
-    ln.seed = seed;
-    ln.stream = 2;
-    ln.ebuf = -dlog(uni(ln));
-    mp_build_initial_tree(ln, ml, (PLog*)nullptr, [&](int, unsigned, unsigned, double) {});
-    double* orig = m.t0 + threadIdx.x;
-    int alive = n - 1;
-    for (int j = 0; j < n - 1; ++j) {
-        orig[j * PF_BS] = LS(ln, j);
-        out_epoch[r * (n - 1) + j] = epoch_of(ln, LS(ln, j));
-        out_dist[r * (n - 1) + j] = -1.0;
-    }
-    unsigned alive_mask = (1u << (n - 1)) - 1u;
-    double next = ml.err ? A.L : sample_next_base(ln, 0.0);
-    const double stop = A.L * 0.6;
-    while (alive > 0 && next < stop && !ml.err) {
-        double x = next;
-        int rp = 0, sb = 0;
-        double h, tc, sp;
-        bool changed;
-        sample_point(ln, &rp, &sb, &h);
-        mp_genealogy_rest(ln, ml, (PLog*)nullptr, -1, rp, sb, h, &tc, &sp, &changed);
-        if (ml.err) break;
-        if (changed) {
-            for (int j = 0; j < n - 1; ++j)
-                if (((alive_mask >> j) & 1u) && orig[j * PF_BS] == sp) {
-                    out_dist[r * (n - 1) + j] = x;
-                    alive_mask &= ~(1u << j);
-                    --alive;
-                    break;
-                }
-        }
-        next = sample_next_base(ln, x);
-    }
-    if (ml.err) *out_err = ml.err;
-}
-
 // ------------------------------------------------------------------ unit-test kernels
 __global__ void k_test_math(const double* x, long long n, double* oe, double* ol, double* of) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2219,7 +1554,7 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     const int P = m->n_pops;
     h->E = E; h->n = n; h->Np = Np; h->P = P;
     h->nblocks = (int)((Np + PF_BS - 1) / PF_BS);
-    h->smem = P > 1 ? smem_bytes_mp(n, E, P) : smem_bytes(n, E);
+    h->smem = P > 1 ? pf_mp_smem_bytes(n, E, P) : smem_bytes(n, E);
     h->max_trace_events = std::max(0, p->max_trace_events);
     h->force_lds = env_ll("SMCSMC_PF_FORCE_LDS", 0) != 0;
     h->h_lags.assign(m->lags, m->lags + E);
@@ -2331,13 +1666,14 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     rc |= dalloc(h, &A.ev_parents, (size_t)std::max(1, h->max_trace_events) * Np);
     rc |= dalloc(h, &A.ctrl, 1);
     if (rc) { pf_destroy(h); return nullptr; }
-    if (h->smem > 64 * 1024) {
+    if (P == 1 && h->smem > 64 * 1024) {
         hipFuncSetAttribute((const void*)k_extend, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem);
         hipFuncSetAttribute((const void*)k_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem);
-        hipFuncSetAttribute((const void*)k_extend_mp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem);
-        hipFuncSetAttribute((const void*)k_init_mp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem);
     }
-    if (h->smem > 160 * 1024) { pf_destroy(h); return fail("pf_create: the local-tree state does not fit the LDS of one workgroup"); }
+    if (h->smem > 160 * 1024 || (P > 1 && pf_mp_prepare(h->smem))) {
+        pf_destroy(h);
+        return fail("pf_create: the local-tree state does not fit the LDS of one workgroup");
+    }
     return h;
 }
 
@@ -2430,7 +1766,7 @@ int pf_sync(pf_handle* h) {
 int pf_init_prior(pf_handle* h, double initial_position) {
     HIPCHK(hipSetDevice(h->device));
     if (h->P > 1)
-        hipLaunchKernelGGL(k_init_mp, dim3(h->nblocks), dim3(PF_BS), h->smem, h->stream, h->A, initial_position);
+        pf_mp_launch_init(h->A, initial_position, h->smem, h->stream);
     else
         hipLaunchKernelGGL(k_init, dim3(h->nblocks), dim3(PF_BS), h->smem, h->stream, h->A, initial_position);
     if (check_launch("k_init")) return -1;
@@ -2504,7 +1840,7 @@ static int launch_extend(pf_handle* h, long long s) {
         const size_t smem_reg = (size_t)(2 * h->E + 2 * PF_BIAS_MAX + 3) * 8;
         const bool biased = h->A.n_bias > 0;
         if (h->P > 1)
-            hipLaunchKernelGGL(k_extend_mp, dim3(h->nblocks), dim3(PF_BS), h->smem, h->stream, h->A, s);
+            pf_mp_launch_extend(h->A, s, h->smem, h->stream);
         else if (h->n <= 4 && biased)
             hipLaunchKernelGGL((k_extend_reg<4, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s);
         else if (h->n <= 8 && biased)
@@ -2948,19 +2284,16 @@ int pf_median_survival(const pf_model* m, uint64_t seed, int32_t min_events, int
     std::vector<int> hep((size_t)PF_CAL_BATCH * (n - 1));
     std::vector<double> hdist((size_t)PF_CAL_BATCH * (n - 1));
     long long trees = 0;
-    const size_t smem = P > 1 ? smem_bytes_mp(n, E, P) : smem_bytes(n, E);
-    if (smem > 64 * 1024) {
-        hipFuncSetAttribute((const void*)k_calibrate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipFuncSetAttribute((const void*)k_calibrate_mp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    }
+    const size_t smem = P > 1 ? pf_mp_smem_bytes(n, E, P) : smem_bytes(n, E);
+    if (P > 1 && pf_mp_prepare(smem)) { g_err = "pf_median_survival: the local-tree state does not fit the LDS"; return -1; }
+    if (P == 1 && smem > 64 * 1024) hipFuncSetAttribute((const void*)k_calibrate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     int cal_err = 0;
     for (;;) {
         int not_done = 0;
         for (int e = 0; e < E; ++e) not_done += (int)surv[e].size() < min_events;
         if (not_done == 0 || trees >= max_trees) break;
         if (P > 1)
-            hipLaunchKernelGGL(k_calibrate_mp, dim3(PF_CAL_BATCH / PF_BS), dim3(PF_BS), smem, 0, A, (unsigned long long)seed, trees,
-                               (long long)PF_CAL_BATCH, dep, ddist, derr);
+            pf_mp_launch_calibrate(A, (unsigned long long)seed, trees, (long long)PF_CAL_BATCH, dep, ddist, derr, smem, 0);
         else
             hipLaunchKernelGGL(k_calibrate, dim3(PF_CAL_BATCH / PF_BS), dim3(PF_BS), smem, 0, A, (unsigned long long)seed, trees,
                                (long long)PF_CAL_BATCH, dep, ddist);

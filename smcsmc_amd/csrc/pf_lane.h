@@ -1,0 +1,170 @@
+// smcsmc_amd/csrc/pf_lane.h -- the per-lane LDS tree as the kernels use it: LDS carve-up, model tables,
+// the SMC' genealogy update, tracked branch length and site likelihood on the LDS tree.
+// Depends on PF_BS (the workgroup size = LDS stride of the per-lane columns), like pf_device.h.
+#pragma once
+#include "pf_device.h"
+#include "pf_types.h"
+
+using namespace pf;
+
+// LDS carve-up shared by k_init / k_extend
+struct Smem {
+    double* S; double* t0; double* t1; double* T; double* I; int* RF; int8_t* C;
+};
+__device__ __forceinline__ Smem carve(double* base, int n, int E) {
+    Smem m;
+    m.S = base;
+    m.t0 = m.S + (size_t)(n - 1) * PF_BS;
+    m.t1 = m.t0 + (size_t)(n - 1) * PF_BS;
+    m.T = m.t1 + (size_t)(n - 1) * PF_BS;
+    m.I = m.T + E;
+    m.RF = (int*)(m.I + E);
+    m.C = (int8_t*)(m.RF + E + (E & 1));
+    return m;
+}
+__host__ __device__ static size_t smem_bytes(int n, int E) {
+    return (size_t)3 * (n - 1) * PF_BS * 8 + (size_t)2 * E * 8 + (size_t)(E + (E & 1)) * 4 + (size_t)2 * (n - 1) * PF_BS;
+}
+
+__device__ __forceinline__ void load_model(const KArgs& A, Smem& m) {
+    for (int e = threadIdx.x; e < A.E; e += blockDim.x) {
+        m.T[e] = A.T[e];
+        m.I[e] = A.inv2N[e];
+        m.RF[e] = A.recflags[e];
+    }
+}
+
+__device__ __forceinline__ Lane make_lane(const KArgs& A, Smem& m, long long p) {
+    Lane ln;
+    ln.S = m.S + threadIdx.x;
+    ln.C = m.C + threadIdx.x;
+    ln.T = m.T; ln.I = m.I; ln.RF = m.RF;
+    ln.E = A.E; ln.n = A.n;
+    ln.L = A.L; ln.mu = A.mu; ln.rho = A.rho;
+    ln.seed = A.seed;
+    ln.slot = (unsigned)p;
+    ln.stream = 0;
+    ln.ctr = 0; ln.ebuf = 0; ln.Ltree = 0;
+    return ln;
+}
+
+// One genealogy update (SMC'): sample the recombination point, coalesce the floating lineage
+// against the old tree, re-attach.  Mirrors oracle Filter::genealogy_update step by step.
+__device__ __forceinline__ void sample_point(Lane& ln, int* rp_out, int* sb_out, double* h_out) {
+    const int n = ln.n;
+    double r = uni(ln) * ln.Ltree;
+    double prev = 0.0, h = 0.0;
+    int lin = 0;
+    for (int ri = 0; ri < n - 1; ++ri) {
+        int k = n - ri;
+        double sr = LS(ln, ri);
+        double d = sr - prev;
+        double seg = (double)k * d;
+        if (r < seg || ri == n - 2) {
+            double q = r / d;
+            lin = min((int)q, k - 1);
+            h = prev + (q - (double)lin) * d;
+            if (!(h < sr)) h = prev;
+            break;
+        }
+        r -= seg;
+        prev = sr;
+    }
+    lineages_at(ln, n - 1, h, lin, rp_out, sb_out);
+    *h_out = h;
+}
+
+__device__ __forceinline__ void genealogy_update(Lane& ln, double* h_out, double* tc_out, double* sp_out, bool* changed_out) {
+    const int n = ln.n;
+    int rp = 0, sb = 0;
+    double h;
+    sample_point(ln, &rp, &sb, &h);
+    *h_out = h;
+    double tc = coalesce_up(ln, [&](int k) { return LS(ln, k); }, n - 1, n, h);
+    *tc_out = tc;
+    double Sp = LS(ln, rp);
+    int b_id = LC(ln, rp, sb), s_id = LC(ln, rp, 1 - sb);
+    bool p_was_root = (rp == n - 2);
+    remove_rank(ln, n - 1, rp, s_id, &b_id, &s_id);
+    int ni = n - 2;
+    int troot = p_was_root ? s_id : n + (ni - 1);
+    int pr = -1, ps = 0;
+    int nslots = lineages_at(ln, ni, tc, -1, &pr, &ps);
+    bool has_root = tc >= node_h(ln, troot);
+    bool has_stub = tc < Sp;
+    int k = nslots + (has_root ? 1 : 0) + (has_stub ? 1 : 0);
+    double u = uni(ln);
+    int idx = min((int)(u * (double)k), k - 1);
+    *sp_out = Sp;
+    *changed_out = !(has_stub && idx == k - 1);
+    if (idx < nslots) {
+        lineages_at(ln, ni, tc, idx, &pr, &ps);
+        insert_node(ln, ni, tc, b_id, pr, ps, troot);
+    } else if (has_root && idx == nslots) {
+        insert_node(ln, ni, tc, b_id, -1, 0, troot);
+    } else {
+        if (p_was_root) {
+            insert_node(ln, ni, Sp, b_id, -1, 0, troot);
+        } else {
+            int want = -1, c = 0;
+            int R = 0;
+            while (R < ni && LS(ln, R) <= Sp) ++R;
+            for (int rr = R; rr < ni && want < 0; ++rr)
+                for (int s = 0; s < 2 && want < 0; ++s) {
+                    int id = LC(ln, rr, s);
+                    if (id < n || id - n < R) {
+                        if (id == s_id) want = c;
+                        ++c;
+                    }
+                }
+            lineages_at(ln, ni, Sp, want, &pr, &ps);
+            insert_node(ln, ni, Sp, b_id, pr, ps, troot);
+        }
+    }
+    ln.Ltree = tree_length(ln, n);
+}
+
+__device__ __forceinline__ double tracked_len_lane(const Lane& ln, const int8_t* data, double* tmp) {
+    // particle.cpp:699-730; tmp holds the per-internal-node values (stride PF_BS)
+    const int n = ln.n;
+    double total = 0.0;
+    for (int r = 0; r < n - 1; ++r) {
+        int c0 = LC(ln, r, 0), c1 = LC(ln, r, 1);
+        double sr = LS(ln, r);
+        double l = c0 < n ? (data[c0] >= 0 ? 0.0 : -1.0) : tmp[(c0 - n) * PF_BS];
+        double rr = c1 < n ? (data[c1] >= 0 ? 0.0 : -1.0) : tmp[(c1 - n) * PF_BS];
+        if (l >= 0.0) l += sr - node_h(ln, c0);
+        if (rr >= 0.0) rr += sr - node_h(ln, c1);
+        double v;
+        if (l >= 0.0 && rr >= 0.0) { total = l + rr; v = total; }
+        else if (l >= 0.0) v = l;
+        else v = rr;
+        tmp[r * PF_BS] = v;
+    }
+    return total;
+}
+
+__device__ __forceinline__ double site_lik_lane(const Lane& ln, unsigned one_mask, unsigned zero_mask, bool anc,
+                                                double* t0, double* t1) {
+    // particle.cpp:625-680.  Leaf i: L0 = (state==1 ? 0 : 1), L1 = (state==0 ? 0 : 1);
+    // one_mask bit i <=> state==1, zero_mask bit i <=> state==0 (missing: neither).
+    const int n = ln.n;
+    for (int r = 0; r < n - 1; ++r) {
+        int c0 = LC(ln, r, 0), c1 = LC(ln, r, 1);
+        double sr = LS(ln, r);
+        double tl = sr - node_h(ln, c0);
+        double trr = sr - node_h(ln, c1);
+        double pl = fastexp(-tl * ln.mu);
+        double pr = fastexp(-trr * ln.mu);
+        double a0, a1, b0, b1;
+        if (c0 < n) { a0 = (one_mask >> c0) & 1 ? 0.0 : 1.0; a1 = (zero_mask >> c0) & 1 ? 0.0 : 1.0; }
+        else { a0 = t0[(c0 - n) * PF_BS]; a1 = t1[(c0 - n) * PF_BS]; }
+        if (c1 < n) { b0 = (one_mask >> c1) & 1 ? 0.0 : 1.0; b1 = (zero_mask >> c1) & 1 ? 0.0 : 1.0; }
+        else { b0 = t0[(c1 - n) * PF_BS]; b1 = t1[(c1 - n) * PF_BS]; }
+        t0[r * PF_BS] = (a0 * pl + a1 * (1 - pl)) * (b0 * pr + b1 * (1 - pr));
+        t1[r * PF_BS] = (a1 * pl + a0 * (1 - pl)) * (b1 * pr + b0 * (1 - pr));
+    }
+    double p0 = anc ? 1.0 : 0.5, p1 = anc ? 0.0 : 0.5;
+    return t0[(n - 2) * PF_BS] * p0 + t1[(n - 2) * PF_BS] * p1;
+}
+

@@ -14,9 +14,8 @@
 // lineage and the events of the cut branch's stub carry the temporary branch tags below.
 #pragma once
 #include "pf_device.h"
+#include "pf_mp_host.h"
 
-#define PF_PMAX 4             // populations supported by the HIP path
-#define PF_MMAX 24            // migration events kept per local tree
 #define PF_TAG_PATH 120       // picked up by the floating lineage during this update
 #define PF_TAG_RPATH 121      // picked up by the root's lineage above the root
 #define PF_TAG_STUB 122       // on the cut branch above the cut
@@ -29,6 +28,7 @@ struct MLane {
     double* Mt;        // &sMt[tid]
     int8_t* Mb;        // &sMb[tid]
     int8_t* Mq;        // &sMq[tid]
+    int8_t* Bp;        // &sBp[tid]   scratch of the walk: current population of the lineage above every node id
     int nm;
     int P;
     const double* I2;  // [E*P]   1/(2 N_e,p)                 (LDS)
@@ -43,6 +43,7 @@ struct MLane {
 #define LMt(ml, m) ((ml).Mt[(m) * PF_BS])
 #define LMb(ml, m) ((ml).Mb[(m) * PF_BS])
 #define LMq(ml, m) ((ml).Mq[(m) * PF_BS])
+#define LBp(ml, id) ((ml).Bp[(id) * PF_BS])
 
 // coal/migr opportunity pieces of one genealogy update, written to the slot's piece ring (three words each):
 //   tag = epoch | pop << 8 | kind << 16 | to << 24   (kind bit0: coalescence at the end, bit1: migration to `to`)
@@ -163,14 +164,52 @@ struct MWalk { double tc; int pf, pr, weight; };
 __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int root_id, double h, int pf0, PLog* pl,
                                             int limit, MWalk& W) {
     const int P = ml.P;
+    const int n = ln.n;
     const double Hr = node_h(ln, root_id);
     double tt = h;
     int e = epoch_of(ln, tt);
     int i = 0, j = 0;
-    while (i < ni && LS(ln, i) <= tt) ++i;
-    while (j < ml.nm && LMt(ml, j) <= tt) ++j;
     int pf = pf0, pr = mp_pop_base(ln, ml, root_id);
     if (pl) { pl->fopen = false; pl->ropen = false; }
+    // Lineages of the stored tree per population, kept up to date while the walk moves up (the restatement
+    // recounts them in every interval; the numbers are the same).  Bp[id] = current population of the lineage
+    // above node id; a lineage is counted from its lower node until its parent node.
+    int cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
+    auto bump = [&](int q, int d) {
+        cnt0 += q == 0 ? d : 0; cnt1 += q == 1 ? d : 0; cnt2 += q == 2 ? d : 0; cnt3 += q == 3 ? d : 0;
+    };
+    auto count_of = [&](int q) { return q == 0 ? cnt0 : q == 1 ? cnt1 : q == 2 ? cnt2 : cnt3; };
+    for (int id = 0; id < n; ++id) LBp(ml, id) = (int8_t)ml.SP[id];
+    for (int r = 0; r < ni; ++r) LBp(ml, n + r) = LPn(ml, r);
+    while (i < ni && LS(ln, i) <= tt) ++i;
+    while (j < ml.nm && LMt(ml, j) <= tt) {
+        int b = LMb(ml, j);
+        if (b < PF_TAG_MIN) LBp(ml, b) = LMq(ml, j);
+        ++j;
+    }
+    for (int r = i; r < ni; ++r)
+        for (int s = 0; s < 2; ++s) {
+            int id = LC(ln, r, s);
+            if (id < n || id - n < i) bump(LBp(ml, id), 1);
+        }
+    // move the bookkeeping over every node / event boundary at or below the new time
+    auto advance = [&](double tnew) {
+        while (i < ni && LS(ln, i) <= tnew) {
+            bump(LBp(ml, LC(ln, i, 0)), -1);
+            bump(LBp(ml, LC(ln, i, 1)), -1);
+            if (i < ni - 1) bump(LPn(ml, i), 1);         // the top node's own lineage is the root lineage, not a slot
+            ++i;
+        }
+        while (j < ml.nm && LMt(ml, j) <= tnew) {
+            int b = LMb(ml, j);
+            if (b < PF_TAG_MIN) {
+                bump(LBp(ml, b), -1);
+                LBp(ml, b) = LMq(ml, j);
+                bump(LBp(ml, b), 1);
+            }
+            ++j;
+        }
+    };
     for (int guard = 0; guard < 100000; ++guard) {
         const bool root_active = tt >= Hr;
         double tn_node = i < ni ? LS(ln, i) : PF_INF;
@@ -178,8 +217,7 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
         double tn_ep = epoch_end(ln, e);
         double tn = tn_node < tn_mig ? tn_node : tn_mig;
         tn = tn < tn_ep ? tn : tn_ep;
-        int dr = 0, dsl = 0;
-        int k = mp_lineages_in_pop(ln, ml, ni, tt, pf, -1, &dr, &dsl);
+        int k = count_of(pf);
         int weight = k + ((root_active && pr == pf) ? 1 : 0);
         double rc = (double)weight * ml.I2[e * P + pf];
         double rmf = ml.MT[e * P + pf];
@@ -234,13 +272,12 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
             else { mp_ev_insert(ml, t1, PF_TAG_RPATH, to); pr = to; }
             if (ml.err) { W.tc = t1; W.pf = pf; W.pr = pr; W.weight = 0; return; }
             tt = t1;
-            while (j < ml.nm && LMt(ml, j) <= tt) ++j;
+            advance(tt);            // steps over the event just inserted (temporary tags are not lineages of the tree)
             continue;
         }
         ln.ebuf -= need;
         tt = tn;
-        while (i < ni && LS(ln, i) <= tt) ++i;
-        while (j < ml.nm && LMt(ml, j) <= tt) ++j;
+        advance(tt);
         if (tn_ep <= tn) {
             ++e;
             int q = ml.JM[e * P + pf];
@@ -250,7 +287,7 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
                 if (qr != pr) { mp_ev_insert(ml, tt, PF_TAG_RPATH, qr); pr = qr; }
             }
             if (ml.err) { W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
-            while (j < ml.nm && LMt(ml, j) <= tt) ++j;
+            advance(tt);
         }
     }
     ml.err = 3;

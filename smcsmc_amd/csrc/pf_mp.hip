@@ -1,0 +1,374 @@
+// smcsmc_amd/csrc/pf_mp.hip -- kernels for structured models (more than one population).
+//
+// Same structure as k_init / k_extend / k_calibrate of pf_hip.hip with the migration-aware genealogy update of
+// pf_mp.h.  Compiled as its own translation unit with 64-lane workgroups: the per-lane LDS columns (local
+// tree + up to PF_MMAX migration events) are large, and with at most a few hundred wavefronts per launch one
+// wavefront per workgroup spreads them over more compute units.
+#define PF_BS 64
+#include <hip/hip_runtime.h>
+
+#include "pf_device.h"
+#include "pf_types.h"
+#include "pf_lane.h"
+#include "pf_mp.h"
+#include "pf_mp_host.h"
+
+// ------------------------------------------------------------------ structured models (P > 1): LDS-tree kernels
+// Same structure as k_init / k_extend / k_calibrate with the migration-aware genealogy update of pf_mp.h.
+struct SmemMP { double* I2; double* MR; double* MT; double* Mt; int* JM; int* SP; int8_t* Pn; int8_t* Mb; int8_t* Mq; int8_t* Bp; };
+__host__ __device__ static size_t smem_mp_extra(int n, int E, int P) {
+    size_t dbl = (size_t)E * P * 2 + (size_t)E * P * P + (size_t)PF_MMAX * PF_BS;
+    size_t ints = (size_t)E * P + (size_t)((n + 1) & ~1) + (size_t)((E * P) & 1);
+    size_t bytes = (size_t)(n - 1) * PF_BS + (size_t)2 * PF_MMAX * PF_BS + (size_t)2 * n * PF_BS;
+    return dbl * 8 + ints * 4 + bytes;
+}
+static size_t smem_bytes_mp(int n, int E, int P) { return smem_bytes(n, E) + smem_mp_extra(n, E, P); }
+__device__ __forceinline__ SmemMP carve_mp(double* base, int n, int E, int P) {
+    SmemMP m;
+    m.I2 = (double*)((char*)base + smem_bytes(n, E));
+    m.MR = m.I2 + (size_t)E * P;
+    m.MT = m.MR + (size_t)E * P * P;
+    m.Mt = m.MT + (size_t)E * P;
+    m.JM = (int*)(m.Mt + (size_t)PF_MMAX * PF_BS);
+    m.SP = m.JM + (size_t)E * P + ((E * P) & 1);
+    m.Pn = (int8_t*)(m.SP + ((n + 1) & ~1));
+    m.Mb = m.Pn + (size_t)(n - 1) * PF_BS;
+    m.Mq = m.Mb + (size_t)PF_MMAX * PF_BS;
+    m.Bp = m.Mq + (size_t)PF_MMAX * PF_BS;
+    return m;
+}
+__device__ __forceinline__ void load_model_mp(const KArgs& A, SmemMP& m) {
+    const int EP = A.E * A.P;
+    for (int i = threadIdx.x; i < EP; i += blockDim.x) { m.I2[i] = A.inv2Np[i]; m.MT[i] = A.mig_tot[i]; m.JM[i] = A.join_map[i]; }
+    for (int i = threadIdx.x; i < EP * A.P; i += blockDim.x) m.MR[i] = A.mig_rate[i];
+    for (int i = threadIdx.x; i < A.n; i += blockDim.x) m.SP[i] = A.sample_pop[i];
+}
+__device__ __forceinline__ MLane make_mlane(const KArgs& A, SmemMP& m) {
+    MLane ml;
+    ml.Pn = m.Pn + threadIdx.x; ml.Mt = m.Mt + threadIdx.x; ml.Mb = m.Mb + threadIdx.x; ml.Mq = m.Mq + threadIdx.x; ml.Bp = m.Bp + threadIdx.x;
+    ml.nm = 0; ml.P = A.P;
+    ml.I2 = m.I2; ml.MR = m.MR; ml.MT = m.MT; ml.JM = m.JM; ml.SP = m.SP;
+    ml.err = 0;
+    return ml;
+}
+__device__ __forceinline__ void mp_report(const KArgs& A, const MLane& ml) {
+    if (ml.err == 1) A.ctrl->err = ERR_MIG_OVERFLOW;
+    if (ml.err == 2) A.ctrl->err = ERR_MP_INTERNAL;
+    if (ml.err == 3) A.ctrl->err = ERR_NO_COALESCENCE;
+}
+__device__ __forceinline__ double piece_ref(unsigned pstart, unsigned npieces) {
+    return __longlong_as_double((long long)((unsigned long long)pstart | ((unsigned long long)npieces << 32)));
+}
+__device__ __forceinline__ void store_mp_state(const KArgs& A, DState& st, const Lane& ln, const MLane& ml, long long p) {
+    const int n = A.n;
+    for (int r = 0; r < n - 1; ++r) st.Pn[(size_t)r * A.Np + p] = LPn(ml, r);
+    st.nm[p] = ml.nm;
+    for (int m = 0; m < ml.nm; ++m) {
+        st.Mt[(size_t)m * A.Np + p] = LMt(ml, m);
+        st.Mb[(size_t)m * A.Np + p] = LMb(ml, m);
+        st.Mq[(size_t)m * A.Np + p] = LMq(ml, m);
+    }
+}
+
+__global__ __launch_bounds__(PF_BS) void k_init_mp(KArgs A, double initial_position) {
+    extern __shared__ double smem[];
+    Smem m = carve(smem, A.n, A.E);
+    SmemMP mm = carve_mp(smem, A.n, A.E, A.P);
+    load_model(A, m);
+    load_model_mp(A, mm);
+    __syncthreads();
+    long long p = (long long)blockIdx.x * PF_BS + threadIdx.x;
+    if (p == 0) {
+        Ctrl* c = A.ctrl;
+        c->cur_pos = initial_position;
+        c->logl = 0; c->inv_T = 1; c->T = 1; c->flag = 0; c->cur = 0; c->gen = 0; c->n_resample = 0;
+        c->first_epoch = A.E; c->err = 0; c->delayed_opp = 0; c->delayed_count = 0; c->count_active = 0; c->end_seq = 0;
+        c->g_retain = 0; c->pending_fin = 0; c->nbx_used = A.nbx; c->gen_prev = 0; c->nres_prev = 0;
+        for (int e = 0; e < A.E; ++e) { c->counted_to[e] = 0; c->update_to[e] = 0; c->g_lo[e] = 0; c->g_hi[e] = 0; }
+        A.gen_x0[0] = 0.0;
+    }
+    if (p >= A.Np) return;
+    const int n = A.n;
+    Lane ln = make_lane(A, m, p);
+    MLane ml = make_mlane(A, mm);
+    ln.ebuf = -dlog(uni(ln));
+    unsigned widx = 0;
+    PLog pl;
+    pl.base = A.plog + (size_t)p * A.pcap * 3; pl.cap = A.pcap; pl.idx = 0; pl.on = true; pl.fopen = false; pl.ropen = false;
+    // every coalescence of the initial tree is logged as a type-2 record at position 0 (particle.cpp:251-300)
+    mp_build_initial_tree(ln, ml, &pl, [&](int i, unsigned p0, unsigned np_, double tc) {
+        double* rec = rec_ptr(A, p, widx);
+        rec[0] = 0.0; rec[1] = 0.0; rec[2] = 0.0;
+        rec[3] = piece_ref(p0, np_);
+        rec[4] = __longlong_as_double((long long)make_meta(2, A.E - 1, A.E - 1, i));
+        for (int r = 0; r < n - 1; ++r) rec[5 + r] = 0.0;
+        (void)tc;
+        ++widx;
+    });
+    mp_report(A, ml);
+    double nb = sample_next_base(ln, 0.0);
+    DState& st = A.st[0];
+    for (int r = 0; r < n - 1; ++r) {
+        st.S[(size_t)r * A.Np + p] = LS(ln, r);
+        st.C[(size_t)(2 * r) * A.Np + p] = LC(ln, r, 0);
+        st.C[(size_t)(2 * r + 1) * A.Np + p] = LC(ln, r, 1);
+    }
+    store_mp_state(A, st, ln, ml, p);
+    st.w_post[p] = 1.0 / (double)A.Np;
+    st.w_pilot[p] = 1.0 / (double)A.Np;
+    st.next_base[p] = nb;
+    st.x_mark[p] = 0.0;
+    st.Ltree[p] = ln.Ltree;
+    st.mark_limit[p] = A.E - 1;
+    A.rng_ctr[p] = ln.ctr;
+    A.ebuf[p] = ln.ebuf;
+    A.widx[p] = widx;
+    A.pidx[p] = pl.idx;
+    A.gstart[p] = 0;
+}
+
+__global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
+    extern __shared__ double smem[];
+    Smem m = carve(smem, A.n, A.E);
+    SmemMP mm = carve_mp(smem, A.n, A.E, A.P);
+    load_model(A, m);
+    load_model_mp(A, mm);
+    __syncthreads();
+    const Ctrl* c = A.ctrl;
+    const int n = A.n;
+    const int cur = c->cur;
+    const long long p = (long long)blockIdx.x * PF_BS + threadIdx.x;
+    const bool active = p < A.Np;
+    const int lane = threadIdx.x & 63;
+    double w_post = 0.0, w_pilot = 0.0;
+    if (active) {
+        DState& st = A.st[cur];
+        Lane ln = make_lane(A, m, p);
+        MLane ml = make_mlane(A, mm);
+        for (int r = 0; r < n - 1; ++r) {
+            LS(ln, r) = st.S[(size_t)r * A.Np + p];
+            LC(ln, r, 0) = st.C[(size_t)(2 * r) * A.Np + p];
+            LC(ln, r, 1) = st.C[(size_t)(2 * r + 1) * A.Np + p];
+            LPn(ml, r) = st.Pn[(size_t)r * A.Np + p];
+        }
+        ml.nm = st.nm[p];
+        for (int q = 0; q < ml.nm; ++q) {
+            LMt(ml, q) = st.Mt[(size_t)q * A.Np + p];
+            LMb(ml, q) = st.Mb[(size_t)q * A.Np + p];
+            LMq(ml, q) = st.Mq[(size_t)q * A.Np + p];
+        }
+        w_post = st.w_post[p];
+        w_pilot = st.w_pilot[p];
+        double next_base = st.next_base[p];
+        double x_mark = st.x_mark[p];
+        int mark_limit = st.mark_limit[p];
+        ln.Ltree = st.Ltree[p];
+        ln.ctr = A.rng_ctr[p];
+        ln.ebuf = A.ebuf[p];
+        unsigned widx = A.widx[p];
+        PLog pl;
+        pl.base = A.plog + (size_t)p * A.pcap * 3; pl.cap = A.pcap; pl.idx = A.pidx[p]; pl.on = true;
+        pl.fopen = false; pl.ropen = false;
+        double* tmp0 = m.t0 + threadIdx.x;
+        double* tmp1 = m.t1 + threadIdx.x;
+
+        const int8_t* data = A.seg_alleles + (size_t)s * n;
+        const double seg_end = A.seg_start[s] + A.seg_len[s];
+        const double extend_to = seg_end < A.L ? seg_end : A.L;
+        const int limit = A.seg_limit[s];
+        int missing = 0;
+        for (int i = 0; i < n; ++i) missing += data[i] == -1;
+        int leaf_status = 0;
+        if (missing == 0) leaf_status = 1;
+        if (missing == n) leaf_status = -1;
+
+        double updated_to = c->cur_pos;
+        double B;
+        if (leaf_status == -1) B = 0;
+        else if (leaf_status == 1) B = ln.Ltree;
+        else B = tracked_len_lane(ln, data, tmp0);
+
+        while (updated_to < extend_to) {
+            double new_to = extend_to < next_base ? extend_to : next_base;
+            double f = fastexp(-A.mu * B * (new_to - updated_to));
+            w_post *= f;
+            w_pilot *= f;
+            updated_to = new_to;
+            if (updated_to < extend_to) {
+                double* rec = rec_ptr(A, p, widx);
+                rec[0] = x_mark;
+                rec[1] = updated_to;
+                for (int r = 0; r < n - 1; ++r) rec[5 + r] = LS(ln, r);
+                int rp = 0, sb = 0;
+                double h, tc, sp_removed;
+                bool changed;
+                sample_point(ln, &rp, &sb, &h);
+                unsigned p0 = pl.idx;
+                mp_genealogy_rest(ln, ml, &pl, limit, rp, sb, h, &tc, &sp_removed, &changed);
+                rec[2] = h;
+                rec[3] = piece_ref(p0, pl.idx - p0);
+                rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n));
+                ++widx;
+                if (ml.err) break;
+                if (leaf_status == 0) B = tracked_len_lane(ln, data, tmp0);
+                if (leaf_status == 1) B = ln.Ltree;
+                next_base = sample_next_base(ln, updated_to);
+                x_mark = updated_to;
+                mark_limit = limit;
+            }
+        }
+        mp_report(A, ml);
+
+        if (A.seg_state[s] == 0) {
+            // update_weight_at_site: marginalise over phasings of unphased hets (pc.cpp:138-224)
+            const bool dephase = A.flags & 2;
+            const bool anc = A.flags & 1;
+            unsigned one_mask = 0, zero_mask = 0, het_pairs = 0;
+            int ncfg = 1;
+            for (int i = 0; i < n; ++i) {
+                if (data[i] == 1) one_mask |= 1u << i;
+                if (data[i] == 0) zero_mask |= 1u << i;
+            }
+            for (int i = 0; i + 1 < n; i += 2) {
+                bool het = (data[i] == 2) || (dephase && data[i] + data[i + 1] == 1);
+                if (het) {
+                    ncfg *= 2;
+                    het_pairs |= 1u << i;
+                    one_mask &= ~(3u << i); zero_mask &= ~(3u << i);
+                    zero_mask |= 1u << i;
+                    one_mask |= 1u << (i + 1);
+                }
+            }
+            double norm = 1.0 / (double)ncfg;
+            double lik = 0;
+            for (;;) {
+                lik += site_lik_lane(ln, one_mask, zero_mask, anc, tmp0, tmp1);
+                if (ncfg == 1) break;
+                bool more = false;
+                for (int i = 0; i + 1 < n; i += 2) {
+                    if (!((het_pairs >> i) & 1)) continue;
+                    if ((zero_mask >> i) & 1) {
+                        zero_mask &= ~(1u << i); one_mask |= 1u << i;
+                        one_mask &= ~(1u << (i + 1)); zero_mask |= 1u << (i + 1);
+                        more = true;
+                        break;
+                    }
+                    one_mask &= ~(1u << i); zero_mask |= 1u << i;
+                    zero_mask &= ~(1u << (i + 1)); one_mask |= 1u << (i + 1);
+                }
+                if (!more) break;
+            }
+            lik *= norm;
+            w_post *= lik;
+            w_pilot *= lik;
+        }
+
+        for (int r = 0; r < n - 1; ++r) {
+            st.S[(size_t)r * A.Np + p] = LS(ln, r);
+            st.C[(size_t)(2 * r) * A.Np + p] = LC(ln, r, 0);
+            st.C[(size_t)(2 * r + 1) * A.Np + p] = LC(ln, r, 1);
+        }
+        store_mp_state(A, st, ln, ml, p);
+        st.w_post[p] = w_post;
+        st.w_pilot[p] = w_pilot;
+        st.next_base[p] = next_base;
+        st.x_mark[p] = x_mark;
+        st.mark_limit[p] = mark_limit;
+        st.Ltree[p] = ln.Ltree;
+        A.rng_ctr[p] = ln.ctr;
+        A.ebuf[p] = ln.ebuf;
+        A.widx[p] = widx;
+        A.pidx[p] = pl.idx;
+        for (int r = 0; r < n - 1; ++r) A.snap_S[A.sp][(size_t)r * A.Np + p] = LS(ln, r);
+        A.snap_w[A.sp][p] = w_post; A.snap_xm[A.sp][p] = x_mark; A.snap_ml[A.sp][p] = mark_limit; A.snap_widx[A.sp][p] = widx;
+    }
+    double sp = wave_tree_sum(w_post);
+    double sq = wave_tree_sum(w_pilot * w_pilot);
+    double sc = wave_hs_scan(w_pilot, lane);
+    double scp = wave_hs_scan(w_post, lane);
+    double scm = wave_max_scan_d(sc, lane);
+    long long chunk = p >> 6;
+    if (active) { A.scan1[p] = sc; A.scanp2[A.sp][p] = scp; A.scan1m[p] = scm; }
+    if (lane == 63 && chunk < (A.Np + 63) / 64) {
+        A.chunk_post[chunk] = sp;
+        A.chunk_sq[chunk] = sq;
+        A.chunk_pil[chunk] = sc;
+        A.chunk_pp[chunk] = scp;
+        A.chunk_mx1[chunk] = scm;
+    }
+}
+
+__global__ __launch_bounds__(PF_BS) void k_calibrate_mp(KArgs A, unsigned long long seed, long long rep0, long long nrep,
+                                                        int* out_epoch, double* out_dist, int* out_err) {
+    extern __shared__ double smem[];
+    Smem m = carve(smem, A.n, A.E);
+    SmemMP mm = carve_mp(smem, A.n, A.E, A.P);
+    load_model(A, m);
+    load_model_mp(A, mm);
+    __syncthreads();
+    long long r = (long long)blockIdx.x * PF_BS + threadIdx.x;
+    if (r >= nrep) return;
+    const int n = A.n;
+    Lane ln = make_lane(A, m, rep0 + r);
+    MLane ml = make_mlane(A, mm);
+    ln.seed = seed;
+    ln.stream = 2;
+    ln.ebuf = -dlog(uni(ln));
+    mp_build_initial_tree(ln, ml, (PLog*)nullptr, [&](int, unsigned, unsigned, double) {});
+    double* orig = m.t0 + threadIdx.x;
+    int alive = n - 1;
+    for (int j = 0; j < n - 1; ++j) {
+        orig[j * PF_BS] = LS(ln, j);
+        out_epoch[r * (n - 1) + j] = epoch_of(ln, LS(ln, j));
+        out_dist[r * (n - 1) + j] = -1.0;
+    }
+    unsigned alive_mask = (1u << (n - 1)) - 1u;
+    double next = ml.err ? A.L : sample_next_base(ln, 0.0);
+    const double stop = A.L * 0.6;
+    while (alive > 0 && next < stop && !ml.err) {
+        double x = next;
+        int rp = 0, sb = 0;
+        double h, tc, sp;
+        bool changed;
+        sample_point(ln, &rp, &sb, &h);
+        mp_genealogy_rest(ln, ml, (PLog*)nullptr, -1, rp, sb, h, &tc, &sp, &changed);
+        if (ml.err) break;
+        if (changed) {
+            for (int j = 0; j < n - 1; ++j)
+                if (((alive_mask >> j) & 1u) && orig[j * PF_BS] == sp) {
+                    out_dist[r * (n - 1) + j] = x;
+                    alive_mask &= ~(1u << j);
+                    --alive;
+                    break;
+                }
+        }
+        next = sample_next_base(ln, x);
+    }
+    if (ml.err) *out_err = ml.err;
+}
+
+
+// ------------------------------------------------------------------ launchers (called from pf_hip.hip)
+size_t pf_mp_smem_bytes(int n, int E, int P) { return smem_bytes_mp(n, E, P); }
+
+int pf_mp_prepare(size_t smem) {
+    if (smem > 160 * 1024) return -1;
+    if (smem > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)k_extend_mp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void*)k_init_mp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void*)k_calibrate_mp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
+    }
+    return 0;
+}
+static unsigned mp_blocks(long long n) { return (unsigned)((n + PF_BS - 1) / PF_BS); }
+void pf_mp_launch_init(const KArgs& A, double initial_position, size_t smem, hipStream_t st) {
+    hipLaunchKernelGGL(k_init_mp, dim3(mp_blocks(A.Np)), dim3(PF_BS), smem, st, A, initial_position);
+}
+void pf_mp_launch_extend(const KArgs& A, long long s, size_t smem, hipStream_t st) {
+    hipLaunchKernelGGL(k_extend_mp, dim3(mp_blocks(A.Np)), dim3(PF_BS), smem, st, A, s);
+}
+void pf_mp_launch_calibrate(const KArgs& A, unsigned long long seed, long long rep0, long long nrep, int* out_epoch,
+                            double* out_dist, int* out_err, size_t smem, hipStream_t st) {
+    hipLaunchKernelGGL(k_calibrate_mp, dim3(mp_blocks(nrep)), dim3(PF_BS), smem, st, A, seed, rep0, nrep, out_epoch, out_dist,
+                       out_err);
+}

@@ -1,0 +1,15 @@
+// smcsmc_amd/csrc/pf_mp_host.h -- host-side entry points of the structured-model kernels (pf_mp.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pf_types.h"
+
+#define PF_PMAX 4             // populations supported by the HIP path
+#define PF_MMAX 96            // migration events kept per local tree
+
+size_t pf_mp_smem_bytes(int n, int E, int P);
+int pf_mp_prepare(size_t smem);      // raises the dynamic-LDS limit of the kernels; -1 if the state does not fit
+void pf_mp_launch_init(const KArgs& A, double initial_position, size_t smem, hipStream_t st);
+void pf_mp_launch_extend(const KArgs& A, long long s, size_t smem, hipStream_t st);
+void pf_mp_launch_calibrate(const KArgs& A, unsigned long long seed, long long rep0, long long nrep, int* out_epoch,
+                            double* out_dist, int* out_err, size_t smem, hipStream_t st);

@@ -1,0 +1,180 @@
+// smcsmc_amd/csrc/pf_types.h -- structures shared by the host code and all kernels of the particle filter
+// (device-visible state, per-step control block, kernel argument block, event-log record helpers).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#define PF_EMAX 64
+#define PF_DCAP 32            // pending delayed factors per particle (the reference's heap is unbounded)
+#define PF_BIAS_MAX 8         // interior bias heights
+#define PF_DECIDE_TAB 16384   // offspring / parent tables fit LDS (16-bit entries) up to this many particles
+#define PF_LEDGER_BLOCKS 192   // extra workgroups of k_resample that maintain the ancestor ledger
+#define REC_RECOMB 1
+#define REC_COALMIGR 2
+
+// ------------------------------------------------------------------ device-visible structures
+struct DState {
+    double* S;        // [(n-1)][Np]
+    int8_t* C;        // [2(n-1)][Np]
+    double* w_post;   // [Np]
+    double* w_pilot;
+    double* next_base;
+    double* x_mark;
+    double* Ltree;
+    int* mark_limit;
+    // delayed importance factors (particle.hpp:59-101, 185-209); allocated only with focused sampling
+    double* total_delayed;   // [Np]
+    int* dcount;             // [Np]
+    double* dpos;            // [PF_DCAP][Np] application positions
+    double* dfac;            // [PF_DCAP][Np]
+    double* ddelta;          // [PF_DCAP][Np]
+    int* dk;                 // [PF_DCAP][Np]
+    // structured models (pf_mp.h); allocated only when P > 1
+    int8_t* Pn;              // [(n-1)][Np] population of every coalescent node
+    int* nm;                 // [Np] migration events on the local tree
+    double* Mt;              // [PF_MMAX][Np]
+    int8_t* Mb;              // [PF_MMAX][Np]
+    int8_t* Mq;              // [PF_MMAX][Np]
+};
+
+struct Ctrl {
+    double cur_pos;        // site_where_weight_was_updated_ (same for every particle)
+    double logl;           // ln_normalization_factor_
+    double inv_T, T, S1, S2, ess, u;
+    double delayed_opp;
+    double delayed_count;
+    double counted_to[PF_EMAX];
+    double update_to[PF_EMAX];
+    long long n_resample;
+    int flag;              // resample at this segment?
+    int cur;               // index of the live state buffer
+    int gen;               // current generation (number of resampling events so far)
+    int first_epoch;       // first epoch updated by the current count step (E = none)
+    int g_retain;          // oldest generation whose run list is still maintained
+    int g_lo[PF_EMAX];     // generation containing counted_to[e]
+    int g_hi[PF_EMAX];     // generation containing update_to[e] of the current count step
+    int err;               // sticky error code
+    int count_active;
+    int end_seq;
+    int pending_fin;       // k_count partials of the previous step still have to be folded into the totals
+    long long nres_prev;   // n_resample as of the end of the last k_resample (stable during k_decide)
+    // what the counting stream needs to know about a step, double-buffered by step parity
+    struct StepInfo { double inv_T; int G; int flag; } step[2];
+    int gen_prev;          // generation index as of the end of the last k_resample (stable during k_decide)
+    int nbx_used;
+};
+
+struct KArgs {
+    // model
+    int E, n, flags;
+    double L, mu, rho;
+    const double* T;
+    const double* inv2N;
+    const double* lags;
+    const int* recflags;
+    // structured models: P populations
+    int P, ncol;                   // ncol = statistics per epoch (6 when P == 1)
+    const double* inv2Np;          // [E*P]
+    const double* mig_rate;        // [E*P*P]
+    const double* mig_tot;         // [E*P]
+    const int* join_map;           // [E*P]
+    const int* sample_pop;         // [n]
+    double* plog;                  // coal/migr opportunity pieces: plog[(p*pcap + k%pcap)*3 .. +3)
+    unsigned pcap;
+    unsigned* pidx;                // slot-owned: pieces ever written by this slot
+    // run parameters
+    long long Np;
+    double ess_threshold;
+    unsigned long long seed;
+    // focused sampling
+    int n_bias, delay_type;
+    double bias_H[PF_BIAS_MAX + 2];
+    double bias_S[PF_BIAS_MAX + 1];
+    const double* app_delays;
+    int* chunk_dpend;              // [nc] particles with pending delayed factors, per wavefront
+    double delayed_count_unused;
+    // state
+    DState st[2];
+    unsigned long long* rng_ctr;   // slot-owned
+    double* ebuf;                  // slot-owned
+    unsigned* widx;                // slot-owned: records ever appended by this slot
+    // event log: rec[(p*cap + k%cap)*RS .. +RS)
+    double* log;
+    unsigned cap;
+    int RS;
+    // ancestor ledger (rings of Gcap generations)
+    int Gcap;
+    unsigned* gstart;              // [Gcap][Np]  widx at the start of generation g
+    int* lo;                       // [Gcap][Np+1] offspring ranges of resampling event r (between gen r and r+1)
+    double* gen_x0;                // [Gcap] position where generation g starts
+    int* parent;                   // [Np] parent slot of every new slot at the current resampling event
+    int* blkcnt;                   // [nblocks] survivors per particle workgroup at the current resampling event
+    // run-length encoded composite ancestor maps: generation g's list maps the slots of the
+    // current generation to slots of generation g: run i covers [run_st[i], run_st[i+1]) -> run_anc[i]
+    int* run_st;                   // [Gcap][Np]
+    int* run_anc;                  // [Gcap][Np]
+    int* nruns;                    // [Gcap]
+    // per-wavefront partials written by k_extend
+    double* chunk_post;            // [nc]
+    double* chunk_sq;
+    double* chunk_pil;
+    double* scan1;                 // [Np] within-wavefront inclusive scan of the pilot weights
+    double* chunk_off;             // [nc]
+    double* l2scan;                // [nc]
+    double* scanp2[2];             // [Np] within-wavefront inclusive scan of the posterior weights (by step parity)
+    // snapshot of what k_count needs from the live particles of a step (by step parity): the counting stream
+    // runs concurrently with k_resample / the next k_extend, which rewrite the live state
+    double* snap_w[2];             // [Np] raw posterior weight
+    double* snap_S[2];             // [(n-1)][Np]
+    double* snap_xm[2];            // [Np] x_mark
+    int* snap_ml[2];               // [Np] mark_limit
+    unsigned* snap_widx[2];        // [Np]
+    int sp;                        // parity of the step this launch belongs to (set by the host per launch)
+    double* scan1m;                // [Np] running max of scan1 inside the wavefront
+    double* chunk_mx1;             // [nc] max of scan1 per wavefront
+    double* chunk_pp;              // [nc] its per-wavefront totals
+    double* chunk_offp2[2];        // [nc] exclusive offsets of the posterior scan (by step parity)
+    double* l2scanp;               // [nc]
+    // counting
+    double* totals;                // [6][E]
+    double* partial;               // [E][nbx][6]
+    int nbx;
+    // segments
+    const double* seg_start;
+    const double* seg_len;
+    const int8_t* seg_state;
+    const int8_t* seg_alleles;
+    const int* seg_limit;
+    // traces
+    double* tr_T;
+    double* tr_ess;
+    double* tr_logl;
+    int* tr_flag;
+    int* ev_seg;
+    int* ev_parents;
+    int max_trace_events;
+    Ctrl* ctrl;
+};
+
+// Count windows of one step (count.cpp:363-385).  The rule depends only on segment positions and lags,
+// so the host evaluates it (host_first_epoch) and hands the result to the kernels by value.
+struct Windows {
+    int first;                 // first epoch that updates (E = none)
+    int end_data;
+    double a[PF_EMAX];         // counted_to before this step
+    double b[PF_EMAX];         // update_to of this step
+};
+
+enum { ERR_LOG_OVERFLOW = 1, ERR_GEN_OVERFLOW = 2, ERR_ZERO_PROB = 3, ERR_COUNT_MISMATCH = 4, ERR_MIG_OVERFLOW = 5,
+       ERR_MP_INTERNAL = 6, ERR_NO_COALESCENCE = 7 };
+
+__device__ __forceinline__ unsigned long long make_meta(int type, int lim_start, int lim_event, int n_eff) {
+    return (unsigned long long)(type & 0xff) | ((unsigned long long)((lim_start + 1) & 0xff) << 8) |
+           ((unsigned long long)((lim_event + 1) & 0xff) << 16) | ((unsigned long long)(n_eff & 0xff) << 24);
+}
+
+__device__ __forceinline__ double* rec_ptr(const KArgs& A, long long p, unsigned k) {
+    return A.log + ((size_t)p * A.cap + (k % A.cap)) * A.RS;
+}
+

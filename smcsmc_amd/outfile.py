@@ -29,22 +29,36 @@ def format_row(em_step, epoch, begin, end, event_type, from_pop, to_pop, opportu
 
 
 def outfile_text(model, counts, np_particles, em_step=0):
-    """The whole .out file for a one-population model from the packed counts of ParticleFilter.counts()."""
+    """The whole .out file from the counts of ParticleFilter.counts() (any number of populations)."""
+    import numpy as np
     ct = list(model["change_times"])
-    ps = list(model["pop_sizes"])
     E = len(ct)
+    P = int(model.get("n_pops", 1))
+    ps = np.asarray(model["pop_sizes"], float).reshape(E, P)
     rho = model["recombination_rate"]
+    end = lambda e: 1e+99 if e == E - 1 else ct[e + 1]      # noqa: E731
+    co = np.asarray(counts["coal_opp"]).reshape(E, P)
+    cc = np.asarray(counts["coal_count"]).reshape(E, P)
+    cw = np.asarray(counts["coal_weight"]).reshape(E, P)
     out = [HEADER]
     for e in range(E):
-        out.append(format_row(em_step, e, ct[e], 1e+99 if e == E - 1 else ct[e + 1], "Coal", 0, -1,
-                              counts["coal_opp"][e] + 1.0, counts["coal_count"][e] + 1.0 / (2.0 * ps[e]),
-                              counts["coal_weight"][e] + 1.0))
+        for a in range(P):
+            out.append(format_row(em_step, e, ct[e], end(e), "Coal", a, -1, co[e, a] + 1.0,
+                                  cc[e, a] + 1.0 / (2.0 * ps[e, a]), cw[e, a] + 1.0))
     ropp = rcount = rweight = 0.0
     for e in range(E):
         ropp += counts["rec_opp"][e] + 1.0
         rcount += counts["rec_count"][e] + rho
         rweight += counts["rec_weight"][e] + 1.0
     out.append(format_row(em_step, -1, 0.0, 1e+99, "Recomb", -1, -1, ropp, rcount, rweight))
+    if P > 1:
+        mr = np.asarray(model["mig_rates"], float).reshape(E, P, P)
+        for e in range(E):
+            for a in range(P):
+                for b in range(P):
+                    if a != b:
+                        out.append(format_row(em_step, e, ct[e], end(e), "Migr", a, b, counts["mig_opp"][e, a] + 1.0,
+                                              counts["mig_count"][e, a, b] + mr[e, a, b], counts["mig_weight"][e, a] + 1.0))
     dopp = counts["delayed_opp"]
     out.append(format_row(em_step, -1, 0.0, 1e+99, "Delay", -1, -1, dopp, counts["delayed_count"] / np_particles, dopp))
     out.append(format_row(em_step, -1, 0.0, 1e+99, "Resamp", -1, -1, dopp, counts["resample_count"], dopp))

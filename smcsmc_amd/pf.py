@@ -287,7 +287,7 @@ class ParticleFilter:
         self._chk(self.L.pf_get_counts(self.h, out.ctypes.data, len(out)))
         return unpack_counts(out, self.E, self.P)
 
-    def migrations(self, cap=24):
+    def migrations(self, cap=96):
         """Migration events on every particle's local tree and the population of every coalescent node."""
         n = self.nsam
         nm = np.zeros(self.Np, np.int32); t = np.zeros((self.Np, cap)); b = np.zeros((self.Np, cap), np.int8)

@@ -82,8 +82,9 @@ def make_structured(model, P=2, split_epoch=None, mig=1.0, N0=1e4, sample_pops=N
                 for b in range(P):
                     if a != b:
                         mr[e, a, b] = mig / (4.0 * N0)
-    for a in range(1, P):
-        sm[split_epoch, a, 0] = 1.0
+    if split_epoch < E:
+        for a in range(1, P):
+            sm[split_epoch, a, 0] = 1.0
     m.update(n_pops=P, pop_sizes=ps, mig_rates=mr, single_mig=sm,
              sample_pops=list(sample_pops) if sample_pops is not None else [i * P // n for i in range(n)])
     return m

@@ -69,8 +69,28 @@ def outfile():
     return rows
 
 
+def seg_prefix(src_rel, dst_name, limit):
+    """First `limit` bp of one of the reference's committed scrm data sets (a data fixture of its own tests),
+    closed with an all-missing row at the cut like convert_scrm_to_seg does (populationmodels.py:535-575)."""
+    src = os.path.join(REF, src_rel)
+    out = []
+    nsam = None
+    for line in open(src):
+        f = line.rstrip("\n").split("\t")
+        start, length = int(f[0]), int(f[1])
+        nsam = len(f[-1])
+        if start + length > limit:
+            break
+        out.append(line)
+    end = int(out[-1].split("\t")[0]) + int(out[-1].split("\t")[1])
+    if end < limit:
+        out.append("%d\t%d\tT\tF\t1\t%s\n" % (end, limit - end, "." * nsam))
+    open(os.path.join(HERE, "seg", dst_name), "w").write("".join(out))
+
+
 if __name__ == "__main__":
     pm = load_ref()
+    seg_prefix("test/old/newtests/testdata/twopopssplit_unidirmigr.seg", "twopopssplit_unidirmigr_first2Mb.seg", 2000001)
     json.dump(cmdlines(pm), open(os.path.join(HERE, "cmdlines.json"), "w"), indent=1)
     if os.path.exists(os.path.join(HERE, "sample.out")):
         json.dump(outfile(), open(os.path.join(HERE, "outfile.json"), "w"), indent=1)

@@ -224,7 +224,7 @@ class Oracle:
         self._chk(self.L.smco_get_counts(self.h, out.ctypes.data, len(out)))
         return unpack_counts(out, E, P)
 
-    def migrations(self, cap=24):
+    def migrations(self, cap=96):
         n = self.inp.nsam
         nm = np.zeros(self.Np, np.int32); t = np.zeros((self.Np, cap)); b = np.zeros((self.Np, cap), np.int8)
         q = np.zeros((self.Np, cap), np.int8); npop = np.zeros((self.Np, n - 1), np.int8)

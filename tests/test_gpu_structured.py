@@ -107,8 +107,8 @@ def test_structured_prior_recovers_model(hiplib):
     segs = cases.nodata_segments(model, 4000.0)
     g = ParticleFilter(model, 4096, seed=3); g.init_prior(0.0); g.load_segments(segs); g.run(); g.finish()
     c = g.counts()
-    coal = c["coal_count"] / c["coal_opp"] * 2 * N0
-    mig = c["mig_count"].sum(2) / c["mig_opp"] * 4 * N0
+    coal = c["coal_count"] / np.maximum(c["coal_opp"], 1e-300) * 2 * N0
+    mig = c["mig_count"].sum(2) / np.maximum(c["mig_opp"], 1e-300) * 4 * N0
     # counts are posterior means per particle: 4096 independent prior ARGs stand behind every unit
     ok = c["coal_count"] > 20
     assert ok.sum() >= 6
@@ -137,3 +137,57 @@ def test_structured_without_a_way_to_coalesce_fails_loudly(hiplib):
     g.init_prior(0.0)
     with pytest.raises(PfError, match="No final coalescence"):
         g.sync()
+
+
+def test_structured_binary_end_to_end(hiplib, tmp_path):
+    """The drop-in binary on the reference's own two-population scrm data (first 2 Mb of
+    test/old/newtests/testdata/twopopssplit_unidirmigr.seg: 4+4 haplotypes, split at 0.5, migration 0.2) with
+    the kind of command line the front-end emits for test_two_pops.py:55-72.  Its .out must equal, character for
+    character, the table written from the same run through the python binding, carry Coal rows per population
+    and Migr rows, and the one-step estimates must sit near the simulation truth."""
+    import json
+    import os
+    import subprocess
+    from smcsmc_amd import ParticleFilter, outfile, segments as segmod
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    binary = os.path.join(root, "bin", "smcsmc")
+    if not os.path.exists(binary):
+        from smcsmc_amd import build
+        build.build_all()
+    seg = os.path.join(root, "tests", "golden", "seg", "twopopssplit_unidirmigr_first2Mb.seg")
+    L = 2000000
+    core = ("-N0 10000 -t %g -r %g %d -I 2 4 4 -eN 0.0 1.0 -ema 0.0 0 0.2 0.2 0 -eN 0.1 1.0 -ema 0.1 0 0.2 0.2 0 "
+            "-eN 0.5 1.0 -ema 0.5 0 0 0 0 -ej 0.5 2 1" % (4e4 * 2.5e-8 * L, 4e4 * 1e-8 * L, L)).split()
+    common = ["-nsam", "8", "-EM", "0", "-tmax", "4", "-seg", seg]
+    r = subprocess.run([binary] + core + common + ["-Np", "1000", "-lag", "50000", "-seed", "5", "-o", str(tmp_path / "run")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    text = open(tmp_path / "run.out").read()
+    m = json.loads(subprocess.run([binary] + core + ["-nsam", "8", "-tmax", "4", "-dumpmodel"], capture_output=True, text=True).stdout)
+    E = len(m["change_times"])
+    assert m["npop"] == 2 and m["sample_pops"] == [0, 0, 0, 0, 1, 1, 1, 1] and E == 3
+    mig = np.array(m["mig_rates"]).reshape(E, 2, 2); smig = np.array(m["single_mig"]).reshape(E, 2, 2)
+    assert mig[0, 0, 1] == pytest.approx(0.2 / 4e4) and mig[2].sum() == 0 and smig[2, 1, 0] == 1.0 and smig[:2].sum() == 0
+    model = dict(change_times=np.array(m["change_times"]), pop_sizes=np.array(m["pop_sizes"]), lags=np.full(E, 50000.0),
+                 nsam=8, loci_length=float(L), mutation_rate=m["mutation_rate"], recombination_rate=m["recombination_rate"],
+                 n_pops=2, mig_rates=mig, single_mig=smig, sample_pops=m["sample_pops"])
+    S = segmod.Segments(seg, 8, L, max_segment_length=int(2.0 / (m["recombination_rate"] * 4 * m["N0"])))
+    segs = S.pack(model["lags"])
+    g = ParticleFilter(model, 1000, seed=5, max_trace_events=0)
+    g.init_prior(segs["start"][0]); g.load_segments(segs); g.run(); g.finish()
+    assert outfile.outfile_text(model, g.counts(), 1000) == text
+    data = outfile.parse_outfile(text, is_text=True)
+    assert data[(("LogL", -1, -1, -1, -1), "Count")] == pytest.approx(g.logl(), rel=1e-7)
+    assert (("Migr", 0, 0, 1, -1), "Count") in data and (("Migr", 1, 1, 0, -1), "Opp") in data
+    # one E-step from the truth stays near the truth (2 Mb of data: generous ranges)
+    for key in [("Coal", 1, 0, -1, -1), ("Coal", 1, 1, -1, -1), ("Coal", 2, 0, -1, -1)]:
+        ne = data[(key, "Opp")] / (2 * data[(key, "Count")])
+        assert 6000 < ne < 16000, (key, ne)
+    rec = data[(("Recomb", -1, -1, -1, -1), "Count")] / data[(("Recomb", -1, -1, -1, -1), "Opp")]
+    assert 0.8e-8 < rec < 1.25e-8
+    assert data[(("Migr", 2, 0, 1, -1), "Count")] == 0                      # after the join
+    # default (calibrated) lags: the calibration kernel handles the structured model too
+    r = subprocess.run([binary] + core + common + ["-Np", "200", "-seed", "3", "-o", str(tmp_path / "cal")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Migr" in open(tmp_path / "cal.out").read()

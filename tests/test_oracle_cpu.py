@@ -221,3 +221,91 @@ def test_delayed_factor_schedule(oracle):
     p = o.particles()
     ratio = p["w_post"] / p["w_pilot"]       # = product of pending factors
     assert ratio.min() > 0 and (np.abs(np.log(ratio)) > 1e-3).any()
+
+
+# ---------------------------------------------------------------- structured models (populations, migration, joins)
+
+def _two_deme_model(n, sample_pops, mig=1.0, N0=1e4, E=1):
+    m = cases.make_model(n=n, E=E, L=1e5)
+    m = cases.make_structured(m, P=2, split_epoch=E + 5, mig=mig, sample_pops=sample_pops)   # no join: split beyond the last epoch
+    m["single_mig"][:] = 0.0
+    return m
+
+
+def test_two_deme_coalescence_time_expectations(oracle):
+    """Symmetric two-deme island model, per-lineage migration rate m = M/(4 N0): two lineages sampled in the same
+    deme coalesce after 4N generations on average, two from different demes after 4N + 1/(2m) (Notohara 1990)."""
+    N0 = 1e4
+    for spops, expect in (([0, 0], 4 * N0), ([0, 1], 4 * N0 + 1.0 / (2 * 1.0 / (4 * N0)))):
+        o = oracle.Oracle(_two_deme_model(2, spops), 40000, seed=17)
+        o.init_prior(0.0)
+        h = o.particles()["heights"][:, 0]
+        assert abs(h.mean() / expect - 1) < 0.02, (spops, h.mean(), expect)
+        mg = o.migrations()
+        # every event list is sorted by time, sits on an existing branch below the root, and changes population
+        for i in range(0, 40000, 997):
+            k = mg["n_events"][i]
+            t = mg["times"][i, :k]
+            assert (np.diff(t) >= 0).all() and (t < h[i]).all()
+            assert set(mg["branch"][i, :k].tolist()) <= {0, 1}
+
+
+def test_structured_no_data_run_reproduces_model_rates(oracle):
+    """Without data the filter samples the prior: coalescence, migration and recombination rates read back from
+    the CountModel sums must equal the model's (cf. the acceptance ranges of test/old/newtests/test_two_pops.py)."""
+    N0 = 1e4
+    base = cases.make_model(n=4, E=6, L=1e6)
+    model = cases.make_structured(base, P=2, split_epoch=4, mig=1.0)
+    o = oracle.Oracle(model, 1000, seed=5)
+    o.init_prior(0.0)
+    o.run(o.pack_segments(model, cases.nodata_segments(model, 4000.0)))
+    c = o.counts()
+    coal = c["coal_count"] / np.maximum(c["coal_opp"], 1e-300) * 2 * N0
+    ok = c["coal_count"] > 10
+    assert ok.sum() >= 4 and np.abs(coal[ok] - 1).max() < 0.1
+    mig = c["mig_count"].sum(2) / np.maximum(c["mig_opp"], 1e-300) * 4 * N0
+    okm = c["mig_count"].sum(2) > 3
+    assert okm.sum() >= 2 and np.abs(mig[okm] - 1).max() < 0.12
+    assert c["coal_count"][4:, 1].sum() == 0 and c["mig_count"][4:].sum() == 0     # nobody is left in population 1
+    assert abs(c["rec_count"].sum() / c["rec_opp"].sum() / 1e-8 - 1) < 0.03
+    assert o.logl() == 0.0
+
+
+def test_population_join_moves_every_lineage(oracle):
+    """-ej: at the join every lineage of population 1 moves to population 0; nodes older than the join are in 0."""
+    base = cases.make_model(n=6, E=8, L=1e5)
+    model = cases.make_structured(base, P=2, split_epoch=4, mig=0.0)        # isolation until the join
+    o = oracle.Oracle(model, 3000, seed=2)
+    o.init_prior(0.0)
+    p, mg = o.particles(), o.migrations()
+    tj = model["change_times"][4]
+    older = p["heights"] >= tj
+    assert (mg["node_pops"][older] == 0).all()
+    # without migration the only events are the joins, exactly at the boundary and into population 0
+    k = mg["n_events"]
+    assert k.max() <= 3 and k.sum() > 0
+    for i in range(3000):
+        assert (mg["times"][i, :k[i]] == tj).all() and (mg["newpop"][i, :k[i]] == 0).all()
+    # lineages of different populations never coalesce before the join
+    young = p["heights"] < tj
+    ch = p["children"]
+    spop = np.array(model["sample_pops"])
+    for i in range(0, 3000, 37):
+        for r in range(5):
+            if young[i, r]:
+                leaves = []
+                stack = [int(ch[i, r, 0]), int(ch[i, r, 1])]
+                while stack:
+                    c_ = stack.pop()
+                    if c_ < 6:
+                        leaves.append(c_)
+                    else:
+                        stack += [int(ch[i, c_ - 6, 0]), int(ch[i, c_ - 6, 1])]
+                assert len(set(spop[leaves])) == 1
+
+
+def test_isolated_populations_cannot_coalesce(oracle):
+    model = _two_deme_model(2, [0, 1], mig=0.0)
+    o = oracle.Oracle(model, 4, seed=1)
+    with pytest.raises(RuntimeError, match="No final coalescence"):
+        o.init_prior(0.0)
