@@ -40,6 +40,16 @@ def build_workload(args, seed):
     lags = np.array([4.0 / (rho * (ct[e + 1] if e + 1 < E else ct[-1])) for e in range(E)]) if E > 1 else np.array([20000.0])
     model = dict(change_times=ct, pop_sizes=ps, lags=lags, nsam=n, loci_length=L, mutation_rate=mu,
                  recombination_rate=rho)
+    if args.pops > 1:
+        P = args.pops
+        split = int(np.searchsorted(ct, 0.5 * 4 * N0))          # first epoch that starts at or after the split
+        split = min(max(split, 1), E - 1)
+        mr = np.zeros((E, P, P)); sm = np.zeros((E, P, P))
+        for e in range(split):
+            mr[e] = (1.0 / (4 * N0)) * (1 - np.eye(P))
+        sm[split, 1:, 0] = 1.0
+        model.update(n_pops=P, pop_sizes=np.repeat(ps[:, None], P, axis=1), mig_rates=mr, single_mig=sm,
+                     sample_pops=[i * P // n for i in range(n)])
     cache = "/tmp/smcsmc_bench_n%d_L%d_E%d_s%d.npz" % (n, int(L), E, seed)
     if os.path.exists(cache):
         z = np.load(cache)
@@ -111,6 +121,9 @@ def main():
     ap.add_argument("--length", type=float, default=1e8)
     ap.add_argument("--epochs", type=int, default=32)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--pops", type=int, default=1,
+                    help="populations: >1 switches to the isolation-with-migration shape of BASELINE.json configs[4] "
+                         "(samples split evenly, symmetric migration 4*N0*m = 1, all populations join at 0.5*4N0)")
     ap.add_argument("--cpu-segments", type=int, default=2000)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu", action="store_true")
@@ -194,8 +207,8 @@ def main():
         dist.all_reduce(segs_all, op=dist.ReduceOp.SUM)
         total_segments = float(segs_all.item())
         # CountModel "all-reduce": all-gather + sum in rank order (bit-identical for any arrival order)
-        packed = np.concatenate([counts[k] for k in ("coal_count", "coal_opp", "coal_weight", "rec_count", "rec_opp",
-                                                     "rec_weight")] + [[counts["delayed_opp"], counts["resample_count"], logl]])
+        packed = np.concatenate([np.ravel(counts[k]) for k in sorted(counts) if isinstance(counts[k], np.ndarray)]
+                                + [[counts["delayed_opp"], counts["resample_count"], logl]])
         mine = torch.tensor(packed, dtype=torch.float64, device="cuda")
         gathered = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
@@ -224,8 +237,10 @@ def main():
             "value": value, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt_max / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "2 diploids (4 haplotypes), %.0f Mb, Np=%d, E=%d epochs, one chunk per GPU"
-                                   % (args.length / 1e6, args.np, args.epochs),
+            "config": {"workload": "%d haplotypes, %s%.0f Mb, Np=%d, E=%d epochs, one chunk per GPU"
+                                   % (args.nsam, "" if args.pops == 1 else "%d-population isolation-with-migration model, " % args.pops,
+                                      args.length / 1e6, args.np, args.epochs),
+                       "populations": args.pops,
                        "segments_per_chunk": n_segments, "nsam": args.nsam, "np": args.np,
                        "sequence_length": args.length, "epochs": args.epochs,
                        "parallelism": "%d chunk(s) per gpu x %d gpu(s)" % (C, world), "log_likelihood_sum": logl_sum},
