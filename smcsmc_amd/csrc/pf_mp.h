@@ -156,6 +156,36 @@ __device__ __forceinline__ void mp_insert_node(Lane& ln, MLane& ml, int ni, doub
     if (*fl >= nid) *fl += 1;
 }
 
+// Lineages in population `pop` crossing time tc, enumerated in the canonical order of the tree WITHOUT its node of
+// rank rp (rp < 0: nothing removed): rows ascending, child 0 then 1, the removed node's parent slot standing for
+// the sibling lineage (below the removed node) or the removed node's own branch (above it).  Populations are read
+// from Bp as the walk left them at tc.  Returns the count; the want-th slot is returned in pruned-tree coordinates.
+__device__ __forceinline__ int mp_slots_at(const Lane& ln, const MLane& ml, int ni, int rp, double tc, int pop, int s_id,
+                                           double Sp, int want, int* pr, int* ps) {
+    const int n = ln.n;
+    const int pid = rp >= 0 ? n + rp : -1;
+    int cnt = 0;
+    for (int r = 0; r < ni; ++r) {
+        if (r == rp || !(LS(ln, r) > tc)) continue;
+        for (int s = 0; s < 2; ++s) {
+            int id = LC(ln, r, s);
+            int eff = id;
+            bool crossing;
+            if (id == pid) {
+                if (tc >= Sp) crossing = true;
+                else { eff = s_id; crossing = node_h(ln, s_id) <= tc; }
+            } else {
+                crossing = node_h(ln, id) <= tc;
+            }
+            if (crossing && LBp(ml, eff) == pop) {
+                if (cnt == want) { *pr = r - ((rp >= 0 && r > rp) ? 1 : 0); *ps = s; }
+                ++cnt;
+            }
+        }
+    }
+    return cnt;
+}
+
 struct MWalk { double tc; int pf, pr, weight; };
 
 // The floating lineage starts at height h in population pf0 and moves up through the stored tree (ni internal
@@ -210,25 +240,66 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
             ++j;
         }
     };
-    for (int guard = 0; guard < 100000; ++guard) {
-        const bool root_active = tt >= Hr;
-        double tn_node = i < ni ? LS(ln, i) : PF_INF;
-        double tn_mig = j < ml.nm ? LMt(ml, j) : PF_INF;
-        double tn_ep = epoch_end(ln, e);
-        double tn = tn_node < tn_mig ? tn_node : tn_mig;
-        tn = tn < tn_ep ? tn : tn_ep;
-        int k = count_of(pf);
-        int weight = k + ((root_active && pr == pf) ? 1 : 0);
-        double rc = (double)weight * ml.I2[e * P + pf];
-        double rmf = ml.MT[e * P + pf];
-        double rmr = root_active ? ml.MT[e * P + pr] : 0.0;
-        double lam = (rc + rmf) + rmr;
-        if (lam == 0.0 && !(tn < PF_INF)) { ml.err = 3; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
-        double need = (tn - tt) * lam;
-        bool fire = !(ln.ebuf > need);
-        double t1 = fire ? tt + ln.ebuf / lam : tn;
-        int kind = 0, to = 0;
-        if (fire) {
+    // record_all_event (particle.cpp:251-300) for the piece of the walk [tt, t1): kind 0 no event, 1 coalescence,
+    // 2 the floating lineage migrates to `to`, 3 the root lineage migrates to `to`
+    auto record = [&](bool root_active, int weight, double dt, int kind, int to) {
+        if (!(pl && pl->on && (ln.RF[e] & 2) && e <= limit)) return;
+        if (pl->fopen && (pl->fe != e || pl->fp != pf)) plog_flush_f(*pl, 0, 0);
+        if (!pl->fopen) { pl->fopen = true; pl->fe = e; pl->fp = pf; pl->fco = 0.0; pl->fmo = 0.0; }
+        pl->fco += (double)weight * dt;
+        pl->fmo += dt;
+        if (kind == 1) plog_flush_f(*pl, 1, 0);
+        if (kind == 2) plog_flush_f(*pl, 2, to);
+        if (root_active) {
+            if (pl->ropen && (pl->re != e || pl->rp != pr)) plog_flush_r(*pl, 0, 0);
+            if (!pl->ropen) { pl->ropen = true; pl->re = e; pl->rp = pr; pl->rmo = 0.0; }
+            pl->rmo += dt;
+            if (kind == 3) plog_flush_r(*pl, 2, to);
+        }
+    };
+    // One pass of the outer loop per EVENT, not per interval: the inner loop runs through the event-free
+    // intervals with a few table lookups each; the expensive part (two Philox draws and a log) then runs once
+    // per event with the lanes of the wavefront converged, instead of in nearly every interval for some lane.
+    for (int guard = 0; guard < 4096; ++guard) {
+        bool root_active = false;
+        int weight = 0;
+        double rc = 0.0, rmf = 0.0, rmr = 0.0, lam = 0.0;
+        for (int g2 = 0; g2 < 100000; ++g2) {
+            root_active = tt >= Hr;
+            double tn_node = i < ni ? LS(ln, i) : PF_INF;
+            double tn_mig = j < ml.nm ? LMt(ml, j) : PF_INF;
+            double tn_ep = epoch_end(ln, e);
+            double tn = tn_node < tn_mig ? tn_node : tn_mig;
+            tn = tn < tn_ep ? tn : tn_ep;
+            int k = count_of(pf);
+            weight = k + ((root_active && pr == pf) ? 1 : 0);
+            rc = (double)weight * ml.I2[e * P + pf];
+            rmf = ml.MT[e * P + pf];
+            rmr = root_active ? ml.MT[e * P + pr] : 0.0;
+            lam = (rc + rmf) + rmr;
+            if (lam == 0.0 && !(tn < PF_INF)) { ml.err = 3; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
+            double need = (tn - tt) * lam;
+            if (!(ln.ebuf > need)) break;                 // an event falls into this interval
+            record(root_active, weight, tn - tt, 0, 0);
+            ln.ebuf -= need;
+            tt = tn;
+            advance(tt);
+            if (tn_ep <= tn) {
+                ++e;
+                int q = ml.JM[e * P + pf];
+                if (q != pf) { mp_ev_insert(ml, tt, PF_TAG_PATH, q); pf = q; }
+                if (tt >= Hr) {
+                    int qr = ml.JM[e * P + pr];
+                    if (qr != pr) { mp_ev_insert(ml, tt, PF_TAG_RPATH, qr); pr = qr; }
+                }
+                if (ml.err) { W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
+                advance(tt);
+            }
+        }
+        // ---- the event
+        double t1 = tt + ln.ebuf / lam;
+        int kind, to = 0;
+        {
             double v = uni(ln) * lam;
             if (v < rc || (rmf == 0.0 && rmr == 0.0)) kind = 1;
             else {
@@ -246,49 +317,18 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
                 }
             }
         }
-        if (pl && pl->on && (ln.RF[e] & 2) && e <= limit) {
-            double dt = t1 - tt;
-            if (pl->fopen && (pl->fe != e || pl->fp != pf)) plog_flush_f(*pl, 0, 0);
-            if (!pl->fopen) { pl->fopen = true; pl->fe = e; pl->fp = pf; pl->fco = 0.0; pl->fmo = 0.0; }
-            pl->fco += (double)weight * dt;
-            pl->fmo += dt;
-            if (kind == 1) plog_flush_f(*pl, 1, 0);
-            if (kind == 2) plog_flush_f(*pl, 2, to);
-            if (root_active) {
-                if (pl->ropen && (pl->re != e || pl->rp != pr)) plog_flush_r(*pl, 0, 0);
-                if (!pl->ropen) { pl->ropen = true; pl->re = e; pl->rp = pr; pl->rmo = 0.0; }
-                pl->rmo += dt;
-                if (kind == 3) plog_flush_r(*pl, 2, to);
-            }
+        record(root_active, weight, t1 - tt, kind, to);
+        ln.ebuf = -dlog(uni(ln));
+        if (kind == 1) {
+            if (pl) { plog_flush_f(*pl, 0, 0); plog_flush_r(*pl, 0, 0); }
+            W.tc = t1; W.pf = pf; W.pr = pr; W.weight = weight;
+            return;
         }
-        if (fire) {
-            ln.ebuf = -dlog(uni(ln));
-            if (kind == 1) {
-                if (pl) { plog_flush_f(*pl, 0, 0); plog_flush_r(*pl, 0, 0); }
-                W.tc = t1; W.pf = pf; W.pr = pr; W.weight = weight;
-                return;
-            }
-            if (kind == 2) { mp_ev_insert(ml, t1, PF_TAG_PATH, to); pf = to; }
-            else { mp_ev_insert(ml, t1, PF_TAG_RPATH, to); pr = to; }
-            if (ml.err) { W.tc = t1; W.pf = pf; W.pr = pr; W.weight = 0; return; }
-            tt = t1;
-            advance(tt);            // steps over the event just inserted (temporary tags are not lineages of the tree)
-            continue;
-        }
-        ln.ebuf -= need;
-        tt = tn;
-        advance(tt);
-        if (tn_ep <= tn) {
-            ++e;
-            int q = ml.JM[e * P + pf];
-            if (q != pf) { mp_ev_insert(ml, tt, PF_TAG_PATH, q); pf = q; }
-            if (tt >= Hr) {
-                int qr = ml.JM[e * P + pr];
-                if (qr != pr) { mp_ev_insert(ml, tt, PF_TAG_RPATH, qr); pr = qr; }
-            }
-            if (ml.err) { W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
-            advance(tt);
-        }
+        if (kind == 2) { mp_ev_insert(ml, t1, PF_TAG_PATH, to); pf = to; }
+        else { mp_ev_insert(ml, t1, PF_TAG_RPATH, to); pr = to; }
+        if (ml.err) { W.tc = t1; W.pf = pf; W.pr = pr; W.weight = 0; return; }
+        tt = t1;
+        advance(tt);            // steps over the event just inserted (temporary tags are not lineages of the tree)
     }
     ml.err = 3;
     W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0;
@@ -314,16 +354,18 @@ __device__ __forceinline__ void mp_build_initial_tree(Lane& ln, MLane& ml, PLog*
         emit(i, p0, pl ? pl->idx - p0 : 0u, W.tc);
         double tc = W.tc;
         mp_retag(ml, PF_TAG_RPATH, root);
+        // candidates: the lineages of the partial tree in the coalescence population (their populations at tc are
+        // what the walk left in Bp), then the root lineage
         int pr = -1, ps = 0;
-        int nslots = mp_lineages_in_pop(ln, ml, ni, tc, W.pf, -1, &pr, &ps);
-        bool has_root = tc >= node_h(ln, root) && mp_pop_at(ln, ml, root, tc) == W.pf;
+        int nslots = mp_slots_at(ln, ml, ni, -1, tc, W.pf, 0, 0, -1, &pr, &ps);
+        bool has_root = tc >= node_h(ln, root) && W.pr == W.pf;
         int k = nslots + (has_root ? 1 : 0);
         if (k != W.weight || k < 1) { ml.err = 2; return; }
         double u = uni(ln);
         int idx = min((int)(u * (double)k), k - 1);
         int fl = i;
         if (idx < nslots) {
-            mp_lineages_in_pop(ln, ml, ni, tc, W.pf, idx, &pr, &ps);
+            mp_slots_at(ln, ml, ni, -1, tc, W.pf, 0, 0, idx, &pr, &ps);
             mp_insert_node(ln, ml, ni, tc, &fl, pr, ps, root, W.pf);
         } else {
             mp_insert_node(ln, ml, ni, tc, &fl, -1, 0, root, W.pf);
@@ -350,6 +392,18 @@ __device__ __forceinline__ void mp_genealogy_rest(Lane& ln, MLane& ml, PLog* pl,
     if (ml.err) return;
     const int p_pop = LPn(ml, rp);
     const bool p_was_root = (rp == n - 2);
+    // candidates in the order of the pruned tree (slots, root lineage, stub), populations from the walk's Bp
+    int pr = -1, ps = 0;
+    const int nslots = mp_slots_at(ln, ml, n - 1, rp, tc, W.pf, s_id, Sp, -1, &pr, &ps);
+    bool has_root;
+    if (p_was_root) has_root = tc >= node_h(ln, s_id) && (tc < Sp ? (int)LBp(ml, s_id) : W.pr) == W.pf;
+    else has_root = tc >= LS(ln, n - 2) && W.pr == W.pf;
+    const bool has_stub = tc < Sp && LBp(ml, b_id) == W.pf;
+    const int k = nslots + (has_root ? 1 : 0) + (has_stub ? 1 : 0);
+    if (k != W.weight || k < 1) { ml.err = 2; return; }
+    const double u = uni(ln);
+    const int idx = min((int)(u * (double)k), k - 1);
+    if (idx < nslots) mp_slots_at(ln, ml, n - 1, rp, tc, W.pf, s_id, Sp, idx, &pr, &ps);
     // the stub: what remains of the cut branch above the cut
     for (int m = 0; m < ml.nm; ++m)
         if (LMb(ml, m) == b_id && LMt(ml, m) > h) LMb(ml, m) = (int8_t)PF_TAG_STUB;
@@ -357,20 +411,8 @@ __device__ __forceinline__ void mp_genealogy_rest(Lane& ln, MLane& ml, PLog* pl,
     int ni = n - 2;
     int troot = p_was_root ? s_id : n + (ni - 1);
     mp_retag(ml, PF_TAG_RPATH, troot);
-    int pr = -1, ps = 0;
-    int nslots = mp_lineages_in_pop(ln, ml, ni, tc, W.pf, -1, &pr, &ps);
-    bool has_root = tc >= node_h(ln, troot) && mp_pop_at(ln, ml, troot, tc) == W.pf;
-    int stub_pop = pf0;
-    for (int m = 0; m < ml.nm; ++m)
-        if (LMb(ml, m) == PF_TAG_STUB && LMt(ml, m) <= tc) stub_pop = LMq(ml, m);
-    bool has_stub = tc < Sp && stub_pop == W.pf;
-    int k = nslots + (has_root ? 1 : 0) + (has_stub ? 1 : 0);
-    if (k != W.weight || k < 1) { ml.err = 2; return; }
-    double u = uni(ln);
-    int idx = min((int)(u * (double)k), k - 1);
     *changed_out = !(has_stub && idx == k - 1);
     if (idx < nslots) {
-        mp_lineages_in_pop(ln, ml, ni, tc, W.pf, idx, &pr, &ps);
         mp_insert_node(ln, ml, ni, tc, &b_id, pr, ps, troot, W.pf);
         mp_ev_drop_above(ml, PF_TAG_STUB, -1.0);
     } else if (has_root && idx == nslots) {
