@@ -290,23 +290,24 @@ __device__ __forceinline__ double coalesce_up(Lane& ln, HeightAt Sh, int ns, int
     int e = epoch_of(ln, t);
     int i = 0;
     while (i < ns && Sh(i) <= t) ++i;
+    // the event tail sits behind the loop exit, where the wavefront has reconverged (see r_coalesce_up)
+    double rate;
     for (;;) {
         double tn_node = i < ns ? Sh(i) : PF_INF;
         double tn_ep = epoch_end(ln, e);
         double tn = tn_node < tn_ep ? tn_node : tn_ep;
         int k = i < ns ? nl - i : 1;
-        double rate = (double)k * ln.I[e];
+        rate = (double)k * ln.I[e];
         double need = (tn - t) * rate;
-        if (!(ln.ebuf > need)) {
-            double t1 = t + ln.ebuf / rate;
-            ln.ebuf = -dlog(uni(ln));
-            return t1;
-        }
+        if (!(ln.ebuf > need)) break;
         ln.ebuf -= need;
         t = tn;
         if (tn_node <= tn) ++i;
         if (tn_ep <= tn) ++e;
     }
+    double t1 = t + ln.ebuf / rate;
+    ln.ebuf = -dlog(uni(ln));
+    return t1;
 }
 
 // particle.cpp:1195-1254 with multiplicity 1 and one recombination-rate segment

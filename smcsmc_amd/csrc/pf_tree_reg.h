@@ -61,10 +61,15 @@ struct RCtx {
 };
 
 __device__ __forceinline__ double r_uni(RCtx& cx) { return philox_uniform(cx.seed, cx.slot, cx.stream, cx.ctr++); }
+// epoch containing time t: the largest e with T[e] <= t (T[0] = 0).  Six dependent LDS reads for E <= 64
+// instead of one per epoch passed.
 __device__ __forceinline__ int r_epoch_of(const RCtx& cx, double t) {
-    int e = 0;
-    while (e + 1 < cx.E && cx.T[e + 1] <= t) ++e;
-    return e;
+    int lo = 0, hi = cx.E;            // invariant: T[lo] <= t, and (hi == E or T[hi] > t)
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (cx.T[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
 }
 __device__ __forceinline__ double r_epoch_end(const RCtx& cx, int e) { return e + 1 < cx.E ? cx.T[e + 1] : PF_INF; }
 
@@ -175,23 +180,35 @@ __device__ __forceinline__ double r_coalesce_up(RCtx& cx, const RTree<NM>& t, in
     int i = 0;
 #pragma unroll
     for (int k = 0; k < RTree<NM>::NI; ++k) i += (k < ns && t.S[k] <= tt) ? 1 : 0;
+    // the epoch tables are read one epoch ahead, so that the LDS latency of the next epoch's entries overlaps
+    // the arithmetic of the current interval instead of heading its dependency chain
+    double ep_end = r_epoch_end(cx, e), ep_inv = cx.I[e];
+    double nx_end = r_epoch_end(cx, e + 1), nx_inv = cx.I[e + 1 < cx.E ? e + 1 : e];
+    // The loop only runs through the event-free intervals.  The expensive tail (a division, a Philox draw and a
+    // log) sits behind the loop exit, where the lanes of the wavefront have reconverged: placed inside the loop it
+    // would be executed once for every iteration in which some lane's lineage coalesces.
+    double rate;
     for (;;) {
         double tn_node = i < ns ? t.getS(i) : PF_INF;
-        double tn_ep = r_epoch_end(cx, e);
+        double tn_ep = ep_end;
         double tn = tn_node < tn_ep ? tn_node : tn_ep;
         int k = i < ns ? nl - i : 1;
-        double rate = (double)k * cx.I[e];
+        rate = (double)k * ep_inv;
         double need = (tn - tt) * rate;
-        if (!(cx.ebuf > need)) {
-            double t1 = tt + cx.ebuf / rate;
-            cx.ebuf = -dlog(r_uni(cx));
-            return t1;
-        }
+        if (!(cx.ebuf > need)) break;
         cx.ebuf -= need;
         tt = tn;
         if (tn_node <= tn) ++i;
-        if (tn_ep <= tn) ++e;
+        if (tn_ep <= tn) {
+            ++e;
+            ep_end = nx_end; ep_inv = nx_inv;
+            nx_end = r_epoch_end(cx, e + 1);
+            nx_inv = cx.I[e + 1 < cx.E ? e + 1 : e];
+        }
     }
+    double t1 = tt + cx.ebuf / rate;
+    cx.ebuf = -dlog(r_uni(cx));
+    return t1;
 }
 
 __device__ __forceinline__ double r_sample_next_base(RCtx& cx, double x) {
