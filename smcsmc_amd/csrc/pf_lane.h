@@ -97,30 +97,24 @@ __device__ __forceinline__ void genealogy_update(Lane& ln, double* h_out, double
     int idx = min((int)(u * (double)k), k - 1);
     *sp_out = Sp;
     *changed_out = !(has_stub && idx == k - 1);
+    double h_ins = tc;
+    int pr_ins = -1, ps_ins = 0;
     if (idx < nslots) {
-        lineages_at(ln, ni, tc, idx, &pr, &ps);
-        insert_node(ln, ni, tc, b_id, pr, ps, troot);
-    } else if (has_root && idx == nslots) {
-        insert_node(ln, ni, tc, b_id, -1, 0, troot);
-    } else {
-        if (p_was_root) {
-            insert_node(ln, ni, Sp, b_id, -1, 0, troot);
-        } else {
-            int want = -1, c = 0;
+        lineages_at(ln, ni, tc, idx, &pr_ins, &ps_ins);
+    } else if (!(has_root && idx == nslots)) {
+        h_ins = Sp;
+        if (!p_was_root) {
             int R = 0;
             while (R < ni && LS(ln, R) <= Sp) ++R;
-            for (int rr = R; rr < ni && want < 0; ++rr)
-                for (int s = 0; s < 2 && want < 0; ++s) {
+            bool found = false;
+            for (int rr = R; rr < ni && !found; ++rr)
+                for (int s = 0; s < 2 && !found; ++s) {
                     int id = LC(ln, rr, s);
-                    if (id < n || id - n < R) {
-                        if (id == s_id) want = c;
-                        ++c;
-                    }
+                    if ((id < n || id - n < R) && id == s_id) { found = true; pr_ins = rr; ps_ins = s; }
                 }
-            lineages_at(ln, ni, Sp, want, &pr, &ps);
-            insert_node(ln, ni, Sp, b_id, pr, ps, troot);
         }
     }
+    insert_node(ln, ni, h_ins, b_id, pr_ins, ps_ins, troot);
     ln.Ltree = tree_length(ln, n);
 }
 

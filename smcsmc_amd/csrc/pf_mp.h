@@ -412,34 +412,35 @@ __device__ __forceinline__ void mp_genealogy_rest(Lane& ln, MLane& ml, PLog* pl,
     int troot = p_was_root ? s_id : n + (ni - 1);
     mp_retag(ml, PF_TAG_RPATH, troot);
     *changed_out = !(has_stub && idx == k - 1);
-    if (idx < nslots) {
-        mp_insert_node(ln, ml, ni, tc, &b_id, pr, ps, troot, W.pf);
-        mp_ev_drop_above(ml, PF_TAG_STUB, -1.0);
-    } else if (has_root && idx == nslots) {
-        mp_insert_node(ln, ml, ni, tc, &b_id, -1, 0, troot, W.pf);
-        mp_ev_drop_above(ml, PF_TAG_STUB, -1.0);
-    } else {
-        // back into its own stub: the tree keeps its shape; the cut branch swaps the events between the cut
-        // and tc for the ones picked up on the way
-        if (p_was_root) {
-            mp_insert_node(ln, ml, ni, Sp, &b_id, -1, 0, troot, p_pop);
-        } else {
-            int fr = -1, fs = 0, R = 0;
+    // one insertion for all three outcomes (slot, root lineage, back into the stub)
+    const bool into_stub = !(idx < nslots) && !(has_root && idx == nslots);
+    double h_ins = tc;
+    int pr_ins = -1, ps_ins = 0, pop_ins = W.pf;
+    if (idx < nslots) { pr_ins = pr; ps_ins = ps; }
+    if (into_stub) {
+        // the tree keeps its shape: p returns at Sp on the sibling lineage's slot (or above the pruned root)
+        h_ins = Sp; pop_ins = p_pop;
+        if (!p_was_root) {
+            int R = 0;
             while (R < ni && LS(ln, R) <= Sp) ++R;
-            for (int rr = R; rr < ni && fr < 0; ++rr)
-                for (int s = 0; s < 2 && fr < 0; ++s) {
+            bool found = false;
+            for (int rr = R; rr < ni && !found; ++rr)
+                for (int s = 0; s < 2 && !found; ++s) {
                     int id = LC(ln, rr, s);
-                    if ((id < n || id - n < R) && id == s_id) { fr = rr; fs = s; }
+                    if ((id < n || id - n < R) && id == s_id) { found = true; pr_ins = rr; ps_ins = s; }
                 }
-            mp_insert_node(ln, ml, ni, Sp, &b_id, fr, fs, troot, p_pop);
         }
-        // stub events at or before tc vanish, later ones return to the branch
+    }
+    mp_insert_node(ln, ml, ni, h_ins, &b_id, pr_ins, ps_ins, troot, pop_ins);
+    {
+        // the stub's events: back into its own stub the ones after tc return to the cut branch, everything else
+        // of the stub vanishes (the cut branch swaps them for the events picked up on the way)
         int o = 0;
         for (int m = 0; m < ml.nm; ++m) {
             int bb = LMb(ml, m);
             double t = LMt(ml, m);
             if (bb == PF_TAG_STUB) {
-                if (!(t > tc)) continue;
+                if (!(into_stub && t > tc)) continue;
                 bb = b_id;
             }
             LMt(ml, o) = t; LMb(ml, o) = (int8_t)bb; LMq(ml, o) = LMq(ml, m);

@@ -188,17 +188,21 @@ __device__ __forceinline__ double r_coalesce_up(RCtx& cx, const RTree<NM>& t, in
     // log) sits behind the loop exit, where the lanes of the wavefront have reconverged: placed inside the loop it
     // would be executed once for every iteration in which some lane's lineage coalesces.
     double rate;
+    double tn_node = i < ns ? t.getS(i) : PF_INF;          // next node height and lineage count, updated only
+    double kd = i < ns ? (double)(nl - i) : 1.0;            // when a node is passed (small integers: exact)
     for (;;) {
-        double tn_node = i < ns ? t.getS(i) : PF_INF;
         double tn_ep = ep_end;
         double tn = tn_node < tn_ep ? tn_node : tn_ep;
-        int k = i < ns ? nl - i : 1;
-        rate = (double)k * ep_inv;
+        rate = kd * ep_inv;
         double need = (tn - tt) * rate;
         if (!(cx.ebuf > need)) break;
         cx.ebuf -= need;
         tt = tn;
-        if (tn_node <= tn) ++i;
+        if (tn_node <= tn) {
+            ++i;
+            tn_node = i < ns ? t.getS(i) : PF_INF;
+            kd = i < ns ? kd - 1.0 : 1.0;
+        }
         if (tn_ep <= tn) {
             ++e;
             ep_end = nx_end; ep_inv = nx_inv;
@@ -345,33 +349,33 @@ __device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, doubl
     int k = nslots + (has_root ? 1 : 0) + (has_stub ? 1 : 0);
     double u = r_uni(cx);
     int idx = min((int)(u * (double)k), k - 1);
+    // where the floating lineage re-attaches: one insertion for all three outcomes (under divergence three
+    // separate calls would each be executed by the whole wavefront)
+    double h_ins = tc;
+    int pr_ins = -1, ps_ins = 0;
     if (idx < nslots) {
-        r_lineages_at(t, n, ni, tc, idx, &pr, &ps);
-        r_insert_node(t, n, ni, tc, b_id, pr, ps, troot);
-    } else if (has_root && idx == nslots) {
-        r_insert_node(t, n, ni, tc, b_id, -1, 0, troot);
-    } else {
-        if (p_was_root) {
-            r_insert_node(t, n, ni, Sp, b_id, -1, 0, troot);
-        } else {
-            // the sibling lineage's slot at time Sp
+        r_lineages_at(t, n, ni, tc, idx, &pr_ins, &ps_ins);
+    } else if (!(has_root && idx == nslots)) {
+        // coalesced back into its own branch above the cut: the tree is unchanged -> restore p on the sibling
+        // lineage's slot at time Sp (or above the pruned root)
+        h_ins = Sp;
+        if (!p_was_root) {
             int R = 0;
 #pragma unroll
             for (int kk = 0; kk < RTree<NM>::NI; ++kk) R += (kk < ni && t.S[kk] <= Sp) ? 1 : 0;
-            int want = -1, c = 0;
+            bool found = false;
 #pragma unroll
             for (int rr = 0; rr < RTree<NM>::NI; ++rr) {
                 if (rr >= R && rr < ni) {
                     int id0 = t.C0[rr];
-                    if (id0 < n || id0 - n < R) { if (want < 0 && id0 == s_id) want = c; ++c; }
+                    if (!found && (id0 < n || id0 - n < R) && id0 == s_id) { found = true; pr_ins = rr; ps_ins = 0; }
                     int id1 = t.C1[rr];
-                    if (id1 < n || id1 - n < R) { if (want < 0 && id1 == s_id) want = c; ++c; }
+                    if (!found && (id1 < n || id1 - n < R) && id1 == s_id) { found = true; pr_ins = rr; ps_ins = 1; }
                 }
             }
-            r_lineages_at(t, n, ni, Sp, want, &pr, &ps);
-            r_insert_node(t, n, ni, Sp, b_id, pr, ps, troot);
         }
     }
+    r_insert_node(t, n, ni, h_ins, b_id, pr_ins, ps_ins, troot);
     cx.Ltree = r_tree_length(t, n);
 }
 
