@@ -53,7 +53,7 @@ static void pf_check(int rc) {
 }
 
 // pfARG_core (smcsmc.cpp:278-401): one E-step over the chunk
-static void pfARG_core(PfParam& P) {
+static void pfARG_core(PfParam& P, const HostModel& M0) {
     HostModel& M = P.model;
     const int E = (int)M.change_times.size();
     const int NP = M.npop;
@@ -86,7 +86,7 @@ static void pfARG_core(PfParam& P) {
     else
         for (int e = 0; e < E; ++e) {
             double top_t = e == E - 1 ? M.change_times[E - 1] : M.change_times[e + 1];
-            lags[e] = P.lag > 0 ? P.lag : 4.0 / (M.recombination_rate * top_t);
+            lags[e] = P.lag > 0 ? P.lag : 4.0 / (M0.recombination_rate * top_t);   // CountModel keeps its initial model
         }
     // calculate_median_survival_distances is always run by the reference (smcsmc.cpp:287); its result feeds the
     // lags (when calibrating) and the application delays of the importance weights (smcsmc.cpp:306-307)
@@ -176,17 +176,51 @@ static void pfARG_core(PfParam& P) {
         const double* cc = &packed[0]; const double* co = &packed[EP]; const double* cw = &packed[2 * EP];
         const double* rc = &packed[3 * EP]; const double* ro = &packed[3 * EP + E]; const double* rw = &packed[3 * EP + 2 * E];
         auto epoch_end = [&](int e) { return e == E - 1 ? 1e+99 : M.change_times[e + 1]; };
+        // reset_model_parameters (count.cpp:44-63, forced at the end of every E-step, smcsmc.cpp:385-386): the M-step
+        // of the in-binary EM.  Totals include the prior pseudo-counts of CountModel::init, which come from the
+        // model the CountModel was constructed with (the initial one, smcsmc.cpp:77).
+        {
+            clog << " MODEL IS RESET at base " << M.loci_length << endl;
+            double ro_ = 0, rc_ = 0, rw_ = 0;
+            for (int e = 0; e < E; ++e) { ro_ += ro[e] + 1.0; rc_ += rc[e] + M0.recombination_rate; rw_ += rw[e] + 1.0; }
+            std::vector<std::vector<double>> new_sizes = M.pop_sizes, new_mig = M.mig_rates;
+            const double new_rho = rc_ / ro_;                                     // reset_recomb_rate, count.cpp:296-313
+            clog << " Setting recombination rate to " << new_rho << " ( " << rc_ << " / " << ro_ << "; post-lag ESS "
+                 << 1.0 / (rw_ / ro_) << " )" << endl;
+            for (int e = 0; e < E; ++e)                                           // reset_Ne, count.cpp:267-293
+                for (int a = 0; a < NP; ++a) {
+                    const size_t k = (size_t)e * NP + a;
+                    double opp = co[k] + 1.0, count = cc[k] + 1.0 / (2.0 * M0.pop_sizes[e][a]), weight = cw[k] + 1.0;
+                    double pop_size = 1.0 / (2.0 * (count / opp));
+                    if (P.useCap && pop_size >= P.Ne_cap) pop_size = P.Ne_cap;
+                    new_sizes[e][a] = pop_size;
+                    clog << " Setting size of population " << a << " @ " << setw(8) << M.change_times[e] << " to " << setw(8)
+                         << pop_size << " ( 0.5 * " << opp << " / " << count << "; post-lag ESS " << 1.0 / (weight / opp)
+                         << " )" << endl;
+                }
+            if (NP > 1) {                                                         // reset_mig_rate, count.cpp:327-352
+                const double* mc = &packed[3 * EP + 3 * E]; const double* mo = mc + EP * NP;
+                for (int e = 0; e < E; ++e)
+                    for (int a = 0; a < NP; ++a)
+                        for (int b = 0; b < NP; ++b)
+                            if (a != b) {
+                                const size_t k = (size_t)e * NP + a;
+                                new_mig[e][(size_t)a * NP + b] = (mc[k * NP + b] + M0.mig_rates[e][(size_t)a * NP + b]) / (mo[k] + 1.0);
+                            }
+            }
+            P.next_sizes = new_sizes; P.next_mig = new_mig; P.next_rho = new_rho;
+        }
         for (int e = 0; e < E; ++e)
             for (int a = 0; a < NP; ++a) {
                 const size_t k = (size_t)e * NP + a;
                 P.appendToOutFile(P.EMcounter, e, M.change_times[e], epoch_end(e), "Coal", a, -1, co[k] + 1.0,
-                                  cc[k] + 1.0 / (2.0 * pop_sizes[k]), cw[k] + 1.0);
+                                  cc[k] + 1.0 / (2.0 * M0.pop_sizes[e][a]), cw[k] + 1.0);
             }
         // recombination is booked on population 0 only (count.cpp:534-539); the report sums the epochs (84-113)
         double ropp = 0, rcount = 0, rweight = 0;
         for (int e = 0; e < E; ++e) {
             ropp += ro[e] + 1.0;
-            rcount += rc[e] + M.recombination_rate;
+            rcount += rc[e] + M0.recombination_rate;
             rweight += rw[e] + 1.0;
         }
         P.appendToOutFile(P.EMcounter, -1, 0.0, 1e+99, "Recomb", -1, -1, ropp, rcount, rweight);
@@ -199,7 +233,7 @@ static void pfARG_core(PfParam& P) {
                         if (a != b) {
                             const size_t k = (size_t)e * NP + a;
                             P.appendToOutFile(P.EMcounter, e, M.change_times[e], epoch_end(e), "Migr", a, b, mo[k] + 1.0,
-                                              mc[k * NP + b] + mig_rates[k * NP + b], mw[k] + 1.0);
+                                              mc[k * NP + b] + M0.mig_rates[e][(size_t)a * NP + b], mw[k] + 1.0);
                         }
         }
         double dopp = tail[0], dcount = tail[1], nres = tail[2], logl = tail[3];
@@ -221,11 +255,13 @@ int main(int argc, char* argv[]) {
         if (P.version()) { P.printVersion(&std::cout); return EXIT_SUCCESS; }
         if (P.help()) { P.printHelp(); return EXIT_SUCCESS; }
         if (P.dump_model) { dump_model_json(P); return EXIT_SUCCESS; }
-        if (P.EM_steps > 0) throw Unsupported("-EM > 0 (the in-binary M-step; the Python front-end always passes -EM 0)");
         P.outFileHeader();
+        const HostModel initial_model = P.model;        // what CountModel is constructed from (smcsmc.cpp:77)
         for (int i = 0; i <= P.EM_steps; i++) {
             clog << "EM step " << i << endl;
-            pfARG_core(P);
+            pfARG_core(P, initial_model);
+            // the model the next E-step runs under (Model::addPopulationSize / addMigrationRate / setRecombinationRate)
+            P.model.pop_sizes = P.next_sizes; P.model.mig_rates = P.next_mig; P.model.recombination_rate = P.next_rho;
             P.EMcounter++;
             clog << "End of EM step " << i << endl;
         }

@@ -357,7 +357,7 @@ void PfParam::printHelp() {   // pfparam.cpp:541-585
     opt("-Np", "INT", "Number of particles [ 100 ]");
     opt("-seg", "STR", "Data file in seg format [ Chrom1.seg ]");
     opt("-o", "STR", "Prefix for output files");
-    opt("-EM", "INT", "EM iterations [ 0 ] (only 0 is supported: the front-end drives EM)");
+    opt("-EM", "INT", "EM iterations [ 0 ]");
     opt("-startpos", "INT", "First nucleotide position to analyze [ 1 ]");
     opt("-apf", "INT", "Use auxiliary particle filter [ 0 ] (only 0 is supported in this build)");
     opt("-log", " ", "Generate *.log file");

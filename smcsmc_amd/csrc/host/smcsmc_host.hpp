@@ -171,6 +171,9 @@ class PfParam {   // pfparam.hpp:225-446
     HostModel model;
     Segment* Segfile = nullptr;
     size_t EMcounter = 0;
+    // result of the M-step of the last E-step (CountModel::reset_model_parameters)
+    std::vector<std::vector<double>> next_sizes, next_mig;
+    double next_rho = 0;
     std::string cmdline;
 
   private:

@@ -1,0 +1,243 @@
+"""In-process EM outer loop: chunk scheduler + reducer + M-step, the native counterpart of the reference's
+per-iteration process farm (/root/reference/smcsmc/model.py:989-1184).
+
+What it removes compared with the front-end: one process launch and `.seg` re-parse per chunk and iteration, the
+1e6-tree lag calibration per chunk (it depends on the model only: done once per iteration), and the text round
+trip of the sufficient statistics (the reduction is the ordered sum of smcsmc_amd.reduce, RCCL all-gather when
+torch.distributed is initialised).
+
+  PopulationModel          the fields of populationmodels.Population the path needs, front-end units
+    .core_command_line()   populationmodels.py:300-437 (argv of the next iteration's E-step)
+    .device_model()        model tables for ParticleFilter (generations, per generation rates)
+  counts_to_data()         .out rows as the front-end's parse_outfile reads them (model.py:865-911)
+  m_step()                 Smcsmc.m_step, model.py:989-1048 (plain and variational-Bayes pseudo-counts)
+  run_em()                 Smcsmc.do_iteration for all iterations, chunks sharded over ranks
+"""
+import copy
+import itertools
+
+import numpy as np
+
+from . import outfile, pf, reduce as reducer
+
+
+class PopulationModel:
+    """Front-end units: times in 4*N0 generations, sizes relative to N0, migration rates 4*N0*m,
+    mutation / recombination rates per bp per generation (populationmodels.py:26-70)."""
+
+    def __init__(self, N0=10000, mutation_rate=2.5e-8, recombination_rate=1e-8, sequence_length=1e6, num_samples=2,
+                 change_points=(0.0,), population_sizes=((1.0,),), num_populations=1, migration_rates=None,
+                 sample_populations=None, migration_commands=None):
+        self.N0 = N0
+        self.mutation_rate = mutation_rate
+        self.recombination_rate = recombination_rate
+        self.sequence_length = sequence_length
+        self.num_samples = num_samples
+        self.num_populations = num_populations
+        self.change_points = list(change_points)
+        E, P = len(self.change_points), num_populations
+        self.population_sizes = [list(row) if isinstance(row, (list, tuple)) else [row] * P for row in population_sizes]
+        self.migration_rates = ([[list(r) for r in m] for m in migration_rates] if migration_rates is not None
+                                else [[[0] * P for _ in range(P)] for _ in range(E)])
+        self.sample_populations = list(sample_populations) if sample_populations is not None else [1] * num_samples
+        self.migration_commands = list(migration_commands) if migration_commands is not None else [None] * E
+        # event counts carried along for the variational-Bayes command line (populationmodels.py:259-268)
+        self.population_event_counts = [[1e10] * P for _ in range(E)]
+        self.migration_event_counts = [[[1e10] * P for _ in range(P)] for _ in range(E)]
+        assert len(self.population_sizes) == E and len(self.migration_rates) == E and self.change_points[0] == 0.0
+
+    # populationmodels.py:272-298 (samples all taken at time 0)
+    def _sample_options(self):
+        if self.num_populations == 1:
+            return ""
+        sizes = [sum(1 for q in self.sample_populations if q == pop) for pop in range(1, self.num_populations + 1)]
+        return "-I {} {}".format(self.num_populations, " ".join(map(str, sizes)))
+
+    # populationmodels.py:301-404
+    def _popsize_migration_options(self, vb):
+        P = self.num_populations
+        expression = []
+        if vb:
+            expression.append("-vb")
+        for i, time in enumerate(self.change_points):
+            popsizes = self.population_sizes[i]
+            if len(set(popsizes)) == 1:
+                if vb:
+                    expression.append("-eN {} {} {}".format(time, popsizes[0], self.population_event_counts[i][0]))
+                else:
+                    expression.append("-eN {} {}".format(time, popsizes[0]))
+            else:
+                for idx, popsize in enumerate(popsizes):
+                    if vb:
+                        expression.append("-en {} {} {} {}".format(time, idx + 1, popsize, self.population_event_counts[i][idx]))
+                    else:
+                        expression.append("-en {} {} {}".format(time, idx + 1, popsize))
+            mm = self.migration_rates[i]
+            all_rates = set(mm[j][k] for j, k in itertools.product(range(P), range(P)) if j != k)
+            if len(all_rates) == 1:
+                rate = all_rates.pop()
+                total_rate = rate * (P - 1)
+                total_count = sum(self.migration_event_counts[i][j][k] for j, k in itertools.product(range(P), range(P)))
+                if vb:
+                    expression.append("-eM {} {} {}".format(time, total_rate, total_count))
+                else:
+                    expression.append("-eM {} {}".format(time, total_rate))
+            elif len(all_rates) > 1:
+                expression.append("-ema {}".format(time))
+                for j in range(P):
+                    for k in range(P):
+                        if vb:
+                            expression.append("{} {}".format(mm[j][k], self.migration_event_counts[i][j][k]))
+                        else:
+                            expression.append("{}".format(mm[j][k]))
+            if self.migration_commands[i] is not None:
+                expression.append(self.migration_commands[i])
+        return " ".join(expression)
+
+    # populationmodels.py:406-437
+    def core_command_line(self, vb=False):
+        mutations = 4 * self.N0 * self.mutation_rate * self.sequence_length
+        recombinations = 4 * self.N0 * self.recombination_rate * self.sequence_length
+        return "-N0 {N0} -t {muts} -r {recs} {seqlen} {sample} {popmigr}".format(
+            N0=self.N0, muts=mutations, recs=recombinations, seqlen=self.sequence_length,
+            sample=self._sample_options(), popmigr=self._popsize_migration_options(vb))
+
+    def device_model(self, lags=None, **extra):
+        """Model tables for ParticleFilter: generations and per-generation rates, -ej commands as joins."""
+        E, P = len(self.change_points), self.num_populations
+        ct = np.array(self.change_points, float) * 4 * self.N0
+        ps = np.array(self.population_sizes, float).reshape(E, P) * self.N0
+        m = dict(change_times=ct, pop_sizes=ps if P > 1 else ps[:, 0], nsam=self.num_samples,
+                 loci_length=float(self.sequence_length), mutation_rate=self.mutation_rate,
+                 recombination_rate=self.recombination_rate,
+                 lags=np.zeros(E) if lags is None else np.asarray(lags, float))
+        if P > 1:
+            mr = np.array(self.migration_rates, float).reshape(E, P, P) / (4.0 * self.N0)
+            sm = np.zeros((E, P, P))
+            for i, cmd in enumerate(self.migration_commands):
+                if not cmd:
+                    continue
+                tok = cmd.split()
+                for k in range(0, len(tok), 4):
+                    if tok[k] != "-ej":
+                        raise ValueError("unsupported migration command: " + cmd)
+                    a, b = int(tok[k + 2]) - 1, int(tok[k + 3]) - 1
+                    sm[i, a, b] = 1.0
+                    # scrm -ej also closes the joined population to migrants at that time; later epochs carry their
+                    # own explicit matrices (same as the binary's flag parser, csrc/host/pfparam.cpp)
+                    mr[i, :, a] = 0.0
+                    mr[i, a, :] = 0.0
+            m.update(n_pops=P, mig_rates=mr, single_mig=sm, sample_pops=[q - 1 for q in self.sample_populations])
+        m.update(extra)
+        return m
+
+
+def counts_to_data(model, counts, np_particles, rounded=True):
+    """The sufficient statistics of one chunk keyed like Smcsmc.parse_outfile (model.py:865-911).  With
+    rounded=True the values pass through the `.out` text form, so they equal what the front-end would read."""
+    text = outfile.outfile_text(model, counts, np_particles)
+    if rounded:
+        return outfile.parse_outfile(text, is_text=True)
+    # exact values: same keys, no text rounding
+    E = len(model["change_times"])
+    P = int(model.get("n_pops", 1))
+    ps = np.asarray(model["pop_sizes"], float).reshape(E, P)
+    data = {}
+    for e in range(E):
+        for a in range(P):
+            key = ("Coal", e, a, -1, -1)
+            data[(key, "Opp")] = float(np.asarray(counts["coal_opp"]).reshape(E, P)[e, a] + 1.0)
+            data[(key, "Count")] = float(np.asarray(counts["coal_count"]).reshape(E, P)[e, a] + 1.0 / (2.0 * ps[e, a]))
+    data[(("Recomb", -1, -1, -1, -1), "Opp")] = float(np.sum(counts["rec_opp"]) + E)
+    data[(("Recomb", -1, -1, -1, -1), "Count")] = float(np.sum(counts["rec_count"]) + E * model["recombination_rate"])
+    if P > 1:
+        mr = np.asarray(model["mig_rates"], float).reshape(E, P, P)
+        for e in range(E):
+            for a in range(P):
+                for b in range(P):
+                    if a != b:
+                        key = ("Migr", e, a, b, -1)
+                        data[(key, "Opp")] = float(counts["mig_opp"][e, a] + 1.0)
+                        data[(key, "Count")] = float(counts["mig_count"][e, a, b] + mr[e, a, b])
+    data[(("LogL", -1, -1, -1, -1), "Count")] = float(counts["logl"])
+    data[(("LogL", -1, -1, -1, -1), "Opp")] = 1.0
+    return data
+
+
+def add_data(total, data):
+    """parse_outfile(..., data) accumulation over chunks (model.py:897-911)."""
+    if total is None:
+        return dict(data)
+    for k, v in data.items():
+        if k[1] in ("Start", "End"):
+            total[k] = v
+        else:
+            total[k] = total.get(k, 0.0) + v
+    return total
+
+
+def m_step(pop, data, vb=False, vb_dirichlet=None, maxNE=1e99, infer_recomb=True):
+    """Smcsmc.m_step (model.py:989-1048): updates `pop` in place from the summed statistics."""
+    vb_dirichlet = vb_dirichlet or {"ne": [1.0, 1.0], "migr": [1.0, 1.0]}
+    E, P = len(pop.change_points), pop.num_populations
+    for epoch in range(E):
+        for a in range(P):
+            key = ("Coal", epoch, a, -1, -1)
+            c0, c1 = vb_dirichlet["ne"] if vb else (1e-30, 0.0)
+            count, opp = data[(key, "Count")] + c1, data[(key, "Opp")] + c0 + c1
+            rate = count / opp
+            pop.population_sizes[epoch][a] = min(maxNE / pop.N0, 1.0 / (2.0 * rate * pop.N0))
+            pop.population_event_counts[epoch][a] = count
+    for epoch in range(E):
+        for a in range(P):
+            for b in range(P):
+                if a != b:
+                    key = ("Migr", epoch, a, b, -1)
+                    c0, c1 = vb_dirichlet["migr"] if vb else (1e-30, 0.0)
+                    count, opp = data[(key, "Count")] + c1, data[(key, "Opp")] + c0 + c1
+                    rate = count / opp
+                    pop.migration_rates[epoch][a][b] = rate * 4 * pop.N0
+                    pop.migration_event_counts[epoch][a][b] = count
+    if infer_recomb:
+        key = ("Recomb", -1, -1, -1, -1)
+        pop.recombination_rate = data[(key, "Count")] / data[(key, "Opp")]
+    return pop
+
+
+def run_em(pop, chunks, iterations, np_particles, seed=1, ess_fraction=0.5, lag_fraction=2.0, vb=False, maxNE=1e99,
+           infer_recomb=True, rounded=True, device=0, rank=0, world=1, on_iteration=None):
+    """EM over `chunks` (each a packable Segments object of smcsmc_amd.segments).  Chunks are sharded over ranks
+    (reduce.assign_chunks, longest first); statistics are summed in chunk order on every rank, so all ranks take
+    identical M-steps.  Returns the list of per-iteration summed statistics; `pop` holds the final model."""
+    pop = copy.deepcopy(pop) if on_iteration is None else pop
+    history = []
+    sizes = [len(c) for c in chunks]
+    mine = reducer.assign_chunks(sizes, world)[rank]
+    for it in range(iterations + 1):
+        base = pop.device_model()
+        lags = pf.calibrated_lags(base, lag_fraction=lag_fraction, device=device)     # model-only: once per iteration
+        model = pop.device_model(lags=lags)
+        per_chunk = {}
+        for c in mine:
+            segs = chunks[c].pack(lags)
+            f = pf.ParticleFilter(model, np_particles, ess_fraction=ess_fraction, seed=seed + 1000 * it + c,
+                                  max_trace_events=0, device=device)
+            f.load_segments(segs)
+            f.init_prior(float(segs["start"][0]))
+            f.run()
+            f.finish()
+            per_chunk[c] = counts_to_data(model, f.counts(), np_particles, rounded=rounded)
+            f.close()
+        template = pf.unpack_counts(np.ones(pf.counts_len(len(pop.change_points), pop.num_populations)),
+                                    len(pop.change_points), pop.num_populations)
+        keys = sorted(counts_to_data(model, template, np_particles, rounded=rounded).keys())
+        gathered = reducer.gather_chunk_data(per_chunk, len(chunks), keys=keys)    # every rank gets every chunk's statistics
+        total = None
+        for c in range(len(chunks)):
+            total = add_data(total, gathered[c])
+        history.append(total)
+        if on_iteration is not None:
+            on_iteration(it, pop, total)
+        if it < iterations:
+            m_step(pop, total, vb=vb, maxNE=maxNE, infer_recomb=infer_recomb)
+    return pop, history

@@ -35,6 +35,30 @@ def allreduce_counts_ordered(packed, device=None):
     return total.cpu().numpy()
 
 
+def gather_chunk_data(per_chunk, n_chunks, keys=None, device=None):
+    """Every rank contributes the statistics dictionaries of the chunks it filtered ({chunk id: {key: value}});
+    every rank receives all of them.  One all-reduce of an [n_chunks, K] matrix in which each row has exactly one
+    non-zero contributor (x + 0 is exact), so the result is bit-identical to a gather; without torch.distributed
+    (single process) it is the identity.  `keys` fixes the column order (needed on ranks that own no chunk)."""
+    try:
+        import torch.distributed as dist
+        active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    except ImportError:
+        active = False
+    if not active:
+        return [per_chunk[c] for c in range(n_chunks)]
+    import torch
+    if keys is None:
+        keys = sorted(next(iter(per_chunk.values())).keys())
+    mat = np.zeros((n_chunks, len(keys)))
+    for c, d in per_chunk.items():
+        mat[c] = [d[k] for k in keys]
+    t = torch.as_tensor(mat, device=device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu"))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    mat = t.cpu().numpy()
+    return [dict(zip(keys, mat[c].tolist())) for c in range(n_chunks)]
+
+
 def assign_chunks(chunk_lengths, world):
     """Longest-first greedy assignment of chunks to ranks; returns rank -> [chunk ids]."""
     order = sorted(range(len(chunk_lengths)), key=lambda c: (-chunk_lengths[c], c))

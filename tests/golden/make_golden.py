@@ -69,6 +69,49 @@ def outfile():
     return rows
 
 
+def mstep(pm):
+    """Smcsmc.m_step (model.py:989-1048) applied to hand-made sufficient statistics: plain and variational-Bayes
+    variants, one- and two-population models, with and without -maxNE / -no_infer_recomb."""
+    import importlib
+    import random
+    model = importlib.import_module("smcsmc.model")
+    cases = []
+    rnd = random.Random(12345)
+    for name, P, E, vb, maxne, infer in [("one_pop", 1, 5, False, 1e99, True), ("one_pop_vb_cap", 1, 4, True, 30000.0, True),
+                                         ("two_pop", 2, 3, False, 1e99, True), ("two_pop_vb_norecomb", 2, 3, True, 1e99, False)]:
+        pop = pm.Population(num_samples=4, sequence_length=1e6, num_populations=P,
+                            sample_populations=[1 + (i * P) // 4 for i in range(4)],
+                            change_points=[0] + [0.1 * (k + 1) for k in range(E - 1)],
+                            population_sizes=[[1.0] * P for _ in range(E)],
+                            migration_rates=[[[0.0 if a == b else 0.5 for b in range(P)] for a in range(P)] for _ in range(E)])
+        pop._finalize_and_validate()      # fills the default event counts the front-end carries along
+        s = model.Smcsmc.__new__(model.Smcsmc)
+        s.pop = pop; s.do_m_step = True; s.vb = vb; s.maxNE = maxne; s.infer_recomb = infer
+        s.vb_dirichlet = {"ne": [1.0, 1.0], "migr": [1.0, 1.0]}
+        data = {}
+        rows = []
+        for e in range(E):
+            for a in range(P):
+                opp, cnt = rnd.uniform(1e5, 1e7), rnd.uniform(1.0, 400.0)
+                data[(("Coal", e, a, -1, -1), "Opp")] = opp; data[(("Coal", e, a, -1, -1), "Count")] = cnt
+                rows.append(dict(type="Coal", epoch=e, frm=a, to=-1, opp=opp, count=cnt))
+                for b in range(P):
+                    if a != b:
+                        opp, cnt = rnd.uniform(1e5, 1e7), rnd.uniform(0.0, 50.0)
+                        data[(("Migr", e, a, b, -1), "Opp")] = opp; data[(("Migr", e, a, b, -1), "Count")] = cnt
+                        rows.append(dict(type="Migr", epoch=e, frm=a, to=b, opp=opp, count=cnt))
+        opp, cnt = rnd.uniform(1e10, 1e11), rnd.uniform(100.0, 2000.0)
+        data[(("Recomb", -1, -1, -1, -1), "Opp")] = opp; data[(("Recomb", -1, -1, -1, -1), "Count")] = cnt
+        rows.append(dict(type="Recomb", epoch=-1, frm=-1, to=-1, opp=opp, count=cnt))
+        rho0 = pop.recombination_rate
+        s.m_step(data)
+        cases.append(dict(name=name, P=P, E=E, vb=vb, maxNE=maxne, infer_recomb=infer, N0=pop.N0, rows=rows,
+                          recombination_rate_before=rho0, population_sizes=pop.population_sizes,
+                          migration_rates=pop.migration_rates, recombination_rate=pop.recombination_rate,
+                          next_cmdline=pop.core_command_line(vb=vb)))
+    return cases
+
+
 def seg_prefix(src_rel, dst_name, limit):
     """First `limit` bp of one of the reference's committed scrm data sets (a data fixture of its own tests),
     closed with an all-missing row at the cut like convert_scrm_to_seg does (populationmodels.py:535-575)."""
@@ -92,6 +135,7 @@ if __name__ == "__main__":
     pm = load_ref()
     seg_prefix("test/old/newtests/testdata/twopopssplit_unidirmigr.seg", "twopopssplit_unidirmigr_first2Mb.seg", 2000001)
     json.dump(cmdlines(pm), open(os.path.join(HERE, "cmdlines.json"), "w"), indent=1)
+    json.dump(mstep(pm), open(os.path.join(HERE, "mstep.json"), "w"), indent=1)
     if os.path.exists(os.path.join(HERE, "sample.out")):
         json.dump(outfile(), open(os.path.join(HERE, "outfile.json"), "w"), indent=1)
     print("golden fixtures written")
