@@ -74,6 +74,29 @@ typedef struct pf_segments {
     const int32_t* max_record_epoch; /* [n] max_epoch_to_update (smcsmc.cpp:266-275) */
 } pf_segments;
 
+/* Auxiliary particle filter (-apf 1..4): the per-row output of Segment::set_lookahead (segdata.cpp:225-410; the host
+ * computes it, smcsmc_amd/csrc/host/segdata.cpp) and the tables of calculate_terminal_branch_length_quantiles
+ * (smcsmc.cpp:128-166).  Consumed by ForestState::includeLookaheadLikelihood (particle.cpp:439-617). */
+typedef struct pf_lookahead {
+    int32_t level;                            /* -apf */
+    int32_t max_doubletons;                   /* D: doubleton slots per row */
+    int32_t n_quantiles;                      /* Q */
+    int32_t reserved;
+    int64_t n;                                /* rows (= segments) */
+    const double* first_singleton_distance;   /* [n*nsam] */
+    const double* relative_mutation_rate;     /* [n*nsam] */
+    const int8_t* is_singleton_unphased;      /* [n*nsam] */
+    const int32_t* n_doubletons;              /* [n] */
+    const int8_t* doubleton_idx;              /* [n*D*4] seq_idx_1, seq_idx_2, unphased_1, unphased_2 */
+    const double* doubleton_dist;             /* [n*D*2] first_evidence_distance, last_evidence_distance */
+    const double* first_split_distance;       /* [n]  (-1: none) */
+    const int8_t* split_alleles;              /* [n*nsam] allelic_state_at_first_split */
+    const int32_t* split_count;               /* [n]  mutation_count_at_first_split */
+    const double* quantiles;                  /* [Q] */
+    const double* tbl_lengths;                /* [nsam*Q] */
+    double mean_total_branch_length;
+} pf_lookahead;
+
 typedef struct pf_handle pf_handle;
 
 /* packed count buffer, identical to the CountModel members read by count.cpp:66-158 (P == 1):
@@ -93,6 +116,11 @@ pf_handle* pf_create(const pf_model* model, const pf_params* params, int device)
 void pf_destroy(pf_handle* h);
 
 int pf_init_prior(pf_handle* h, double initial_position);
+/* after pf_load_segments: switches the auxiliary particle filter on (update_lookahead_likelihood, pc.cpp:227-240) */
+int pf_load_lookahead(pf_handle* h, const pf_lookahead* la);
+/* calculate_terminal_branch_length_quantiles (smcsmc.cpp:128-166) over n_trees prior trees */
+int pf_terminal_branch_quantiles(const pf_model* model, uint64_t seed, int64_t n_trees, const double* quantiles, int32_t nq,
+                                 double* lengths_out, double* mean_total_out, int device);
 int pf_load_segments(pf_handle* h, const pf_segments* segs);
 
 /* single steps (each enqueues on the handle's stream; pf_sync waits) */

@@ -115,6 +115,13 @@ static inline double smc_log(double x) {
 }
 
 /* reference: particle.cpp:30-40 */
+/* particle.cpp:45-55: one-division continued-fraction form for x^2 < 2.099166 (rel. error < 1e-2), exp otherwise */
+static inline double fastexp_approx(double x) {
+    double xx = x * x;
+    if (xx < 2.099166) return 1 + 2 * x / (2 - x + xx * (1.0 / 6));
+    return smc_exp(x);
+}
+
 static inline double fastexp(double x) {
     double xx = x * x;
     if (xx < 0.516167859) {

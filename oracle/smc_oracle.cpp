@@ -224,6 +224,7 @@ struct Particle {
     double x_mark;          /* start of the current recombination-opportunity stretch */
     int mark_limit;         /* max_epoch_to_record_ in force when the stretch was opened */
     double Ltree;
+    double lookahead = 1.0;                  /* lookahead_weight_ (particle.hpp:239) */
     double total_delayed = 1.0;              /* total_delayed_adjustment_ */
     int dcount = 0;                          /* pending DelayedFactors (particle.hpp:248) */
     double dpos[DCAP], dfac[DCAP], ddelta[DCAP];
@@ -261,7 +262,13 @@ struct Filter {
     std::vector<std::vector<int32_t>> ev_parents;
     int64_t seg_done = 0;
 
-    uint32_t stream = 0;          /* Philox stream id: 0 particle filter, 2 lag calibration */
+    /* auxiliary particle filter */
+    int apf = 0, la_D = 0, la_Q = 0;
+    std::vector<double> la_fsd, la_rmr, la_ddist, la_split, la_q, la_tbl;
+    std::vector<int8_t> la_unph, la_didx, la_salleles;
+    std::vector<int32_t> la_nd, la_sk;
+    double la_mean_tbl = 0;
+    uint32_t stream = 0;          /* Philox stream id: 0 particle filter, 2 lag calibration, 3 branch-length quantiles */
     bool record_events = true;
     double last_sp = 0; bool last_changed = false;
     double last_iw = 1.0, last_tc = 0.0;
@@ -958,7 +965,8 @@ struct Filter {
     }
 
     /* calculate_likelihood + cal_partial_likelihood_infinite (particle.cpp:625-680) */
-    double site_likelihood(const Tree& t, const int* hap) const {
+    double site_likelihood(const Tree& t, const int* hap) const { return site_likelihood_aa(t, hap, M.ancestral_aware); }
+    double site_likelihood_aa(const Tree& t, const int* hap, bool ancestral_aware) const {
         const int n = M.n;
         double m0[2 * NMAX], m1[2 * NMAX];
         for (int i = 0; i < n; ++i) {
@@ -975,8 +983,125 @@ struct Filter {
             m1[n + r] = (m1[c0] * pl + m0[c0] * (1 - pl)) * (m1[c1] * pr + m0[c1] * (1 - pr));
         }
         int root = n + n - 2;
-        double p0 = M.ancestral_aware ? 1.0 : 0.5, p1 = M.ancestral_aware ? 0.0 : 0.5;
+        double p0 = ancestral_aware ? 1.0 : 0.5, p1 = ancestral_aware ? 0.0 : 0.5;
         return m0[root] * p0 + m1[root] * p1;
+    }
+
+    /* ---------------- auxiliary particle filter (particle.cpp:439-617) ---------------- */
+    /* height of the first local node above leaf i: its coalescent parent, or the first migration on its branch */
+    double leaf_parent_height(const Tree& t, int leaf, int* parent_rank) const {
+        const int n = M.n;
+        int pr = -1;
+        for (int r = 0; r < n - 1 && pr < 0; ++r)
+            if (t.C[r][0] == leaf || t.C[r][1] == leaf) pr = r;
+        *parent_rank = pr;
+        double hgt = t.S[pr];
+        if (M.P > 1)
+            for (int m = 0; m < t.nm; ++m)
+                if (t.Mb[m] == leaf) { hgt = t.Mt[m]; pr = -2 - m; *parent_rank = pr; break; }   /* a migrating node */
+        return hgt;
+    }
+
+    double lookahead_likelihood(const Tree& t, double Ltree, int64_t row) const {
+        const int n = M.n, Q = la_Q, D = la_D;
+        const double* fsd = &la_fsd[row * n];
+        const double* rmr = &la_rmr[row * n];
+        const int8_t* unph = &la_unph[row * n];
+        const double recomb_rate = M.rho, mut_rate = M.mu;
+        const double rel_rho[2] = {1.0, 0.5}, rel_rho_p[2] = {0.5, 0.5};
+        double likelihood = 1.0;
+        double rho_tbl = 2 * recomb_rate * (n - 1) / n;
+        double mut_prob[NMAX];
+        double lh[NMAX]; int lpar[NMAX];
+        for (int i = 0; i < n; ++i) { mut_prob[i] = 0; lh[i] = leaf_parent_height(t, i, &lpar[i]); }
+        for (int i = 0; i < n; i++) {
+            double p = 0;
+            double si = fsd[i];
+            double li = lh[i];
+            if (unph[i]) li += lh[i + 1];
+            double rel_mut_rate = rmr[i];
+            double li_mu = li * mut_rate * rel_mut_rate;
+            mut_prob[i] = li_mu;
+            if (unph[i]) mut_prob[i + 1] = li_mu;
+            for (int r = 0; r < 2; r++) {
+                double li_rho = li * rho_tbl * rel_rho[r];
+                double fe = fastexp_approx(-(li_rho + li_mu) * std::fabs(si));
+                for (int q = 0; q < Q; ++q) {
+                    double qbot = (q == 0 ? 0.0 : la_q[q - 1]);
+                    double qtop = (q == Q - 1 ? 1.0 : la_q[q]);
+                    double l_prime = la_tbl[i * Q + q];
+                    double lprime_mu = l_prime * mut_rate * rel_mut_rate;
+                    double div = (li_rho + li_mu - lprime_mu);
+                    if (std::fabs(div) < (li_rho + li_mu + lprime_mu) * 1e-5) lprime_mu = lprime_mu * 1.0001;
+                    if (si > 0) {
+                        p += rel_rho_p[r] * (qtop - qbot) * ((li_rho * lprime_mu * fastexp_approx(-lprime_mu * si) +
+                                                              (li_mu - lprime_mu) * (li_rho + li_mu) * fe)
+                                                             / (li_rho + li_mu - lprime_mu));
+                    } else {
+                        p += rel_rho_p[r] * (qtop - qbot) * ((li_rho * fastexp_approx(-lprime_mu * (-si)) +
+                                                              (li_mu - lprime_mu) * fe)
+                                                             / (li_rho + li_mu - lprime_mu));
+                    }
+                }
+            }
+            likelihood *= p;
+            if (unph[i]) i++;        /* do not double-count unphased singletons */
+        }
+        if (apf >= 2) {
+            double l_mean = 0.0;
+            for (int i = 0; i < n; i++) l_mean += la_tbl[i * Q + (Q - 1)] / n;
+            double rho_c = 4 * recomb_rate * (n - 2) / n;
+            double rhoprime_c = recomb_rate * (n - 1);
+            double p_equilibrium = 2.0 / (3 * (n - 1));
+            const int nd = la_nd[row];
+            for (int k = 0; k < nd; ++k) {
+                const int8_t* di = &la_didx[(row * D + k) * 4];
+                const double fed = la_ddist[(row * D + k) * 2], led = la_ddist[(row * D + k) * 2 + 1];
+                int ph1, ph2;
+                for (ph1 = 0; ph1 <= di[2]; ph1++) {
+                    for (ph2 = 0; ph2 <= di[3]; ph2++) {
+                        int a = di[0] + ph1, b = di[1] + ph2;
+                        if (lpar[a] >= 0 && lpar[a] == lpar[b]) {
+                            double l = lh[a];
+                            double p = 0;
+                            for (int r = 0; r < 2; r++) {
+                                double exp_rho = fastexp_approx(-rho_c * rel_rho[r] * l * led);
+                                p += rel_rho_p[r] * exp_rho + p_equilibrium * (1.0 - exp_rho);
+                            }
+                            likelihood *= p;
+                            ph1 = ph2 = 99;
+                        }
+                    }
+                }
+                if (ph1 < 99) {
+                    double mutprob = (mut_prob[di[0]] + mut_prob[di[1]]) * 0.5;
+                    double p = 0;
+                    for (int r = 0; r < 2; r++)
+                        p += rel_rho_p[r] * (mutprob + (1.0 - mutprob) * p_equilibrium *
+                                             (1.0 - fastexp_approx(-rhoprime_c * rel_rho[r] * l_mean * fed)));
+                    likelihood *= p;
+                }
+            }
+        }
+        if (la_split[row] > -1 && apf >= 3) {
+            double rate_of_change = Ltree * recomb_rate / 2;
+            double p_nochange = fastexp_approx(-rate_of_change * la_split[row]);
+            int hap[NMAX];
+            for (int i = 0; i < n; ++i) hap[i] = la_salleles[row * n + i];
+            double p_splitdata = site_likelihood_aa(t, hap, false);
+            int k = la_sk[row];
+            double p_correct_split = k / double(4.0 * n * n);
+            if (apf == 4) {
+                double nCk = 1.0;
+                for (int i = 1; i <= k; i++) nCk *= (n - i + 1) / double(i);
+                p_correct_split = 1.0 / nCk;
+            }
+            double etbl = la_mean_tbl;
+            double split_branch_length = k * etbl / (2 * n * (0.577 * smc_log((double)n)));
+            double p = p_nochange * p_splitdata + (1.0 - p_nochange) * p_correct_split * mut_rate * split_branch_length;
+            likelihood *= p;
+        }
+        return likelihood;
     }
 
     /* ---------------- ParticleContainer ---------------- */
@@ -1144,6 +1269,19 @@ struct Filter {
                 p.w_pilot *= lik;
             }
         }
+        /* update_lookahead_likelihood (pc.cpp:227-240): remove the previous look-ahead factor from the pilot weight,
+         * include the new one.  (The reference does this between the extension and the site weight, pc.cpp:455-459;
+         * the pilot weight is the same product of factors either way.) */
+        if (apf > 0) {
+            for (int64_t pi = 0; pi < Np; ++pi) {
+                Particle& p = parts[pi];
+                p.w_pilot /= p.lookahead;
+                p.lookahead = 1.0;
+                double lk = lookahead_likelihood(p.tr, p.Ltree, s);
+                p.lookahead *= lk;
+                p.w_pilot *= lk;
+            }
+        }
         normalize();
     }
 
@@ -1280,6 +1418,7 @@ struct Filter {
                 if (q == lo[i] && cnt == 1) { d = std::move(src); continue; }
                 d.tr = src.tr; d.w_post = src.w_post; d.w_pilot = src.w_pilot;
                 d.next_base = src.next_base; d.Ltree = src.Ltree;
+                d.lookahead = src.lookahead;
                 d.total_delayed = src.total_delayed; d.dcount = src.dcount;
                 for (int k = 0; k < src.dcount; ++k) { d.dpos[k] = src.dpos[k]; d.dfac[k] = src.dfac[k]; d.ddelta[k] = src.ddelta[k]; d.dk[k] = src.dk[k]; }
                 d.head = src.head;                       /* copyEventContainers: particle.cpp:139-148 */
@@ -1388,8 +1527,8 @@ static void median_survival(const Model& M, uint64_t seed, int min_events, int64
 
 using namespace smco;
 
-#define GUARD(body)                                                  \
-    try { body }                                                     \
+#define GUARD(...)                                                   \
+    try { __VA_ARGS__ }                                              \
     catch (const std::exception& e) { g_err = e.what(); return -1; } \
     return 0;
 
@@ -1465,6 +1604,66 @@ void* smco_create(const smco_model* m, const smco_params* p) {
 }
 
 void smco_destroy(void* h) { delete (Filter*)h; }
+
+int smco_load_lookahead(void* h, const smco_lookahead* la) {
+    GUARD(
+        Filter* f = (Filter*)h;
+        const int n = f->M.n;
+        const int64_t S = la->n;
+        if (la->level < 0 || la->level > 4) throw std::runtime_error("-apf must be 0..4");
+        f->apf = la->level; f->la_D = la->max_doubletons; f->la_Q = la->n_quantiles;
+        f->la_fsd.assign(la->first_singleton_distance, la->first_singleton_distance + S * n);
+        f->la_rmr.assign(la->relative_mutation_rate, la->relative_mutation_rate + S * n);
+        f->la_unph.assign(la->is_singleton_unphased, la->is_singleton_unphased + S * n);
+        f->la_nd.assign(la->n_doubletons, la->n_doubletons + S);
+        f->la_didx.assign(la->doubleton_idx, la->doubleton_idx + S * f->la_D * 4);
+        f->la_ddist.assign(la->doubleton_dist, la->doubleton_dist + S * f->la_D * 2);
+        f->la_split.assign(la->first_split_distance, la->first_split_distance + S);
+        f->la_salleles.assign(la->split_alleles, la->split_alleles + S * n);
+        f->la_sk.assign(la->split_count, la->split_count + S);
+        f->la_q.assign(la->quantiles, la->quantiles + f->la_Q);
+        f->la_tbl.assign(la->tbl_lengths, la->tbl_lengths + (int64_t)n * f->la_Q);
+        f->la_mean_tbl = la->mean_total_branch_length;
+    )
+}
+
+int smco_terminal_branch_quantiles(const smco_model* m, uint64_t seed, int64_t n_trees, const double* quantiles, int32_t nq,
+                                   double* lengths_out, double* mean_total_out) {
+    GUARD(
+        Filter f;
+        fill_model(f.M, m);
+        f.M.recflags.assign(f.M.E, 3);
+        f.M.lags.assign(f.M.E, 0.0);
+        const int n = f.M.n;
+        f.Np = 1; f.seed = seed; f.stream = 3; f.record_events = false;
+        f.rng.assign(1, SlotRng{0, 0.0});
+        std::vector<std::vector<double>> tbls(n);
+        for (auto& v : tbls) v.reserve(n_trees);
+        std::vector<double> lengths(n_trees);
+        for (int64_t r = 0; r < n_trees; ++r) {
+            Particle p;
+            p.head.assign(f.M.E, nullptr);
+            f.rng[0] = SlotRng{0, 0.0};
+            f.slot_override = r;
+            f.rng[0].ebuf = -smc_log(f.uni(0));
+            f.build_initial_tree(0, p);
+            lengths[r] = p.Ltree;
+            for (int i = 0; i < n; ++i) {
+                int pr = -1;
+                for (int k = 0; k < n - 1 && pr < 0; ++k)
+                    if (p.tr.C[k][0] == i || p.tr.C[k][1] == i) pr = k;
+                tbls[i].push_back(p.tr.S[pr]);          /* parent_height_ignoring_migrations (smcsmc.cpp:115-125) */
+            }
+        }
+        for (int i = 0; i < n; ++i) {
+            std::sort(tbls[i].begin(), tbls[i].end());
+            for (int q = 0; q < nq; ++q) lengths_out[i * nq + q] = tbls[i][(int64_t)(quantiles[q] * (double)n_trees)];
+        }
+        double total_length = 0.0;                      /* serial, in tree order (smcsmc.cpp:145) */
+        for (int64_t r = 0; r < n_trees; ++r) total_length += lengths[r];
+        *mean_total_out = total_length / (double)n_trees;
+    )
+}
 
 int smco_init_prior(void* h, double initial_position) { GUARD(((Filter*)h)->init_prior(initial_position);) }
 

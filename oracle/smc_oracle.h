@@ -64,6 +64,28 @@ typedef struct smco_segments {
     const int32_t* max_record_epoch; /* [n] smcsmc.cpp:266-275 */
 } smco_segments;
 
+/* auxiliary particle filter (-apf 1..4): the per-row output of Segment::set_lookahead (segdata.cpp:225-410) and the
+ * tables of calculate_terminal_branch_length_quantiles (smcsmc.cpp:128-166); same layout as pf_lookahead */
+typedef struct smco_lookahead {
+    int32_t level;                            /* -apf */
+    int32_t max_doubletons;                   /* D: doubleton slots per row */
+    int32_t n_quantiles;                      /* Q */
+    int32_t reserved;
+    int64_t n;                                /* rows (= segments) */
+    const double* first_singleton_distance;   /* [n*nsam] */
+    const double* relative_mutation_rate;     /* [n*nsam] */
+    const int8_t* is_singleton_unphased;      /* [n*nsam] */
+    const int32_t* n_doubletons;              /* [n] */
+    const int8_t* doubleton_idx;              /* [n*D*4] seq_idx_1, seq_idx_2, unphased_1, unphased_2 */
+    const double* doubleton_dist;             /* [n*D*2] first_evidence_distance, last_evidence_distance */
+    const double* first_split_distance;       /* [n]  (-1: none) */
+    const int8_t* split_alleles;              /* [n*nsam] allelic_state_at_first_split */
+    const int32_t* split_count;               /* [n]  mutation_count_at_first_split */
+    const double* quantiles;                  /* [Q] */
+    const double* tbl_lengths;                /* [nsam*Q] */
+    double mean_total_branch_length;
+} smco_lookahead;
+
 /* layout of the packed count buffer (doubles), P == 1:
  *   [0*E..1*E) coal_count  [1*E..2*E) coal_opp  [2*E..3*E) coal_weight
  *   [3*E..4*E) rec_count   [4*E..5*E) rec_opp   [5*E..6*E) rec_weight
@@ -79,6 +101,10 @@ void* smco_create(const smco_model* m, const smco_params* p);
 void smco_destroy(void* h);
 const char* smco_last_error(void);
 
+int smco_load_lookahead(void* h, const smco_lookahead* la);            /* switches the auxiliary particle filter on */
+/* calculate_terminal_branch_length_quantiles (smcsmc.cpp:128-166) over n_trees prior trees (Philox stream 3) */
+int smco_terminal_branch_quantiles(const smco_model* m, uint64_t seed, int64_t n_trees, const double* quantiles, int32_t nq,
+                                   double* lengths_out, double* mean_total_out);
 int smco_init_prior(void* h, double initial_position);               /* particleContainer.cpp:33-65 */
 int smco_run(void* h, const smco_segments* segs);                    /* smcsmc.cpp:324-373 */
 /* single steps, mirroring the reference's public methods */

@@ -48,6 +48,32 @@ static void dump_model_json(const PfParam& p) {
     cout << "]}" << endl;
 }
 
+static void dump_lookahead_json(const PfParam& p) {
+    LookaheadArrays la;
+    p.Segfile->pack_lookahead(la);
+    const size_t S = la.n_doubletons.size();
+    const int n = p.model.nsam, D = la.max_doubletons;
+    cout << setprecision(17) << "{\"max_doubletons\": " << D << ", \"rows\": [";
+    for (size_t i = 0; i < S; ++i) {
+        cout << (i ? ", " : "") << "{\"fsd\": [";
+        for (int j = 0; j < n; ++j) cout << (j ? ", " : "") << la.first_singleton_distance[i * n + j];
+        cout << "], \"rmr\": [";
+        for (int j = 0; j < n; ++j) cout << (j ? ", " : "") << la.relative_mutation_rate[i * n + j];
+        cout << "], \"unph\": [";
+        for (int j = 0; j < n; ++j) cout << (j ? ", " : "") << (int)la.is_singleton_unphased[i * n + j];
+        cout << "], \"dbl\": [";
+        for (int k = 0; k < la.n_doubletons[i]; ++k) {
+            const int8_t* di = &la.doubleton_idx[(i * D + k) * 4];
+            cout << (k ? ", " : "") << "[" << (int)di[0] << ", " << (int)di[1] << ", " << (int)di[2] << ", " << (int)di[3] << ", "
+                 << la.doubleton_dist[(i * D + k) * 2] << ", " << la.doubleton_dist[(i * D + k) * 2 + 1] << "]";
+        }
+        cout << "], \"split\": " << la.first_split_distance[i] << ", \"split_alleles\": [";
+        for (int j = 0; j < n; ++j) cout << (j ? ", " : "") << (int)la.split_alleles[i * n + j];
+        cout << "], \"split_count\": " << la.split_count[i] << "}";
+    }
+    cout << "]}" << endl;
+}
+
 static void pf_check(int rc) {
     if (rc < 0) throw std::runtime_error(pf_last_error());
 }
@@ -123,6 +149,25 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
     P.Segfile->pack(lags, start, length, state, alleles, mre);
     pf_segments sg = {(int64_t)start.size(), start.data(), length.data(), state.data(), alleles.data(), mre.data()};
 
+    // auxiliary particle filter: look-ahead per row + terminal branch length quantiles (smcsmc.cpp:288, 128-166)
+    LookaheadArrays la;
+    std::vector<double> tbl_lengths;
+    double mean_tbl = 0;
+    const double tbl_quantiles[7] = {0.001, 0.003, 0.01, 0.03, 0.1, 0.5, 0.95};
+    if (P.auxiliary_particle_filter > 0) {
+        if (NP > 1) throw Unsupported("-apf with more than one population");
+        if (P.Segfile->empty_file()) throw Unsupported("-apf without -seg data");
+        cout << "Calculating terminal branch length quantiles..." << endl;
+        tbl_lengths.resize((size_t)M.nsam * 7);
+        pf_check(pf_terminal_branch_quantiles(&pm, 1, 1000000, tbl_quantiles, 7, tbl_lengths.data(), &mean_tbl, device));
+        for (int i = 0; i < M.nsam; ++i) {
+            cout << "Lineage " << i << "; Terminal branch length quantiles:";
+            for (int q = 0; q < 7; ++q) cout << " [" << tbl_quantiles[q] << ":] " << tbl_lengths[(size_t)i * 7 + q];
+            cout << endl;
+        }
+        P.Segfile->pack_lookahead(la);
+    }
+
     pf_params pp;
     memset(&pp, 0, sizeof(pp));
     pp.np = (int64_t)P.N; pp.ess_fraction = P.ESS_fraction; pp.seed = M.seed_set ? M.seed : (uint64_t)time(nullptr);
@@ -131,6 +176,20 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
     if (!h) throw std::runtime_error(pf_last_error());
     try {
         pf_check(pf_load_segments(h, &sg));
+        if (P.auxiliary_particle_filter > 0) {
+            pf_lookahead pl;
+            memset(&pl, 0, sizeof(pl));
+            pl.level = P.auxiliary_particle_filter; pl.max_doubletons = la.max_doubletons; pl.n_quantiles = 7; pl.n = sg.n;
+            pl.first_singleton_distance = la.first_singleton_distance.data();
+            pl.relative_mutation_rate = la.relative_mutation_rate.data();
+            pl.is_singleton_unphased = la.is_singleton_unphased.data();
+            pl.n_doubletons = la.n_doubletons.data();
+            pl.doubleton_idx = la.doubleton_idx.data(); pl.doubleton_dist = la.doubleton_dist.data();
+            pl.first_split_distance = la.first_split_distance.data();
+            pl.split_alleles = la.split_alleles.data(); pl.split_count = la.split_count.data();
+            pl.quantiles = tbl_quantiles; pl.tbl_lengths = tbl_lengths.data(); pl.mean_total_branch_length = mean_tbl;
+            pf_check(pf_load_lookahead(h, &pl));
+        }
         pf_check(pf_init_prior(h, start.empty() ? 0.0 : start[0]));
         const int64_t S = sg.n;
         const int64_t step = 1000;
@@ -255,6 +314,7 @@ int main(int argc, char* argv[]) {
         if (P.version()) { P.printVersion(&std::cout); return EXIT_SUCCESS; }
         if (P.help()) { P.printHelp(); return EXIT_SUCCESS; }
         if (P.dump_model) { dump_model_json(P); return EXIT_SUCCESS; }
+        if (P.dump_lookahead) { dump_lookahead_json(P); return EXIT_SUCCESS; }
         P.outFileHeader();
         const HostModel initial_model = P.model;        // what CountModel is constructed from (smcsmc.cpp:77)
         for (int i = 0; i <= P.EM_steps; i++) {

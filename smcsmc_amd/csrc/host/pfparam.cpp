@@ -260,6 +260,7 @@ void PfParam::parse(int argc, char* argv[]) {
         else if (a == "-log") log_bool = true;
         else if (a == "-record_ess") record_resample_file = true;
         else if (a == "-dumpmodel") dump_model = true;      // not a reference flag: prints the parsed tables as JSON
+        else if (a == "-dumplookahead") dump_lookahead = true;   // not a reference flag: prints set_lookahead per row as JSON
         else if (a == "-h" || a == "-help") help_ = true;
         else if (a == "-v" || a == "-version") version_ = true;
         else { scrm_tokens.push_back(a); scrm_input += a + " "; }
@@ -278,7 +279,7 @@ void PfParam::finalize() {
     resample_NAME = out_NAME_prefix + ".resample";
     if (!input_RecombinationBiasFileName.empty() && auxiliary_particle_filter > 0)
         throw std::invalid_argument("Recombination guiding and auxiliary particle filters cannot currently be used together");
-    if (!dump_model) {
+    if (!dump_model && !dump_lookahead) {
         remove(outFileName.c_str());
         remove(log_NAME.c_str());
         remove(recombination_map_NAME.c_str());
@@ -286,7 +287,6 @@ void PfParam::finalize() {
     }
     if (!pattern.empty()) throw Unsupported("-p (the Python front-end generates epochs itself)");
     if (!input_RecombinationBiasFileName.empty()) throw Unsupported("-guide");
-    if (auxiliary_particle_filter > 0) throw Unsupported("-apf > 0");
     model.nsam = (int)default_nsam;
     model.parse(scrm_tokens);
     default_loci_length = model.loci_length;
@@ -359,7 +359,7 @@ void PfParam::printHelp() {   // pfparam.cpp:541-585
     opt("-o", "STR", "Prefix for output files");
     opt("-EM", "INT", "EM iterations [ 0 ]");
     opt("-startpos", "INT", "First nucleotide position to analyze [ 1 ]");
-    opt("-apf", "INT", "Use auxiliary particle filter [ 0 ] (only 0 is supported in this build)");
+    opt("-apf", "INT", "Use auxiliary particle filter [ 0 ]; 1 singletons, 2 + doubletons, 3 + splits, 4 n-choose-k split factor");
     opt("-log", " ", "Generate *.log file");
     opt("-v", " ", "Display timestamp and versions");
     cout << endl << "Inference tuning:" << endl;

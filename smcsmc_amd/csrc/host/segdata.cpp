@@ -158,3 +158,137 @@ void Segment::pack(const vector<double>& lags, vector<double>& start, vector<dou
         mre[i] = max_epoch_to_update(lags, d);
     }
 }
+
+
+// ------------------------------------------------------------------ auxiliary particle filter look-ahead
+// Segment::set_lookahead (segdata.cpp:225-410) for every buffered row, written into the arrays of pf_lookahead.
+void Segment::pack_lookahead(LookaheadArrays& out) const {
+    const size_t S = buffer_.size();
+    const int nsam = (int)nsam_;
+    const int D = std::max(1, nsam / 2);
+    out.max_doubletons = D;
+    out.first_singleton_distance.assign(S * nsam, 0.0);
+    out.relative_mutation_rate.assign(S * nsam, 0.0);
+    out.is_singleton_unphased.assign(S * nsam, 0);
+    out.n_doubletons.assign(S, 0);
+    out.doubleton_idx.assign(S * D * 4, 0);
+    out.doubleton_dist.assign(S * D * 2, 0.0);
+    out.first_split_distance.assign(S, -1.0);
+    out.split_alleles.assign(S * nsam, 0);
+    out.split_count.assign(S, 0);
+    struct Doubleton { int s1, s2; double first, last; bool u1, u2, incompatible; };
+    const double max_missing_data = 2000000;
+    for (size_t cur = 0; cur < S; ++cur) {
+        vector<double> fsd(nsam, 0.0), rmr(nsam, 0.0);
+        vector<Doubleton> doubleton;
+        double first_split_distance = -1;
+        vector<int> split_alleles(nsam, 0);
+        int split_count = 0;
+        vector<bool> found_doubleton(nsam + 1, false);
+        int num_singletons = 0, num_unphased_singletons = 0, num_doubleton_sequences = 0;
+        double tl = 0.1, tl_missing = 0.1, total_current_missing = 0.0, last_singleton_distance = 0.0, distance = 0.0;
+        vector<int> unph;
+        const long long start0 = buffer_[cur].segment_start;
+        for (size_t i = cur; i < S; i++) {
+            const SegDatum& b = buffer_[i];
+            int num_var = 0, num_missing = 0, s1 = -1, s2 = -1;
+            unph.clear();
+            for (int j = 0; j < nsam; j++) {
+                unph.push_back(0);
+                if (b.allele_state[j] > 0) {
+                    num_var++;
+                    if (num_var == 1) s1 = j;
+                    if (num_var == 2) s2 = j;
+                    if (b.allele_state[j] == 2) {
+                        unph[j] = 1;
+                        unph.push_back(1);
+                        j++;
+                    }
+                }
+                if (j < nsam && b.allele_state[j] == -1) {
+                    num_missing++;
+                    if (num_missing == 1) total_current_missing += b.segment_length;
+                    if (total_current_missing > max_missing_data) {
+                        if (fsd[j] == 0) {
+                            const double epsilon = 1e-6;
+                            fsd[j] = -(double)(b.segment_start - start0) - epsilon;
+                            last_singleton_distance = -fsd[j];
+                            if (fsd[j] < 0.5 * total_current_missing) fsd[j] = -epsilon;
+                            rmr[j] = tl_missing / tl;
+                            num_singletons++;
+                        }
+                        if (!found_doubleton[j]) { found_doubleton[j] = true; num_doubleton_sequences++; }
+                    }
+                }
+            }
+            if (num_missing == 0) total_current_missing = 0.0;
+            tl += (double)b.segment_length * nsam;
+            tl_missing += (double)b.segment_length * (nsam - num_missing);
+            if (total_current_missing > max_missing_data) continue;
+            bool have_doubleton = false;
+            distance = (double)(b.segment_start + b.segment_length - start0) + 0.5;
+            if (num_var == 1) {
+                if (fsd[s1] == 0) {
+                    fsd[s1] = distance;
+                    rmr[s1] = tl_missing / tl;
+                    num_singletons++;
+                    last_singleton_distance = fsd[s1];
+                    if (unph[s1]) {
+                        fsd[s1 + 1] = distance;
+                        rmr[s1 + 1] = rmr[s1];
+                        num_singletons++;
+                        num_unphased_singletons++;
+                    }
+                }
+            } else {
+                for (Doubleton& d : doubleton) {
+                    int a1 = b.allele_state[d.s1], a2 = b.allele_state[d.s2];
+                    if (((d.s1 | 1) == d.s2 && a1 == 2) || ((a1 + a2 == 1) && ((a1 | a2) == 1))) d.incompatible = true;
+                    if (num_var == 2 && d.s1 == s1 && d.s2 == s2) {
+                        have_doubleton = true;
+                        if (!d.incompatible) d.last = distance;
+                    }
+                }
+            }
+            if (num_var == 2 && !have_doubleton && b.allele_state[s1] > -1 && b.allele_state[s2] > -1) {
+                for (int d1 = 0; d1 <= (b.allele_state[s1] == 2); d1++)
+                    for (int d2 = 0; d2 <= (b.allele_state[s2] == 2); d2++)
+                        if (!found_doubleton[s1 + d1] && !found_doubleton[s2 + d2]) {
+                            doubleton.push_back(Doubleton{s1, s2, distance, distance, b.allele_state[s1] == 2,
+                                                          b.allele_state[s2] == 2, false});
+                            found_doubleton[s1 + d1] = true; num_doubleton_sequences++;
+                            found_doubleton[s2 + d2] = true; num_doubleton_sequences++;
+                            d1 = 1; d2 = 1;
+                        }
+            }
+            if (first_split_distance == -1 && num_var > 2 && nsam - num_var > 2) {
+                first_split_distance = distance;
+                split_alleles = b.allele_state;
+                split_count = std::min(num_var, nsam - num_var);
+            }
+            if ((num_singletons == nsam) && num_doubleton_sequences >= nsam - 1) break;
+            if ((num_singletons == nsam) && distance > (2 + num_unphased_singletons) * last_singleton_distance) break;
+        }
+        if (num_singletons < nsam)
+            for (int j = 0; j < nsam; j++)
+                if (fsd[j] == 0) { fsd[j] = -distance; rmr[j] = tl_missing / tl; }
+        unph.resize(nsam, 0);
+        for (int j = 0; j < nsam; ++j) {
+            out.first_singleton_distance[cur * nsam + j] = fsd[j];
+            out.relative_mutation_rate[cur * nsam + j] = rmr[j];
+            out.is_singleton_unphased[cur * nsam + j] = (int8_t)unph[j];
+            out.split_alleles[cur * nsam + j] = (int8_t)split_alleles[j];
+        }
+        if ((int)doubleton.size() > D) throw InvalidSeg("Internal error - more doubletons than sequence pairs");
+        out.n_doubletons[cur] = (int32_t)doubleton.size();
+        for (size_t k = 0; k < doubleton.size(); ++k) {
+            int8_t* di = &out.doubleton_idx[(cur * D + k) * 4];
+            di[0] = (int8_t)doubleton[k].s1; di[1] = (int8_t)doubleton[k].s2;
+            di[2] = doubleton[k].u1; di[3] = doubleton[k].u2;
+            out.doubleton_dist[(cur * D + k) * 2] = doubleton[k].first;
+            out.doubleton_dist[(cur * D + k) * 2 + 1] = doubleton[k].last;
+        }
+        out.first_split_distance[cur] = first_split_distance;
+        out.split_count[cur] = split_count;
+    }
+}

@@ -102,6 +102,14 @@ struct SegDatum {
     }
 };
 
+// per-row arrays of Segment::set_lookahead in the layout of pf_lookahead (include/smcsmc_pf.h)
+struct LookaheadArrays {
+    int max_doubletons = 1;
+    std::vector<double> first_singleton_distance, relative_mutation_rate, doubleton_dist, first_split_distance;
+    std::vector<int8_t> is_singleton_unphased, doubleton_idx, split_alleles;
+    std::vector<int32_t> n_doubletons, split_count;
+};
+
 class Segment {   // segdata.hpp:86-177
   public:
     Segment(std::string file_name, size_t nsam, double seqlen, double num_of_mut, long long data_start = 1,
@@ -111,6 +119,7 @@ class Segment {   // segdata.hpp:86-177
     // arrays for pf_load_segments (coordinates relative to data_start; read_new_line semantics)
     void pack(const std::vector<double>& lags, std::vector<double>& start, std::vector<double>& length,
               std::vector<int8_t>& state, std::vector<int8_t>& alleles, std::vector<int32_t>& max_record_epoch) const;
+    void pack_lookahead(LookaheadArrays& out) const;   // set_lookahead (segdata.cpp:225-410) for every row
   private:
     void prepare();
     std::vector<int> extract_field_VARIANT(const std::string& field);
@@ -158,7 +167,7 @@ class PfParam {   // pfparam.hpp:225-446
     double top_t = 2;
     bool useCap = false;
     double Ne_cap = 200000;
-    bool log_bool = true, record_resample_file = false, record_trees = false, dump_model = false;
+    bool log_bool = true, record_resample_file = false, record_trees = false, dump_model = false, dump_lookahead = false;
     size_t default_nsam = 2;
     double default_loci_length = 2e7;
     double default_num_mut = 0;

@@ -116,6 +116,13 @@ __device__ __forceinline__ double dlog(double x) {
 }
 
 // reference: particle.cpp:30-40
+// particle.cpp:45-55
+__device__ __forceinline__ double fastexp_approx(double x) {
+    double xx = x * x;
+    if (xx < 2.099166) return 1 + 2 * x / (2 - x + xx * (1.0 / 6));
+    return dexp(x);
+}
+
 __device__ __forceinline__ double fastexp(double x) {
     double xx = x * x;
     if (xx < 0.516167859) {

@@ -93,6 +93,7 @@ __global__ __launch_bounds__(PF_BS) void k_init(KArgs A, double initial_position
     st.Ltree[p] = ln.Ltree;
     st.mark_limit[p] = A.E - 1;
     if (A.n_bias > 0) { st.total_delayed[p] = 1.0; st.dcount[p] = 0; }
+    if (st.lookahead) st.lookahead[p] = 1.0;
     A.rng_ctr[p] = ln.ctr;
     A.ebuf[p] = ln.ebuf;
     A.widx[p] = widx;
@@ -1266,6 +1267,7 @@ __global__ __launch_bounds__(PF_BS) void k_resample(KArgs A, long long s, int nb
     dst.Ltree[q] = Lt;
     dst.x_mark[q] = pos;
     dst.mark_limit[q] = src.mark_limit[a];
+    if (A.apf > 0) dst.lookahead[q] = src.lookahead[a];
     if (A.n_bias > 0) {
         // the copy constructor copies the pending factors (particle.cpp:122-123)
         int dc = src.dcount[a];
@@ -1383,6 +1385,201 @@ __global__ __launch_bounds__(PF_BS) void k_calibrate(KArgs A, unsigned long long
     }
 }
 
+// ------------------------------------------------------------------ k_lookahead
+// update_lookahead_likelihood (pc.cpp:227-240) with ForestState::includeLookaheadLikelihood (particle.cpp:439-617):
+// the previous look-ahead factor leaves the pilot weight, the new one enters it.  Runs after k_extend (the pilot
+// weight is a product of the same factors in either order) and rewrites the pilot part of the per-wavefront
+// partials that k_decide consumes.  One population.
+static size_t smem_bytes_la(int n, int E) { return smem_bytes(n, E) + (size_t)PF_BS * (2 * n * 8 + n * 4); }
+
+__global__ __launch_bounds__(PF_BS) void k_lookahead(KArgs A, long long row) {
+    extern __shared__ double smem[];
+    Smem m = carve(smem, A.n, A.E);
+    double* s_lh = (double*)((char*)smem + smem_bytes(A.n, A.E)) + threadIdx.x;       // [n] stride PF_BS
+    double* s_mp = s_lh + (size_t)A.n * PF_BS;                                           // [n]
+    int* s_par = (int*)((double*)((char*)smem + smem_bytes(A.n, A.E)) + (size_t)2 * A.n * PF_BS) + threadIdx.x;   // [n]
+    load_model(A, m);
+    __syncthreads();
+    const Ctrl* c = A.ctrl;
+    const int n = A.n, Q = A.la_Q, D = A.la_D;
+    const long long p = (long long)blockIdx.x * PF_BS + threadIdx.x;
+    const bool active = p < A.Np;
+    const int lane = threadIdx.x & 63;
+    double w_pilot = 0.0;
+    if (active) {
+        DState& st = A.st[c->cur];
+        Lane ln = make_lane(A, m, p);
+        for (int r = 0; r < n - 1; ++r) {
+            LS(ln, r) = st.S[(size_t)r * A.Np + p];
+            LC(ln, r, 0) = st.C[(size_t)(2 * r) * A.Np + p];
+            LC(ln, r, 1) = st.C[(size_t)(2 * r + 1) * A.Np + p];
+        }
+        const double Ltree = st.Ltree[p];
+        const double* fsd = A.la_fsd + (size_t)row * n;
+        const double* rmr = A.la_rmr + (size_t)row * n;
+        const int8_t* unph = A.la_unph + (size_t)row * n;
+        const double recomb_rate = A.rho, mut_rate = A.mu;
+        double likelihood = 1.0;
+        const double rho_tbl = 2 * recomb_rate * (n - 1) / n;
+        for (int i = 0; i < n; ++i) {
+            int pr = -1;
+            for (int r = 0; r < n - 1 && pr < 0; ++r)
+                if (LC(ln, r, 0) == i || LC(ln, r, 1) == i) pr = r;
+            s_par[i * PF_BS] = pr;
+            s_lh[i * PF_BS] = LS(ln, pr);
+            s_mp[i * PF_BS] = 0.0;
+        }
+        for (int i = 0; i < n; i++) {
+            double pp = 0;
+            const double si = fsd[i];
+            double li = s_lh[i * PF_BS];
+            const bool up = unph[i] != 0;
+            if (up) li += s_lh[(i + 1) * PF_BS];
+            const double rel_mut_rate = rmr[i];
+            const double li_mu = li * mut_rate * rel_mut_rate;
+            s_mp[i * PF_BS] = li_mu;
+            if (up) s_mp[(i + 1) * PF_BS] = li_mu;
+            for (int r = 0; r < 2; r++) {
+                const double rel = r == 0 ? 1.0 : 0.5;
+                const double li_rho = li * rho_tbl * rel;
+                const double fe = fastexp_approx(-(li_rho + li_mu) * fabs(si));
+                for (int q = 0; q < Q; ++q) {
+                    double qbot = (q == 0 ? 0.0 : A.la_q[q - 1]);
+                    double qtop = (q == Q - 1 ? 1.0 : A.la_q[q]);
+                    double l_prime = A.la_tbl[i * Q + q];
+                    double lprime_mu = l_prime * mut_rate * rel_mut_rate;
+                    double div = (li_rho + li_mu - lprime_mu);
+                    if (fabs(div) < (li_rho + li_mu + lprime_mu) * 1e-5) lprime_mu = lprime_mu * 1.0001;
+                    if (si > 0) {
+                        pp += 0.5 * (qtop - qbot) * ((li_rho * lprime_mu * fastexp_approx(-lprime_mu * si) +
+                                                      (li_mu - lprime_mu) * (li_rho + li_mu) * fe)
+                                                     / (li_rho + li_mu - lprime_mu));
+                    } else {
+                        pp += 0.5 * (qtop - qbot) * ((li_rho * fastexp_approx(-lprime_mu * (-si)) +
+                                                      (li_mu - lprime_mu) * fe)
+                                                     / (li_rho + li_mu - lprime_mu));
+                    }
+                }
+            }
+            likelihood *= pp;
+            if (up) i++;
+        }
+        if (A.apf >= 2) {
+            double l_mean = 0.0;
+            for (int i = 0; i < n; i++) l_mean += A.la_tbl[i * Q + (Q - 1)] / n;
+            const double rho_c = 4 * recomb_rate * (n - 2) / n;
+            const double rhoprime_c = recomb_rate * (n - 1);
+            const double p_equilibrium = 2.0 / (3 * (n - 1));
+            const int nd = A.la_nd[row];
+            for (int k = 0; k < nd; ++k) {
+                const int8_t* di = A.la_didx + ((size_t)row * D + k) * 4;
+                const double fed = A.la_ddist[((size_t)row * D + k) * 2], led = A.la_ddist[((size_t)row * D + k) * 2 + 1];
+                int ph1, ph2;
+                for (ph1 = 0; ph1 <= di[2]; ph1++) {
+                    for (ph2 = 0; ph2 <= di[3]; ph2++) {
+                        int a = di[0] + ph1, b = di[1] + ph2;
+                        if (s_par[a * PF_BS] == s_par[b * PF_BS]) {
+                            double l = s_lh[a * PF_BS];
+                            double pp = 0;
+                            for (int r = 0; r < 2; r++) {
+                                double exp_rho = fastexp_approx(-rho_c * (r == 0 ? 1.0 : 0.5) * l * led);
+                                pp += 0.5 * exp_rho + p_equilibrium * (1.0 - exp_rho);
+                            }
+                            likelihood *= pp;
+                            ph1 = ph2 = 99;
+                        }
+                    }
+                }
+                if (ph1 < 99) {
+                    double mutprob = (s_mp[di[0] * PF_BS] + s_mp[di[1] * PF_BS]) * 0.5;
+                    double pp = 0;
+                    for (int r = 0; r < 2; r++)
+                        pp += 0.5 * (mutprob + (1.0 - mutprob) * p_equilibrium *
+                                     (1.0 - fastexp_approx(-rhoprime_c * (r == 0 ? 1.0 : 0.5) * l_mean * fed)));
+                    likelihood *= pp;
+                }
+            }
+        }
+        if (A.la_split[row] > -1 && A.apf >= 3) {
+            double rate_of_change = Ltree * recomb_rate / 2;
+            double p_nochange = fastexp_approx(-rate_of_change * A.la_split[row]);
+            unsigned one_mask = 0, zero_mask = 0;
+            for (int i = 0; i < n; ++i) {
+                int v = A.la_salleles[(size_t)row * n + i];
+                if (v == 1) one_mask |= 1u << i;
+                if (v == 0) zero_mask |= 1u << i;
+            }
+            double p_splitdata = site_lik_lane(ln, one_mask, zero_mask, false, m.t0 + threadIdx.x, m.t1 + threadIdx.x);
+            int k = A.la_sk[row];
+            double p_correct_split = k / double(4.0 * n * n);
+            if (A.apf == 4) {
+                double nCk = 1.0;
+                for (int i = 1; i <= k; i++) nCk *= (n - i + 1) / double(i);
+                p_correct_split = 1.0 / nCk;
+            }
+            double split_branch_length = k * A.la_mean_tbl / (2 * n * (0.577 * dlog((double)n)));
+            double pp = p_nochange * p_splitdata + (1.0 - p_nochange) * p_correct_split * mut_rate * split_branch_length;
+            likelihood *= pp;
+        }
+        // removeLookaheadLikelihood + includeLookaheadLikelihood (particle.hpp:182, particle.cpp:614-616)
+        w_pilot = st.w_pilot[p];
+        w_pilot /= st.lookahead[p];
+        double la_w = 1.0;
+        la_w *= likelihood;
+        w_pilot *= likelihood;
+        st.lookahead[p] = la_w;
+        st.w_pilot[p] = w_pilot;
+    }
+    double sq = wave_tree_sum(w_pilot * w_pilot);
+    double sc = wave_hs_scan(w_pilot, lane);
+    double scm = wave_max_scan_d(sc, lane);
+    long long chunk = p >> 6;
+    if (active) { A.scan1[p] = sc; A.scan1m[p] = scm; }
+    if (lane == 63 && chunk < (A.Np + 63) / 64) {
+        A.chunk_sq[chunk] = sq;
+        A.chunk_pil[chunk] = sc;
+        A.chunk_mx1[chunk] = scm;
+    }
+}
+
+// calculate_terminal_branch_length_quantiles (smcsmc.cpp:128-166): one prior tree per lane (Philox stream 3); reports
+// every sample's coalescent parent height and the tree length
+__global__ __launch_bounds__(PF_BS) void k_tbl(KArgs A, unsigned long long seed, long long rep0, long long nrep,
+                                               double* out_h /* [n][nrep] */, double* out_len /* [nrep] */) {
+    extern __shared__ double smem[];
+    Smem m = carve(smem, A.n, A.E);
+    load_model(A, m);
+    __syncthreads();
+    long long r = (long long)blockIdx.x * PF_BS + threadIdx.x;
+    if (r >= nrep) return;
+    const int n = A.n;
+    Lane ln = make_lane(A, m, rep0 + r);
+    ln.seed = seed;
+    ln.stream = 3;
+    ln.ebuf = -dlog(uni(ln));
+    int root = 0;
+    for (int i = 1; i < n; ++i) {
+        int ni = i - 1;
+        double tc = coalesce_up(ln, [&](int k) { return LS(ln, k); }, ni, i, 0.0);
+        int pr = -1, ps = 0;
+        int k = lineages_at(ln, ni, tc, -1, &pr, &ps);
+        bool above_root = (ni == 0) || (tc >= LS(ln, ni - 1));
+        int kk = above_root ? 1 : k;
+        double u = uni(ln);
+        int idx = min((int)(u * (double)kk), kk - 1);
+        if (above_root) insert_node(ln, ni, tc, i, -1, 0, root);
+        else { lineages_at(ln, ni, tc, idx, &pr, &ps); insert_node(ln, ni, tc, i, pr, ps, root); }
+        root = n + ni;
+    }
+    out_len[r] = tree_length(ln, n);
+    for (int i = 0; i < n; ++i) {
+        int pr = -1;
+        for (int k = 0; k < n - 1 && pr < 0; ++k)
+            if (LC(ln, k, 0) == i || LC(ln, k, 1) == i) pr = k;
+        out_h[(size_t)i * nrep + r] = LS(ln, pr);
+    }
+}
+
 // ------------------------------------------------------------------ unit-test kernels
 __global__ void k_test_math(const double* x, long long n, double* oe, double* ol, double* of) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1431,7 +1628,7 @@ struct pf_handle {
     int E = 0, n = 0, P = 1;
     long long Np = 0;
     int nblocks = 0;
-    size_t smem = 0;
+    size_t smem = 0, smem_la = 0;
     int max_trace_events = 0;
     bool finished = false;
     bool fin_pending = false;     // k_count partials not yet folded into the totals
@@ -1852,7 +2049,12 @@ static int launch_extend(pf_handle* h, long long s) {
         else
             hipLaunchKernelGGL(k_extend, dim3(h->nblocks), dim3(PF_BS), h->smem, h->stream, h->A, s);
     }
-    return check_launch("k_extend");
+    if (check_launch("k_extend")) return -1;
+    if (h->A.apf > 0) {
+        hipLaunchKernelGGL(k_lookahead, dim3(h->nblocks), dim3(PF_BS), h->smem_la, h->stream, h->A, s);
+        return check_launch("k_lookahead");
+    }
+    return 0;
 }
 
 static int launch_decide(pf_handle* h, long long s, int mode, const Windows& W) {
@@ -2244,6 +2446,88 @@ int pf_test_systematic(const double* pilot, int64_t n, double u, int32_t* lo, in
     // the production kernel draws u from the resampler stream (seed 1, event 0); the caller
     // obtains the same u through pf_test_uniform(1, 0xFFFFFFFF, 1, 0, ...)
     return test_reduce_impl(pilot, n, nullptr, nullptr, u, lo, device);
+}
+
+int pf_load_lookahead(pf_handle* h, const pf_lookahead* la) {
+    HIPCHK(hipSetDevice(h->device));
+    if (la->level < 0 || la->level > 4) { g_err = "-apf must be in 0..4"; return -1; }
+    if (h->P > 1) { g_err = "pf_load_lookahead: the auxiliary particle filter is implemented for one population"; return -1; }
+    if (la->n != h->n_segs) { g_err = "pf_load_lookahead: one look-ahead record per segment expected"; return -1; }
+    if (la->level == 0) { h->A.apf = 0; return 0; }
+    const long long S = la->n;
+    const int n = h->n, D = la->max_doubletons, Q = la->n_quantiles;
+    KArgs& A = h->A;
+    double *fsd, *rmr, *ddist, *split, *q, *tbl; int8_t *unph, *didx, *sal; int *nd, *sk;
+    int rc = 0;
+    rc |= dalloc(h, &fsd, (size_t)S * n); rc |= dalloc(h, &rmr, (size_t)S * n); rc |= dalloc(h, &unph, (size_t)S * n);
+    rc |= dalloc(h, &nd, S); rc |= dalloc(h, &didx, (size_t)S * D * 4); rc |= dalloc(h, &ddist, (size_t)S * D * 2);
+    rc |= dalloc(h, &split, S); rc |= dalloc(h, &sal, (size_t)S * n); rc |= dalloc(h, &sk, S);
+    rc |= dalloc(h, &q, Q); rc |= dalloc(h, &tbl, (size_t)n * Q);
+    for (int b = 0; b < 2; ++b)
+        if (!A.st[b].lookahead) rc |= dalloc(h, &A.st[b].lookahead, h->Np);
+    if (rc) return -1;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(fsd, la->first_singleton_distance, (size_t)S * n * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(rmr, la->relative_mutation_rate, (size_t)S * n * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(unph, la->is_singleton_unphased, (size_t)S * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(nd, la->n_doubletons, (size_t)S * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(didx, la->doubleton_idx, (size_t)S * D * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ddist, la->doubleton_dist, (size_t)S * D * 2 * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(split, la->first_split_distance, (size_t)S * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sal, la->split_alleles, (size_t)S * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sk, la->split_count, (size_t)S * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(q, la->quantiles, (size_t)Q * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(tbl, la->tbl_lengths, (size_t)n * Q * 8, hipMemcpyHostToDevice));
+    std::vector<double> ones(h->Np, 1.0);
+    for (int b = 0; b < 2; ++b) HIPCHK(hipMemcpy(A.st[b].lookahead, ones.data(), h->Np * 8, hipMemcpyHostToDevice));
+    A.apf = la->level; A.la_D = D; A.la_Q = Q;
+    A.la_fsd = fsd; A.la_rmr = rmr; A.la_unph = unph; A.la_nd = nd; A.la_didx = didx; A.la_ddist = ddist;
+    A.la_split = split; A.la_salleles = sal; A.la_sk = sk; A.la_q = q; A.la_tbl = tbl;
+    A.la_mean_tbl = la->mean_total_branch_length;
+    h->smem_la = smem_bytes_la(n, h->E);
+    if (h->smem_la > 64 * 1024) hipFuncSetAttribute((const void*)k_lookahead, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem_la);
+    return 0;
+}
+
+int pf_terminal_branch_quantiles(const pf_model* m, uint64_t seed, int64_t n_trees, const double* quantiles, int32_t nq,
+                                 double* lengths_out, double* mean_total_out, int device) {
+    if (test_setup(device)) return -1;
+    if (m->n_pops != 1 || m->nsam < 2 || m->nsam > PF_NMAX || m->n_epochs < 1 || m->n_epochs > PF_EMAX || n_trees < 1) {
+        g_err = "pf_terminal_branch_quantiles: unsupported model";
+        return -1;
+    }
+    const int E = m->n_epochs, n = m->nsam;
+    KArgs A;
+    memset(&A, 0, sizeof(A));
+    A.E = E; A.n = n; A.P = 1; A.L = m->loci_length; A.mu = m->mutation_rate; A.rho = m->recombination_rate;
+    double *dT, *dI, *dh, *dl; int* dRF;
+    HIPCHK(hipMalloc(&dT, E * 8)); HIPCHK(hipMalloc(&dI, E * 8)); HIPCHK(hipMalloc(&dRF, E * 4));
+    HIPCHK(hipMalloc(&dh, (size_t)n * n_trees * 8)); HIPCHK(hipMalloc(&dl, (size_t)n_trees * 8));
+    std::vector<double> inv2N(E);
+    for (int e = 0; e < E; ++e) inv2N[e] = 1.0 / (2.0 * m->pop_sizes[e]);
+    std::vector<int> rf(E, 3);
+    HIPCHK(hipMemcpy(dT, m->change_times, E * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dI, inv2N.data(), E * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dRF, rf.data(), E * 4, hipMemcpyHostToDevice));
+    A.T = dT; A.inv2N = dI; A.recflags = dRF;
+    const size_t smem = smem_bytes(n, E);
+    if (smem > 64 * 1024) hipFuncSetAttribute((const void*)k_tbl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(k_tbl, dim3((unsigned)((n_trees + PF_BS - 1) / PF_BS)), dim3(PF_BS), smem, 0, A, (unsigned long long)seed,
+                       (long long)0, (long long)n_trees, dh, dl);
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<double> hh((size_t)n * n_trees), ll(n_trees);
+    HIPCHK(hipMemcpy(hh.data(), dh, hh.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ll.data(), dl, ll.size() * 8, hipMemcpyDeviceToHost));
+    hipFree(dT); hipFree(dI); hipFree(dRF); hipFree(dh); hipFree(dl);
+    for (int i = 0; i < n; ++i) {
+        double* row = hh.data() + (size_t)i * n_trees;
+        std::sort(row, row + n_trees);
+        for (int q = 0; q < nq; ++q) lengths_out[i * nq + q] = row[(long long)(quantiles[q] * (double)n_trees)];
+    }
+    double total = 0.0;
+    for (long long r = 0; r < n_trees; ++r) total += ll[r];      // serial, in tree order (smcsmc.cpp:145)
+    *mean_total_out = total / (double)n_trees;
+    return 0;
 }
 
 // ------------------------------------------------------------------ lag calibration (host driver)

@@ -30,6 +30,7 @@ struct DState {
     double* dfac;            // [PF_DCAP][Np]
     double* ddelta;          // [PF_DCAP][Np]
     int* dk;                 // [PF_DCAP][Np]
+    double* lookahead;       // [Np] lookahead_weight_ (auxiliary particle filter); allocated with pf_load_lookahead
     // structured models (pf_mp.h); allocated only when P > 1
     int8_t* Pn;              // [(n-1)][Np] population of every coalescent node
     int* nm;                 // [Np] migration events on the local tree
@@ -83,6 +84,12 @@ struct KArgs {
     double* plog;                  // coal/migr opportunity pieces: plog[(p*pcap + k%pcap)*3 .. +3)
     unsigned pcap;
     unsigned* pidx;                // slot-owned: pieces ever written by this slot
+    // auxiliary particle filter (pf_lookahead)
+    int apf, la_D, la_Q;
+    const double* la_fsd; const double* la_rmr; const int8_t* la_unph; const int* la_nd; const int8_t* la_didx;
+    const double* la_ddist; const double* la_split; const int8_t* la_salleles; const int* la_sk;
+    const double* la_q; const double* la_tbl;
+    double la_mean_tbl;
     // run parameters
     long long Np;
     double ess_threshold;

@@ -52,8 +52,37 @@ class _Segments(C.Structure):
                 ("max_record_epoch", C.POINTER(C.c_int32))]
 
 
+class _Lookahead(C.Structure):
+    _fields_ = [("level", C.c_int32), ("max_doubletons", C.c_int32), ("n_quantiles", C.c_int32), ("reserved", C.c_int32),
+                ("n", C.c_int64),
+                ("first_singleton_distance", C.POINTER(C.c_double)), ("relative_mutation_rate", C.POINTER(C.c_double)),
+                ("is_singleton_unphased", C.POINTER(C.c_int8)), ("n_doubletons", C.POINTER(C.c_int32)),
+                ("doubleton_idx", C.POINTER(C.c_int8)), ("doubleton_dist", C.POINTER(C.c_double)),
+                ("first_split_distance", C.POINTER(C.c_double)), ("split_alleles", C.POINTER(C.c_int8)),
+                ("split_count", C.POINTER(C.c_int32)), ("quantiles", C.POINTER(C.c_double)),
+                ("tbl_lengths", C.POINTER(C.c_double)), ("mean_total_branch_length", C.c_double)]
+
+
+class PackedLookahead:
+    """Owns the buffers behind a pf_lookahead / smco_lookahead struct.  `la` = segments.pack_lookahead(...),
+    `tbl` = (lengths[nsam][Q], mean_total_branch_length) from terminal_branch_quantiles."""
+
+    def __init__(self, la, level, tbl, quantiles, struct_cls=_Lookahead):
+        f = lambda a, t: np.ascontiguousarray(a, dtype=t)      # noqa: E731
+        self.a = [f(la["first_singleton_distance"], np.float64), f(la["relative_mutation_rate"], np.float64),
+                  f(la["is_singleton_unphased"], np.int8), f(la["n_doubletons"], np.int32), f(la["doubleton_idx"], np.int8),
+                  f(la["doubleton_dist"], np.float64), f(la["first_split_distance"], np.float64),
+                  f(la["split_alleles"], np.int8), f(la["split_count"], np.int32), f(quantiles, np.float64),
+                  f(tbl[0], np.float64)]
+        ptr = lambda a: a.ctypes.data_as(C.POINTER({np.dtype(np.float64): C.c_double, np.dtype(np.int8): C.c_int8,      # noqa: E731
+                                                    np.dtype(np.int32): C.c_int32}[a.dtype]))
+        self.struct = struct_cls(int(level), int(la["max_doubletons"]), len(quantiles), 0, len(la["n_doubletons"]),
+                                 *[ptr(a) for a in self.a], float(tbl[1]))
+
+
 EXPORTS = [
-    "pf_last_error", "pf_device_count", "pf_create", "pf_destroy", "pf_init_prior", "pf_load_segments",
+    "pf_last_error", "pf_device_count", "pf_create", "pf_destroy", "pf_init_prior", "pf_load_segments", "pf_load_lookahead",
+    "pf_terminal_branch_quantiles",
     "pf_update_segment", "pf_count", "pf_resample", "pf_run", "pf_finish", "pf_sync",
     "pf_num_segments_done", "pf_logl", "pf_get_counts", "pf_get_trace", "pf_get_resample_events",
     "pf_get_particles", "pf_get_migrations", "pf_get_kernel_time", "pf_set_timing", "pf_get_stats",
@@ -79,6 +108,8 @@ def load_library(path=None):
     L.pf_destroy.argtypes = [vp]
     L.pf_init_prior.argtypes = [vp, C.c_double]
     L.pf_load_segments.argtypes = [vp, C.POINTER(_Segments)]
+    L.pf_load_lookahead.argtypes = [vp, C.POINTER(_Lookahead)]
+    L.pf_terminal_branch_quantiles.argtypes = [C.POINTER(_Model), C.c_uint64, C.c_int64, vp, C.c_int32, vp, vp, C.c_int]
     L.pf_update_segment.argtypes = [vp, C.c_int64]
     L.pf_count.argtypes = [vp, C.c_int64, C.c_int]
     L.pf_resample.argtypes = [vp, C.c_int64]
@@ -237,6 +268,13 @@ class ParticleFilter:
         self._chk(self.L.pf_load_segments(self.h, C.byref(sg)))
         self.n_segs = n
 
+    def load_lookahead(self, la, level, tbl, quantiles=None):
+        """Switches the auxiliary particle filter on (-apf level): `la` from segments.pack_lookahead, `tbl` from
+        terminal_branch_quantiles.  Call after load_segments."""
+        from . import segments as segmod
+        self._la = PackedLookahead(la, level, tbl, segmod.TBL_QUANTILES if quantiles is None else quantiles)
+        self._chk(self.L.pf_load_lookahead(self.h, C.byref(self._la.struct)))
+
     def run(self, s_begin=0, s_end=None):
         self._chk(self.L.pf_run(self.h, int(s_begin), int(self.n_segs if s_end is None else s_end)))
 
@@ -345,6 +383,21 @@ def median_survival(model, seed=1, min_events=200, max_trees=1000000, device=0):
                             C.byref(trees), int(device)) < 0:
         raise PfError(_err(L))
     return out, trees.value
+
+
+def terminal_branch_quantiles(model, seed=1, n_trees=1000000, quantiles=None, device=0):
+    """calculate_terminal_branch_length_quantiles (smcsmc.cpp:128-166) on the device:
+    returns (lengths[nsam][Q], mean_total_branch_length)."""
+    from . import segments as segmod
+    L = load_library()
+    mod, keep = _pack_model(model)
+    q = np.ascontiguousarray(segmod.TBL_QUANTILES if quantiles is None else quantiles, dtype=np.float64)
+    out = np.zeros((mod.nsam, len(q)))
+    mean = C.c_double()
+    if L.pf_terminal_branch_quantiles(C.byref(mod), int(seed), int(n_trees), q.ctypes.data, len(q), out.ctypes.data,
+                                      C.byref(mean), int(device)) < 0:
+        raise PfError(_err(L))
+    return out, mean.value
 
 
 def calibrated_lags(model, lag_fraction=2.0, seed=1, device=0):

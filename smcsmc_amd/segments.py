@@ -223,3 +223,151 @@ def max_epoch_to_update(lags, distance):
     while epoch < len(lags) and distance < 0.5 * lags[epoch]:
         epoch += 1
     return epoch - 1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Auxiliary particle filter look-ahead (Segment::set_lookahead, segdata.cpp:225-410)
+
+MAX_MISSING_DATA = 2000000          # segdata.cpp:244
+TBL_QUANTILES = (0.001, 0.003, 0.01, 0.03, 0.1, 0.5, 0.95)   # smcsmc.cpp:134
+
+
+def set_lookahead(rows, cur, nsam):
+    """Look-ahead summary for the row `cur` of the buffered SegDatum list (file coordinates), a line-by-line
+    restatement of segdata.cpp:225-410: distance to the first singleton per lineage (negative: none seen within
+    that distance), relative mutation rate under missing data, the doubletons (cherry evidence) with first and
+    last evidence distances, and the first split."""
+    fsd = [0.0] * nsam
+    rmr = [0.0] * nsam
+    doubleton = []            # [s1, s2, first_evidence, last_evidence, unphased_1, unphased_2, incompatible]
+    first_split_distance = -1
+    split_alleles = [0] * nsam
+    split_count = 0
+    found_doubleton = [False] * (nsam + 1)
+    num_singletons = num_unphased_singletons = num_doubleton_sequences = 0
+    tl = 0.1
+    tl_missing = 0.1
+    total_current_missing = 0.0
+    last_singleton_distance = 0.0
+    distance = 0.0
+    unph = [False] * nsam
+    start0 = rows[cur][0]
+    for i in range(cur, len(rows)):
+        seg_start, seg_len, _, al = rows[i]
+        num_var = num_missing = 0
+        s1 = s2 = -1
+        unph = []
+        j = 0
+        while j < nsam:
+            unph.append(False)
+            if al[j] > 0:
+                num_var += 1
+                if num_var == 1:
+                    s1 = j
+                if num_var == 2:
+                    s2 = j
+                if al[j] == 2:
+                    unph[j] = True
+                    unph.append(True)
+                    j += 1          # skip the second allele of an unphased het
+            if j < nsam and al[j] == -1:
+                num_missing += 1
+                if num_missing == 1:
+                    total_current_missing += seg_len
+                if total_current_missing > MAX_MISSING_DATA:
+                    if fsd[j] == 0:
+                        eps = 1e-6
+                        fsd[j] = -(seg_start - start0) - eps
+                        last_singleton_distance = -fsd[j]
+                        if fsd[j] < 0.5 * total_current_missing:
+                            fsd[j] = -eps
+                        rmr[j] = tl_missing / tl
+                        num_singletons += 1
+                    if not found_doubleton[j]:
+                        found_doubleton[j] = True
+                        num_doubleton_sequences += 1
+            j += 1
+        if num_missing == 0:
+            total_current_missing = 0.0
+        tl += seg_len * nsam
+        tl_missing += seg_len * (nsam - num_missing)
+        if total_current_missing > MAX_MISSING_DATA:
+            continue
+        have_doubleton = False
+        distance = seg_start + seg_len - start0 + 0.5
+        if num_var == 1:
+            if fsd[s1] == 0:
+                fsd[s1] = distance
+                rmr[s1] = tl_missing / tl
+                num_singletons += 1
+                last_singleton_distance = fsd[s1]
+                if unph[s1]:
+                    fsd[s1 + 1] = distance
+                    rmr[s1 + 1] = rmr[s1]
+                    num_singletons += 1
+                    num_unphased_singletons += 1
+        else:
+            for d in doubleton:
+                a1, a2 = al[d[0]], al[d[1]]
+                if ((d[0] | 1) == d[1] and a1 == 2) or ((a1 + a2 == 1) and ((a1 | a2) == 1)):
+                    d[6] = True
+                if num_var == 2 and d[0] == s1 and d[1] == s2:
+                    have_doubleton = True
+                    if not d[6]:
+                        d[3] = distance
+        if num_var == 2 and not have_doubleton and al[s1] > -1 and al[s2] > -1:
+            done = False
+            for d1 in range(0, (1 if al[s1] == 2 else 0) + 1):
+                for d2 in range(0, (1 if al[s2] == 2 else 0) + 1):
+                    if done:
+                        continue
+                    if not found_doubleton[s1 + d1] and not found_doubleton[s2 + d2]:
+                        doubleton.append([s1, s2, distance, distance, al[s1] == 2, al[s2] == 2, False])
+                        found_doubleton[s1 + d1] = True
+                        num_doubleton_sequences += 1
+                        found_doubleton[s2 + d2] = True
+                        num_doubleton_sequences += 1
+                        done = True
+        if first_split_distance == -1 and num_var > 2 and nsam - num_var > 2:
+            first_split_distance = distance
+            split_alleles = list(al)
+            split_count = min(num_var, nsam - num_var)
+        if num_singletons == nsam and num_doubleton_sequences >= nsam - 1:
+            break
+        if num_singletons == nsam and distance > (2 + num_unphased_singletons) * last_singleton_distance:
+            break
+    if num_singletons < nsam:
+        for j in range(nsam):
+            if fsd[j] == 0:
+                fsd[j] = -distance
+                rmr[j] = tl_missing / tl
+    unph = (list(unph) + [False] * nsam)[:nsam]
+    return dict(first_singleton_distance=fsd, relative_mutation_rate=rmr, is_singleton_unphased=unph,
+                doubleton=doubleton, first_split_distance=first_split_distance, split_alleles=split_alleles,
+                split_count=split_count)
+
+
+def pack_lookahead(rows, nsam):
+    """Per-row look-ahead arrays in the layout of pf_lookahead (include/smcsmc_pf.h)."""
+    S = len(rows)
+    D = max(1, nsam // 2)
+    out = dict(first_singleton_distance=np.zeros((S, nsam)), relative_mutation_rate=np.zeros((S, nsam)),
+               is_singleton_unphased=np.zeros((S, nsam), np.int8), n_doubletons=np.zeros(S, np.int32),
+               doubleton_idx=np.zeros((S, D, 4), np.int8), doubleton_dist=np.zeros((S, D, 2)),
+               first_split_distance=np.full(S, -1.0), split_alleles=np.zeros((S, nsam), np.int8),
+               split_count=np.zeros(S, np.int32), max_doubletons=D)
+    for i in range(S):
+        la = set_lookahead(rows, i, nsam)
+        out["first_singleton_distance"][i] = la["first_singleton_distance"]
+        out["relative_mutation_rate"][i] = la["relative_mutation_rate"]
+        out["is_singleton_unphased"][i] = la["is_singleton_unphased"]
+        nd = len(la["doubleton"])
+        assert nd <= D
+        out["n_doubletons"][i] = nd
+        for k, d in enumerate(la["doubleton"]):
+            out["doubleton_idx"][i, k] = [d[0], d[1], int(d[4]), int(d[5])]
+            out["doubleton_dist"][i, k] = [d[2], d[3]]
+        out["first_split_distance"][i] = la["first_split_distance"]
+        out["split_alleles"][i] = la["split_alleles"]
+        out["split_count"][i] = la["split_count"]
+    return out

@@ -55,6 +55,8 @@ def lib():
         L.smco_destroy.argtypes = [C.c_void_p]
         L.smco_last_error.restype = C.c_char_p
         L.smco_init_prior.argtypes = [C.c_void_p, C.c_double]
+        L.smco_load_lookahead.argtypes = [C.c_void_p, C.c_void_p]
+        L.smco_terminal_branch_quantiles.argtypes = [C.POINTER(Model), C.c_uint64, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.smco_run.argtypes = [C.c_void_p, C.POINTER(Segments)]
         L.smco_update_segment.argtypes = [C.c_void_p, C.POINTER(Segments), C.c_int64]
         L.smco_count.argtypes = [C.c_void_p, C.c_double, C.c_int]
@@ -180,6 +182,11 @@ class Oracle:
     def init_prior(self, initial_position=0.0):
         self._chk(self.L.smco_init_prior(self.h, float(initial_position)))
 
+    def load_lookahead(self, la, level, tbl, quantiles=None):
+        from smcsmc_amd import pf, segments as segmod      # struct layout only (shared with the product's C-ABI)
+        self._la = pf.PackedLookahead(la, level, tbl, segmod.TBL_QUANTILES if quantiles is None else quantiles)
+        self._chk(self.L.smco_load_lookahead(self.h, C.byref(self._la.struct)))
+
     def pack_segments(self, model, segs):
         self.seg_inp = PackedInputs(model, segs)
         return self.seg_inp
@@ -265,6 +272,19 @@ def unpack_counts(out, E, P=1):
         d[k] = out[o:o + E * P].reshape(E, P).copy(); o += E * P
     d["delayed_opp"], d["delayed_count"], d["resample_count"], d["logl"] = out[o:o + 4]
     return d
+
+
+def terminal_branch_quantiles(model, seed=1, n_trees=100000, quantiles=None):
+    from smcsmc_amd import segments as segmod
+    L = lib()
+    inp = PackedInputs(dict(model, lags=model.get("lags", np.zeros(len(model["change_times"])))), None)
+    q = np.ascontiguousarray(segmod.TBL_QUANTILES if quantiles is None else quantiles, dtype=np.float64)
+    out = np.zeros((inp.nsam, len(q)))
+    mean = C.c_double()
+    if L.smco_terminal_branch_quantiles(C.byref(inp.model), int(seed), int(n_trees), q.ctypes.data, len(q), out.ctypes.data,
+                                        C.byref(mean)) < 0:
+        raise RuntimeError(L.smco_last_error().decode())
+    return out, mean.value
 
 
 def median_survival(model, seed=1, min_events=200, max_trees=1000000):

@@ -300,3 +300,85 @@ def test_three_bias_bands(oracle, hiplib):
     o.run(si); g.run(); g.finish()
     assert (_bits(o.trace()["logl"]) == _bits(g.trace()["logl"])).all()
     _assert_counts_close(o.counts(), g.counts())
+
+
+# ---------------------------------------------------------------- auxiliary particle filter (-apf)
+
+def _lookahead_inputs(model, segs):
+    from smcsmc_amd import segments as segmod
+    n = model["nsam"]
+    rows = [(int(s) + 1, int(l), int(st), list(map(int, a)))
+            for s, l, st, a in zip(segs["start"], segs["length"], segs["state"], segs["alleles"])]
+    return segmod.pack_lookahead(rows, n)
+
+
+def test_terminal_branch_length_quantiles_parity(oracle, hiplib):
+    """calculate_terminal_branch_length_quantiles (smcsmc.cpp:128-166): device == oracle bit for bit, and the mean
+    total branch length is the coalescent expectation 4N * H(n-1)."""
+    from smcsmc_amd import pf
+    model = cases.make_model(n=6, E=8, L=1e6)
+    dl, dm = pf.terminal_branch_quantiles(model, seed=1, n_trees=60000)
+    ol_, om = oracle.terminal_branch_quantiles(model, seed=1, n_trees=60000)
+    assert (_bits(dl) == _bits(ol_)).all() and _bits([dm])[0] == _bits([om])[0]
+    expect = 4e4 * sum(1.0 / k for k in range(1, 6))
+    assert abs(dm / expect - 1) < 0.01
+    assert (np.diff(dl, axis=1) > 0).all()
+
+
+@pytest.mark.parametrize("n,level,unphased", [(4, 1, False), (4, 2, True), (8, 3, False), (8, 4, True)])
+def test_auxiliary_particle_filter_parity(oracle, hiplib, n, level, unphased):
+    """update_lookahead_likelihood / includeLookaheadLikelihood (pc.cpp:227-240, particle.cpp:439-617): the look-ahead
+    factor enters the pilot weight only; trees, weights, ESS and resampling indices stay bit-identical to the oracle."""
+    from smcsmc_amd import pf
+    model = cases.make_model(n=n, E=8, L=1.2e5)
+    segs = cases.make_segments(model, seed=20 + n + level, unphased=unphased, max_seg_len=5000,
+                               missing_block=(40000, 60000, (0, 1)) if level == 2 else None)
+    la = _lookahead_inputs(model, segs)
+    tbl = pf.terminal_branch_quantiles(model, seed=1, n_trees=20000)
+    assert (la["n_doubletons"] > 0).any()
+    if level >= 3:
+        assert (la["first_split_distance"] > 0).any()
+    o, si, g = _run_both(oracle, model, segs, 400, seed=9)
+    o.load_lookahead(la, level, tbl); g.load_lookahead(la, level, tbl)
+    o.run(si); g.run(); g.finish()
+    to, tg = o.trace(), g.trace()
+    assert (to["resampled"] == tg["resampled"]).all() and to["resampled"].sum() > 0
+    for k in ("T", "ess", "logl"):
+        assert (_bits(to[k]) == _bits(tg[k])).all(), k
+    so, po_ = o.resample_events(); sg_, pg_ = g.resample_events()
+    assert (so == sg_).all() and (po_ == pg_).all()
+    _assert_state_equal(o, g)
+    _assert_counts_close(o.counts(), g.counts())
+    # the look-ahead changes which particles survive, not the estimator: same data without it gives another run
+    o0, si0, g0 = _run_both(oracle, model, segs, 400, seed=9)
+    g0.run(); g0.finish()
+    assert (g0.trace()["ess"] != tg["ess"]).any()
+    assert abs(g0.logl() - g.logl()) < 0.02 * abs(g.logl())
+
+
+def test_binary_auxiliary_particle_filter(hiplib, tmp_path):
+    """bin/smcsmc -apf 2 equals the library run with the same look-ahead tables, character for character."""
+    import json
+    import os
+    import subprocess
+    from smcsmc_amd import ParticleFilter, outfile, pf, segments as segmod
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    binary = os.path.join(root, "bin", "smcsmc")
+    seg = os.path.join(root, "tests", "golden", "seg", "constpopsize_first3000.seg")
+    L = 1000000
+    core = ("-N0 10000 -t %g -r %g %d -eN 0 1 -eN 0.01 1 -eN 0.25 1 -eN 1 1" % (4e4 * 2.5e-8 * L, 4e4 * 1e-8 * L, L)).split()
+    r = subprocess.run([binary] + core + ["-nsam", "2", "-Np", "300", "-EM", "0", "-tmax", "4", "-lag", "20000", "-seed", "4",
+                                          "-apf", "2", "-seg", seg, "-o", str(tmp_path / "apf")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Terminal branch length quantiles" in r.stdout
+    m = json.loads(subprocess.run([binary] + core + ["-nsam", "2", "-tmax", "4", "-dumpmodel"], capture_output=True, text=True).stdout)
+    E = len(m["change_times"])
+    model = dict(change_times=np.array(m["change_times"]), pop_sizes=np.array(m["pop_sizes"])[:, 0], lags=np.full(E, 20000.0),
+                 nsam=2, loci_length=float(L), mutation_rate=m["mutation_rate"], recombination_rate=m["recombination_rate"])
+    S = segmod.Segments(seg, 2, L, max_segment_length=int(2.0 / (m["recombination_rate"] * 4 * m["N0"])))
+    segs = S.pack(model["lags"])
+    g = ParticleFilter(model, 300, seed=4, max_trace_events=0)
+    g.init_prior(segs["start"][0]); g.load_segments(segs)
+    g.load_lookahead(segmod.pack_lookahead(S.rows, 2), 2, pf.terminal_branch_quantiles(model, seed=1, n_trees=1000000))
+    g.run(); g.finish()
+    assert outfile.outfile_text(model, g.counts(), 300) == open(tmp_path / "apf.out").read()
