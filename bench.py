@@ -232,6 +232,14 @@ def main():
         # plus the event records appended
         alg_bytes = args.np * 2 * state_bytes + rec_per_seg * rec_bytes
         achieved = alg_bytes / (avg_ext_us * 1e-6) / 1e9 if avg_ext_us > 0 else 0.0
+        # HBM traffic of the same kernel from the PMC counters: collected by profiles/collect_round1.sh in separate
+        # rocprofv3 passes (counters cannot be read from inside this process) and kept under profiles/
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "round1", "v4_pmc_k_extend.json")
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            if pmc["shape"] == {"nsam": args.nsam, "np": args.np, "epochs": args.epochs, "pops": args.pops}:
+                traffic = pmc["traffic_bytes_per_launch"]
         out = {
             "metric": "genome segments/sec per EM iteration (Np=10000, 2 diploids, 100 Mb)",
             "value": value, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -245,7 +253,7 @@ def main():
                        "sequence_length": args.length, "epochs": args.epochs,
                        "parallelism": "%d chunk(s) per gpu x %d gpu(s)" % (C, world), "log_likelihood_sum": logl_sum},
             "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_us": avg_ext_us,
                          "kernel_ms_estimate": {k: v[0] for k, v in kt.items()},
                          "kernel_launches": {k: v[1] for k, v in kt.items()}},

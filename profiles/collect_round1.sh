@@ -1,0 +1,12 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence behind DESIGN.md section 7 on the GPU box (run through gpurun from the repo root):
+#   1. kernel-trace statistics of the default bench workload shape on a 10 Mb prefix (per-kernel average durations)
+#   2. HBM traffic counters, one pass per counter (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950)
+# Outputs land under gpurun_out/prof_*; the summaries are copied into profiles/round1/ by hand.
+set -e
+REPO=$(pwd)
+cd /tmp && export TMPDIR=/tmp
+ARGS="$REPO/bench.py --length 1e7 --steps 1 --warmup 0 --no-cpu"
+rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_stats -o stats -- python3 $ARGS > $REPO/gpurun_out/prof_stats.json
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $REPO/gpurun_out/prof_fetch -o fetch -- python3 $ARGS > /dev/null
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $REPO/gpurun_out/prof_write -o write -- python3 $ARGS > /dev/null
