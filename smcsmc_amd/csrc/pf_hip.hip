@@ -302,7 +302,10 @@ __device__ __forceinline__ void d_adjust_with_delay(DStore& d, double& w_post, d
 }
 
 template <int NM, bool BIASED>
-__global__ __launch_bounds__(PF_BS) void k_extend_reg(KArgs A, long long s) {
+// With fuse != 0 the launch also completes the previous row: the in-place normalisation or the resampling gather of
+// k_resample (pc.cpp:321-392, 435-437) happens while the particle is loaded, which removes one kernel and its
+// launch gap from the per-row critical path.  The arithmetic is k_resample's, operation for operation.
+__global__ __launch_bounds__(PF_BS) void k_extend_reg(KArgs A, long long s, int fuse) {
     extern __shared__ double smem[];
     double* sT = smem;
     double* sI = smem + A.E;
@@ -324,14 +327,17 @@ __global__ __launch_bounds__(PF_BS) void k_extend_reg(KArgs A, long long s) {
     bool has_pending = false;
     if (active) {
         DState& st = A.st[cur];
+        const bool gather = fuse && c->flag;              // the previous row resampled: this slot starts as a copy of its parent
+        const DState& from = gather ? A.st[cur ^ 1] : st;
+        const long long a = gather ? (long long)A.parent[p] : p;
         RTree<NM> t;
 #pragma unroll
         for (int r = 0; r < RTree<NM>::NI; ++r) {
             t.S[r] = 0.0; t.C0[r] = 0; t.C1[r] = 0;
             if (r < n - 1) {
-                t.S[r] = st.S[(size_t)r * A.Np + p];
-                t.C0[r] = st.C[(size_t)(2 * r) * A.Np + p];
-                t.C1[r] = st.C[(size_t)(2 * r + 1) * A.Np + p];
+                t.S[r] = from.S[(size_t)r * A.Np + a];
+                t.C0[r] = from.C[(size_t)(2 * r) * A.Np + a];
+                t.C1[r] = from.C[(size_t)(2 * r + 1) * A.Np + a];
             }
         }
         RCtx cx;
@@ -341,17 +347,59 @@ __global__ __launch_bounds__(PF_BS) void k_extend_reg(KArgs A, long long s) {
         DStore ds;
         if (BIASED) {
             ds.pos = st.dpos + p; ds.fac = st.dfac + p; ds.delta = st.ddelta + p; ds.k = st.dk + p; ds.Np = A.Np;
-            ds.count = st.dcount[p]; ds.total = st.total_delayed[p];
+            ds.count = from.dcount[a]; ds.total = from.total_delayed[a];
+            if (gather)        // the copy constructor copies the pending factors (particle.cpp:122-123)
+                for (int k = 0; k < ds.count; ++k) {
+                    st.dpos[(size_t)k * A.Np + p] = from.dpos[(size_t)k * A.Np + a];
+                    st.dfac[(size_t)k * A.Np + p] = from.dfac[(size_t)k * A.Np + a];
+                    st.ddelta[(size_t)k * A.Np + p] = from.ddelta[(size_t)k * A.Np + a];
+                    st.dk[(size_t)k * A.Np + p] = from.dk[(size_t)k * A.Np + a];
+                }
         }
-        w_post = st.w_post[p];
-        w_pilot = st.w_pilot[p];
-        double next_base = st.next_base[p];
-        double x_mark = st.x_mark[p];
-        int mark_limit = st.mark_limit[p];
-        cx.Ltree = st.Ltree[p];
+        w_post = from.w_post[a];
+        w_pilot = from.w_pilot[a];
+        double next_base = from.next_base[a];
+        double x_mark = from.x_mark[a];
+        int mark_limit = from.mark_limit[a];
+        cx.Ltree = from.Ltree[a];
         cx.ctr = A.rng_ctr[p];
         cx.ebuf = A.ebuf[p];
         unsigned widx = A.widx[p];
+        if (fuse) {
+            const double inv = c->inv_T;
+            if (p == 0) { Ctrl* cw = A.ctrl; cw->gen_prev = c->gen; cw->nres_prev = c->n_resample; }
+            if (!gather) {
+                w_post *= inv;                             // normalize_probability, pc.cpp:435-437
+                w_pilot *= inv;
+            } else {
+                const int G = c->gen - 1;                  // the generation that ended with the previous row
+                const int* lo = A.lo + (size_t)(G % A.Gcap) * (A.Np + 1);
+                const double pos = c->cur_pos;
+                const DState& src = from;
+                // role of the old slot p: close its stretch if it has offspring
+                if (lo[p + 1] > lo[p]) {
+                    double* rec = rec_ptr(A, p, widx);
+                    rec[0] = src.x_mark[p];
+                    rec[1] = pos;
+                    rec[2] = 0.0; rec[3] = 0.0;
+                    rec[4] = __longlong_as_double((long long)make_meta(1, src.mark_limit[p], -1, n));
+                    for (int r = 0; r < n - 1; ++r) rec[5 + r] = src.S[(size_t)r * A.Np + p];
+                    ++widx;
+                }
+                A.gstart[(size_t)((G + 1) % A.Gcap) * A.Np + p] = widx;
+                // role of the new slot p: weights of the copy (pc.cpp:350-351), fresh position for all but the first
+                int ev = (int)c->n_resample - 1;
+                if (ev < A.max_trace_events) A.ev_parents[(size_t)ev * A.Np + p] = (int)a;
+                double wp = w_post * inv;
+                double wq = w_pilot * inv;
+                double sumn = c->S1 * inv;
+                double adj = sumn / ((double)A.Np * wq);
+                w_post = wp * adj;
+                w_pilot = wq * adj;
+                x_mark = pos;
+                if (p != lo[a] && pos < A.L) next_base = r_sample_next_base(cx, pos);     // pc.cpp:357-368
+            }
+        }
 
         const int8_t* data = A.seg_alleles + (size_t)s * n;
         const double seg_end = A.seg_start[s] + A.seg_len[s];
@@ -1634,6 +1682,7 @@ struct pf_handle {
     bool fin_pending = false;     // k_count partials not yet folded into the totals
     Windows step_windows;         // windows of the step being processed
     bool force_lds = false;       // SMCSMC_PF_FORCE_LDS=1: use the LDS-tree kernel for every n (testing)
+    bool no_fuse = false;         // SMCSMC_PF_NO_FUSE=1: always run k_resample as its own kernel (testing)
     // timing
     int timing_period = 0;
     struct Span { hipEvent_t a, b; int k; };
@@ -1754,6 +1803,7 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     h->smem = P > 1 ? pf_mp_smem_bytes(n, E, P) : smem_bytes(n, E);
     h->max_trace_events = std::max(0, p->max_trace_events);
     h->force_lds = env_ll("SMCSMC_PF_FORCE_LDS", 0) != 0;
+    h->no_fuse = env_ll("SMCSMC_PF_NO_FUSE", 0) != 0;
     h->h_lags.assign(m->lags, m->lags + E);
     h->h_counted_to.assign(E, 0.0);
     h->h_L = m->loci_length;
@@ -2030,7 +2080,12 @@ static Windows no_windows(pf_handle* h) {
     return W;
 }
 
-static int launch_extend(pf_handle* h, long long s) {
+// the register-tree kernels can complete the previous row while loading the particle (fused k_resample)
+static bool extend_can_fuse(const pf_handle* h) {
+    return h->P == 1 && h->n <= 8 && (h->A.n_bias > 0 || !h->force_lds) && !h->no_fuse && h->A.apf == 0;
+}
+
+static int launch_extend(pf_handle* h, long long s, int fuse = 0) {
     const bool t = timing_on(h, s);
     {
         Timed tm(h, 0, t);
@@ -2039,13 +2094,13 @@ static int launch_extend(pf_handle* h, long long s) {
         if (h->P > 1)
             pf_mp_launch_extend(h->A, s, h->smem, h->stream);
         else if (h->n <= 4 && biased)
-            hipLaunchKernelGGL((k_extend_reg<4, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s);
+            hipLaunchKernelGGL((k_extend_reg<4, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);
         else if (h->n <= 8 && biased)
-            hipLaunchKernelGGL((k_extend_reg<8, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s);
+            hipLaunchKernelGGL((k_extend_reg<8, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);
         else if (h->n <= 4 && !h->force_lds)
-            hipLaunchKernelGGL((k_extend_reg<4, false>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s);
+            hipLaunchKernelGGL((k_extend_reg<4, false>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);
         else if (h->n <= 8 && !h->force_lds)
-            hipLaunchKernelGGL((k_extend_reg<8, false>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s);
+            hipLaunchKernelGGL((k_extend_reg<8, false>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);
         else
             hipLaunchKernelGGL(k_extend, dim3(h->nblocks), dim3(PF_BS), h->smem, h->stream, h->A, s);
     }
@@ -2149,12 +2204,16 @@ int pf_resample(pf_handle* h, int64_t s) {
 int pf_run(pf_handle* h, int64_t s_begin, int64_t s_end) {
     HIPCHK(hipSetDevice(h->device));
     if (s_begin < 0 || s_end > h->n_segs) { g_err = "segment range out of bounds"; return -1; }
+    const bool can_fuse = extend_can_fuse(h);
     for (long long s = s_begin; s < s_end; ++s) {
         h->step_windows = host_windows(h, seg_pos(h, s), false);
         h->A.sp = (int)(s & 1);
-        if (launch_extend(h, s)) return -1;
+        // rows after the first of this call complete their predecessor inside k_extend; the last row of the call is
+        // completed by k_resample so that the particle state is whole when pf_run returns
+        const bool last = (s + 1 == s_end) || (h->h_seg_start[s] + h->h_seg_len[s] >= h->h_L);
+        if (launch_extend(h, s, (can_fuse && s > s_begin) ? 1 : 0)) return -1;
         if (launch_decide(h, s, 0, h->step_windows)) return -1;
-        if (launch_resample(h, s)) return -1;
+        if (!can_fuse || last) { if (launch_resample(h, s)) return -1; }
         if (launch_count(h, s, h->step_windows)) return -1;
         if (launch_ledger(h, s)) return -1;
         h->seg_done = s + 1;
