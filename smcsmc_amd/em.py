@@ -205,10 +205,13 @@ def m_step(pop, data, vb=False, vb_dirichlet=None, maxNE=1e99, infer_recomb=True
 
 
 def run_em(pop, chunks, iterations, np_particles, seed=1, ess_fraction=0.5, lag_fraction=2.0, vb=False, maxNE=1e99,
-           infer_recomb=True, rounded=True, device=0, rank=0, world=1, on_iteration=None):
+           infer_recomb=True, rounded=True, device=0, rank=0, world=1, on_iteration=None, concurrent=4):
     """EM over `chunks` (each a packable Segments object of smcsmc_amd.segments).  Chunks are sharded over ranks
     (reduce.assign_chunks, longest first); statistics are summed in chunk order on every rank, so all ranks take
-    identical M-steps.  Returns the list of per-iteration summed statistics; `pop` holds the final model."""
+    identical M-steps.  Up to `concurrent` chunks of a rank are filtered at the same time (one host thread and one
+    stream pair each): a single chunk keeps only ~150 wavefronts busy, four chunks scale 4x on one MI355X.
+    Returns (final model, list of per-iteration summed statistics)."""
+    from concurrent.futures import ThreadPoolExecutor
     pop = copy.deepcopy(pop) if on_iteration is None else pop
     history = []
     sizes = [len(c) for c in chunks]
@@ -217,8 +220,7 @@ def run_em(pop, chunks, iterations, np_particles, seed=1, ess_fraction=0.5, lag_
         base = pop.device_model()
         lags = pf.calibrated_lags(base, lag_fraction=lag_fraction, device=device)     # model-only: once per iteration
         model = pop.device_model(lags=lags)
-        per_chunk = {}
-        for c in mine:
+        def e_step(c):
             segs = chunks[c].pack(lags)
             f = pf.ParticleFilter(model, np_particles, ess_fraction=ess_fraction, seed=seed + 1000 * it + c,
                                   max_trace_events=0, device=device)
@@ -226,8 +228,15 @@ def run_em(pop, chunks, iterations, np_particles, seed=1, ess_fraction=0.5, lag_
             f.init_prior(float(segs["start"][0]))
             f.run()
             f.finish()
-            per_chunk[c] = counts_to_data(model, f.counts(), np_particles, rounded=rounded)
+            data = counts_to_data(model, f.counts(), np_particles, rounded=rounded)
             f.close()
+            return c, data
+
+        if concurrent > 1 and len(mine) > 1:
+            with ThreadPoolExecutor(max_workers=min(concurrent, len(mine))) as pool:
+                per_chunk = dict(pool.map(e_step, mine))
+        else:
+            per_chunk = dict(e_step(c) for c in mine)
         template = pf.unpack_counts(np.ones(pf.counts_len(len(pop.change_points), pop.num_populations)),
                                     len(pop.change_points), pop.num_populations)
         keys = sorted(counts_to_data(model, template, np_particles, rounded=rounded).keys())
