@@ -52,6 +52,7 @@ struct PLog {
     double* base;            // ring of this slot
     unsigned cap;
     unsigned idx;            // pieces ever written by this slot
+    unsigned pos;            // idx % cap, kept incrementally
     bool on;
     int fe, fp, re, rp;
     double fco, fmo, rmo;
@@ -59,13 +60,14 @@ struct PLog {
 };
 
 __device__ __forceinline__ void plog_write(PLog& pl, int e, int pop, int kind, int to, double co, double mo) {
-    double* q = pl.base + (size_t)(pl.idx % pl.cap) * 3;
+    double* q = pl.base + (size_t)pl.pos * 3;
     long long tag = (long long)(e & 0xff) | ((long long)(pop & 0xff) << 8) | ((long long)(kind & 0xff) << 16) |
                     ((long long)(to & 0xff) << 24);
     q[0] = __longlong_as_double(tag);
     q[1] = co;
     q[2] = mo;
     ++pl.idx;
+    if (++pl.pos == pl.cap) pl.pos = 0;
 }
 __device__ __forceinline__ void plog_flush_f(PLog& pl, int kind, int to) {
     if (pl.fopen) plog_write(pl, pl.fe, pl.fp, kind, to, pl.fco, pl.fmo);
@@ -222,22 +224,38 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
             int id = LC(ln, r, s);
             if (id < n || id - n < i) bump(LBp(ml, id), 1);
         }
+    // The next node and the next event are held in registers, fetched with independent LDS reads when i / j move,
+    // so crossing a boundary costs one LDS round trip instead of a chain of dependent ones.
+    double nS = PF_INF, eT = PF_INF;
+    int nC0 = 0, nC1 = 0, nP = 0, eB = 0, eQ = 0;
+    auto fetch_node = [&]() {
+        if (i < ni) { nS = LS(ln, i); nC0 = LC(ln, i, 0); nC1 = LC(ln, i, 1); nP = LPn(ml, i); }
+        else nS = PF_INF;
+    };
+    auto fetch_event = [&]() {
+        if (j < ml.nm) { eT = LMt(ml, j); eB = LMb(ml, j); eQ = LMq(ml, j); }
+        else eT = PF_INF;
+    };
+    fetch_node();
+    fetch_event();
     // move the bookkeeping over every node / event boundary at or below the new time
     auto advance = [&](double tnew) {
-        while (i < ni && LS(ln, i) <= tnew) {
-            bump(LBp(ml, LC(ln, i, 0)), -1);
-            bump(LBp(ml, LC(ln, i, 1)), -1);
-            if (i < ni - 1) bump(LPn(ml, i), 1);         // the top node's own lineage is the root lineage, not a slot
+        while (nS <= tnew) {
+            int p0 = LBp(ml, nC0), p1 = LBp(ml, nC1);
+            bump(p0, -1);
+            bump(p1, -1);
+            if (i < ni - 1) bump(nP, 1);                 // the top node's own lineage is the root lineage, not a slot
             ++i;
+            fetch_node();
         }
-        while (j < ml.nm && LMt(ml, j) <= tnew) {
-            int b = LMb(ml, j);
-            if (b < PF_TAG_MIN) {
-                bump(LBp(ml, b), -1);
-                LBp(ml, b) = LMq(ml, j);
-                bump(LBp(ml, b), 1);
+        while (eT <= tnew) {
+            if (eB < PF_TAG_MIN) {
+                bump(LBp(ml, eB), -1);
+                LBp(ml, eB) = (int8_t)eQ;
+                bump(eQ, 1);
             }
             ++j;
+            fetch_event();
         }
     };
     // record_all_event (particle.cpp:251-300) for the piece of the walk [tt, t1): kind 0 no event, 1 coalescence,
@@ -264,27 +282,28 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
         bool root_active = false;
         int weight = 0;
         double rc = 0.0, rmf = 0.0, rmr = 0.0, lam = 0.0;
+        // boundary times and rate-table entries are carried in registers and re-read only when their index moves
+        double tn_ep = epoch_end(ln, e);
+        double inv_f = ml.I2[e * P + pf], mt_f = ml.MT[e * P + pf], mt_r = ml.MT[e * P + pr];
         for (int g2 = 0; g2 < 100000; ++g2) {
             root_active = tt >= Hr;
-            double tn_node = i < ni ? LS(ln, i) : PF_INF;
-            double tn_mig = j < ml.nm ? LMt(ml, j) : PF_INF;
-            double tn_ep = epoch_end(ln, e);
-            double tn = tn_node < tn_mig ? tn_node : tn_mig;
+            double tn = nS < eT ? nS : eT;
             tn = tn < tn_ep ? tn : tn_ep;
             int k = count_of(pf);
             weight = k + ((root_active && pr == pf) ? 1 : 0);
-            rc = (double)weight * ml.I2[e * P + pf];
-            rmf = ml.MT[e * P + pf];
-            rmr = root_active ? ml.MT[e * P + pr] : 0.0;
+            rc = (double)weight * inv_f;
+            rmf = mt_f;
+            rmr = root_active ? mt_r : 0.0;
             lam = (rc + rmf) + rmr;
             if (lam == 0.0 && !(tn < PF_INF)) { ml.err = 3; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
             double need = (tn - tt) * lam;
             if (!(ln.ebuf > need)) break;                 // an event falls into this interval
             record(root_active, weight, tn - tt, 0, 0);
             ln.ebuf -= need;
+            const bool cross_ep = tn_ep <= tn;
             tt = tn;
             advance(tt);
-            if (tn_ep <= tn) {
+            if (cross_ep) {
                 ++e;
                 int q = ml.JM[e * P + pf];
                 if (q != pf) { mp_ev_insert(ml, tt, PF_TAG_PATH, q); pf = q; }
@@ -293,7 +312,10 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
                     if (qr != pr) { mp_ev_insert(ml, tt, PF_TAG_RPATH, qr); pr = qr; }
                 }
                 if (ml.err) { W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
+                fetch_event();          // the list moved under j
                 advance(tt);
+                tn_ep = epoch_end(ln, e);
+                inv_f = ml.I2[e * P + pf]; mt_f = ml.MT[e * P + pf]; mt_r = ml.MT[e * P + pr];
             }
         }
         // ---- the event
@@ -328,6 +350,7 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
         else { mp_ev_insert(ml, t1, PF_TAG_RPATH, to); pr = to; }
         if (ml.err) { W.tc = t1; W.pf = pf; W.pr = pr; W.weight = 0; return; }
         tt = t1;
+        fetch_event();          // the list moved under j
         advance(tt);            // steps over the event just inserted (temporary tags are not lineages of the tree)
     }
     ml.err = 3;
@@ -404,16 +427,19 @@ __device__ __forceinline__ void mp_genealogy_rest(Lane& ln, MLane& ml, PLog* pl,
     const double u = uni(ln);
     const int idx = min((int)(u * (double)k), k - 1);
     if (idx < nslots) mp_slots_at(ln, ml, n - 1, rp, tc, W.pf, s_id, Sp, idx, &pr, &ps);
-    // the stub: what remains of the cut branch above the cut
-    for (int m = 0; m < ml.nm; ++m)
-        if (LMb(ml, m) == b_id && LMt(ml, m) > h) LMb(ml, m) = (int8_t)PF_TAG_STUB;
-    mp_remove_rank(ln, ml, n - 1, rp, s_id, &b_id, &s_id);
-    int ni = n - 2;
-    int troot = p_was_root ? s_id : n + (ni - 1);
-    mp_retag(ml, PF_TAG_RPATH, troot);
     *changed_out = !(has_stub && idx == k - 1);
-    // one insertion for all three outcomes (slot, root lineage, back into the stub)
+    // ---- the edit.  Tree: remove p, insert the re-attachment node (one insertion for all three outcomes: slot,
+    // root lineage, back into the stub).  Event list: everything that the separate steps (tag the stub, relabel for
+    // the removal, hand the root path to the pruned root, relabel for the insertion and split the target branch,
+    // settle the stub, hand the floating path to the cut branch, clear the branch above the root) would do to an
+    // event depends on that event alone, so it is ONE pass with in-place compaction.
+    const int pid = n + rp;
+    const int b0 = b_id, s0 = s_id;                      // children of p: ids below pid, unchanged by the removal
     const bool into_stub = !(idx < nslots) && !(has_root && idx == nslots);
+    for (int r = rp; r + 1 < n - 1; ++r) LPn(ml, r) = LPn(ml, r + 1);
+    remove_rank(ln, n - 1, rp, s_id, &b_id, &s_id);
+    const int ni = n - 2;
+    const int troot = p_was_root ? s0 : n + (ni - 1);
     double h_ins = tc;
     int pr_ins = -1, ps_ins = 0, pop_ins = W.pf;
     if (idx < nslots) { pr_ins = pr; ps_ins = ps; }
@@ -427,29 +453,53 @@ __device__ __forceinline__ void mp_genealogy_rest(Lane& ln, MLane& ml, PLog* pl,
             for (int rr = R; rr < ni && !found; ++rr)
                 for (int s = 0; s < 2 && !found; ++s) {
                     int id = LC(ln, rr, s);
-                    if ((id < n || id - n < R) && id == s_id) { found = true; pr_ins = rr; ps_ins = s; }
+                    if ((id < n || id - n < R) && id == s0) { found = true; pr_ins = rr; ps_ins = s; }
                 }
         }
     }
-    mp_insert_node(ln, ml, ni, h_ins, &b_id, pr_ins, ps_ins, troot, pop_ins);
+    int rn = 0;
+    while (rn < ni && LS(ln, rn) <= h_ins) ++rn;
+    const int nid = n + rn;
+    int tg = pr_ins >= 0 ? (int)LC(ln, pr_ins, ps_ins) : troot;       // target branch (pruned-tree id) ...
+    if (tg >= nid) tg += 1;                                           // ... as labelled after the insertion
+    const int troot2 = troot >= nid ? troot + 1 : troot;
+    const int b2 = b0 >= nid ? b0 + 1 : b0;
+    const int root_final = n + n - 2;
     {
-        // the stub's events: back into its own stub the ones after tc return to the cut branch, everything else
-        // of the stub vanishes (the cut branch swaps them for the events picked up on the way)
         int o = 0;
-        for (int m = 0; m < ml.nm; ++m) {
-            int bb = LMb(ml, m);
-            double t = LMt(ml, m);
-            if (bb == PF_TAG_STUB) {
-                if (!(into_stub && t > tc)) continue;
-                bb = b_id;
+        const int nmv = ml.nm;
+        for (int q = 0; q < nmv; ++q) {
+            int v = LMb(ml, q);
+            const double t = LMt(ml, q);
+            const int8_t to = LMq(ml, q);
+            bool keep = true;
+            if (v < PF_TAG_MIN) {
+                if (v == b0 && t > h) {
+                    // the stub: events after tc return to the cut branch when the lineage fell back into its stub
+                    keep = into_stub && t > tc;
+                    v = b2;
+                } else {
+                    if (v == pid) v = s0; else if (v > pid) v -= 1;          // removal of p
+                    if (v >= nid) v += 1;                                     // insertion of the new node
+                    if (v == tg && t > h_ins) { if (pr_ins >= 0) v = nid; else keep = false; }
+                }
+            } else if (v == PF_TAG_RPATH) {
+                v = troot2;
+                if (v == tg && t > h_ins) { if (pr_ins >= 0) v = nid; else keep = false; }
+            } else {                                                           // PF_TAG_PATH
+                v = b2;
             }
-            LMt(ml, o) = t; LMb(ml, o) = (int8_t)bb; LMq(ml, o) = LMq(ml, m);
-            ++o;
+            if (v == root_final) keep = false;            // nothing is kept above the root of the local tree
+            if (keep) {
+                LMt(ml, o) = t; LMb(ml, o) = (int8_t)v; LMq(ml, o) = to;
+                ++o;
+            }
         }
         ml.nm = o;
     }
-    mp_retag(ml, PF_TAG_PATH, b_id);
-    mp_ev_drop_above(ml, n + n - 2, -1.0);      // nothing is kept above the root of the local tree
+    for (int r = ni; r > rn; --r) LPn(ml, r) = LPn(ml, r - 1);
+    LPn(ml, rn) = (int8_t)pop_ins;
+    insert_node(ln, ni, h_ins, b0, pr_ins, ps_ins, troot);
     ln.Ltree = tree_length(ln, n);
 }
 

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(PF_BS) void k_init_mp(KArgs A, double initial_posit
     ln.ebuf = -dlog(uni(ln));
     unsigned widx = 0;
     PLog pl;
-    pl.base = A.plog + (size_t)p * A.pcap * 3; pl.cap = A.pcap; pl.idx = 0; pl.on = true; pl.fopen = false; pl.ropen = false;
+    pl.base = A.plog + (size_t)p * A.pcap * 3; pl.cap = A.pcap; pl.idx = 0; pl.pos = 0; pl.on = true; pl.fopen = false; pl.ropen = false;
     // every coalescence of the initial tree is logged as a type-2 record at position 0 (particle.cpp:251-300)
     mp_build_initial_tree(ln, ml, &pl, [&](int i, unsigned p0, unsigned np_, double tc) {
         double* rec = rec_ptr(A, p, widx);
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
         ln.ebuf = A.ebuf[p];
         unsigned widx = A.widx[p];
         PLog pl;
-        pl.base = A.plog + (size_t)p * A.pcap * 3; pl.cap = A.pcap; pl.idx = A.pidx[p]; pl.on = true;
+        pl.base = A.plog + (size_t)p * A.pcap * 3; pl.cap = A.pcap; pl.idx = A.pidx[p]; pl.pos = pl.idx % pl.cap; pl.on = true;
         pl.fopen = false; pl.ropen = false;
         double* tmp0 = m.t0 + threadIdx.x;
         double* tmp1 = m.t1 + threadIdx.x;
