@@ -275,29 +275,94 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
             if (kind == 3) plog_flush_r(*pl, 2, to);
         }
     };
-    // One pass of the outer loop per EVENT, not per interval: the inner loop runs through the event-free
-    // intervals with a few table lookups each; the expensive part (two Philox draws and a log) then runs once
-    // per event with the lanes of the wavefront converged, instead of in nearly every interval for some lane.
-    for (int guard = 0; guard < 4096; ++guard) {
-        bool root_active = false;
-        int weight = 0;
-        double rc = 0.0, rmf = 0.0, rmr = 0.0, lam = 0.0;
+    // Events picked up by the two active lineages wait in registers until the walk is over (they are not lineages of
+    // the stored tree, so nothing in the walk reads them); inserting into the LDS list inside the loop would make
+    // the whole wavefront pay for every lane's migration.
+    constexpr int KB = 4;
+    double bt[KB]; int bq[KB], btag[KB];
+    int nb = 0;
+    auto flush_buffer = [&]() {
+#pragma unroll
+        for (int k = 0; k < KB; ++k)
+            if (k < nb) { mp_ev_insert(ml, bt[k], btag[k], bq[k]); ++j; }      // lands at or before j: j keeps its event
+        nb = 0;
+        fetch_event();
+    };
+    auto buf_push = [&](double t, int tag, int q) {
+        if (nb == KB) flush_buffer();
+#pragma unroll
+        for (int k = 0; k < KB; ++k)
+            if (k == nb) { bt[k] = t; btag[k] = tag; bq[k] = q; }
+        ++nb;
+    };
+    // The random numbers an event needs (one uniform for its kind, one log for the next waiting time) are drawn
+    // ahead, KP events' worth at a time, with the wavefront converged: Philox is counter-based, so numbers drawn
+    // ahead and not used cost nothing but the arithmetic -- the draw counter only advances by what was consumed.
+    // Inside the loop an event is then a division and a table lookup, and one loop serves the whole walk.
+    constexpr int KP = 2;
+    bool done = false;
+    for (int guard = 0; guard < 4096 && !done; ++guard) {
+        const unsigned long long ctr0 = ln.ctr;
+        double u_type[KP], eb_new[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            u_type[k] = philox_uniform(ln.seed, ln.slot, ln.stream, ctr0 + 2 * k);
+            eb_new[k] = -dlog(philox_uniform(ln.seed, ln.slot, ln.stream, ctr0 + 2 * k + 1));
+        }
+        int used = 0;
         // boundary times and rate-table entries are carried in registers and re-read only when their index moves
         double tn_ep = epoch_end(ln, e);
         double inv_f = ml.I2[e * P + pf], mt_f = ml.MT[e * P + pf], mt_r = ml.MT[e * P + pr];
         for (int g2 = 0; g2 < 100000; ++g2) {
-            root_active = tt >= Hr;
+            const bool root_active = tt >= Hr;
             double tn = nS < eT ? nS : eT;
             tn = tn < tn_ep ? tn : tn_ep;
-            int k = count_of(pf);
-            weight = k + ((root_active && pr == pf) ? 1 : 0);
-            rc = (double)weight * inv_f;
-            rmf = mt_f;
-            rmr = root_active ? mt_r : 0.0;
-            lam = (rc + rmf) + rmr;
+            const int k = count_of(pf);
+            const int weight = k + ((root_active && pr == pf) ? 1 : 0);
+            const double rc = (double)weight * inv_f;
+            const double rmf = mt_f;
+            const double rmr = root_active ? mt_r : 0.0;
+            const double lam = (rc + rmf) + rmr;
             if (lam == 0.0 && !(tn < PF_INF)) { ml.err = 3; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
-            double need = (tn - tt) * lam;
-            if (!(ln.ebuf > need)) break;                 // an event falls into this interval
+            const double need = (tn - tt) * lam;
+            if (!(ln.ebuf > need)) {
+                // ---- an event falls into this interval
+                if (used == KP) break;                    // out of pre-drawn numbers: draw more, then carry on
+                const double t1 = tt + ln.ebuf / lam;
+                const double ut = used == 0 ? u_type[0] : u_type[1];
+                int kind, to = 0;
+                {
+                    double v = ut * lam;
+                    if (v < rc || (rmf == 0.0 && rmr == 0.0)) kind = 1;
+                    else {
+                        v -= rc;
+                        int from;
+                        if (v < rmf || rmr == 0.0) { kind = 2; from = pf; }
+                        else { kind = 3; from = pr; v -= rmf; }
+                        to = -1;
+                        for (int q = 0; q < P; ++q) {
+                            double mr = ml.MR[(e * P + from) * P + q];
+                            if (q == from || mr == 0.0) continue;
+                            to = q;
+                            if (v < mr) break;
+                            v -= mr;
+                        }
+                    }
+                }
+                record(root_active, weight, t1 - tt, kind, to);
+                ln.ebuf = used == 0 ? eb_new[0] : eb_new[1];
+                ++used;
+                if (kind == 1) {
+                    W.tc = t1; W.pf = pf; W.pr = pr; W.weight = weight;
+                    done = true;
+                    break;
+                }
+                buf_push(t1, kind == 2 ? PF_TAG_PATH : PF_TAG_RPATH, to);
+                if (kind == 2) pf = to; else pr = to;
+                tt = t1;
+                inv_f = ml.I2[e * P + pf]; mt_f = ml.MT[e * P + pf]; mt_r = ml.MT[e * P + pr];
+                continue;
+            }
             record(root_active, weight, tn - tt, 0, 0);
             ln.ebuf -= need;
             const bool cross_ep = tn_ep <= tn;
@@ -306,55 +371,21 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
             if (cross_ep) {
                 ++e;
                 int q = ml.JM[e * P + pf];
-                if (q != pf) { mp_ev_insert(ml, tt, PF_TAG_PATH, q); pf = q; }
+                if (q != pf) { buf_push(tt, PF_TAG_PATH, q); pf = q; }
                 if (tt >= Hr) {
                     int qr = ml.JM[e * P + pr];
-                    if (qr != pr) { mp_ev_insert(ml, tt, PF_TAG_RPATH, qr); pr = qr; }
+                    if (qr != pr) { buf_push(tt, PF_TAG_RPATH, qr); pr = qr; }
                 }
-                if (ml.err) { W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
-                fetch_event();          // the list moved under j
-                advance(tt);
                 tn_ep = epoch_end(ln, e);
                 inv_f = ml.I2[e * P + pf]; mt_f = ml.MT[e * P + pf]; mt_r = ml.MT[e * P + pr];
             }
+            if (ml.err) { W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
         }
-        // ---- the event
-        double t1 = tt + ln.ebuf / lam;
-        int kind, to = 0;
-        {
-            double v = uni(ln) * lam;
-            if (v < rc || (rmf == 0.0 && rmr == 0.0)) kind = 1;
-            else {
-                v -= rc;
-                int from;
-                if (v < rmf || rmr == 0.0) { kind = 2; from = pf; }
-                else { kind = 3; from = pr; v -= rmf; }
-                to = -1;
-                for (int q = 0; q < P; ++q) {
-                    double mr = ml.MR[(e * P + from) * P + q];
-                    if (q == from || mr == 0.0) continue;
-                    to = q;
-                    if (v < mr) break;
-                    v -= mr;
-                }
-            }
-        }
-        record(root_active, weight, t1 - tt, kind, to);
-        ln.ebuf = -dlog(uni(ln));
-        if (kind == 1) {
-            if (pl) { plog_flush_f(*pl, 0, 0); plog_flush_r(*pl, 0, 0); }
-            W.tc = t1; W.pf = pf; W.pr = pr; W.weight = weight;
-            return;
-        }
-        if (kind == 2) { mp_ev_insert(ml, t1, PF_TAG_PATH, to); pf = to; }
-        else { mp_ev_insert(ml, t1, PF_TAG_RPATH, to); pr = to; }
-        if (ml.err) { W.tc = t1; W.pf = pf; W.pr = pr; W.weight = 0; return; }
-        tt = t1;
-        fetch_event();          // the list moved under j
-        advance(tt);            // steps over the event just inserted (temporary tags are not lineages of the tree)
+        ln.ctr = ctr0 + 2 * (unsigned long long)used;
     }
-    ml.err = 3;
-    W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0;
+    if (!done) { ml.err = 3; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
+    flush_buffer();
+    if (pl) { plog_flush_f(*pl, 0, 0); plog_flush_r(*pl, 0, 0); }
 }
 
 __device__ __forceinline__ void mp_retag(MLane& ml, int from, int to) {

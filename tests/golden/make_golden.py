@@ -134,6 +134,9 @@ def seg_prefix(src_rel, dst_name, limit):
 if __name__ == "__main__":
     pm = load_ref()
     seg_prefix("test/old/newtests/testdata/twopopssplit_unidirmigr.seg", "twopopssplit_unidirmigr_first2Mb.seg", 2000001)
+    # the whole 10 Mb data set of the reference's constant-size regression test (test_const_pop_size.py:15-49)
+    import shutil
+    shutil.copyfile(os.path.join(REF, "test/old/newtests/testdata/constpopsize.seg"), os.path.join(HERE, "seg", "constpopsize.seg"))
     json.dump(cmdlines(pm), open(os.path.join(HERE, "cmdlines.json"), "w"), indent=1)
     json.dump(mstep(pm), open(os.path.join(HERE, "mstep.json"), "w"), indent=1)
     if os.path.exists(os.path.join(HERE, "sample.out")):
