@@ -1475,11 +1475,8 @@ static void median_survival(const Model& M, uint64_t seed, int min_events, int64
             Particle p;
             p.head.assign(E, nullptr);
             /* the replicate's own stream: slot = global replicate index */
-            struct Tmp { Filter& f; int64_t slot; } tmp{f, trees + r};
             f.rng[0] = SlotRng{0, 0.0};
-            auto uni = [&]() { return philox_uniform(seed, (uint32_t)tmp.slot, 2, f.rng[0].ctr++); };
-            (void)uni;
-            f.slot_override = tmp.slot;
+            f.slot_override = trees + r;
             f.rng[0].ebuf = -smc_log(f.uni(0));
             f.build_initial_tree(0, p);
             double orig[NMAX];
