@@ -301,11 +301,11 @@ __device__ __forceinline__ void d_adjust_with_delay(DStore& d, double& w_post, d
     d.k[(size_t)i * d.Np] = 3;
 }
 
-template <int NM, bool BIASED>
 // With fuse != 0 the launch also completes the previous row: the in-place normalisation or the resampling gather of
 // k_resample (pc.cpp:321-392, 435-437) happens while the particle is loaded, which removes one kernel and its
 // launch gap from the per-row critical path.  The arithmetic is k_resample's, operation for operation.
-__global__ __launch_bounds__(PF_BS) void k_extend_reg(KArgs A, long long s, int fuse) {
+template <int NM, bool BIASED>
+__device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int fuse) {
     extern __shared__ double smem[];
     double* sT = smem;
     double* sI = smem + A.E;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(PF_BS) void k_extend_reg(KArgs A, long long s, int 
     double w_post = 0.0, w_pilot = 0.0;
     bool has_pending = false;
     if (active) {
-        DState& st = A.st[cur];
+        const DState& st = A.st[cur];
         const bool gather = fuse && c->flag;              // the previous row resampled: this slot starts as a copy of its parent
         const DState& from = gather ? A.st[cur ^ 1] : st;
         const long long a = gather ? (long long)A.parent[p] : p;
@@ -557,6 +557,11 @@ __global__ __launch_bounds__(PF_BS) void k_extend_reg(KArgs A, long long s, int 
     }
 }
 
+template <int NM, bool BIASED>
+__global__ __launch_bounds__(PF_BS) void k_extend_reg(KArgs A, long long s, int fuse) {
+    extend_reg_body<NM, BIASED>(A, s, fuse);
+}
+
 // ------------------------------------------------------------------ count bookkeeping (shared)
 // Ordered reduction of the k_count partials of the previous step into the totals
 // (count.cpp:407-414).  Runs in the second workgroup of k_decide (off the critical path) or in
@@ -654,7 +659,7 @@ __device__ void window_generations(const KArgs& A, Ctrl* c, const Windows& W, in
 //     the parent table entries of their offspring and its survivor count: no inter-workgroup wait;
 //   * the bookkeeping workgroup folds the previous step's k_count partials and advances the window
 //     generations (off the critical path).
-__global__ __launch_bounds__(PF_BS) void k_decide(KArgs A, long long s, int mode, Windows W, int nblocks) {
+__device__ __forceinline__ void decide_body(const KArgs& A, long long s, int mode, const Windows& W, int nblocks) {
     __shared__ double l2s[4096];          // level-2 inclusive scan of the per-wavefront pilot totals / finalize staging
     __shared__ double l2_post[64], l2_sq[64], l2_tot[64], l2_totp[64];
     __shared__ int wred[PF_BS / 64];
@@ -807,7 +812,7 @@ __global__ __launch_bounds__(PF_BS) void k_decide(KArgs A, long long s, int mode
     if (tid == 0) {
         int tot = 0;
         for (int w = 0; w < nwaves; ++w) tot += wred[w];
-        A.blkcnt[blockIdx.x] = tot;
+        A.blkcnt2[A.sp][blockIdx.x] = tot;
         if (blockIdx.x == 0) {
             // toggle buffers / open the next generation
             int ev = (int)n_res;
@@ -951,15 +956,15 @@ __device__ __forceinline__ void records_contrib(AccT<P>& acc, const KArgs& A, co
 #define PF_CNT_WIDE 128       // run lists longer than this are strided over by the whole grid column
 
 template <int NI, int P>
-__device__ __forceinline__ void count_run(AccT<P>& acc, const KArgs& A, const Win& W, int g, long long i, int nr, const int* rst,
-                                          const int* ran, double inv) {
+__device__ __forceinline__ void count_run(AccT<P>& acc, const KArgs& A, int sp, const Win& W, int g, long long i, int nr,
+                                          const int* rst, const int* ran, double inv) {
     const long long Np = A.Np;
     int q0 = rst[i];
     int q1 = i + 1 < nr ? rst[i + 1] : (int)Np;
     long long a = ran[i];
     // posterior mass of the descendants of (g, a): difference of the inclusive posterior scan
-    const double* offp = A.chunk_offp2[A.sp];
-    const double* scp_ = A.scanp2[A.sp];
+    const double* offp = A.chunk_offp2[sp];
+    const double* scp_ = A.scanp2[sp];
     double hi = offp[(q1 - 1) >> 6] + scp_[q1 - 1];
     double lo = q0 > 0 ? offp[(q0 - 1) >> 6] + scp_[q0 - 1] : 0.0;
     double w = (hi - lo) * inv;
@@ -970,21 +975,23 @@ __device__ __forceinline__ void count_run(AccT<P>& acc, const KArgs& A, const Wi
     records_contrib<NI, P>(acc, A, W, w, a, k0, k1);
 }
 
+// The body of k_count for the workgroup (bx, by) of a column of nbxg workgroups; `sp` = parity of the step whose
+// weights and snapshot it reads.  Called from k_count and from the count workgroups of k_row.
 template <int NM, int P>
-__global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0, Windows Wn) {
+__device__ __forceinline__ void count_body(const KArgs& A, int sp, int e0, const Windows& Wn, int bx, int by, int nbxg) {
     constexpr int NI = NM - 1;
     using AC = AccT<P>;
     __shared__ AC red[PF_BS / 64];
     __shared__ int s_off[PF_CNT_TILE + 1];
     __shared__ int s_wsum[PF_BS / 64];
     const Ctrl* c = A.ctrl;
-    const int e = e0 + blockIdx.y;
+    const int e = e0 + by;
     const int first = Wn.first;
     if (e < first || e >= A.E) return;
     const long long Np = A.Np;
     const int n = A.n;
-    const int G = c->step[A.sp].G;                        // the generation the weights belong to
-    const double inv = c->step[A.sp].inv_T;
+    const int G = c->step[sp].G;                        // the generation the weights belong to
+    const double inv = c->step[sp].inv_T;
     Win W;
     W.e = e; W.rf = A.recflags[e];
     W.T0 = A.T[e]; W.T1 = e + 1 < A.E ? A.T[e + 1] : PF_INF;
@@ -992,8 +999,8 @@ __global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0, Windows Wn) {
     W.end_seq = (A.L == W.b_e);
     const int g_lo = c->g_lo[e], g_hi = c->g_hi[e];
     const int lane = threadIdx.x & 63;
-    const long long gtid = (long long)blockIdx.x * PF_BS + threadIdx.x;
-    const long long nthreads = (long long)gridDim.x * PF_BS;
+    const long long gtid = (long long)bx * PF_BS + threadIdx.x;
+    const long long nthreads = (long long)nbxg * PF_BS;
     const int my_wave = (int)(gtid >> 6);
     const int total_waves = (int)(nthreads >> 6);
     AC acc;
@@ -1053,14 +1060,14 @@ __global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0, Windows Wn) {
             if (g == G) {
                 // live particle: its own weight, its open stretch, the records it wrote this generation
                 const long long a = i;
-                double w = A.snap_w[A.sp][a] * inv;
+                double w = A.snap_w[sp][a] * inv;
                 double S[NI];
 #pragma unroll
-                for (int r = 0; r < NI; ++r) S[r] = r < n - 1 ? A.snap_S[A.sp][(size_t)r * Np + a] : 0.0;
-                double xm = A.snap_xm[A.sp][a];
-                int ml = A.snap_ml[A.sp][a];
+                for (int r = 0; r < NI; ++r) S[r] = r < n - 1 ? A.snap_S[sp][(size_t)r * Np + a] : 0.0;
+                double xm = A.snap_xm[sp][a];
+                int ml = A.snap_ml[sp][a];
                 unsigned k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
-                unsigned k1 = A.snap_widx[A.sp][a];
+                unsigned k1 = A.snap_widx[sp][a];
                 if (w == 0.0) continue;
                 stretch_contrib<NI, P>(acc, A, W, w, xm, PF_INF, S, ml);
                 if (k1 - k0 > A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;
@@ -1069,7 +1076,7 @@ __global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0, Windows Wn) {
                 const int nr = s_off[lo_i + 1] - s_off[lo_i];
                 const int* rst = A.run_st + (size_t)(g % A.Gcap) * Np;
                 const int* ran = A.run_anc + (size_t)(g % A.Gcap) * Np;
-                count_run<NI, P>(acc, A, W, g, i, nr, rst, ran, inv);
+                count_run<NI, P>(acc, A, sp, W, g, i, nr, rst, ran, inv);
             }
         }
     }
@@ -1082,7 +1089,27 @@ __global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0, Windows Wn) {
         const int k = threadIdx.x;
         double t = red[0].v[k];
         for (int w = 1; w < PF_BS / 64; ++w) t += red[w].v[k];
-        A.partial[((size_t)e * A.nbx + blockIdx.x) * AC::NC + k] = t;
+        A.partial[((size_t)e * A.nbx + bx) * AC::NC + k] = t;
+    }
+}
+
+template <int NM, int P>
+__global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0, Windows Wn) {
+    count_body<NM, P>(A, A.sp, e0, Wn, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+}
+
+// ------------------------------------------------------------------ k_row
+// One launch per row on a single stream: workgroups [0, nb) extend the particles over row s (and complete row s-1 on
+// load), the remaining workgroups evaluate the lagged counts of row s-1 (k_count's body).  The two halves touch
+// disjoint data -- everything the counts read from row s-1 is immutable or double-buffered by row parity -- so the
+// counting costs no synchronisation at all: no second stream, no event record / wait packets on the critical path.
+template <int NM, bool BIASED>
+__global__ __launch_bounds__(PF_BS) void k_row(KArgs A, long long s, int fuse, int nb, int count_first, Windows Wprev) {
+    if ((int)blockIdx.x < nb) {
+        extend_reg_body<NM, BIASED>(A, s, fuse);
+    } else {
+        const int idx = (int)blockIdx.x - nb;
+        count_body<NM, 1>(A, A.sp ^ 1, count_first, Wprev, idx % nb, idx / nb, nb);
     }
 }
 
@@ -1212,16 +1239,17 @@ __device__ void ledger_update(const KArgs& A, int lb, int nlb, int G) {
 // in slot order: start = lo[a], ancestor = a); the others re-base the run-length encoded composite ancestor
 // maps of all retained generations onto the new slots (st' = lo[st], empty runs dropped).  Only k_count reads
 // these lists, so the whole maintenance lives on the counting stream, off the filter's critical path.
-__global__ __launch_bounds__(PF_BS) void k_ledger(KArgs A, int nblocks) {
+// body of k_ledger for workgroup bx of nbt; `sp` = parity of the step whose resampling it follows up
+__device__ __forceinline__ void ledger_body(const KArgs& A, int sp, int nblocks, int bx, int nbt) {
     const Ctrl* c = A.ctrl;
-    if (!c->step[A.sp].flag) return;
-    const int Gx = c->step[A.sp].G;
-    if ((int)blockIdx.x >= nblocks) {
-        ledger_update(A, (int)blockIdx.x - nblocks, (int)gridDim.x - nblocks, Gx);
+    if (!c->step[sp].flag) return;
+    const int Gx = c->step[sp].G;
+    if (bx >= nblocks) {
+        ledger_update(A, bx - nblocks, nbt - nblocks, Gx);
         return;
     }
     const long long Np = A.Np;
-    const long long i = (long long)blockIdx.x * PF_BS + threadIdx.x;
+    const long long i = (long long)bx * PF_BS + threadIdx.x;
     {
         // run list of the generation that ends here: its survivors, in slot order (start = lo[a], ancestor = a).
         // Position = survivors in earlier workgroups (k_decide's blkcnt) + rank inside this workgroup.
@@ -1234,21 +1262,36 @@ __global__ __launch_bounds__(PF_BS) void k_ledger(KArgs A, int nblocks) {
         unsigned long long bal = __ballot(surv);
         if (lane == 0) wsum[wave] = __popcll(bal);
         __shared__ int sblk[1024];
-        for (int b = threadIdx.x; b < nblocks; b += PF_BS) sblk[b] = A.blkcnt[b];
+        for (int b = threadIdx.x; b < nblocks; b += PF_BS) sblk[b] = A.blkcnt2[sp][b];
         __syncthreads();
         int base = 0;
-        for (int b = 0; b < (int)blockIdx.x; ++b) base += sblk[b];
+        for (int b = 0; b < bx; ++b) base += sblk[b];
         for (int w = 0; w < wave; ++w) base += wsum[w];
         if (surv) {
             int pos = base + __popcll(bal & ((1ULL << lane) - 1ULL));
             A.run_st[(size_t)(Gx % A.Gcap) * Np + pos] = l0;
             A.run_anc[(size_t)(Gx % A.Gcap) * Np + pos] = (int)i;
         }
-        if (blockIdx.x == (unsigned)nblocks - 1 && threadIdx.x == PF_BS - 1) {
+        if (bx == nblocks - 1 && threadIdx.x == PF_BS - 1) {
             int tot = base + __popcll(bal);           // base already holds the earlier wavefronts of this workgroup
             A.nruns[Gx % A.Gcap] = tot;
         }
     }
+}
+
+__global__ __launch_bounds__(PF_BS) void k_ledger(KArgs A, int nblocks) {
+    ledger_body(A, A.sp, nblocks, (int)blockIdx.x, (int)gridDim.x);
+}
+
+__global__ __launch_bounds__(PF_BS) void k_decide(KArgs A, long long s, int mode, Windows W, int nblocks) {
+    decide_body(A, s, mode, W, nblocks);
+}
+
+// k_decide of row s with the ledger maintenance of row s-1 riding along in extra workgroups (single-stream pipeline:
+// it has to follow the counts of row s-1, which ran inside k_row(s), and precede those of row s)
+__global__ __launch_bounds__(PF_BS) void k_decide_ledger(KArgs A, long long s, int mode, Windows W, int nblocks, int ledger_nbt) {
+    if ((int)blockIdx.x <= nblocks) decide_body(A, s, mode, W, nblocks);
+    else ledger_body(A, A.sp ^ 1, nblocks, (int)blockIdx.x - (nblocks + 1), ledger_nbt);
 }
 
 __global__ __launch_bounds__(PF_BS) void k_resample(KArgs A, long long s, int nblocks) {
@@ -1890,7 +1933,7 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     rc |= dalloc(h, &A.lo, (size_t)A.Gcap * (Np + 1));
     rc |= dalloc(h, &A.gen_x0, A.Gcap);
     rc |= dalloc(h, &A.parent, Np);
-    rc |= dalloc(h, &A.blkcnt, (size_t)h->nblocks);
+    rc |= dalloc(h, &A.blkcnt2[0], (size_t)h->nblocks); rc |= dalloc(h, &A.blkcnt2[1], (size_t)h->nblocks);
     rc |= dalloc(h, &A.run_st, (size_t)A.Gcap * Np);
     rc |= dalloc(h, &A.run_anc, (size_t)A.Gcap * Np);
     rc |= dalloc(h, &A.nruns, A.Gcap);
@@ -2122,12 +2165,15 @@ static int launch_decide(pf_handle* h, long long s, int mode, const Windows& W) 
         hipLaunchKernelGGL(k_decide, dim3(h->nblocks + 1), dim3(PF_BS), 0, h->stream, h->A, s, mode, W, h->nblocks);
         h->fin_pending = false;      // the bookkeeping workgroup folds the previous step's partials
     }
-    h->ev_dec = next_sync_event(h);
-    hipEventRecord(h->ev_dec, h->stream);
+    if (!getenv("SMCSMC_PF_DEBUG_NOCOUNT")) {
+        h->ev_dec = next_sync_event(h);
+        hipEventRecord(h->ev_dec, h->stream);
+    }
     return check_launch("k_decide");
 }
 
 static int launch_count(pf_handle* h, long long s, const Windows& W) {
+    if (getenv("SMCSMC_PF_DEBUG_NOCOUNT")) return 0;
     const int first = W.first;
     if (first >= h->E) return 0;
     const bool t = timing_on(h, s);
@@ -2158,6 +2204,7 @@ static int launch_count(pf_handle* h, long long s, const Windows& W) {
 // ancestor-ledger maintenance of this step (no-op unless the step resampled); closes the step on the counting stream
 static int launch_ledger(pf_handle* h, long long s) {
     (void)s;
+    if (getenv("SMCSMC_PF_DEBUG_NOCOUNT")) return 0;
     if (h->ev_dec) hipStreamWaitEvent(h->cstream, h->ev_dec, 0);
     hipLaunchKernelGGL(k_ledger, dim3(h->nblocks + PF_LEDGER_BLOCKS), dim3(PF_BS), 0, h->cstream, h->A, h->nblocks);
     h->ev_cnt = next_sync_event(h);
@@ -2201,34 +2248,98 @@ int pf_resample(pf_handle* h, int64_t s) {
     return rc;
 }
 
-int pf_run(pf_handle* h, int64_t s_begin, int64_t s_end) {
-    HIPCHK(hipSetDevice(h->device));
-    if (s_begin < 0 || s_end > h->n_segs) { g_err = "segment range out of bounds"; return -1; }
-    const bool can_fuse = extend_can_fuse(h);
+// keep the timing-event pool bounded without stalling the queue: only harvest finished spans
+static void trim_spans(pf_handle* h) {
+    if (h->spans.empty() || hipEventQuery(h->spans.front().b) != hipSuccess) return;
+    size_t done = 0;
+    while (done < h->spans.size() && hipEventQuery(h->spans[done].b) == hipSuccess) ++done;
+    std::vector<pf_handle::Span> rest(h->spans.begin() + done, h->spans.end());
+    h->spans.resize(done);
+    harvest_spans(h);
+    h->spans = rest;
+}
+
+// The single-stream pipeline of the register-tree kernels.  Per row two launches and nothing else:
+//   k_row(s)           extend over row s (completing row s-1 while loading)  ||  lagged counts of row s-1
+//   k_decide_ledger(s) normalisation / ESS / offspring table of row s        ||  ancestor-ledger upkeep of row s-1
+// Stream order provides every dependency; the two halves of each launch touch disjoint (immutable or parity
+// double-buffered) data.  The last row of the call is flushed with the stand-alone kernels so that the state is
+// whole when the call returns.
+template <int NM, bool BIASED>
+static void launch_row(pf_handle* h, long long s, int fuse, int count_first, const Windows& Wprev) {
+    const size_t smem_reg = (size_t)(2 * h->E + 2 * PF_BIAS_MAX + 3) * 8;
+    const int nb = h->nblocks;
+    const int ncount = count_first < h->E ? nb * (h->E - count_first) : 0;
+    hipLaunchKernelGGL((k_row<NM, BIASED>), dim3(nb + ncount), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse, nb, count_first, Wprev);
+}
+
+static int run_single_stream(pf_handle* h, long long s_begin, long long s_end) {
+    const bool biased = h->A.n_bias > 0;
+    bool pending = false;             // counts + ledger of the previous row still to be launched
+    Windows Wprev = no_windows(h);
+    // whatever the two-stream kernels of an earlier call left on the counting stream must be done first
+    if (h->ev_cnt) { hipStreamWaitEvent(h->stream, h->ev_cnt, 0); h->ev_cnt = nullptr; }
     for (long long s = s_begin; s < s_end; ++s) {
         h->step_windows = host_windows(h, seg_pos(h, s), false);
         h->A.sp = (int)(s & 1);
-        // rows after the first of this call complete their predecessor inside k_extend; the last row of the call is
-        // completed by k_resample so that the particle state is whole when pf_run returns
+        const bool t = timing_on(h, s);
+        {
+            Timed tm(h, 0, t);
+            const int cf = pending ? Wprev.first : h->E;
+            const int fuse = s > s_begin ? 1 : 0;
+            if (h->n <= 4 && biased) launch_row<4, true>(h, s, fuse, cf, Wprev);
+            else if (h->n <= 4) launch_row<4, false>(h, s, fuse, cf, Wprev);
+            else if (biased) launch_row<8, true>(h, s, fuse, cf, Wprev);
+            else launch_row<8, false>(h, s, fuse, cf, Wprev);
+            if (pending && Wprev.first < h->E) { h->k_launches[2] += 1; h->fin_pending = true; }
+        }
+        if (check_launch("k_row")) return -1;
+        {
+            Timed tm(h, 1, t);
+            const int lnbt = pending ? h->nblocks + PF_LEDGER_BLOCKS : 0;
+            hipLaunchKernelGGL(k_decide_ledger, dim3(h->nblocks + 1 + lnbt), dim3(PF_BS), 0, h->stream, h->A, s, 0, h->step_windows,
+                               h->nblocks, lnbt);
+            h->fin_pending = false;      // the bookkeeping workgroup folds the partials of the counts that rode in k_row
+        }
+        if (check_launch("k_decide")) return -1;
+        pending = true;
+        Wprev = h->step_windows;
+        h->seg_done = s + 1;
         const bool last = (s + 1 == s_end) || (h->h_seg_start[s] + h->h_seg_len[s] >= h->h_L);
-        if (launch_extend(h, s, (can_fuse && s > s_begin) ? 1 : 0)) return -1;
+        if (last) {
+            // flush: complete the row, then its counts and ledger with the stand-alone kernels (same stream)
+            if (launch_resample(h, s)) return -1;
+            if (Wprev.first < h->E) {
+                const dim3 grid(h->nblocks, h->E - Wprev.first), blk(PF_BS);
+                if (h->n <= 4) hipLaunchKernelGGL((k_count<4, 1>), grid, blk, 0, h->stream, h->A, Wprev.first, Wprev);
+                else hipLaunchKernelGGL((k_count<8, 1>), grid, blk, 0, h->stream, h->A, Wprev.first, Wprev);
+                h->k_launches[2] += 1;
+                h->fin_pending = true;
+            }
+            hipLaunchKernelGGL(k_ledger, dim3(h->nblocks + PF_LEDGER_BLOCKS), dim3(PF_BS), 0, h->stream, h->A, h->nblocks);
+            if (check_launch("k_count/k_ledger")) return -1;
+            break;
+        }
+        if ((s & 1023) == 1023) trim_spans(h);
+    }
+    return 0;
+}
+
+int pf_run(pf_handle* h, int64_t s_begin, int64_t s_end) {
+    HIPCHK(hipSetDevice(h->device));
+    if (s_begin < 0 || s_end > h->n_segs) { g_err = "segment range out of bounds"; return -1; }
+    if (extend_can_fuse(h)) return run_single_stream(h, s_begin, s_end);
+    for (long long s = s_begin; s < s_end; ++s) {
+        h->step_windows = host_windows(h, seg_pos(h, s), false);
+        h->A.sp = (int)(s & 1);
+        if (launch_extend(h, s, 0)) return -1;
         if (launch_decide(h, s, 0, h->step_windows)) return -1;
-        if (!can_fuse || last) { if (launch_resample(h, s)) return -1; }
+        if (launch_resample(h, s)) return -1;
         if (launch_count(h, s, h->step_windows)) return -1;
         if (launch_ledger(h, s)) return -1;
         h->seg_done = s + 1;
         if (h->h_seg_start[s] + h->h_seg_len[s] >= h->h_L) break;   // smcsmc.cpp:353-356
-        if ((s & 1023) == 1023 && !h->spans.empty()) {
-            // keep the event pool bounded without stalling the queue: only harvest finished spans
-            if (hipEventQuery(h->spans.front().b) == hipSuccess) {
-                size_t done = 0;
-                while (done < h->spans.size() && hipEventQuery(h->spans[done].b) == hipSuccess) ++done;
-                std::vector<pf_handle::Span> rest(h->spans.begin() + done, h->spans.end());
-                h->spans.resize(done);
-                if (harvest_spans(h)) return -1;
-                h->spans = rest;
-            }
-        }
+        if ((s & 1023) == 1023) trim_spans(h);
     }
     return 0;
 }

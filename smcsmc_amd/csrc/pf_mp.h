@@ -193,7 +193,8 @@ struct MWalk { double tc; int pf, pr, weight; };
 // The floating lineage starts at height h in population pf0 and moves up through the stored tree (ni internal
 // nodes, root_id its top node or the single leaf); above the root the root's own lineage is the second active
 // lineage.  Migration events picked up on the way enter the list under PF_TAG_PATH / PF_TAG_RPATH.
-__device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int root_id, double h, int pf0, PLog* pl,
+template <bool LOG>
+__device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int root_id, double h, int pf0, PLog& pl,
                                             int limit, MWalk& W) {
     const int P = ml.P;
     const int n = ln.n;
@@ -202,15 +203,15 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
     int e = epoch_of(ln, tt);
     int i = 0, j = 0;
     int pf = pf0, pr = mp_pop_base(ln, ml, root_id);
-    if (pl) { pl->fopen = false; pl->ropen = false; }
+    if (LOG) { pl.fopen = false; pl.ropen = false; }
     // Lineages of the stored tree per population, kept up to date while the walk moves up (the restatement
     // recounts them in every interval; the numbers are the same).  Bp[id] = current population of the lineage
     // above node id; a lineage is counted from its lower node until its parent node.
     int cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
-    auto bump = [&](int q, int d) {
+    auto bump = [&](int q, int d) __attribute__((always_inline)) {
         cnt0 += q == 0 ? d : 0; cnt1 += q == 1 ? d : 0; cnt2 += q == 2 ? d : 0; cnt3 += q == 3 ? d : 0;
     };
-    auto count_of = [&](int q) { return q == 0 ? cnt0 : q == 1 ? cnt1 : q == 2 ? cnt2 : cnt3; };
+    auto count_of = [&](int q) __attribute__((always_inline)) { return q == 0 ? cnt0 : q == 1 ? cnt1 : q == 2 ? cnt2 : cnt3; };
     for (int id = 0; id < n; ++id) LBp(ml, id) = (int8_t)ml.SP[id];
     for (int r = 0; r < ni; ++r) LBp(ml, n + r) = LPn(ml, r);
     while (i < ni && LS(ln, i) <= tt) ++i;
@@ -228,18 +229,18 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
     // so crossing a boundary costs one LDS round trip instead of a chain of dependent ones.
     double nS = PF_INF, eT = PF_INF;
     int nC0 = 0, nC1 = 0, nP = 0, eB = 0, eQ = 0;
-    auto fetch_node = [&]() {
+    auto fetch_node = [&]() __attribute__((always_inline)) {
         if (i < ni) { nS = LS(ln, i); nC0 = LC(ln, i, 0); nC1 = LC(ln, i, 1); nP = LPn(ml, i); }
         else nS = PF_INF;
     };
-    auto fetch_event = [&]() {
+    auto fetch_event = [&]() __attribute__((always_inline)) {
         if (j < ml.nm) { eT = LMt(ml, j); eB = LMb(ml, j); eQ = LMq(ml, j); }
         else eT = PF_INF;
     };
     fetch_node();
     fetch_event();
     // move the bookkeeping over every node / event boundary at or below the new time
-    auto advance = [&](double tnew) {
+    auto advance = [&](double tnew) __attribute__((always_inline)) {
         while (nS <= tnew) {
             int p0 = LBp(ml, nC0), p1 = LBp(ml, nC1);
             bump(p0, -1);
@@ -260,41 +261,47 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
     };
     // record_all_event (particle.cpp:251-300) for the piece of the walk [tt, t1): kind 0 no event, 1 coalescence,
     // 2 the floating lineage migrates to `to`, 3 the root lineage migrates to `to`
-    auto record = [&](bool root_active, int weight, double dt, int kind, int to) {
-        if (!(pl && pl->on && (ln.RF[e] & 2) && e <= limit)) return;
-        if (pl->fopen && (pl->fe != e || pl->fp != pf)) plog_flush_f(*pl, 0, 0);
-        if (!pl->fopen) { pl->fopen = true; pl->fe = e; pl->fp = pf; pl->fco = 0.0; pl->fmo = 0.0; }
-        pl->fco += (double)weight * dt;
-        pl->fmo += dt;
-        if (kind == 1) plog_flush_f(*pl, 1, 0);
-        if (kind == 2) plog_flush_f(*pl, 2, to);
+    auto record = [&](bool root_active, int weight, double dt, int kind, int to) __attribute__((always_inline)) {
+        if (!LOG) return;
+        if (!(pl.on && (ln.RF[e] & 2) && e <= limit)) return;
+        if (pl.fopen && (pl.fe != e || pl.fp != pf)) plog_flush_f(pl, 0, 0);
+        if (!pl.fopen) { pl.fopen = true; pl.fe = e; pl.fp = pf; pl.fco = 0.0; pl.fmo = 0.0; }
+        pl.fco += (double)weight * dt;
+        pl.fmo += dt;
+        if (kind == 1) plog_flush_f(pl, 1, 0);
+        if (kind == 2) plog_flush_f(pl, 2, to);
         if (root_active) {
-            if (pl->ropen && (pl->re != e || pl->rp != pr)) plog_flush_r(*pl, 0, 0);
-            if (!pl->ropen) { pl->ropen = true; pl->re = e; pl->rp = pr; pl->rmo = 0.0; }
-            pl->rmo += dt;
-            if (kind == 3) plog_flush_r(*pl, 2, to);
+            if (pl.ropen && (pl.re != e || pl.rp != pr)) plog_flush_r(pl, 0, 0);
+            if (!pl.ropen) { pl.ropen = true; pl.re = e; pl.rp = pr; pl.rmo = 0.0; }
+            pl.rmo += dt;
+            if (kind == 3) plog_flush_r(pl, 2, to);
         }
     };
     // Events picked up by the two active lineages wait in registers until the walk is over (they are not lineages of
     // the stored tree, so nothing in the walk reads them); inserting into the LDS list inside the loop would make
     // the whole wavefront pay for every lane's migration.
-    constexpr int KB = 4;
-    double bt[KB]; int bq[KB], btag[KB];
+    // (four scalar slots, not an array: a dynamically indexed array would be placed in scratch memory)
+    double bt0 = 0, bt1 = 0, bt2 = 0, bt3 = 0;
+    int bq0 = 0, bq1 = 0, bq2 = 0, bq3 = 0, bg0 = 0, bg1 = 0, bg2 = 0, bg3 = 0;
     int nb = 0;
-    auto flush_buffer = [&]() {
-#pragma unroll
-        for (int k = 0; k < KB; ++k)
-            if (k < nb) { mp_ev_insert(ml, bt[k], btag[k], bq[k]); ++j; }      // lands at or before j: j keeps its event
-        nb = 0;
-        fetch_event();
-    };
-    auto buf_push = [&](double t, int tag, int q) {
-        if (nb == KB) flush_buffer();
-#pragma unroll
-        for (int k = 0; k < KB; ++k)
-            if (k == nb) { bt[k] = t; btag[k] = tag; bq[k] = q; }
-        ++nb;
-    };
+#define PF_MP_FLUSH_BUFFER()                                                                                     \
+    do {                                                                                                        \
+        if (nb > 0) { mp_ev_insert(ml, bt0, bg0, bq0); ++j; } /* lands at or before j: j keeps its event */     \
+        if (nb > 1) { mp_ev_insert(ml, bt1, bg1, bq1); ++j; }                                                   \
+        if (nb > 2) { mp_ev_insert(ml, bt2, bg2, bq2); ++j; }                                                   \
+        if (nb > 3) { mp_ev_insert(ml, bt3, bg3, bq3); ++j; }                                                   \
+        nb = 0;                                                                                                 \
+        fetch_event();                                                                                          \
+    } while (0)
+#define PF_MP_BUF_PUSH(T_, TAG_, Q_)                                                                            \
+    do {                                                                                                        \
+        if (nb == 4) PF_MP_FLUSH_BUFFER();                                                                      \
+        if (nb == 0) { bt0 = (T_); bg0 = (TAG_); bq0 = (Q_); }                                                  \
+        else if (nb == 1) { bt1 = (T_); bg1 = (TAG_); bq1 = (Q_); }                                             \
+        else if (nb == 2) { bt2 = (T_); bg2 = (TAG_); bq2 = (Q_); }                                             \
+        else { bt3 = (T_); bg3 = (TAG_); bq3 = (Q_); }                                                          \
+        ++nb;                                                                                                   \
+    } while (0)
     // The random numbers an event needs (one uniform for its kind, one log for the next waiting time) are drawn
     // ahead, KP events' worth at a time, with the wavefront converged: Philox is counter-based, so numbers drawn
     // ahead and not used cost nothing but the arithmetic -- the draw counter only advances by what was consumed.
@@ -357,7 +364,7 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
                     done = true;
                     break;
                 }
-                buf_push(t1, kind == 2 ? PF_TAG_PATH : PF_TAG_RPATH, to);
+                PF_MP_BUF_PUSH(t1, kind == 2 ? PF_TAG_PATH : PF_TAG_RPATH, to);
                 if (kind == 2) pf = to; else pr = to;
                 tt = t1;
                 inv_f = ml.I2[e * P + pf]; mt_f = ml.MT[e * P + pf]; mt_r = ml.MT[e * P + pr];
@@ -371,10 +378,10 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
             if (cross_ep) {
                 ++e;
                 int q = ml.JM[e * P + pf];
-                if (q != pf) { buf_push(tt, PF_TAG_PATH, q); pf = q; }
+                if (q != pf) { PF_MP_BUF_PUSH(tt, PF_TAG_PATH, q); pf = q; }
                 if (tt >= Hr) {
                     int qr = ml.JM[e * P + pr];
-                    if (qr != pr) { buf_push(tt, PF_TAG_RPATH, qr); pr = qr; }
+                    if (qr != pr) { PF_MP_BUF_PUSH(tt, PF_TAG_RPATH, qr); pr = qr; }
                 }
                 tn_ep = epoch_end(ln, e);
                 inv_f = ml.I2[e * P + pf]; mt_f = ml.MT[e * P + pf]; mt_r = ml.MT[e * P + pr];
@@ -384,9 +391,11 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
         ln.ctr = ctr0 + 2 * (unsigned long long)used;
     }
     if (!done) { ml.err = 3; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
-    flush_buffer();
-    if (pl) { plog_flush_f(*pl, 0, 0); plog_flush_r(*pl, 0, 0); }
+    PF_MP_FLUSH_BUFFER();
+    if (LOG) { plog_flush_f(pl, 0, 0); plog_flush_r(pl, 0, 0); }
 }
+#undef PF_MP_FLUSH_BUFFER
+#undef PF_MP_BUF_PUSH
 
 __device__ __forceinline__ void mp_retag(MLane& ml, int from, int to) {
     for (int m = 0; m < ml.nm; ++m)
@@ -394,18 +403,18 @@ __device__ __forceinline__ void mp_retag(MLane& ml, int from, int to) {
 }
 
 // Forest::buildInitialTree(true) for a structured model.  `emit(i, pstart, npieces, tc)` logs the record of leaf i.
-template <class Emit>
-__device__ __forceinline__ void mp_build_initial_tree(Lane& ln, MLane& ml, PLog* pl, Emit emit) {
+template <bool LOG, class Emit>
+__device__ __forceinline__ void mp_build_initial_tree(Lane& ln, MLane& ml, PLog& pl, Emit emit) {
     const int n = ln.n;
     ml.nm = 0;
     int root = 0;
     for (int i = 1; i < n; ++i) {
         int ni = i - 1;
         MWalk W;
-        unsigned p0 = pl ? pl->idx : 0u;
-        mp_coalesce(ln, ml, ni, root, 0.0, ml.SP[i], pl, ln.E - 1, W);
+        unsigned p0 = LOG ? pl.idx : 0u;
+        mp_coalesce<LOG>(ln, ml, ni, root, 0.0, ml.SP[i], pl, ln.E - 1, W);
         if (ml.err) return;
-        emit(i, p0, pl ? pl->idx - p0 : 0u, W.tc);
+        emit(i, p0, LOG ? pl.idx - p0 : 0u, W.tc);
         double tc = W.tc;
         mp_retag(ml, PF_TAG_RPATH, root);
         // candidates: the lineages of the partial tree in the coalescence population (their populations at tc are
@@ -431,13 +440,14 @@ __device__ __forceinline__ void mp_build_initial_tree(Lane& ln, MLane& ml, PLog*
 }
 
 // the part of a genealogy update after the recombination point (slot (rp,sb), height h) has been sampled
-__device__ __forceinline__ void mp_genealogy_rest(Lane& ln, MLane& ml, PLog* pl, int limit, int rp, int sb, double h,
+template <bool LOG>
+__device__ __forceinline__ void mp_genealogy_rest(Lane& ln, MLane& ml, PLog& pl, int limit, int rp, int sb, double h,
                                                   double* tc_out, double* sp_out, bool* changed_out) {
     const int n = ln.n;
     int b_id = LC(ln, rp, sb), s_id = LC(ln, rp, 1 - sb);
     const int pf0 = mp_pop_at(ln, ml, b_id, h);
     MWalk W;
-    mp_coalesce(ln, ml, n - 1, n + n - 2, h, pf0, pl, limit, W);
+    mp_coalesce<LOG>(ln, ml, n - 1, n + n - 2, h, pf0, pl, limit, W);
     const double tc = W.tc;
     *tc_out = tc;
     const double Sp = LS(ln, rp);

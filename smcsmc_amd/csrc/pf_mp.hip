@@ -96,7 +96,7 @@ __global__ __launch_bounds__(PF_BS) void k_init_mp(KArgs A, double initial_posit
     PLog pl;
     pl.base = A.plog + (size_t)p * A.pcap * 3; pl.cap = A.pcap; pl.idx = 0; pl.pos = 0; pl.on = true; pl.fopen = false; pl.ropen = false;
     // every coalescence of the initial tree is logged as a type-2 record at position 0 (particle.cpp:251-300)
-    mp_build_initial_tree(ln, ml, &pl, [&](int i, unsigned p0, unsigned np_, double tc) {
+    mp_build_initial_tree<true>(ln, ml, pl, [&](int i, unsigned p0, unsigned np_, double tc) {
         double* rec = rec_ptr(A, p, widx);
         rec[0] = 0.0; rec[1] = 0.0; rec[2] = 0.0;
         rec[3] = piece_ref(p0, np_);
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
                 bool changed;
                 sample_point(ln, &rp, &sb, &h);
                 unsigned p0 = pl.idx;
-                mp_genealogy_rest(ln, ml, &pl, limit, rp, sb, h, &tc, &sp_removed, &changed);
+                mp_genealogy_rest<true>(ln, ml, pl, limit, rp, sb, h, &tc, &sp_removed, &changed);
                 rec[2] = h;
                 rec[3] = piece_ref(p0, pl.idx - p0);
                 rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n));
@@ -314,7 +314,9 @@ __global__ __launch_bounds__(PF_BS) void k_calibrate_mp(KArgs A, unsigned long l
     ln.seed = seed;
     ln.stream = 2;
     ln.ebuf = -dlog(uni(ln));
-    mp_build_initial_tree(ln, ml, (PLog*)nullptr, [&](int, unsigned, unsigned, double) {});
+    PLog nolog;
+    nolog.on = false;
+    mp_build_initial_tree<false>(ln, ml, nolog, [&](int, unsigned, unsigned, double) {});
     double* orig = m.t0 + threadIdx.x;
     int alive = n - 1;
     for (int j = 0; j < n - 1; ++j) {
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(PF_BS) void k_calibrate_mp(KArgs A, unsigned long l
         double h, tc, sp;
         bool changed;
         sample_point(ln, &rp, &sb, &h);
-        mp_genealogy_rest(ln, ml, (PLog*)nullptr, -1, rp, sb, h, &tc, &sp, &changed);
+        mp_genealogy_rest<false>(ln, ml, nolog, -1, rp, sb, h, &tc, &sp, &changed);
         if (ml.err) break;
         if (changed) {
             for (int j = 0; j < n - 1; ++j)

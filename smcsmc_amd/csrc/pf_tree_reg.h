@@ -17,11 +17,16 @@ struct RTree {
     double S[NI];
     int C0[NI], C1[NI];
 
+    // Bit-mask select: written as `(r == k) ? S[k] : v` the compiler folds the chain back into a dynamically indexed
+    // load, which puts the whole tree into scratch memory and a scratch round trip into the coalescence walk.
     __device__ __forceinline__ double getS(int r) const {
-        double v = S[0];
+        long long bits = __double_as_longlong(S[0]);
 #pragma unroll
-        for (int k = 1; k < NI; ++k) v = (r == k) ? S[k] : v;
-        return v;
+        for (int k = 1; k < NI; ++k) {
+            const long long m = -(long long)(r == k);
+            bits = (bits & ~m) | (__double_as_longlong(S[k]) & m);
+        }
+        return __longlong_as_double(bits);
     }
     __device__ __forceinline__ void setS(int r, double x) {
 #pragma unroll

@@ -116,7 +116,7 @@ struct KArgs {
     int* lo;                       // [Gcap][Np+1] offspring ranges of resampling event r (between gen r and r+1)
     double* gen_x0;                // [Gcap] position where generation g starts
     int* parent;                   // [Np] parent slot of every new slot at the current resampling event
-    int* blkcnt;                   // [nblocks] survivors per particle workgroup at the current resampling event
+    int* blkcnt2[2];               // [nblocks] survivors per particle workgroup at the resampling event of a step (by step parity)
     // run-length encoded composite ancestor maps: generation g's list maps the slots of the
     // current generation to slots of generation g: run i covers [run_st[i], run_st[i+1]) -> run_anc[i]
     int* run_st;                   // [Gcap][Np]
