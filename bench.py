@@ -235,7 +235,7 @@ def main():
         # HBM traffic of the same kernel from the PMC counters: collected by profiles/collect_round1.sh in separate
         # rocprofv3 passes (counters cannot be read from inside this process) and kept under profiles/
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "round1", "v4_pmc_k_extend.json")
+        pmc_path = os.path.join(ROOT, "profiles", "round1", "v6_pmc_k_row.json")
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
             if pmc["shape"] == {"nsam": args.nsam, "np": args.np, "epochs": args.epochs, "pops": args.pops}:
@@ -252,7 +252,7 @@ def main():
                        "segments_per_chunk": n_segments, "nsam": args.nsam, "np": args.np,
                        "sequence_length": args.length, "epochs": args.epochs,
                        "parallelism": "%d chunk(s) per gpu x %d gpu(s)" % (C, world), "log_likelihood_sum": logl_sum},
-            "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_row (extend workgroups; the counts of the previous row ride along)" if args.pops == 1 and args.nsam <= 8 else "k_extend", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_us": avg_ext_us,
                          "kernel_ms_estimate": {k: v[0] for k, v in kt.items()},

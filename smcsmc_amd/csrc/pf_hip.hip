@@ -2291,12 +2291,14 @@ static int run_single_stream(pf_handle* h, long long s_begin, long long s_end) {
             else if (h->n <= 4) launch_row<4, false>(h, s, fuse, cf, Wprev);
             else if (biased) launch_row<8, true>(h, s, fuse, cf, Wprev);
             else launch_row<8, false>(h, s, fuse, cf, Wprev);
-            if (pending && Wprev.first < h->E) { h->k_launches[2] += 1; h->fin_pending = true; }
+            if (pending && Wprev.first < h->E) h->fin_pending = true;
         }
         if (check_launch("k_row")) return -1;
         {
             Timed tm(h, 1, t);
-            const int lnbt = pending ? h->nblocks + PF_LEDGER_BLOCKS : 0;
+            // decide and ledger workgroups each hold ~120 KB of LDS, one per CU: keep the launch within one wave of 256 CUs
+            const int lroom = 256 - (h->nblocks + 1) - h->nblocks;
+            const int lnbt = pending ? h->nblocks + std::max(16, std::min(PF_LEDGER_BLOCKS, lroom)) : 0;
             hipLaunchKernelGGL(k_decide_ledger, dim3(h->nblocks + 1 + lnbt), dim3(PF_BS), 0, h->stream, h->A, s, 0, h->step_windows,
                                h->nblocks, lnbt);
             h->fin_pending = false;      // the bookkeeping workgroup folds the partials of the counts that rode in k_row
