@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--timing-period", type=int, default=16, help="time every k-th segment's kernels with HIP events")
+    ap.add_argument("--no-local-recomb", action="store_true",
+                    help="do not record the 100-bp local recombination map (the binary always records it, smcsmc.cpp:376-383)")
     ap.add_argument("--chunks-per-gpu", type=int, default=1,
                     help="independent chunks filtered concurrently on each GPU (one host thread + stream each); "
                          "1 = the headline single-chunk configuration")
@@ -155,7 +157,7 @@ def main():
     for k in range(C):
         model, segs = build_workload(args, seed=args.seed + rank * C + k)     # independent chunks
         f = ParticleFilter(model, args.np, ess_fraction=0.5, seed=args.seed + 1000 * (rank * C + k), max_trace_events=0,
-                           device=dev)
+                           device=dev, local_recomb=not args.no_local_recomb)
         f.load_segments(segs)
         chunks.append((f, segs))
     pf, segs = chunks[0]
@@ -248,7 +250,7 @@ def main():
             "config": {"workload": "%d haplotypes, %s%.0f Mb, Np=%d, E=%d epochs, one chunk per GPU"
                                    % (args.nsam, "" if args.pops == 1 else "%d-population isolation-with-migration model, " % args.pops,
                                       args.length / 1e6, args.np, args.epochs),
-                       "populations": args.pops,
+                       "populations": args.pops, "local_recombination_map": not args.no_local_recomb,
                        "segments_per_chunk": n_segments, "nsam": args.nsam, "np": args.np,
                        "sequence_length": args.length, "epochs": args.epochs,
                        "parallelism": "%d chunk(s) per gpu x %d gpu(s)" % (C, world), "log_likelihood_sum": logl_sum},

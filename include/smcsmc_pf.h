@@ -62,7 +62,7 @@ typedef struct pf_params {
     double ess_fraction;         /* -ESS */
     uint64_t seed;               /* -seed */
     int32_t max_trace_events;    /* resampling events whose ancestor arrays are retained for inspection */
-    int32_t reserved;
+    int32_t flags;               /* bit0: record the 100-bp local recombination map (count.cpp:559-654) */
 } pf_params;
 
 typedef struct pf_segments {
@@ -141,6 +141,10 @@ int pf_get_resample_events(pf_handle* h, int32_t* seg_idx, int32_t* parents, int
 /* structured models: the migration events on every particle's local tree ([np*cap], sorted by time; event k sits
  * on the branch above node id branch[k] and moves the lineage to newpop[k]) and the population of every
  * coalescent node ([np*(nsam-1)]); scrm keeps these as migrating unary nodes (Node::is_migrating) */
+/* the local recombination map (CountModel::local_recomb_opportunity / local_recomb_counts, count.hpp:101-102):
+ * opp_diff[nbins] = differential opportunity per 100-bp interval (dump_local_recomb_logs cumulates it, count.cpp:616-654),
+ * counts[(nsam+2)*nbins] = per-sample, time-weighted and log-time-weighted event counts */
+int pf_get_local_recomb(pf_handle* h, double* opp_diff, double* counts, int64_t nbins);
 int pf_get_migrations(pf_handle* h, int32_t* n_events, double* times, int8_t* branch, int8_t* newpop, int8_t* node_pops,
                       int32_t cap);
 int pf_get_particles(pf_handle* h, double* w_post, double* w_pilot, double* heights, int8_t* children,

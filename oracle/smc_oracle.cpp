@@ -177,6 +177,7 @@ struct Ev {
     int8_t pop;         /* coal/migr records: population of the active lineage */
     int8_t mig_to;      /* event == 2: destination population of the migration event */
     double ev_t;        /* recombination event height (coalevent.hpp:170-176) */
+    uint64_t desc;      /* recombination event: samples below the cut branch (descendants.hpp:22-33), bit i = sample i */
 };
 
 struct Pool {
@@ -253,6 +254,11 @@ struct Filter {
     std::vector<double> rec_count, rec_opp, rec_w2, counted_to;
     std::vector<double> mig_count;                       /* [E*P*P] */
     std::vector<double> mig_opp, mig_w2;                 /* [E*P] */
+    /* local recombination map (count.hpp:101-102, 115): differential opportunity and per-sample / time / log-time counts
+     * per 100-bp interval */
+    bool local_map = false;
+    std::vector<double> local_opp;
+    std::vector<std::vector<double>> local_cnt;
     double delayed_opp = 0, delayed_count = 0;
     /* trace */
     std::vector<double> tr_T, tr_ess, tr_logl;
@@ -271,6 +277,7 @@ struct Filter {
     uint32_t stream = 0;          /* Philox stream id: 0 particle filter, 2 lag calibration, 3 branch-length quantiles */
     bool record_events = true;
     double last_sp = 0; bool last_changed = false;
+    uint64_t last_desc = 0;       /* samples below the branch cut by the last genealogy update */
     double last_iw = 1.0, last_tc = 0.0;
     int64_t slot_override = -1;   /* calibration: RNG state lives in rng[0], stream keyed by the replicate index */
     double uni(int64_t slot) {
@@ -364,7 +371,7 @@ struct Filter {
         Ev* e = pool.get();
         e->t0 = t0; e->t1 = t1; e->x0 = x0; e->x1 = x1;
         e->acc = 0; e->arrived = 0; e->refs = 1;
-        e->weight = (int16_t)weight; e->kind = (int8_t)kind; e->event = 0; e->dead = 0; e->ev_t = -1; e->pop = 0; e->mig_to = 0;
+        e->weight = (int16_t)weight; e->kind = (int8_t)kind; e->event = 0; e->dead = 0; e->ev_t = -1; e->pop = 0; e->mig_to = 0; e->desc = 0;
         e->parent = p.head[epoch];      /* add_leaf_to_tree: coalevent.hpp:288-303 (takes over the head's reference) */
         p.head[epoch] = e;
         return e;
@@ -877,6 +884,12 @@ struct Filter {
         int rp = 0, sb = 0;
         lineages_at(t, n - 1, h, lin, &rp, &sb);   /* branch b = slot (rp,sb); its parent p has rank rp */
         *h_out = h;
+        {   /* get_descendants (descendants.hpp:22-33) of the cut branch, on the tree before it changes */
+            uint64_t below[2 * NMAX];
+            for (int i = 0; i < n; ++i) below[i] = 1ull << i;
+            for (int r = 0; r < n - 1; ++r) below[n + r] = below[t.C[r][0]] | below[t.C[r][1]];
+            last_desc = below[t.C[rp][sb]];
+        }
         if (M.P > 1) { mp_genealogy_rest(slot, p, x, limit, rp, sb, h); return; }
         /* --- coalesce upwards against the full old tree (SMC': the cut branch's stub is a target) --- */
         double Sold[NMAX - 1];
@@ -938,7 +951,7 @@ struct Filter {
         if (!(M.recflags[e] & REC_RECOMB)) return;
         for (Ev* ev = p.head[e]; ev; ev = ev->parent) {
             if (ev->kind == 0 && ev->t0 <= h && h <= ev->t1) {
-                if (ev->x0 == p.x_mark && !ev->event) { ev->event = 1; ev->ev_t = h; }
+                if (ev->x0 == p.x_mark && !ev->event) { ev->event = 1; ev->ev_t = h; ev->desc = last_desc; }
                 return;
             }
         }
@@ -1126,6 +1139,11 @@ struct Filter {
         const int P = M.P;
         coal_count.assign(E * P, 0); coal_opp.assign(E * P, 0); coal_w2.assign(E * P, 0);
         mig_count.assign(E * P * P, 0); mig_opp.assign(E * P, 0); mig_w2.assign(E * P, 0);
+        if (local_map) {
+            size_t nb = (size_t)(M.L / 100.0) + 4;
+            local_opp.assign(nb, 0.0);
+            local_cnt.assign(M.n + 2, std::vector<double>(nb, 0.0));
+        }
         rec_count.assign(E, 0); rec_opp.assign(E, 0); rec_w2.assign(E, 0);
         counted_to.assign(E, 0);
     }
@@ -1330,6 +1348,47 @@ struct Filter {
             }
             rec_opp[e] += w * opp;
             rec_w2[e] += w * w * opp;
+            if (local_map) {                              /* count.cpp:540-551 */
+                double local_x_start = std::max(x_start, ev->x0);
+                double local_x_end = std::min(x_end, ev->x1);
+                if (local_x_start < local_x_end) {
+                    double event_base = ev->event ? ev->x0 : -1.0;       /* recomb_event_base, coalevent.hpp:236-241 */
+                    double event_time = -1;
+                    uint64_t d = 0;
+                    if (x_start <= event_base && event_base <= x_end) { event_time = ev->ev_t; d = ev->desc; }
+                    record_local(local_x_start, local_x_end, w, opp, event_base, event_time, d);
+                }
+            }
+        }
+    }
+
+    /* record_local_recomb_events (count.cpp:559-613) */
+    void record_local(double x_start, double x_end, double weight, double opportunity, double event_base, double event_time,
+                      uint64_t descendants) {
+        const double iv = 100.0;
+        size_t first_index = (size_t)(x_start / iv);
+        size_t last_index = (size_t)(1 + x_end / iv);
+        double first_interval = std::min((first_index + 1) * iv, x_end) - x_start;
+        double last_interval = x_end - std::max((last_index - 1) * iv, x_start);
+        double opp_density = weight * opportunity / (x_end - x_start);
+        if (last_index >= local_opp.size()) throw std::logic_error("local recombination map too small");
+        if (first_index == last_index - 1) {
+            local_opp[first_index] += first_interval * opp_density;
+            local_opp[first_index + 1] -= first_interval * opp_density;
+        } else {
+            local_opp[first_index] += first_interval * opp_density;
+            local_opp[first_index + 1] += (iv - first_interval) * opp_density;
+            local_opp[last_index - 1] += (last_interval - iv) * opp_density;
+            local_opp[last_index] -= last_interval * opp_density;
+        }
+        if (x_start <= event_base && event_base <= x_end) {
+            int nd = 0;
+            for (int i = 0; i < M.n; ++i) nd += (int)((descendants >> i) & 1);
+            size_t index = (size_t)(event_base / iv);
+            for (int i = 0; i < M.n; ++i)
+                if ((descendants >> i) & 1) local_cnt[i][index] += weight / nd;
+            local_cnt[M.n][index] += weight * event_time;
+            local_cnt[M.n + 1][index] += weight * smc_log(event_time + 1.0);
         }
     }
 
@@ -1754,6 +1813,20 @@ int smco_get_counts(void* h, double* out, int32_t n) {
     }
     o[0] = f->delayed_opp; o[1] = f->delayed_count;
     o[2] = (double)f->n_resample; o[3] = f->logl;
+    return 0;
+}
+
+int smco_enable_local_recomb(void* h) { ((Filter*)h)->local_map = true; return 0; }
+
+/* opp_diff[nbins], counts[(nsam+2)*nbins] */
+int smco_get_local_recomb(void* h, double* opp_diff, double* counts, int64_t nbins) {
+    Filter* f = (Filter*)h;
+    if (!f->local_map) return -1;
+    for (int64_t b = 0; b < nbins; ++b) {
+        opp_diff[b] = b < (int64_t)f->local_opp.size() ? f->local_opp[b] : 0.0;
+        for (int k = 0; k < f->M.n + 2; ++k)
+            counts[(int64_t)k * nbins + b] = b < (int64_t)f->local_cnt[k].size() ? f->local_cnt[k][b] : 0.0;
+    }
     return 0;
 }
 

@@ -119,6 +119,10 @@ int smco_get_resample_events(void* h, int32_t* seg_idx, int32_t* parents, int32_
 int smco_get_particles(void* h, double* w_post, double* w_pilot, double* heights, int8_t* children,
                        double* next_base);
 int smco_get_counts(void* h, double* packed, int32_t n);
+/* 100-bp local recombination map (count.cpp:559-654): call enable before init_prior; opp_diff[nbins] is the
+ * differential opportunity of count.hpp:101, counts[(nsam+2)*nbins] the per-sample, time and log-time weighted counts */
+int smco_enable_local_recomb(void* h);
+int smco_get_local_recomb(void* h, double* opp_diff, double* counts, int64_t nbins);
 /* structured models: migration events kept on each particle's local tree ([np*cap], sorted by time) and the
  * population of every coalescent node ([np*(nsam-1)]) */
 int smco_get_migrations(void* h, int32_t* n_events, double* times, int8_t* branch, int8_t* newpop, int8_t* node_pops,

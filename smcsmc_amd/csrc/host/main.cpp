@@ -172,6 +172,7 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
     memset(&pp, 0, sizeof(pp));
     pp.np = (int64_t)P.N; pp.ess_fraction = P.ESS_fraction; pp.seed = M.seed_set ? M.seed : (uint64_t)time(nullptr);
     pp.max_trace_events = 0;
+    pp.flags = 1;          // the local recombination map is always recorded (smcsmc.cpp:376-383)
     pf_handle* h = pf_create(&pm, &pp, device);
     if (!h) throw std::runtime_error(pf_last_error());
     try {
@@ -215,9 +216,11 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
             for (int64_t s = 0; s < done; ++s)
                 if (flag[s]) P.append_resample_file(std::min(start[s] + length[s], M.loci_length), ess[s]);
         }
-        // <prefix>.recomb.gz (smcsmc.cpp:376-383, count.cpp:616-654): the 100-bp local recombination map is not
-        // recorded by this build; an empty table with the reference's header keeps the file contract.
+        // <prefix>.recomb.gz (smcsmc.cpp:376-383): CountModel::dump_local_recomb_logs (count.cpp:616-654)
         {
+            const int64_t nb = (int64_t)(M.loci_length / 100.0);
+            std::vector<double> lopp(nb), lcnt((size_t)(M.nsam + 2) * nb);
+            pf_check(pf_get_local_recomb(h, lopp.data(), lcnt.data(), nb));
             gzFile gz = gzopen(P.recombination_map_NAME.c_str(), "ab");
             if (gz) {
                 std::ostringstream o;
@@ -225,6 +228,15 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
                     o << "iter\tlocus\tsize\topp_per_nt";
                     for (int s = 0; s < M.nsam; ++s) o << "\t" << s + 1;
                     o << "\ttime\tlog_time\n";
+                }
+                double current_opportunity = 0.0;
+                for (int64_t idx = 0; idx < nb; ++idx) {
+                    current_opportunity += lopp[idx];
+                    o << P.EMcounter << "\t" << fixed << setprecision(0) << idx * 100.0 + P.start_position << "\t" << 100.0 << "\t"
+                      << scientific << setprecision(5) << current_opportunity / 100.0;
+                    for (int k = 0; k < M.nsam + 2; ++k) o << "\t" << lcnt[(size_t)k * nb + idx] / 100.0;
+                    o << "\n";
+                    if (o.tellp() > (1 << 20)) { gzwrite(gz, o.str().data(), (unsigned)o.str().size()); o.str(""); }
                 }
                 gzwrite(gz, o.str().data(), (unsigned)o.str().size());
                 gzclose(gz);

@@ -165,10 +165,11 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
                 for (int r = 0; r < n - 1; ++r) rec[5 + r] = LS(ln, r);
                 double h, tc, sp_removed;
                 bool changed;
-                genealogy_update(ln, &h, &tc, &sp_removed, &changed);
+                unsigned desc = 0;
+                genealogy_update(ln, &h, &tc, &sp_removed, &changed, A.lmap_opp ? &desc : nullptr, tmp0);
                 rec[2] = h;
                 rec[3] = tc;
-                rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n));
+                rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n, desc));
                 ++widx;
                 if (leaf_status == 0) B = tracked_len_lane(ln, data, tmp0);
                 if (leaf_status == 1) B = ln.Ltree;
@@ -344,6 +345,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
         cx.T = sT; cx.I = sI; cx.E = A.E; cx.n = n; cx.L = A.L; cx.mu = A.mu; cx.rho = A.rho;
         cx.seed = A.seed; cx.slot = (unsigned)p; cx.stream = 0;
         cx.nb = A.n_bias + 1; cx.bH = sBH; cx.bS = sBS; cx.last_iw = 1.0;
+        cx.want_desc = A.lmap_opp != nullptr; cx.last_desc = 0;
         DStore ds;
         if (BIASED) {
             ds.pos = st.dpos + p; ds.fac = st.dfac + p; ds.delta = st.ddelta + p; ds.k = st.dk + p; ds.Np = A.Np;
@@ -441,7 +443,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
                 r_genealogy_update<NM, BIASED>(cx, t, &h, &tc);
                 rec[2] = h;
                 rec[3] = tc;
-                rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n));
+                rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n, cx.last_desc));
                 ++widx;
                 if (leaf_status == 0) B = r_tracked_len(t, n, present_mask);
                 if (leaf_status == 1) B = cx.Ltree;
@@ -869,9 +871,56 @@ __device__ __forceinline__ double slice_len(const double (&S)[NI], int nint, int
 
 struct Win { int e, rf; double T0, T1, a_e, b_e; bool end_seq; };
 
+// local recombination map (record_local_recomb_events, count.cpp:559-613): per workgroup the differential
+// opportunity of its window is collected in LDS bins and flushed with one global atomic per touched bin
+#define PF_LBINS 2048
+struct LMap {
+    double* lds;          // [PF_LBINS] bins of this workgroup, bin 0 = interval b0
+    long long b0;
+    double* gopp;         // global differential opportunity (null: map not recorded)
+    double* gcnt;         // global counts [(n+2)][nbins]
+    long long nbins;
+};
+__device__ __forceinline__ void lmap_add(const LMap& L, long long idx, double v) {
+    if (idx < 0 || idx >= L.nbins) return;
+    long long k = idx - L.b0;
+    if (k >= 0 && k < PF_LBINS) atomicAdd(&L.lds[k], v);
+    else atomicAdd(&L.gopp[idx], v);
+}
+// constant opportunity density over [x_lo, x_hi): the differential encoding of count.cpp:578-588
+__device__ __forceinline__ void lmap_opportunity(const LMap& L, double x_lo, double x_hi, double weight, double opp) {
+    const double iv = 100.0;
+    long long first = (long long)(x_lo / iv);
+    long long last = (long long)(1 + x_hi / iv);
+    double top = (double)(first + 1) * iv;
+    double first_interval = (top < x_hi ? top : x_hi) - x_lo;
+    double bot = (double)(last - 1) * iv;
+    double last_interval = x_hi - (bot > x_lo ? bot : x_lo);
+    double dens = weight * opp / (x_hi - x_lo);
+    if (first == last - 1) {
+        lmap_add(L, first, first_interval * dens);
+        lmap_add(L, first + 1, -(first_interval * dens));
+    } else {
+        lmap_add(L, first, first_interval * dens);
+        lmap_add(L, first + 1, (iv - first_interval) * dens);
+        lmap_add(L, last - 1, (last_interval - iv) * dens);
+        lmap_add(L, last, -(last_interval * dens));
+    }
+}
+// a recombination event at event_base, height h, below which the samples `desc` hang (count.cpp:590-612)
+__device__ __forceinline__ void lmap_event(const LMap& L, int n, double event_base, double h, unsigned desc, double weight) {
+    long long idx = (long long)(event_base / 100.0);
+    if (idx < 0 || idx >= L.nbins) return;
+    const int nd = __popc(desc);
+    for (int i = 0; i < n; ++i)
+        if ((desc >> i) & 1u) atomicAdd(&L.gcnt[(size_t)i * L.nbins + idx], weight / nd);
+    atomicAdd(&L.gcnt[(size_t)n * L.nbins + idx], weight * h);
+    atomicAdd(&L.gcnt[(size_t)(n + 1) * L.nbins + idx], weight * dlog(h + 1.0));
+}
+
 template <int NI, int P>
-__device__ __forceinline__ void stretch_contrib(AccT<P>& acc, const KArgs& A, const Win& W, double w, double x0, double x1,
-                                                const double (&S)[NI], int lim_start) {
+__device__ __forceinline__ void stretch_contrib(AccT<P>& acc, const KArgs& A, const Win& W, const LMap& L, double w, double x0,
+                                                double x1, const double (&S)[NI], int lim_start) {
     if (!(W.rf & REC_RECOMB) || W.e > lim_start) return;
     double xs = ovl(x0, x1, W.a_e, W.b_e);
     if (!(xs > 0.0)) return;
@@ -879,13 +928,14 @@ __device__ __forceinline__ void stretch_contrib(AccT<P>& acc, const KArgs& A, co
     double opp = len * xs;
     acc.v[AccT<P>::RO] += w * opp;
     acc.v[AccT<P>::RW] += w * w * opp;
+    if (L.gopp) lmap_opportunity(L, x0 > W.a_e ? x0 : W.a_e, x1 < W.b_e ? x1 : W.b_e, w, opp);
 }
 
 // All fields of a record are fetched in one round of independent loads before anything is tested:
 // the kernel is bound by dependent-load latency, not by bytes.
 template <int NI, int P>
-__device__ __forceinline__ void records_contrib(AccT<P>& acc, const KArgs& A, const Win& W, double w, long long a, unsigned k0,
-                                                unsigned k1) {
+__device__ __forceinline__ void records_contrib(AccT<P>& acc, const KArgs& A, const Win& W, const LMap& L, double w, long long a,
+                                                unsigned k0, unsigned k1) {
     using AC = AccT<P>;
     const int n = A.n;
     for (unsigned k = k0; k != k1; ++k) {
@@ -901,7 +951,7 @@ __device__ __forceinline__ void records_contrib(AccT<P>& acc, const KArgs& A, co
         int lim_start = (int)((meta >> 8) & 0xff) - 1;
         int lim_event = (int)((meta >> 16) & 0xff) - 1;
         int n_eff = (int)((meta >> 24) & 0xff);
-        if (type <= 1) stretch_contrib<NI, P>(acc, A, W, w, x0, x1, S, lim_start);
+        if (type <= 1) stretch_contrib<NI, P>(acc, A, W, L, w, x0, x1, S, lim_start);
         if (type == 0 || type == 2) {
             double h = f2;
             bool inwin = (W.a_e <= x1) && (x1 < W.b_e);
@@ -946,7 +996,10 @@ __device__ __forceinline__ void records_contrib(AccT<P>& acc, const KArgs& A, co
             }
             if (type == 0) {
                 bool inwin_r = (W.a_e <= x1) && ((x1 < W.b_e) || W.end_seq);
-                if (inwin_r && (W.rf & REC_RECOMB) && W.e <= lim_event && W.T0 <= h && h < W.T1) acc.v[AC::RC] += w;
+                if (inwin_r && (W.rf & REC_RECOMB) && W.e <= lim_event && W.T0 <= h && h < W.T1) {
+                    acc.v[AC::RC] += w;
+                    if (L.gopp) lmap_event(L, n, x1, h, (unsigned)((meta >> 32) & 0xffff), w);
+                }
             }
         }
     }
@@ -956,8 +1009,8 @@ __device__ __forceinline__ void records_contrib(AccT<P>& acc, const KArgs& A, co
 #define PF_CNT_WIDE 128       // run lists longer than this are strided over by the whole grid column
 
 template <int NI, int P>
-__device__ __forceinline__ void count_run(AccT<P>& acc, const KArgs& A, int sp, const Win& W, int g, long long i, int nr,
-                                          const int* rst, const int* ran, double inv) {
+__device__ __forceinline__ void count_run(AccT<P>& acc, const KArgs& A, int sp, const Win& W, const LMap& L, int g, long long i,
+                                          int nr, const int* rst, const int* ran, double inv) {
     const long long Np = A.Np;
     int q0 = rst[i];
     int q1 = i + 1 < nr ? rst[i + 1] : (int)Np;
@@ -972,7 +1025,7 @@ __device__ __forceinline__ void count_run(AccT<P>& acc, const KArgs& A, int sp, 
     unsigned k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
     unsigned k1 = A.gstart[(size_t)((g + 1) % A.Gcap) * Np + a];
     if (A.widx[a] - k0 > A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;
-    records_contrib<NI, P>(acc, A, W, w, a, k0, k1);
+    records_contrib<NI, P>(acc, A, W, L, w, a, k0, k1);
 }
 
 // The body of k_count for the workgroup (bx, by) of a column of nbxg workgroups; `sp` = parity of the step whose
@@ -997,6 +1050,13 @@ __device__ __forceinline__ void count_body(const KArgs& A, int sp, int e0, const
     W.T0 = A.T[e]; W.T1 = e + 1 < A.E ? A.T[e + 1] : PF_INF;
     W.a_e = Wn.a[e]; W.b_e = Wn.b[e];
     W.end_seq = (A.L == W.b_e);
+    __shared__ double s_lbins[PF_LBINS];
+    LMap L;
+    L.lds = s_lbins; L.b0 = (long long)(W.a_e / 100.0); L.gopp = A.lmap_opp; L.gcnt = A.lmap_cnt; L.nbins = A.lmap_bins;
+    if (L.gopp) {
+        for (int k = threadIdx.x; k < PF_LBINS; k += PF_BS) s_lbins[k] = 0.0;
+        __syncthreads();
+    }
     const int g_lo = c->g_lo[e], g_hi = c->g_hi[e];
     const int lane = threadIdx.x & 63;
     const long long gtid = (long long)bx * PF_BS + threadIdx.x;
@@ -1069,18 +1129,26 @@ __device__ __forceinline__ void count_body(const KArgs& A, int sp, int e0, const
                 unsigned k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
                 unsigned k1 = A.snap_widx[sp][a];
                 if (w == 0.0) continue;
-                stretch_contrib<NI, P>(acc, A, W, w, xm, PF_INF, S, ml);
+                stretch_contrib<NI, P>(acc, A, W, L, w, xm, PF_INF, S, ml);
                 if (k1 - k0 > A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;
-                records_contrib<NI, P>(acc, A, W, w, a, k0, k1);
+                records_contrib<NI, P>(acc, A, W, L, w, a, k0, k1);
             } else {
                 const int nr = s_off[lo_i + 1] - s_off[lo_i];
                 const int* rst = A.run_st + (size_t)(g % A.Gcap) * Np;
                 const int* ran = A.run_anc + (size_t)(g % A.Gcap) * Np;
-                count_run<NI, P>(acc, A, sp, W, g, i, nr, rst, ran, inv);
+                count_run<NI, P>(acc, A, sp, W, L, g, i, nr, rst, ran, inv);
             }
         }
     }
     // deterministic workgroup reduction: butterfly per wavefront, then wavefronts in order
+    if (L.gopp) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < PF_LBINS; k += PF_BS) {
+            double v = s_lbins[k];
+            long long idx = L.b0 + k;
+            if (v != 0.0 && idx < L.nbins) atomicAdd(&L.gopp[idx], v);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < AC::NC; ++k) acc.v[k] = wave_tree_sum(acc.v[k]);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -1916,6 +1984,12 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
             rc |= dalloc(h, &A.st[b].dk, (size_t)PF_DCAP * Np);
         }
     }
+    if (p->flags & 1) {
+        // 100-bp local recombination map (count.hpp:101-102, 115)
+        A.lmap_bins = (long long)(m->loci_length / 100.0) + 4;
+        rc |= dalloc(h, &A.lmap_opp, (size_t)A.lmap_bins);
+        rc |= dalloc(h, &A.lmap_cnt, (size_t)(n + 2) * A.lmap_bins);
+    }
     rc |= dalloc(h, &A.rng_ctr, Np);
     rc |= dalloc(h, &A.ebuf, Np);
     rc |= dalloc(h, &A.widx, Np);
@@ -2060,6 +2134,10 @@ int pf_init_prior(pf_handle* h, double initial_position) {
     else
         hipLaunchKernelGGL(k_init, dim3(h->nblocks), dim3(PF_BS), h->smem, h->stream, h->A, initial_position);
     if (check_launch("k_init")) return -1;
+    if (h->A.lmap_opp) {
+        HIPCHK(hipMemsetAsync(h->A.lmap_opp, 0, (size_t)h->A.lmap_bins * 8, h->stream));
+        HIPCHK(hipMemsetAsync(h->A.lmap_cnt, 0, (size_t)(h->n + 2) * h->A.lmap_bins * 8, h->stream));
+    }
     std::fill(h->h_counted_to.begin(), h->h_counted_to.end(), 0.0);
     h->fin_pending = false;
     h->ev_dec = nullptr; h->ev_cnt = nullptr;
@@ -2410,6 +2488,20 @@ int pf_get_counts(pf_handle* h, double* out, int32_t n) {
     tail[1] = c.delayed_count;
     tail[2] = (double)c.n_resample;
     tail[3] = c.logl;
+    return 0;
+}
+
+int pf_get_local_recomb(pf_handle* h, double* opp_diff, double* counts, int64_t nbins) {
+    if (pf_sync(h)) return -1;
+    if (!h->A.lmap_opp) { g_err = "pf_get_local_recomb: the map was not recorded (pf_params.flags bit 0)"; return -1; }
+    const long long nb = h->A.lmap_bins;
+    std::vector<double> o(nb), c((size_t)(h->n + 2) * nb);
+    HIPCHK(hipMemcpy(o.data(), h->A.lmap_opp, o.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(c.data(), h->A.lmap_cnt, c.size() * 8, hipMemcpyDeviceToHost));
+    for (long long b = 0; b < nbins; ++b) {
+        opp_diff[b] = b < nb ? o[b] : 0.0;
+        for (int k = 0; k < h->n + 2; ++k) counts[(size_t)k * nbins + b] = b < nb ? c[(size_t)k * nb + b] : 0.0;
+    }
     return 0;
 }
 

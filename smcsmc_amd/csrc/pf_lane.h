@@ -74,11 +74,28 @@ __device__ __forceinline__ void sample_point(Lane& ln, int* rp_out, int* sb_out,
     *h_out = h;
 }
 
-__device__ __forceinline__ void genealogy_update(Lane& ln, double* h_out, double* tc_out, double* sp_out, bool* changed_out) {
+// get_descendants (descendants.hpp:22-33): samples below node `id`; `tmp` = per-lane LDS scratch of n-1 doubles
+__device__ __forceinline__ unsigned lane_desc_mask(const Lane& ln, int id, double* tmp) {
+    const int n = ln.n;
+    if (id < n) return 1u << id;
+    unsigned res = 0;
+    for (int r = 0; r <= id - n; ++r) {
+        int c0 = LC(ln, r, 0), c1 = LC(ln, r, 1);
+        unsigned m0 = c0 < n ? (1u << c0) : (unsigned)__double_as_longlong(tmp[(c0 - n) * PF_BS]);
+        unsigned m1 = c1 < n ? (1u << c1) : (unsigned)__double_as_longlong(tmp[(c1 - n) * PF_BS]);
+        res = m0 | m1;
+        tmp[r * PF_BS] = __longlong_as_double((long long)res);
+    }
+    return res;
+}
+
+__device__ __forceinline__ void genealogy_update(Lane& ln, double* h_out, double* tc_out, double* sp_out, bool* changed_out,
+                                                 unsigned* desc_out = nullptr, double* tmp = nullptr) {
     const int n = ln.n;
     int rp = 0, sb = 0;
     double h;
     sample_point(ln, &rp, &sb, &h);
+    if (desc_out) *desc_out = lane_desc_mask(ln, LC(ln, rp, sb), tmp);
     *h_out = h;
     double tc = coalesce_up(ln, [&](int k) { return LS(ln, k); }, n - 1, n, h);
     *tc_out = tc;

@@ -203,11 +203,12 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
                 double h, tc, sp_removed;
                 bool changed;
                 sample_point(ln, &rp, &sb, &h);
+                const unsigned desc = A.lmap_opp ? lane_desc_mask(ln, LC(ln, rp, sb), tmp0) : 0u;
                 unsigned p0 = pl.idx;
                 mp_genealogy_rest<true>(ln, ml, pl, limit, rp, sb, h, &tc, &sp_removed, &changed);
                 rec[2] = h;
                 rec[3] = piece_ref(p0, pl.idx - p0);
-                rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n));
+                rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n, desc));
                 ++widx;
                 if (ml.err) break;
                 if (leaf_status == 0) B = tracked_len_lane(ln, data, tmp0);

@@ -63,6 +63,8 @@ struct RCtx {
     const double* bH;
     const double* bS;
     double last_iw;
+    unsigned last_desc;   // samples below the branch cut by the last update (only computed when want_desc)
+    bool want_desc;
 };
 
 __device__ __forceinline__ double r_uni(RCtx& cx) { return philox_uniform(cx.seed, cx.slot, cx.stream, cx.ctr++); }
@@ -339,6 +341,25 @@ __device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, doubl
     int rp = 0, sb = 0;
     r_lineages_at(t, n, n - 1, h, lin, &rp, &sb);
     *h_out = h;
+    if (cx.want_desc) {
+        // get_descendants (descendants.hpp:22-33) of the cut branch on the tree before it changes: masks bottom-up
+        unsigned below[RTree<NM>::NI];
+        unsigned cut = 0;
+#pragma unroll
+        for (int r = 0; r < RTree<NM>::NI; ++r) {
+            below[r] = 0;
+            if (r < n - 1) {
+                const int c0 = t.C0[r], c1 = t.C1[r];
+                unsigned m0 = c0 < n ? (1u << c0) : 0u, m1 = c1 < n ? (1u << c1) : 0u;
+#pragma unroll
+                for (int k = 0; k < RTree<NM>::NI; ++k)
+                    if (k < r) { m0 = (c0 - n == k) ? below[k] : m0; m1 = (c1 - n == k) ? below[k] : m1; }
+                below[r] = m0 | m1;
+                if (r == rp) cut = sb ? m1 : m0;
+            }
+        }
+        cx.last_desc = cut;
+    }
     double tc = r_coalesce_up(cx, t, n - 1, n, h);
     *tc_out = tc;
     double Sp = t.getS(rp);

@@ -90,6 +90,11 @@ struct KArgs {
     const double* la_ddist; const double* la_split; const int8_t* la_salleles; const int* la_sk;
     const double* la_q; const double* la_tbl;
     double la_mean_tbl;
+    // local recombination map (count.cpp:559-654): differential opportunity [lmap_bins] and per-sample / time /
+    // log-time weighted counts [(n+2)][lmap_bins] per 100-bp interval; null when not recorded
+    double* lmap_opp;
+    double* lmap_cnt;
+    long long lmap_bins;
     // run parameters
     long long Np;
     double ess_threshold;
@@ -176,9 +181,12 @@ struct Windows {
 enum { ERR_LOG_OVERFLOW = 1, ERR_GEN_OVERFLOW = 2, ERR_ZERO_PROB = 3, ERR_COUNT_MISMATCH = 4, ERR_MIG_OVERFLOW = 5,
        ERR_MP_INTERNAL = 6, ERR_NO_COALESCENCE = 7 };
 
-__device__ __forceinline__ unsigned long long make_meta(int type, int lim_start, int lim_event, int n_eff) {
+// record meta word: type | lim_start+1 << 8 | lim_event+1 << 16 | n_eff << 24 | descendants << 32 (samples below the
+// branch cut by the recombination that ends the stretch, bit i = sample i; descendants.hpp:22-33)
+__device__ __forceinline__ unsigned long long make_meta(int type, int lim_start, int lim_event, int n_eff, unsigned desc = 0) {
     return (unsigned long long)(type & 0xff) | ((unsigned long long)((lim_start + 1) & 0xff) << 8) |
-           ((unsigned long long)((lim_event + 1) & 0xff) << 16) | ((unsigned long long)(n_eff & 0xff) << 24);
+           ((unsigned long long)((lim_event + 1) & 0xff) << 16) | ((unsigned long long)(n_eff & 0xff) << 24) |
+           ((unsigned long long)(desc & 0xffff) << 32);
 }
 
 __device__ __forceinline__ double* rec_ptr(const KArgs& A, long long p, unsigned k) {

@@ -66,6 +66,27 @@ def outfile_text(model, counts, np_particles, em_step=0):
     return "".join(out)
 
 
+def _cxx_scientific(v, prec=5):
+    """operator<< with std::scientific << setprecision(prec): at least two exponent digits"""
+    return "%.*e" % (prec, v)
+
+
+def recomb_text(local, nsam, iteration=0, start_position=1.0):
+    """The `.recomb.gz` table of CountModel::dump_local_recomb_logs (count.cpp:616-654): one row per 100-bp interval,
+    `iter locus size opp_per_nt <per-sample counts> time log_time`, the differential opportunity cumulated on the fly."""
+    out = []
+    if iteration == 0:
+        out.append("iter\tlocus\tsize\topp_per_nt" + "".join("\t%d" % (k + 1) for k in range(nsam)) + "\ttime\tlog_time\n")
+    cur = 0.0
+    opp, cnt = local["opp_diff"], local["counts"]
+    for idx in range(len(opp)):
+        cur += opp[idx]
+        row = ["%d" % iteration, "%.0f" % (idx * 100.0 + start_position), "%.0f" % 100.0, _cxx_scientific(cur / 100.0)]
+        row += [_cxx_scientific(cnt[k][idx] / 100.0) for k in range(nsam + 2)]
+        out.append("\t".join(row) + "\n")
+    return "".join(out)
+
+
 def parse_outfile(path_or_text, is_text=False):
     """Same reduction keys and the same Wt reconstruction as model.py:865-911."""
     text = path_or_text if is_text else open(path_or_text).read()

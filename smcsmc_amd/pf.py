@@ -43,7 +43,7 @@ class _Model(C.Structure):
 
 class _Params(C.Structure):
     _fields_ = [("np", C.c_int64), ("ess_fraction", C.c_double), ("seed", C.c_uint64),
-                ("max_trace_events", C.c_int32), ("reserved", C.c_int32)]
+                ("max_trace_events", C.c_int32), ("flags", C.c_int32)]
 
 
 class _Segments(C.Structure):
@@ -85,7 +85,7 @@ EXPORTS = [
     "pf_terminal_branch_quantiles",
     "pf_update_segment", "pf_count", "pf_resample", "pf_run", "pf_finish", "pf_sync",
     "pf_num_segments_done", "pf_logl", "pf_get_counts", "pf_get_trace", "pf_get_resample_events",
-    "pf_get_particles", "pf_get_migrations", "pf_get_kernel_time", "pf_set_timing", "pf_get_stats",
+    "pf_get_particles", "pf_get_migrations", "pf_get_local_recomb", "pf_get_kernel_time", "pf_set_timing", "pf_get_stats",
     "pf_median_survival", "pf_test_math", "pf_test_div", "pf_test_uniform", "pf_test_reduce", "pf_test_systematic",
 ]
 
@@ -125,6 +125,7 @@ def load_library(path=None):
     L.pf_get_resample_events.argtypes = [vp, vp, vp, C.c_int32]
     L.pf_get_particles.argtypes = [vp, vp, vp, vp, vp, vp]
     L.pf_get_migrations.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int32]
+    L.pf_get_local_recomb.argtypes = [vp, vp, vp, C.c_int64]
     L.pf_get_kernel_time.argtypes = [vp, C.c_int, vp, vp]
     L.pf_set_timing.argtypes = [vp, C.c_int]
     L.pf_get_stats.argtypes = [vp, vp, vp, vp]
@@ -213,7 +214,7 @@ KERNEL_CLASSES = ("extend", "decide", "count", "resample")
 
 
 class ParticleFilter:
-    def __init__(self, model, np_particles, ess_fraction=0.5, seed=1, max_trace_events=64, device=0):
+    def __init__(self, model, np_particles, ess_fraction=0.5, seed=1, max_trace_events=64, device=0, local_recomb=False):
         self.L = load_library()
         m = model
         self._ct = np.ascontiguousarray(m["change_times"], dtype=np.float64)
@@ -230,7 +231,8 @@ class ParticleFilter:
                              self._rf.ctypes.data_as(C.POINTER(C.c_int32)), _dp(self._lags))
         _attach_bias(self, self._model, m)
         _attach_structure(self, self._model, m, E, P)
-        self._params = _Params(self.Np, float(ess_fraction), int(seed), self.max_trace_events, 0)
+        self.loci_length = float(m["loci_length"])
+        self._params = _Params(self.Np, float(ess_fraction), int(seed), self.max_trace_events, 1 if local_recomb else 0)
         self.h = self.L.pf_create(C.byref(self._model), C.byref(self._params), int(device))
         if not self.h:
             raise PfError(_err(self.L))
@@ -324,6 +326,14 @@ class ParticleFilter:
         out = np.zeros(counts_len(self.E, self.P))
         self._chk(self.L.pf_get_counts(self.h, out.ctypes.data, len(out)))
         return unpack_counts(out, self.E, self.P)
+
+    def local_recomb(self):
+        """The 100-bp local recombination map: differential opportunity [nbins], counts [nsam+2][nbins]
+        (per sample, time-weighted, log-time-weighted); nbins = loci_length / 100 as dump_local_recomb_logs writes."""
+        nb = int(self.loci_length / 100.0)
+        opp = np.zeros(nb); cnt = np.zeros((self.nsam + 2, nb))
+        self._chk(self.L.pf_get_local_recomb(self.h, opp.ctypes.data, cnt.ctypes.data, nb))
+        return {"opp_diff": opp, "counts": cnt}
 
     def migrations(self, cap=96):
         """Migration events on every particle's local tree and the population of every coalescent node."""

@@ -69,6 +69,8 @@ def lib():
         L.smco_get_particles.argtypes = [C.c_void_p] + [C.c_void_p] * 5
         L.smco_get_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.smco_get_migrations.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int32]
+        L.smco_enable_local_recomb.argtypes = [C.c_void_p]
+        L.smco_get_local_recomb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.smco_logl.restype = C.c_double
         L.smco_logl.argtypes = [C.c_void_p]
         L.smco_get_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -230,6 +232,15 @@ class Oracle:
         out = np.zeros(counts_len(E, P))
         self._chk(self.L.smco_get_counts(self.h, out.ctypes.data, len(out)))
         return unpack_counts(out, E, P)
+
+    def enable_local_recomb(self):
+        self.L.smco_enable_local_recomb(self.h)
+
+    def local_recomb(self, loci_length):
+        nb = int(loci_length / 100.0)
+        opp = np.zeros(nb); cnt = np.zeros((self.inp.nsam + 2, nb))
+        self._chk(self.L.smco_get_local_recomb(self.h, opp.ctypes.data, cnt.ctypes.data, nb))
+        return {"opp_diff": opp, "counts": cnt}
 
     def migrations(self, cap=96):
         n = self.inp.nsam

@@ -413,3 +413,69 @@ def test_reference_regression_data_set_constant_size(hiplib, tmp_path):
     assert (np.abs(est[:, :5] / 1e4 - 1) < 0.04).all(), est
     assert (np.abs(est[:, 5] / 1e4 - 1) < 0.015).all(), est
     assert (np.abs(est[0] / est[1] - 1) < 0.015).all(), est
+
+
+# ---------------------------------------------------------------- local recombination map (.recomb.gz)
+
+@pytest.mark.parametrize("n,E,Np,force_lds", [(4, 8, 600, False), (2, 4, 300, False), (6, 8, 256, True)])
+def test_local_recombination_map_parity(oracle, hiplib, n, E, Np, force_lds, monkeypatch):
+    """record_local_recomb_events (count.cpp:559-613): the 100-bp differential opportunity and the per-sample / time /
+    log-time counts equal the oracle's (sums of the same terms in another order: relative 1e-9 of the column scale)."""
+    from smcsmc_amd import ParticleFilter
+    if force_lds:
+        monkeypatch.setenv("SMCSMC_PF_FORCE_LDS", "1")
+    model = cases.make_model(n=n, E=E, L=1.0e5)
+    segs = cases.make_segments(model, seed=40 + n, max_seg_len=5000)
+    o = oracle.Oracle(model, Np, seed=3); o.enable_local_recomb(); o.init_prior(0.0)
+    o.run(o.pack_segments(model, segs))
+    g = ParticleFilter(model, Np, seed=3, local_recomb=True)
+    g.init_prior(0.0); g.load_segments(segs); g.run(); g.finish()
+    assert _bits([o.logl()])[0] == _bits([g.logl()])[0]
+    lo, lg = o.local_recomb(model["loci_length"]), g.local_recomb()
+    # compare the absolute (cumulated) opportunity: the differential form cancels large terms
+    co, cg = np.cumsum(lo["opp_diff"]), np.cumsum(lg["opp_diff"])
+    assert co.max() > 0
+    np.testing.assert_allclose(cg, co, rtol=1e-7, atol=1e-7 * co.max())
+    assert lo["counts"][:n].sum() > 0
+    np.testing.assert_allclose(lg["counts"], lo["counts"], rtol=1e-9, atol=1e-12 * max(1.0, lo["counts"].max()))
+    # what the map means: per-interval opportunity = posterior mean tree length x 100 bp (x recorded epochs), and the
+    # per-sample counts of an event sum to its posterior weight
+    tot_rec = g.counts()["rec_count"].sum()
+    assert lg["counts"][:n].sum() == pytest.approx(tot_rec, rel=1e-9)
+    assert cg[:-1].sum() == pytest.approx(g.counts()["rec_opp"].sum(), rel=5e-3)      # up to the edge intervals
+
+
+def test_binary_writes_the_local_recombination_map(hiplib, tmp_path):
+    """<prefix>.recomb.gz (count.cpp:616-654) from the binary equals the table written from the same run through the
+    python binding, and has the reference's header and one row per 100 bp."""
+    import gzip
+    import json
+    import os
+    import subprocess
+    from smcsmc_amd import ParticleFilter, outfile, segments as segmod
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    binary = os.path.join(root, "bin", "smcsmc")
+    seg = os.path.join(root, "tests", "golden", "seg", "constpopsize_first3000.seg")
+    L = 500000
+    core = ("-N0 10000 -t %g -r %g %d -eN 0 1 -eN 0.05 1 -eN 0.5 1" % (4e4 * 2.5e-8 * L, 4e4 * 1e-8 * L, L)).split()
+    r = subprocess.run([binary] + core + ["-nsam", "2", "-Np", "200", "-EM", "0", "-tmax", "4", "-lag", "10000", "-seed", "2",
+                                          "-seg", seg, "-o", str(tmp_path / "m")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    text = gzip.open(tmp_path / "m.recomb.gz", "rt").read()
+    lines = text.splitlines()
+    assert lines[0].split("\t") == ["iter", "locus", "size", "opp_per_nt", "1", "2", "time", "log_time"]
+    assert len(lines) == 1 + L // 100 and lines[1].split("\t")[1:3] == ["1", "100"]
+    m = json.loads(subprocess.run([binary] + core + ["-nsam", "2", "-tmax", "4", "-dumpmodel"], capture_output=True, text=True).stdout)
+    E = len(m["change_times"])
+    model = dict(change_times=np.array(m["change_times"]), pop_sizes=np.array(m["pop_sizes"])[:, 0], lags=np.full(E, 10000.0),
+                 nsam=2, loci_length=float(L), mutation_rate=m["mutation_rate"], recombination_rate=m["recombination_rate"])
+    S = segmod.Segments(seg, 2, L, max_segment_length=int(2.0 / (m["recombination_rate"] * 4 * m["N0"])))
+    segs = S.pack(model["lags"])
+    g = ParticleFilter(model, 200, seed=2, max_trace_events=0, local_recomb=True)
+    g.init_prior(segs["start"][0]); g.load_segments(segs); g.run(); g.finish()
+    mine = outfile.recomb_text(g.local_recomb(), 2).splitlines()
+    # atomics make the last digits of a sum order-dependent: compare numerically at the printed precision
+    a = np.array([[float(v) for v in ln.split("\t")] for ln in lines[1:]])
+    b = np.array([[float(v) for v in ln.split("\t")] for ln in mine[1:]])
+    np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-12)
+    assert a[:, 3].max() > 0 and a[:, 4:6].sum() > 0
