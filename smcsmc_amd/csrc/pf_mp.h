@@ -295,7 +295,6 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
     } while (0)
 #define PF_MP_BUF_PUSH(T_, TAG_, Q_)                                                                            \
     do {                                                                                                        \
-        if (nb == 4) PF_MP_FLUSH_BUFFER();                                                                      \
         if (nb == 0) { bt0 = (T_); bg0 = (TAG_); bq0 = (Q_); }                                                  \
         else if (nb == 1) { bt1 = (T_); bg1 = (TAG_); bq1 = (Q_); }                                             \
         else if (nb == 2) { bt2 = (T_); bg2 = (TAG_); bq2 = (Q_); }                                             \
@@ -309,6 +308,9 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
     constexpr int KP = 2;
     bool done = false;
     for (int guard = 0; guard < 4096 && !done; ++guard) {
+        // an interval adds at most three events (one migration, two joins): the loop below only starts an
+        // interval with two free slots, so the list insertion never has to happen inside it
+        if (nb > 1) PF_MP_FLUSH_BUFFER();
         const unsigned long long ctr0 = ln.ctr;
         double u_type[KP], eb_new[KP];
 #pragma unroll
@@ -321,6 +323,7 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
         double tn_ep = epoch_end(ln, e);
         double inv_f = ml.I2[e * P + pf], mt_f = ml.MT[e * P + pf], mt_r = ml.MT[e * P + pr];
         for (int g2 = 0; g2 < 100000; ++g2) {
+            if (nb > 1) break;                            // make room in the event buffer first
             const bool root_active = tt >= Hr;
             double tn = nS < eT ? nS : eT;
             tn = tn < tn_ep ? tn : tn_ep;
