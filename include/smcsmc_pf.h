@@ -55,6 +55,10 @@ typedef struct pf_model {
     const double* bias_heights;  /* [k] */
     const double* bias_strengths;/* [k+1] */
     const double* application_delays; /* [E] Model::application_delays (smcsmc.cpp:306-307) */
+    /* variational-Bayes event counts (-vb: the extra operand of -eN/-en/-eM/-ema): every coalescence / migration event
+     * multiplies the particle's weights by exp_digamma(c)/c (particle.cpp:266-272); NULL = off */
+    const double* vb_coal_counts;     /* [E*P] */
+    const double* vb_mig_counts;      /* [E*P*P] or NULL */
 } pf_model;
 
 typedef struct pf_params {

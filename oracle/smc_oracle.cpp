@@ -146,6 +146,9 @@ struct Model {
     std::vector<double> Mtot;        /* [E*P]   sum_q Mrate[e][p][q], summed q ascending */
     std::vector<int> jmap;           /* [E*P]   population after the fixed-time moves at the start of epoch e (-ej) */
     std::vector<int> sample_pop;     /* [n] */
+    /* variational-Bayes weight factors exp_digamma(c)/c per event (particle.cpp:266-272); empty = off */
+    std::vector<double> vb_coal;     /* [E*P] */
+    std::vector<double> vb_mig;      /* [E*P*P] */
     /* focused sampling (Model::bias_heights / bias_strengths of the scrm fork; particle.cpp:1020-1050) */
     bool biased = false;
     std::vector<double> bias_H;      /* 0, h1..hk, +inf */
@@ -278,6 +281,10 @@ struct Filter {
     bool record_events = true;
     double last_sp = 0; bool last_changed = false;
     uint64_t last_desc = 0;       /* samples below the branch cut by the last genealogy update */
+    /* product of the variational-Bayes factors of the events of one walk; applied to the weights when the walk is
+     * over (the reference multiplies event by event: same product, rounding aside) */
+    double upd_fac = 1.0;
+    void apply_vb(Particle& p) { if (!M.vb_coal.empty()) { p.w_post *= upd_fac; p.w_pilot *= upd_fac; } upd_fac = 1.0; }
     double last_iw = 1.0, last_tc = 0.0;
     int64_t slot_override = -1;   /* calibration: RNG state lives in rng[0], stream keyed by the replicate index */
     double uni(int64_t slot) {
@@ -544,6 +551,8 @@ struct Filter {
             }
             if (fire) {
                 g.ebuf = -smc_log(uni(slot));
+                if (rec_p && !M.vb_coal.empty())            /* adjustWeights(exp_digamma(c)/c), particle.cpp:266-272 */
+                    upd_fac *= kind == 1 ? M.vb_coal[e * P + pf] : M.vb_mig[(e * P + (kind == 2 ? pf : pr)) * P + to];
                 if (kind == 1) {
                     W.tc = t1; W.pf = pf; W.pr = pr; W.weight = weight;
                     return;
@@ -594,6 +603,7 @@ struct Filter {
             int ni = i - 1;
             Walk W;
             mp_coalesce(slot, &p, t, ni, root, 0.0, M.sample_pop[i], 0.0, M.E - 1, W);
+            apply_vb(p);
             double tc = W.tc;
             for (int m = 0; m < W.nrpath; ++m) ev_insert(t, W.rt[m], root, W.rq[m]);
             int pr = -1, ps = 0;
@@ -739,6 +749,7 @@ struct Filter {
             }
             if (fire) {
                 g.ebuf = -smc_log(uni(slot));
+                if (rec_p && !M.vb_coal.empty()) upd_fac *= M.vb_coal[e];   /* particle.cpp:266-272 */
                 return t1;
             }
             g.ebuf -= need;
@@ -776,6 +787,7 @@ struct Filter {
         for (int i = 1; i < n; ++i) {
             int ni = i - 1;
             double tc = coalesce_up(slot, &p, t.S, ni, i, 0.0, 0.0, M.E - 1);
+            apply_vb(p);
             int pr = -1, ps = 0;
             int k = lineages_at(t, ni, tc, -1, &pr, &ps);
             bool above_root = (ni == 0) || (tc >= t.S[ni - 1]);
@@ -1127,11 +1139,11 @@ struct Filter {
             Particle& p = parts[i];
             p.head.assign(M.E, nullptr);
             rng[i].ebuf = -smc_log(uni(i));
+            p.w_post = 1.0 / (double)Np;
+            p.w_pilot = 1.0 / (double)Np;
             build_initial_tree(i, p);
             sample_next_base(i, p, 0.0);
             open_stretch(p, 0.0, M.E - 1);
-            p.w_post = 1.0 / (double)Np;
-            p.w_pilot = 1.0 / (double)Np;
         }
         cur_pos = initial_position;
         logl = 0;
@@ -1169,6 +1181,7 @@ struct Filter {
                 close_stretch(p, updated_to);
                 double h;
                 genealogy_update(slot, p, updated_to, limit, &h);
+                apply_vb(p);
                 if (leaf_status == 0) B = tracked_length(p.tr, data);
                 if (leaf_status == 1) B = p.Ltree;
                 if (M.biased) {
@@ -1632,6 +1645,13 @@ static void fill_model(Model& M, const smco_model* m) {
             }
             M.jmap[e * P + a] = cur;
         }
+    if (m->vb_coal_counts) {
+        M.vb_coal.resize(E * P);
+        for (int i = 0; i < E * P; ++i) M.vb_coal[i] = exp_digamma(m->vb_coal_counts[i]) / m->vb_coal_counts[i];
+        M.vb_mig.assign(E * P * P, 1.0);
+        if (m->vb_mig_counts)
+            for (int i = 0; i < E * P * P; ++i) M.vb_mig[i] = exp_digamma(m->vb_mig_counts[i]) / m->vb_mig_counts[i];
+    }
     M.sample_pop.assign(M.n, 0);
     if (m->sample_pops) M.sample_pop.assign(m->sample_pops, m->sample_pops + M.n);
     for (int v : M.sample_pop) if (v < 0 || v >= P) throw std::runtime_error("oracle: sample population out of range");

@@ -45,6 +45,10 @@ typedef struct smco_model {
     const double* bias_heights;  /* [k] */
     const double* bias_strengths;/* [k+1] */
     const double* application_delays; /* [E] bp (smcsmc.cpp:306-307) */
+    /* variational-Bayes event counts (-vb: the extra operand of -eN/-en/-eM/-ema): every coalescence / migration event
+     * multiplies the particle's weights by exp_digamma(c)/c (particle.cpp:266-272); NULL = off */
+    const double* vb_coal_counts;     /* [E*P] */
+    const double* vb_mig_counts;      /* [E*P*P] or NULL */
 } smco_model;
 
 typedef struct smco_params {

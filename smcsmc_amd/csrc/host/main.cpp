@@ -101,6 +101,14 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
     memset(&pm, 0, sizeof(pm));
     pm.n_epochs = E; pm.n_pops = NP; pm.nsam = M.nsam;
     if (NP > 1) { pm.mig_rates = mig_rates.data(); pm.single_mig = single_mig.data(); pm.sample_pops = sample_pops.data(); }
+    std::vector<double> vb_cc, vb_mc;
+    if (M.vb) {          // variational_bayes_correction_ (particle.cpp:266-272)
+        for (int e = 0; e < E; ++e) {
+            for (int a = 0; a < NP; ++a) vb_cc.push_back(M.coal_counts[e][a]);
+            for (int k = 0; k < NP * NP; ++k) vb_mc.push_back(M.mig_counts[e][k]);
+        }
+        pm.vb_coal_counts = vb_cc.data(); pm.vb_mig_counts = vb_mc.data();
+    }
     pm.flags = (P.ancestral_aware ? 1 : 0) | (P.dephase ? 2 : 0);
     pm.loci_length = M.loci_length; pm.mutation_rate = M.mutation_rate; pm.recombination_rate = M.recombination_rate;
     pm.change_times = M.change_times.data(); pm.pop_sizes = pop_sizes.data();

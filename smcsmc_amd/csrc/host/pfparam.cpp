@@ -43,6 +43,8 @@ struct Change {
     std::vector<double> size;     // per pop, NaN = inherit
     std::vector<double> mig;      // P*P per generation, NaN = inherit
     std::vector<double> single;   // P*P
+    std::vector<double> ccount;   // per pop: variational-Bayes coalescence event count (-vb), NaN = inherit
+    std::vector<double> mcount;   // P*P: migration event counts, NaN = inherit
 };
 }  // namespace
 
@@ -65,6 +67,8 @@ void HostModel::parse(const std::vector<std::string>& tok) {
             c.size.assign(P, NAN);
             c.mig.assign((size_t)P * P, NAN);
             c.single.assign((size_t)P * P, 0.0);
+            c.ccount.assign(P, NAN);
+            c.mcount.assign((size_t)P * P, NAN);
         }
         return c;
     };
@@ -100,36 +104,51 @@ void HostModel::parse(const std::vector<std::string>& tok) {
             }
         } else if (f == "-eN") {
             need(f, 2); double t = convert<double>(f, tok[++i]) * 4 * N0; double x = convert<double>(f, tok[++i]);
-            if (vb) { need(f, 1); ++i; }
+            double cnt = NAN;
+            if (vb) { need(f, 1); cnt = convert<double>(f, tok[++i]); }
             Change& c = at(t);
-            for (int p = 0; p < P; ++p) c.size[p] = x * N0;
+            for (int p = 0; p < P; ++p) { c.size[p] = x * N0; c.ccount[p] = cnt; }
         } else if (f == "-en") {
             need(f, 3); double t = convert<double>(f, tok[++i]) * 4 * N0; int p = convert<int>(f, tok[++i]);
             double x = convert<double>(f, tok[++i]);
-            if (vb) { need(f, 1); ++i; }
+            double cnt = NAN;
+            if (vb) { need(f, 1); cnt = convert<double>(f, tok[++i]); }
             if (p < 1 || p > P) throw InvalidInput("Population index out of range in -en");
             at(t).size[p - 1] = x * N0;
+            at(t).ccount[p - 1] = cnt;
         } else if (f == "-eM") {
             need(f, 2); double t = convert<double>(f, tok[++i]) * 4 * N0; double M = convert<double>(f, tok[++i]);
-            if (vb) { need(f, 1); ++i; }
+            double cnt = NAN;
+            if (vb) { need(f, 1); cnt = convert<double>(f, tok[++i]); }
             Change& c = at(t);
             for (int a = 0; a < P; ++a)
                 for (int b = 0; b < P; ++b)
-                    if (a != b) c.mig[(size_t)a * P + b] = (P > 1 ? M / (P - 1) : 0.0) / (4 * N0);
+                    if (a != b) {
+                        c.mig[(size_t)a * P + b] = (P > 1 ? M / (P - 1) : 0.0) / (4 * N0);
+                        // [INFERRED] the event count of the symmetric form is the total over the matrix, as the
+                        // front-end writes it (populationmodels.py:362-376): spread like the rate
+                        c.mcount[(size_t)a * P + b] = cnt / ((double)P * P);
+                    }
         } else if (f == "-em") {
             need(f, 4); double t = convert<double>(f, tok[++i]) * 4 * N0; int a = convert<int>(f, tok[++i]);
             int b = convert<int>(f, tok[++i]); double M = convert<double>(f, tok[++i]);
-            if (vb) { need(f, 1); ++i; }
+            double cnt = NAN;
+            if (vb) { need(f, 1); cnt = convert<double>(f, tok[++i]); }
             if (a < 1 || a > P || b < 1 || b > P) throw InvalidInput("Population index out of range in -em");
             at(t).mig[(size_t)(a - 1) * P + (b - 1)] = M / (4 * N0);
+            at(t).mcount[(size_t)(a - 1) * P + (b - 1)] = cnt;
         } else if (f == "-ema") {
             need(f, 1 + (size_t)P * P * (vb ? 2 : 1)); double t = convert<double>(f, tok[++i]) * 4 * N0;
             Change& c = at(t);
             for (int a = 0; a < P; ++a)
                 for (int b = 0; b < P; ++b) {
                     const string& v = tok[++i];
-                    if (vb) ++i;
-                    if (a != b) c.mig[(size_t)a * P + b] = (v == "x" ? 0.0 : convert<double>(f, v)) / (4 * N0);
+                    double cnt = NAN;
+                    if (vb) cnt = convert<double>(f, tok[++i]);
+                    if (a != b) {
+                        c.mig[(size_t)a * P + b] = (v == "x" ? 0.0 : convert<double>(f, v)) / (4 * N0);
+                        c.mcount[(size_t)a * P + b] = cnt;
+                    }
                 }
         } else if (f == "-ej") {
             need(f, 3); double t = convert<double>(f, tok[++i]) * 4 * N0; int a = convert<int>(f, tok[++i]);
@@ -171,12 +190,17 @@ void HostModel::parse(const std::vector<std::string>& tok) {
     if (loci_length <= 1) throw InvalidInput("Locus length must be larger than 1");
     recombination_rate = R / (4 * N0) / (loci_length - 1);
     // Model::finalize: fill unset values forward in time
-    change_times.clear(); pop_sizes.clear(); mig_rates.clear(); single_mig.clear();
+    change_times.clear(); pop_sizes.clear(); mig_rates.clear(); single_mig.clear(); coal_counts.clear(); mig_counts.clear();
     std::vector<double> cur_size(P, N0), cur_mig((size_t)P * P, 0.0);
+    std::vector<double> cur_cc(P, 1e10), cur_mc((size_t)P * P, 1e10);      // populationmodels.py:259-268 defaults
     for (auto& kv : changes) {
         Change& c = kv.second;
         for (int p = 0; p < P; ++p) if (!std::isnan(c.size[p])) cur_size[p] = c.size[p];
         for (size_t k = 0; k < c.mig.size(); ++k) if (!std::isnan(c.mig[k])) cur_mig[k] = c.mig[k];
+        for (int p = 0; p < P; ++p) if (!std::isnan(c.ccount[p])) cur_cc[p] = c.ccount[p];
+        for (size_t k = 0; k < c.mcount.size(); ++k) if (!std::isnan(c.mcount[k])) cur_mc[k] = c.mcount[k];
+        coal_counts.push_back(cur_cc);
+        mig_counts.push_back(cur_mc);
         change_times.push_back(kv.first);
         pop_sizes.push_back(cur_size);
         mig_rates.push_back(cur_mig);

@@ -80,6 +80,8 @@ struct HostModel {
     std::vector<std::vector<double>> pop_sizes;  // [E][P]
     std::vector<std::vector<double>> mig_rates;  // [E][P*P] per generation
     std::vector<std::vector<double>> single_mig; // [E][P*P]
+    std::vector<std::vector<double>> coal_counts; // [E][P]   -vb event counts (1e10 when not given)
+    std::vector<std::vector<double>> mig_counts;  // [E][P*P]
     std::vector<int> sample_pops;
     std::vector<double> bias_heights, bias_strengths;
     bool vb = false;

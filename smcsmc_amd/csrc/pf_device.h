@@ -116,6 +116,18 @@ __device__ __forceinline__ double dlog(double x) {
 }
 
 // reference: particle.cpp:30-40
+// particle.cpp:65-74
+__device__ __forceinline__ double exp_digamma(double x) {
+    if (x > 10) return x - 0.5 + (x + 0.5) / (24 * x * x);
+    double f = 0.0;
+    while (x < 6) {
+        f = f + 1.0 / x;
+        x = x + 1.0;
+    }
+    double psi = dlog(x) - 1 / (2 * x) - 1 / (12 * x * x);
+    return dexp(psi - f);
+}
+
 // particle.cpp:45-55
 __device__ __forceinline__ double fastexp_approx(double x) {
     double xx = x * x;
@@ -202,6 +214,8 @@ struct Lane {
     unsigned long long ctr;   // draws consumed by this slot
     double ebuf;              // buffered unit exponential (RandomGenerator::sampleExpoLimit)
     double Ltree;
+    const double* vbc;        // variational-Bayes factor per (epoch[, population]) of a coalescence, or null
+    double upd_fac;           // product of the factors of the events of the current walk
 };
 
 #define LS(ln, r) ((ln).S[(r) * PF_BS])
@@ -314,6 +328,7 @@ __device__ __forceinline__ double coalesce_up(Lane& ln, HeightAt Sh, int ns, int
     }
     double t1 = t + ln.ebuf / rate;
     ln.ebuf = -dlog(uni(ln));
+    if (ln.vbc) ln.upd_fac *= ln.vbc[e];
     return t1;
 }
 

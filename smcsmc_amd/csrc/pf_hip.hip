@@ -53,6 +53,7 @@ __global__ __launch_bounds__(PF_BS) void k_init(KArgs A, double initial_position
     ln.ebuf = -dlog(uni(ln));
     unsigned widx = 0;
     int root = 0;
+    double w0 = 1.0 / (double)A.Np;
     // Forest::buildInitialTree(true): add the samples one by one; every coalescence is logged
     // as a type-2 record at position 0 (record_all_event, particle.cpp:251-300)
     for (int i = 1; i < n; ++i) {
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(PF_BS) void k_init(KArgs A, double initial_position
         rec[0] = 0.0; rec[1] = 0.0; rec[2] = 0.0;
         for (int r = 0; r < n - 1; ++r) rec[5 + r] = r < ni ? LS(ln, r) : 0.0;
         double tc = coalesce_up(ln, [&](int k) { return LS(ln, k); }, ni, i, 0.0);
+        if (ln.vbc) { w0 *= ln.upd_fac; ln.upd_fac = 1.0; }
         rec[3] = tc;
         rec[4] = __longlong_as_double((long long)make_meta(2, A.E - 1, A.E - 1, i));
         ++widx;
@@ -86,8 +88,8 @@ __global__ __launch_bounds__(PF_BS) void k_init(KArgs A, double initial_position
         st.C[(size_t)(2 * r) * A.Np + p] = LC(ln, r, 0);
         st.C[(size_t)(2 * r + 1) * A.Np + p] = LC(ln, r, 1);
     }
-    st.w_post[p] = 1.0 / (double)A.Np;
-    st.w_pilot[p] = 1.0 / (double)A.Np;
+    st.w_post[p] = w0;
+    st.w_pilot[p] = w0;
     st.next_base[p] = nb;
     st.x_mark[p] = 0.0;
     st.Ltree[p] = ln.Ltree;
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
                 bool changed;
                 unsigned desc = 0;
                 genealogy_update(ln, &h, &tc, &sp_removed, &changed, A.lmap_opp ? &desc : nullptr, tmp0);
+                if (ln.vbc) { w_post *= ln.upd_fac; w_pilot *= ln.upd_fac; ln.upd_fac = 1.0; }
                 rec[2] = h;
                 rec[3] = tc;
                 rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n, desc));
@@ -346,6 +349,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
         cx.seed = A.seed; cx.slot = (unsigned)p; cx.stream = 0;
         cx.nb = A.n_bias + 1; cx.bH = sBH; cx.bS = sBS; cx.last_iw = 1.0;
         cx.want_desc = A.lmap_opp != nullptr; cx.last_desc = 0;
+        cx.vbc = A.vb_coal; cx.upd_fac = 1.0;
         DStore ds;
         if (BIASED) {
             ds.pos = st.dpos + p; ds.fac = st.dfac + p; ds.delta = st.ddelta + p; ds.k = st.dk + p; ds.Np = A.Np;
@@ -441,6 +445,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
                 for (int r = 0; r < RTree<NM>::NI; ++r) if (r < n - 1) rec[5 + r] = t.S[r];
                 double h, tc;
                 r_genealogy_update<NM, BIASED>(cx, t, &h, &tc);
+                if (cx.vbc) { w_post *= cx.upd_fac; w_pilot *= cx.upd_fac; cx.upd_fac = 1.0; }
                 rec[2] = h;
                 rec[3] = tc;
                 rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n, cx.last_desc));
@@ -1739,6 +1744,12 @@ __global__ __launch_bounds__(PF_BS) void k_tbl(KArgs A, unsigned long long seed,
     }
 }
 
+// exp_digamma(c)/c for every event count (particle.cpp:266-272), with the device's own exp / log
+__global__ void k_vb_table(const double* counts, long long n, double* out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = exp_digamma(counts[i]) / counts[i];
+}
+
 // ------------------------------------------------------------------ unit-test kernels
 __global__ void k_test_math(const double* x, long long n, double* oe, double* ol, double* of) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1939,6 +1950,20 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     if (P > 1) {
         MpTables tb;
         if (build_mp_tables(m, tb) || upload_mp_tables(tb, A, h->allocs)) { pf_destroy(h); return nullptr; }
+    }
+    if (m->vb_coal_counts) {
+        const size_t nc = (size_t)E * P, nm = (size_t)E * P * P;
+        double *cin, *cout_, *mout;
+        if (dalloc(h, &cin, nc + nm) || dalloc(h, &cout_, nc) || dalloc(h, &mout, nm)) { pf_destroy(h); return nullptr; }
+        std::vector<double> cnt(nc + nm, 1e10);
+        for (size_t i = 0; i < nc; ++i) cnt[i] = m->vb_coal_counts[i];
+        if (m->vb_mig_counts) for (size_t i = 0; i < nm; ++i) cnt[nc + i] = m->vb_mig_counts[i];
+        for (double v : cnt) if (!(v > 0)) { pf_destroy(h); return fail("pf_create: variational-Bayes event counts must be positive"); }
+        hipMemcpyAsync(cin, cnt.data(), cnt.size() * 8, hipMemcpyHostToDevice, h->stream);
+        hipLaunchKernelGGL(k_vb_table, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, h->stream, cin, (long long)nc, cout_);
+        hipLaunchKernelGGL(k_vb_table, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, h->stream, cin + nc, (long long)nm, mout);
+        hipStreamSynchronize(h->stream);
+        A.vb_coal = cout_; A.vb_mig = mout;
     }
     hipMemcpyAsync(dT, m->change_times, E * 8, hipMemcpyHostToDevice, h->stream);
     hipMemcpyAsync(dI, inv2N.data(), E * 8, hipMemcpyHostToDevice, h->stream);

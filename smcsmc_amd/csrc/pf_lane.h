@@ -45,6 +45,7 @@ __device__ __forceinline__ Lane make_lane(const KArgs& A, Smem& m, long long p) 
     ln.slot = (unsigned)p;
     ln.stream = 0;
     ln.ctr = 0; ln.ebuf = 0; ln.Ltree = 0;
+    ln.vbc = A.vb_coal; ln.upd_fac = 1.0;
     return ln;
 }
 

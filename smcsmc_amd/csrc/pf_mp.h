@@ -36,6 +36,7 @@ struct MLane {
     const double* MT;  // [E*P]   total emigration rate       (LDS)
     const int* JM;     // [E*P]   fixed-time moves at the start of epoch e (LDS)
     const int* SP;     // [n]     sample populations          (LDS)
+    const double* vbm; // [E*P*P] variational-Bayes factor of a migration event (global), or null
     int err;           // 1 list overflow, 2 partner count inconsistent, 3 no final coalescence possible
 };
 
@@ -360,6 +361,7 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
                     }
                 }
                 record(root_active, weight, t1 - tt, kind, to);
+                if (ln.vbc) ln.upd_fac *= kind == 1 ? ln.vbc[e * P + pf] : ml.vbm[(e * P + (kind == 2 ? pf : pr)) * P + to];
                 ln.ebuf = used == 0 ? eb_new[0] : eb_new[1];
                 ++used;
                 if (kind == 1) {

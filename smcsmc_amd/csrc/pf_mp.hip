@@ -47,7 +47,7 @@ __device__ __forceinline__ MLane make_mlane(const KArgs& A, SmemMP& m) {
     MLane ml;
     ml.Pn = m.Pn + threadIdx.x; ml.Mt = m.Mt + threadIdx.x; ml.Mb = m.Mb + threadIdx.x; ml.Mq = m.Mq + threadIdx.x; ml.Bp = m.Bp + threadIdx.x;
     ml.nm = 0; ml.P = A.P;
-    ml.I2 = m.I2; ml.MR = m.MR; ml.MT = m.MT; ml.JM = m.JM; ml.SP = m.SP;
+    ml.I2 = m.I2; ml.MR = m.MR; ml.MT = m.MT; ml.JM = m.JM; ml.SP = m.SP; ml.vbm = A.vb_mig;
     ml.err = 0;
     return ml;
 }
@@ -96,7 +96,9 @@ __global__ __launch_bounds__(PF_BS) void k_init_mp(KArgs A, double initial_posit
     PLog pl;
     pl.base = A.plog + (size_t)p * A.pcap * 3; pl.cap = A.pcap; pl.idx = 0; pl.pos = 0; pl.on = true; pl.fopen = false; pl.ropen = false;
     // every coalescence of the initial tree is logged as a type-2 record at position 0 (particle.cpp:251-300)
+    double w0 = 1.0 / (double)A.Np;
     mp_build_initial_tree<true>(ln, ml, pl, [&](int i, unsigned p0, unsigned np_, double tc) {
+        if (ln.vbc) { w0 *= ln.upd_fac; ln.upd_fac = 1.0; }
         double* rec = rec_ptr(A, p, widx);
         rec[0] = 0.0; rec[1] = 0.0; rec[2] = 0.0;
         rec[3] = piece_ref(p0, np_);
@@ -114,8 +116,8 @@ __global__ __launch_bounds__(PF_BS) void k_init_mp(KArgs A, double initial_posit
         st.C[(size_t)(2 * r + 1) * A.Np + p] = LC(ln, r, 1);
     }
     store_mp_state(A, st, ln, ml, p);
-    st.w_post[p] = 1.0 / (double)A.Np;
-    st.w_pilot[p] = 1.0 / (double)A.Np;
+    st.w_post[p] = w0;
+    st.w_pilot[p] = w0;
     st.next_base[p] = nb;
     st.x_mark[p] = 0.0;
     st.Ltree[p] = ln.Ltree;
@@ -206,6 +208,7 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
                 const unsigned desc = A.lmap_opp ? lane_desc_mask(ln, LC(ln, rp, sb), tmp0) : 0u;
                 unsigned p0 = pl.idx;
                 mp_genealogy_rest<true>(ln, ml, pl, limit, rp, sb, h, &tc, &sp_removed, &changed);
+                if (ln.vbc) { w_post *= ln.upd_fac; w_pilot *= ln.upd_fac; ln.upd_fac = 1.0; }
                 rec[2] = h;
                 rec[3] = piece_ref(p0, pl.idx - p0);
                 rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n, desc));

@@ -63,6 +63,8 @@ struct RCtx {
     const double* bH;
     const double* bS;
     double last_iw;
+    const double* vbc;    // variational-Bayes factor per epoch of a coalescence (particle.cpp:266-272), or null
+    double upd_fac;       // the factor of the current update
     unsigned last_desc;   // samples below the branch cut by the last update (only computed when want_desc)
     bool want_desc;
 };
@@ -219,6 +221,7 @@ __device__ __forceinline__ double r_coalesce_up(RCtx& cx, const RTree<NM>& t, in
     }
     double t1 = tt + cx.ebuf / rate;
     cx.ebuf = -dlog(r_uni(cx));
+    if (cx.vbc) cx.upd_fac *= cx.vbc[e];
     return t1;
 }
 

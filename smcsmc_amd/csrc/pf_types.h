@@ -95,6 +95,10 @@ struct KArgs {
     double* lmap_opp;
     double* lmap_cnt;
     long long lmap_bins;
+    // variational-Bayes weight factors exp_digamma(c)/c (particle.cpp:266-272), computed on the device from the event
+    // counts so that they carry the device's exp / log; null = off
+    const double* vb_coal;         // [E*P]
+    const double* vb_mig;          // [E*P*P]
     // run parameters
     long long Np;
     double ess_threshold;

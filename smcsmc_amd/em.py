@@ -102,7 +102,7 @@ class PopulationModel:
             N0=self.N0, muts=mutations, recs=recombinations, seqlen=self.sequence_length,
             sample=self._sample_options(), popmigr=self._popsize_migration_options(vb))
 
-    def device_model(self, lags=None, **extra):
+    def device_model(self, lags=None, vb=False, **extra):
         """Model tables for ParticleFilter: generations and per-generation rates, -ej commands as joins."""
         E, P = len(self.change_points), self.num_populations
         ct = np.array(self.change_points, float) * 4 * self.N0
@@ -128,6 +128,9 @@ class PopulationModel:
                     mr[i, :, a] = 0.0
                     mr[i, a, :] = 0.0
             m.update(n_pops=P, mig_rates=mr, single_mig=sm, sample_pops=[q - 1 for q in self.sample_populations])
+        if vb:        # the event counts the -vb command line carries (populationmodels.py:335-398)
+            m.update(vb_coal_counts=np.array(self.population_event_counts, float).reshape(E, P),
+                     vb_mig_counts=np.array(self.migration_event_counts, float).reshape(E, P, P))
         m.update(extra)
         return m
 
@@ -219,7 +222,7 @@ def run_em(pop, chunks, iterations, np_particles, seed=1, ess_fraction=0.5, lag_
     for it in range(iterations + 1):
         base = pop.device_model()
         lags = pf.calibrated_lags(base, lag_fraction=lag_fraction, device=device)     # model-only: once per iteration
-        model = pop.device_model(lags=lags)
+        model = pop.device_model(lags=lags, vb=vb)
         def e_step(c):
             segs = chunks[c].pack(lags)
             f = pf.ParticleFilter(model, np_particles, ess_fraction=ess_fraction, seed=seed + 1000 * it + c,

@@ -25,6 +25,7 @@ class Model(C.Structure):
         ("n_bias_heights", C.c_int32), ("delay_type", C.c_int32),
         ("bias_heights", C.POINTER(C.c_double)), ("bias_strengths", C.POINTER(C.c_double)),
         ("application_delays", C.POINTER(C.c_double)),
+        ("vb_coal_counts", C.POINTER(C.c_double)), ("vb_mig_counts", C.POINTER(C.c_double)),
     ]
 
 
@@ -117,6 +118,13 @@ def attach_structure(owner, cmodel, m, E, P):
     if m.get("single_mig") is not None:
         owner._smig = np.ascontiguousarray(m["single_mig"], dtype=np.float64).reshape(E * P * P)
         cmodel.single_mig = _dp(owner._smig)
+    if m.get("vb_coal_counts") is not None:
+        # variational-Bayes event counts: [E][P] per coalescence, [E][P][P] per migration (-vb)
+        owner._vbc = np.ascontiguousarray(m["vb_coal_counts"], dtype=np.float64).reshape(E * P)
+        cmodel.vb_coal_counts = _dp(owner._vbc)
+        if m.get("vb_mig_counts") is not None:
+            owner._vbm = np.ascontiguousarray(m["vb_mig_counts"], dtype=np.float64).reshape(E * P * P)
+            cmodel.vb_mig_counts = _dp(owner._vbm)
     if m.get("sample_pops") is not None:
         owner._spop = np.ascontiguousarray(m["sample_pops"], dtype=np.int32)
         assert len(owner._spop) == cmodel.nsam

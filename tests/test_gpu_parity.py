@@ -479,3 +479,43 @@ def test_binary_writes_the_local_recombination_map(hiplib, tmp_path):
     b = np.array([[float(v) for v in ln.split("\t")] for ln in mine[1:]])
     np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-12)
     assert a[:, 3].max() > 0 and a[:, 4:6].sum() > 0
+
+
+# ---------------------------------------------------------------- variational-Bayes event-count correction (-vb)
+
+@pytest.mark.parametrize("n,P", [(4, 1), (10, 1), (4, 2)])
+def test_variational_bayes_weight_factors_parity(oracle, hiplib, n, P):
+    """model().variational_bayes_correction_ (particle.cpp:266-272): every coalescence / migration event multiplies the
+    particle's weights by exp_digamma(c)/c for the event count c of its epoch (and populations)."""
+    E = 6
+    base = cases.make_model(n=n, E=E, L=8e4)
+    segs = cases.make_segments(base, seed=60 + n, max_seg_len=5000)
+    rng = np.random.default_rng(5)
+    model = base if P == 1 else cases.make_structured(base, P=P, split_epoch=4, mig=2.0)
+    model = dict(model, vb_coal_counts=rng.uniform(0.5, 40.0, (E, P)), vb_mig_counts=rng.uniform(0.5, 40.0, (E, P, P)))
+    o, si, g = _run_both(oracle, model, segs, 300, seed=4)
+    po, pg = o.particles(), g.particles()
+    assert (_bits(po["w_post"]) == _bits(pg["w_post"])).all()            # the prior trees already carry factors
+    assert np.ptp(po["w_post"]) > 0
+    o.run(si); g.run(); g.finish()
+    to, tg = o.trace(), g.trace()
+    assert (to["resampled"] == tg["resampled"]).all() and to["resampled"].sum() > 0
+    for k in ("T", "ess", "logl"):
+        assert (_bits(to[k]) == _bits(tg[k])).all(), k
+    # the correction changes the weights: the same run without it has another likelihood
+    o0, si0, g0 = _run_both(oracle, {k: v for k, v in model.items() if not k.startswith("vb_")}, segs, 300, seed=4)
+    g0.run(); g0.finish()
+    assert g0.logl() != g.logl()
+
+
+def test_device_exp_digamma(oracle, hiplib):
+    """exp_digamma (particle.cpp:65-74) through the factor table the device builds: close to exp(psi(c))/c."""
+    from scipy.special import digamma
+    from smcsmc_amd import ParticleFilter
+    c = np.array([[0.3], [1.0], [5.9], [6.0], [10.0], [10.5], [1e10]])
+    model = dict(cases.make_model(n=2, E=7, L=1e4), vb_coal_counts=c)
+    g = ParticleFilter(model, 64, seed=1); g.init_prior(0.0)
+    w = g.particles()["w_post"] * 64                                     # one coalescence per prior tree: w = factor of its epoch
+    expect = np.exp(digamma(c[:, 0])) / c[:, 0]
+    for v in np.unique(w):
+        assert np.min(np.abs(expect / v - 1)) < 2e-3                     # the reference's asymptotic series, not exact digamma
