@@ -155,6 +155,12 @@ struct Model {
     std::vector<double> bias_S;      /* k+1 strengths */
     std::vector<double> app_delays;  /* Model::application_delays (smcsmc.cpp:306-307) */
     int delay_type = 0;              /* PfParam::ResampleDelayType: 0 recombination height, 1 coalescence, 2 coal/migr */
+    /* recombination guide (pfparam.hpp:96-223 RecombinationBias): piecewise-constant sampling rate along the sequence and
+     * relative rates per leaf; rho stays the true rate */
+    bool guided = false;
+    std::vector<double> seg_pos;     /* [K] segment starts, seg_pos[0] == 0 */
+    std::vector<double> seg_rho;     /* [K] */
+    std::vector<double> leaf_rate;   /* [K*n] */
     int epoch_of(double t) const {
         int e = 0;
         while (e + 1 < E && T[e + 1] <= t) ++e;
@@ -229,6 +235,7 @@ struct Particle {
     int mark_limit;         /* max_epoch_to_record_ in force when the stretch was opened */
     double Ltree;
     double lookahead = 1.0;                  /* lookahead_weight_ (particle.hpp:239) */
+    int ridx = 0;                            /* _current_seq_idx: guide segment the particle is in (particle.hpp:177-178) */
     double total_delayed = 1.0;              /* total_delayed_adjustment_ */
     int dcount = 0;                          /* pending DelayedFactors (particle.hpp:248) */
     double dpos[DCAP], dfac[DCAP], ddelta[DCAP];
@@ -286,6 +293,7 @@ struct Filter {
     double upd_fac = 1.0;
     void apply_vb(Particle& p) { if (!M.vb_coal.empty()) { p.w_post *= upd_fac; p.w_pilot *= upd_fac; } upd_fac = 1.0; }
     double last_iw = 1.0, last_tc = 0.0;
+    double last_rbiw = 1.0;       /* recombination_bias_importance_weight_ (particle.cpp:1113-1121) */
     int64_t slot_override = -1;   /* calibration: RNG state lives in rng[0], stream keyed by the replicate index */
     double uni(int64_t slot) {
         return philox_uniform(seed, (uint32_t)(slot_override >= 0 ? slot_override : slot), stream, rng[slot].ctr++);
@@ -762,17 +770,23 @@ struct Filter {
     /* Forest::sampleNextBase via ForestState::sampleNextBase (particle.cpp:1195-1254), multiplicity 1 */
     void sample_next_base(int64_t slot, Particle& p, double x) {
         SlotRng& g = rng[slot];
-        double rate = M.rho * p.Ltree;
-        double limit = M.L - x;
+        /* with a guide the sampling rate is that of the particle's current segment and the draw is limited to the
+         * segment (sampleExpoLimit(rate, distance_until_rate_change), particle.cpp:1203-1232) */
+        const int K = (int)M.seg_pos.size();
+        const bool use_guide = M.guided && stream == 0;          /* calibration uses the true rate (particle.cpp:1211-1218) */
+        double rho_here = use_guide ? M.seg_rho[p.ridx] : M.rho;
+        double seg_end = (use_guide && p.ridx + 1 < K && M.seg_pos[p.ridx + 1] < M.L) ? M.seg_pos[p.ridx + 1] : M.L;
+        double rate = rho_here * p.Ltree;
+        double limit = seg_end - x;
         double need = limit * rate;
         if (g.ebuf > need) {
             g.ebuf -= need;
-            p.next_base = M.L;
+            p.next_base = seg_end;
         } else {
             double nb = x + g.ebuf / rate;
             g.ebuf = -smc_log(uni(slot));
             if (nb == x) nb = std::nextafter(x, x * 2 + 1);   /* particle.cpp:1238-1244 */
-            if (nb > M.L) nb = M.L;
+            if (nb > seg_end) nb = seg_end;
             p.next_base = nb;
         }
     }
@@ -814,7 +828,75 @@ struct Filter {
         double prev = 0.0, h = 0.0;
         int lin = 0, slice = 0;
         last_iw = 1.0;
-        if (!M.biased) {
+        last_rbiw = 1.0;
+        int g_rp = -1, g_sb = 0;
+        if (M.guided && stream == 0) {
+            /* samplePoint with a recombination guide (particle.cpp:942-1126): every branch carries a relative rate --
+             * leaf: the guide's rate for that sample in the current segment; binary node: the arithmetic mean of its
+             * children (:1015); the two branches below the root: the larger of the two (:958, 1091) -- times the
+             * strength of its height band.  Pieces are visited branch by branch in slot order, bands ascending. */
+            const int nbands = (int)M.bias_S.size();
+            double brate[2 * NMAX];
+            for (int i = 0; i < n; ++i) brate[i] = M.leaf_rate[(size_t)p.ridx * n + i];
+            for (int r = 0; r < n - 1; ++r) brate[n + r] = (brate[t.C[r][0]] + brate[t.C[r][1]]) * 0.5;
+            const double rroot = std::max(brate[t.C[n - 2][0]], brate[t.C[n - 2][1]]);
+            auto visit = [&](auto&& fn) {
+                for (int r = 0; r < n - 1; ++r)
+                    for (int sdx = 0; sdx < 2; ++sdx) {
+                        int c = t.C[r][sdx];
+                        double rb = (r == n - 2) ? rroot : brate[c];
+                        double lo_b = node_h(t, c), hi_b = t.S[r];
+                        for (int b = 0; b < nbands; ++b) {
+                            double lo_ = std::max(lo_b, M.bias_H[b]);
+                            double hi_ = std::min(hi_b, M.bias_H[b + 1]);
+                            if (hi_ > lo_) { if (fn(r, sdx, lo_, hi_, rb * M.bias_S[b])) return; }
+                            if (M.bias_H[b + 1] >= hi_b) break;
+                        }
+                    }
+            };
+            double Lw = 0.0;
+            visit([&](int, int, double lo_, double hi_, double wt) { Lw += wt * (hi_ - lo_); return false; });
+            double rr = uni(slot) * Lw;
+            double l_lo = 0, l_hi = 0, l_wt = 1;
+            bool sel = false;
+            visit([&](int r, int sdx, double lo_, double hi_, double wt) {
+                double wlen = wt * (hi_ - lo_);
+                l_lo = lo_; l_hi = hi_; l_wt = wt; g_rp = r; g_sb = sdx;
+                if (rr < wlen) { sel = true; return true; }
+                rr -= wlen;
+                return false;
+            });
+            (void)sel;
+            h = l_lo + rr / l_wt;
+            if (!(h < l_hi)) h = l_lo;
+            if (h < l_lo) h = l_lo;
+            double sampled = l_wt / Lw;
+            double target = 1.0 / p.Ltree;
+            last_iw = target / sampled;
+            /* the position itself was drawn at the guide's rate: density ratio of the event, true over guide rate.  (The
+             * reference returns samplePoint's weight through the absent Forest::sampleNextGenealogy; without this factor
+             * the guided sampler is not an importance sampler of the model -- the no-data test checks E[w] = 1.) */
+            last_iw *= M.rho / M.seg_rho[p.ridx];
+            if (M.biased) {
+                /* importance weight of the height bias alone (particle.cpp:1113-1121) */
+                double Lrw = 0.0, pv = 0.0;
+                for (int ri = 0; ri < n - 1; ++ri) {
+                    int k = n - ri;
+                    double top = t.S[ri];
+                    for (int b = 0; b < nbands; ++b) {
+                        double lo_ = std::max(pv, M.bias_H[b]);
+                        double hi_ = std::min(top, M.bias_H[b + 1]);
+                        if (hi_ > lo_) Lrw += ((double)k * M.bias_S[b]) * (hi_ - lo_);
+                        if (M.bias_H[b + 1] >= top) break;
+                    }
+                    pv = top;
+                }
+                int idx = 0;
+                while (idx + 1 < nbands && M.bias_H[idx + 1] < h) ++idx;
+                double recomb_density = M.bias_S[idx] / Lrw;
+                last_rbiw = target / recomb_density;
+            }
+        } else if (!M.biased) {
             double r = uni(slot) * p.Ltree;
             for (int ri = 0; ri < n - 1; ++ri) {
                 int k = n - ri;
@@ -891,10 +973,12 @@ struct Filter {
             double sampled = wloc / Lw;
             double target = 1.0 / p.Ltree;
             last_iw = target / sampled;
+            last_rbiw = last_iw;
         }
         (void)slice;
         int rp = 0, sb = 0;
-        lineages_at(t, n - 1, h, lin, &rp, &sb);   /* branch b = slot (rp,sb); its parent p has rank rp */
+        if (g_rp >= 0) { rp = g_rp; sb = g_sb; }
+        else lineages_at(t, n - 1, h, lin, &rp, &sb);   /* branch b = slot (rp,sb); its parent p has rank rp */
         *h_out = h;
         {   /* get_descendants (descendants.hpp:22-33) of the cut branch, on the tree before it changes */
             uint64_t below[2 * NMAX];
@@ -1175,8 +1259,26 @@ struct Filter {
             double f = fastexp(-M.mu * B * (new_updated_to - updated_to));
             p.w_post *= f;
             p.w_pilot *= f;
+            if (M.guided) {
+                /* importance_weight_over_segment (particle.cpp:1138-1181): true rate over guide rate for the stretch
+                 * without recombination.  (The reference gates it on model().biased_sampling, particle.cpp:811-813, a
+                 * flag of the absent fork; a guide without it would bias every estimate, so it is applied with any guide.) */
+                double dist = new_updated_to - updated_to;
+                double target_rate = dist * M.rho * p.Ltree;
+                double sampled_rate = dist * M.seg_rho[p.ridx] * p.Ltree;
+                double iws = fastexp(sampled_rate - target_rate);
+                p.w_post *= iws;
+                p.w_pilot *= iws;
+            }
             updated_to = new_updated_to;
             if (updated_to < extend_to) {
+                if (M.guided && p.ridx + 1 < (int)M.seg_pos.size() && updated_to == M.seg_pos[p.ridx + 1]) {
+                    /* reached a change of the guide rate: no genealogy change, new draw under the new rate
+                     * (particle.cpp:822-826); the open stretch simply continues (D6) */
+                    p.ridx += 1;
+                    sample_next_base(slot, p, updated_to);
+                    continue;
+                }
                 /* a recombination has occurred (particle.cpp:828-903) */
                 close_stretch(p, updated_to);
                 double h;
@@ -1184,10 +1286,10 @@ struct Filter {
                 apply_vb(p);
                 if (leaf_status == 0) B = tracked_length(p.tr, data);
                 if (leaf_status == 1) B = p.Ltree;
-                if (M.biased) {
+                if (M.biased || M.guided) {
                     /* particle.cpp:866-891: immediate vs delayed application of the importance weight */
                     double iw = last_iw;
-                    double rbiw = last_iw;                         /* no guide: both weights coincide */
+                    double rbiw = last_rbiw;                       /* without a guide both weights coincide */
                     double delay_height = M.delay_type == 0 ? h : last_tc;
                     int idx = 0;
                     while (idx + 1 < (int)M.bias_H.size() && M.bias_H[idx + 1] < delay_height) ++idx;
@@ -1204,7 +1306,7 @@ struct Filter {
                 record_recomb_event(p, h, limit);
             }
         }
-        if (M.biased) apply_due(p, extend_to);
+        if (M.biased || M.guided) apply_due(p, extend_to);
     }
 
     /* adjustWeightsWithDelay(adjustment, delay, k = 3) (particle.hpp:189-198) with DelayedFactor (59-77):
@@ -1215,7 +1317,7 @@ struct Filter {
             p.w_pilot *= adj;
             return;
         }
-        if (p.dcount == DCAP) apply_earliest(p);        /* bounded store: make room (the reference's heap is unbounded) */
+        while (p.dcount == DCAP) apply_earliest(p);     /* bounded store: make room (the reference's heap is unbounded) */
         p.total_delayed *= adj;
         double final_pos = cur + delay;
         double delta = (final_pos - cur) / 7.0;
@@ -1490,7 +1592,7 @@ struct Filter {
                 if (q == lo[i] && cnt == 1) { d = std::move(src); continue; }
                 d.tr = src.tr; d.w_post = src.w_post; d.w_pilot = src.w_pilot;
                 d.next_base = src.next_base; d.Ltree = src.Ltree;
-                d.lookahead = src.lookahead;
+                d.lookahead = src.lookahead; d.ridx = src.ridx;
                 d.total_delayed = src.total_delayed; d.dcount = src.dcount;
                 for (int k = 0; k < src.dcount; ++k) { d.dpos[k] = src.dpos[k]; d.dfac[k] = src.dfac[k]; d.ddelta[k] = src.ddelta[k]; d.dk[k] = src.dk[k]; }
                 d.head = src.head;                       /* copyEventContainers: particle.cpp:139-148 */
@@ -1672,6 +1774,24 @@ void* smco_create(const smco_model* m, const smco_params* p) {
             M.bias_S.assign(m->bias_strengths, m->bias_strengths + m->n_bias_heights + 1);
             M.app_delays.assign(m->application_delays, m->application_delays + M.E);
             M.delay_type = m->delay_type;
+        }
+        if (m->n_rate_segments > 0) {
+            /* RecombinationBias::set_model_rates (pfparam.hpp:199-211): segments that start inside the locus */
+            M.guided = true;
+            for (int k = 0; k < m->n_rate_segments; ++k) {
+                if (!(m->rate_positions[k] < M.L)) break;
+                M.seg_pos.push_back(m->rate_positions[k]);
+                M.seg_rho.push_back(m->rate_values[k]);
+                for (int i = 0; i < M.n; ++i) M.leaf_rate.push_back(m->leaf_rel_rates[(size_t)k * M.n + i]);
+            }
+            if (M.seg_pos.empty() || M.seg_pos[0] != 0.0) throw std::runtime_error("recombination guide must start at position 0");
+            if (!M.biased) {
+                if (!m->application_delays) throw std::runtime_error("a recombination guide needs application_delays");
+                M.bias_H = {0.0, HUGE_VAL};
+                M.bias_S = {1.0};
+                M.app_delays.assign(m->application_delays, m->application_delays + M.E);
+                M.delay_type = m->delay_type;
+            }
         }
         f->Np = p->np; f->ess_fraction = p->ess_fraction; f->seed = p->seed;
         f->max_trace_events = p->max_trace_events;

@@ -49,6 +49,14 @@ typedef struct smco_model {
      * multiplies the particle's weights by exp_digamma(c)/c (particle.cpp:266-272); NULL = off */
     const double* vb_coal_counts;     /* [E*P] */
     const double* vb_mig_counts;      /* [E*P*P] or NULL */
+    /* recombination guide (-guide; RecombinationBias, pfparam.hpp:96-223): piecewise-constant sampling rate along the
+     * sequence with relative rates per sample; recombination_rate above stays the true rate.  0 segments = no guide.
+     * Needs application_delays (the importance weights of guided samples are applied with delay). */
+    int32_t n_rate_segments;
+    int32_t reserved2;
+    const double* rate_positions;     /* [K] segment starts (0-based, first = 0, no gaps) */
+    const double* rate_values;        /* [K] sampling recombination rate per bp per generation */
+    const double* leaf_rel_rates;     /* [K*nsam] relative rate of every sample's lineage */
 } smco_model;
 
 typedef struct smco_params {

@@ -45,6 +45,12 @@ static void dump_model_json(const PfParam& p) {
     for (size_t k = 0; k < m.sample_pops.size(); ++k) cout << (k ? ", " : "") << m.sample_pops[k];
     cout << "], \"record_event_in_epoch\": [";
     for (size_t k = 0; k < p.record_event_in_epoch.size(); ++k) cout << (k ? ", " : "") << p.record_event_in_epoch[k];
+    cout << "], \"guide_positions\": [";
+    for (size_t k = 0; k < p.guide_positions.size(); ++k) cout << (k ? ", " : "") << p.guide_positions[k];
+    cout << "], \"guide_rates\": [";
+    for (size_t k = 0; k < p.guide_rates.size(); ++k) cout << (k ? ", " : "") << p.guide_rates[k];
+    cout << "], \"guide_leaf_rates\": [";
+    for (size_t k = 0; k < p.guide_leaf_rates.size(); ++k) cout << (k ? ", " : "") << p.guide_leaf_rates[k];
     cout << "]}" << endl;
 }
 
@@ -125,8 +131,9 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
     // calculate_median_survival_distances is always run by the reference (smcsmc.cpp:287); its result feeds the
     // lags (when calibrating) and the application delays of the importance weights (smcsmc.cpp:306-307)
     const bool biased = !M.bias_heights.empty();
+    const bool guided = !P.guide_positions.empty();          // the calibration runs at the true rate (smcsmc.cpp:287-291)
     std::vector<double> med(E, 0.0), app_delays(E, 0.0);
-    if (P.calibrate_lag || biased) {
+    if (P.calibrate_lag || biased || guided) {
         int64_t trees = 0;
         pm.lags = lags.data();
         pf_check(pf_median_survival(&pm, 1, 200, 1000000, med.data(), &trees, device));
@@ -134,11 +141,22 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
     }
     if (P.calibrate_lag)
         for (int e = 0; e < E; ++e) lags[e] = med[e] * P.lag_fraction;      // reset_lag, count.cpp:261-265
-    if (biased) {
+    if (biased || guided) {
         for (int e = 0; e < E; ++e) {
             app_delays[e] = med[e] * P.delay;                                 // Model::lags_to_application_delays
             if (P.delay > 0) clog << " Application delay for epoch " << e << " set to " << app_delays[e] << endl;
         }
+        pm.delay_type = P.delay_type;
+        pm.application_delays = app_delays.data();
+    }
+    if (guided) {          // PfParam::setModelRates (pfparam.cpp:383-388)
+        cout << "Setting model rates" << endl;
+        pm.n_rate_segments = (int32_t)P.guide_positions.size();
+        pm.rate_positions = P.guide_positions.data();
+        pm.rate_values = P.guide_rates.data();
+        pm.leaf_rel_rates = P.guide_leaf_rates.data();
+    }
+    if (biased) {
         pm.n_bias_heights = (int32_t)M.bias_heights.size();
         pm.delay_type = P.delay_type;
         pm.bias_heights = M.bias_heights.data();

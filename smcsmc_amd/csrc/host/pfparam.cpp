@@ -4,6 +4,8 @@
 // flags the Python front-end emits (smcsmc/populationmodels.py:300-437) are understood.
 #include "smcsmc_host.hpp"
 
+#include <zlib.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -294,6 +296,68 @@ void PfParam::parse(int argc, char* argv[]) {
     clog << "Command line:-" << endl << cmdline << endl;
 }
 
+// RecombinationBias::parse_recomb_bias_file and operator>>(RecombBiasSegment) (pfparam.hpp:124-198): tab-separated
+// `locus size recomb_rate 1 .. n`, 0-based, no gaps, plain or gzipped; the records that start inside the locus are
+// the ones the model takes (set_model_rates, pfparam.hpp:202-212)
+void PfParam::parse_recomb_bias_file(const std::string& filename) {
+    gzFile in = gzopen(filename.c_str(), "rb");          // reads plain text as well
+    if (!in) {
+        cout << "Problem opening file " << filename << endl;
+        throw InvalidInput("Recombination guide file could not be opened.");
+    }
+    std::string text;
+    char buf[1 << 16];
+    int got;
+    while ((got = gzread(in, buf, sizeof buf)) > 0) text.append(buf, (size_t)got);
+    gzclose(in);
+    std::istringstream in_file(text);
+    std::string header, line, elt;
+    std::getline(in_file, header);
+    if (header.substr(0, 5) != "locus")
+        throw InvalidInput("Expected header line (with columns 'locus', 'size', 'recomb_rate', '1', ...) in recombination guide file");
+    long end = 0;
+    while (std::getline(in_file, line)) {
+        if (std::count(line.begin(), line.end(), ' ') > 0) {
+            cerr << "Found spaces in recombination record; columns must be tab-separated" << endl;
+            cerr << "Record: '" << line << "'" << endl;
+            throw InvalidInput("Found spaces in recombination record");
+        }
+        long locus = 0, size = 0;
+        double rate = 0;
+        std::vector<double> leaf;
+        std::stringstream iss(line);
+        if (!std::getline(iss, elt, '\t')) throw InvalidInput("Parse error on 1st element");
+        try {
+            locus = std::stoi(elt);
+            if (!std::getline(iss, elt, '\t')) throw InvalidInput("Parse error on 2nd element");
+            size = std::stoi(elt);
+            if (!std::getline(iss, elt, '\t')) throw InvalidInput("Parse error on 3rd element");
+            rate = std::stod(elt);
+            while (std::getline(iss, elt, '\t')) leaf.push_back(std::stod(elt));
+        } catch (const InvalidInput&) {
+            throw;
+        } catch (...) {
+            throw InvalidInput("Problem reading or parsing recombination guide file");
+        }
+        if (leaf.size() != default_nsam) {
+            cerr << "Problem on record at position " << locus << " with " << leaf.size() << " leaf columns; expected "
+                 << default_nsam << endl;
+            throw InvalidInput("Did not find expected number of leaf columns");
+        }
+        if (locus != end) {
+            cerr << "Problem on record at position " << locus << endl;
+            throw InvalidInput("Did not get expected locus position (records should start at 0, and leave no gaps)");
+        }
+        end = locus + size;
+        if ((double)locus < model.loci_length) {
+            guide_positions.push_back((double)locus);
+            guide_rates.push_back(rate);
+            guide_leaf_rates.insert(guide_leaf_rates.end(), leaf.begin(), leaf.end());
+        }
+    }
+    if (guide_positions.empty()) throw InvalidInput("Recombination guide file holds no records");
+}
+
 // pfparam.cpp:321-380
 void PfParam::finalize() {
     ESSthreshold = N * ESS_fraction;
@@ -310,9 +374,13 @@ void PfParam::finalize() {
         if (record_resample_file) remove(resample_NAME.c_str());
     }
     if (!pattern.empty()) throw Unsupported("-p (the Python front-end generates epochs itself)");
-    if (!input_RecombinationBiasFileName.empty()) throw Unsupported("-guide");
     model.nsam = (int)default_nsam;
     model.parse(scrm_tokens);
+    if (!input_RecombinationBiasFileName.empty()) {
+        if (model.npop > 1) throw Unsupported("-guide with more than one population");
+        if (default_nsam > 8) throw Unsupported("-guide with more than 8 samples");
+        parse_recomb_bias_file(input_RecombinationBiasFileName);
+    }
     default_loci_length = model.loci_length;
     if (model.change_times.back() >= top_t * 40000)
         throw std::invalid_argument("Problem: -tmax must be larger than bottom of final epoch");

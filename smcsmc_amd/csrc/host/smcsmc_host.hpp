@@ -186,6 +186,9 @@ class PfParam {   // pfparam.hpp:225-446
     std::vector<std::vector<double>> next_sizes, next_mig;
     double next_rho = 0;
     std::string cmdline;
+    // recombination guide (RecombinationBias, pfparam.hpp:152-223): segment starts, sampling rates, relative leaf rates
+    std::vector<double> guide_positions, guide_rates, guide_leaf_rates;
+    void parse_recomb_bias_file(const std::string& filename);
 
   private:
     void finalize();

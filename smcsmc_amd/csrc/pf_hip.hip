@@ -81,6 +81,11 @@ __global__ __launch_bounds__(PF_BS) void k_init(KArgs A, double initial_position
         root = n + ni;
     }
     ln.Ltree = tree_length(ln, n);
+    if (A.g_K > 0) {
+        // with a guide the first draw uses the rate of the first segment and stops at its end
+        ln.rho = A.g_rho[0];
+        if (A.g_K > 1 && A.g_pos[1] < A.L) ln.L = A.g_pos[1];
+    }
     double nb = sample_next_base(ln, 0.0);
     DState& st = A.st[0];
     for (int r = 0; r < n - 1; ++r) {
@@ -94,7 +99,8 @@ __global__ __launch_bounds__(PF_BS) void k_init(KArgs A, double initial_position
     st.x_mark[p] = 0.0;
     st.Ltree[p] = ln.Ltree;
     st.mark_limit[p] = A.E - 1;
-    if (A.n_bias > 0) { st.total_delayed[p] = 1.0; st.dcount[p] = 0; }
+    if (A.n_bias > 0 || A.g_K > 0) { st.total_delayed[p] = 1.0; st.dcount[p] = 0; }
+    if (A.g_K > 0) st.ridx[p] = 0;
     if (st.lookahead) st.lookahead[p] = 1.0;
     A.rng_ctr[p] = ln.ctr;
     A.ebuf[p] = ln.ebuf;
@@ -294,7 +300,7 @@ __device__ __forceinline__ void d_apply_earliest(DStore& d, double& w_pilot) {
 __device__ __forceinline__ void d_adjust_with_delay(DStore& d, double& w_post, double& w_pilot, double adj, double delay, double cur) {
     w_post *= adj;
     if ((adj > 0.99 && adj < 1.01) || (delay <= 1)) { w_pilot *= adj; return; }
-    if (d.count == PF_DCAP) d_apply_earliest(d, w_pilot);
+    while (d.count == PF_DCAP) d_apply_earliest(d, w_pilot);      // an entry leaves only with its third part
     d.total *= adj;
     double final_pos = cur + delay;
     double delta = (final_pos - cur) / 7.0;
@@ -350,6 +356,8 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
         cx.nb = A.n_bias + 1; cx.bH = sBH; cx.bS = sBS; cx.last_iw = 1.0;
         cx.want_desc = A.lmap_opp != nullptr; cx.last_desc = 0;
         cx.vbc = A.vb_coal; cx.upd_fac = 1.0;
+        cx.gK = BIASED ? A.g_K : 0; cx.gpos = A.g_pos; cx.grho = A.g_rho; cx.gleaf = A.g_leaf; cx.last_rbiw = 1.0;
+        cx.ridx = cx.gK > 0 ? from.ridx[a] : 0; cx.g_rp = 0; cx.g_sb = 0;
         DStore ds;
         if (BIASED) {
             ds.pos = st.dpos + p; ds.fac = st.dfac + p; ds.delta = st.ddelta + p; ds.k = st.dk + p; ds.Np = A.Np;
@@ -436,7 +444,24 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
             double f = fastexp(-A.mu * B * (new_to - updated_to));
             w_post *= f;
             w_pilot *= f;
+            if (BIASED && cx.gK > 0) {
+                // importance_weight_over_segment (particle.cpp:1138-1181): true over guide rate for the stretch
+                // without recombination
+                double dist = new_to - updated_to;
+                double target_rate = dist * A.rho * cx.Ltree;
+                double sampled_rate = dist * cx.grho[cx.ridx] * cx.Ltree;
+                double iws = fastexp(sampled_rate - target_rate);
+                w_post *= iws;
+                w_pilot *= iws;
+            }
             updated_to = new_to;
+            if (BIASED && cx.gK > 0 && updated_to < extend_to && cx.ridx + 1 < cx.gK && updated_to == cx.gpos[cx.ridx + 1]) {
+                // reached a change of the guide rate: no genealogy change, new draw under the new rate
+                // (particle.cpp:822-826); the open stretch continues
+                cx.ridx += 1;
+                next_base = r_sample_next_base(cx, updated_to);
+                continue;
+            }
             if (updated_to < extend_to) {
                 double* rec = rec_ptr(A, p, widx);
                 rec[0] = x_mark;
@@ -454,7 +479,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
                 if (leaf_status == 1) B = cx.Ltree;
                 if (BIASED) {
                     // particle.cpp:866-891: immediate vs delayed application of the importance weight
-                    double iw = cx.last_iw, rbiw = cx.last_iw;
+                    double iw = cx.last_iw, rbiw = cx.last_rbiw;
                     double delay_height = A.delay_type == 0 ? h : tc;
                     int idx = 0;
                     while (idx + 1 < cx.nb + 1 && sBH[idx + 1] < delay_height) ++idx;
@@ -480,6 +505,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
             }
             st.dcount[p] = ds.count;
             st.total_delayed[p] = ds.total;
+            if (cx.gK > 0) st.ridx[p] = cx.ridx;
             has_pending = ds.count > 0;
         }
         if (A.seg_state[s] == 0) {
@@ -1432,7 +1458,8 @@ __global__ __launch_bounds__(PF_BS) void k_resample(KArgs A, long long s, int nb
     dst.x_mark[q] = pos;
     dst.mark_limit[q] = src.mark_limit[a];
     if (A.apf > 0) dst.lookahead[q] = src.lookahead[a];
-    if (A.n_bias > 0) {
+    if (A.g_K > 0) dst.ridx[q] = src.ridx[a];
+    if (A.n_bias > 0 || A.g_K > 0) {
         // the copy constructor copies the pending factors (particle.cpp:122-123)
         int dc = src.dcount[a];
         dst.dcount[q] = dc;
@@ -1451,6 +1478,12 @@ __global__ __launch_bounds__(PF_BS) void k_resample(KArgs A, long long s, int nb
         ln.E = A.E; ln.n = n; ln.L = A.L; ln.mu = A.mu; ln.rho = A.rho; ln.seed = A.seed;
         ln.slot = (unsigned)q; ln.stream = 0; ln.ctr = A.rng_ctr[q]; ln.ebuf = A.ebuf[q]; ln.Ltree = Lt;
         ln.S = nullptr; ln.C = nullptr; ln.T = nullptr; ln.I = nullptr; ln.RF = nullptr;
+        if (A.g_K > 0) {
+            // with a guide: the rate of the copy's segment, the draw limited to the segment
+            const int ri = src.ridx[a];
+            ln.rho = A.g_rho[ri];
+            if (ri + 1 < A.g_K && A.g_pos[ri + 1] < A.L) ln.L = A.g_pos[ri + 1];
+        }
         nb = sample_next_base(ln, pos);
         A.rng_ctr[q] = ln.ctr;
         A.ebuf[q] = ln.ebuf;
@@ -1910,6 +1943,12 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     if (m->n_bias_heights > 0 && m->nsam > 8) return fail("pf_create: focused sampling is implemented for nsam <= 8");
     if (m->n_bias_heights > 0 && (!m->bias_heights || !m->bias_strengths || !m->application_delays))
         return fail("pf_create: bias_heights, bias_strengths and application_delays must all be given");
+    if (m->n_rate_segments > 0) {
+        if (m->n_pops != 1 || m->nsam > 8) return fail("pf_create: a recombination guide is implemented for one population and nsam <= 8");
+        if (!m->rate_positions || !m->rate_values || !m->leaf_rel_rates || !m->application_delays)
+            return fail("pf_create: rate_positions, rate_values, leaf_rel_rates and application_delays must all be given with a guide");
+        if (m->rate_positions[0] != 0.0) return fail("pf_create: the recombination guide must start at position 0");
+    }
     pf_handle* h = new pf_handle();
     h->device = device;
     if (hipSetDevice(device) != hipSuccess) { delete h; return fail("hipSetDevice failed"); }
@@ -1976,9 +2015,9 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     for (int k = 0; k < PF_BIAS_MAX + 2; ++k) A.bias_H[k] = HUGE_VAL;
     for (int k = 0; k < PF_BIAS_MAX + 1; ++k) A.bias_S[k] = 1.0;
     A.bias_H[0] = 0.0;
-    if (A.n_bias > 0) {
+    if (A.n_bias > 0 || m->n_rate_segments > 0) {
         for (int k = 0; k < A.n_bias; ++k) A.bias_H[k + 1] = m->bias_heights[k];
-        for (int k = 0; k <= A.n_bias; ++k) A.bias_S[k] = m->bias_strengths[k];
+        for (int k = 0; k <= A.n_bias && A.n_bias > 0; ++k) A.bias_S[k] = m->bias_strengths[k];
         double* dad;
         if (dalloc(h, &dad, E)) { pf_destroy(h); return nullptr; }
         hipMemcpy(dad, m->application_delays, E * 8, hipMemcpyHostToDevice);
@@ -2000,7 +2039,8 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
             rc |= dalloc(h, &A.st[b].Mb, (size_t)PF_MMAX * Np);
             rc |= dalloc(h, &A.st[b].Mq, (size_t)PF_MMAX * Np);
         }
-        if (m->n_bias_heights > 0) {
+        if (m->n_rate_segments > 0) rc |= dalloc(h, &A.st[b].ridx, Np);
+        if (m->n_bias_heights > 0 || m->n_rate_segments > 0) {
             rc |= dalloc(h, &A.st[b].total_delayed, Np);
             rc |= dalloc(h, &A.st[b].dcount, Np);
             rc |= dalloc(h, &A.st[b].dpos, (size_t)PF_DCAP * Np);
@@ -2014,6 +2054,20 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
         A.lmap_bins = (long long)(m->loci_length / 100.0) + 4;
         rc |= dalloc(h, &A.lmap_opp, (size_t)A.lmap_bins);
         rc |= dalloc(h, &A.lmap_cnt, (size_t)(n + 2) * A.lmap_bins);
+    }
+    if (m->n_rate_segments > 0) {
+        // RecombinationBias::set_model_rates (pfparam.hpp:199-211): the segments that start inside the locus
+        int K = 0;
+        while (K < m->n_rate_segments && m->rate_positions[K] < m->loci_length) ++K;
+        double *gp, *gr, *gl;
+        rc |= dalloc(h, &gp, K); rc |= dalloc(h, &gr, K); rc |= dalloc(h, &gl, (size_t)K * n);
+        if (!rc) {
+            hipMemcpyAsync(gp, m->rate_positions, (size_t)K * 8, hipMemcpyHostToDevice, h->stream);
+            hipMemcpyAsync(gr, m->rate_values, (size_t)K * 8, hipMemcpyHostToDevice, h->stream);
+            hipMemcpyAsync(gl, m->leaf_rel_rates, (size_t)K * n * 8, hipMemcpyHostToDevice, h->stream);
+            hipStreamSynchronize(h->stream);
+        }
+        A.g_K = K; A.g_pos = gp; A.g_rho = gr; A.g_leaf = gl;
     }
     rc |= dalloc(h, &A.rng_ctr, Np);
     rc |= dalloc(h, &A.ebuf, Np);
@@ -2228,7 +2282,7 @@ static Windows no_windows(pf_handle* h) {
 
 // the register-tree kernels can complete the previous row while loading the particle (fused k_resample)
 static bool extend_can_fuse(const pf_handle* h) {
-    return h->P == 1 && h->n <= 8 && (h->A.n_bias > 0 || !h->force_lds) && !h->no_fuse && h->A.apf == 0;
+    return h->P == 1 && h->n <= 8 && (h->A.n_bias > 0 || h->A.g_K > 0 || !h->force_lds) && !h->no_fuse && h->A.apf == 0;
 }
 
 static int launch_extend(pf_handle* h, long long s, int fuse = 0) {
@@ -2236,7 +2290,7 @@ static int launch_extend(pf_handle* h, long long s, int fuse = 0) {
     {
         Timed tm(h, 0, t);
         const size_t smem_reg = (size_t)(2 * h->E + 2 * PF_BIAS_MAX + 3) * 8;
-        const bool biased = h->A.n_bias > 0;
+        const bool biased = h->A.n_bias > 0 || h->A.g_K > 0;
         if (h->P > 1)
             pf_mp_launch_extend(h->A, s, h->smem, h->stream);
         else if (h->n <= 4 && biased)
@@ -2377,7 +2431,7 @@ static void launch_row(pf_handle* h, long long s, int fuse, int count_first, con
 }
 
 static int run_single_stream(pf_handle* h, long long s_begin, long long s_end) {
-    const bool biased = h->A.n_bias > 0;
+    const bool biased = h->A.n_bias > 0 || h->A.g_K > 0;
     bool pending = false;             // counts + ledger of the previous row still to be launched
     Windows Wprev = no_windows(h);
     // whatever the two-stream kernels of an earlier call left on the counting stream must be done first

@@ -63,6 +63,13 @@ struct RCtx {
     const double* bH;
     const double* bS;
     double last_iw;
+    double last_rbiw;     // importance weight of the height bias alone (recombination_bias_importance_weight_)
+    // recombination guide (RecombinationBias, pfparam.hpp:96-223); gK == 0: none
+    int gK, ridx;
+    const double* gpos;   // [gK] segment starts
+    const double* grho;   // [gK] sampling rate per segment
+    const double* gleaf;  // [gK*n] relative rate per sample
+    int g_rp, g_sb;       // slot chosen by the guided sampler
     const double* vbc;    // variational-Bayes factor per epoch of a coalescence (particle.cpp:266-272), or null
     double upd_fac;       // the factor of the current update
     unsigned last_desc;   // samples below the branch cut by the last update (only computed when want_desc)
@@ -226,12 +233,18 @@ __device__ __forceinline__ double r_coalesce_up(RCtx& cx, const RTree<NM>& t, in
 }
 
 __device__ __forceinline__ double r_sample_next_base(RCtx& cx, double x) {
-    double rate = cx.rho * cx.Ltree;
-    double limit = cx.L - x;
+    // with a guide: the rate of the particle's current segment, the draw limited to the segment (particle.cpp:1203-1232)
+    double rho_here = cx.rho, seg_end = cx.L;
+    if (cx.gK > 0) {
+        rho_here = cx.grho[cx.ridx];
+        if (cx.ridx + 1 < cx.gK) { double nxt = cx.gpos[cx.ridx + 1]; if (nxt < cx.L) seg_end = nxt; }
+    }
+    double rate = rho_here * cx.Ltree;
+    double limit = seg_end - x;
     double need = limit * rate;
     if (cx.ebuf > need) {
         cx.ebuf -= need;
-        return cx.L;
+        return seg_end;
     }
     double nb = x + cx.ebuf / rate;
     cx.ebuf = -dlog(r_uni(cx));
@@ -239,7 +252,7 @@ __device__ __forceinline__ double r_sample_next_base(RCtx& cx, double x) {
         nb = __longlong_as_double(__double_as_longlong(x) + 1);
         if (x == 0.0) nb = 4.9406564584124654e-324;
     }
-    if (nb > cx.L) nb = cx.L;
+    if (nb > seg_end) nb = seg_end;
     return nb;
 }
 
@@ -309,14 +322,129 @@ __device__ __forceinline__ void r_sample_point_biased(RCtx& cx, const RTree<NM>&
     *lin_out = lin;
 }
 
+// samplePoint with a recombination guide (particle.cpp:942-1126): every branch carries a relative rate -- leaf: the guide's
+// rate for that sample in the particle's segment; binary node: the arithmetic mean of its children; the two branches
+// below the root: the larger of the two -- times the strength of its height band.  Pieces are visited branch by branch in
+// slot order (rank ascending, child 0 then 1), bands ascending; same operation order as the oracle.
+template <int NM>
+__device__ __forceinline__ void r_sample_point_guided(RCtx& cx, const RTree<NM>& t, bool height_bias, double* h_out) {
+    constexpr int NI = RTree<NM>::NI;
+    const int n = cx.n;
+    const int nb = cx.nb;
+    const double* lr = cx.gleaf + (size_t)cx.ridx * n;
+    double bl[NM], bn[NI];
+#pragma unroll
+    for (int i = 0; i < NM; ++i) bl[i] = i < n ? lr[i] : 0.0;
+    auto rate_of = [&](int id, int upto) __attribute__((always_inline)) {
+        double v = 0.0;
+#pragma unroll
+        for (int i = 0; i < NM; ++i) v = (id == i) ? bl[i] : v;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) if (k < upto) v = (id - n == k) ? bn[k] : v;
+        return v;
+    };
+#pragma unroll
+    for (int rr = 0; rr < NI; ++rr) {
+        bn[rr] = 0.0;
+        if (rr < n - 1) bn[rr] = (rate_of(t.C0[rr], rr) + rate_of(t.C1[rr], rr)) * 0.5;
+    }
+    const int c0r = t.getC(n - 2, 0), c1r = t.getC(n - 2, 1);
+    const double ra = rate_of(c0r, NI), rbb = rate_of(c1r, NI);
+    const double rroot = ra > rbb ? ra : rbb;
+    // pass 1: weighted length
+    double Lw = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < NI; ++rr)
+        if (rr < n - 1) {
+            const double hi_b = t.S[rr];
+#pragma unroll
+            for (int sdx = 0; sdx < 2; ++sdx) {
+                const int c = sdx ? t.C1[rr] : t.C0[rr];
+                const double rb = (rr == n - 2) ? rroot : rate_of(c, NI);
+                const double lo_b = r_node_h(t, n, c);
+                for (int b = 0; b < nb; ++b) {
+                    double lo_ = lo_b > cx.bH[b] ? lo_b : cx.bH[b];
+                    double hi_ = hi_b < cx.bH[b + 1] ? hi_b : cx.bH[b + 1];
+                    if (hi_ > lo_) Lw += (rb * cx.bS[b]) * (hi_ - lo_);
+                    if (cx.bH[b + 1] >= hi_b) break;
+                }
+            }
+        }
+    // pass 2: the piece that holds U * Lw
+    double rr_ = r_uni(cx) * Lw;
+    double l_lo = 0, l_hi = 0, l_wt = 1;
+    bool sel = false;
+    int g_rp = 0, g_sb = 0;
+#pragma unroll
+    for (int rr = 0; rr < NI; ++rr)
+        if (rr < n - 1 && !sel) {
+            const double hi_b = t.S[rr];
+#pragma unroll
+            for (int sdx = 0; sdx < 2; ++sdx)
+                if (!sel) {
+                    const int c = sdx ? t.C1[rr] : t.C0[rr];
+                    const double rb = (rr == n - 2) ? rroot : rate_of(c, NI);
+                    const double lo_b = r_node_h(t, n, c);
+                    for (int b = 0; b < nb; ++b) {
+                        double lo_ = lo_b > cx.bH[b] ? lo_b : cx.bH[b];
+                        double hi_ = hi_b < cx.bH[b + 1] ? hi_b : cx.bH[b + 1];
+                        if (hi_ > lo_) {
+                            double wt = rb * cx.bS[b];
+                            double wlen = wt * (hi_ - lo_);
+                            l_lo = lo_; l_hi = hi_; l_wt = wt; g_rp = rr; g_sb = sdx;
+                            if (rr_ < wlen) { sel = true; break; }
+                            rr_ -= wlen;
+                        }
+                        if (cx.bH[b + 1] >= hi_b) break;
+                    }
+                }
+        }
+    double h = l_lo + rr_ / l_wt;
+    if (!(h < l_hi)) h = l_lo;
+    if (h < l_lo) h = l_lo;
+    const double sampled = l_wt / Lw;
+    const double target = 1.0 / cx.Ltree;
+    cx.last_iw = target / sampled;
+    cx.last_iw *= cx.rho / cx.grho[cx.ridx];       // the position was drawn at the guide's rate
+    cx.last_rbiw = 1.0;
+    if (height_bias) {
+        // importance weight of the height bias alone (particle.cpp:1113-1121)
+        double Lrw = 0.0, pv = 0.0;
+#pragma unroll
+        for (int ri = 0; ri < NI; ++ri)
+            if (ri < n - 1) {
+                const int k = n - ri;
+                const double top = t.S[ri];
+                for (int b = 0; b < nb; ++b) {
+                    double lo_ = pv > cx.bH[b] ? pv : cx.bH[b];
+                    double hi_ = top < cx.bH[b + 1] ? top : cx.bH[b + 1];
+                    if (hi_ > lo_) Lrw += ((double)k * cx.bS[b]) * (hi_ - lo_);
+                    if (cx.bH[b + 1] >= top) break;
+                }
+                pv = top;
+            }
+        int idx = 0;
+        while (idx + 1 < nb && cx.bH[idx + 1] < h) ++idx;
+        const double recomb_density = cx.bS[idx] / Lrw;
+        cx.last_rbiw = target / recomb_density;
+    }
+    cx.g_rp = g_rp; cx.g_sb = g_sb;
+    *h_out = h;
+}
+
 // One SMC' genealogy update; mirrors genealogy_update() in pf_hip.hip / Filter::genealogy_update in the oracle.
 template <int NM, bool BIASED>
 __device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, double* h_out, double* tc_out) {
     const int n = cx.n;
     double h = 0.0;
     int lin = 0;
-    if (BIASED) {
+    bool guided_pt = false;
+    if (BIASED && cx.gK > 0 && cx.stream == 0) {
+        r_sample_point_guided(cx, t, cx.nb > 1, &h);
+        guided_pt = true;
+    } else if (BIASED) {
         r_sample_point_biased(cx, t, &h, &lin);
+        cx.last_rbiw = cx.last_iw;
     } else {
         double r = r_uni(cx) * cx.Ltree;
         double prev = 0.0;
@@ -342,7 +470,8 @@ __device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, doubl
         }
     }
     int rp = 0, sb = 0;
-    r_lineages_at(t, n, n - 1, h, lin, &rp, &sb);
+    if (guided_pt) { rp = cx.g_rp; sb = cx.g_sb; }
+    else r_lineages_at(t, n, n - 1, h, lin, &rp, &sb);
     *h_out = h;
     if (cx.want_desc) {
         // get_descendants (descendants.hpp:22-33) of the cut branch on the tree before it changes: masks bottom-up

@@ -30,6 +30,7 @@ struct DState {
     double* dfac;            // [PF_DCAP][Np]
     double* ddelta;          // [PF_DCAP][Np]
     int* dk;                 // [PF_DCAP][Np]
+    int* ridx;               // [Np] guide segment the particle is in (_current_seq_idx); allocated with a guide
     double* lookahead;       // [Np] lookahead_weight_ (auxiliary particle filter); allocated with pf_load_lookahead
     // structured models (pf_mp.h); allocated only when P > 1
     int8_t* Pn;              // [(n-1)][Np] population of every coalescent node
@@ -99,6 +100,9 @@ struct KArgs {
     // counts so that they carry the device's exp / log; null = off
     const double* vb_coal;         // [E*P]
     const double* vb_mig;          // [E*P*P]
+    // recombination guide (RecombinationBias, pfparam.hpp:96-223): g_K segments (0 = none)
+    int g_K;
+    const double* g_pos; const double* g_rho; const double* g_leaf;
     // run parameters
     long long Np;
     double ess_threshold;

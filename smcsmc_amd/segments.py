@@ -371,3 +371,42 @@ def pack_lookahead(rows, nsam):
         out["split_alleles"][i] = la["split_alleles"]
         out["split_count"][i] = la["split_count"]
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Recombination guide files (RecombinationBias::parse_recomb_bias_file, pfparam.hpp:171-198)
+
+def read_guide(path, nsam):
+    """Reads a recombination guide (`locus size recomb_rate 1 .. n`, tab separated, plain or .gz, 0-based, no gaps)
+    into the dict the model takes: positions[K], rates[K], leaf_rates[K][nsam]."""
+    import gzip
+    opener = gzip.open if path.endswith(".gz") else open
+    try:
+        f = opener(path, "rt")
+    except OSError:
+        raise InvalidSeg("Recombination guide file could not be opened.")
+    pos, rates, leaves = [], [], []
+    with f:
+        header = f.readline()
+        if header[:5] != "locus":
+            raise InvalidSeg("Expected header line (with columns 'locus', 'size', 'recomb_rate', '1', ...) in recombination guide file")
+        end = 0
+        for line in f:
+            line = line.rstrip("\n")
+            if not line:
+                continue
+            if " " in line:
+                raise InvalidSeg("Found spaces in recombination record")
+            elts = line.split("\t")
+            try:
+                locus, size, rate = int(elts[0]), int(elts[1]), float(elts[2])
+                lr = [float(v) for v in elts[3:]]
+            except (ValueError, IndexError):
+                raise InvalidSeg("Problem reading or parsing recombination guide file")
+            if len(lr) != nsam:
+                raise InvalidSeg("Did not find expected number of leaf columns")
+            if locus != end:
+                raise InvalidSeg("Did not get expected locus position (records should start at 0, and leave no gaps)")
+            end = locus + size
+            pos.append(float(locus)); rates.append(rate); leaves.append(lr)
+    return dict(positions=np.array(pos), rates=np.array(rates), leaf_rates=np.array(leaves).reshape(len(pos), nsam))

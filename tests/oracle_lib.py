@@ -26,6 +26,9 @@ class Model(C.Structure):
         ("bias_heights", C.POINTER(C.c_double)), ("bias_strengths", C.POINTER(C.c_double)),
         ("application_delays", C.POINTER(C.c_double)),
         ("vb_coal_counts", C.POINTER(C.c_double)), ("vb_mig_counts", C.POINTER(C.c_double)),
+        ("n_rate_segments", C.c_int32), ("reserved2", C.c_int32),
+        ("rate_positions", C.POINTER(C.c_double)), ("rate_values", C.POINTER(C.c_double)),
+        ("leaf_rel_rates", C.POINTER(C.c_double)),
     ]
 
 
@@ -118,6 +121,20 @@ def attach_structure(owner, cmodel, m, E, P):
     if m.get("single_mig") is not None:
         owner._smig = np.ascontiguousarray(m["single_mig"], dtype=np.float64).reshape(E * P * P)
         cmodel.single_mig = _dp(owner._smig)
+    if m.get("guide") is not None:
+        # recombination guide: dict(positions[K], rates[K], leaf_rates[K][nsam]) (RecombinationBias, pfparam.hpp:96-223)
+        gd = m["guide"]
+        owner._gpos = np.ascontiguousarray(gd["positions"], dtype=np.float64)
+        owner._grate = np.ascontiguousarray(gd["rates"], dtype=np.float64)
+        owner._gleaf = np.ascontiguousarray(gd["leaf_rates"], dtype=np.float64).reshape(len(owner._gpos) * cmodel.nsam)
+        cmodel.n_rate_segments = len(owner._gpos)
+        cmodel.rate_positions = _dp(owner._gpos)
+        cmodel.rate_values = _dp(owner._grate)
+        cmodel.leaf_rel_rates = _dp(owner._gleaf)
+        if not cmodel.application_delays:
+            owner._gad = np.ascontiguousarray(m["application_delays"], dtype=np.float64)
+            cmodel.application_delays = _dp(owner._gad)
+            cmodel.delay_type = int(m.get("delay_type", 0))
     if m.get("vb_coal_counts") is not None:
         # variational-Bayes event counts: [E][P] per coalescence, [E][P][P] per migration (-vb)
         owner._vbc = np.ascontiguousarray(m["vb_coal_counts"], dtype=np.float64).reshape(E * P)

@@ -519,3 +519,92 @@ def test_device_exp_digamma(oracle, hiplib):
     expect = np.exp(digamma(c[:, 0])) / c[:, 0]
     for v in np.unique(w):
         assert np.min(np.abs(expect / v - 1)) < 2e-3                     # the reference's asymptotic series, not exact digamma
+
+
+# ---------------------------------------------------------------- recombination guide (-guide)
+
+def _guide(model, K, spread, seed):
+    rng = np.random.default_rng(seed)
+    L, n = model["loci_length"], model["nsam"]
+    pos = np.floor(np.arange(K) * L / K)
+    rates = model["recombination_rate"] * rng.uniform(1.0 / spread, spread, K)
+    leaf = rng.uniform(1.0 / spread, spread, (K, n))
+    leaf /= leaf.sum(1, keepdims=True)
+    return dict(positions=pos, rates=rates, leaf_rates=leaf)
+
+
+@pytest.mark.parametrize("n,bias", [(4, False), (4, True), (7, True), (2, False)])
+def test_recombination_guide_parity(oracle, hiplib, n, bias):
+    """Position-dependent sampling rate with per-sample relative rates (RecombinationBias, pfparam.hpp:96-223;
+    samplePoint / importance_weight_over_segment / sampleNextBase, particle.cpp:942-1254), with and without the height
+    bias: trees, weights, delayed factors, ESS and resampling indices bit-identical to the oracle."""
+    E = 6
+    model = cases.make_model(n=n, E=E, L=1.2e5)
+    segs = cases.make_segments(model, seed=70 + n, max_seg_len=5000)
+    extra = dict(guide=_guide(model, 9, 2.5, n), application_delays=np.full(E, 3000.0))
+    if bias:
+        extra.update(bias_heights=[400.0], bias_strengths=[3.0, 1.0])
+    model = dict(model, **extra)
+    o, si, g = _run_both(oracle, model, segs, 400, seed=6)
+    o.run(si); g.run(); g.finish()
+    to, tg = o.trace(), g.trace()
+    assert (to["resampled"] == tg["resampled"]).all() and to["resampled"].sum() > 0
+    for k in ("T", "ess", "logl"):
+        assert (_bits(to[k]) == _bits(tg[k])).all(), k
+    so, po_ = o.resample_events(); sg_, pg_ = g.resample_events()
+    assert (so == sg_).all() and (po_ == pg_).all()
+    _assert_state_equal(o, g)
+    _assert_counts_close(o.counts(), g.counts())
+
+
+def test_recombination_guide_is_an_importance_sampler_of_the_model(hiplib):
+    """Without data the weights of the guided sampler average to one and the lagged counts recover the model's
+    rates -- the true recombination rate, not the guide's (importance_weight_over_segment + the event weights)."""
+    from smcsmc_amd import ParticleFilter
+    E = 6
+    model = cases.make_model(n=4, E=E, L=2e6)
+    model = dict(model, guide=_guide(model, 8, 1.4, 1), application_delays=np.full(E, 5000.0))
+    assert abs(model["guide"]["rates"].mean() / 1e-8 - 1) > 0.02          # the guide is off on average
+    segs = cases.nodata_segments(model, 4000.0)
+    g = ParticleFilter(model, 4096, seed=3); g.init_prior(0.0); g.load_segments(segs); g.run(); g.finish()
+    c = g.counts()
+    assert abs(c["rec_count"].sum() / c["rec_opp"].sum() / 1e-8 - 1) < 0.01
+    coal = c["coal_count"][2:5] / c["coal_opp"][2:5] * 2e4
+    assert np.abs(coal - 1).max() < 0.03
+    assert abs(g.logl()) < 0.5
+
+
+def test_binary_recombination_guide(hiplib, tmp_path):
+    """bin/smcsmc -guide file equals the library run with the guide read by the Python mirror and the application
+    delays from the calibration at the true rate (smcsmc.cpp:287-307), character for character."""
+    import json
+    import os
+    import subprocess
+    from smcsmc_amd import ParticleFilter, outfile, pf, segments as segmod
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    binary = os.path.join(root, "bin", "smcsmc")
+    seg = os.path.join(root, "tests", "golden", "seg", "constpopsize_first3000.seg")
+    L = 1000000
+    rng = np.random.default_rng(5)
+    guide = tmp_path / "guide.txt"
+    with open(guide, "w") as f:
+        f.write("locus\tsize\trecomb_rate\t1\t2\n")
+        for k in range(10):
+            lr = rng.uniform(0.5, 2.0, 2)
+            f.write("%d\t%d\t%.6g\t%s\n" % (k * 100000, 100000, 1e-8 * rng.uniform(0.6, 1.6), "\t".join("%.4f" % v for v in lr / lr.sum())))
+    core = ("-N0 10000 -t %g -r %g %d -eN 0 1 -eN 0.01 1 -eN 0.25 1 -eN 1 1" % (4e4 * 2.5e-8 * L, 4e4 * 1e-8 * L, L)).split()
+    r = subprocess.run([binary] + core + ["-nsam", "2", "-Np", "300", "-EM", "0", "-tmax", "4", "-lag", "20000", "-seed", "4",
+                                          "-guide", str(guide), "-seg", seg, "-o", str(tmp_path / "gd")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Setting model rates" in r.stdout
+    m = json.loads(subprocess.run([binary] + core + ["-nsam", "2", "-tmax", "4", "-dumpmodel"], capture_output=True, text=True).stdout)
+    E = len(m["change_times"])
+    model = dict(change_times=np.array(m["change_times"]), pop_sizes=np.array(m["pop_sizes"])[:, 0], lags=np.full(E, 20000.0),
+                 nsam=2, loci_length=float(L), mutation_rate=m["mutation_rate"], recombination_rate=m["recombination_rate"])
+    med, _ = pf.median_survival(model, seed=1, min_events=200, max_trees=1000000)
+    model = dict(model, guide=segmod.read_guide(str(guide), 2), application_delays=med * 0.5)
+    S = segmod.Segments(seg, 2, L, max_segment_length=int(2.0 / (m["recombination_rate"] * 4 * m["N0"])))
+    segs = S.pack(model["lags"])
+    g = ParticleFilter(model, 300, seed=4, max_trace_events=0)
+    g.init_prior(segs["start"][0]); g.load_segments(segs); g.run(); g.finish()
+    assert outfile.outfile_text(model, g.counts(), 300) == open(tmp_path / "gd.out").read()

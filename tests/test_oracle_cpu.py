@@ -309,3 +309,24 @@ def test_isolated_populations_cannot_coalesce(oracle):
     o = oracle.Oracle(model, 4, seed=1)
     with pytest.raises(RuntimeError, match="No final coalescence"):
         o.init_prior(0.0)
+
+
+def test_recombination_guide_importance_weights_are_unbiased(oracle):
+    """A guide that is off from the model (sampling rates 0.7-1.4 x the true rate, uneven leaf rates), no data: the
+    weighted counts still recover the model's recombination and coalescence rates and the likelihood stays at one
+    (importance_weight_over_segment, particle.cpp:1159-1192; the event weights of samplePoint, particle.cpp:942-1010)."""
+    n, E, L, K = 4, 6, 1e6, 8
+    model = cases.make_model(n=n, E=E, L=L)
+    rng = np.random.default_rng(1)
+    leaf = rng.uniform(0.6, 1.4, (K, n))
+    guide = dict(positions=np.arange(K) * L / K, rates=1e-8 * rng.uniform(0.7, 1.4, K), leaf_rates=leaf / leaf.sum(1, keepdims=True))
+    segs = cases.nodata_segments(model, 4000.0)
+    for extra in (dict(), dict(bias_heights=[400.0], bias_strengths=[3.0, 1.0])):
+        m = dict(model, guide=guide, application_delays=np.full(E, 5000.0), **extra)
+        o = oracle.Oracle(m, 1500, seed=3)
+        o.init_prior(0.0)
+        o.run(o.pack_segments(m, segs))
+        c = o.counts()
+        assert abs(c["rec_count"].sum() / c["rec_opp"].sum() / 1e-8 - 1) < 0.02
+        assert np.abs(c["coal_count"][2:5] / c["coal_opp"][2:5] * 2e4 - 1).max() < 0.06
+        assert abs(o.logl()) < 0.5
