@@ -1948,6 +1948,12 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
         if (!m->rate_positions || !m->rate_values || !m->leaf_rel_rates || !m->application_delays)
             return fail("pf_create: rate_positions, rate_values, leaf_rel_rates and application_delays must all be given with a guide");
         if (m->rate_positions[0] != 0.0) return fail("pf_create: the recombination guide must start at position 0");
+        for (int k = 0; k < m->n_rate_segments; ++k) {
+            if (k && !(m->rate_positions[k] > m->rate_positions[k - 1])) return fail("pf_create: guide segment starts must increase");
+            if (!(m->rate_values[k] > 0)) return fail("pf_create: guide recombination rates must be positive");
+            for (int i = 0; i < m->nsam; ++i)
+                if (!(m->leaf_rel_rates[(size_t)k * m->nsam + i] > 0)) return fail("pf_create: relative leaf rates of the guide must be positive");
+        }
     }
     pf_handle* h = new pf_handle();
     h->device = device;

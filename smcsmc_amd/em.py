@@ -18,7 +18,7 @@ import itertools
 
 import numpy as np
 
-from . import outfile, pf, reduce as reducer
+from . import outfile, pf, recombguide, reduce as reducer
 
 
 class PopulationModel:
@@ -208,30 +208,43 @@ def m_step(pop, data, vb=False, vb_dirichlet=None, maxNE=1e99, infer_recomb=True
 
 
 def run_em(pop, chunks, iterations, np_particles, seed=1, ess_fraction=0.5, lag_fraction=2.0, vb=False, maxNE=1e99,
-           infer_recomb=True, rounded=True, device=0, rank=0, world=1, on_iteration=None, concurrent=4):
+           infer_recomb=True, rounded=True, device=0, rank=0, world=1, on_iteration=None, concurrent=4,
+           alpha=0.0, beta=4.0, delay=0.5, guides=None):
     """EM over `chunks` (each a packable Segments object of smcsmc_amd.segments).  Chunks are sharded over ranks
     (reduce.assign_chunks, longest first); statistics are summed in chunk order on every rank, so all ranks take
     identical M-steps.  Up to `concurrent` chunks of a rank are filtered at the same time (one host thread and one
     stream pair each): a single chunk keeps only ~150 wavefronts busy, four chunks scale 4x on one MI355X.
+    With `alpha` > 0 the local recombination map of every chunk becomes that chunk's recombination guide of the next
+    iteration (Smcsmc.do_iteration, model.py:1129-1143: LocalRecombination(...).smooth(alpha, beta) -> `-guide`), kept
+    in memory on the rank that owns the chunk; `guides` (dict chunk -> guide), if given, receives them.
     Returns (final model, list of per-iteration summed statistics)."""
     from concurrent.futures import ThreadPoolExecutor
     pop = copy.deepcopy(pop) if on_iteration is None else pop
     history = []
     sizes = [len(c) for c in chunks]
     mine = reducer.assign_chunks(sizes, world)[rank]
+    guides = {} if guides is None else guides
+    if alpha > 0 and (pop.num_populations != 1 or pop.num_samples > 8):
+        raise pf.PfError("recombination guiding (alpha > 0) is implemented for one population and up to 8 samples")
     for it in range(iterations + 1):
         base = pop.device_model()
         lags = pf.calibrated_lags(base, lag_fraction=lag_fraction, device=device)     # model-only: once per iteration
         model = pop.device_model(lags=lags, vb=vb)
         def e_step(c):
             segs = chunks[c].pack(lags)
-            f = pf.ParticleFilter(model, np_particles, ess_fraction=ess_fraction, seed=seed + 1000 * it + c,
-                                  max_trace_events=0, device=device)
+            m_c = model
+            if c in guides:          # application delays: Model::lags_to_application_delays (smcsmc.cpp:306-307)
+                m_c = dict(model, guide=guides[c], application_delays=lags / lag_fraction * delay)
+            f = pf.ParticleFilter(m_c, np_particles, ess_fraction=ess_fraction, seed=seed + 1000 * it + c,
+                                  max_trace_events=0, device=device, local_recomb=alpha > 0)
             f.load_segments(segs)
             f.init_prior(float(segs["start"][0]))
             f.run()
             f.finish()
             data = counts_to_data(model, f.counts(), np_particles, rounded=rounded)
+            if alpha > 0 and it < iterations:
+                lr = recombguide.LocalRecombination.from_filter(f.local_recomb(), pop.num_samples)
+                guides[c] = lr.smooth(alpha, beta).guide(rounded=rounded)
             f.close()
             return c, data
 

@@ -81,3 +81,37 @@ def test_in_process_em_loop(hiplib):
     # the argv a front-end would launch next is well-formed for the binary's parser
     line = final.core_command_line()
     assert line.startswith("-N0 10000 -t ") and line.count("-eN") == 6
+
+
+def test_guided_em_loop(hiplib):
+    """alpha > 0: the local recombination map of iteration i becomes the recombination guide of iteration i + 1
+    (Smcsmc.do_iteration, model.py:1129-1143; processrecombination.py) without leaving the process."""
+    from smcsmc_amd import em, segments as segmod
+    n, L = 4, 1.5e6
+    truth = cases.make_model(n=n, E=6, L=L)
+    chunks = []
+    for seed in (21, 22):
+        packed = cases.make_segments(truth, seed=seed, max_seg_len=5000)
+        S = segmod.Segments.__new__(segmod.Segments)
+        S.file_name = "<memory>"; S.nsam = n; S.seqlen = L; S.data_start = 1; S.max_segment_length = 5000
+        S.empty_file = False; S._nfields = None
+        S.rows = [(int(s) + 1, int(l), int(st), list(map(int, a)))
+                  for s, l, st, a in zip(packed["start"], packed["length"], packed["state"], packed["alleles"])]
+        chunks.append(S)
+    cp = list(np.array(truth["change_times"]) / 4e4)
+    pop = em.PopulationModel(N0=10000, sequence_length=L, num_samples=n, change_points=cp, population_sizes=[[1.0]] * 6)
+    guides = {}
+    final, hist = em.run_em(pop, chunks, iterations=2, np_particles=2000, seed=5, alpha=0.5, beta=4.0, guides=guides)
+    assert sorted(guides) == [0, 1]
+    for g in guides.values():
+        assert g["positions"][0] == 0 and (np.diff(g["positions"]) > 0).all() and g["positions"][-1] < L
+        assert (g["rates"] > 0).all() and (g["leaf_rates"] > 0).all()
+        assert g["leaf_rates"].shape == (len(g["positions"]), n)
+        assert abs(np.average(g["rates"], weights=np.diff(np.append(g["positions"], L))) / 1e-8 - 1) < 0.5
+    ll = [h[(("LogL", -1, -1, -1, -1), "Count")] for h in hist]
+    assert np.isfinite(ll).all() and abs(ll[2] - ll[0]) < 0.02 * abs(ll[0])
+    # guided sampling is an importance sampler of the same posterior: the estimates stay where the unguided ones are
+    rho = [h[(("Recomb", -1, -1, -1, -1), "Count")] / h[(("Recomb", -1, -1, -1, -1), "Opp")] for h in hist]
+    assert abs(rho[2] / rho[0] - 1) < 0.15
+    sizes = np.array([row[0] for row in final.population_sizes])
+    assert (sizes[2:5] > 0.7).all() and (sizes[2:5] < 1.4).all()          # epochs 0 and 1 hold a handful of events
