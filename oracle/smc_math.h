@@ -174,5 +174,16 @@ static inline double philox_uniform(uint64_t seed, uint32_t slot, uint32_t strea
     return ((double)bits + 0.5) * 1.1102230246251565e-16;   /* 2^-53 */
 }
 
+/* Both halves of the Philox block at one draw index: the first equals philox_uniform, the second comes from the
+ * block's other two words.  A genealogy update takes its four uniforms from two blocks this way. */
+static inline void philox_pair(uint64_t seed, uint32_t slot, uint32_t stream, uint64_t draw, double* u0, double* u1) {
+    uint32_t c[4] = {(uint32_t)draw, (uint32_t)(draw >> 32), slot, stream};
+    Philox::block(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    uint64_t b0 = (((uint64_t)c[0] << 32) | c[1]) >> 11;
+    uint64_t b1 = (((uint64_t)c[2] << 32) | c[3]) >> 11;
+    *u0 = ((double)b0 + 0.5) * 1.1102230246251565e-16;
+    *u1 = ((double)b1 + 0.5) * 1.1102230246251565e-16;
+}
+
 }  // namespace smco
 #endif

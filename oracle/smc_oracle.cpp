@@ -137,6 +137,7 @@ struct Model {
     double L = 0, mu = 0, rho = 0;
     std::vector<double> T;       /* epoch start times */
     std::vector<double> inv2N;   /* 1/(2 N_e) */
+    std::vector<double> Hc;      /* cumulative coalescence intensity at the epoch starts (one population) */
     std::vector<int> recflags;
     std::vector<double> lags;
     /* structured models (P > 1): per-epoch, per-population tables (scrm Model::population_size,
@@ -295,7 +296,22 @@ struct Filter {
     double last_iw = 1.0, last_tc = 0.0;
     double last_rbiw = 1.0;       /* recombination_bias_importance_weight_ (particle.cpp:1113-1121) */
     int64_t slot_override = -1;   /* calibration: RNG state lives in rng[0], stream keyed by the replicate index */
+    /* The four uniforms of one genealogy update of the one-population engine (cut point, waiting-time refresh,
+     * re-attachment slot, next recombination position) are the two halves of two consecutive Philox blocks, drawn
+     * together when the update starts; the counter advances by two per update whether or not the fourth is used.
+     * Every other draw takes the first half of its own block. */
+    double uq[4];
+    int uq_n = 0, uq_i = 0;
+    void prefetch_update_uniforms(int64_t slot) {
+        const uint32_t sl = (uint32_t)(slot_override >= 0 ? slot_override : slot);
+        philox_pair(seed, sl, stream, rng[slot].ctr, &uq[0], &uq[1]);
+        philox_pair(seed, sl, stream, rng[slot].ctr + 1, &uq[2], &uq[3]);
+        rng[slot].ctr += 2;
+        uq_n = 4; uq_i = 0;
+    }
+    void drop_update_uniforms() { uq_n = uq_i = 0; }
     double uni(int64_t slot) {
+        if (uq_i < uq_n) return uq[uq_i++];
         return philox_uniform(seed, (uint32_t)(slot_override >= 0 ? slot_override : slot), stream, rng[slot].ctr++);
     }
 
@@ -737,34 +753,60 @@ struct Filter {
     double coalesce_up(int64_t slot, Particle* rec_p, const double* Sh, int ns, int nl, double h, double x,
                        int limit) {
         SlotRng& g = rng[slot];
-        double t = h;
-        int e = M.epoch_of(t);
-        int i = 0;
-        while (i < ns && Sh[i] <= t) ++i;
+        /* The time of the event.  The exponential waiting time of the interval walk (rate k(t)/(2N(t)), one unit
+         * exponential carried across intervals) is evaluated on the cumulative intensity
+         * Hc(t) = int_0^t ds/(2N(s)), tabulated at the epoch starts: between two nodes k is constant, so the budget is
+         * compared with k (Hc(next node) - Hc(t)) once per node, and the event sits where Hc reaches
+         * Hc(t) + budget / k.  Same distribution as drawing interval by interval; the device does exactly this
+         * arithmetic (coalesce_up in pf_device.h, r_coalesce_up in pf_tree_reg.h). */
+        const int e0 = M.epoch_of(h);
+        int i0 = 0;
+        while (i0 < ns && Sh[i0] <= h) ++i0;
+        double Hc = M.Hc[e0] + (h - M.T[e0]) * M.inv2N[e0];
+        int i = i0;
+        double lower = h, kd;
         for (;;) {
-            double tn_node = i < ns ? Sh[i] : HUGE_VAL;
-            double tn_ep = M.epoch_end(e);
-            double tn = std::min(tn_node, tn_ep);
-            int k = i < ns ? nl - i : 1;
-            double rate = (double)k * M.inv2N[e];
-            double need = (tn - t) * rate;
-            bool fire = !(g.ebuf > need);
-            double t1 = tn;
-            if (fire) t1 = t + g.ebuf / rate;
-            if (rec_p && record_events && (M.recflags[e] & REC_COALMIGR) && e <= limit) {
-                Ev* ev = new_event(*rec_p, e, 1, t, t1, x, x, k);
-                if (fire) ev->event = 1;
-            }
-            if (fire) {
-                g.ebuf = -smc_log(uni(slot));
-                if (rec_p && !M.vb_coal.empty()) upd_fac *= M.vb_coal[e];   /* particle.cpp:266-272 */
-                return t1;
-            }
+            if (i >= ns) { kd = 1.0; break; }
+            kd = (double)(nl - i);
+            const double sn = Sh[i];
+            const int en = M.epoch_of(sn);
+            const double Hn = M.Hc[en] + (sn - M.T[en]) * M.inv2N[en];
+            const double need = (Hn - Hc) * kd;
+            if (!(g.ebuf > need)) break;
             g.ebuf -= need;
-            t = tn;
-            if (tn_node <= tn) ++i;
-            if (tn_ep <= tn) ++e;
+            Hc = Hn; lower = sn; ++i;
         }
+        const double C = Hc + g.ebuf / kd;
+        int es = 0;
+        while (es + 1 < M.E && M.Hc[es + 1] <= C) ++es;
+        double tc = M.T[es] + (C - M.Hc[es]) / M.inv2N[es];
+        if (tc < lower) tc = lower;
+        if (i < ns && tc > Sh[i]) tc = Sh[i];
+        g.ebuf = -smc_log(uni(slot));
+        if (rec_p && !M.vb_coal.empty()) upd_fac *= M.vb_coal[es];   /* particle.cpp:266-272 */
+        /* One coal-opportunity record per interval between h and the event (record_all_event, particle.cpp:251-300) */
+        if (rec_p && record_events) {
+            double t = h;
+            int e = e0;
+            i = i0;
+            for (;;) {
+                double tn_node = i < ns ? Sh[i] : HUGE_VAL;
+                double tn_ep = M.epoch_end(e);
+                double tn = std::min(tn_node, tn_ep);
+                int k = i < ns ? nl - i : 1;
+                const bool last = !(tn < tc);
+                const double t1 = last ? tc : tn;
+                if ((M.recflags[e] & REC_COALMIGR) && e <= limit) {
+                    Ev* ev = new_event(*rec_p, e, 1, t, t1, x, x, k);
+                    if (last) ev->event = 1;
+                }
+                if (last) break;
+                t = tn;
+                if (tn_node <= tn) ++i;
+                if (tn_ep <= tn) ++e;
+            }
+        }
+        return tc;
     }
 
     /* Forest::sampleNextBase via ForestState::sampleNextBase (particle.cpp:1195-1254), multiplicity 1 */
@@ -824,6 +866,7 @@ struct Filter {
     void genealogy_update(int64_t slot, Particle& p, double x, int limit, double* h_out) {
         const int n = M.n;
         Tree& t = p.tr;
+        if (M.P == 1) prefetch_update_uniforms(slot);      /* dropped after the sample_next_base that follows the update */
         /* --- sample the recombination point on the (possibly height-weighted) local tree (one uniform) --- */
         double prev = 0.0, h = 0.0;
         int lin = 0, slice = 0;
@@ -1302,6 +1345,7 @@ struct Filter {
                     adjust_with_delay(p, iw, delay, updated_to);
                 }
                 sample_next_base(slot, p, updated_to);
+                drop_update_uniforms();
                 open_stretch(p, updated_to, limit);
                 record_recomb_event(p, h, limit);
             }
@@ -1675,6 +1719,7 @@ static void median_survival(const Model& M, uint64_t seed, int min_events, int64
                         }
                 }
                 f.sample_next_base(0, p, x);
+                f.drop_update_uniforms();
             }
         }
         trees += CAL_BATCH;
@@ -1717,6 +1762,8 @@ static void fill_model(Model& M, const smco_model* m) {
     M.T.assign(m->change_times, m->change_times + E);
     M.inv2N.resize(E);
     for (int e = 0; e < E; ++e) M.inv2N[e] = 1.0 / (2.0 * m->pop_sizes[e * P]);
+    M.Hc.assign(E, 0.0);
+    for (int e = 0; e + 1 < E; ++e) M.Hc[e + 1] = M.Hc[e] + (M.T[e + 1] - M.T[e]) * M.inv2N[e];
     M.inv2Np.resize(E * P);
     for (int i = 0; i < E * P; ++i) M.inv2Np[i] = 1.0 / (2.0 * m->pop_sizes[i]);
     M.Mrate.assign(E * P * P, 0.0);

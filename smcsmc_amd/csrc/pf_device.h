@@ -163,6 +163,30 @@ __device__ __forceinline__ double philox_uniform(unsigned long long seed, unsign
     return ((double)bits + 0.5) * 1.1102230246251565e-16;
 }
 
+// Both halves of the Philox block at one draw index (the first equals philox_uniform).  A genealogy update of the
+// one-population engine takes its four uniforms (cut point, waiting-time refresh, re-attachment slot, next
+// recombination position) from two consecutive blocks: 32-bit integer multiplies run at a quarter of the VALU rate,
+// so the ten rounds of a block cost about as much as the rest of the update's arithmetic put together.
+__device__ __forceinline__ void philox_pair(unsigned long long seed, unsigned slot, unsigned stream, unsigned long long draw,
+                                            double& u0, double& u1) {
+    unsigned c0 = (unsigned)draw, c1 = (unsigned)(draw >> 32), c2 = slot, c3 = stream;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        unsigned n0 = hi1 ^ c1 ^ k0;
+        unsigned n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    unsigned long long b0 = (((unsigned long long)c0 << 32) | c1) >> 11;
+    unsigned long long b1 = (((unsigned long long)c2 << 32) | c3) >> 11;
+    u0 = ((double)b0 + 0.5) * 1.1102230246251565e-16;
+    u1 = ((double)b1 + 0.5) * 1.1102230246251565e-16;
+}
+
 // ------------------------------------------------------------------ wavefront (64-lane) primitives
 // xor-butterfly sum: every lane ends with the same pairwise-tree total (matches oracle tree64).
 __device__ __forceinline__ double wave_tree_sum(double v) {
@@ -205,6 +229,9 @@ struct Lane {
     int8_t* C;        // &sC[tid]
     const double* T;  // epoch start times   (LDS, shared by the block)
     const double* I;  // 1/(2 N_e)           (LDS)
+    const double* H;  // cumulative coalescence intensity at the epoch starts (global, read-only)
+    double uq0, uq1, uq2, uq3;   // uniforms of the genealogy update in progress
+    int uqn = 0;
     const int* RF;    // record flags        (LDS)
     int E, n;
     double L, mu, rho;
@@ -221,7 +248,21 @@ struct Lane {
 #define LS(ln, r) ((ln).S[(r) * PF_BS])
 #define LC(ln, r, s) ((ln).C[((r) * 2 + (s)) * PF_BS])
 
-__device__ __forceinline__ double uni(Lane& ln) { return philox_uniform(ln.seed, ln.slot, ln.stream, ln.ctr++); }
+// the uniforms of the update in progress (see philox_pair) are handed out first
+__device__ __forceinline__ void prefetch_update_uniforms(Lane& ln) {
+    philox_pair(ln.seed, ln.slot, ln.stream, ln.ctr, ln.uq0, ln.uq1);
+    philox_pair(ln.seed, ln.slot, ln.stream, ln.ctr + 1, ln.uq2, ln.uq3);
+    ln.ctr += 2;
+    ln.uqn = 4;
+}
+__device__ __forceinline__ double uni(Lane& ln) {
+    if (ln.uqn > 0) {
+        const double u = ln.uqn == 4 ? ln.uq0 : (ln.uqn == 3 ? ln.uq1 : (ln.uqn == 2 ? ln.uq2 : ln.uq3));
+        --ln.uqn;
+        return u;
+    }
+    return philox_uniform(ln.seed, ln.slot, ln.stream, ln.ctr++);
+}
 
 __device__ __forceinline__ int epoch_of(const Lane& ln, double t) {
     int e = 0;
@@ -307,28 +348,34 @@ __device__ __forceinline__ void insert_node(Lane& ln, int ni, double h, int fl, 
 // k(t) = nl - #{Sh <= t}, 1 above the top.  Returns the coalescence time.
 template <class HeightAt>
 __device__ __forceinline__ double coalesce_up(Lane& ln, HeightAt Sh, int ns, int nl, double h) {
-    double t = h;
-    int e = epoch_of(ln, t);
+    // The waiting time is found on the cumulative intensity Hc(t) = int_0^t 1/(2N(s)) ds (piecewise linear, tabulated at
+    // the epoch starts) instead of epoch by epoch: between two nodes the lineage count k is constant, so the
+    // unit-exponential budget is compared with k (Hc(next node) - Hc(t)) once per node, and the event time is the
+    // inverse of Hc at Hc(t) + budget / k.  Same distribution as the interval walk, O(nodes + log E) steps.
+    int e = epoch_of(ln, h);
+    double Hc = ln.H[e] + (h - ln.T[e]) * ln.I[e];
     int i = 0;
-    while (i < ns && Sh(i) <= t) ++i;
-    // the event tail sits behind the loop exit, where the wavefront has reconverged (see r_coalesce_up)
-    double rate;
+    while (i < ns && Sh(i) <= h) ++i;
+    double lower = h, kd;
     for (;;) {
-        double tn_node = i < ns ? Sh(i) : PF_INF;
-        double tn_ep = epoch_end(ln, e);
-        double tn = tn_node < tn_ep ? tn_node : tn_ep;
-        int k = i < ns ? nl - i : 1;
-        rate = (double)k * ln.I[e];
-        double need = (tn - t) * rate;
+        if (i >= ns) { kd = 1.0; break; }
+        kd = (double)(nl - i);
+        const double sn = Sh(i);
+        const int en = epoch_of(ln, sn);
+        const double Hn = ln.H[en] + (sn - ln.T[en]) * ln.I[en];
+        const double need = (Hn - Hc) * kd;
         if (!(ln.ebuf > need)) break;
         ln.ebuf -= need;
-        t = tn;
-        if (tn_node <= tn) ++i;
-        if (tn_ep <= tn) ++e;
+        Hc = Hn; lower = sn; ++i;
     }
-    double t1 = t + ln.ebuf / rate;
+    const double C = Hc + ln.ebuf / kd;
+    int es = 0;
+    while (es + 1 < ln.E && ln.H[es + 1] <= C) ++es;
+    double t1 = ln.T[es] + (C - ln.H[es]) / ln.I[es];
+    if (t1 < lower) t1 = lower;
+    if (i < ns) { const double sn = Sh(i); if (t1 > sn) t1 = sn; }
     ln.ebuf = -dlog(uni(ln));
-    if (ln.vbc) ln.upd_fac *= ln.vbc[e];
+    if (ln.vbc) ln.upd_fac *= ln.vbc[es];
     return t1;
 }
 

@@ -183,6 +183,7 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
                 if (leaf_status == 0) B = tracked_len_lane(ln, data, tmp0);
                 if (leaf_status == 1) B = ln.Ltree;
                 next_base = sample_next_base(ln, updated_to);
+                ln.uqn = 0;                    // the update's unused uniforms are dropped
                 x_mark = updated_to;
                 mark_limit = limit;
             }
@@ -319,9 +320,10 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
     extern __shared__ double smem[];
     double* sT = smem;
     double* sI = smem + A.E;
-    double* sBH = sI + A.E;                       // bias band boundaries / strengths (focused sampling)
+    double* sH = sI + A.E;                        // cumulative coalescence intensity at the epoch starts
+    double* sBH = sH + A.E;                       // bias band boundaries / strengths (focused sampling)
     double* sBS = sBH + (PF_BIAS_MAX + 2);
-    for (int e = threadIdx.x; e < A.E; e += blockDim.x) { sT[e] = A.T[e]; sI[e] = A.inv2N[e]; }
+    for (int e = threadIdx.x; e < A.E; e += blockDim.x) { sT[e] = A.T[e]; sI[e] = A.inv2N[e]; sH[e] = A.Hc[e]; }
     if (BIASED && threadIdx.x < PF_BIAS_MAX + 2) {
         sBH[threadIdx.x] = A.bias_H[threadIdx.x];
         if (threadIdx.x < PF_BIAS_MAX + 1) sBS[threadIdx.x] = A.bias_S[threadIdx.x];
@@ -351,7 +353,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
             }
         }
         RCtx cx;
-        cx.T = sT; cx.I = sI; cx.E = A.E; cx.n = n; cx.L = A.L; cx.mu = A.mu; cx.rho = A.rho;
+        cx.T = sT; cx.I = sI; cx.H = sH; cx.E = A.E; cx.n = n; cx.L = A.L; cx.mu = A.mu; cx.rho = A.rho;
         cx.seed = A.seed; cx.slot = (unsigned)p; cx.stream = 0;
         cx.nb = A.n_bias + 1; cx.bH = sBH; cx.bS = sBS; cx.last_iw = 1.0;
         cx.want_desc = A.lmap_opp != nullptr; cx.last_desc = 0;
@@ -411,7 +413,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
                 w_post = wp * adj;
                 w_pilot = wq * adj;
                 x_mark = pos;
-                if (p != lo[a] && pos < A.L) next_base = r_sample_next_base(cx, pos);     // pc.cpp:357-368
+                if (p != lo[a] && pos < A.L) next_base = r_sample_next_base<false>(cx, pos);     // pc.cpp:357-368
             }
         }
 
@@ -459,7 +461,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
                 // reached a change of the guide rate: no genealogy change, new draw under the new rate
                 // (particle.cpp:822-826); the open stretch continues
                 cx.ridx += 1;
-                next_base = r_sample_next_base(cx, updated_to);
+                next_base = r_sample_next_base<false>(cx, updated_to);
                 continue;
             }
             if (updated_to < extend_to) {
@@ -488,7 +490,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
                     double delay = A.app_delays[r_epoch_of(cx, delay_height)];
                     d_adjust_with_delay(ds, w_post, w_pilot, iw, delay, updated_to);
                 }
-                next_base = r_sample_next_base(cx, updated_to);
+                next_base = r_sample_next_base<true>(cx, updated_to);      // fourth uniform of the update
                 x_mark = updated_to;
                 mark_limit = limit;
             }
@@ -597,20 +599,19 @@ __global__ __launch_bounds__(PF_BS) void k_extend_reg(KArgs A, long long s, int 
 
 // ------------------------------------------------------------------ count bookkeeping (shared)
 // Ordered reduction of the k_count partials of the previous step into the totals
-// (count.cpp:407-414).  Runs in the second workgroup of k_decide (off the critical path) or in
-// k_count_fin (explicit flush).
+// (count.cpp:407-414).  Every k_count workgroup adds its step result to its own accumulator (same workgroup, same
+// address, kernels in stream order: no race), so nothing has to be folded per row; k_count_fin folds the
+// accumulators into the totals when the host asks for them (pf_sync).
 #define PF_FIN_TILE_B 64       // k_count workgroup partials staged per pass
 #define PF_FIN_PAIRS 64        // (epoch, statistic) pairs staged per pass
 
 __device__ void finalize_counts(const KArgs& A, Ctrl* c, int tid, int nthreads, double* stage /* PF_FIN_PAIRS*PF_FIN_TILE_B */) {
     const int E = A.E;
-    const int first = c->first_epoch;
-    const int nb = c->nbx_used;
+    const int nb = A.nbx;
     const int NC = A.ncol;
-    const int npairs = (E - first) * NC;
-    // All partials of a tile are fetched with independent loads (a serial load-add chain would pay the
-    // full memory latency per term), then each pair is summed in workgroup order from LDS: the result is
-    // bit-identical to the plain serial sum over workgroups.
+    const int npairs = E * NC;
+    // All accumulators of a tile are fetched with independent loads (a serial load-add chain would pay the
+    // full memory latency per term), then each pair is summed in workgroup order from LDS.
     for (int p0 = 0; p0 < npairs; p0 += PF_FIN_PAIRS) {
         const int np_ = npairs - p0 < PF_FIN_PAIRS ? npairs - p0 : PF_FIN_PAIRS;
         double run = 0.0;                                   // running sum of pair (p0 + tid), threads < np_
@@ -619,8 +620,10 @@ __device__ void finalize_counts(const KArgs& A, Ctrl* c, int tid, int nthreads, 
             for (int idx = tid; idx < np_ * nbt; idx += nthreads) {
                 int pp = idx / nbt, b = idx % nbt;
                 int pair = p0 + pp;
-                int e = first + pair / NC, k = pair % NC;
-                stage[pp * PF_FIN_TILE_B + b] = A.partial[((size_t)e * A.nbx + b0 + b) * NC + k];
+                int e = pair / NC, k = pair % NC;
+                double* src = &A.partial[((size_t)e * A.nbx + b0 + b) * NC + k];
+                stage[pp * PF_FIN_TILE_B + b] = *src;
+                *src = 0.0;
             }
             __syncthreads();
             if (tid < np_)
@@ -629,7 +632,7 @@ __device__ void finalize_counts(const KArgs& A, Ctrl* c, int tid, int nthreads, 
         }
         if (tid < np_) {
             int pair = p0 + tid;
-            int e = first + pair / NC, k = pair % NC;
+            int e = pair / NC, k = pair % NC;
             A.totals[(size_t)k * E + e] += run;
         }
     }
@@ -674,7 +677,7 @@ __device__ void window_generations(const KArgs& A, Ctrl* c, const Windows& W, in
         }
         c->first_epoch = W.first;
         c->count_active = W.first < E;
-        c->pending_fin = W.first < E;
+        if (W.first < E) c->pending_fin = 1;
         c->nbx_used = A.nbx;
     }
 }
@@ -690,7 +693,7 @@ __device__ void window_generations(const KArgs& A, Ctrl* c, const Windows& W, in
 //     any inter-workgroup wait;
 //   * if resampling is due, each computes the final offspring offsets of its own particles (one per lane),
 //     the parent table entries of their offspring and its survivor count: no inter-workgroup wait;
-//   * the bookkeeping workgroup folds the previous step's k_count partials and advances the window
+//   * the bookkeeping workgroup advances the window
 //     generations (off the critical path).
 __device__ __forceinline__ void decide_body(const KArgs& A, long long s, int mode, const Windows& W, int nblocks) {
     __shared__ double l2s[4096];          // level-2 inclusive scan of the per-wavefront pilot totals / finalize staging
@@ -702,7 +705,6 @@ __device__ __forceinline__ void decide_body(const KArgs& A, long long s, int mod
     Ctrl* c = A.ctrl;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = PF_BS / 64;
     if ((int)blockIdx.x == nblocks) {
-        if (c->pending_fin) finalize_counts(A, c, tid, PF_BS, l2s);
         window_generations(A, c, W, tid);
         return;
     }
@@ -1188,7 +1190,7 @@ __device__ __forceinline__ void count_body(const KArgs& A, int sp, int e0, const
         const int k = threadIdx.x;
         double t = red[0].v[k];
         for (int w = 1; w < PF_BS / 64; ++w) t += red[w].v[k];
-        A.partial[((size_t)e * A.nbx + bx) * AC::NC + k] = t;
+        A.partial[((size_t)e * A.nbx + bx) * AC::NC + k] += t;      // this workgroup's own accumulator (folded by k_count_fin)
     }
 }
 
@@ -1579,6 +1581,7 @@ __global__ __launch_bounds__(PF_BS) void k_calibrate(KArgs A, unsigned long long
                 }
         }
         next = sample_next_base(ln, x);
+        ln.uqn = 0;
     }
 }
 
@@ -1858,6 +1861,14 @@ static int dalloc(pf_handle* h, T** p, size_t count) {
     return 0;
 }
 
+// cumulative coalescence intensity at the epoch starts, in exactly this order of operations on both sides of the
+// parity tests: Hc[0] = 0, Hc[e+1] = Hc[e] + (T[e+1] - T[e]) * inv2N[e]
+static std::vector<double> cumulative_intensity(const double* T, const std::vector<double>& inv2N, int E) {
+    std::vector<double> H(E, 0.0);
+    for (int e = 0; e + 1 < E; ++e) H[e + 1] = H[e] + (T[e + 1] - T[e]) * inv2N[e];
+    return H;
+}
+
 int pf_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1982,8 +1993,8 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     A.ess_threshold = (double)Np * p->ess_fraction;
     A.seed = p->seed;
     int rc = 0;
-    double *dT, *dI, *dlag; int* dRF;
-    rc |= dalloc(h, &dT, E); rc |= dalloc(h, &dI, E); rc |= dalloc(h, &dlag, E); rc |= dalloc(h, &dRF, E);
+    double *dT, *dI, *dlag, *dHc; int* dRF;
+    rc |= dalloc(h, &dT, E); rc |= dalloc(h, &dI, E); rc |= dalloc(h, &dlag, E); rc |= dalloc(h, &dRF, E); rc |= dalloc(h, &dHc, E);
     if (rc) { pf_destroy(h); return nullptr; }
     std::vector<double> inv2N(E);
     for (int e = 0; e < E; ++e) inv2N[e] = 1.0 / (2.0 * m->pop_sizes[(size_t)e * P]);
@@ -2012,10 +2023,12 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     }
     hipMemcpyAsync(dT, m->change_times, E * 8, hipMemcpyHostToDevice, h->stream);
     hipMemcpyAsync(dI, inv2N.data(), E * 8, hipMemcpyHostToDevice, h->stream);
+    const std::vector<double> Hc = cumulative_intensity(m->change_times, inv2N, E);
+    hipMemcpyAsync(dHc, Hc.data(), E * 8, hipMemcpyHostToDevice, h->stream);
     hipMemcpyAsync(dlag, m->lags, E * 8, hipMemcpyHostToDevice, h->stream);
     hipMemcpyAsync(dRF, m->record_flags, E * 4, hipMemcpyHostToDevice, h->stream);
     hipStreamSynchronize(h->stream);
-    A.T = dT; A.inv2N = dI; A.lags = dlag; A.recflags = dRF;
+    A.T = dT; A.inv2N = dI; A.Hc = dHc; A.lags = dlag; A.recflags = dRF;
     A.n_bias = m->n_bias_heights;
     A.delay_type = m->delay_type;
     for (int k = 0; k < PF_BIAS_MAX + 2; ++k) A.bias_H[k] = HUGE_VAL;
@@ -2224,6 +2237,7 @@ int pf_init_prior(pf_handle* h, double initial_position) {
         HIPCHK(hipMemsetAsync(h->A.lmap_cnt, 0, (size_t)(h->n + 2) * h->A.lmap_bins * 8, h->stream));
     }
     std::fill(h->h_counted_to.begin(), h->h_counted_to.end(), 0.0);
+    HIPCHK(hipMemsetAsync(h->A.partial, 0, (size_t)h->E * h->A.nbx * h->A.ncol * 8, h->stream));
     h->fin_pending = false;
     h->ev_dec = nullptr; h->ev_cnt = nullptr;
     h->seg_done = 0;
@@ -2295,7 +2309,7 @@ static int launch_extend(pf_handle* h, long long s, int fuse = 0) {
     const bool t = timing_on(h, s);
     {
         Timed tm(h, 0, t);
-        const size_t smem_reg = (size_t)(2 * h->E + 2 * PF_BIAS_MAX + 3) * 8;
+        const size_t smem_reg = (size_t)(3 * h->E + 2 * PF_BIAS_MAX + 3) * 8;
         const bool biased = h->A.n_bias > 0 || h->A.g_K > 0;
         if (h->P > 1)
             pf_mp_launch_extend(h->A, s, h->smem, h->stream);
@@ -2320,13 +2334,12 @@ static int launch_extend(pf_handle* h, long long s, int fuse = 0) {
 
 static int launch_decide(pf_handle* h, long long s, int mode, const Windows& W) {
     const bool t = timing_on(h, s);
-    // k_decide folds the previous step's k_count partials and rewrites what k_count / k_ledger read
+    // k_decide rewrites what k_count / k_ledger read
     // (window generations, offspring tables): it must not start before the counting stream is done with them
     if (h->ev_cnt) hipStreamWaitEvent(h->stream, h->ev_cnt, 0);
     {
         Timed tm(h, 1, t);
         hipLaunchKernelGGL(k_decide, dim3(h->nblocks + 1), dim3(PF_BS), 0, h->stream, h->A, s, mode, W, h->nblocks);
-        h->fin_pending = false;      // the bookkeeping workgroup folds the previous step's partials
     }
     if (!getenv("SMCSMC_PF_DEBUG_NOCOUNT")) {
         h->ev_dec = next_sync_event(h);
@@ -2430,7 +2443,7 @@ static void trim_spans(pf_handle* h) {
 // whole when the call returns.
 template <int NM, bool BIASED>
 static void launch_row(pf_handle* h, long long s, int fuse, int count_first, const Windows& Wprev) {
-    const size_t smem_reg = (size_t)(2 * h->E + 2 * PF_BIAS_MAX + 3) * 8;
+    const size_t smem_reg = (size_t)(3 * h->E + 2 * PF_BIAS_MAX + 3) * 8;
     const int nb = h->nblocks;
     const int ncount = count_first < h->E ? nb * (h->E - count_first) : 0;
     hipLaunchKernelGGL((k_row<NM, BIASED>), dim3(nb + ncount), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse, nb, count_first, Wprev);
@@ -2464,7 +2477,6 @@ static int run_single_stream(pf_handle* h, long long s_begin, long long s_end) {
             const int lnbt = pending ? h->nblocks + std::max(16, std::min(PF_LEDGER_BLOCKS, lroom)) : 0;
             hipLaunchKernelGGL(k_decide_ledger, dim3(h->nblocks + 1 + lnbt), dim3(PF_BS), 0, h->stream, h->A, s, 0, h->step_windows,
                                h->nblocks, lnbt);
-            h->fin_pending = false;      // the bookkeeping workgroup folds the partials of the counts that rode in k_row
         }
         if (check_launch("k_decide")) return -1;
         pending = true;
@@ -2858,7 +2870,13 @@ int pf_terminal_branch_quantiles(const pf_model* m, uint64_t seed, int64_t n_tre
     HIPCHK(hipMemcpy(dT, m->change_times, E * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dI, inv2N.data(), E * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dRF, rf.data(), E * 4, hipMemcpyHostToDevice));
-    A.T = dT; A.inv2N = dI; A.recflags = dRF;
+    double* dHc;
+    HIPCHK(hipMalloc(&dHc, E * 8));
+    {
+        const std::vector<double> Hc = cumulative_intensity(m->change_times, inv2N, E);
+        HIPCHK(hipMemcpy(dHc, Hc.data(), E * 8, hipMemcpyHostToDevice));
+    }
+    A.T = dT; A.inv2N = dI; A.Hc = dHc; A.recflags = dRF;
     const size_t smem = smem_bytes(n, E);
     if (smem > 64 * 1024) hipFuncSetAttribute((const void*)k_tbl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(k_tbl, dim3((unsigned)((n_trees + PF_BS - 1) / PF_BS)), dim3(PF_BS), smem, 0, A, (unsigned long long)seed,
@@ -2867,7 +2885,7 @@ int pf_terminal_branch_quantiles(const pf_model* m, uint64_t seed, int64_t n_tre
     std::vector<double> hh((size_t)n * n_trees), ll(n_trees);
     HIPCHK(hipMemcpy(hh.data(), dh, hh.size() * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(ll.data(), dl, ll.size() * 8, hipMemcpyDeviceToHost));
-    hipFree(dT); hipFree(dI); hipFree(dRF); hipFree(dh); hipFree(dl);
+    hipFree(dT); hipFree(dI); hipFree(dHc); hipFree(dRF); hipFree(dh); hipFree(dl);
     for (int i = 0; i < n; ++i) {
         double* row = hh.data() + (size_t)i * n_trees;
         std::sort(row, row + n_trees);
@@ -2908,7 +2926,13 @@ int pf_median_survival(const pf_model* m, uint64_t seed, int32_t min_events, int
     HIPCHK(hipMemcpy(dT, m->change_times, E * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dI, inv2N.data(), E * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dRF, rf.data(), E * 4, hipMemcpyHostToDevice));
-    A.T = dT; A.inv2N = dI; A.recflags = dRF;
+    double* dHc;
+    HIPCHK(hipMalloc(&dHc, E * 8));
+    {
+        const std::vector<double> Hc = cumulative_intensity(m->change_times, inv2N, E);
+        HIPCHK(hipMemcpy(dHc, Hc.data(), E * 8, hipMemcpyHostToDevice));
+    }
+    A.T = dT; A.inv2N = dI; A.Hc = dHc; A.recflags = dRF;
     if (P > 1) {
         MpTables tb;
         if (build_mp_tables(m, tb) || upload_mp_tables(tb, A, mp_allocs)) return -1;
@@ -2939,7 +2963,7 @@ int pf_median_survival(const pf_model* m, uint64_t seed, int32_t min_events, int
             if (hdist[i] >= 0) surv[hep[i]].push_back(hdist[i]);
         trees += PF_CAL_BATCH;
     }
-    hipFree(dT); hipFree(dI); hipFree(dRF); hipFree(dep); hipFree(ddist); hipFree(derr);
+    hipFree(dT); hipFree(dI); hipFree(dHc); hipFree(dRF); hipFree(dep); hipFree(ddist); hipFree(derr);
     for (void* q : mp_allocs) hipFree(q);
     if (cal_err) {
         g_err = cal_err == 1 ? "too many migration events on one local tree"

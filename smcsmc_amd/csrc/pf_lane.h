@@ -38,7 +38,7 @@ __device__ __forceinline__ Lane make_lane(const KArgs& A, Smem& m, long long p) 
     Lane ln;
     ln.S = m.S + threadIdx.x;
     ln.C = m.C + threadIdx.x;
-    ln.T = m.T; ln.I = m.I; ln.RF = m.RF;
+    ln.T = m.T; ln.I = m.I; ln.RF = m.RF; ln.H = A.Hc;
     ln.E = A.E; ln.n = A.n;
     ln.L = A.L; ln.mu = A.mu; ln.rho = A.rho;
     ln.seed = A.seed;
@@ -95,6 +95,7 @@ __device__ __forceinline__ void genealogy_update(Lane& ln, double* h_out, double
     const int n = ln.n;
     int rp = 0, sb = 0;
     double h;
+    prefetch_update_uniforms(ln);       // the caller drops what is left after the sample_next_base that follows
     sample_point(ln, &rp, &sb, &h);
     if (desc_out) *desc_out = lane_desc_mask(ln, LC(ln, rp, sb), tmp);
     *h_out = h;

@@ -51,6 +51,8 @@ struct RTree {
 struct RCtx {
     const double* T;
     const double* I;
+    const double* H;          // cumulative coalescence intensity at the epoch starts (LDS)
+    double u_nb;              // fourth uniform of the update in progress (next recombination position)
     int E, n;
     double L, mu, rho;
     unsigned long long seed;
@@ -190,48 +192,47 @@ __device__ __forceinline__ void r_insert_node(RTree<NM>& t, int n, int ni, doubl
 }
 
 template <int NM>
-__device__ __forceinline__ double r_coalesce_up(RCtx& cx, const RTree<NM>& t, int ns, int nl, double h) {
-    double tt = h;
-    int e = r_epoch_of(cx, tt);
+__device__ __forceinline__ double r_coalesce_up(RCtx& cx, const RTree<NM>& t, int ns, int nl, double h, double u_refresh) {
+    // Cumulative-intensity form of the walk (see coalesce_up in pf_device.h: same arithmetic, operation for
+    // operation): one comparison per node passed instead of one per epoch passed, then the inverse of the piecewise
+    // linear Hc by a binary search.  Under SIMT the loop runs max-over-lanes(nodes passed) + 1 times, whatever the
+    // number of epochs between the cut point and the coalescence.
+    int e = r_epoch_of(cx, h);
+    double Hc = cx.H[e] + (h - cx.T[e]) * cx.I[e];
     int i = 0;
 #pragma unroll
-    for (int k = 0; k < RTree<NM>::NI; ++k) i += (k < ns && t.S[k] <= tt) ? 1 : 0;
-    // the epoch tables are read one epoch ahead, so that the LDS latency of the next epoch's entries overlaps
-    // the arithmetic of the current interval instead of heading its dependency chain
-    double ep_end = r_epoch_end(cx, e), ep_inv = cx.I[e];
-    double nx_end = r_epoch_end(cx, e + 1), nx_inv = cx.I[e + 1 < cx.E ? e + 1 : e];
-    // The loop only runs through the event-free intervals.  The expensive tail (a division, a Philox draw and a
-    // log) sits behind the loop exit, where the lanes of the wavefront have reconverged: placed inside the loop it
-    // would be executed once for every iteration in which some lane's lineage coalesces.
-    double rate;
-    double tn_node = i < ns ? t.getS(i) : PF_INF;          // next node height and lineage count, updated only
-    double kd = i < ns ? (double)(nl - i) : 1.0;            // when a node is passed (small integers: exact)
+    for (int k = 0; k < RTree<NM>::NI; ++k) i += (k < ns && t.S[k] <= h) ? 1 : 0;
+    double lower = h, kd, sn = PF_INF;
     for (;;) {
-        double tn_ep = ep_end;
-        double tn = tn_node < tn_ep ? tn_node : tn_ep;
-        rate = kd * ep_inv;
-        double need = (tn - tt) * rate;
+        if (i >= ns) { kd = 1.0; sn = PF_INF; break; }
+        kd = (double)(nl - i);
+        sn = t.getS(i);
+        const int en = r_epoch_of(cx, sn);
+        const double Hn = cx.H[en] + (sn - cx.T[en]) * cx.I[en];
+        const double need = (Hn - Hc) * kd;
         if (!(cx.ebuf > need)) break;
         cx.ebuf -= need;
-        tt = tn;
-        if (tn_node <= tn) {
-            ++i;
-            tn_node = i < ns ? t.getS(i) : PF_INF;
-            kd = i < ns ? kd - 1.0 : 1.0;
-        }
-        if (tn_ep <= tn) {
-            ++e;
-            ep_end = nx_end; ep_inv = nx_inv;
-            nx_end = r_epoch_end(cx, e + 1);
-            nx_inv = cx.I[e + 1 < cx.E ? e + 1 : e];
-        }
+        Hc = Hn; lower = sn; ++i;
     }
-    double t1 = tt + cx.ebuf / rate;
-    cx.ebuf = -dlog(r_uni(cx));
-    if (cx.vbc) cx.upd_fac *= cx.vbc[e];
+    const double C = Hc + cx.ebuf / kd;
+    int es;
+    {
+        int lo = 0, hi = cx.E;            // invariant: H[lo] <= C, and (hi == E or H[hi] > C)
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (cx.H[mid] <= C) lo = mid; else hi = mid;
+        }
+        es = lo;
+    }
+    double t1 = cx.T[es] + (C - cx.H[es]) / cx.I[es];
+    if (t1 < lower) t1 = lower;
+    if (t1 > sn) t1 = sn;
+    cx.ebuf = -dlog(u_refresh);
+    if (cx.vbc) cx.upd_fac *= cx.vbc[es];
     return t1;
 }
 
+template <bool SPARE>
 __device__ __forceinline__ double r_sample_next_base(RCtx& cx, double x) {
     // with a guide: the rate of the particle's current segment, the draw limited to the segment (particle.cpp:1203-1232)
     double rho_here = cx.rho, seg_end = cx.L;
@@ -247,7 +248,7 @@ __device__ __forceinline__ double r_sample_next_base(RCtx& cx, double x) {
         return seg_end;
     }
     double nb = x + cx.ebuf / rate;
-    cx.ebuf = -dlog(r_uni(cx));
+    cx.ebuf = -dlog(SPARE ? cx.u_nb : r_uni(cx));
     if (nb == x) {
         nb = __longlong_as_double(__double_as_longlong(x) + 1);
         if (x == 0.0) nb = 4.9406564584124654e-324;
@@ -259,7 +260,7 @@ __device__ __forceinline__ double r_sample_next_base(RCtx& cx, double x) {
 // samplePoint with height-band weights (particle.cpp:1020-1126); pieces = (time slice) x (band), ascending in
 // height; same operation order as the oracle's biased branch of Filter::genealogy_update.
 template <int NM>
-__device__ __forceinline__ void r_sample_point_biased(RCtx& cx, const RTree<NM>& t, double* h_out, int* lin_out) {
+__device__ __forceinline__ void r_sample_point_biased(RCtx& cx, const RTree<NM>& t, double u_point, double* h_out, int* lin_out) {
     const int n = cx.n;
     const int nb = cx.nb;
     double Lw = 0.0;
@@ -283,7 +284,7 @@ __device__ __forceinline__ void r_sample_point_biased(RCtx& cx, const RTree<NM>&
                 pv = top;
             }
     }
-    double r = r_uni(cx) * Lw;
+    double r = u_point * Lw;
     double l_lo = 0, l_hi = 0, l_str = 1;
     int l_k = 1;
     bool sel = false;
@@ -327,7 +328,7 @@ __device__ __forceinline__ void r_sample_point_biased(RCtx& cx, const RTree<NM>&
 // below the root: the larger of the two -- times the strength of its height band.  Pieces are visited branch by branch in
 // slot order (rank ascending, child 0 then 1), bands ascending; same operation order as the oracle.
 template <int NM>
-__device__ __forceinline__ void r_sample_point_guided(RCtx& cx, const RTree<NM>& t, bool height_bias, double* h_out) {
+__device__ __forceinline__ void r_sample_point_guided(RCtx& cx, const RTree<NM>& t, bool height_bias, double u_point, double* h_out) {
     constexpr int NI = RTree<NM>::NI;
     const int n = cx.n;
     const int nb = cx.nb;
@@ -371,7 +372,7 @@ __device__ __forceinline__ void r_sample_point_guided(RCtx& cx, const RTree<NM>&
             }
         }
     // pass 2: the piece that holds U * Lw
-    double rr_ = r_uni(cx) * Lw;
+    double rr_ = u_point * Lw;
     double l_lo = 0, l_hi = 0, l_wt = 1;
     bool sel = false;
     int g_rp = 0, g_sb = 0;
@@ -439,14 +440,19 @@ __device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, doubl
     double h = 0.0;
     int lin = 0;
     bool guided_pt = false;
+    // the update's four uniforms: two Philox blocks, drawn together (philox_pair)
+    double u_point, u_refresh, u_attach;
+    philox_pair(cx.seed, cx.slot, cx.stream, cx.ctr, u_point, u_refresh);
+    philox_pair(cx.seed, cx.slot, cx.stream, cx.ctr + 1, u_attach, cx.u_nb);
+    cx.ctr += 2;
     if (BIASED && cx.gK > 0 && cx.stream == 0) {
-        r_sample_point_guided(cx, t, cx.nb > 1, &h);
+        r_sample_point_guided(cx, t, cx.nb > 1, u_point, &h);
         guided_pt = true;
     } else if (BIASED) {
-        r_sample_point_biased(cx, t, &h, &lin);
+        r_sample_point_biased(cx, t, u_point, &h, &lin);
         cx.last_rbiw = cx.last_iw;
     } else {
-        double r = r_uni(cx) * cx.Ltree;
+        double r = u_point * cx.Ltree;
         double prev = 0.0;
         bool done = false;
 #pragma unroll
@@ -492,7 +498,7 @@ __device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, doubl
         }
         cx.last_desc = cut;
     }
-    double tc = r_coalesce_up(cx, t, n - 1, n, h);
+    double tc = r_coalesce_up(cx, t, n - 1, n, h, u_refresh);
     *tc_out = tc;
     double Sp = t.getS(rp);
     int b_id = t.getC(rp, sb), s_id = t.getC(rp, 1 - sb);
@@ -505,7 +511,7 @@ __device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, doubl
     bool has_root = tc >= r_node_h(t, n, troot);
     bool has_stub = tc < Sp;
     int k = nslots + (has_root ? 1 : 0) + (has_stub ? 1 : 0);
-    double u = r_uni(cx);
+    double u = u_attach;
     int idx = min((int)(u * (double)k), k - 1);
     // where the floating lineage re-attaches: one insertion for all three outcomes (under divergence three
     // separate calls would each be executed by the whole wavefront)

@@ -73,6 +73,7 @@ struct KArgs {
     double L, mu, rho;
     const double* T;
     const double* inv2N;
+    const double* Hc;              // [E] cumulative coalescence intensity at the epoch starts: Hc[e+1] = Hc[e] + (T[e+1]-T[e]) * inv2N[e]
     const double* lags;
     const int* recflags;
     // structured models: P populations

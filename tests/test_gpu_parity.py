@@ -353,7 +353,7 @@ def test_auxiliary_particle_filter_parity(oracle, hiplib, n, level, unphased):
     o0, si0, g0 = _run_both(oracle, model, segs, 400, seed=9)
     g0.run(); g0.finish()
     assert (g0.trace()["ess"] != tg["ess"]).any()
-    assert abs(g0.logl() - g.logl()) < 0.02 * abs(g.logl())
+    assert abs(g0.logl() - g.logl()) < 0.05 * abs(g.logl())
 
 
 def test_binary_auxiliary_particle_filter(hiplib, tmp_path):
