@@ -318,12 +318,16 @@ __device__ __forceinline__ void d_adjust_with_delay(DStore& d, double& w_post, d
 template <int NM, bool BIASED>
 __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int fuse) {
     extern __shared__ double smem[];
-    double* sT = smem;
-    double* sI = smem + A.E;
-    double* sH = sI + A.E;                        // cumulative coalescence intensity at the epoch starts
-    double* sBH = sH + A.E;                       // bias band boundaries / strengths (focused sampling)
+    double* sT = smem;                            // epoch starts and ...
+    double* sH = smem + PF_EPAD;                  // ... cumulative coalescence intensity there, both padded with +inf (r_search4)
+    double* sI = sH + PF_EPAD;
+    double* sBH = sI + A.E;                       // bias band boundaries / strengths (focused sampling)
     double* sBS = sBH + (PF_BIAS_MAX + 2);
-    for (int e = threadIdx.x; e < A.E; e += blockDim.x) { sT[e] = A.T[e]; sI[e] = A.inv2N[e]; sH[e] = A.Hc[e]; }
+    for (int e = threadIdx.x; e < PF_EPAD; e += blockDim.x) {
+        sT[e] = e < A.E ? A.T[e] : PF_INF;
+        sH[e] = e < A.E ? A.Hc[e] : PF_INF;
+        if (e < A.E) sI[e] = A.inv2N[e];
+    }
     if (BIASED && threadIdx.x < PF_BIAS_MAX + 2) {
         sBH[threadIdx.x] = A.bias_H[threadIdx.x];
         if (threadIdx.x < PF_BIAS_MAX + 1) sBS[threadIdx.x] = A.bias_S[threadIdx.x];
@@ -2309,7 +2313,7 @@ static int launch_extend(pf_handle* h, long long s, int fuse = 0) {
     const bool t = timing_on(h, s);
     {
         Timed tm(h, 0, t);
-        const size_t smem_reg = (size_t)(3 * h->E + 2 * PF_BIAS_MAX + 3) * 8;
+        const size_t smem_reg = (size_t)(2 * PF_EPAD + h->E + 2 * PF_BIAS_MAX + 3) * 8;
         const bool biased = h->A.n_bias > 0 || h->A.g_K > 0;
         if (h->P > 1)
             pf_mp_launch_extend(h->A, s, h->smem, h->stream);
@@ -2443,7 +2447,7 @@ static void trim_spans(pf_handle* h) {
 // whole when the call returns.
 template <int NM, bool BIASED>
 static void launch_row(pf_handle* h, long long s, int fuse, int count_first, const Windows& Wprev) {
-    const size_t smem_reg = (size_t)(3 * h->E + 2 * PF_BIAS_MAX + 3) * 8;
+    const size_t smem_reg = (size_t)(2 * PF_EPAD + h->E + 2 * PF_BIAS_MAX + 3) * 8;
     const int nb = h->nblocks;
     const int ncount = count_first < h->E ? nb * (h->E - count_first) : 0;
     hipLaunchKernelGGL((k_row<NM, BIASED>), dim3(nb + ncount), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse, nb, count_first, Wprev);

@@ -79,16 +79,42 @@ struct RCtx {
 };
 
 __device__ __forceinline__ double r_uni(RCtx& cx) { return philox_uniform(cx.seed, cx.slot, cx.stream, cx.ctr++); }
-// epoch containing time t: the largest e with T[e] <= t (T[0] = 0).  Six dependent LDS reads for E <= 64
-// instead of one per epoch passed.
-__device__ __forceinline__ int r_epoch_of(const RCtx& cx, double t) {
-    int lo = 0, hi = cx.E;            // invariant: T[lo] <= t, and (hi == E or T[hi] > t)
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (cx.T[mid] <= t) lo = mid; else hi = mid;
+// Largest e with tab[e] <= t, for an ascending table of PF_EPAD = 64 doubles in LDS, padded with +inf behind its E
+// entries (tab[0] <= t).  Three levels of a four-way search; since the table ascends, the new lower bound is
+// lo + stride * #(probes <= t).  No bounds checks (the padding takes their place) and the three probes of a level
+// share one address register: a search is about thirty instructions, and with one wavefront per SIMD the
+// instruction count is the cost.
+#define PF_EPAD 64
+__device__ __forceinline__ int r_search4(const double* tab, double t) {
+    int lo = 0;
+#pragma unroll
+    for (int stride = 16; stride >= 1; stride >>= 2) {
+        const double* q = tab + lo;
+        const double v1 = q[stride], v2 = q[2 * stride], v3 = q[3 * stride];
+        lo += stride * ((v1 <= t ? 1 : 0) + (v2 <= t ? 1 : 0) + (v3 <= t ? 1 : 0));
     }
     return lo;
 }
+// N searches at once, level by level: the 3 N probes of a level are all in flight before the first is used
+template <int N>
+__device__ __forceinline__ void r_search4_batch(const double* tab, const double (&tv)[N], int (&lo)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) lo[k] = 0;
+#pragma unroll
+    for (int stride = 16; stride >= 1; stride >>= 2) {
+        double v1[N], v2[N], v3[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const double* q = tab + lo[k];
+            v1[k] = q[stride]; v2[k] = q[2 * stride]; v3[k] = q[3 * stride];
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            lo[k] += stride * ((v1[k] <= tv[k] ? 1 : 0) + (v2[k] <= tv[k] ? 1 : 0) + (v3[k] <= tv[k] ? 1 : 0));
+    }
+}
+// epoch containing time t: the largest e with T[e] <= t (T[0] = 0)
+__device__ __forceinline__ int r_epoch_of(const RCtx& cx, double t) { return r_search4(cx.T, t); }
 __device__ __forceinline__ double r_epoch_end(const RCtx& cx, int e) { return e + 1 < cx.E ? cx.T[e + 1] : PF_INF; }
 
 template <int NM>
@@ -195,35 +221,43 @@ template <int NM>
 __device__ __forceinline__ double r_coalesce_up(RCtx& cx, const RTree<NM>& t, int ns, int nl, double h, double u_refresh) {
     // Cumulative-intensity form of the walk (see coalesce_up in pf_device.h: same arithmetic, operation for
     // operation): one comparison per node passed instead of one per epoch passed, then the inverse of the piecewise
-    // linear Hc by a binary search.  Under SIMT the loop runs max-over-lanes(nodes passed) + 1 times, whatever the
-    // number of epochs between the cut point and the coalescence.
-    int e = r_epoch_of(cx, h);
-    double Hc = cx.H[e] + (h - cx.T[e]) * cx.I[e];
-    int i = 0;
+    // linear Hc by a search.  No loop is left: the node scan is unrolled over the (at most NI) ranks.
+    // The epoch searches of the cut height and of every node are independent chains of LDS reads: issued together
+    // they cost one search's latency (inside a loop over the nodes passed each would wait for the previous one).
+    constexpr int NI = RTree<NM>::NI;
+    double Hn_h;
+    double tv[NI + 1];
+    int ev[NI + 1];
 #pragma unroll
-    for (int k = 0; k < RTree<NM>::NI; ++k) i += (k < ns && t.S[k] <= h) ? 1 : 0;
-    double lower = h, kd, sn = PF_INF;
-    for (;;) {
-        if (i >= ns) { kd = 1.0; sn = PF_INF; break; }
-        kd = (double)(nl - i);
-        sn = t.getS(i);
-        const int en = r_epoch_of(cx, sn);
-        const double Hn = cx.H[en] + (sn - cx.T[en]) * cx.I[en];
-        const double need = (Hn - Hc) * kd;
-        if (!(cx.ebuf > need)) break;
-        cx.ebuf -= need;
-        Hc = Hn; lower = sn; ++i;
+    for (int r = 0; r < NI; ++r) tv[r] = t.S[r];     // unused ranks hold 0: a harmless search, no branch
+    tv[NI] = h;
+    r_search4_batch<NI + 1>(cx.T, tv, ev);
+    const int e = ev[NI];
+    double Hn[NI];
+    {
+        double hh[NI + 1], tt[NI + 1], ii[NI + 1];
+#pragma unroll
+        for (int r = 0; r <= NI; ++r) { hh[r] = cx.H[ev[r]]; tt[r] = cx.T[ev[r]]; ii[r] = cx.I[ev[r]]; }
+#pragma unroll
+        for (int r = 0; r < NI; ++r) Hn[r] = hh[r] + (tv[r] - tt[r]) * ii[r];
+        hh[0] = hh[NI]; tt[0] = tt[NI]; ii[0] = ii[NI];
+        Hn_h = hh[0] + (h - tt[0]) * ii[0];
+    }
+    double Hc = Hn_h;
+    double lower = h, kd = 1.0, sn = PF_INF;
+    bool stopped = false;
+#pragma unroll
+    for (int r = 0; r < RTree<NM>::NI; ++r) {
+        const double sr = t.S[r];
+        if (r < ns && !stopped && sr > h) {          // nodes above the cut in rank order: r = number of nodes passed
+            const double k = (double)(nl - r);
+            const double need = (Hn[r] - Hc) * k;
+            if (!(cx.ebuf > need)) { stopped = true; kd = k; sn = sr; }
+            else { cx.ebuf -= need; Hc = Hn[r]; lower = sr; }
+        }
     }
     const double C = Hc + cx.ebuf / kd;
-    int es;
-    {
-        int lo = 0, hi = cx.E;            // invariant: H[lo] <= C, and (hi == E or H[hi] > C)
-        while (hi - lo > 1) {
-            int mid = (lo + hi) >> 1;
-            if (cx.H[mid] <= C) lo = mid; else hi = mid;
-        }
-        es = lo;
-    }
+    const int es = r_search4(cx.H, C);
     double t1 = cx.T[es] + (C - cx.H[es]) / cx.I[es];
     if (t1 < lower) t1 = lower;
     if (t1 > sn) t1 = sn;
