@@ -1229,23 +1229,28 @@ __global__ void k_count_fin(KArgs A) {
 // implement_resampling (pc.cpp:321-392) as a gather from the old buffer into the new one.
 // Blocks [nblocks, gridDim.x): after a resampling, re-base the run-length encoded composite
 // ancestor maps of all retained generations onto the new slots (st' = lo[st], empty runs dropped).
-#define PF_LEDGER_TILE 4096   // runs compacted per LDS tile (32 KB of staging)
-#define PF_LEDGER_PER (PF_LEDGER_TILE / PF_BS)
+#define PF_LEDGER_PER 8       // rounds per tile: a tile holds PF_LEDGER_PER * blockDim.x runs
+#define PF_LEDGER_MAXT 1024   // largest workgroup the ledger code is launched with
 #define PF_LEDGER_NEW 64      // the newest generations (long run lists) are re-based by a whole workgroup each
 
 __device__ void ledger_update(const KArgs& A, int lb, int nlb, int G) {
-    __shared__ int wcnt[PF_BS / 64];
-    __shared__ int stage[2 * PF_LEDGER_TILE];
-    __shared__ int stage_in[PF_BS * (PF_LEDGER_PER + 1)];
+    __shared__ int scnt[PF_LEDGER_PER * (PF_LEDGER_MAXT / 64)], sexc[PF_LEDGER_PER * (PF_LEDGER_MAXT / 64)];
+    __shared__ int stot;
     const Ctrl* c = A.ctrl;
     const long long Np = A.Np;
     const int* lo = A.lo + (size_t)(G % A.Gcap) * (Np + 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NT = (int)blockDim.x, NW = NT >> 6;
+    const int NCNT = PF_LEDGER_PER * NW;                 // <= 128: scanned by one wavefront, two counts per lane
     const int g_ret = c->g_retain;
     // ---- pass 1: workgroup per generation, newest PF_LEDGER_NEW generations (G itself: written by k_decide) ----
-    // Blocked compaction: every thread owns a contiguous slice of the run list (count, one workgroup
-    // scan, write), the survivors are staged in LDS and copied back, so a list of any length costs two
-    // barriers instead of one per 256 runs.  Loads are issued in batches of 8 independent requests.
+    // Compaction of a tile of PF_LEDGER_PER * blockDim.x runs with coalesced traffic only: element i of the tile
+    // belongs to (round j, wavefront, lane) = (i / NT, (i % NT) / 64, i % 64).  All starts and ancestors of the tile
+    // are requested at once, then all offspring offsets: two memory round trips per tile, and with the 1024
+    // threads of k_decide_ledger the newest list (the survivors of the last resampling) is a single tile.  The
+    // survivors of each (round, wavefront) are counted with a ballot, the counts are scanned by the first
+    // wavefront, and every lane writes its survivors to their final places.  In place is safe: every input of the
+    // tile is in registers before the first barrier, and the output never passes the tile's first input.
     for (int k = 1 + lb; k < PF_LEDGER_NEW; k += nlb) {
         const int g = G - k;
         if (g < g_ret) break;
@@ -1253,65 +1258,68 @@ __device__ void ledger_update(const KArgs& A, int lb, int nlb, int G) {
         int* ran = A.run_anc + (size_t)(g % A.Gcap) * Np;
         const int nr = A.nruns[g % A.Gcap];
         int out_base = 0;
-        for (int tile0 = 0; tile0 < nr; tile0 += PF_LEDGER_TILE) {
-            const int tile_n = nr - tile0 < PF_LEDGER_TILE ? nr - tile0 : PF_LEDGER_TILE;
-            const int per = (tile_n + PF_BS - 1) / PF_BS;
-            const int i0 = tile0 + tid * per;
-            const int i1 = i0 + per < tile0 + tile_n ? i0 + per : tile0 + tile_n;
-            // phase A: new starts of the slice (+1 sentinel) into LDS staging, 8 loads in flight
-            int cntk = 0;
-            int* my = stage_in + (size_t)tid * (PF_LEDGER_PER + 1);
-            for (int b = i0; b <= i1; b += 8) {
-                int st8[8];
+        for (int tile0 = 0; tile0 < nr; tile0 += PF_LEDGER_PER * NT) {
+            int ns[PF_LEDGER_PER], an[PF_LEDGER_PER], nx[PF_LEDGER_PER];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    int i = b + j;
-                    st8[j] = i <= i1 ? (i < nr ? rst[i] : (int)Np) : 0;
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    int i = b + j;
-                    if (i <= i1) my[i - i0] = lo[st8[j]];
-                }
+            for (int j = 0; j < PF_LEDGER_PER; ++j) {
+                const int i = tile0 + j * NT + tid;
+                ns[j] = i < nr ? rst[i] : 0;
+                an[j] = i < nr ? ran[i] : 0;
+                nx[j] = (lane == 63 && i < nr) ? (i + 1 < nr ? rst[i + 1] : (int)Np) : 0;     // successor of the last lane
             }
-            for (int i = i0; i < i1; ++i) cntk += my[i - i0 + 1] > my[i - i0] ? 1 : 0;
-            int incl = cntk;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                int o = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += o;
+            for (int j = 0; j < PF_LEDGER_PER; ++j) {
+                const int i = tile0 + j * NT + tid;
+                ns[j] = i < nr ? lo[ns[j]] : 0;
+                nx[j] = (lane == 63 && i < nr) ? lo[nx[j]] : 0;
             }
-            if (lane == 63) wcnt[wave] = incl;
+            unsigned keep = 0;
+#pragma unroll
+            for (int j = 0; j < PF_LEDGER_PER; ++j) {
+                const int i = tile0 + j * NT + tid;
+                int ne = __shfl_down(ns[j], 1, 64);
+                if (lane == 63) ne = nx[j];
+                else if (i + 1 >= nr) ne = (int)Np;                           // successor of the list's last run: lo[Np] = Np
+                const bool kp = i < nr && ne > ns[j];
+                const unsigned long long bal = __ballot(kp);
+                if (kp) keep |= 1u << j;
+                if (lane == 0) scnt[j * NW + wave] = __popcll(bal);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ancestors too have arrived before anyone stores
             __syncthreads();
-            int wbase = 0, total = 0;
-            for (int w = 0; w < PF_BS / 64; ++w) { if (w < wave) wbase += wcnt[w]; total += wcnt[w]; }
-            int pos = wbase + incl - cntk;
-            for (int b = i0; b < i1; b += 8) {
-                int an8[8];
+            if (tid < 64) {
+                const int c0 = 2 * lane < NCNT ? scnt[2 * lane] : 0;
+                const int c1 = 2 * lane + 1 < NCNT ? scnt[2 * lane + 1] : 0;
+                int incl = c0 + c1;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) an8[j] = b + j < i1 ? ran[b + j] : 0;
+                for (int d = 1; d < 64; d <<= 1) {
+                    int o = __shfl_up(incl, d, 64);
+                    if (lane >= d) incl += o;
+                }
+                const int excl = incl - (c0 + c1);
+                if (2 * lane < NCNT) sexc[2 * lane] = excl;
+                if (2 * lane + 1 < NCNT) sexc[2 * lane + 1] = excl + c0;
+                if (lane == 63) stot = incl;
+            }
+            __syncthreads();
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    int i = b + j;
-                    if (i < i1) {
-                        int ns = my[i - i0];
-                        if (my[i - i0 + 1] > ns) { stage[2 * pos] = ns; stage[2 * pos + 1] = an8[j]; ++pos; }
-                    }
+            for (int j = 0; j < PF_LEDGER_PER; ++j) {
+                const bool kp = (keep >> j) & 1u;
+                const unsigned long long bal = __ballot(kp);
+                if (kp) {
+                    const int pos = out_base + sexc[j * NW + wave] + __popcll(bal & ((1ULL << lane) - 1ULL));
+                    rst[pos] = ns[j];
+                    ran[pos] = an[j];
                 }
             }
-            __syncthreads();                 // all inputs of this tile are read, survivors sit in LDS
-            for (int j = tid; j < total; j += PF_BS) {
-                rst[out_base + j] = stage[2 * j];
-                ran[out_base + j] = stage[2 * j + 1];
-            }
-            out_base += total;
-            __syncthreads();
+            out_base += stot;
+            __syncthreads();                 // the count arrays are reused by the next tile
         }
         if (tid == 0) A.nruns[g % A.Gcap] = out_base;
     }
     // ---- pass 2: wavefront per generation for everything older (short lists, no workgroup barriers) ----
-    const int wl = lb * (PF_BS / 64) + wave;
-    const int nwl = nlb * (PF_BS / 64);
+    const int wl = lb * NW + wave;
+    const int nwl = nlb * NW;
     for (int g = G - PF_LEDGER_NEW - wl; g >= g_ret; g -= nwl) {
         int* rst = A.run_st + (size_t)(g % A.Gcap) * Np;
         int* ran = A.run_anc + (size_t)(g % A.Gcap) * Np;
@@ -1394,9 +1402,16 @@ __global__ __launch_bounds__(PF_BS) void k_decide(KArgs A, long long s, int mode
 
 // k_decide of row s with the ledger maintenance of row s-1 riding along in extra workgroups (single-stream pipeline:
 // it has to follow the counts of row s-1, which ran inside k_row(s), and precede those of row s)
-__global__ __launch_bounds__(PF_BS) void k_decide_ledger(KArgs A, long long s, int mode, Windows W, int nblocks, int ledger_nbt) {
-    if ((int)blockIdx.x <= nblocks) decide_body(A, s, mode, W, nblocks);
-    else ledger_body(A, A.sp ^ 1, nblocks, (int)blockIdx.x - (nblocks + 1), ledger_nbt);
+// Launched with PF_LEDGER_MAXT threads per workgroup: the re-basing of a run list is bound by memory round trips per
+// tile, and with 1024 threads the longest list is one tile.  The decide, bookkeeping and run-list workgroups are
+// written for PF_BS threads; their other wavefronts leave at once.
+__global__ __launch_bounds__(PF_LEDGER_MAXT) void k_decide_ledger(KArgs A, long long s, int mode, Windows W, int nblocks, int ledger_nbt) {
+    if ((int)blockIdx.x <= nblocks) {
+        if (threadIdx.x < PF_BS) decide_body(A, s, mode, W, nblocks);
+    } else {
+        const int bx = (int)blockIdx.x - (nblocks + 1);
+        if (bx >= nblocks || threadIdx.x < PF_BS) ledger_body(A, A.sp ^ 1, nblocks, bx, ledger_nbt);
+    }
 }
 
 __global__ __launch_bounds__(PF_BS) void k_resample(KArgs A, long long s, int nblocks) {
@@ -2479,7 +2494,7 @@ static int run_single_stream(pf_handle* h, long long s_begin, long long s_end) {
             // decide and ledger workgroups each hold ~120 KB of LDS, one per CU: keep the launch within one wave of 256 CUs
             const int lroom = 256 - (h->nblocks + 1) - h->nblocks;
             const int lnbt = pending ? h->nblocks + std::max(16, std::min(PF_LEDGER_BLOCKS, lroom)) : 0;
-            hipLaunchKernelGGL(k_decide_ledger, dim3(h->nblocks + 1 + lnbt), dim3(PF_BS), 0, h->stream, h->A, s, 0, h->step_windows,
+            hipLaunchKernelGGL(k_decide_ledger, dim3(h->nblocks + 1 + lnbt), dim3(PF_LEDGER_MAXT), 0, h->stream, h->A, s, 0, h->step_windows,
                                h->nblocks, lnbt);
         }
         if (check_launch("k_decide")) return -1;
