@@ -7,6 +7,6 @@ set -e
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 ARGS="$REPO/bench.py --length 1e7 --steps 1 --warmup 0 --no-cpu"
-rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_stats -o stats -- python3 $ARGS > $REPO/gpurun_out/prof_stats.json
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $REPO/gpurun_out/prof_fetch -o fetch -- python3 $ARGS > /dev/null
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $REPO/gpurun_out/prof_write -o write -- python3 $ARGS > /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_stats -o stats -- python3 $ARGS > $REPO/gpurun_out/prof_stats.json
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $REPO/gpurun_out/prof_fetch -o fetch -- python3 $ARGS > /dev/null
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $REPO/gpurun_out/prof_write -o write -- python3 $ARGS > /dev/null

@@ -165,8 +165,8 @@ __device__ __forceinline__ double philox_uniform(unsigned long long seed, unsign
 
 // Both halves of the Philox block at one draw index (the first equals philox_uniform).  A genealogy update of the
 // one-population engine takes its four uniforms (cut point, waiting-time refresh, re-attachment slot, next
-// recombination position) from two consecutive blocks: 32-bit integer multiplies run at a quarter of the VALU rate,
-// so the ten rounds of a block cost about as much as the rest of the update's arithmetic put together.
+// recombination position) from two consecutive blocks instead of four (a block is ~100 instructions; measured
+// ~300 cycles with one wavefront per SIMD).
 __device__ __forceinline__ void philox_pair(unsigned long long seed, unsigned slot, unsigned stream, unsigned long long draw,
                                             double& u0, double& u1) {
     unsigned c0 = (unsigned)draw, c1 = (unsigned)(draw >> 32), c2 = slot, c3 = stream;
