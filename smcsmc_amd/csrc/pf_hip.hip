@@ -315,7 +315,9 @@ __device__ __forceinline__ void d_adjust_with_delay(DStore& d, double& w_post, d
 // With fuse != 0 the launch also completes the previous row: the in-place normalisation or the resampling gather of
 // k_resample (pc.cpp:321-392, 435-437) happens while the particle is loaded, which removes one kernel and its
 // launch gap from the per-row critical path.  The arithmetic is k_resample's, operation for operation.
-template <int NM, bool BIASED>
+// EXACT: the number of haplotypes equals NM, so every `r < n - 1` guard of the unrolled tree loops is decided at
+// compile time (the guards are compare + exec-mask instructions, and instructions are what the time is made of)
+template <int NM, bool BIASED, bool EXACT = false>
 __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int fuse) {
     extern __shared__ double smem[];
     double* sT = smem;                            // epoch starts and ...
@@ -334,7 +336,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
     }
     __syncthreads();
     const Ctrl* c = A.ctrl;
-    const int n = A.n;
+    const int n = EXACT ? NM : A.n;
     const int cur = c->cur;
     const long long p = (long long)blockIdx.x * PF_BS + threadIdx.x;
     const bool active = p < A.Np;
@@ -1067,7 +1069,7 @@ __device__ __forceinline__ void count_run(AccT<P>& acc, const KArgs& A, int sp, 
 
 // The body of k_count for the workgroup (bx, by) of a column of nbxg workgroups; `sp` = parity of the step whose
 // weights and snapshot it reads.  Called from k_count and from the count workgroups of k_row.
-template <int NM, int P>
+template <int NM, int P, bool EXACT = false>
 __device__ __forceinline__ void count_body(const KArgs& A, int sp, int e0, const Windows& Wn, int bx, int by, int nbxg) {
     constexpr int NI = NM - 1;
     using AC = AccT<P>;
@@ -1079,7 +1081,7 @@ __device__ __forceinline__ void count_body(const KArgs& A, int sp, int e0, const
     const int first = Wn.first;
     if (e < first || e >= A.E) return;
     const long long Np = A.Np;
-    const int n = A.n;
+    const int n = EXACT ? NM : A.n;
     const int G = c->step[sp].G;                        // the generation the weights belong to
     const double inv = c->step[sp].inv_T;
     Win W;
@@ -1208,13 +1210,13 @@ __global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0, Windows Wn) {
 // load), the remaining workgroups evaluate the lagged counts of row s-1 (k_count's body).  The two halves touch
 // disjoint data -- everything the counts read from row s-1 is immutable or double-buffered by row parity -- so the
 // counting costs no synchronisation at all: no second stream, no event record / wait packets on the critical path.
-template <int NM, bool BIASED>
+template <int NM, bool BIASED, bool EXACT>
 __global__ __launch_bounds__(PF_BS) void k_row(KArgs A, long long s, int fuse, int nb, int count_first, Windows Wprev) {
     if ((int)blockIdx.x < nb) {
-        extend_reg_body<NM, BIASED>(A, s, fuse);
+        extend_reg_body<NM, BIASED, EXACT>(A, s, fuse);
     } else {
         const int idx = (int)blockIdx.x - nb;
-        count_body<NM, 1>(A, A.sp ^ 1, count_first, Wprev, idx % nb, idx / nb, nb);
+        count_body<NM, 1, EXACT>(A, A.sp ^ 1, count_first, Wprev, idx % nb, idx / nb, nb);
     }
 }
 
@@ -2465,7 +2467,10 @@ static void launch_row(pf_handle* h, long long s, int fuse, int count_first, con
     const size_t smem_reg = (size_t)(2 * PF_EPAD + h->E + 2 * PF_BIAS_MAX + 3) * 8;
     const int nb = h->nblocks;
     const int ncount = count_first < h->E ? nb * (h->E - count_first) : 0;
-    hipLaunchKernelGGL((k_row<NM, BIASED>), dim3(nb + ncount), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse, nb, count_first, Wprev);
+    if (h->n == NM)
+        hipLaunchKernelGGL((k_row<NM, BIASED, true>), dim3(nb + ncount), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse, nb, count_first, Wprev);
+    else
+        hipLaunchKernelGGL((k_row<NM, BIASED, false>), dim3(nb + ncount), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse, nb, count_first, Wprev);
 }
 
 static int run_single_stream(pf_handle* h, long long s_begin, long long s_end) {
