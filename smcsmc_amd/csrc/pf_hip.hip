@@ -348,6 +348,11 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
         const bool gather = fuse && c->flag;              // the previous row resampled: this slot starts as a copy of its parent
         const DState& from = gather ? A.st[cur ^ 1] : st;
         const long long a = gather ? (long long)A.parent[p] : p;
+        // offspring offsets of this slot (as the old particle) and of its parent: requested with the parent index and
+        // with the parent's state, not after them (each dependent request is a memory round trip of about 1 us)
+        const int* lo_tab = A.lo + (size_t)((c->gen - 1 + A.Gcap) % A.Gcap) * (A.Np + 1);
+        int lo_p = 0, lo_p1 = 0, lo_a = 0;
+        if (gather) { lo_p = lo_tab[p]; lo_p1 = lo_tab[p + 1]; lo_a = lo_tab[a]; }
         RTree<NM> t;
 #pragma unroll
         for (int r = 0; r < RTree<NM>::NI; ++r) {
@@ -395,11 +400,10 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
                 w_pilot *= inv;
             } else {
                 const int G = c->gen - 1;                  // the generation that ended with the previous row
-                const int* lo = A.lo + (size_t)(G % A.Gcap) * (A.Np + 1);
                 const double pos = c->cur_pos;
                 const DState& src = from;
                 // role of the old slot p: close its stretch if it has offspring
-                if (lo[p + 1] > lo[p]) {
+                if (lo_p1 > lo_p) {
                     double* rec = rec_ptr(A, p, widx);
                     rec[0] = src.x_mark[p];
                     rec[1] = pos;
@@ -419,7 +423,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
                 w_post = wp * adj;
                 w_pilot = wq * adj;
                 x_mark = pos;
-                if (p != lo[a] && pos < A.L) next_base = r_sample_next_base<false>(cx, pos);     // pc.cpp:357-368
+                if (p != lo_a && pos < A.L) next_base = r_sample_next_base<false>(cx, pos);     // pc.cpp:357-368
             }
         }
 
