@@ -121,7 +121,7 @@ def test_prior_initial_trees_bit_exact(oracle, hiplib):
     _assert_state_equal(o, g)
 
 
-@pytest.mark.parametrize("n,E,Np,seed", [(2, 1, 300, 1), (4, 8, 1000, 2), (8, 16, 256, 3), (3, 4, 65, 4), (6, 64, 200, 5), (4, 33, 130, 6)])
+@pytest.mark.parametrize("n,E,Np,seed", [(2, 1, 300, 1), (4, 8, 1000, 2), (8, 16, 256, 3), (3, 4, 65, 4), (6, 64, 200, 5), (4, 33, 130, 6), (12, 8, 128, 7)])
 def test_full_sweep_parity(oracle, hiplib, n, E, Np, seed):
     model = cases.make_model(n=n, E=E, L=1.5e5)
     segs = cases.make_segments(model, seed=seed, max_seg_len=5000)
