@@ -111,7 +111,67 @@ def cpu_baseline(args, model, segs):
                       "(-O3 -DNDEBUG); %d genealogy updates" % (done, args.np, dt, st["recombinations"])}
 
 
+def cpu_worker(path):
+    """Child process of cpu_baseline_all_cores: the same bounded oracle run on a saved prefix; prints one JSON line."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pickle
+    import oracle_lib
+    d = pickle.load(open(path, "rb"))
+    model, sub, Np, seed, seconds = d["model"], d["segs"], d["np"], d["seed"], d["seconds"]
+    o = oracle_lib.Oracle(model, Np, ess_fraction=0.5, seed=seed, max_trace_events=0)
+    o.init_prior(float(sub["start"][0]))
+    si = o.pack_segments(model, sub)
+    t0 = time.perf_counter()
+    done = 0
+    for s in range(len(sub["start"])):
+        o.update_segment(si, s)
+        pos = min(sub["start"][s] + sub["length"][s], model["loci_length"])
+        o.count(pos)
+        o.resample(pos)
+        done += 1
+        if time.perf_counter() - t0 > seconds:
+            break
+    print(json.dumps({"done": done, "dt": time.perf_counter() - t0}))
+
+
+def cpu_baseline_all_cores(args, model, segs):
+    """How the reference's front-end uses a host: one single-threaded process per chunk, all at once
+    (model.py:1094-1098).  One oracle process per core, each on the same prefix with its own seed; the processes never
+    touch the GPU (plain children started with subprocess, nothing is exec'ed from this process)."""
+    import pickle
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    oracle_lib.build()
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))      # a one-GPU box of this pool has a 16-core share
+    nseg = min(args.cpu_segments, len(segs["start"]))
+    sub = {k: v[:nseg] for k, v in segs.items()}
+    procs = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for c in range(cores):
+            path = os.path.join(tmp, "w%d.pkl" % c)
+            pickle.dump({"model": model, "segs": sub, "np": args.np, "seed": args.seed + c, "seconds": args.cpu_seconds},
+                        open(path, "wb"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path],
+                                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+        rates = []
+        for pr in procs:
+            out, _ = pr.communicate(timeout=args.cpu_seconds * 4 + 120)
+            try:
+                r = json.loads(out.strip().splitlines()[-1])
+                rates.append(r["done"] / r["dt"])
+            except Exception:
+                pass
+    return {"value": float(sum(rates)), "unit": "segments/s", "cores": len(rates), "kind": "port",
+            "sample": "%d concurrent single-threaded oracle processes, each the first segments of the same workload "
+                      "(Np=%d) for %.0f s; aggregate rate" % (len(rates), args.np, args.cpu_seconds)}
+
+
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-worker":
+        cpu_worker(sys.argv[2])
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -127,6 +187,7 @@ def main():
     ap.add_argument("--cpu-segments", type=int, default=2000)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the one-oracle-process-per-core baseline")
     ap.add_argument("--timing-period", type=int, default=16, help="time every k-th segment's kernels with HIP events")
     ap.add_argument("--no-local-recomb", action="store_true",
                     help="do not record the 100-bp local recombination map (the binary always records it, smcsmc.cpp:376-383)")
@@ -262,6 +323,8 @@ def main():
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, model, segs)
+            if not args.no_cpu_all_cores:
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args, model, segs)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
