@@ -321,6 +321,18 @@ def main():
                          "kernel_ms_estimate": {k: v[0] for k, v in kt.items()},
                          "kernel_launches": {k: v[1] for k, v in kt.items()}},
         }
+        if world == 1:
+            # the lag calibration (calculate_median_survival_distances, smcsmc.cpp:169-263: prior ARGs until every
+            # epoch has 200 survival distances) is model-only work outside the sweep: timed separately, and an
+            # all-in rate with it included, as the reference pays it once per chunk and E-step
+            from smcsmc_amd import pf as _pf
+            tc0 = time.perf_counter()
+            _, cal_trees = _pf.median_survival(model, seed=1, device=dev)
+            cal_s = time.perf_counter() - tc0
+            sweep_s = dt_max / args.steps
+            out["config"]["lag_calibration_ms"] = 1e3 * cal_s
+            out["config"]["lag_calibration_trees"] = int(cal_trees)
+            out["config"]["all_in_segments_per_s"] = total_segments / (sweep_s + cal_s)
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, model, segs)
             if not args.no_cpu_all_cores:

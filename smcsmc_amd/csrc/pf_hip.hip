@@ -1552,11 +1552,24 @@ __global__ __launch_bounds__(PF_BS) void k_partials(KArgs A) {
 // calculate_median_survival_distances (smcsmc.cpp:169-263): one prior ARG per lane; evolve it along
 // the sequence without data until every internal node of the initial tree has been removed (or
 // 0.6 L is reached) and report, per original node, its epoch and the position where it disappeared.
+// NM = 0: the recombination loop runs on the LDS tree (any nsam); NM = 4 / 8: on the register tree of the extend
+// kernels (nsam <= NM), same arithmetic operation for operation, about half the instructions.  The epoch tables of
+// the register path sit behind the LDS-tree block.
+template <int NM>
 __global__ __launch_bounds__(PF_BS) void k_calibrate(KArgs A, unsigned long long seed, long long rep0, long long nrep,
                                                      int* out_epoch, double* out_dist) {
     extern __shared__ double smem[];
     Smem m = carve(smem, A.n, A.E);
     load_model(A, m);
+    double* sT = (double*)((char*)smem + smem_bytes(A.n, A.E));
+    double* sH = sT + PF_EPAD;
+    double* sI = sH + PF_EPAD;
+    if (NM > 0)
+        for (int e = threadIdx.x; e < PF_EPAD; e += blockDim.x) {
+            sT[e] = e < A.E ? A.T[e] : PF_INF;
+            sH[e] = e < A.E ? A.Hc[e] : PF_INF;
+            if (e < A.E) sI[e] = A.inv2N[e];
+        }
     __syncthreads();
     long long r = (long long)blockIdx.x * PF_BS + threadIdx.x;
     if (r >= nrep) return;
@@ -1591,6 +1604,37 @@ __global__ __launch_bounds__(PF_BS) void k_calibrate(KArgs A, unsigned long long
     unsigned alive_mask = (1u << (n - 1)) - 1u;
     double next = sample_next_base(ln, 0.0);
     const double stop = A.L * 0.6;
+    if constexpr (NM > 0) {
+        RTree<NM> t;
+#pragma unroll
+        for (int rr = 0; rr < RTree<NM>::NI; ++rr) {
+            t.S[rr] = 0.0; t.C0[rr] = 0; t.C1[rr] = 0;
+            if (rr < n - 1) { t.S[rr] = LS(ln, rr); t.C0[rr] = LC(ln, rr, 0); t.C1[rr] = LC(ln, rr, 1); }
+        }
+        RCtx cx;
+        cx.T = sT; cx.I = sI; cx.H = sH; cx.E = A.E; cx.n = n; cx.L = A.L; cx.mu = A.mu; cx.rho = A.rho;
+        cx.seed = seed; cx.slot = ln.slot; cx.stream = 2; cx.ctr = ln.ctr; cx.ebuf = ln.ebuf; cx.Ltree = ln.Ltree;
+        cx.nb = 1; cx.bH = nullptr; cx.bS = nullptr; cx.last_iw = 1.0; cx.want_desc = false; cx.last_desc = 0;
+        cx.vbc = nullptr; cx.upd_fac = 1.0;
+        cx.gK = 0; cx.gpos = nullptr; cx.grho = nullptr; cx.gleaf = nullptr; cx.last_rbiw = 1.0; cx.ridx = 0; cx.g_rp = 0; cx.g_sb = 0;
+        while (alive > 0 && next < stop) {
+            const double x = next;
+            double h, tc, sp;
+            bool changed;
+            r_genealogy_update<NM, false>(cx, t, &h, &tc, &sp, &changed);
+            if (changed) {
+                for (int j = 0; j < n - 1; ++j)
+                    if (((alive_mask >> j) & 1u) && orig[j * PF_BS] == sp) {
+                        out_dist[r * (n - 1) + j] = x;
+                        alive_mask &= ~(1u << j);
+                        --alive;
+                        break;
+                    }
+            }
+            next = r_sample_next_base<true>(cx, x);
+        }
+        return;
+    }
     while (alive > 0 && next < stop) {
         double x = next;
         double h, tc, sp;
@@ -2947,7 +2991,12 @@ int pf_median_survival(const pf_model* m, uint64_t seed, int32_t min_events, int
     std::vector<void*> mp_allocs;
     HIPCHK(hipMalloc(&dT, E * 8)); HIPCHK(hipMalloc(&dI, E * 8)); HIPCHK(hipMalloc(&dRF, E * 4)); HIPCHK(hipMalloc(&derr, 4));
     HIPCHK(hipMemset(derr, 0, 4));
-    HIPCHK(hipMalloc(&dep, (size_t)PF_CAL_BATCH * (n - 1) * 4)); HIPCHK(hipMalloc(&ddist, (size_t)PF_CAL_BATCH * (n - 1) * 8));
+    // The stopping rule is evaluated batch by batch (D8), but PF_CAL_GROUP batches are simulated per launch: a batch of
+    // 16 384 trees fills a quarter of the SIMDs and takes as long as four.  Batches behind the one at which the rule
+    // fires are discarded, so the result is that of one launch per batch.
+    constexpr int PF_CAL_GROUP = 4;
+    const size_t per_batch = (size_t)PF_CAL_BATCH * (n - 1);
+    HIPCHK(hipMalloc(&dep, PF_CAL_GROUP * per_batch * 4)); HIPCHK(hipMalloc(&ddist, PF_CAL_GROUP * per_batch * 8));
     std::vector<double> inv2N(E);
     for (int e = 0; e < E; ++e) inv2N[e] = 1.0 / (2.0 * m->pop_sizes[(size_t)e * P]);
     std::vector<int> rf(E, 3);
@@ -2966,30 +3015,44 @@ int pf_median_survival(const pf_model* m, uint64_t seed, int32_t min_events, int
         if (build_mp_tables(m, tb) || upload_mp_tables(tb, A, mp_allocs)) return -1;
     }
     std::vector<std::vector<double>> surv(E);
-    std::vector<int> hep((size_t)PF_CAL_BATCH * (n - 1));
-    std::vector<double> hdist((size_t)PF_CAL_BATCH * (n - 1));
+    std::vector<int> hep(PF_CAL_GROUP * per_batch);
+    std::vector<double> hdist(PF_CAL_GROUP * per_batch);
     long long trees = 0;
     const size_t smem = P > 1 ? pf_mp_smem_bytes(n, E, P) : smem_bytes(n, E);
     if (P > 1 && pf_mp_prepare(smem)) { g_err = "pf_median_survival: the local-tree state does not fit the LDS"; return -1; }
-    if (P == 1 && smem > 64 * 1024) hipFuncSetAttribute((const void*)k_calibrate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    const size_t smem_cal = smem + (size_t)(2 * PF_EPAD + E) * 8;          // + the padded epoch tables of the register path
+    if (P == 1 && smem_cal > 64 * 1024) {
+        hipFuncSetAttribute((const void*)k_calibrate<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_cal);
+        hipFuncSetAttribute((const void*)k_calibrate<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_cal);
+        hipFuncSetAttribute((const void*)k_calibrate<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_cal);
+    }
     int cal_err = 0;
-    for (;;) {
+    auto finished = [&]() {
         int not_done = 0;
         for (int e = 0; e < E; ++e) not_done += (int)surv[e].size() < min_events;
-        if (not_done == 0 || trees >= max_trees) break;
+        return not_done == 0 || trees >= max_trees;
+    };
+    while (!finished()) {
+        const long long nrep = (long long)PF_CAL_GROUP * PF_CAL_BATCH;
         if (P > 1)
-            pf_mp_launch_calibrate(A, (unsigned long long)seed, trees, (long long)PF_CAL_BATCH, dep, ddist, derr, smem, 0);
+            pf_mp_launch_calibrate(A, (unsigned long long)seed, trees, nrep, dep, ddist, derr, smem, 0);
         else
-            hipLaunchKernelGGL(k_calibrate, dim3(PF_CAL_BATCH / PF_BS), dim3(PF_BS), smem, 0, A, (unsigned long long)seed, trees,
-                               (long long)PF_CAL_BATCH, dep, ddist);
+        {
+            const dim3 grid((unsigned)(nrep / PF_BS)), blk(PF_BS);
+            if (n <= 4) hipLaunchKernelGGL(k_calibrate<4>, grid, blk, smem_cal, 0, A, (unsigned long long)seed, trees, nrep, dep, ddist);
+            else if (n <= 8) hipLaunchKernelGGL(k_calibrate<8>, grid, blk, smem_cal, 0, A, (unsigned long long)seed, trees, nrep, dep, ddist);
+            else hipLaunchKernelGGL(k_calibrate<0>, grid, blk, smem_cal, 0, A, (unsigned long long)seed, trees, nrep, dep, ddist);
+        }
         HIPCHK(hipDeviceSynchronize());
         HIPCHK(hipMemcpy(&cal_err, derr, 4, hipMemcpyDeviceToHost));
         if (cal_err) break;
         HIPCHK(hipMemcpy(hep.data(), dep, hep.size() * 4, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(hdist.data(), ddist, hdist.size() * 8, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < hep.size(); ++i)
-            if (hdist[i] >= 0) surv[hep[i]].push_back(hdist[i]);
-        trees += PF_CAL_BATCH;
+        for (int b = 0; b < PF_CAL_GROUP && !finished(); ++b) {
+            for (size_t i = b * per_batch; i < (b + 1) * per_batch; ++i)
+                if (hdist[i] >= 0) surv[hep[i]].push_back(hdist[i]);
+            trees += PF_CAL_BATCH;
+        }
     }
     hipFree(dT); hipFree(dI); hipFree(dHc); hipFree(dRF); hipFree(dep); hipFree(ddist); hipFree(derr);
     for (void* q : mp_allocs) hipFree(q);

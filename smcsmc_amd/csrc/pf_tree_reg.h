@@ -469,7 +469,8 @@ __device__ __forceinline__ void r_sample_point_guided(RCtx& cx, const RTree<NM>&
 
 // One SMC' genealogy update; mirrors genealogy_update() in pf_hip.hip / Filter::genealogy_update in the oracle.
 template <int NM, bool BIASED>
-__device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, double* h_out, double* tc_out) {
+__device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, double* h_out, double* tc_out,
+                                                   double* sp_out = nullptr, bool* changed_out = nullptr) {
     const int n = cx.n;
     double h = 0.0;
     int lin = 0;
@@ -547,6 +548,8 @@ __device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, doubl
     int k = nslots + (has_root ? 1 : 0) + (has_stub ? 1 : 0);
     double u = u_attach;
     int idx = min((int)(u * (double)k), k - 1);
+    if (sp_out) *sp_out = Sp;
+    if (changed_out) *changed_out = !(has_stub && idx == k - 1);
     // where the floating lineage re-attaches: one insertion for all three outcomes (under divergence three
     // separate calls would each be executed by the whole wavefront)
     double h_ins = tc;
