@@ -2,6 +2,11 @@
 // (/root/reference/src/smcsmc.cpp:46-103, 278-401) on top of the HIP C-ABI (include/smcsmc_pf.h).
 #include <zlib.h>
 
+#include <algorithm>
+#include <string>
+#include <thread>
+#include <vector>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -247,25 +252,59 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
             const int64_t nb = (int64_t)(M.loci_length / 100.0);
             std::vector<double> lopp(nb), lcnt((size_t)(M.nsam + 2) * nb);
             pf_check(pf_get_local_recomb(h, lopp.data(), lcnt.data(), nb));
-            gzFile gz = gzopen(P.recombination_map_NAME.c_str(), "ab");
-            if (gz) {
-                std::ostringstream o;
-                if (P.EMcounter == 0) {
-                    o << "iter\tlocus\tsize\topp_per_nt";
-                    for (int s = 0; s < M.nsam; ++s) o << "\t" << s + 1;
-                    o << "\ttime\tlog_time\n";
+            // One million rows of eight numbers for a 100 Mb chunk: formatted and deflated in slices by a few threads,
+            // each slice a complete gzip member; members written in order form a valid .gz (zcat, Python's gzip and
+            // the boost reader of the front-end all read multi-member files).
+            std::vector<double> cumopp(nb);
+            {
+                double cur = 0.0;
+                for (int64_t idx = 0; idx < nb; ++idx) { cur += lopp[idx]; cumopp[idx] = cur; }
+            }
+            const int nthr = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((int64_t)std::thread::hardware_concurrency(), 16), nb / 4096 + 1));
+            std::vector<std::string> member(nthr);
+            std::vector<int> zrc(nthr, 0);
+            auto work = [&](int t) {
+                const int64_t i0 = nb * t / nthr, i1 = nb * (t + 1) / nthr;
+                std::string text;
+                text.reserve((size_t)(i1 - i0) * (24 + 12 * (M.nsam + 3)) + 256);
+                char buf[64];
+                if (t == 0 && P.EMcounter == 0) {
+                    text += "iter\tlocus\tsize\topp_per_nt";
+                    for (int sdx = 0; sdx < M.nsam; ++sdx) { snprintf(buf, sizeof buf, "\t%d", sdx + 1); text += buf; }
+                    text += "\ttime\tlog_time\n";
                 }
-                double current_opportunity = 0.0;
-                for (int64_t idx = 0; idx < nb; ++idx) {
-                    current_opportunity += lopp[idx];
-                    o << P.EMcounter << "\t" << fixed << setprecision(0) << idx * 100.0 + P.start_position << "\t" << 100.0 << "\t"
-                      << scientific << setprecision(5) << current_opportunity / 100.0;
-                    for (int k = 0; k < M.nsam + 2; ++k) o << "\t" << lcnt[(size_t)k * nb + idx] / 100.0;
-                    o << "\n";
-                    if (o.tellp() > (1 << 20)) { gzwrite(gz, o.str().data(), (unsigned)o.str().size()); o.str(""); }
+                for (int64_t idx = i0; idx < i1; ++idx) {
+                    // same characters as operator<< with fixed/setprecision(0) and scientific/setprecision(5)
+                    int len = snprintf(buf, sizeof buf, "%zu\t%.0f\t%.0f\t%.5e", P.EMcounter, idx * 100.0 + P.start_position, 100.0,
+                                       cumopp[idx] / 100.0);
+                    text.append(buf, (size_t)len);
+                    for (int k = 0; k < M.nsam + 2; ++k) {
+                        len = snprintf(buf, sizeof buf, "\t%.5e", lcnt[(size_t)k * nb + idx] / 100.0);
+                        text.append(buf, (size_t)len);
+                    }
+                    text += '\n';
                 }
-                gzwrite(gz, o.str().data(), (unsigned)o.str().size());
-                gzclose(gz);
+                z_stream zs;
+                memset(&zs, 0, sizeof zs);
+                if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) { zrc[t] = 1; return; }
+                std::string& out = member[t];
+                out.resize(deflateBound(&zs, (uLong)text.size()) + 64);
+                zs.next_in = (Bytef*)text.data(); zs.avail_in = (uInt)text.size();
+                zs.next_out = (Bytef*)&out[0]; zs.avail_out = (uInt)out.size();
+                if (deflate(&zs, Z_FINISH) != Z_STREAM_END) zrc[t] = 1;
+                out.resize(zs.total_out);
+                deflateEnd(&zs);
+            };
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nthr; ++t) pool.emplace_back(work, t);
+            work(0);
+            for (auto& th : pool) th.join();
+            bool ok = true;
+            for (int t = 0; t < nthr; ++t) ok = ok && zrc[t] == 0;
+            FILE* fz = ok ? fopen(P.recombination_map_NAME.c_str(), "ab") : nullptr;
+            if (fz) {
+                for (int t = 0; t < nthr; ++t) fwrite(member[t].data(), 1, member[t].size(), fz);
+                fclose(fz);
             }
         }
         // log_counts (count.cpp:66-158) with the prior pseudo-counts of init_coal_and_recomb (count.cpp:161-193)
