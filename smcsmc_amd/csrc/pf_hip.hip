@@ -270,48 +270,6 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
 // ------------------------------------------------------------------ k_extend_reg
 // Same computation as k_extend with the local tree held in registers (pf_tree_reg.h); used for
 // n <= 8.  LDS only carries the two epoch tables.
-// delayed importance weights: adjustWeightsWithDelay / applyDelayedAdjustment (particle.hpp:185-209)
-struct DStore {
-    double* pos; double* fac; double* delta; int* k;   // column of this particle: element i at [i * Np]
-    long long Np;
-    int count;
-    double total;
-};
-__device__ __forceinline__ void d_apply_earliest(DStore& d, double& w_pilot) {
-    int m = 0;
-    double pm = d.pos[0];
-    for (int i = 1; i < d.count; ++i) { double pi = d.pos[(size_t)i * d.Np]; if (pi < pm) { pm = pi; m = i; } }
-    double f = d.fac[(size_t)m * d.Np];
-    w_pilot *= f;
-    d.total /= f;
-    int km = d.k[(size_t)m * d.Np];
-    if (km > 1) {
-        double dl = d.delta[(size_t)m * d.Np];
-        d.pos[(size_t)m * d.Np] = pm + 2 * dl;
-        d.delta[(size_t)m * d.Np] = 2 * dl;
-        d.k[(size_t)m * d.Np] = km - 1;
-    } else {
-        int last = --d.count;
-        d.pos[(size_t)m * d.Np] = d.pos[(size_t)last * d.Np];
-        d.fac[(size_t)m * d.Np] = d.fac[(size_t)last * d.Np];
-        d.delta[(size_t)m * d.Np] = d.delta[(size_t)last * d.Np];
-        d.k[(size_t)m * d.Np] = d.k[(size_t)last * d.Np];
-    }
-}
-__device__ __forceinline__ void d_adjust_with_delay(DStore& d, double& w_post, double& w_pilot, double adj, double delay, double cur) {
-    w_post *= adj;
-    if ((adj > 0.99 && adj < 1.01) || (delay <= 1)) { w_pilot *= adj; return; }
-    while (d.count == PF_DCAP) d_apply_earliest(d, w_pilot);      // an entry leaves only with its third part
-    d.total *= adj;
-    double final_pos = cur + delay;
-    double delta = (final_pos - cur) / 7.0;
-    int i = d.count++;
-    d.pos[(size_t)i * d.Np] = cur + delta;
-    d.fac[(size_t)i * d.Np] = dexp(dlog(adj) * (1.0 / 3));
-    d.delta[(size_t)i * d.Np] = delta;
-    d.k[(size_t)i * d.Np] = 3;
-}
-
 // With fuse != 0 the launch also completes the previous row: the in-place normalisation or the resampling gather of
 // k_resample (pc.cpp:321-392, 435-437) happens while the particle is loaded, which removes one kernel and its
 // launch gap from the per-row critical path.  The arithmetic is k_resample's, operation for operation.
@@ -2015,12 +1973,11 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     if (ndev <= 0) return fail("pf_create: no HIP device available (there is no CPU fallback)");
     if (device < 0 || device >= ndev) return fail("pf_create: device index out of range");
     if (m->n_pops < 1 || m->n_pops > PF_PMAX) return fail("pf_create: n_pops must be in 1..4");
-    if (m->n_pops > 1 && m->n_bias_heights > 0) return fail("pf_create: focused sampling is implemented for one population");
     if (m->nsam < 2 || m->nsam > PF_NMAX) return fail("pf_create: nsam must be in 2..16");
     if (m->n_epochs < 1 || m->n_epochs > PF_EMAX) return fail("pf_create: n_epochs must be in 1..64");
     if (p->np < 1 || p->np > 262144) return fail("pf_create: np must be in 1..262144");
     if (m->n_bias_heights < 0 || m->n_bias_heights > PF_BIAS_MAX) return fail("pf_create: at most 8 bias heights are supported");
-    if (m->n_bias_heights > 0 && m->nsam > 8) return fail("pf_create: focused sampling is implemented for nsam <= 8");
+    if (m->n_bias_heights > 0 && m->nsam > 8 && m->n_pops == 1) return fail("pf_create: focused sampling with one population is implemented for nsam <= 8");
     if (m->n_bias_heights > 0 && (!m->bias_heights || !m->bias_strengths || !m->application_delays))
         return fail("pf_create: bias_heights, bias_strengths and application_delays must all be given");
     if (m->n_rate_segments > 0) {

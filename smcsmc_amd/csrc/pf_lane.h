@@ -7,6 +7,48 @@
 
 using namespace pf;
 
+// delayed importance weights: adjustWeightsWithDelay / applyDelayedAdjustment (particle.hpp:185-209)
+struct DStore {
+    double* pos; double* fac; double* delta; int* k;   // column of this particle: element i at [i * Np]
+    long long Np;
+    int count;
+    double total;
+};
+__device__ __forceinline__ void d_apply_earliest(DStore& d, double& w_pilot) {
+    int m = 0;
+    double pm = d.pos[0];
+    for (int i = 1; i < d.count; ++i) { double pi = d.pos[(size_t)i * d.Np]; if (pi < pm) { pm = pi; m = i; } }
+    double f = d.fac[(size_t)m * d.Np];
+    w_pilot *= f;
+    d.total /= f;
+    int km = d.k[(size_t)m * d.Np];
+    if (km > 1) {
+        double dl = d.delta[(size_t)m * d.Np];
+        d.pos[(size_t)m * d.Np] = pm + 2 * dl;
+        d.delta[(size_t)m * d.Np] = 2 * dl;
+        d.k[(size_t)m * d.Np] = km - 1;
+    } else {
+        int last = --d.count;
+        d.pos[(size_t)m * d.Np] = d.pos[(size_t)last * d.Np];
+        d.fac[(size_t)m * d.Np] = d.fac[(size_t)last * d.Np];
+        d.delta[(size_t)m * d.Np] = d.delta[(size_t)last * d.Np];
+        d.k[(size_t)m * d.Np] = d.k[(size_t)last * d.Np];
+    }
+}
+__device__ __forceinline__ void d_adjust_with_delay(DStore& d, double& w_post, double& w_pilot, double adj, double delay, double cur) {
+    w_post *= adj;
+    if ((adj > 0.99 && adj < 1.01) || (delay <= 1)) { w_pilot *= adj; return; }
+    while (d.count == PF_DCAP) d_apply_earliest(d, w_pilot);      // an entry leaves only with its third part
+    d.total *= adj;
+    double final_pos = cur + delay;
+    double delta = (final_pos - cur) / 7.0;
+    int i = d.count++;
+    d.pos[(size_t)i * d.Np] = cur + delta;
+    d.fac[(size_t)i * d.Np] = dexp(dlog(adj) * (1.0 / 3));
+    d.delta[(size_t)i * d.Np] = delta;
+    d.k[(size_t)i * d.Np] = 3;
+}
+
 // LDS carve-up shared by k_init / k_extend
 struct Smem {
     double* S; double* t0; double* t1; double* T; double* I; int* RF; int8_t* C;
@@ -71,6 +113,68 @@ __device__ __forceinline__ void sample_point(Lane& ln, int* rp_out, int* sb_out,
         r -= seg;
         prev = sr;
     }
+    lineages_at(ln, n - 1, h, lin, rp_out, sb_out);
+    *h_out = h;
+}
+
+// samplePoint with height-band weights (particle.cpp:1020-1126) on the LDS tree; pieces = (time slice) x (band),
+// ascending in height.  Same operation order as r_sample_point_biased and the oracle's biased branch; `iw_out` = target
+// density over sampled density.  bH = 0, h1..hk, +inf; bS = strengths; nb = number of bands.
+__device__ __forceinline__ void sample_point_biased(Lane& ln, const double* bH, const double* bS, int nb, int* rp_out, int* sb_out,
+                                                    double* h_out, double* iw_out) {
+    const int n = ln.n;
+    double Lw = 0.0;
+    {
+        double pv = 0.0;
+        int b = 0;
+        for (int ri = 0; ri < n - 1; ++ri) {
+            int k = n - ri;
+            double top = LS(ln, ri);
+            while (b + 1 < nb && bH[b + 1] <= pv) ++b;
+            int bb = b;
+            for (;;) {
+                double lo_ = pv > bH[bb] ? pv : bH[bb];
+                double hi_ = top < bH[bb + 1] ? top : bH[bb + 1];
+                if (hi_ > lo_) Lw += ((double)k * bS[bb]) * (hi_ - lo_);
+                if (bH[bb + 1] >= top || bb + 1 >= nb) break;
+                ++bb;
+            }
+            pv = top;
+        }
+    }
+    double r = uni(ln) * Lw;
+    double l_lo = 0, l_hi = 0, l_str = 1;
+    int l_k = 1;
+    bool sel = false;
+    double pv = 0.0;
+    int b = 0;
+    for (int ri = 0; ri < n - 1 && !sel; ++ri) {
+        int k = n - ri;
+        double top = LS(ln, ri);
+        while (b + 1 < nb && bH[b + 1] <= pv) ++b;
+        int bb = b;
+        for (;;) {
+            double lo_ = pv > bH[bb] ? pv : bH[bb];
+            double hi_ = top < bH[bb + 1] ? top : bH[bb + 1];
+            if (hi_ > lo_) {
+                double wlen = ((double)k * bS[bb]) * (hi_ - lo_);
+                l_lo = lo_; l_hi = hi_; l_str = bS[bb]; l_k = k;
+                if (r < wlen) { sel = true; break; }
+                r -= wlen;
+            }
+            if (bH[bb + 1] >= top || bb + 1 >= nb) break;
+            ++bb;
+        }
+        pv = top;
+    }
+    double q = r / (l_str * (l_hi - l_lo));
+    int lin = min((int)q, l_k - 1);
+    if (lin < 0) lin = 0;
+    double h = l_lo + (q - (double)lin) * (l_hi - l_lo);
+    if (!(h < l_hi)) h = l_lo;
+    double sampled = l_str / Lw;
+    double target = 1.0 / ln.Ltree;
+    *iw_out = target / sampled;
     lineages_at(ln, n - 1, h, lin, rp_out, sb_out);
     *h_out = h;
 }

@@ -122,6 +122,7 @@ __global__ __launch_bounds__(PF_BS) void k_init_mp(KArgs A, double initial_posit
     st.x_mark[p] = 0.0;
     st.Ltree[p] = ln.Ltree;
     st.mark_limit[p] = A.E - 1;
+    if (A.n_bias > 0) { A.st[0].total_delayed[p] = 1.0; A.st[0].dcount[p] = 0; }
     A.rng_ctr[p] = ln.ctr;
     A.ebuf[p] = ln.ebuf;
     A.widx[p] = widx;
@@ -135,6 +136,11 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
     SmemMP mm = carve_mp(smem, A.n, A.E, A.P);
     load_model(A, m);
     load_model_mp(A, mm);
+    __shared__ double sBH[PF_BIAS_MAX + 2], sBS[PF_BIAS_MAX + 1];      // focused sampling: band boundaries / strengths
+    if (threadIdx.x < PF_BIAS_MAX + 2) {
+        sBH[threadIdx.x] = A.bias_H[threadIdx.x];
+        if (threadIdx.x < PF_BIAS_MAX + 1) sBS[threadIdx.x] = A.bias_S[threadIdx.x];
+    }
     __syncthreads();
     const Ctrl* c = A.ctrl;
     const int n = A.n;
@@ -143,10 +149,16 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
     const bool active = p < A.Np;
     const int lane = threadIdx.x & 63;
     double w_post = 0.0, w_pilot = 0.0;
+    const bool biased = A.n_bias > 0;
+    bool has_pending = false;
     if (active) {
         DState& st = A.st[cur];
         Lane ln = make_lane(A, m, p);
         MLane ml = make_mlane(A, mm);
+        DStore ds;
+        ds.pos = st.dpos + p; ds.fac = st.dfac + p; ds.delta = st.ddelta + p; ds.k = st.dk + p; ds.Np = A.Np;
+        ds.count = 0; ds.total = 1.0;
+        if (biased) { ds.count = st.dcount[p]; ds.total = st.total_delayed[p]; }
         for (int r = 0; r < n - 1; ++r) {
             LS(ln, r) = st.S[(size_t)r * A.Np + p];
             LC(ln, r, 0) = st.C[(size_t)(2 * r) * A.Np + p];
@@ -204,7 +216,9 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
                 int rp = 0, sb = 0;
                 double h, tc, sp_removed;
                 bool changed;
-                sample_point(ln, &rp, &sb, &h);
+                double iw = 1.0;
+                if (biased) sample_point_biased(ln, sBH, sBS, A.n_bias + 1, &rp, &sb, &h, &iw);
+                else sample_point(ln, &rp, &sb, &h);
                 const unsigned desc = A.lmap_opp ? lane_desc_mask(ln, LC(ln, rp, sb), tmp0) : 0u;
                 unsigned p0 = pl.idx;
                 mp_genealogy_rest<true>(ln, ml, pl, limit, rp, sb, h, &tc, &sp_removed, &changed);
@@ -216,12 +230,37 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
                 if (ml.err) break;
                 if (leaf_status == 0) B = tracked_len_lane(ln, data, tmp0);
                 if (leaf_status == 1) B = ln.Ltree;
+                if (biased) {
+                    // particle.cpp:866-891: immediate vs delayed application of the importance weight
+                    const int nbands = A.n_bias + 1;
+                    const double delay_height = A.delay_type == 0 ? h : tc;
+                    int idx = 0;
+                    while (idx + 1 < nbands + 1 && sBH[idx + 1] < delay_height) ++idx;
+                    if (idx >= nbands) idx = nbands - 1;
+                    double rbiw = iw;                       // without a guide both weights coincide
+                    if (sBS[idx] == 1.0) { w_post *= rbiw; w_pilot *= rbiw; iw /= rbiw; }
+                    const double delay = A.app_delays[epoch_of(ln, delay_height)];
+                    d_adjust_with_delay(ds, w_post, w_pilot, iw, delay, updated_to);
+                }
                 next_base = sample_next_base(ln, updated_to);
                 x_mark = updated_to;
                 mark_limit = limit;
             }
         }
         mp_report(A, ml);
+        if (biased) {
+            // apply the factors that fell due during this extension (particle.cpp:910-916)
+            for (;;) {
+                if (ds.count == 0) break;
+                double pm = ds.pos[0];
+                for (int i = 1; i < ds.count; ++i) { double pi = ds.pos[(size_t)i * ds.Np]; if (pi < pm) pm = pi; }
+                if (!(pm < extend_to)) break;
+                d_apply_earliest(ds, w_pilot);
+            }
+            st.dcount[p] = ds.count;
+            st.total_delayed[p] = ds.total;
+            has_pending = ds.count > 0;
+        }
 
         if (A.seg_state[s] == 0) {
             // update_weight_at_site: marginalise over phasings of unphased hets (pc.cpp:138-224)
@@ -299,6 +338,10 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
         A.chunk_pil[chunk] = sc;
         A.chunk_pp[chunk] = scp;
         A.chunk_mx1[chunk] = scm;
+    }
+    if (biased) {
+        unsigned long long pend = __ballot(has_pending);
+        if (lane == 0 && chunk < (A.Np + 63) / 64) A.chunk_dpend[chunk] = __popcll(pend);
     }
 }
 

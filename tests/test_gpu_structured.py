@@ -191,3 +191,45 @@ def test_structured_binary_end_to_end(hiplib, tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "Migr" in open(tmp_path / "cal.out").read()
+    # the regression configuration itself (test_two_pops.py:31-37): focused sampling, bias heights [400], strengths [10, 1]
+    r = subprocess.run([binary] + core + common + ["-Np", "1000", "-seed", "8", "-bias_heights", "400", "-bias_strengths", "10", "1",
+                                                   "-o", str(tmp_path / "bias")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Application delay for epoch" in r.stderr
+    db = outfile.parse_outfile(str(tmp_path / "bias.out"))
+    for key in [("Coal", 1, 0, -1, -1), ("Coal", 1, 1, -1, -1), ("Coal", 2, 0, -1, -1)]:
+        ne = db[(key, "Opp")] / (2 * db[(key, "Count")])
+        assert 6000 < ne < 16000, (key, ne)
+    recb = db[(("Recomb", -1, -1, -1, -1), "Count")] / db[(("Recomb", -1, -1, -1, -1), "Opp")]
+    assert 0.8e-8 < recb < 1.25e-8
+    assert db[(("Delay", -1, -1, -1, -1), "Count")] > 0                      # importance weights were held back
+
+
+@pytest.mark.parametrize("n,P,delay_type", [(4, 2, 0), (8, 2, 0), (6, 3, 1)])
+def test_focused_sampling_with_structure_parity(oracle, hiplib, n, P, delay_type):
+    """-bias_heights / -bias_strengths with several populations (the configuration of the reference's own two-population
+    regression tests, test_two_pops.py:36-37): biased cut point on the LDS tree, delayed importance weights, resampling
+    with pending factors -- trees, migration events, weights, ESS and resampling indices bit-identical to the oracle."""
+    from smcsmc_amd import ParticleFilter
+    E = 6
+    model = cases.make_structured(cases.make_model(n=n, E=E, L=1.2e5), P=P)
+    model = dict(model, bias_heights=[400.0], bias_strengths=[5.0, 1.0], application_delays=np.full(E, 3000.0), delay_type=delay_type)
+    segs = cases.make_segments(cases.make_model(n=n, E=E, L=1.2e5), seed=90 + n, max_seg_len=5000)
+    o = oracle.Oracle(model, 320, seed=8, max_trace_events=64); o.init_prior(segs["start"][0]); si = o.pack_segments(model, segs)
+    g = ParticleFilter(model, 320, seed=8, max_trace_events=64); g.init_prior(segs["start"][0]); g.load_segments(segs)
+    o.run(si); g.run(); g.finish()
+    to, tg = o.trace(), g.trace()
+    assert (to["resampled"] == tg["resampled"]).all() and to["resampled"].sum() > 0
+    bits = lambda a: np.asarray(a, dtype=np.float64).view(np.int64)   # noqa: E731
+    for k in ("T", "ess", "logl"):
+        assert (bits(to[k]) == bits(tg[k])).all(), k
+    so, po_ = o.resample_events(); sg_, pg_ = g.resample_events()
+    assert (so == sg_).all() and (po_ == pg_).all()
+    po, pg = o.particles(), g.particles()
+    assert (po["children"] == pg["children"]).all()
+    for k in ("heights", "w_post", "w_pilot", "next_base"):
+        assert (bits(po[k]) == bits(pg[k])).all(), k
+    co, cg = o.counts(), g.counts()
+    for k in ("coal_count", "coal_opp", "rec_count", "rec_opp", "mig_count", "mig_opp"):       # sums in another order
+        np.testing.assert_allclose(cg[k], co[k], rtol=1e-9, atol=1e-9 * np.abs(co[k]).max(), err_msg=k)
+    np.testing.assert_allclose(cg["delayed_opp"], co["delayed_opp"], rtol=1e-12)

@@ -330,3 +330,21 @@ def test_recombination_guide_importance_weights_are_unbiased(oracle):
         assert abs(c["rec_count"].sum() / c["rec_opp"].sum() / 1e-8 - 1) < 0.02
         assert np.abs(c["coal_count"][2:5] / c["coal_opp"][2:5] * 2e4 - 1).max() < 0.06
         assert abs(o.logl()) < 0.5
+
+
+def test_focused_sampling_with_structure_is_unbiased(oracle):
+    """Height-biased cut points in an isolation-with-migration model, no data: weighted counts still reproduce the
+    model's recombination and per-population coalescence rates, and the likelihood stays at one."""
+    n, E, L = 4, 6, 1e6
+    model = cases.make_structured(cases.make_model(n=n, E=E, L=L), P=2)
+    model = dict(model, bias_heights=[400.0], bias_strengths=[5.0, 1.0], application_delays=np.full(E, 5000.0))
+    segs = cases.nodata_segments(model, 4000.0)
+    o = oracle.Oracle(model, 1500, seed=3)
+    o.init_prior(0.0)
+    o.run(o.pack_segments(model, segs))
+    c = o.counts()
+    assert o.trace()["resampled"].sum() > 0                                     # the bias does move the weights
+    assert abs(c["rec_count"].sum() / c["rec_opp"].sum() / 1e-8 - 1) < 0.02
+    rates = c["coal_count"][2:4] / c["coal_opp"][2:4] * 2e4
+    assert np.abs(rates - 1).max() < 0.06
+    assert abs(o.logl()) < 0.5
