@@ -293,7 +293,7 @@ struct Filter {
      * over (the reference multiplies event by event: same product, rounding aside) */
     double upd_fac = 1.0;
     void apply_vb(Particle& p) { if (!M.vb_coal.empty()) { p.w_post *= upd_fac; p.w_pilot *= upd_fac; } upd_fac = 1.0; }
-    double last_iw = 1.0, last_tc = 0.0;
+    double last_iw = 1.0, last_tc = 0.0, last_first_event = 0.0;
     double last_rbiw = 1.0;       /* recombination_bias_importance_weight_ (particle.cpp:1113-1121) */
     int64_t slot_override = -1;   /* calibration: RNG state lives in rng[0], stream keyed by the replicate index */
     /* The four uniforms of one genealogy update of the one-population engine (cut point, waiting-time refresh,
@@ -507,6 +507,7 @@ struct Filter {
         double pt[MMAX], rt[MMAX];        /* migration events picked up on the way: floating / root lineage */
         int8_t pq[MMAX], rq[MMAX];
         int weight;                       /* coalescence partners at tc (consistency check) */
+        double tfirst;                    /* first sampled event of the walk, migration or coalescence (first_event_height_) */
     };
 
     /* The floating lineage starts at height h in population pf0 and moves up through the tree `t`
@@ -525,6 +526,7 @@ struct Filter {
         while (j < t.nm && t.Mt[j] <= tt) ++j;
         int pf = pf0, pr = pop_base(t, root_id);
         W.npath = W.nrpath = 0;
+        W.tfirst = -1.0;
         for (;;) {
             const bool root_active = tt >= Hr;
             double tn_node = i < ni ? t.S[i] : HUGE_VAL;
@@ -574,6 +576,7 @@ struct Filter {
                 }
             }
             if (fire) {
+                if (W.tfirst < 0.0) W.tfirst = t1;          /* particle.cpp:263-264 */
                 g.ebuf = -smc_log(uni(slot));
                 if (rec_p && !M.vb_coal.empty())            /* adjustWeights(exp_digamma(c)/c), particle.cpp:266-272 */
                     upd_fac *= kind == 1 ? M.vb_coal[e * P + pf] : M.vb_mig[(e * P + (kind == 2 ? pf : pr)) * P + to];
@@ -660,6 +663,7 @@ struct Filter {
         mp_coalesce(slot, &p, t, n - 1, n + n - 2, h, pf0, x, limit, W);
         const double tc = W.tc;
         last_tc = tc;
+        last_first_event = W.tfirst;
         const double Sp = t.S[rp];
         const int p_pop = t.Pn[rp];
         const bool p_was_root = (rp == n - 2);
@@ -1035,6 +1039,7 @@ struct Filter {
         for (int i = 0; i < n - 1; ++i) Sold[i] = t.S[i];
         double tc = coalesce_up(slot, &p, Sold, n - 1, n, h, x, limit);
         last_tc = tc;
+        last_first_event = tc;
         double Sp = t.S[rp];
         /* --- detach: remove p, sibling takes its place --- */
         int b_id = t.C[rp][sb], s_id = t.C[rp][1 - sb];
@@ -1333,7 +1338,8 @@ struct Filter {
                     /* particle.cpp:866-891: immediate vs delayed application of the importance weight */
                     double iw = last_iw;
                     double rbiw = last_rbiw;                       /* without a guide both weights coincide */
-                    double delay_height = M.delay_type == 0 ? h : last_tc;
+                    /* RESAMPLE_DELAY_RECOMB: the cut height; _COAL: first_coal_height_; _COALMIGR: first_event_height_ */
+                    double delay_height = M.delay_type == 0 ? h : (M.delay_type == 2 ? last_first_event : last_tc);
                     int idx = 0;
                     while (idx + 1 < (int)M.bias_H.size() && M.bias_H[idx + 1] < delay_height) ++idx;
                     if (idx >= (int)M.bias_S.size()) idx = (int)M.bias_S.size() - 1;

@@ -189,7 +189,7 @@ __device__ __forceinline__ int mp_slots_at(const Lane& ln, const MLane& ml, int 
     return cnt;
 }
 
-struct MWalk { double tc; int pf, pr, weight; };
+struct MWalk { double tc; int pf, pr, weight; double tfirst; };   // tfirst: first sampled event of the walk (migration or coalescence)
 
 // The floating lineage starts at height h in population pf0 and moves up through the stored tree (ni internal
 // nodes, root_id its top node or the single leaf); above the root the root's own lineage is the second active
@@ -204,6 +204,7 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
     int e = epoch_of(ln, tt);
     int i = 0, j = 0;
     int pf = pf0, pr = mp_pop_base(ln, ml, root_id);
+    W.tfirst = -1.0;
     if (LOG) { pl.fopen = false; pl.ropen = false; }
     // Lineages of the stored tree per population, kept up to date while the walk moves up (the restatement
     // recounts them in every interval; the numbers are the same).  Bp[id] = current population of the lineage
@@ -340,6 +341,7 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
                 // ---- an event falls into this interval
                 if (used == KP) break;                    // out of pre-drawn numbers: draw more, then carry on
                 const double t1 = tt + ln.ebuf / lam;
+                if (W.tfirst < 0.0) W.tfirst = t1;
                 const double ut = used == 0 ? u_type[0] : u_type[1];
                 int kind, to = 0;
                 {
@@ -447,7 +449,7 @@ __device__ __forceinline__ void mp_build_initial_tree(Lane& ln, MLane& ml, PLog&
 // the part of a genealogy update after the recombination point (slot (rp,sb), height h) has been sampled
 template <bool LOG>
 __device__ __forceinline__ void mp_genealogy_rest(Lane& ln, MLane& ml, PLog& pl, int limit, int rp, int sb, double h,
-                                                  double* tc_out, double* sp_out, bool* changed_out) {
+                                                  double* tc_out, double* sp_out, bool* changed_out, double* tfirst_out = nullptr) {
     const int n = ln.n;
     int b_id = LC(ln, rp, sb), s_id = LC(ln, rp, 1 - sb);
     const int pf0 = mp_pop_at(ln, ml, b_id, h);
@@ -455,6 +457,7 @@ __device__ __forceinline__ void mp_genealogy_rest(Lane& ln, MLane& ml, PLog& pl,
     mp_coalesce<LOG>(ln, ml, n - 1, n + n - 2, h, pf0, pl, limit, W);
     const double tc = W.tc;
     *tc_out = tc;
+    if (tfirst_out) *tfirst_out = W.tfirst;
     const double Sp = LS(ln, rp);
     *sp_out = Sp;
     *changed_out = true;

@@ -221,7 +221,8 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
                 else sample_point(ln, &rp, &sb, &h);
                 const unsigned desc = A.lmap_opp ? lane_desc_mask(ln, LC(ln, rp, sb), tmp0) : 0u;
                 unsigned p0 = pl.idx;
-                mp_genealogy_rest<true>(ln, ml, pl, limit, rp, sb, h, &tc, &sp_removed, &changed);
+                double tfirst = 0.0;
+                mp_genealogy_rest<true>(ln, ml, pl, limit, rp, sb, h, &tc, &sp_removed, &changed, &tfirst);
                 if (ln.vbc) { w_post *= ln.upd_fac; w_pilot *= ln.upd_fac; ln.upd_fac = 1.0; }
                 rec[2] = h;
                 rec[3] = piece_ref(p0, pl.idx - p0);
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
                 if (biased) {
                     // particle.cpp:866-891: immediate vs delayed application of the importance weight
                     const int nbands = A.n_bias + 1;
-                    const double delay_height = A.delay_type == 0 ? h : tc;
+                    const double delay_height = A.delay_type == 0 ? h : (A.delay_type == 2 ? tfirst : tc);
                     int idx = 0;
                     while (idx + 1 < nbands + 1 && sBH[idx + 1] < delay_height) ++idx;
                     if (idx >= nbands) idx = nbands - 1;

@@ -205,7 +205,7 @@ def test_structured_binary_end_to_end(hiplib, tmp_path):
     assert db[(("Delay", -1, -1, -1, -1), "Count")] > 0                      # importance weights were held back
 
 
-@pytest.mark.parametrize("n,P,delay_type", [(4, 2, 0), (8, 2, 0), (6, 3, 1)])
+@pytest.mark.parametrize("n,P,delay_type", [(4, 2, 0), (8, 2, 0), (6, 3, 1), (4, 2, 2)])
 def test_focused_sampling_with_structure_parity(oracle, hiplib, n, P, delay_type):
     """-bias_heights / -bias_strengths with several populations (the configuration of the reference's own two-population
     regression tests, test_two_pops.py:36-37): biased cut point on the LDS tree, delayed importance weights, resampling
