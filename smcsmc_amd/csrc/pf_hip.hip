@@ -115,7 +115,14 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
     extern __shared__ double smem[];
     Smem m = carve(smem, A.n, A.E);
     load_model(A, m);
+    __shared__ double sBH[PF_BIAS_MAX + 2], sBS[PF_BIAS_MAX + 1];      // focused sampling: band boundaries / strengths
+    if (threadIdx.x < PF_BIAS_MAX + 2) {
+        sBH[threadIdx.x] = A.bias_H[threadIdx.x];
+        if (threadIdx.x < PF_BIAS_MAX + 1) sBS[threadIdx.x] = A.bias_S[threadIdx.x];
+    }
     __syncthreads();
+    const bool biased = A.n_bias > 0;
+    bool has_pending = false;
     const Ctrl* c = A.ctrl;
     const int n = A.n;
     const int cur = c->cur;
@@ -140,6 +147,10 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
         ln.ctr = A.rng_ctr[p];
         ln.ebuf = A.ebuf[p];
         unsigned widx = A.widx[p];
+        DStore ds;
+        ds.pos = st.dpos + p; ds.fac = st.dfac + p; ds.delta = st.ddelta + p; ds.k = st.dk + p; ds.Np = A.Np;
+        ds.count = 0; ds.total = 1.0;
+        if (biased) { ds.count = st.dcount[p]; ds.total = st.total_delayed[p]; }
         double* tmp0 = m.t0 + threadIdx.x;
         double* tmp1 = m.t1 + threadIdx.x;
 
@@ -174,7 +185,9 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
                 double h, tc, sp_removed;
                 bool changed;
                 unsigned desc = 0;
-                genealogy_update(ln, &h, &tc, &sp_removed, &changed, A.lmap_opp ? &desc : nullptr, tmp0);
+                double iw = 1.0;
+                genealogy_update(ln, &h, &tc, &sp_removed, &changed, A.lmap_opp ? &desc : nullptr, tmp0,
+                                 biased ? sBH : nullptr, sBS, A.n_bias + 1, &iw);
                 if (ln.vbc) { w_post *= ln.upd_fac; w_pilot *= ln.upd_fac; ln.upd_fac = 1.0; }
                 rec[2] = h;
                 rec[3] = tc;
@@ -182,6 +195,18 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
                 ++widx;
                 if (leaf_status == 0) B = tracked_len_lane(ln, data, tmp0);
                 if (leaf_status == 1) B = ln.Ltree;
+                if (biased) {
+                    // particle.cpp:866-891: immediate vs delayed application of the importance weight
+                    const int nbands = A.n_bias + 1;
+                    const double delay_height = A.delay_type == 0 ? h : tc;
+                    int idx = 0;
+                    while (idx + 1 < nbands + 1 && sBH[idx + 1] < delay_height) ++idx;
+                    if (idx >= nbands) idx = nbands - 1;
+                    const double rbiw = iw;
+                    if (sBS[idx] == 1.0) { w_post *= rbiw; w_pilot *= rbiw; iw /= rbiw; }
+                    const double delay = A.app_delays[epoch_of(ln, delay_height)];
+                    d_adjust_with_delay(ds, w_post, w_pilot, iw, delay, updated_to);
+                }
                 next_base = sample_next_base(ln, updated_to);
                 ln.uqn = 0;                    // the update's unused uniforms are dropped
                 x_mark = updated_to;
@@ -189,6 +214,19 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
             }
         }
 
+        if (biased) {
+            // apply the factors that fell due during this extension (particle.cpp:910-916)
+            for (;;) {
+                if (ds.count == 0) break;
+                double pm = ds.pos[0];
+                for (int i = 1; i < ds.count; ++i) { double pi = ds.pos[(size_t)i * ds.Np]; if (pi < pm) pm = pi; }
+                if (!(pm < extend_to)) break;
+                d_apply_earliest(ds, w_pilot);
+            }
+            st.dcount[p] = ds.count;
+            st.total_delayed[p] = ds.total;
+            has_pending = ds.count > 0;
+        }
         if (A.seg_state[s] == 0) {
             // update_weight_at_site: marginalise over phasings of unphased hets (pc.cpp:138-224)
             const bool dephase = A.flags & 2;
@@ -264,6 +302,10 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
         A.chunk_pil[chunk] = sc;
         A.chunk_pp[chunk] = scp;
         A.chunk_mx1[chunk] = scm;
+    }
+    if (biased) {
+        unsigned long long pend = __ballot(has_pending);
+        if (lane == 0 && chunk < (A.Np + 63) / 64) A.chunk_dpend[chunk] = __popcll(pend);
     }
 }
 
@@ -1977,7 +2019,6 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     if (m->n_epochs < 1 || m->n_epochs > PF_EMAX) return fail("pf_create: n_epochs must be in 1..64");
     if (p->np < 1 || p->np > 262144) return fail("pf_create: np must be in 1..262144");
     if (m->n_bias_heights < 0 || m->n_bias_heights > PF_BIAS_MAX) return fail("pf_create: at most 8 bias heights are supported");
-    if (m->n_bias_heights > 0 && m->nsam > 8 && m->n_pops == 1) return fail("pf_create: focused sampling with one population is implemented for nsam <= 8");
     if (m->n_bias_heights > 0 && (!m->bias_heights || !m->bias_strengths || !m->application_delays))
         return fail("pf_create: bias_heights, bias_strengths and application_delays must all be given");
     if (m->n_rate_segments > 0) {
@@ -2328,7 +2369,7 @@ static Windows no_windows(pf_handle* h) {
 
 // the register-tree kernels can complete the previous row while loading the particle (fused k_resample)
 static bool extend_can_fuse(const pf_handle* h) {
-    return h->P == 1 && h->n <= 8 && (h->A.n_bias > 0 || h->A.g_K > 0 || !h->force_lds) && !h->no_fuse && h->A.apf == 0;
+    return h->P == 1 && h->n <= 8 && (h->A.g_K > 0 || !h->force_lds) && !h->no_fuse && h->A.apf == 0;
 }
 
 static int launch_extend(pf_handle* h, long long s, int fuse = 0) {
@@ -2339,9 +2380,9 @@ static int launch_extend(pf_handle* h, long long s, int fuse = 0) {
         const bool biased = h->A.n_bias > 0 || h->A.g_K > 0;
         if (h->P > 1)
             pf_mp_launch_extend(h->A, s, h->smem, h->stream);
-        else if (h->n <= 4 && biased)
+        else if (h->n <= 4 && biased && (h->A.g_K > 0 || !h->force_lds))
             hipLaunchKernelGGL((k_extend_reg<4, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);
-        else if (h->n <= 8 && biased)
+        else if (h->n <= 8 && biased && (h->A.g_K > 0 || !h->force_lds))
             hipLaunchKernelGGL((k_extend_reg<8, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);
         else if (h->n <= 4 && !h->force_lds)
             hipLaunchKernelGGL((k_extend_reg<4, false>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);

@@ -194,13 +194,18 @@ __device__ __forceinline__ unsigned lane_desc_mask(const Lane& ln, int id, doubl
     return res;
 }
 
+// With bH != nullptr the cut point is drawn with height-band weights (focused sampling) and *iw_out receives the
+// importance weight of the draw.
 __device__ __forceinline__ void genealogy_update(Lane& ln, double* h_out, double* tc_out, double* sp_out, bool* changed_out,
-                                                 unsigned* desc_out = nullptr, double* tmp = nullptr) {
+                                                 unsigned* desc_out = nullptr, double* tmp = nullptr,
+                                                 const double* bH = nullptr, const double* bS = nullptr, int nb = 1,
+                                                 double* iw_out = nullptr) {
     const int n = ln.n;
     int rp = 0, sb = 0;
     double h;
     prefetch_update_uniforms(ln);       // the caller drops what is left after the sample_next_base that follows
-    sample_point(ln, &rp, &sb, &h);
+    if (bH) sample_point_biased(ln, bH, bS, nb, &rp, &sb, &h, iw_out);
+    else sample_point(ln, &rp, &sb, &h);
     if (desc_out) *desc_out = lane_desc_mask(ln, LC(ln, rp, sb), tmp);
     *h_out = h;
     double tc = coalesce_up(ln, [&](int k) { return LS(ln, k); }, n - 1, n, h);

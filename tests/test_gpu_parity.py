@@ -266,7 +266,7 @@ def test_binary_end_to_end_matches_library_and_front_end_contract(oracle, hiplib
     assert d[(("Delay", -1, -1, -1, -1), "Count")] > 0
 
 
-@pytest.mark.parametrize("n,delay_type", [(4, 0), (2, 1), (6, 0)])
+@pytest.mark.parametrize("n,delay_type", [(4, 0), (2, 1), (6, 0), (12, 0), (10, 1)])
 def test_focused_sampling_and_delayed_importance_weights(oracle, hiplib, n, delay_type):
     """-bias_heights / -bias_strengths with delayed application of the importance weights
     (particle.cpp:866-891, 1020-1126; particle.hpp:59-101, 185-209): the configuration of the reference's own
@@ -275,7 +275,7 @@ def test_focused_sampling_and_delayed_importance_weights(oracle, hiplib, n, dela
     model.update(bias_heights=[400.0], bias_strengths=[3.0, 1.0], delay_type=delay_type,
                  application_delays=np.array(model["lags"]) * 0.25)
     segs = cases.make_segments(model, seed=17 + n, max_seg_len=5000)
-    o, si, g = _run_both(oracle, model, segs, 700, seed=5)
+    o, si, g = _run_both(oracle, model, segs, 700 if n <= 8 else 200, seed=5)      # n > 8: the LDS-tree kernel
     o.run(si); g.run(); g.finish()
     to, tg = o.trace(), g.trace()
     assert (to["resampled"] == tg["resampled"]).all() and to["resampled"].sum() > 0
