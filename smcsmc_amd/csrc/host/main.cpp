@@ -186,7 +186,6 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
     double mean_tbl = 0;
     const double tbl_quantiles[7] = {0.001, 0.003, 0.01, 0.03, 0.1, 0.5, 0.95};
     if (P.auxiliary_particle_filter > 0) {
-        if (NP > 1) throw Unsupported("-apf with more than one population");
         if (P.Segfile->empty_file()) throw Unsupported("-apf without -seg data");
         cout << "Calculating terminal branch length quantiles..." << endl;
         tbl_lengths.resize((size_t)M.nsam * 7);

@@ -1694,8 +1694,16 @@ __global__ __launch_bounds__(PF_BS) void k_lookahead(KArgs A, long long row) {
             int pr = -1;
             for (int r = 0; r < n - 1 && pr < 0; ++r)
                 if (LC(ln, r, 0) == i || LC(ln, r, 1) == i) pr = r;
+            double hgt = LS(ln, pr);
+            if (A.P > 1) {
+                // structured models: the first local node above a leaf may be a migration on its branch (the events
+                // of a particle are sorted by time, so the first hit is the lowest)
+                const int nmig = st.nm[p];
+                for (int mi = 0; mi < nmig; ++mi)
+                    if (st.Mb[(size_t)mi * A.Np + p] == i) { hgt = st.Mt[(size_t)mi * A.Np + p]; pr = -2 - mi; break; }
+            }
             s_par[i * PF_BS] = pr;
-            s_lh[i * PF_BS] = LS(ln, pr);
+            s_lh[i * PF_BS] = hgt;
             s_mp[i * PF_BS] = 0.0;
         }
         for (int i = 0; i < n; i++) {
@@ -2882,7 +2890,6 @@ int pf_test_systematic(const double* pilot, int64_t n, double u, int32_t* lo, in
 int pf_load_lookahead(pf_handle* h, const pf_lookahead* la) {
     HIPCHK(hipSetDevice(h->device));
     if (la->level < 0 || la->level > 4) { g_err = "-apf must be in 0..4"; return -1; }
-    if (h->P > 1) { g_err = "pf_load_lookahead: the auxiliary particle filter is implemented for one population"; return -1; }
     if (la->n != h->n_segs) { g_err = "pf_load_lookahead: one look-ahead record per segment expected"; return -1; }
     if (la->level == 0) { h->A.apf = 0; return 0; }
     const long long S = la->n;
@@ -2923,19 +2930,21 @@ int pf_load_lookahead(pf_handle* h, const pf_lookahead* la) {
 int pf_terminal_branch_quantiles(const pf_model* m, uint64_t seed, int64_t n_trees, const double* quantiles, int32_t nq,
                                  double* lengths_out, double* mean_total_out, int device) {
     if (test_setup(device)) return -1;
-    if (m->n_pops != 1 || m->nsam < 2 || m->nsam > PF_NMAX || m->n_epochs < 1 || m->n_epochs > PF_EMAX || n_trees < 1) {
+    if (m->n_pops < 1 || m->n_pops > PF_PMAX || m->nsam < 2 || m->nsam > PF_NMAX || m->n_epochs < 1 || m->n_epochs > PF_EMAX || n_trees < 1) {
         g_err = "pf_terminal_branch_quantiles: unsupported model";
         return -1;
     }
-    const int E = m->n_epochs, n = m->nsam;
+    const int E = m->n_epochs, n = m->nsam, P = m->n_pops;
     KArgs A;
     memset(&A, 0, sizeof(A));
-    A.E = E; A.n = n; A.P = 1; A.L = m->loci_length; A.mu = m->mutation_rate; A.rho = m->recombination_rate;
-    double *dT, *dI, *dh, *dl; int* dRF;
-    HIPCHK(hipMalloc(&dT, E * 8)); HIPCHK(hipMalloc(&dI, E * 8)); HIPCHK(hipMalloc(&dRF, E * 4));
+    A.E = E; A.n = n; A.P = P; A.L = m->loci_length; A.mu = m->mutation_rate; A.rho = m->recombination_rate;
+    double *dT, *dI, *dh, *dl; int *dRF, *derr;
+    std::vector<void*> mp_allocs;
+    HIPCHK(hipMalloc(&dT, E * 8)); HIPCHK(hipMalloc(&dI, E * 8)); HIPCHK(hipMalloc(&dRF, E * 4)); HIPCHK(hipMalloc(&derr, 4));
+    HIPCHK(hipMemset(derr, 0, 4));
     HIPCHK(hipMalloc(&dh, (size_t)n * n_trees * 8)); HIPCHK(hipMalloc(&dl, (size_t)n_trees * 8));
     std::vector<double> inv2N(E);
-    for (int e = 0; e < E; ++e) inv2N[e] = 1.0 / (2.0 * m->pop_sizes[e]);
+    for (int e = 0; e < E; ++e) inv2N[e] = 1.0 / (2.0 * m->pop_sizes[(size_t)e * P]);
     std::vector<int> rf(E, 3);
     HIPCHK(hipMemcpy(dT, m->change_times, E * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dI, inv2N.data(), E * 8, hipMemcpyHostToDevice));
@@ -2947,15 +2956,30 @@ int pf_terminal_branch_quantiles(const pf_model* m, uint64_t seed, int64_t n_tre
         HIPCHK(hipMemcpy(dHc, Hc.data(), E * 8, hipMemcpyHostToDevice));
     }
     A.T = dT; A.inv2N = dI; A.Hc = dHc; A.recflags = dRF;
-    const size_t smem = smem_bytes(n, E);
-    if (smem > 64 * 1024) hipFuncSetAttribute((const void*)k_tbl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k_tbl, dim3((unsigned)((n_trees + PF_BS - 1) / PF_BS)), dim3(PF_BS), smem, 0, A, (unsigned long long)seed,
-                       (long long)0, (long long)n_trees, dh, dl);
+    int tbl_err = 0;
+    if (P > 1) {
+        MpTables tb;
+        if (build_mp_tables(m, tb) || upload_mp_tables(tb, A, mp_allocs)) return -1;
+        const size_t smem = pf_mp_smem_bytes(n, E, P);
+        if (pf_mp_prepare(smem)) { g_err = "pf_terminal_branch_quantiles: the local-tree state does not fit the LDS"; return -1; }
+        pf_mp_launch_tbl(A, (unsigned long long)seed, (long long)n_trees, dh, dl, derr, smem, 0);
+    } else {
+        const size_t smem = smem_bytes(n, E);
+        if (smem > 64 * 1024) hipFuncSetAttribute((const void*)k_tbl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(k_tbl, dim3((unsigned)((n_trees + PF_BS - 1) / PF_BS)), dim3(PF_BS), smem, 0, A, (unsigned long long)seed,
+                           (long long)0, (long long)n_trees, dh, dl);
+    }
     HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(&tbl_err, derr, 4, hipMemcpyDeviceToHost));
     std::vector<double> hh((size_t)n * n_trees), ll(n_trees);
     HIPCHK(hipMemcpy(hh.data(), dh, hh.size() * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(ll.data(), dl, ll.size() * 8, hipMemcpyDeviceToHost));
-    hipFree(dT); hipFree(dI); hipFree(dHc); hipFree(dRF); hipFree(dh); hipFree(dl);
+    hipFree(dT); hipFree(dI); hipFree(dHc); hipFree(dRF); hipFree(dh); hipFree(dl); hipFree(derr);
+    for (void* q : mp_allocs) hipFree(q);
+    if (tbl_err) {
+        g_err = tbl_err == 1 ? "too many migration events on one local tree" : "No final coalescence event was sampled!";
+        return -1;
+    }
     for (int i = 0; i < n; ++i) {
         double* row = hh.data() + (size_t)i * n_trees;
         std::sort(row, row + n_trees);

@@ -398,6 +398,37 @@ __global__ __launch_bounds__(PF_BS) void k_calibrate_mp(KArgs A, unsigned long l
 }
 
 
+// calculate_terminal_branch_length_quantiles (smcsmc.cpp:128-166) for a structured model: the parent height of every
+// leaf in nrep prior trees (migrations ignored: parent_height_ignoring_migrations, smcsmc.cpp:115-125) and the tree length
+__global__ __launch_bounds__(PF_BS) void k_tbl_mp(KArgs A, unsigned long long seed, long long nrep, double* out_h /* [n][nrep] */,
+                                                  double* out_len /* [nrep] */, int* out_err) {
+    extern __shared__ double smem[];
+    Smem m = carve(smem, A.n, A.E);
+    SmemMP mm = carve_mp(smem, A.n, A.E, A.P);
+    load_model(A, m);
+    load_model_mp(A, mm);
+    __syncthreads();
+    long long r = (long long)blockIdx.x * PF_BS + threadIdx.x;
+    if (r >= nrep) return;
+    const int n = A.n;
+    Lane ln = make_lane(A, m, r);
+    MLane ml = make_mlane(A, mm);
+    ln.seed = seed;
+    ln.stream = 3;
+    ln.ebuf = -dlog(uni(ln));
+    PLog nolog;
+    nolog.on = false;
+    mp_build_initial_tree<false>(ln, ml, nolog, [&](int, unsigned, unsigned, double) {});
+    out_len[r] = ln.Ltree;
+    for (int i = 0; i < n; ++i) {
+        int pr = -1;
+        for (int k = 0; k < n - 1 && pr < 0; ++k)
+            if (LC(ln, k, 0) == i || LC(ln, k, 1) == i) pr = k;
+        out_h[(size_t)i * nrep + r] = pr >= 0 ? LS(ln, pr) : 0.0;
+    }
+    if (ml.err) *out_err = ml.err;
+}
+
 // ------------------------------------------------------------------ launchers (called from pf_hip.hip)
 size_t pf_mp_smem_bytes(int n, int E, int P) { return smem_bytes_mp(n, E, P); }
 
@@ -407,6 +438,7 @@ int pf_mp_prepare(size_t smem) {
         if (hipFuncSetAttribute((const void*)k_extend_mp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
         if (hipFuncSetAttribute((const void*)k_init_mp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
         if (hipFuncSetAttribute((const void*)k_calibrate_mp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void*)k_tbl_mp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
     }
     return 0;
 }
@@ -421,4 +453,9 @@ void pf_mp_launch_calibrate(const KArgs& A, unsigned long long seed, long long r
                             double* out_dist, int* out_err, size_t smem, hipStream_t st) {
     hipLaunchKernelGGL(k_calibrate_mp, dim3(mp_blocks(nrep)), dim3(PF_BS), smem, st, A, seed, rep0, nrep, out_epoch, out_dist,
                        out_err);
+}
+
+void pf_mp_launch_tbl(const KArgs& A, unsigned long long seed, long long nrep, double* out_h, double* out_len, int* out_err,
+                      size_t smem, hipStream_t st) {
+    hipLaunchKernelGGL(k_tbl_mp, dim3(mp_blocks(nrep)), dim3(PF_BS), smem, st, A, seed, nrep, out_h, out_len, out_err);
 }

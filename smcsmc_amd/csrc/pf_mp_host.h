@@ -13,3 +13,5 @@ void pf_mp_launch_init(const KArgs& A, double initial_position, size_t smem, hip
 void pf_mp_launch_extend(const KArgs& A, long long s, size_t smem, hipStream_t st);
 void pf_mp_launch_calibrate(const KArgs& A, unsigned long long seed, long long rep0, long long nrep, int* out_epoch,
                             double* out_dist, int* out_err, size_t smem, hipStream_t st);
+void pf_mp_launch_tbl(const KArgs& A, unsigned long long seed, long long nrep, double* out_h, double* out_len, int* out_err,
+                      size_t smem, hipStream_t st);

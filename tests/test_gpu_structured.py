@@ -203,6 +203,14 @@ def test_structured_binary_end_to_end(hiplib, tmp_path):
     recb = db[(("Recomb", -1, -1, -1, -1), "Count")] / db[(("Recomb", -1, -1, -1, -1), "Opp")]
     assert 0.8e-8 < recb < 1.25e-8
     assert db[(("Delay", -1, -1, -1, -1), "Count")] > 0                      # importance weights were held back
+    # auxiliary particle filter on the structured model: quantile tables from prior trees with migration
+    r = subprocess.run([binary] + core + common + ["-Np", "500", "-seed", "2", "-lag", "50000", "-apf", "2", "-o", str(tmp_path / "apf")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Terminal branch length quantiles" in r.stdout
+    da = outfile.parse_outfile(str(tmp_path / "apf.out"))
+    ll_plain = data[(("LogL", -1, -1, -1, -1), "Count")]
+    assert abs(da[(("LogL", -1, -1, -1, -1), "Count")] - ll_plain) < 0.02 * abs(ll_plain)
 
 
 @pytest.mark.parametrize("n,P,delay_type", [(4, 2, 0), (8, 2, 0), (6, 3, 1), (4, 2, 2)])
@@ -233,3 +241,48 @@ def test_focused_sampling_with_structure_parity(oracle, hiplib, n, P, delay_type
     for k in ("coal_count", "coal_opp", "rec_count", "rec_opp", "mig_count", "mig_opp"):       # sums in another order
         np.testing.assert_allclose(cg[k], co[k], rtol=1e-9, atol=1e-9 * np.abs(co[k]).max(), err_msg=k)
     np.testing.assert_allclose(cg["delayed_opp"], co["delayed_opp"], rtol=1e-12)
+
+
+def test_terminal_branch_quantiles_with_structure(oracle, hiplib):
+    """calculate_terminal_branch_length_quantiles (smcsmc.cpp:128-166) from prior trees of an isolation-with-migration
+    model: device == oracle bit for bit."""
+    from smcsmc_amd import pf
+    model = cases.make_structured(cases.make_model(n=6, E=8, L=1e6), P=2)
+    dl, dm = pf.terminal_branch_quantiles(model, seed=1, n_trees=30000)
+    ol_, om = oracle.terminal_branch_quantiles(model, seed=1, n_trees=30000)
+    bits = lambda a: np.asarray(a, dtype=np.float64).view(np.int64)   # noqa: E731
+    assert (bits(dl) == bits(ol_)).all() and bits([dm])[0] == bits([om])[0]
+    assert (np.diff(dl, axis=1) > 0).all()
+    # structure lengthens the trees: more than the panmictic expectation 4N H(n-1)
+    assert dm > 4e4 * sum(1.0 / k for k in range(1, 6))
+
+
+@pytest.mark.parametrize("n,P,level", [(4, 2, 2), (8, 2, 3)])
+def test_auxiliary_particle_filter_with_structure_parity(oracle, hiplib, n, P, level):
+    """-apf with several populations: the look-ahead factor (particle.cpp:439-617) depends on the local tree only; the
+    quantile tables come from prior trees of the structured model.  Trees, weights, ESS, resampling indices as the oracle's."""
+    from smcsmc_amd import ParticleFilter, pf, segments as segmod
+    E = 6
+    base = cases.make_model(n=n, E=E, L=1.2e5)
+    model = cases.make_structured(base, P=P)
+    segs = cases.make_segments(base, seed=30 + n, max_seg_len=5000)
+    rows = [(int(s) + 1, int(l), int(st), list(map(int, a)))
+            for s, l, st, a in zip(segs["start"], segs["length"], segs["state"], segs["alleles"])]
+    la = segmod.pack_lookahead(rows, n)
+    tbl = pf.terminal_branch_quantiles(model, seed=1, n_trees=20000)
+    o = oracle.Oracle(model, 320, seed=9, max_trace_events=64); o.init_prior(segs["start"][0]); si = o.pack_segments(model, segs)
+    g = ParticleFilter(model, 320, seed=9, max_trace_events=64); g.init_prior(segs["start"][0]); g.load_segments(segs)
+    o.load_lookahead(la, level, tbl); g.load_lookahead(la, level, tbl)
+    o.run(si); g.run(); g.finish()
+    to, tg = o.trace(), g.trace()
+    assert (to["resampled"] == tg["resampled"]).all() and to["resampled"].sum() > 0
+    bits = lambda a: np.asarray(a, dtype=np.float64).view(np.int64)   # noqa: E731
+    for k in ("T", "ess", "logl"):
+        assert (bits(to[k]) == bits(tg[k])).all(), k
+    so, po_ = o.resample_events(); sg_, pg_ = g.resample_events()
+    assert (so == sg_).all() and (po_ == pg_).all()
+    po, pg = o.particles(), g.particles()
+    assert (po["children"] == pg["children"]).all()
+    for k in ("heights", "w_post", "w_pilot", "next_base"):
+        assert (bits(po[k]) == bits(pg[k])).all(), k
+    assert not np.allclose(pg["w_post"], pg["w_pilot"])          # the look-ahead sits in the pilot weight only
