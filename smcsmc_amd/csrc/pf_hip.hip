@@ -121,7 +121,8 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
         if (threadIdx.x < PF_BIAS_MAX + 1) sBS[threadIdx.x] = A.bias_S[threadIdx.x];
     }
     __syncthreads();
-    const bool biased = A.n_bias > 0;
+    const bool guided = A.g_K > 0;
+    const bool biased = A.n_bias > 0 || guided;          // a guide alone runs with one band of strength 1
     bool has_pending = false;
     const Ctrl* c = A.ctrl;
     const int n = A.n;
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
         ds.pos = st.dpos + p; ds.fac = st.dfac + p; ds.delta = st.ddelta + p; ds.k = st.dk + p; ds.Np = A.Np;
         ds.count = 0; ds.total = 1.0;
         if (biased) { ds.count = st.dcount[p]; ds.total = st.total_delayed[p]; }
+        int ridx = guided ? st.ridx[p] : 0;
         double* tmp0 = m.t0 + threadIdx.x;
         double* tmp1 = m.t1 + threadIdx.x;
 
@@ -175,7 +177,23 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
             double f = fastexp(-A.mu * B * (new_to - updated_to));
             w_post *= f;
             w_pilot *= f;
+            if (guided) {
+                // importance_weight_over_segment (particle.cpp:1138-1181): true over guide rate for the stretch
+                // without recombination
+                const double dist = new_to - updated_to;
+                const double target_rate = dist * A.rho * ln.Ltree;
+                const double sampled_rate = dist * A.g_rho[ridx] * ln.Ltree;
+                const double iws = fastexp(sampled_rate - target_rate);
+                w_post *= iws;
+                w_pilot *= iws;
+            }
             updated_to = new_to;
+            if (guided && updated_to < extend_to && ridx + 1 < A.g_K && updated_to == A.g_pos[ridx + 1]) {
+                // reached a change of the guide rate: no genealogy change, new draw under the new rate
+                ridx += 1;
+                next_base = sample_next_base_guided(ln, updated_to, A.g_K, A.g_pos, A.g_rho, ridx);
+                continue;
+            }
             if (updated_to < extend_to) {
                 // a recombination: log the stretch that ends here together with the event
                 double* rec = rec_ptr(A, p, widx);
@@ -185,9 +203,10 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
                 double h, tc, sp_removed;
                 bool changed;
                 unsigned desc = 0;
-                double iw = 1.0;
+                double iw = 1.0, rbiw = 1.0;
                 genealogy_update(ln, &h, &tc, &sp_removed, &changed, A.lmap_opp ? &desc : nullptr, tmp0,
-                                 biased ? sBH : nullptr, sBS, A.n_bias + 1, &iw);
+                                 biased ? sBH : nullptr, sBS, A.n_bias + 1, &iw,
+                                 guided ? A.g_leaf + (size_t)ridx * n : nullptr, guided ? A.rho / A.g_rho[ridx] : 1.0, &rbiw);
                 if (ln.vbc) { w_post *= ln.upd_fac; w_pilot *= ln.upd_fac; ln.upd_fac = 1.0; }
                 rec[2] = h;
                 rec[3] = tc;
@@ -202,12 +221,11 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
                     int idx = 0;
                     while (idx + 1 < nbands + 1 && sBH[idx + 1] < delay_height) ++idx;
                     if (idx >= nbands) idx = nbands - 1;
-                    const double rbiw = iw;
                     if (sBS[idx] == 1.0) { w_post *= rbiw; w_pilot *= rbiw; iw /= rbiw; }
                     const double delay = A.app_delays[epoch_of(ln, delay_height)];
                     d_adjust_with_delay(ds, w_post, w_pilot, iw, delay, updated_to);
                 }
-                next_base = sample_next_base(ln, updated_to);
+                next_base = sample_next_base_guided(ln, updated_to, A.g_K, A.g_pos, A.g_rho, ridx);
                 ln.uqn = 0;                    // the update's unused uniforms are dropped
                 x_mark = updated_to;
                 mark_limit = limit;
@@ -225,6 +243,7 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
             }
             st.dcount[p] = ds.count;
             st.total_delayed[p] = ds.total;
+            if (guided) st.ridx[p] = ridx;
             has_pending = ds.count > 0;
         }
         if (A.seg_state[s] == 0) {
@@ -2030,7 +2049,6 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     if (m->n_bias_heights > 0 && (!m->bias_heights || !m->bias_strengths || !m->application_delays))
         return fail("pf_create: bias_heights, bias_strengths and application_delays must all be given");
     if (m->n_rate_segments > 0) {
-        if (m->n_pops != 1 || m->nsam > 8) return fail("pf_create: a recombination guide is implemented for one population and nsam <= 8");
         if (!m->rate_positions || !m->rate_values || !m->leaf_rel_rates || !m->application_delays)
             return fail("pf_create: rate_positions, rate_values, leaf_rel_rates and application_delays must all be given with a guide");
         if (m->rate_positions[0] != 0.0) return fail("pf_create: the recombination guide must start at position 0");
@@ -2377,7 +2395,7 @@ static Windows no_windows(pf_handle* h) {
 
 // the register-tree kernels can complete the previous row while loading the particle (fused k_resample)
 static bool extend_can_fuse(const pf_handle* h) {
-    return h->P == 1 && h->n <= 8 && (h->A.g_K > 0 || !h->force_lds) && !h->no_fuse && h->A.apf == 0;
+    return h->P == 1 && h->n <= 8 && !h->force_lds && !h->no_fuse && h->A.apf == 0;
 }
 
 static int launch_extend(pf_handle* h, long long s, int fuse = 0) {
@@ -2388,9 +2406,9 @@ static int launch_extend(pf_handle* h, long long s, int fuse = 0) {
         const bool biased = h->A.n_bias > 0 || h->A.g_K > 0;
         if (h->P > 1)
             pf_mp_launch_extend(h->A, s, h->smem, h->stream);
-        else if (h->n <= 4 && biased && (h->A.g_K > 0 || !h->force_lds))
+        else if (h->n <= 4 && biased && !h->force_lds)
             hipLaunchKernelGGL((k_extend_reg<4, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);
-        else if (h->n <= 8 && biased && (h->A.g_K > 0 || !h->force_lds))
+        else if (h->n <= 8 && biased && !h->force_lds)
             hipLaunchKernelGGL((k_extend_reg<8, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);
         else if (h->n <= 4 && !h->force_lds)
             hipLaunchKernelGGL((k_extend_reg<4, false>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);

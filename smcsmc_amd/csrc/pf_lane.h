@@ -179,6 +179,102 @@ __device__ __forceinline__ void sample_point_biased(Lane& ln, const double* bH, 
     *h_out = h;
 }
 
+// samplePoint with a recombination guide (particle.cpp:942-1126) on the LDS tree: every branch carries a relative rate --
+// leaf: the guide's rate `lr[i]` for that sample in the particle's segment; binary node: the mean of its children; the two
+// branches below the root: the larger of the two -- times the strength of its height band.  Pieces are visited branch by
+// branch in slot order, bands ascending; same operation order as r_sample_point_guided and the oracle.  `tmp` = per-lane
+// LDS column of n-1 doubles (node rates).  rho_ratio = true rate / guide rate of the segment.
+__device__ __forceinline__ void sample_point_guided(Lane& ln, const double* bH, const double* bS, int nb, const double* lr,
+                                                    double rho_ratio, int* rp_out, int* sb_out, double* h_out, double* iw_out,
+                                                    double* rbiw_out, double* tmp) {
+    const int n = ln.n;
+    auto rate_of = [&](int id) __attribute__((always_inline)) { return id < n ? lr[id] : tmp[(id - n) * PF_BS]; };
+    for (int rr = 0; rr < n - 1; ++rr) tmp[rr * PF_BS] = (rate_of(LC(ln, rr, 0)) + rate_of(LC(ln, rr, 1))) * 0.5;
+    const double ra = rate_of(LC(ln, n - 2, 0)), rbb = rate_of(LC(ln, n - 2, 1));
+    const double rroot = ra > rbb ? ra : rbb;
+    double Lw = 0.0;
+    for (int rr = 0; rr < n - 1; ++rr) {
+        const double hi_b = LS(ln, rr);
+        for (int sdx = 0; sdx < 2; ++sdx) {
+            const int c = LC(ln, rr, sdx);
+            const double rb = (rr == n - 2) ? rroot : rate_of(c);
+            const double lo_b = node_h(ln, c);
+            for (int b = 0; b < nb; ++b) {
+                double lo_ = lo_b > bH[b] ? lo_b : bH[b];
+                double hi_ = hi_b < bH[b + 1] ? hi_b : bH[b + 1];
+                if (hi_ > lo_) Lw += (rb * bS[b]) * (hi_ - lo_);
+                if (bH[b + 1] >= hi_b) break;
+            }
+        }
+    }
+    double rr_ = uni(ln) * Lw;
+    double l_lo = 0, l_hi = 0, l_wt = 1;
+    bool sel = false;
+    int g_rp = 0, g_sb = 0;
+    for (int rr = 0; rr < n - 1 && !sel; ++rr) {
+        const double hi_b = LS(ln, rr);
+        for (int sdx = 0; sdx < 2 && !sel; ++sdx) {
+            const int c = LC(ln, rr, sdx);
+            const double rb = (rr == n - 2) ? rroot : rate_of(c);
+            const double lo_b = node_h(ln, c);
+            for (int b = 0; b < nb; ++b) {
+                double lo_ = lo_b > bH[b] ? lo_b : bH[b];
+                double hi_ = hi_b < bH[b + 1] ? hi_b : bH[b + 1];
+                if (hi_ > lo_) {
+                    double wt = rb * bS[b];
+                    double wlen = wt * (hi_ - lo_);
+                    l_lo = lo_; l_hi = hi_; l_wt = wt; g_rp = rr; g_sb = sdx;
+                    if (rr_ < wlen) { sel = true; break; }
+                    rr_ -= wlen;
+                }
+                if (bH[b + 1] >= hi_b) break;
+            }
+        }
+    }
+    double h = l_lo + rr_ / l_wt;
+    if (!(h < l_hi)) h = l_lo;
+    if (h < l_lo) h = l_lo;
+    const double sampled = l_wt / Lw;
+    const double target = 1.0 / ln.Ltree;
+    double iw = target / sampled;
+    iw *= rho_ratio;                                  // the position was drawn at the guide's rate
+    double rbiw = 1.0;
+    if (nb > 1) {
+        // importance weight of the height bias alone (particle.cpp:1113-1121)
+        double Lrw = 0.0, pv = 0.0;
+        for (int ri = 0; ri < n - 1; ++ri) {
+            const int k = n - ri;
+            const double top = LS(ln, ri);
+            for (int b = 0; b < nb; ++b) {
+                double lo_ = pv > bH[b] ? pv : bH[b];
+                double hi_ = top < bH[b + 1] ? top : bH[b + 1];
+                if (hi_ > lo_) Lrw += ((double)k * bS[b]) * (hi_ - lo_);
+                if (bH[b + 1] >= top) break;
+            }
+            pv = top;
+        }
+        int idx = 0;
+        while (idx + 1 < nb && bH[idx + 1] < h) ++idx;
+        const double recomb_density = bS[idx] / Lrw;
+        rbiw = target / recomb_density;
+    }
+    *iw_out = iw; *rbiw_out = rbiw;
+    *rp_out = g_rp; *sb_out = g_sb;
+    *h_out = h;
+}
+
+// sample_next_base under a guide: the rate of the particle's segment, the draw limited to the segment
+// (particle.cpp:1203-1232); without a guide (gK == 0) the plain draw
+__device__ __forceinline__ double sample_next_base_guided(Lane& ln, double x, int gK, const double* gpos, const double* grho, int ridx) {
+    if (gK == 0) return sample_next_base(ln, x);
+    const double rho0 = ln.rho, L0 = ln.L;
+    ln.rho = grho[ridx];
+    if (ridx + 1 < gK) { const double nxt = gpos[ridx + 1]; if (nxt < L0) ln.L = nxt; }
+    const double nb = sample_next_base(ln, x);
+    ln.rho = rho0; ln.L = L0;
+    return nb;
+}
+
 // get_descendants (descendants.hpp:22-33): samples below node `id`; `tmp` = per-lane LDS scratch of n-1 doubles
 __device__ __forceinline__ unsigned lane_desc_mask(const Lane& ln, int id, double* tmp) {
     const int n = ln.n;
@@ -199,12 +295,14 @@ __device__ __forceinline__ unsigned lane_desc_mask(const Lane& ln, int id, doubl
 __device__ __forceinline__ void genealogy_update(Lane& ln, double* h_out, double* tc_out, double* sp_out, bool* changed_out,
                                                  unsigned* desc_out = nullptr, double* tmp = nullptr,
                                                  const double* bH = nullptr, const double* bS = nullptr, int nb = 1,
-                                                 double* iw_out = nullptr) {
+                                                 double* iw_out = nullptr, const double* lr = nullptr, double rho_ratio = 1.0,
+                                                 double* rbiw_out = nullptr) {
     const int n = ln.n;
     int rp = 0, sb = 0;
     double h;
     prefetch_update_uniforms(ln);       // the caller drops what is left after the sample_next_base that follows
-    if (bH) sample_point_biased(ln, bH, bS, nb, &rp, &sb, &h, iw_out);
+    if (lr) sample_point_guided(ln, bH, bS, nb, lr, rho_ratio, &rp, &sb, &h, iw_out, rbiw_out, tmp);
+    else if (bH) { sample_point_biased(ln, bH, bS, nb, &rp, &sb, &h, iw_out); if (rbiw_out) *rbiw_out = *iw_out; }
     else sample_point(ln, &rp, &sb, &h);
     if (desc_out) *desc_out = lane_desc_mask(ln, LC(ln, rp, sb), tmp);
     *h_out = h;

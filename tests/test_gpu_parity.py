@@ -533,7 +533,7 @@ def _guide(model, K, spread, seed):
     return dict(positions=pos, rates=rates, leaf_rates=leaf)
 
 
-@pytest.mark.parametrize("n,bias", [(4, False), (4, True), (7, True), (2, False)])
+@pytest.mark.parametrize("n,bias", [(4, False), (4, True), (7, True), (2, False), (10, True), (12, False)])
 def test_recombination_guide_parity(oracle, hiplib, n, bias):
     """Position-dependent sampling rate with per-sample relative rates (RecombinationBias, pfparam.hpp:96-223;
     samplePoint / importance_weight_over_segment / sampleNextBase, particle.cpp:942-1254), with and without the height
@@ -545,7 +545,7 @@ def test_recombination_guide_parity(oracle, hiplib, n, bias):
     if bias:
         extra.update(bias_heights=[400.0], bias_strengths=[3.0, 1.0])
     model = dict(model, **extra)
-    o, si, g = _run_both(oracle, model, segs, 400, seed=6)
+    o, si, g = _run_both(oracle, model, segs, 400 if n <= 8 else 160, seed=6)      # n > 8: the LDS-tree kernel
     o.run(si); g.run(); g.finish()
     to, tg = o.trace(), g.trace()
     assert (to["resampled"] == tg["resampled"]).all() and to["resampled"].sum() > 0
