@@ -377,8 +377,6 @@ void PfParam::finalize() {
     model.nsam = (int)default_nsam;
     model.parse(scrm_tokens);
     if (!input_RecombinationBiasFileName.empty()) {
-        if (model.npop > 1) throw Unsupported("-guide with more than one population");
-        if (default_nsam > 8) throw Unsupported("-guide with more than 8 samples");
         parse_recomb_bias_file(input_RecombinationBiasFileName);
     }
     default_loci_length = model.loci_length;

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(PF_BS) void k_init_mp(KArgs A, double initial_posit
         ++widx;
     });
     mp_report(A, ml);
-    double nb = sample_next_base(ln, 0.0);
+    double nb = sample_next_base_guided(ln, 0.0, A.g_K, A.g_pos, A.g_rho, 0);
     DState& st = A.st[0];
     for (int r = 0; r < n - 1; ++r) {
         st.S[(size_t)r * A.Np + p] = LS(ln, r);
@@ -122,7 +122,8 @@ __global__ __launch_bounds__(PF_BS) void k_init_mp(KArgs A, double initial_posit
     st.x_mark[p] = 0.0;
     st.Ltree[p] = ln.Ltree;
     st.mark_limit[p] = A.E - 1;
-    if (A.n_bias > 0) { A.st[0].total_delayed[p] = 1.0; A.st[0].dcount[p] = 0; }
+    if (A.n_bias > 0 || A.g_K > 0) { A.st[0].total_delayed[p] = 1.0; A.st[0].dcount[p] = 0; }
+    if (A.g_K > 0) A.st[0].ridx[p] = 0;
     A.rng_ctr[p] = ln.ctr;
     A.ebuf[p] = ln.ebuf;
     A.widx[p] = widx;
@@ -149,7 +150,8 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
     const bool active = p < A.Np;
     const int lane = threadIdx.x & 63;
     double w_post = 0.0, w_pilot = 0.0;
-    const bool biased = A.n_bias > 0;
+    const bool guided = A.g_K > 0;
+    const bool biased = A.n_bias > 0 || guided;          // a guide alone runs with one band of strength 1
     bool has_pending = false;
     if (active) {
         DState& st = A.st[cur];
@@ -159,6 +161,7 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
         ds.pos = st.dpos + p; ds.fac = st.dfac + p; ds.delta = st.ddelta + p; ds.k = st.dk + p; ds.Np = A.Np;
         ds.count = 0; ds.total = 1.0;
         if (biased) { ds.count = st.dcount[p]; ds.total = st.total_delayed[p]; }
+        int ridx = guided ? st.ridx[p] : 0;
         for (int r = 0; r < n - 1; ++r) {
             LS(ln, r) = st.S[(size_t)r * A.Np + p];
             LC(ln, r, 0) = st.C[(size_t)(2 * r) * A.Np + p];
@@ -207,7 +210,22 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
             double f = fastexp(-A.mu * B * (new_to - updated_to));
             w_post *= f;
             w_pilot *= f;
+            if (guided) {
+                // importance_weight_over_segment (particle.cpp:1138-1181)
+                const double dist = new_to - updated_to;
+                const double target_rate = dist * A.rho * ln.Ltree;
+                const double sampled_rate = dist * A.g_rho[ridx] * ln.Ltree;
+                const double iws = fastexp(sampled_rate - target_rate);
+                w_post *= iws;
+                w_pilot *= iws;
+            }
             updated_to = new_to;
+            if (guided && updated_to < extend_to && ridx + 1 < A.g_K && updated_to == A.g_pos[ridx + 1]) {
+                // reached a change of the guide rate: no genealogy change, new draw under the new rate
+                ridx += 1;
+                next_base = sample_next_base_guided(ln, updated_to, A.g_K, A.g_pos, A.g_rho, ridx);
+                continue;
+            }
             if (updated_to < extend_to) {
                 double* rec = rec_ptr(A, p, widx);
                 rec[0] = x_mark;
@@ -216,8 +234,11 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
                 int rp = 0, sb = 0;
                 double h, tc, sp_removed;
                 bool changed;
-                double iw = 1.0;
-                if (biased) sample_point_biased(ln, sBH, sBS, A.n_bias + 1, &rp, &sb, &h, &iw);
+                double iw = 1.0, rbiw = 1.0;
+                if (guided)
+                    sample_point_guided(ln, sBH, sBS, A.n_bias + 1, A.g_leaf + (size_t)ridx * n, A.rho / A.g_rho[ridx], &rp, &sb, &h,
+                                        &iw, &rbiw, tmp0);
+                else if (biased) { sample_point_biased(ln, sBH, sBS, A.n_bias + 1, &rp, &sb, &h, &iw); rbiw = iw; }
                 else sample_point(ln, &rp, &sb, &h);
                 const unsigned desc = A.lmap_opp ? lane_desc_mask(ln, LC(ln, rp, sb), tmp0) : 0u;
                 unsigned p0 = pl.idx;
@@ -238,12 +259,11 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
                     int idx = 0;
                     while (idx + 1 < nbands + 1 && sBH[idx + 1] < delay_height) ++idx;
                     if (idx >= nbands) idx = nbands - 1;
-                    double rbiw = iw;                       // without a guide both weights coincide
                     if (sBS[idx] == 1.0) { w_post *= rbiw; w_pilot *= rbiw; iw /= rbiw; }
                     const double delay = A.app_delays[epoch_of(ln, delay_height)];
                     d_adjust_with_delay(ds, w_post, w_pilot, iw, delay, updated_to);
                 }
-                next_base = sample_next_base(ln, updated_to);
+                next_base = sample_next_base_guided(ln, updated_to, A.g_K, A.g_pos, A.g_rho, ridx);
                 x_mark = updated_to;
                 mark_limit = limit;
             }
@@ -260,6 +280,7 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
             }
             st.dcount[p] = ds.count;
             st.total_delayed[p] = ds.total;
+            if (guided) st.ridx[p] = ridx;
             has_pending = ds.count > 0;
         }
 

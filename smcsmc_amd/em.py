@@ -224,8 +224,6 @@ def run_em(pop, chunks, iterations, np_particles, seed=1, ess_fraction=0.5, lag_
     sizes = [len(c) for c in chunks]
     mine = reducer.assign_chunks(sizes, world)[rank]
     guides = {} if guides is None else guides
-    if alpha > 0 and (pop.num_populations != 1 or pop.num_samples > 8):
-        raise pf.PfError("recombination guiding (alpha > 0) is implemented for one population and up to 8 samples")
     for it in range(iterations + 1):
         base = pop.device_model()
         lags = pf.calibrated_lags(base, lag_fraction=lag_fraction, device=device)     # model-only: once per iteration

@@ -286,3 +286,37 @@ def test_auxiliary_particle_filter_with_structure_parity(oracle, hiplib, n, P, l
     for k in ("heights", "w_post", "w_pilot", "next_base"):
         assert (bits(po[k]) == bits(pg[k])).all(), k
     assert not np.allclose(pg["w_post"], pg["w_pilot"])          # the look-ahead sits in the pilot weight only
+
+
+@pytest.mark.parametrize("n,P,bias", [(4, 2, False), (8, 2, True)])
+def test_recombination_guide_with_structure_parity(oracle, hiplib, n, P, bias):
+    """-guide with several populations: position-dependent sampling rate, per-sample relative rates, importance weights
+    over the stretch and per event (particle.cpp:942-1254), alone and together with the height bias."""
+    from smcsmc_amd import ParticleFilter
+    E = 6
+    base = cases.make_model(n=n, E=E, L=1.2e5)
+    rng = np.random.default_rng(n)
+    K = 9
+    leaf = rng.uniform(0.4, 2.5, (K, n)); leaf /= leaf.sum(1, keepdims=True)
+    guide = dict(positions=np.floor(np.arange(K) * 1.2e5 / K), rates=1e-8 * rng.uniform(0.4, 2.5, K), leaf_rates=leaf)
+    model = dict(cases.make_structured(base, P=P), guide=guide, application_delays=np.full(E, 3000.0))
+    if bias:
+        model.update(bias_heights=[400.0], bias_strengths=[3.0, 1.0])
+    segs = cases.make_segments(base, seed=60 + n, max_seg_len=5000)
+    o = oracle.Oracle(model, 320, seed=6, max_trace_events=64); o.init_prior(segs["start"][0]); si = o.pack_segments(model, segs)
+    g = ParticleFilter(model, 320, seed=6, max_trace_events=64); g.init_prior(segs["start"][0]); g.load_segments(segs)
+    o.run(si); g.run(); g.finish()
+    to, tg = o.trace(), g.trace()
+    assert (to["resampled"] == tg["resampled"]).all() and to["resampled"].sum() > 0
+    bits = lambda a: np.asarray(a, dtype=np.float64).view(np.int64)   # noqa: E731
+    for k in ("T", "ess", "logl"):
+        assert (bits(to[k]) == bits(tg[k])).all(), k
+    so, po_ = o.resample_events(); sg_, pg_ = g.resample_events()
+    assert (so == sg_).all() and (po_ == pg_).all()
+    po, pg = o.particles(), g.particles()
+    assert (po["children"] == pg["children"]).all()
+    for k in ("heights", "w_post", "w_pilot", "next_base"):
+        assert (bits(po[k]) == bits(pg[k])).all(), k
+    co, cg = o.counts(), g.counts()
+    for k in ("coal_count", "coal_opp", "rec_count", "rec_opp", "mig_count", "mig_opp"):
+        np.testing.assert_allclose(cg[k], co[k], rtol=1e-9, atol=1e-9 * np.abs(co[k]).max(), err_msg=k)
