@@ -358,6 +358,50 @@ void PfParam::parse_recomb_bias_file(const std::string& filename) {
     if (guide_positions.empty()) throw InvalidInput("Recombination guide file holds no records");
 }
 
+// The -p pattern of time segments (Pattern, pattern.cpp:33-163), PSMC style: "a*b" = a groups of b atomic intervals,
+// a bare number = one group of that many.  The n atomic boundaries are t_i = 0.1 exp(i/(n-1) log(1 + 10 tmax)) - 0.1
+// (i = 0..n-1, so t_0 = 0 and t_{n-1} = tmax); every group starts an epoch, written as "-eN <t/2> 1" with the six
+// decimals of std::to_string.  Fewer than two atomic intervals: no epochs.
+std::vector<std::string> expand_pattern(const std::string& pattern, double top_t) {
+    const char* expr = pattern.c_str();
+    auto number = [&]() -> size_t {
+        if (!isdigit((unsigned char)*expr)) throw PatternDigitsExpected(std::string(expr));
+        char* end_ptr;
+        size_t res = (size_t)strtol(expr, &end_ptr, 10);
+        expr = end_ptr;
+        return res;
+    };
+    std::vector<size_t> groups, sizes;
+    auto factor = [&]() -> size_t {
+        size_t a = number();
+        char op = *expr;
+        if (op == '+' || op == '\0') { groups.push_back(1); sizes.push_back(a); return a; }
+        if (op != '*') throw PatternTimesExpected(std::string(expr));
+        ++expr;
+        size_t b = number();
+        groups.push_back(a); sizes.push_back(b);
+        op = *expr;
+        if (op != '+' && op != '\0') throw PatternAddsExpected(std::string(expr));
+        return a * b;
+    };
+    size_t num_seg = factor();
+    while (*expr) { ++expr; num_seg += factor(); }
+    std::vector<std::string> out;
+    if (num_seg < 2) return out;
+    std::vector<double> t_i(num_seg);
+    for (size_t i = 0; i < num_seg; ++i)
+        t_i[i] = 0.1 * exp((double)i / (double)(num_seg - 1) * log(1 + 10 * top_t)) - 0.1;
+    size_t index = 0;
+    for (size_t g = 0; g < groups.size(); ++g)
+        for (size_t i = 0; i < groups[g]; ++i) {
+            out.push_back("-eN");
+            out.push_back(std::to_string(t_i[index] / 2));
+            out.push_back("1");
+            index += sizes[g];
+        }
+    return out;
+}
+
 // pfparam.cpp:321-380
 void PfParam::finalize() {
     ESSthreshold = N * ESS_fraction;
@@ -373,7 +417,10 @@ void PfParam::finalize() {
         remove(recombination_map_NAME.c_str());
         if (record_resample_file) remove(resample_NAME.c_str());
     }
-    if (!pattern.empty()) throw Unsupported("-p (the Python front-end generates epochs itself)");
+    if (!pattern.empty()) {
+        // pfparam.cpp:292-295: the epochs of the pattern are appended to the scrm arguments
+        for (const std::string& tok : expand_pattern(pattern, top_t)) scrm_tokens.push_back(tok);
+    }
     model.nsam = (int)default_nsam;
     model.parse(scrm_tokens);
     if (!input_RecombinationBiasFileName.empty()) {

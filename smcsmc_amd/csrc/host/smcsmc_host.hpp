@@ -64,9 +64,30 @@ struct NoDataError : InvalidSeg {
         throwMsg = reason + s + " between positions " + std::to_string(a) + " and " + std::to_string(b);
     }
 };
+// pattern.hpp:32-67
+struct PatternDigitsExpected : InvalidInput {
+    explicit PatternDigitsExpected(std::string s) : InvalidInput(s) {
+        reason = "While parsing expression: expected digit as first character in number; got ";
+        throwMsg = reason + src;
+    }
+};
+struct PatternTimesExpected : InvalidInput {
+    explicit PatternTimesExpected(std::string s) : InvalidInput(s) {
+        reason = "While parsing expression: expected '*' to separate factors; got ";
+        throwMsg = reason + src;
+    }
+};
+struct PatternAddsExpected : InvalidInput {
+    explicit PatternAddsExpected(std::string s) : InvalidInput(s) {
+        reason = "While parsing expression: expected '+' to separate factors; got ";
+        throwMsg = reason + src;
+    }
+};
 struct Unsupported : InvalidInput {
     explicit Unsupported(std::string s) : InvalidInput(s) { throwMsg = "Not supported by this build: " + s; }
 };
+
+std::vector<std::string> expand_pattern(const std::string& pattern, double top_t);
 
 // ---- the model tables handed to the device (what scrm's Model holds after Param::parse) ----
 struct HostModel {
