@@ -131,6 +131,8 @@ __global__ __launch_bounds__(PF_BS) void k_init_mp(KArgs A, double initial_posit
     A.gstart[p] = 0;
 }
 
+// BIASED = false: no focused sampling and no guide; their code is compiled out
+template <bool BIASED>
 __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
     extern __shared__ double smem[];
     Smem m = carve(smem, A.n, A.E);
@@ -150,8 +152,8 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
     const bool active = p < A.Np;
     const int lane = threadIdx.x & 63;
     double w_post = 0.0, w_pilot = 0.0;
-    const bool guided = A.g_K > 0;
-    const bool biased = A.n_bias > 0 || guided;          // a guide alone runs with one band of strength 1
+    const bool guided = BIASED && A.g_K > 0;
+    const bool biased = BIASED && (A.n_bias > 0 || guided);          // a guide alone runs with one band of strength 1
     bool has_pending = false;
     if (active) {
         DState& st = A.st[cur];
@@ -456,7 +458,8 @@ size_t pf_mp_smem_bytes(int n, int E, int P) { return smem_bytes_mp(n, E, P); }
 int pf_mp_prepare(size_t smem) {
     if (smem > 160 * 1024) return -1;
     if (smem > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)k_extend_mp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void*)k_extend_mp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void*)k_extend_mp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
         if (hipFuncSetAttribute((const void*)k_init_mp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
         if (hipFuncSetAttribute((const void*)k_calibrate_mp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
         if (hipFuncSetAttribute((const void*)k_tbl_mp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
@@ -468,7 +471,10 @@ void pf_mp_launch_init(const KArgs& A, double initial_position, size_t smem, hip
     hipLaunchKernelGGL(k_init_mp, dim3(mp_blocks(A.Np)), dim3(PF_BS), smem, st, A, initial_position);
 }
 void pf_mp_launch_extend(const KArgs& A, long long s, size_t smem, hipStream_t st) {
-    hipLaunchKernelGGL(k_extend_mp, dim3(mp_blocks(A.Np)), dim3(PF_BS), smem, st, A, s);
+    if (A.n_bias > 0 || A.g_K > 0)
+        hipLaunchKernelGGL(k_extend_mp<true>, dim3(mp_blocks(A.Np)), dim3(PF_BS), smem, st, A, s);
+    else
+        hipLaunchKernelGGL(k_extend_mp<false>, dim3(mp_blocks(A.Np)), dim3(PF_BS), smem, st, A, s);
 }
 void pf_mp_launch_calibrate(const KArgs& A, unsigned long long seed, long long rep0, long long nrep, int* out_epoch,
                             double* out_dist, int* out_err, size_t smem, hipStream_t st) {
