@@ -321,6 +321,20 @@ def main():
                          "kernel_ms_estimate": {k: v[0] for k, v in kt.items()},
                          "kernel_launches": {k: v[1] for k, v in kt.items()}},
         }
+        try:
+            # achievable HBM bandwidth on this device, for scale: a 1 GiB device-to-device copy (bytes read + written)
+            src = torch.empty(1 << 27, dtype=torch.float64, device="cuda:%d" % dev).fill_(1.0)
+            dst = torch.empty_like(src)
+            torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            best = 1e30
+            for _ in range(4):
+                e0.record(); dst.copy_(src); e1.record(); torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1))
+            out["roofline"]["measured_copy_GBs"] = 2 * src.numel() * 8 / (best * 1e-3) / 1e9
+            del src, dst
+        except Exception:
+            pass
         if world == 1:
             # the lag calibration (calculate_median_survival_distances, smcsmc.cpp:169-263: prior ARGs until every
             # epoch has 200 survival distances) is model-only work outside the sweep: timed separately, and an
