@@ -417,6 +417,8 @@ void PfParam::finalize() {
         remove(recombination_map_NAME.c_str());
         if (record_resample_file) remove(resample_NAME.c_str());
     }
+    if (record_trees)
+        std::clog << "Warning: -arg is accepted, but this build does not write " << out_NAME_prefix << ".trees.gz" << std::endl;
     if (!pattern.empty()) {
         // pfparam.cpp:292-295: the epochs of the pattern are appended to the scrm arguments
         for (const std::string& tok : expand_pattern(pattern, top_t)) scrm_tokens.push_back(tok);
