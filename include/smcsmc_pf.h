@@ -74,7 +74,8 @@ typedef struct pf_params {
     double ess_fraction;         /* -ESS */
     uint64_t seed;               /* -seed */
     int32_t max_trace_events;    /* resampling events whose ancestor arrays are retained for inspection */
-    int32_t flags;               /* bit0: record the 100-bp local recombination map (count.cpp:559-654) */
+    int32_t flags;               /* bit0: record the 100-bp local recombination map (count.cpp:559-654);
+                                  * bit1: -arg, keep what pf_sample_tree_events needs (one population) */
 } pf_params;
 
 typedef struct pf_segments {
@@ -128,6 +129,14 @@ pf_handle* pf_create(const pf_model* model, const pf_params* params, int device)
 void pf_destroy(pf_handle* h);
 
 int pf_init_prior(pf_handle* h, double initial_position);
+/* -arg (pfparam.cpp:353-357, smcsmc.cpp:395, ParticleContainer::printTrees pc.cpp:515-555): after pf_finish, draws the
+ * one particle of resample(..., NULL, 1) and returns the tree-modifying events of its history, last position first,
+ * as the lines of <prefix>.trees.gz: kind 0 = R (recombination: position, height of the cut, samples under the cut
+ * branch), 1 = C (coalescence of the floating lineage: position, time, samples under the node it created -- the cut
+ * samples alone when it went back into its own branch).  Returns the number of events (fills at most max_events). */
+int64_t pf_sample_tree_events(pf_handle* h, int32_t* kind, double* pos, double* height, uint32_t* desc, int64_t max_events,
+                              int64_t* particle_out);
+
 /* after pf_load_segments: switches the auxiliary particle filter on (update_lookahead_likelihood, pc.cpp:227-240) */
 int pf_load_lookahead(pf_handle* h, const pf_lookahead* la);
 /* calculate_terminal_branch_length_quantiles (smcsmc.cpp:128-166) over n_trees prior trees */

@@ -408,6 +408,7 @@ void PfParam::finalize() {
     outFileName = out_NAME_prefix + ".out";
     log_NAME = out_NAME_prefix + ".log";
     recombination_map_NAME = out_NAME_prefix + ".recomb.gz";
+    tree_NAME = out_NAME_prefix + ".trees.gz";
     resample_NAME = out_NAME_prefix + ".resample";
     if (!input_RecombinationBiasFileName.empty() && auxiliary_particle_filter > 0)
         throw std::invalid_argument("Recombination guiding and auxiliary particle filters cannot currently be used together");
@@ -417,8 +418,7 @@ void PfParam::finalize() {
         remove(recombination_map_NAME.c_str());
         if (record_resample_file) remove(resample_NAME.c_str());
     }
-    if (record_trees)
-        std::clog << "Warning: -arg is accepted, but this build does not write " << out_NAME_prefix << ".trees.gz" << std::endl;
+    if (record_trees && !dump_model && !dump_lookahead) remove(tree_NAME.c_str());
     if (!pattern.empty()) {
         // pfparam.cpp:292-295: the epochs of the pattern are appended to the scrm arguments
         for (const std::string& tok : expand_pattern(pattern, top_t)) scrm_tokens.push_back(tok);

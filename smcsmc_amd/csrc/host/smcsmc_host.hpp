@@ -196,7 +196,7 @@ class PfParam {   // pfparam.hpp:225-446
     double default_num_mut = 0;
     double max_segment_length_factor = 2.0;
     std::string out_NAME_prefix = "smcsmc", input_SegmentDataFileName, input_RecombinationBiasFileName, pattern;
-    std::string outFileName, log_NAME, recombination_map_NAME, resample_NAME;
+    std::string outFileName, log_NAME, recombination_map_NAME, resample_NAME, tree_NAME;
     std::vector<int> record_event_in_epoch;
     std::vector<std::string> scrm_tokens;
     std::string scrm_input;

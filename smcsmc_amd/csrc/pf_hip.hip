@@ -64,7 +64,6 @@ __global__ __launch_bounds__(PF_BS) void k_init(KArgs A, double initial_position
         double tc = coalesce_up(ln, [&](int k) { return LS(ln, k); }, ni, i, 0.0);
         if (ln.vbc) { w0 *= ln.upd_fac; ln.upd_fac = 1.0; }
         rec[3] = tc;
-        rec[4] = __longlong_as_double((long long)make_meta(2, A.E - 1, A.E - 1, i));
         ++widx;
         int pr = -1, ps = 0;
         int k = lineages_at(ln, ni, tc, -1, &pr, &ps);
@@ -72,12 +71,15 @@ __global__ __launch_bounds__(PF_BS) void k_init(KArgs A, double initial_position
         int kk = above_root ? 1 : k;
         double u = uni(ln);
         int idx = min((int)(u * (double)kk), kk - 1);
+        unsigned dn = (2u << i) - 1u;                 // above the root: all samples added so far
         if (above_root) {
             insert_node(ln, ni, tc, i, -1, 0, root);
         } else {
             lineages_at(ln, ni, tc, idx, &pr, &ps);
+            if (A.rec_trees) dn = (1u << i) | lane_desc_mask(ln, LC(ln, pr, ps), m.t0 + threadIdx.x);
             insert_node(ln, ni, tc, i, pr, ps, root);
         }
+        rec[4] = __longlong_as_double((long long)make_meta(2, A.E - 1, A.E - 1, i, 0, A.rec_trees ? dn : 0u));
         root = n + ni;
     }
     ln.Ltree = tree_length(ln, n);
@@ -202,15 +204,16 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
                 for (int r = 0; r < n - 1; ++r) rec[5 + r] = LS(ln, r);
                 double h, tc, sp_removed;
                 bool changed;
-                unsigned desc = 0;
+                unsigned desc = 0, desc_new = 0;
                 double iw = 1.0, rbiw = 1.0;
-                genealogy_update(ln, &h, &tc, &sp_removed, &changed, A.lmap_opp ? &desc : nullptr, tmp0,
+                genealogy_update(ln, &h, &tc, &sp_removed, &changed, (A.lmap_opp || A.rec_trees) ? &desc : nullptr, tmp0,
                                  biased ? sBH : nullptr, sBS, A.n_bias + 1, &iw,
-                                 guided ? A.g_leaf + (size_t)ridx * n : nullptr, guided ? A.rho / A.g_rho[ridx] : 1.0, &rbiw);
+                                 guided ? A.g_leaf + (size_t)ridx * n : nullptr, guided ? A.rho / A.g_rho[ridx] : 1.0, &rbiw,
+                                 A.rec_trees ? &desc_new : nullptr);
                 if (ln.vbc) { w_post *= ln.upd_fac; w_pilot *= ln.upd_fac; ln.upd_fac = 1.0; }
                 rec[2] = h;
                 rec[3] = tc;
-                rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n, desc));
+                rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n, desc, desc_new));
                 ++widx;
                 if (leaf_status == 0) B = tracked_len_lane(ln, data, tmp0);
                 if (leaf_status == 1) B = ln.Ltree;
@@ -304,6 +307,7 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
         A.rng_ctr[p] = ln.ctr;
         A.ebuf[p] = ln.ebuf;
         A.widx[p] = widx;
+        if (A.rec_trees && widx >= A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;
         for (int r = 0; r < n - 1; ++r) A.snap_S[A.sp][(size_t)r * A.Np + p] = LS(ln, r);
         A.snap_w[A.sp][p] = w_post; A.snap_xm[A.sp][p] = x_mark; A.snap_ml[A.sp][p] = mark_limit; A.snap_widx[A.sp][p] = widx;
     }
@@ -386,7 +390,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
         cx.T = sT; cx.I = sI; cx.H = sH; cx.E = A.E; cx.n = n; cx.L = A.L; cx.mu = A.mu; cx.rho = A.rho;
         cx.seed = A.seed; cx.slot = (unsigned)p; cx.stream = 0;
         cx.nb = A.n_bias + 1; cx.bH = sBH; cx.bS = sBS; cx.last_iw = 1.0;
-        cx.want_desc = A.lmap_opp != nullptr; cx.last_desc = 0;
+        cx.want_desc = A.lmap_opp != nullptr || A.rec_trees; cx.last_desc = 0; cx.last_desc_new = 0;
         cx.vbc = A.vb_coal; cx.upd_fac = 1.0;
         cx.gK = BIASED ? A.g_K : 0; cx.gpos = A.g_pos; cx.grho = A.g_rho; cx.gleaf = A.g_leaf; cx.last_rbiw = 1.0;
         cx.ridx = cx.gK > 0 ? from.ridx[a] : 0; cx.g_rp = 0; cx.g_sb = 0;
@@ -504,7 +508,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
                 if (cx.vbc) { w_post *= cx.upd_fac; w_pilot *= cx.upd_fac; cx.upd_fac = 1.0; }
                 rec[2] = h;
                 rec[3] = tc;
-                rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n, cx.last_desc));
+                rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n, cx.last_desc, cx.last_desc_new));
                 ++widx;
                 if (leaf_status == 0) B = r_tracked_len(t, n, present_mask);
                 if (leaf_status == 1) B = cx.Ltree;
@@ -597,6 +601,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
         A.rng_ctr[p] = cx.ctr;
         A.ebuf[p] = cx.ebuf;
         A.widx[p] = widx;
+        if (A.rec_trees && widx >= A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;       // -arg keeps every record
 #pragma unroll
         for (int r = 0; r < RTree<NM>::NI; ++r) if (r < n - 1) A.snap_S[A.sp][(size_t)r * A.Np + p] = t.S[r];
         A.snap_w[A.sp][p] = w_post; A.snap_xm[A.sp][p] = x_mark; A.snap_ml[A.sp][p] = mark_limit; A.snap_widx[A.sp][p] = widx;
@@ -886,6 +891,7 @@ __device__ __forceinline__ void decide_body(const KArgs& A, long long s, int mod
             A.gen_x0[(G + 1) % A.Gcap] = pos;
             c->n_resample = (long long)n_res + 1;
             if (G + 1 - c->g_retain >= A.Gcap - 1) c->err = ERR_GEN_OVERFLOW;
+            if (A.rec_trees && G + 2 >= A.Gcap) c->err = ERR_GEN_OVERFLOW;      // -arg keeps every generation
         }
     }
 }
@@ -1633,7 +1639,7 @@ __global__ __launch_bounds__(PF_BS) void k_calibrate(KArgs A, unsigned long long
         RCtx cx;
         cx.T = sT; cx.I = sI; cx.H = sH; cx.E = A.E; cx.n = n; cx.L = A.L; cx.mu = A.mu; cx.rho = A.rho;
         cx.seed = seed; cx.slot = ln.slot; cx.stream = 2; cx.ctr = ln.ctr; cx.ebuf = ln.ebuf; cx.Ltree = ln.Ltree;
-        cx.nb = 1; cx.bH = nullptr; cx.bS = nullptr; cx.last_iw = 1.0; cx.want_desc = false; cx.last_desc = 0;
+        cx.nb = 1; cx.bH = nullptr; cx.bS = nullptr; cx.last_iw = 1.0; cx.want_desc = false; cx.last_desc = 0; cx.last_desc_new = 0;
         cx.vbc = nullptr; cx.upd_fac = 1.0;
         cx.gK = 0; cx.gpos = nullptr; cx.grho = nullptr; cx.gleaf = nullptr; cx.last_rbiw = 1.0; cx.ridx = 0; cx.g_rp = 0; cx.g_sb = 0;
         while (alive > 0 && next < stop) {
@@ -2073,6 +2079,12 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     h->nblocks = (int)((Np + PF_BS - 1) / PF_BS);
     h->smem = P > 1 ? pf_mp_smem_bytes(n, E, P) : smem_bytes(n, E);
     h->max_trace_events = std::max(0, p->max_trace_events);
+    if (p->flags & 2) {
+        // -arg: the parent table of every resampling is kept (it is the ancestry the tree dump walks back through)
+        if (P > 1) { delete h; return fail("pf_create: tree recording (-arg) is implemented for one population"); }
+        if (gen_cap > 0x7fffffffLL / 2) gen_cap = 0x7fffffffLL / 2;
+        h->max_trace_events = (int)gen_cap;
+    }
     h->force_lds = env_ll("SMCSMC_PF_FORCE_LDS", 0) != 0;
     h->no_fuse = env_ll("SMCSMC_PF_NO_FUSE", 0) != 0;
     h->h_lags.assign(m->lags, m->lags + E);
@@ -2185,6 +2197,7 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     rc |= dalloc(h, &A.ebuf, Np);
     rc |= dalloc(h, &A.widx, Np);
     A.cap = (unsigned)log_cap;
+    A.rec_trees = (p->flags & 2) ? 1 : 0;
     A.RS = 5 + (n - 1);
     A.Gcap = (int)gen_cap;
     rc |= dalloc(h, &A.log, (size_t)Np * A.cap * A.RS);
@@ -2233,7 +2246,9 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
 }
 
 pf_handle* pf_create(const pf_model* m, const pf_params* p, int device) {
-    return create_impl(m, p, device, env_ll("SMCSMC_PF_LOG_CAP", 16384), env_ll("SMCSMC_PF_GEN_CAP", 8192));
+    // with -arg (flags bit 1) nothing may be overwritten: rings sized for a whole chunk by default
+    const bool trees = p && (p->flags & 2);
+    return create_impl(m, p, device, env_ll("SMCSMC_PF_LOG_CAP", trees ? 131072 : 16384), env_ll("SMCSMC_PF_GEN_CAP", trees ? 131072 : 8192));
 }
 
 void pf_destroy(pf_handle* h) {
@@ -2773,6 +2788,106 @@ int pf_get_particles(pf_handle* h, double* w_post, double* w_pilot, double* heig
             for (int k = 0; k < 2 * (n - 1); ++k) children[p * 2 * (n - 1) + k] = tmp[(size_t)k * Np + p];
     }
     return 0;
+}
+
+// Philox4x32-10 on the host (the same stream definition as philox_uniform in pf_device.h): the final one-particle draw
+// needs a single uniform
+static double philox_uniform_host(unsigned long long seed, unsigned slot, unsigned stream, unsigned long long draw) {
+    unsigned c0 = (unsigned)draw, c1 = (unsigned)(draw >> 32), c2 = slot, c3 = stream;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0, hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const unsigned long long bits = (((unsigned long long)c0 << 32) | c1) >> 11;
+    return ((double)bits + 0.5) * 1.1102230246251565e-16;
+}
+
+// ------------------------------------------------------------------ -arg: the history of one particle
+// ParticleContainer::printTrees (pc.cpp:515-555) prints the tree-modifying events of the particle left by the final
+// one-particle draw (smcsmc.cpp:395).  Here: walk back through the generations (the parent tables of all resamplings
+// are kept with -arg), collect the record ranges of every ancestor, copy them out.
+__global__ void k_trace_ancestry(KArgs A, int G, int slot, int* out_slot, unsigned* out_k0, unsigned* out_k1) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    long long a = slot;
+    for (int g = G; g >= 0; --g) {
+        out_slot[g] = (int)a;
+        out_k0[g] = A.gstart[(size_t)(g % A.Gcap) * A.Np + a];
+        out_k1[g] = g == G ? A.widx[a] : A.gstart[(size_t)((g + 1) % A.Gcap) * A.Np + a];
+        if (g > 0) a = A.ev_parents[(size_t)(g - 1) * A.Np + a];
+    }
+}
+__global__ void k_gather_records(KArgs A, int ngen, const int* slot, const unsigned* k0, const unsigned* k1, const long long* off,
+                                 double* out) {
+    const int g = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (g >= ngen) return;
+    double* o = out + (size_t)off[g] * A.RS;
+    for (unsigned k = k0[g]; k < k1[g]; ++k) {
+        const double* rec = rec_ptr(A, slot[g], k);
+        for (int j = 0; j < A.RS; ++j) *o++ = rec[j];
+    }
+}
+
+int64_t pf_sample_tree_events(pf_handle* h, int32_t* kind, double* pos, double* height, uint32_t* desc, int64_t max_events,
+                              int64_t* particle_out) {
+    if (!h->A.rec_trees) { g_err = "pf_sample_tree_events: the handle was not created with tree recording (pf_params.flags bit 1)"; return -1; }
+    if (pf_sync(h)) return -1;
+    Ctrl c;
+    HIPCHK(hipMemcpy(&c, h->A.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
+    const long long Np = h->Np;
+    // the one-particle systematic draw of resample(..., NULL, 1): the particle whose cumulative weight passes U * total
+    std::vector<double> w(Np);
+    HIPCHK(hipMemcpy(w.data(), h->A.st[c.cur].w_post, Np * 8, hipMemcpyDeviceToHost));
+    double total = 0.0;
+    for (double v : w) total += v;
+    const double u = philox_uniform_host((unsigned long long)h->A.seed, 0xFFFFFFFFu, 1, (unsigned long long)c.n_resample);
+    long long j = 0;
+    double acc = 0.0;
+    for (; j < Np - 1; ++j) { acc += w[j]; if (acc > u * total) break; }
+    if (particle_out) *particle_out = j;
+    const int G = c.gen;
+    int* dslot; unsigned *dk0, *dk1; long long* doff;
+    HIPCHK(hipMalloc(&dslot, (size_t)(G + 1) * 4)); HIPCHK(hipMalloc(&dk0, (size_t)(G + 1) * 4)); HIPCHK(hipMalloc(&dk1, (size_t)(G + 1) * 4));
+    HIPCHK(hipMalloc(&doff, (size_t)(G + 1) * 8));
+    hipLaunchKernelGGL(k_trace_ancestry, dim3(1), dim3(1), 0, h->stream, h->A, G, (int)j, dslot, dk0, dk1);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<unsigned> k0(G + 1), k1(G + 1);
+    HIPCHK(hipMemcpy(k0.data(), dk0, (size_t)(G + 1) * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(k1.data(), dk1, (size_t)(G + 1) * 4, hipMemcpyDeviceToHost));
+    std::vector<long long> off(G + 1);
+    long long nrec = 0;
+    for (int g = 0; g <= G; ++g) { off[g] = nrec; nrec += (long long)(k1[g] - k0[g]); }
+    HIPCHK(hipMemcpy(doff, off.data(), (size_t)(G + 1) * 8, hipMemcpyHostToDevice));
+    const int RS = h->A.RS;
+    double* drec;
+    HIPCHK(hipMalloc(&drec, std::max<size_t>(1, (size_t)nrec * RS) * 8));
+    hipLaunchKernelGGL(k_gather_records, dim3((unsigned)((G + 1 + 255) / 256)), dim3(256), 0, h->stream, h->A, G + 1, dslot, dk0, dk1, doff, drec);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<double> rec((size_t)nrec * RS);
+    if (nrec) HIPCHK(hipMemcpy(rec.data(), drec, rec.size() * 8, hipMemcpyDeviceToHost));
+    hipFree(dslot); hipFree(dk0); hipFree(dk1); hipFree(doff); hipFree(drec);
+    // last position first; within an update the R line precedes the C line (pc.cpp:527-551)
+    int64_t nout = 0;
+    auto emit = [&](int kd, double x, double t, unsigned d) {
+        if (nout < max_events) { if (kind) kind[nout] = kd; if (pos) pos[nout] = x; if (height) height[nout] = t; if (desc) desc[nout] = d; }
+        ++nout;
+    };
+    for (long long r = nrec - 1; r >= 0; --r) {
+        const double* q = &rec[(size_t)r * RS];
+        unsigned long long meta;
+        memcpy(&meta, &q[4], 8);
+        const int type = (int)(meta & 0xff);
+        if (type == 0) {
+            emit(0, q[1], q[2], (unsigned)((meta >> 32) & 0xffff));
+            emit(1, q[1], q[3], (unsigned)((meta >> 48) & 0xffff));
+        } else if (type == 2) {
+            emit(1, q[1], q[3], (unsigned)((meta >> 48) & 0xffff));
+        }
+    }
+    return nout;
 }
 
 int pf_set_timing(pf_handle* h, int period) { h->timing_period = period; return 0; }

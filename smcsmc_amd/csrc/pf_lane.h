@@ -296,7 +296,7 @@ __device__ __forceinline__ void genealogy_update(Lane& ln, double* h_out, double
                                                  unsigned* desc_out = nullptr, double* tmp = nullptr,
                                                  const double* bH = nullptr, const double* bS = nullptr, int nb = 1,
                                                  double* iw_out = nullptr, const double* lr = nullptr, double rho_ratio = 1.0,
-                                                 double* rbiw_out = nullptr) {
+                                                 double* rbiw_out = nullptr, unsigned* desc_new_out = nullptr) {
     const int n = ln.n;
     int rp = 0, sb = 0;
     double h;
@@ -339,6 +339,13 @@ __device__ __forceinline__ void genealogy_update(Lane& ln, double* h_out, double
                     if ((id < n || id - n < R) && id == s_id) { found = true; pr_ins = rr; ps_ins = s; }
                 }
         }
+    }
+    if (desc_new_out && desc_out) {
+        // samples below the node this update creates (masks taken on the pruned tree, before the insertion)
+        unsigned dn = *desc_out;
+        if (idx < nslots) dn |= lane_desc_mask(ln, LC(ln, pr_ins, ps_ins), tmp);
+        else if (has_root && idx == nslots) dn = (1u << n) - 1u;
+        *desc_new_out = dn;
     }
     insert_node(ln, ni, h_ins, b_id, pr_ins, ps_ins, troot);
     ln.Ltree = tree_length(ln, n);

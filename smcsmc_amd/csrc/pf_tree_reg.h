@@ -75,6 +75,7 @@ struct RCtx {
     const double* vbc;    // variational-Bayes factor per epoch of a coalescence (particle.cpp:266-272), or null
     double upd_fac;       // the factor of the current update
     unsigned last_desc;   // samples below the branch cut by the last update (only computed when want_desc)
+    unsigned last_desc_new;   // samples below the node created by the last update (only computed when want_desc)
     bool want_desc;
 };
 
@@ -514,10 +515,10 @@ __device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, doubl
     if (guided_pt) { rp = cx.g_rp; sb = cx.g_sb; }
     else r_lineages_at(t, n, n - 1, h, lin, &rp, &sb);
     *h_out = h;
+    unsigned below[RTree<NM>::NI];
+    unsigned cut = 0;
     if (cx.want_desc) {
         // get_descendants (descendants.hpp:22-33) of the cut branch on the tree before it changes: masks bottom-up
-        unsigned below[RTree<NM>::NI];
-        unsigned cut = 0;
 #pragma unroll
         for (int r = 0; r < RTree<NM>::NI; ++r) {
             below[r] = 0;
@@ -575,6 +576,22 @@ __device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, doubl
                 }
             }
         }
+    }
+    if (cx.want_desc) {
+        // samples below the node this update creates: the cut samples plus those below the branch it lands on (masks of
+        // the tree before the cut: rank q of the pruned tree was rank q, or q + 1 from the removed parent on)
+        unsigned dn = cut;
+        if (idx < nslots) {
+            const int tid_ = t.getC(pr_ins, ps_ins);
+            unsigned tm = tid_ < n ? (1u << tid_) : 0u;
+            const int oldr = (tid_ - n) + ((tid_ - n) >= rp ? 1 : 0);
+#pragma unroll
+            for (int k = 0; k < RTree<NM>::NI; ++k) tm = (tid_ >= n && oldr == k) ? below[k] : tm;
+            dn = cut | tm;
+        } else if (has_root && idx == nslots) {
+            dn = (1u << n) - 1u;
+        }
+        cx.last_desc_new = dn;
     }
     r_insert_node(t, n, ni, h_ins, b_id, pr_ins, ps_ins, troot);
     cx.Ltree = r_tree_length(t, n);

@@ -72,6 +72,7 @@ struct KArgs {
     int E, n, flags;
     double L, mu, rho;
     const double* T;
+    int rec_trees;                 // -arg: records carry the descendants of the new node, rings hold the whole chunk
     const double* inv2N;
     const double* Hc;              // [E] cumulative coalescence intensity at the epoch starts: Hc[e+1] = Hc[e] + (T[e+1]-T[e]) * inv2N[e]
     const double* lags;
@@ -191,11 +192,14 @@ enum { ERR_LOG_OVERFLOW = 1, ERR_GEN_OVERFLOW = 2, ERR_ZERO_PROB = 3, ERR_COUNT_
        ERR_MP_INTERNAL = 6, ERR_NO_COALESCENCE = 7 };
 
 // record meta word: type | lim_start+1 << 8 | lim_event+1 << 16 | n_eff << 24 | descendants << 32 (samples below the
-// branch cut by the recombination that ends the stretch, bit i = sample i; descendants.hpp:22-33)
-__device__ __forceinline__ unsigned long long make_meta(int type, int lim_start, int lim_event, int n_eff, unsigned desc = 0) {
+// branch cut by the recombination that ends the stretch, bit i = sample i; descendants.hpp:22-33) | descendants of the
+// node the floating lineage created << 48 (what the C line of a .trees.gz carries; only the cut samples themselves
+// when the lineage went back into its own branch)
+__device__ __forceinline__ unsigned long long make_meta(int type, int lim_start, int lim_event, int n_eff, unsigned desc = 0,
+                                                        unsigned desc_new = 0) {
     return (unsigned long long)(type & 0xff) | ((unsigned long long)((lim_start + 1) & 0xff) << 8) |
            ((unsigned long long)((lim_event + 1) & 0xff) << 16) | ((unsigned long long)(n_eff & 0xff) << 24) |
-           ((unsigned long long)(desc & 0xffff) << 32);
+           ((unsigned long long)(desc & 0xffff) << 32) | ((unsigned long long)(desc_new & 0xffff) << 48);
 }
 
 __device__ __forceinline__ double* rec_ptr(const KArgs& A, long long p, unsigned k) {

@@ -87,6 +87,28 @@ def recomb_text(local, nsam, iteration=0, start_position=1.0):
     return "".join(out)
 
 
+def descendants_text(mask):
+    """print_descendants (descendants.hpp:51-65): '1' for each sample below the node, '0' for the ones before the last of
+    them, nothing after it; '0' for the empty set."""
+    mask = int(mask)
+    if mask == 0:
+        return "0"
+    top = mask.bit_length()
+    return "".join("1" if (mask >> i) & 1 else "0" for i in range(top))
+
+
+def trees_text(kind, pos, height, desc, start_position=1.0):
+    """The lines of `<prefix>.trees.gz` (ParticleContainer::printTrees, pc.cpp:515-555): event code, position
+    (x + start_position - 1), height, from and to population, descendants; fixed notation with one decimal."""
+    out = []
+    for k, x, t, d in zip(kind, pos, height, desc):
+        if k == 0:
+            out.append("R\t%.1f\t%.1f\t-1\t-1\t%s\n" % (x + start_position - 1, t, descendants_text(d)))
+        else:
+            out.append("C\t%.1f\t%.1f\t0\t-1\t%s\n" % (x + start_position - 1, t, descendants_text(d)))
+    return "".join(out)
+
+
 def parse_outfile(path_or_text, is_text=False):
     """Same reduction keys and the same Wt reconstruction as model.py:865-911."""
     text = path_or_text if is_text else open(path_or_text).read()

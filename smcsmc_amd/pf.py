@@ -89,7 +89,7 @@ EXPORTS = [
     "pf_terminal_branch_quantiles",
     "pf_update_segment", "pf_count", "pf_resample", "pf_run", "pf_finish", "pf_sync",
     "pf_num_segments_done", "pf_logl", "pf_get_counts", "pf_get_trace", "pf_get_resample_events",
-    "pf_get_particles", "pf_get_migrations", "pf_get_local_recomb", "pf_get_kernel_time", "pf_set_timing", "pf_get_stats",
+    "pf_get_particles", "pf_get_migrations", "pf_get_local_recomb", "pf_sample_tree_events", "pf_get_kernel_time", "pf_set_timing", "pf_get_stats",
     "pf_median_survival", "pf_test_math", "pf_test_div", "pf_test_uniform", "pf_test_reduce", "pf_test_systematic",
 ]
 
@@ -120,6 +120,8 @@ def load_library(path=None):
     L.pf_run.argtypes = [vp, C.c_int64, C.c_int64]
     L.pf_finish.argtypes = [vp]
     L.pf_sync.argtypes = [vp]
+    L.pf_sample_tree_events.restype = C.c_int64
+    L.pf_sample_tree_events.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.pf_num_segments_done.restype = C.c_int64
     L.pf_num_segments_done.argtypes = [vp]
     L.pf_logl.restype = C.c_double
@@ -239,7 +241,8 @@ KERNEL_CLASSES = ("extend", "decide", "count", "resample")
 
 
 class ParticleFilter:
-    def __init__(self, model, np_particles, ess_fraction=0.5, seed=1, max_trace_events=64, device=0, local_recomb=False):
+    def __init__(self, model, np_particles, ess_fraction=0.5, seed=1, max_trace_events=64, device=0, local_recomb=False,
+                 record_trees=False):
         self.L = load_library()
         m = model
         self._ct = np.ascontiguousarray(m["change_times"], dtype=np.float64)
@@ -257,7 +260,8 @@ class ParticleFilter:
         _attach_bias(self, self._model, m)
         _attach_structure(self, self._model, m, E, P)
         self.loci_length = float(m["loci_length"])
-        self._params = _Params(self.Np, float(ess_fraction), int(seed), self.max_trace_events, 1 if local_recomb else 0)
+        self._params = _Params(self.Np, float(ess_fraction), int(seed), self.max_trace_events,
+                               (1 if local_recomb else 0) | (2 if record_trees else 0))
         self.h = self.L.pf_create(C.byref(self._model), C.byref(self._params), int(device))
         if not self.h:
             raise PfError(_err(self.L))
@@ -359,6 +363,17 @@ class ParticleFilter:
         opp = np.zeros(nb); cnt = np.zeros((self.nsam + 2, nb))
         self._chk(self.L.pf_get_local_recomb(self.h, opp.ctypes.data, cnt.ctypes.data, nb))
         return {"opp_diff": opp, "counts": cnt}
+
+    def sample_tree_events(self):
+        """-arg: the particle of the final one-particle draw and the tree-modifying events of its history, last position
+        first: (particle, kind[K] (0 R, 1 C), pos[K], height[K], descendants[K] as sample bit masks)."""
+        part = C.c_int64()
+        n = self.L.pf_sample_tree_events(self.h, None, None, None, None, 0, C.byref(part))
+        if n < 0:
+            raise PfError(_err(self.L))
+        kind = np.zeros(n, np.int32); pos = np.zeros(n); hgt = np.zeros(n); desc = np.zeros(n, np.uint32)
+        self.L.pf_sample_tree_events(self.h, kind.ctypes.data, pos.ctypes.data, hgt.ctypes.data, desc.ctypes.data, n, C.byref(part))
+        return int(part.value), kind, pos, hgt, desc
 
     def migrations(self, cap=96):
         """Migration events on every particle's local tree and the population of every coalescent node."""

@@ -608,3 +608,131 @@ def test_binary_recombination_guide(hiplib, tmp_path):
     g = ParticleFilter(model, 300, seed=4, max_trace_events=0)
     g.init_prior(segs["start"][0]); g.load_segments(segs); g.run(); g.finish()
     assert outfile.outfile_text(model, g.counts(), 300) == open(tmp_path / "gd.out").read()
+
+
+# ---------------------------------------------------------------- -arg: tree dump of one sampled particle
+
+def _replay_tree_events(n, kind, pos, height, desc):
+    """Rebuilds the local tree from the events of a tree dump, first position first (what smcsmc/trees2tskit.py:125-190
+    does with them): every node is (height, samples below).  Returns the node list of the last tree."""
+    order = list(range(len(kind)))[::-1]               # the dump runs from the last position back to the first
+    nodes = []                                         # (height, mask), the coalescent nodes of the current tree
+    i = 0
+    while i < len(order):
+        c = order[i]                                   # read backwards, a coalescence comes before its recombination
+        assert kind[c] == 1
+        if i + 1 >= len(order) or kind[order[i + 1]] != 0:
+            nodes.append((height[c], int(desc[c])))    # initial tree: a new sample joins, no recombination
+            i += 1
+            continue
+        e = order[i + 1]
+        cut, h = int(desc[e]), height[e]               # R: remove the cut samples from every node above the cut ...
+        assert pos[c] == pos[e] and height[c] > h
+        new_mask, tc = int(desc[c]), height[c]
+        assert new_mask & cut == cut
+        pruned = []
+        for (t, m) in nodes:
+            if t > h and (m & cut) == cut:
+                m &= ~cut
+            pruned.append((t, m))
+        # ... a node left with a single subtree below it disappears (the old parent of the cut branch)
+        keep = []
+        for (t, m) in pruned:
+            below = [mm for (tt, mm) in pruned if tt < t and (mm & m) == mm and mm]
+            covered = 0
+            for mm in below:
+                covered |= mm
+            leaves = m & ~covered
+            nsub = bin(leaves).count("1") + len([mm for mm in below if not any((mm & m2) == mm and m2 != mm and (m2 & m) == m2 for (t2, m2) in pruned if t2 < t)])
+            keep.append((t, m, nsub))
+        pruned = [(t, m) for (t, m, nsub) in keep if nsub >= 2 and m]
+        # ... and the new node adds them to everything above it on the path to the root
+        target = new_mask & ~cut
+        if target == 0:                                # back into its own branch: the old tree returns
+            nodes = sorted(nodes)
+            i += 2
+            continue
+        out = []
+        for (t, m) in pruned:
+            if t > tc and (m & target) == target:
+                m |= cut
+            out.append((t, m))
+        out.append((tc, new_mask))
+        nodes = sorted(out)
+        i += 2
+    return sorted(nodes)
+
+
+@pytest.mark.parametrize("n,Np,force_lds", [(4, 300, False), (6, 200, False), (5, 150, True), (2, 100, False)])
+def test_tree_dump_of_the_sampled_particle(hiplib, n, Np, force_lds, monkeypatch):
+    """-arg (pc.cpp:515-555): replaying the dumped events of the drawn particle's history from the first position on must
+    end in that particle's own local tree (node heights and the samples below each node); every recombination is
+    followed by its coalescence at the same position, above the cut; the descendants of a coalescence contain those of
+    its recombination."""
+    from smcsmc_amd import ParticleFilter, outfile
+    if force_lds:
+        monkeypatch.setenv("SMCSMC_PF_FORCE_LDS", "1")
+    monkeypatch.setenv("SMCSMC_PF_LOG_CAP", "8192"); monkeypatch.setenv("SMCSMC_PF_GEN_CAP", "4096")
+    model = cases.make_model(n=n, E=8, L=1.5e5)
+    segs = cases.make_segments(model, seed=80 + n, max_seg_len=5000)
+    g = ParticleFilter(model, Np, seed=4, max_trace_events=0, record_trees=True)
+    g.init_prior(segs["start"][0]); g.load_segments(segs); g.run(); g.finish()
+    assert g.trace()["resampled"].sum() > 3
+    part, kind, pos, hgt, desc = g.sample_tree_events()
+    assert 0 <= part < Np and len(kind) > 2 * (n - 1)
+    assert (np.diff(pos) <= 0).all()                                        # last position first
+    nodes = _replay_tree_events(n, kind, pos, hgt, desc)
+    p = g.particles()
+    S = p["heights"][part]; Cc = p["children"][part].reshape(n - 1, 2)
+    masks = []
+    for r in range(n - 1):
+        m = 0
+        for c in Cc[r]:
+            m |= (1 << int(c)) if c < n else masks[int(c) - n]
+        masks.append(m)
+    expect = sorted((float(S[r]), masks[r]) for r in range(n - 1))
+    assert [m for _, m in nodes] == [m for _, m in expect]
+    np.testing.assert_allclose([t for t, _ in nodes], [t for t, _ in expect], rtol=0, atol=0)
+    # the text form: one decimal, positions shifted by the start position
+    text = outfile.trees_text(kind, pos, hgt, desc, start_position=1.0)
+    first = text.splitlines()[0].split("\t")
+    assert first[0] in "RC" and float(first[1]) == pytest.approx(pos[0], abs=0.05) and len(text.splitlines()) == len(kind)
+    assert outfile.descendants_text(0b0101) == "101" and outfile.descendants_text(0) == "0" and outfile.descendants_text(0b1000) == "0001"
+
+
+def test_binary_writes_the_tree_dump(hiplib, tmp_path):
+    """bin/smcsmc -arg writes <prefix>.trees.gz: the lines the python mirror makes from the same run, character for
+    character, in the reference's format (code, position, height, from, to, descendants; pc.cpp:515-555)."""
+    import gzip
+    import json
+    import os
+    import subprocess
+    from smcsmc_amd import ParticleFilter, outfile, segments as segmod
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    binary = os.path.join(root, "bin", "smcsmc")
+    seg = os.path.join(root, "tests", "golden", "seg", "constpopsize_first3000.seg")
+    L = 1000000
+    core = ("-N0 10000 -t %g -r %g %d -eN 0 1 -eN 0.01 1 -eN 0.25 1 -eN 1 1" % (4e4 * 2.5e-8 * L, 4e4 * 1e-8 * L, L)).split()
+    env = dict(os.environ, SMCSMC_PF_LOG_CAP="16384", SMCSMC_PF_GEN_CAP="8192")
+    r = subprocess.run([binary] + core + ["-nsam", "2", "-Np", "200", "-EM", "0", "-tmax", "4", "-lag", "20000", "-seed", "4",
+                                          "-arg", "-seg", seg, "-o", str(tmp_path / "arg")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    text = gzip.open(tmp_path / "arg.trees.gz", "rt").read()
+    lines = text.splitlines()
+    assert len(lines) > 10 and all(ln.split("\t")[0] in ("R", "C") and len(ln.split("\t")) == 6 for ln in lines)
+    assert lines[-1].split("\t")[0] == "C" and lines[-1].split("\t")[5] == "11"       # the first tree: sample 2 joins sample 1
+    m = json.loads(subprocess.run([binary] + core + ["-nsam", "2", "-tmax", "4", "-dumpmodel"], capture_output=True, text=True).stdout)
+    E = len(m["change_times"])
+    model = dict(change_times=np.array(m["change_times"]), pop_sizes=np.array(m["pop_sizes"])[:, 0], lags=np.full(E, 20000.0),
+                 nsam=2, loci_length=float(L), mutation_rate=m["mutation_rate"], recombination_rate=m["recombination_rate"])
+    S = segmod.Segments(seg, 2, L, max_segment_length=int(2.0 / (m["recombination_rate"] * 4 * m["N0"])))
+    segs = S.pack(model["lags"])
+    for k, v in (("SMCSMC_PF_LOG_CAP", "16384"), ("SMCSMC_PF_GEN_CAP", "8192")):
+        os.environ[k] = v
+    try:
+        g = ParticleFilter(model, 200, seed=4, max_trace_events=0, local_recomb=True, record_trees=True)
+        g.init_prior(segs["start"][0]); g.load_segments(segs); g.run(); g.finish()
+        _, kind, pos, hgt, desc = g.sample_tree_events()
+    finally:
+        os.environ.pop("SMCSMC_PF_LOG_CAP"); os.environ.pop("SMCSMC_PF_GEN_CAP")
+    assert outfile.trees_text(kind, pos, hgt, desc, start_position=1.0) == text
