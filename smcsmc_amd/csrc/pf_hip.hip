@@ -390,7 +390,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
         cx.T = sT; cx.I = sI; cx.H = sH; cx.E = A.E; cx.n = n; cx.L = A.L; cx.mu = A.mu; cx.rho = A.rho;
         cx.seed = A.seed; cx.slot = (unsigned)p; cx.stream = 0;
         cx.nb = A.n_bias + 1; cx.bH = sBH; cx.bS = sBS; cx.last_iw = 1.0;
-        cx.want_desc = A.lmap_opp != nullptr || A.rec_trees; cx.last_desc = 0; cx.last_desc_new = 0;
+        cx.want_desc = A.lmap_opp != nullptr || A.rec_trees; cx.want_desc_new = A.rec_trees != 0; cx.last_desc = 0; cx.last_desc_new = 0;
         cx.vbc = A.vb_coal; cx.upd_fac = 1.0;
         cx.gK = BIASED ? A.g_K : 0; cx.gpos = A.g_pos; cx.grho = A.g_rho; cx.gleaf = A.g_leaf; cx.last_rbiw = 1.0;
         cx.ridx = cx.gK > 0 ? from.ridx[a] : 0; cx.g_rp = 0; cx.g_sb = 0;
@@ -1639,7 +1639,7 @@ __global__ __launch_bounds__(PF_BS) void k_calibrate(KArgs A, unsigned long long
         RCtx cx;
         cx.T = sT; cx.I = sI; cx.H = sH; cx.E = A.E; cx.n = n; cx.L = A.L; cx.mu = A.mu; cx.rho = A.rho;
         cx.seed = seed; cx.slot = ln.slot; cx.stream = 2; cx.ctr = ln.ctr; cx.ebuf = ln.ebuf; cx.Ltree = ln.Ltree;
-        cx.nb = 1; cx.bH = nullptr; cx.bS = nullptr; cx.last_iw = 1.0; cx.want_desc = false; cx.last_desc = 0; cx.last_desc_new = 0;
+        cx.nb = 1; cx.bH = nullptr; cx.bS = nullptr; cx.last_iw = 1.0; cx.want_desc = false; cx.want_desc_new = false; cx.last_desc = 0; cx.last_desc_new = 0;
         cx.vbc = nullptr; cx.upd_fac = 1.0;
         cx.gK = 0; cx.gpos = nullptr; cx.grho = nullptr; cx.gleaf = nullptr; cx.last_rbiw = 1.0; cx.ridx = 0; cx.g_rp = 0; cx.g_sb = 0;
         while (alive > 0 && next < stop) {

@@ -77,6 +77,7 @@ struct RCtx {
     unsigned last_desc;   // samples below the branch cut by the last update (only computed when want_desc)
     unsigned last_desc_new;   // samples below the node created by the last update (only computed when want_desc)
     bool want_desc;
+    bool want_desc_new;   // -arg only
 };
 
 __device__ __forceinline__ double r_uni(RCtx& cx) { return philox_uniform(cx.seed, cx.slot, cx.stream, cx.ctr++); }
@@ -515,10 +516,11 @@ __device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, doubl
     if (guided_pt) { rp = cx.g_rp; sb = cx.g_sb; }
     else r_lineages_at(t, n, n - 1, h, lin, &rp, &sb);
     *h_out = h;
-    unsigned below[RTree<NM>::NI];
-    unsigned cut = 0;
+    unsigned tmask[RTree<NM>::NI + NM];          // -arg only: samples below every node id of the tree before the cut
     if (cx.want_desc) {
         // get_descendants (descendants.hpp:22-33) of the cut branch on the tree before it changes: masks bottom-up
+        unsigned below[RTree<NM>::NI];
+        unsigned cut = 0;
 #pragma unroll
         for (int r = 0; r < RTree<NM>::NI; ++r) {
             below[r] = 0;
@@ -533,6 +535,10 @@ __device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, doubl
             }
         }
         cx.last_desc = cut;
+        if (cx.want_desc_new) {
+#pragma unroll
+            for (int r = 0; r < RTree<NM>::NI; ++r) tmask[r] = below[r];
+        }
     }
     double tc = r_coalesce_up(cx, t, n - 1, n, h, u_refresh);
     *tc_out = tc;
@@ -577,16 +583,17 @@ __device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, doubl
             }
         }
     }
-    if (cx.want_desc) {
+    if (cx.want_desc_new) {
         // samples below the node this update creates: the cut samples plus those below the branch it lands on (masks of
         // the tree before the cut: rank q of the pruned tree was rank q, or q + 1 from the removed parent on)
+        const unsigned cut = cx.last_desc;
         unsigned dn = cut;
         if (idx < nslots) {
             const int tid_ = t.getC(pr_ins, ps_ins);
             unsigned tm = tid_ < n ? (1u << tid_) : 0u;
             const int oldr = (tid_ - n) + ((tid_ - n) >= rp ? 1 : 0);
 #pragma unroll
-            for (int k = 0; k < RTree<NM>::NI; ++k) tm = (tid_ >= n && oldr == k) ? below[k] : tm;
+            for (int k = 0; k < RTree<NM>::NI; ++k) tm = (tid_ >= n && oldr == k) ? tmask[k] : tm;
             dn = cut | tm;
         } else if (has_root && idx == nslots) {
             dn = (1u << n) - 1u;
