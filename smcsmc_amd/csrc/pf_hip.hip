@@ -340,7 +340,8 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
 // launch gap from the per-row critical path.  The arithmetic is k_resample's, operation for operation.
 // EXACT: the number of haplotypes equals NM, so every `r < n - 1` guard of the unrolled tree loops is decided at
 // compile time (the guards are compare + exec-mask instructions, and instructions are what the time is made of)
-template <int NM, bool BIASED, bool EXACT = false>
+// TREES: -arg, the records also carry the descendants of the node each update creates
+template <int NM, bool BIASED, bool EXACT = false, bool TREES = false>
 __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int fuse) {
     extern __shared__ double smem[];
     double* sT = smem;                            // epoch starts and ...
@@ -390,7 +391,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
         cx.T = sT; cx.I = sI; cx.H = sH; cx.E = A.E; cx.n = n; cx.L = A.L; cx.mu = A.mu; cx.rho = A.rho;
         cx.seed = A.seed; cx.slot = (unsigned)p; cx.stream = 0;
         cx.nb = A.n_bias + 1; cx.bH = sBH; cx.bS = sBS; cx.last_iw = 1.0;
-        cx.want_desc = A.lmap_opp != nullptr || A.rec_trees; cx.want_desc_new = A.rec_trees != 0; cx.last_desc = 0; cx.last_desc_new = 0;
+        cx.want_desc = A.lmap_opp != nullptr || TREES; cx.want_desc_new = TREES; cx.last_desc = 0; cx.last_desc_new = 0;
         cx.vbc = A.vb_coal; cx.upd_fac = 1.0;
         cx.gK = BIASED ? A.g_K : 0; cx.gpos = A.g_pos; cx.grho = A.g_rho; cx.gleaf = A.g_leaf; cx.last_rbiw = 1.0;
         cx.ridx = cx.gK > 0 ? from.ridx[a] : 0; cx.g_rp = 0; cx.g_sb = 0;
@@ -508,7 +509,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
                 if (cx.vbc) { w_post *= cx.upd_fac; w_pilot *= cx.upd_fac; cx.upd_fac = 1.0; }
                 rec[2] = h;
                 rec[3] = tc;
-                rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n, cx.last_desc, cx.last_desc_new));
+                rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n, cx.last_desc, TREES ? cx.last_desc_new : 0u));
                 ++widx;
                 if (leaf_status == 0) B = r_tracked_len(t, n, present_mask);
                 if (leaf_status == 1) B = cx.Ltree;
@@ -601,7 +602,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
         A.rng_ctr[p] = cx.ctr;
         A.ebuf[p] = cx.ebuf;
         A.widx[p] = widx;
-        if (A.rec_trees && widx >= A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;       // -arg keeps every record
+        if (TREES && widx >= A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;       // -arg keeps every record
 #pragma unroll
         for (int r = 0; r < RTree<NM>::NI; ++r) if (r < n - 1) A.snap_S[A.sp][(size_t)r * A.Np + p] = t.S[r];
         A.snap_w[A.sp][p] = w_post; A.snap_xm[A.sp][p] = x_mark; A.snap_ml[A.sp][p] = mark_limit; A.snap_widx[A.sp][p] = widx;
@@ -626,9 +627,9 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
     }
 }
 
-template <int NM, bool BIASED>
+template <int NM, bool BIASED, bool TREES = false>
 __global__ __launch_bounds__(PF_BS) void k_extend_reg(KArgs A, long long s, int fuse) {
-    extend_reg_body<NM, BIASED>(A, s, fuse);
+    extend_reg_body<NM, BIASED, false, TREES>(A, s, fuse);
 }
 
 // ------------------------------------------------------------------ count bookkeeping (shared)
@@ -1239,10 +1240,10 @@ __global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0, Windows Wn) {
 // load), the remaining workgroups evaluate the lagged counts of row s-1 (k_count's body).  The two halves touch
 // disjoint data -- everything the counts read from row s-1 is immutable or double-buffered by row parity -- so the
 // counting costs no synchronisation at all: no second stream, no event record / wait packets on the critical path.
-template <int NM, bool BIASED, bool EXACT>
+template <int NM, bool BIASED, bool EXACT, bool TREES = false>
 __global__ __launch_bounds__(PF_BS) void k_row(KArgs A, long long s, int fuse, int nb, int count_first, Windows Wprev) {
     if ((int)blockIdx.x < nb) {
-        extend_reg_body<NM, BIASED, EXACT>(A, s, fuse);
+        extend_reg_body<NM, BIASED, EXACT, TREES>(A, s, fuse);
     } else {
         const int idx = (int)blockIdx.x - nb;
         count_body<NM, 1, EXACT>(A, A.sp ^ 1, count_first, Wprev, idx % nb, idx / nb, nb);
@@ -2422,13 +2423,25 @@ static int launch_extend(pf_handle* h, long long s, int fuse = 0) {
         if (h->P > 1)
             pf_mp_launch_extend(h->A, s, h->smem, h->stream);
         else if (h->n <= 4 && biased && !h->force_lds)
-            hipLaunchKernelGGL((k_extend_reg<4, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);
+        {
+            if (h->A.rec_trees) hipLaunchKernelGGL((k_extend_reg<4, true, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);
+            else hipLaunchKernelGGL((k_extend_reg<4, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);
+        }
         else if (h->n <= 8 && biased && !h->force_lds)
-            hipLaunchKernelGGL((k_extend_reg<8, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);
+        {
+            if (h->A.rec_trees) hipLaunchKernelGGL((k_extend_reg<8, true, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);
+            else hipLaunchKernelGGL((k_extend_reg<8, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);
+        }
         else if (h->n <= 4 && !h->force_lds)
-            hipLaunchKernelGGL((k_extend_reg<4, false>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);
+        {
+            if (h->A.rec_trees) hipLaunchKernelGGL((k_extend_reg<4, false, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);
+            else hipLaunchKernelGGL((k_extend_reg<4, false>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);
+        }
         else if (h->n <= 8 && !h->force_lds)
-            hipLaunchKernelGGL((k_extend_reg<8, false>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);
+        {
+            if (h->A.rec_trees) hipLaunchKernelGGL((k_extend_reg<8, false, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);
+            else hipLaunchKernelGGL((k_extend_reg<8, false>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);
+        }
         else
             hipLaunchKernelGGL(k_extend, dim3(h->nblocks), dim3(PF_BS), h->smem, h->stream, h->A, s);
     }
@@ -2554,7 +2567,9 @@ static void launch_row(pf_handle* h, long long s, int fuse, int count_first, con
     const size_t smem_reg = (size_t)(2 * PF_EPAD + h->E + 2 * PF_BIAS_MAX + 3) * 8;
     const int nb = h->nblocks;
     const int ncount = count_first < h->E ? nb * (h->E - count_first) : 0;
-    if (h->n == NM)
+    if (h->A.rec_trees)
+        hipLaunchKernelGGL((k_row<NM, BIASED, false, true>), dim3(nb + ncount), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse, nb, count_first, Wprev);
+    else if (h->n == NM)
         hipLaunchKernelGGL((k_row<NM, BIASED, true>), dim3(nb + ncount), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse, nb, count_first, Wprev);
     else
         hipLaunchKernelGGL((k_row<NM, BIASED, false>), dim3(nb + ncount), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse, nb, count_first, Wprev);
