@@ -663,8 +663,9 @@ def _replay_tree_events(n, kind, pos, height, desc):
     return sorted(nodes)
 
 
-@pytest.mark.parametrize("n,Np,force_lds", [(4, 300, False), (6, 200, False), (5, 150, True), (2, 100, False)])
-def test_tree_dump_of_the_sampled_particle(hiplib, n, Np, force_lds, monkeypatch):
+@pytest.mark.parametrize("n,Np,force_lds,bias", [(4, 300, False, False), (6, 200, False, False), (5, 150, True, False), (2, 100, False, False),
+                                                 (8, 200, False, True), (7, 120, True, True)])
+def test_tree_dump_of_the_sampled_particle(hiplib, n, Np, force_lds, bias, monkeypatch):
     """-arg (pc.cpp:515-555): replaying the dumped events of the drawn particle's history from the first position on must
     end in that particle's own local tree (node heights and the samples below each node); every recombination is
     followed by its coalescence at the same position, above the cut; the descendants of a coalescence contain those of
@@ -675,6 +676,8 @@ def test_tree_dump_of_the_sampled_particle(hiplib, n, Np, force_lds, monkeypatch
     monkeypatch.setenv("SMCSMC_PF_LOG_CAP", "8192"); monkeypatch.setenv("SMCSMC_PF_GEN_CAP", "4096")
     model = cases.make_model(n=n, E=8, L=1.5e5)
     segs = cases.make_segments(model, seed=80 + n, max_seg_len=5000)
+    if bias:
+        model = dict(model, bias_heights=[400.0], bias_strengths=[4.0, 1.0], application_delays=np.full(8, 3000.0))
     g = ParticleFilter(model, Np, seed=4, max_trace_events=0, record_trees=True)
     g.init_prior(segs["start"][0]); g.load_segments(segs); g.run(); g.finish()
     assert g.trace()["resampled"].sum() > 3
