@@ -298,7 +298,7 @@ def main():
         # HBM traffic of the same kernel from the PMC counters: collected by profiles/collect_round1.sh in separate
         # rocprofv3 passes (counters cannot be read from inside this process) and kept under profiles/
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "round1", "v8_pmc_k_row.json")
+        pmc_path = os.path.join(ROOT, "profiles", "round1", "v9_pmc_k_row.json")
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
             if pmc["shape"] == {"nsam": args.nsam, "np": args.np, "epochs": args.epochs, "pops": args.pops}:
