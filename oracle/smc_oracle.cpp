@@ -38,6 +38,7 @@
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
+#include <memory>
 #include <vector>
 
 namespace smco {
@@ -228,7 +229,17 @@ struct Tree {
     int8_t Mb[MMAX], Mq[MMAX];
 };
 
+/* a tree-modifying event of the pseudo-epoch of particle.cpp:240-249, 292-298, 379-389 (RECORD_TREE_EVENT): the
+ * list is immutable and shared between a particle and its copies, as the reference's ref-counted event chains are */
+struct TreeEv {
+    int kind;                 /* 0 recombination (R), 1 coalescence (C) */
+    double x, t;
+    uint32_t desc;
+    std::shared_ptr<const TreeEv> parent;
+};
+
 struct Particle {
+    std::shared_ptr<const TreeEv> tree_head;   /* eventTrees[tree_epoch] (particle.cpp:242, 294, 381) */
     Tree tr;
     double w_post, w_pilot;
     double next_base;
@@ -294,6 +305,17 @@ struct Filter {
     double upd_fac = 1.0;
     void apply_vb(Particle& p) { if (!M.vb_coal.empty()) { p.w_post *= upd_fac; p.w_pilot *= upd_fac; } upd_fac = 1.0; }
     double last_iw = 1.0, last_tc = 0.0, last_first_event = 0.0;
+    bool record_trees = false;      /* -arg (pfparam.cpp:353-357) */
+    void push_tree_event(Particle& p, int kind, double x, double t, uint32_t desc) {
+        auto ev = std::make_shared<TreeEv>();
+        ev->kind = kind; ev->x = x; ev->t = t; ev->desc = desc; ev->parent = p.tree_head;
+        p.tree_head = ev;
+    }
+    /* samples below node id of tree t */
+    uint32_t desc_mask(const Tree& t, int id) const {
+        if (id < M.n) return 1u << id;
+        return desc_mask(t, t.C[id - M.n][0]) | desc_mask(t, t.C[id - M.n][1]);
+    }
     double last_rbiw = 1.0;       /* recombination_bias_importance_weight_ (particle.cpp:1113-1121) */
     int64_t slot_override = -1;   /* calibration: RNG state lives in rng[0], stream keyed by the replicate index */
     /* The four uniforms of one genealogy update of the one-population engine (cut point, waiting-time refresh,
@@ -855,9 +877,11 @@ struct Filter {
             double u = uni(slot);
             int idx = std::min((int)(u * (double)kk), kk - 1);
             if (above_root) {
+                if (record_trees) push_tree_event(p, 1, 0.0, tc, (2u << i) - 1u);
                 insert_node(t, ni, tc, i, -1, 0, root);
             } else {
                 lineages_at(t, ni, tc, idx, &pr, &ps);
+                if (record_trees) push_tree_event(p, 1, 0.0, tc, (1u << i) | desc_mask(t, t.C[pr][ps]));
                 insert_node(t, ni, tc, i, pr, ps, root);
             }
             root = n + ni;     /* the top-ranked node is the root of the partial tree */
@@ -1057,6 +1081,24 @@ struct Filter {
         int idx = std::min((int)(u * (double)k), k - 1);
         last_sp = Sp;
         last_changed = !(has_stub && idx == k - 1);
+        if (record_trees) {
+            /* R: the cut (record_recomb_event, particle.cpp:379-389); C: the floating lineage's coalescence
+             * (particle.cpp:292-298), with the samples below the node it creates -- its own only when it goes back
+             * into its branch (what smcsmc/trees2tskit.py:161-170 calls a back coalescence) */
+            const uint32_t cut = (uint32_t)last_desc;
+            uint32_t dn = cut;
+            if (idx < nslots) {
+                int qr = -1, qs = 0;
+                lineages_at(t, ni, tc, idx, &qr, &qs);
+                dn = cut | desc_mask(t, t.C[qr][qs]);
+            } else if (has_root && idx == nslots) {
+                dn = (1u << n) - 1u;
+            }
+            /* the coalescence is recorded while the new genealogy is sampled, the recombination afterwards
+             * (record_recomb_event follows sampleNextGenealogy, particle.cpp:861-903): the list then reads R, C */
+            push_tree_event(p, 1, x, tc, dn);
+            push_tree_event(p, 0, x, h, cut);
+        }
         if (idx < nslots) {
             lineages_at(t, ni, tc, idx, &pr, &ps);
             insert_node(t, ni, tc, b_id, pr, ps, troot);
@@ -1645,6 +1687,7 @@ struct Filter {
                 d.lookahead = src.lookahead; d.ridx = src.ridx;
                 d.total_delayed = src.total_delayed; d.dcount = src.dcount;
                 for (int k = 0; k < src.dcount; ++k) { d.dpos[k] = src.dpos[k]; d.dfac[k] = src.dfac[k]; d.ddelta[k] = src.ddelta[k]; d.dk[k] = src.dk[k]; }
+                d.tree_head = src.tree_head;             /* the pseudo-epoch of tree events is copied with the others */
                 d.head = src.head;                       /* copyEventContainers: particle.cpp:139-148 */
                 for (Ev* h : d.head) if (h) ++h->refs;
             }
@@ -2010,6 +2053,35 @@ int smco_get_counts(void* h, double* out, int32_t n) {
 }
 
 int smco_enable_local_recomb(void* h) { ((Filter*)h)->local_map = true; return 0; }
+
+/* -arg: call before smco_init_prior */
+int smco_enable_tree_recording(void* h) {
+    Filter* f = (Filter*)h;
+    if (f->M.P > 1) { g_err = "tree recording is restated for one population"; return -1; }
+    f->record_trees = true;
+    return 0;
+}
+
+/* ParticleContainer::printTrees (pc.cpp:515-555) after resample(..., NULL, 1) (smcsmc.cpp:395): the particle whose
+ * cumulative posterior weight passes U * total, U the next uniform of the resampler's stream; its events last first */
+int64_t smco_sample_tree_events(void* h, int32_t* kind, double* pos, double* height, uint32_t* desc, int64_t max_events,
+                                int64_t* particle_out) {
+    Filter* f = (Filter*)h;
+    if (!f->record_trees) return -1;
+    double total = 0.0;
+    for (int64_t i = 0; i < f->Np; ++i) total += f->parts[i].w_post;
+    const double u = philox_uniform(f->seed, 0xFFFFFFFFu, 1, (uint64_t)f->n_resample);
+    int64_t j = 0;
+    double acc = 0.0;
+    for (; j < f->Np - 1; ++j) { acc += f->parts[j].w_post; if (acc > u * total) break; }
+    if (particle_out) *particle_out = j;
+    int64_t n = 0;
+    for (const TreeEv* ev = f->parts[j].tree_head.get(); ev; ev = ev->parent.get()) {
+        if (n < max_events) { if (kind) kind[n] = ev->kind; if (pos) pos[n] = ev->x; if (height) height[n] = ev->t; if (desc) desc[n] = ev->desc; }
+        ++n;
+    }
+    return n;
+}
 
 /* opp_diff[nbins], counts[(nsam+2)*nbins] */
 int smco_get_local_recomb(void* h, double* opp_diff, double* counts, int64_t nbins) {

@@ -134,6 +134,9 @@ int smco_get_counts(void* h, double* packed, int32_t n);
 /* 100-bp local recombination map (count.cpp:559-654): call enable before init_prior; opp_diff[nbins] is the
  * differential opportunity of count.hpp:101, counts[(nsam+2)*nbins] the per-sample, time and log-time weighted counts */
 int smco_enable_local_recomb(void* h);
+int smco_enable_tree_recording(void* h);
+int64_t smco_sample_tree_events(void* h, int32_t* kind, double* pos, double* height, uint32_t* desc, int64_t max_events,
+                                int64_t* particle_out);
 int smco_get_local_recomb(void* h, double* opp_diff, double* counts, int64_t nbins);
 /* structured models: migration events kept on each particle's local tree ([np*cap], sorted by time) and the
  * population of every coalescent node ([np*(nsam-1)]) */

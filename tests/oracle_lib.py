@@ -74,6 +74,9 @@ def lib():
         L.smco_get_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.smco_get_migrations.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int32]
         L.smco_enable_local_recomb.argtypes = [C.c_void_p]
+        L.smco_enable_tree_recording.argtypes = [C.c_void_p]
+        L.smco_sample_tree_events.restype = C.c_int64
+        L.smco_sample_tree_events.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.smco_get_local_recomb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.smco_logl.restype = C.c_double
         L.smco_logl.argtypes = [C.c_void_p]
@@ -220,6 +223,19 @@ class Oracle:
 
     def run(self, seg_inp):
         self._chk(self.L.smco_run(self.h, C.byref(seg_inp.segs)))
+
+    def enable_tree_recording(self):
+        """-arg: before init_prior"""
+        self._chk(self.L.smco_enable_tree_recording(self.h))
+
+    def sample_tree_events(self):
+        part = C.c_int64()
+        n = self.L.smco_sample_tree_events(self.h, None, None, None, None, 0, C.byref(part))
+        if n < 0:
+            raise RuntimeError("tree recording is off")
+        kind = np.zeros(n, np.int32); pos = np.zeros(n); hgt = np.zeros(n); desc = np.zeros(n, np.uint32)
+        self.L.smco_sample_tree_events(self.h, kind.ctypes.data, pos.ctypes.data, hgt.ctypes.data, desc.ctypes.data, n, C.byref(part))
+        return int(part.value), kind, pos, hgt, desc
 
     def update_segment(self, seg_inp, s):
         self._chk(self.L.smco_update_segment(self.h, C.byref(seg_inp.segs), s))

@@ -665,7 +665,7 @@ def _replay_tree_events(n, kind, pos, height, desc):
 
 @pytest.mark.parametrize("n,Np,force_lds,bias", [(4, 300, False, False), (6, 200, False, False), (5, 150, True, False), (2, 100, False, False),
                                                  (8, 200, False, True), (7, 120, True, True)])
-def test_tree_dump_of_the_sampled_particle(hiplib, n, Np, force_lds, bias, monkeypatch):
+def test_tree_dump_of_the_sampled_particle(oracle, hiplib, n, Np, force_lds, bias, monkeypatch):
     """-arg (pc.cpp:515-555): replaying the dumped events of the drawn particle's history from the first position on must
     end in that particle's own local tree (node heights and the samples below each node); every recombination is
     followed by its coalescence at the same position, above the cut; the descendants of a coalescence contain those of
@@ -683,6 +683,13 @@ def test_tree_dump_of_the_sampled_particle(hiplib, n, Np, force_lds, bias, monke
     assert g.trace()["resampled"].sum() > 3
     part, kind, pos, hgt, desc = g.sample_tree_events()
     assert 0 <= part < Np and len(kind) > 2 * (n - 1)
+    # the oracle keeps the reference's own structure, a linked list of tree events per particle shared with its copies
+    o = oracle.Oracle(model, Np, seed=4, max_trace_events=0)
+    o.enable_tree_recording()
+    o.init_prior(segs["start"][0]); o.run(o.pack_segments(model, segs))
+    opart, okind, opos, ohgt, odesc = o.sample_tree_events()
+    assert opart == part and (okind == kind).all() and (odesc == desc).all()
+    assert (_bits(opos) == _bits(pos)).all() and (_bits(ohgt) == _bits(hgt)).all()
     assert (np.diff(pos) <= 0).all()                                        # last position first
     nodes = _replay_tree_events(n, kind, pos, hgt, desc)
     p = g.particles()
