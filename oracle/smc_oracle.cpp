@@ -27,6 +27,12 @@
  *   D6 recombination-opportunity rectangles are closed when the stretch ends instead of being
  *      written with the sampled next_base and patched on resampling (particle.cpp:393-436);
  *      the sums of count.cpp:495-555 are identical
+ *   D12 one population: the floating lineage's coalescence time is read off the cumulative intensity
+ *      Hc(t) = int_0^t ds/(2N(s)) (one comparison per node passed, then the inverse) instead of interval by
+ *      interval; same distribution, and the arithmetic the device uses.  One opportunity record per interval is
+ *      still written, between the cut height and the time found.
+ *   D13 one population: the four uniforms of a genealogy update are the halves of two consecutive Philox blocks
+ *   (D7-D11, R1, R2: DESIGN.md section 6)
  */
 #include "smc_oracle.h"
 #include "smc_math.h"
