@@ -746,3 +746,37 @@ def test_binary_writes_the_tree_dump(hiplib, tmp_path):
     finally:
         os.environ.pop("SMCSMC_PF_LOG_CAP"); os.environ.pop("SMCSMC_PF_GEN_CAP")
     assert outfile.trees_text(kind, pos, hgt, desc, start_position=1.0) == text
+
+
+def test_binary_flag_combinations(hiplib, tmp_path):
+    """The flag combinations a front-end or a user can ask for run through, and none of the sampling aids moves the
+    likelihood estimate of the same data by more than a per cent."""
+    import os
+    import subprocess
+    from smcsmc_amd import outfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    binary = os.path.join(root, "bin", "smcsmc")
+    seg = os.path.join(root, "tests", "golden", "seg", "constpopsize_first3000.seg")
+    L = 1000000
+    core = ("-N0 10000 -t %g -r %g %d -eN 0 1 -eN 0.01 1 -eN 0.25 1 -eN 1 1" % (4e4 * 2.5e-8 * L, 4e4 * 1e-8 * L, L)).split()
+    common = ["-nsam", "2", "-seg", seg, "-Np", "300", "-tmax", "4", "-seed", "3"]
+    env = dict(os.environ, SMCSMC_PF_LOG_CAP="32768", SMCSMC_PF_GEN_CAP="16384")
+    runs = {
+        "plain": [],
+        "apf_bias": ["-apf", "2", "-bias_heights", "400", "-bias_strengths", "3", "1"],
+        "arg_apf": ["-apf", "1", "-arg"],
+        "arg_bias_xr": ["-arg", "-bias_heights", "400", "-bias_strengths", "3", "1", "-xr", "0-1", "-delay_coal"],
+        "em_arg": ["-arg", "-EM", "1"],
+        "ess_record": ["-ESS", "0.7", "-record_ess", "-calibrate_lag", "1.5"],
+    }
+    ll = {}
+    for name, extra in runs.items():
+        r = subprocess.run([binary] + core + common + extra + ["-o", str(tmp_path / name)], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, (name, r.stderr[-300:])
+        rows = [ln.split() for ln in open(tmp_path / (name + ".out")).read().splitlines()[1:]]
+        ll[name] = float([x for x in rows if x[4] == "LogL" and x[0] == "0"][0][8])
+        if "-arg" in extra:
+            assert os.path.getsize(tmp_path / (name + ".trees.gz")) > 100
+    assert os.path.exists(tmp_path / "ess_record.resample")
+    for name, v in ll.items():
+        assert abs(v / ll["plain"] - 1) < 0.01, (name, v, ll["plain"])
