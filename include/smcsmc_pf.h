@@ -76,7 +76,19 @@ typedef struct pf_params {
     int32_t max_trace_events;    /* resampling events whose ancestor arrays are retained for inspection */
     int32_t flags;               /* bit0: record the 100-bp local recombination map (count.cpp:559-654);
                                   * bit1: -arg, keep what pf_sample_tree_events needs (one population) */
+    /* Capacities of the device-side rings that stand in for the reference's Arena of EvolutionaryEvents
+     * (arena.cpp:56-111, unbounded there).  0 = default.  A ring that is too small for the lags in force is a
+     * reported error (pf_sync returns -2, "event log ring overflow" / "generation ledger overflow"), never a
+     * silent overwrite. */
+    int64_t log_cap;             /* event-log records per particle slot (default 16384; with -arg 131072) */
+    int64_t gen_cap;             /* resampling generations kept by the ancestor ledger (default 8192; -arg 131072) */
+    int64_t piece_cap;           /* structured models: coal/migr opportunity pieces per slot (default 4*log_cap) */
+    int32_t debug;               /* testing switches: PF_DEBUG_* below */
+    int32_t reserved;
 } pf_params;
+#define PF_DEBUG_FORCE_LDS 1     /* run the LDS-tree kernels whatever nsam is */
+#define PF_DEBUG_NO_FUSE   2     /* complete every row with the stand-alone k_resample (two-stream pipeline) */
+#define PF_DEBUG_NO_COUNT  4     /* profiling: skip the lagged counting and the ledger upkeep */
 
 typedef struct pf_segments {
     int64_t n;

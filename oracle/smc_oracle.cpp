@@ -2075,11 +2075,11 @@ int64_t smco_sample_tree_events(void* h, int32_t* kind, double* pos, double* hei
     Filter* f = (Filter*)h;
     if (!f->record_trees) return -1;
     double total = 0.0;
-    for (int64_t i = 0; i < f->Np; ++i) total += f->parts[i].w_post;
+    for (int64_t i = 0; i < f->Np; ++i) total += f->parts[i].w_pilot;   /* pilotWeight(), pc.cpp:256-262 */
     const double u = philox_uniform(f->seed, 0xFFFFFFFFu, 1, (uint64_t)f->n_resample);
     int64_t j = 0;
     double acc = 0.0;
-    for (; j < f->Np - 1; ++j) { acc += f->parts[j].w_post; if (acc > u * total) break; }
+    for (; j < f->Np - 1; ++j) { acc += f->parts[j].w_pilot; if (acc > u * total) break; }
     if (particle_out) *particle_out = j;
     int64_t n = 0;
     for (const TreeEv* ev = f->parts[j].tree_head.get(); ev; ev = ev->parent.get()) {

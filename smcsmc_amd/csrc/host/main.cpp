@@ -89,6 +89,13 @@ static void pf_check(int rc) {
     if (rc < 0) throw std::runtime_error(pf_last_error());
 }
 
+// The reference carries one generator across its EM iterations (pfparam.cpp:316); with counter-based streams every
+// iteration gets its own key instead, derived from one base seed that is resolved once per process.
+static uint64_t base_seed(const HostModel& M) {
+    static const uint64_t from_clock = (uint64_t)time(nullptr);
+    return M.seed_set ? M.seed : from_clock;
+}
+
 // pfARG_core (smcsmc.cpp:278-401): one E-step over the chunk
 static void pfARG_core(PfParam& P, const HostModel& M0) {
     HostModel& M = P.model;
@@ -200,7 +207,7 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
 
     pf_params pp;
     memset(&pp, 0, sizeof(pp));
-    pp.np = (int64_t)P.N; pp.ess_fraction = P.ESS_fraction; pp.seed = M.seed_set ? M.seed : (uint64_t)time(nullptr);
+    pp.np = (int64_t)P.N; pp.ess_fraction = P.ESS_fraction; pp.seed = base_seed(M) + 1000ull * (uint64_t)P.EMcounter;   // same rule as smcsmc_amd/em.py: seed + 1000 * iteration + chunk
     pp.max_trace_events = 0;
     pp.flags = 1;          // the local recombination map is always recorded (smcsmc.cpp:376-383)
     if (P.record_trees) {
@@ -214,8 +221,8 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
         const double gib = ((double)P.N * (double)log_cap * (5.0 + M.nsam - 1) * 8.0 + (double)gen_cap * (double)P.N * 20.0) / (1024.0 * 1024.0 * 1024.0);
         clog << " -arg: event log of " << log_cap << " records per particle, " << gen_cap << " generations (" << fixed << setprecision(1)
              << gib << " GiB)" << setprecision(6) << scientific << endl;
-        if (!getenv("SMCSMC_PF_LOG_CAP")) setenv("SMCSMC_PF_LOG_CAP", std::to_string(log_cap).c_str(), 1);
-        if (!getenv("SMCSMC_PF_GEN_CAP")) setenv("SMCSMC_PF_GEN_CAP", std::to_string(gen_cap).c_str(), 1);
+        pp.log_cap = log_cap;
+        pp.gen_cap = gen_cap;
     }
     pf_handle* h = pf_create(&pm, &pp, device);
     if (!h) throw std::runtime_error(pf_last_error());

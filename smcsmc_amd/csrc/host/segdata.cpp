@@ -1,294 +1,406 @@
-// smcsmc_amd/csrc/host/segdata.cpp -- .seg reader; follows /root/reference/src/segdata.cpp line by line
-// in behaviour (prepare 55-166, extract_field_VARIANT 413-451, read_new_line 182-222, the
-// distance_to_mutation part of set_lookahead 234-262) and smcsmc.cpp:266-275.
+// smcsmc_amd/csrc/host/segdata.cpp -- the .seg input of the drop-in binary: text file -> resident row table ->
+// the flat arrays of pf_load_segments / pf_load_lookahead (include/smcsmc_pf.h).
+//
+// What is contract here is the file format and the per-row quantities the filter consumes (the
+// reference's reader is /root/reference/src/segdata.cpp, its per-row look-ahead segdata.cpp:225-410 and the
+// recording limit smcsmc.cpp:266-275).  How they are computed is this file's own:
+//   * the file is read into memory once and rows are cut out of it as string_views; a row is a small struct, the
+//     genotype strings are decoded into one flat int8 table that the pieces of a split row share;
+//   * each genotype row is classified once (carriers, missing samples, unphased marks); the look-ahead of a row then
+//     scans these classes instead of re-reading genotypes per (row, later row) pair;
+//   * the distance from an all-missing row to the nearest data (which limits event recording) comes from one forward
+//     and one backward sweep.
+#include <algorithm>
+#include <charconv>
 #include <cmath>
-#include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <sstream>
+#include <string_view>
 
 #include "smcsmc_host.hpp"
 
-using namespace std;
+namespace {
 
-Segment::Segment(string file_name, size_t nsam, double seqlen, double num_of_mut, long long data_start, double max_segment_length)
-    : file_name_(file_name), nsam_(nsam), data_start_(data_start), seqlen_(seqlen), max_segment_length_(max_segment_length) {
-    if (file_name_.size() == 0) {
-        // no-data mode: all-missing pseudo segments (segdata.cpp:36-43, 175-178, 454-461)
-        empty_file_ = true;
-        double s = 0.0;
-        for (size_t i = 1; i < nsam; i++) s += 1.0 / i;
-        num_of_expected_mutations_ = s * num_of_mut;
-        long long seglen = (long long)ceil((size_t)seqlen_ / num_of_expected_mutations_);
-        if (seglen < 1) seglen = 1;
-        for (long long pos = 0; pos < (long long)seqlen_; pos += seglen)
-            buffer_.push_back(SegDatum{pos + data_start_, seglen, SEGMENT_MISSING, vector<int>(nsam_, -1)});
-    } else {
-        prepare();
-    }
+constexpr int kMaxFields = 8;
+
+std::string slurp(const std::string& path) {
+    std::ifstream in(path, std::ios::binary);
+    if (!in.good()) throw InvalidInputFile(path);
+    std::ostringstream ss;
+    ss << in.rdbuf();
+    return ss.str();
 }
 
-vector<int> Segment::extract_field_VARIANT(const string& field) {
-    vector<int> out;
-    if (nsam_ > field.size()) throw WrongNumberOfEntry(field);
-    if (number_of_fields_ == -1) {
-        number_of_fields_ = (int)field.size();
-        if (nsam_ != field.size())
-            cout << "Warning: analyzing " << nsam_ << " haplotypes, but input .seg file contains " << field.size()
-                 << " haplotypes.  Ignoring remainder." << endl;
-    } else if (number_of_fields_ != (int)field.size()) {
-        throw WrongNumberOfEntry(field);
+// Cuts the next line (without its newline) off the front of `rest`.
+std::string_view take_line(std::string_view& rest) {
+    const size_t nl = rest.find('\n');
+    std::string_view line = rest.substr(0, nl);
+    rest.remove_prefix(nl == std::string_view::npos ? rest.size() : nl + 1);
+    return line;
+}
+
+// Tab-separated fields of a line; a tab at the very end of the line does not open another field.
+int split_fields(std::string_view line, std::string_view (&field)[kMaxFields]) {
+    int count = 0;
+    while (!line.empty()) {
+        const size_t tab = line.find('\t');
+        if (count < kMaxFields) field[count] = line.substr(0, tab);
+        ++count;
+        if (tab == std::string_view::npos) break;
+        line.remove_prefix(tab + 1);
     }
-    for (size_t i = 0; i < nsam_; i++) {
-        int v;
-        switch (field[i]) {
-            case '.': v = -1; break;
-            case '/': v = 2; break;
-            case '0': v = 0; break;
-            case '1': v = 1; break;
+    return count;
+}
+
+// Leading integer of a field ("521", "521.0" and "521 " all give 521); `whole` tells whether that was all of it.
+long long leading_integer(std::string_view f, bool* whole) {
+    long long v = 0;
+    const char* b = f.data();
+    const char* e = f.data() + f.size();
+    while (b < e && (*b == ' ' || *b == '+')) ++b;
+    auto r = std::from_chars(b, e, v);
+    if (r.ec != std::errc()) { v = 0; r.ptr = b; }
+    if (whole) *whole = (r.ptr == e);
+    return v;
+}
+
+bool is_flag(std::string_view f) { return f == "T" || f == "F"; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ reading
+Segment::Segment(std::string file_name, size_t nsam, double seqlen, double num_of_mut, long long data_start,
+                 double max_segment_length)
+    : file_name_(std::move(file_name)), nsam_(nsam), data_start_(data_start), seqlen_(seqlen),
+      max_segment_length_(max_segment_length) {
+    if (!file_name_.empty()) {
+        read_file();
+        return;
+    }
+    // No -seg: the filter runs over pseudo rows without data whose length is the expected distance between
+    // segregating sites, ceil(L / (theta * H(n-1))).
+    empty_file_ = true;
+    double harmonic = 0.0;
+    for (size_t i = 1; i < nsam_; ++i) harmonic += 1.0 / (double)i;
+    long long step = (long long)std::ceil((double)(size_t)seqlen_ / (harmonic * num_of_mut));
+    if (step < 1) step = 1;
+    genotypes_.assign(nsam_, -1);
+    for (long long at = 0; at < (long long)seqlen_; at += step)
+        pieces_.push_back(SegPiece{at + data_start_, step, SEGMENT_MISSING, 0});
+}
+
+// Decodes one genotype field into a new row of genotypes_; returns its index.
+uint32_t Segment::add_genotype(std::string_view field) {
+    if (field.size() < nsam_) throw WrongNumberOfEntry(std::string(field));
+    if (field_width_ < 0) {
+        field_width_ = (int)field.size();
+        if (field.size() != nsam_)
+            std::cout << "Warning: analyzing " << nsam_ << " haplotypes, but input .seg file contains " << field.size()
+                      << " haplotypes.  Ignoring remainder." << std::endl;
+    } else if ((size_t)field_width_ != field.size()) {
+        throw WrongNumberOfEntry(std::string(field));
+    }
+    const uint32_t row = (uint32_t)(genotypes_.size() / nsam_);
+    for (size_t k = 0; k < nsam_; ++k) {
+        int8_t code;
+        switch (field[k]) {
+            case '0': code = 0; break;
+            case '1': code = 1; break;
+            case '/': code = 2; break;      // unphased heterozygote
+            case '.': code = -1; break;     // missing
             default: throw InvalidSeg("Unknown character found in .seg file; expect one of '.', '/', '0' or '1'.");
         }
-        out.push_back(v);
-        if (v == -1 && (i % 2) == 1 && out[i - 1] != -1) throw InvalidSeg("Found inconsistent unphased heterozygous marks");
+        // the second haplotype of an individual cannot be missing when the first is not
+        if (code == -1 && (k & 1) && genotypes_.back() != -1)
+            throw InvalidSeg("Found inconsistent unphased heterozygous marks");
+        genotypes_.push_back(code);
     }
-    return out;
+    return row;
 }
 
-void Segment::prepare() {
-    ifstream in(file_name_.c_str());
-    if (!in.good()) throw InvalidInputFile(file_name_);
-    string line;
-    long long next_start_pos = -1;
-    getline(in, line);
-    while (line.size() > 0) {
-        if (line[0] != '#') {
-            vector<int> col_starts;
-            int pos = 0;
-            while (line[pos] && line[pos] != '\n') {
-                col_starts.push_back(pos);
-                for (; line[pos] && line[pos] != '\n' && line[pos] != '\t'; ++pos) {}
-                if (line[pos] == '\t') ++pos;
-            }
-            if (col_starts.size() < 3) throw InvalidSeg("Require 3 or 6 columns");
-            char* end_ptr;
-            vector<int> allele;
-            long long new_seg_start = strtoll(line.c_str(), &end_ptr, 10);
-            if (*end_ptr != '\t') throw InvalidSegmentStartPosition(line, to_string(new_seg_start));
-            long new_seg_len = strtol(line.c_str() + col_starts[1], &end_ptr, 10);
-            if ((line[col_starts[2]] == 'T' || line[col_starts[2]] == 'F') && line[col_starts[2] + 1] == '\t') {
-                if (col_starts.size() != 6) throw InvalidSeg("Require 6 (or 3) columns");
-                if ((line[col_starts[3]] != 'T' && line[col_starts[3]] != 'F') || line[col_starts[3] + 1] != '\t')
-                    throw InvalidSeg("Expected T or F in .seg file column 3 and 4");
-                strtol(line.c_str() + col_starts[4], &end_ptr, 10);
-                if (*end_ptr != '\t') throw InvalidSeg("Bad chromosome (not an integer) in column 5");
-                allele = extract_field_VARIANT(string(line.c_str() + col_starts[5]));
-            } else {
-                if (col_starts.size() != 3) throw InvalidSeg("Require 3 (or 6) columns");
-                allele = extract_field_VARIANT(string(line.c_str() + col_starts[2]));
-            }
-            if (next_start_pos > -1 && next_start_pos != new_seg_start) throw InvalidSeg("Segments are not consecutive");
-            next_start_pos = new_seg_start + new_seg_len;
-            if (new_seg_start >= data_start_ + seqlen_) break;
-            Segment_State state;
-            if (new_seg_start + new_seg_len > data_start_) {
-                do {
-                    if (new_seg_len > max_segment_length_) {
-                        new_seg_len = (long)max_segment_length_;
-                        state = SEGMENT_INVARIANT_PARTIAL;
-                    } else {
-                        state = SEGMENT_INVARIANT;
-                    }
-                    if (new_seg_start + new_seg_len > data_start_)
-                        buffer_.push_back(SegDatum{new_seg_start, new_seg_len, state, allele});
-                    new_seg_start += new_seg_len;
-                    new_seg_len = next_start_pos - new_seg_start;
-                } while (new_seg_start < next_start_pos);
-            }
-        }
-        line.clear();
-        getline(in, line);
-    }
-    if (buffer_.size() == 0) throw NoDataError(file_name_, data_start_, (long long)(data_start_ + seqlen_));
-}
-
-int max_epoch_to_update(const vector<double>& lags, double distance_to_mutation) {
-    int epoch = 0;
-    const double scale_factor = 0.5;
-    while (epoch < (int)lags.size() && distance_to_mutation < scale_factor * lags[epoch]) epoch++;
-    return epoch - 1;
-}
-
-void Segment::pack(const vector<double>& lags, vector<double>& start, vector<double>& length, vector<int8_t>& state,
-                   vector<int8_t>& alleles, vector<int32_t>& mre) const {
-    const size_t n = buffer_.size();
-    start.resize(n); length.resize(n); state.resize(n); alleles.resize(n * nsam_); mre.resize(n);
-    double segment_start = 0, segment_length = 0;
-    for (size_t i = 0; i < n; ++i) {
-        const SegDatum& sd = buffer_[i];
-        segment_start += segment_length;                       // read_new_line (segdata.cpp:187)
-        long new_seg_start = (long)(sd.segment_start - data_start_);
-        long new_seg_end = new_seg_start + sd.segment_length;
-        if (new_seg_start < 0) new_seg_start = 0;
-        if (new_seg_start > segment_start) throw InvalidSeg("Internal error - segment computation problem (start)");
-        if (new_seg_end < 0) throw InvalidSeg("Internal error - segment computation problem (end)");
-        segment_start = new_seg_start;
-        segment_length = new_seg_end - new_seg_start;
-        start[i] = segment_start; length[i] = segment_length; state[i] = (int8_t)sd.segment_state;
-        for (size_t k = 0; k < nsam_; ++k) alleles[i * nsam_ + k] = (int8_t)sd.allele_state[k];
-    }
-    // distance_to_mutation (segdata.cpp:234-262) -> max_epoch_to_update
-    vector<long long> next_data(n, -1);
-    long long last = -1;
-    for (long long i = (long long)n - 1; i >= 0; --i) {
-        if (!buffer_[i].all_alleles_missing()) last = i;
-        next_data[i] = last;
-    }
-    size_t run_start = 0;
-    for (size_t i = 0; i < n; ++i) {
-        double d = 0;
-        if (!buffer_[i].all_alleles_missing()) {
-            run_start = i + 1;
+void Segment::read_file() {
+    const std::string text = slurp(file_name_);
+    const long long window_first = data_start_;
+    const double window_end = (double)data_start_ + seqlen_;
+    const long long piece_cap = max_segment_length_ >= 9e18 ? (long long)9e18 : (long long)max_segment_length_;
+    std::string_view rest(text);
+    long long expected_first = -1;          // first base the next row must start at
+    std::string_view field[kMaxFields];
+    while (!rest.empty()) {
+        const std::string_view line = take_line(rest);
+        if (line.empty()) break;            // an empty line ends the data
+        if (line.front() == '#') continue;
+        const int nf = split_fields(line, field);
+        if (nf < 3) throw InvalidSeg("Require 3 or 6 columns");
+        bool whole = false;
+        const long long first = leading_integer(field[0], &whole);
+        if (!whole) throw InvalidSegmentStartPosition(std::string(line), std::to_string(first));
+        const long long bases = leading_integer(field[1], nullptr);
+        std::string_view genotype;
+        if (is_flag(field[2])) {
+            // six columns: start, length, two flags, chromosome, genotypes
+            if (nf != 6) throw InvalidSeg("Require 6 (or 3) columns");
+            if (!is_flag(field[3])) throw InvalidSeg("Expected T or F in .seg file column 3 and 4");
+            bool chrom_ok = true;
+            if (!field[4].empty()) leading_integer(field[4], &chrom_ok);
+            if (!chrom_ok) throw InvalidSeg("Bad chromosome (not an integer) in column 5");
+            genotype = field[5];
         } else {
-            d = (double)(buffer_[i].segment_start - buffer_[run_start].segment_start);
-            if (next_data[i] >= 0) {
-                const SegDatum& nd = buffer_[next_data[i]];
-                d = std::min(d, (double)(nd.segment_start + nd.segment_length - buffer_[i].segment_start));
-            }
+            if (nf != 3) throw InvalidSeg("Require 3 (or 6) columns");
+            genotype = field[2];
         }
-        if (empty_file_) d = 0;   // no-data mode never calls set_lookahead (segdata.cpp:189-191)
-        mre[i] = max_epoch_to_update(lags, d);
+        const uint32_t geno = add_genotype(genotype);
+        if (expected_first >= 0 && first != expected_first) throw InvalidSeg("Segments are not consecutive");
+        expected_first = first + bases;
+        if ((double)first >= window_end) break;
+        // Rows longer than the cap are cut into capped pieces that carry no site (INVARIANT_PARTIAL) followed by the
+        // remainder with the site at its end; pieces that end before the window are dropped.
+        // A row of zero bases (two sites at one position) still carries its site: it is one empty piece.
+        long long at = first;
+        do {
+            const long long left = expected_first - at;
+            const bool capped = left > piece_cap;
+            const long long take = capped ? piece_cap : left;
+            if (at + take > window_first)
+                pieces_.push_back(SegPiece{at, take, capped ? SEGMENT_INVARIANT_PARTIAL : SEGMENT_INVARIANT, geno});
+            at += take;
+        } while (at < expected_first);
     }
+    if (pieces_.empty()) throw NoDataError(file_name_, data_start_, (long long)window_end);
 }
 
+// ------------------------------------------------------------------------------------------------ device arrays
+int max_epoch_to_update(const std::vector<double>& lags, double distance_to_mutation) {
+    // events of epoch e are worth recording only while data is nearer than half that epoch's lag; lags decrease with
+    // the epoch, so the answer is the last epoch of the leading run that still qualifies (-1: none)
+    int last = -1;
+    for (size_t e = 0; e < lags.size() && distance_to_mutation < 0.5 * lags[e]; ++e) last = (int)e;
+    return last;
+}
 
-// ------------------------------------------------------------------ auxiliary particle filter look-ahead
-// Segment::set_lookahead (segdata.cpp:225-410) for every buffered row, written into the arrays of pf_lookahead.
-void Segment::pack_lookahead(LookaheadArrays& out) const {
-    const size_t S = buffer_.size();
-    const int nsam = (int)nsam_;
-    const int D = std::max(1, nsam / 2);
-    out.max_doubletons = D;
-    out.first_singleton_distance.assign(S * nsam, 0.0);
-    out.relative_mutation_rate.assign(S * nsam, 0.0);
-    out.is_singleton_unphased.assign(S * nsam, 0);
-    out.n_doubletons.assign(S, 0);
-    out.doubleton_idx.assign(S * D * 4, 0);
-    out.doubleton_dist.assign(S * D * 2, 0.0);
-    out.first_split_distance.assign(S, -1.0);
-    out.split_alleles.assign(S * nsam, 0);
-    out.split_count.assign(S, 0);
-    struct Doubleton { int s1, s2; double first, last; bool u1, u2, incompatible; };
-    const double max_missing_data = 2000000;
-    for (size_t cur = 0; cur < S; ++cur) {
-        vector<double> fsd(nsam, 0.0), rmr(nsam, 0.0);
-        vector<Doubleton> doubleton;
-        double first_split_distance = -1;
-        vector<int> split_alleles(nsam, 0);
-        int split_count = 0;
-        vector<bool> found_doubleton(nsam + 1, false);
-        int num_singletons = 0, num_unphased_singletons = 0, num_doubleton_sequences = 0;
-        double tl = 0.1, tl_missing = 0.1, total_current_missing = 0.0, last_singleton_distance = 0.0, distance = 0.0;
-        vector<int> unph;
-        const long long start0 = buffer_[cur].segment_start;
-        for (size_t i = cur; i < S; i++) {
-            const SegDatum& b = buffer_[i];
-            int num_var = 0, num_missing = 0, s1 = -1, s2 = -1;
-            unph.clear();
-            for (int j = 0; j < nsam; j++) {
-                unph.push_back(0);
-                if (b.allele_state[j] > 0) {
-                    num_var++;
-                    if (num_var == 1) s1 = j;
-                    if (num_var == 2) s2 = j;
-                    if (b.allele_state[j] == 2) {
-                        unph[j] = 1;
-                        unph.push_back(1);
-                        j++;
-                    }
-                }
-                if (j < nsam && b.allele_state[j] == -1) {
-                    num_missing++;
-                    if (num_missing == 1) total_current_missing += b.segment_length;
-                    if (total_current_missing > max_missing_data) {
-                        if (fsd[j] == 0) {
-                            const double epsilon = 1e-6;
-                            fsd[j] = -(double)(b.segment_start - start0) - epsilon;
-                            last_singleton_distance = -fsd[j];
-                            if (fsd[j] < 0.5 * total_current_missing) fsd[j] = -epsilon;
-                            rmr[j] = tl_missing / tl;
-                            num_singletons++;
-                        }
-                        if (!found_doubleton[j]) { found_doubleton[j] = true; num_doubleton_sequences++; }
-                    }
-                }
+bool Segment::no_data_in(const SegPiece& p) const {
+    const int8_t* g = &genotypes_[(size_t)p.geno * nsam_];
+    return std::all_of(g, g + nsam_, [](int8_t v) { return v == -1; });
+}
+
+void Segment::pack(const std::vector<double>& lags, std::vector<double>& start, std::vector<double>& length,
+                   std::vector<int8_t>& state, std::vector<int8_t>& alleles, std::vector<int32_t>& max_record_epoch) const {
+    const size_t rows = pieces_.size();
+    start.resize(rows); length.resize(rows); state.resize(rows); alleles.resize(rows * nsam_); max_record_epoch.resize(rows);
+    // coordinates relative to the first base of the window; the first piece may begin before it
+    for (size_t i = 0; i < rows; ++i) {
+        const SegPiece& p = pieces_[i];
+        const long long lo = std::max<long long>(0, p.first - data_start_);
+        const long long hi = p.first + p.bases - data_start_;
+        start[i] = (double)lo;
+        length[i] = (double)(hi - lo);
+        state[i] = (int8_t)p.kind;
+        std::copy_n(&genotypes_[(size_t)p.geno * nsam_], nsam_, &alleles[i * nsam_]);
+    }
+    // Distance from each row without data to the nearest data: to the left, back to the first row of its run of
+    // data-free rows; to the right, to the end of the next row that has data.  Rows with data are at distance 0.
+    std::vector<double> gap(rows, 0.0);
+    long long run_first = -1;
+    for (size_t i = 0; i < rows; ++i) {
+        if (!no_data_in(pieces_[i])) { run_first = -1; continue; }
+        if (run_first < 0) run_first = (long long)i;
+        gap[i] = (double)(pieces_[i].first - pieces_[(size_t)run_first].first);
+    }
+    long long data_end = -1;                 // end of the nearest row with data to the right
+    for (size_t k = rows; k-- > 0;) {
+        if (!no_data_in(pieces_[k])) { data_end = pieces_[k].first + pieces_[k].bases; continue; }
+        if (data_end >= 0) gap[k] = std::min(gap[k], (double)(data_end - pieces_[k].first));
+    }
+    for (size_t i = 0; i < rows; ++i) max_record_epoch[i] = max_epoch_to_update(lags, empty_file_ ? 0.0 : gap[i]);
+}
+
+// ------------------------------------------------------------------------------------------------ look-ahead
+// What the auxiliary particle filter wants to know at a row (ForestState::includeLookaheadLikelihood,
+// particle.cpp:439-617): per sample, how far ahead the next mutation carried by that sample alone lies (and what share
+// of the bases up to there had data); the pairs of samples that next share a mutation nobody else carries, with the
+// first and last evidence for each pair; the first mutation that splits the samples into two groups of three or more.
+namespace {
+
+// Everything the scan needs to know about one genotype row, derived once.
+struct SiteClass {
+    int carriers = 0;          // samples carrying the derived allele (an unphased pair counts once)
+    int absent = 0;            // samples without data
+    int first = -1, second = -1;   // the first two carriers
+    uint64_t unphased = 0;     // bit j: sample j opened an unphased pair at this row
+    uint64_t no_data = 0;      // bit j: sample j is missing (as seen by the scan, see classify())
+    uint64_t flags_len = 0;    // how many unphased flags the row produces (nsam + one per unphased pair)
+};
+
+SiteClass classify(const int8_t* g, int nsam) {
+    SiteClass c;
+    int j = 0;
+    while (j < nsam) {
+        if (g[j] > 0) {
+            ++c.carriers;
+            if (c.carriers == 1) c.first = j;
+            if (c.carriers == 2) c.second = j;
+            if (g[j] == 2) {
+                // an unphased heterozygote: its partner haplotype is not looked at as a carrier
+                c.unphased |= 1ull << j;
+                ++j;
             }
-            if (num_missing == 0) total_current_missing = 0.0;
-            tl += (double)b.segment_length * nsam;
-            tl_missing += (double)b.segment_length * (nsam - num_missing);
-            if (total_current_missing > max_missing_data) continue;
-            bool have_doubleton = false;
-            distance = (double)(b.segment_start + b.segment_length - start0) + 0.5;
-            if (num_var == 1) {
-                if (fsd[s1] == 0) {
-                    fsd[s1] = distance;
-                    rmr[s1] = tl_missing / tl;
-                    num_singletons++;
-                    last_singleton_distance = fsd[s1];
-                    if (unph[s1]) {
-                        fsd[s1 + 1] = distance;
-                        rmr[s1 + 1] = rmr[s1];
-                        num_singletons++;
-                        num_unphased_singletons++;
+        }
+        // the missing-data test follows the carrier test and therefore sees the partner of an unphased pair
+        if (j < nsam && g[j] == -1) { ++c.absent; c.no_data |= 1ull << j; }
+        ++j;
+    }
+    return c;
+}
+
+struct SharedPair { int a, b; double first_seen, last_seen; bool a_unphased, b_unphased, refuted; };
+
+// State of one forward scan.
+struct Ahead {
+    std::vector<double> next_private, data_share;
+    std::vector<SharedPair> pairs;
+    std::vector<char> in_pair;
+    double split_at = -1.0;
+    uint32_t split_row = 0;
+    int split_minor = 0;
+    int have_private = 0, have_private_unphased = 0, samples_in_pairs = 0;
+    double bases_seen = 0.1, bases_with_data = 0.1;     // x samples; the offset keeps the ratio defined
+    double missing_streak = 0.0, last_private = 0.0, reach = 0.0;
+    explicit Ahead(int nsam) : next_private(nsam, 0.0), data_share(nsam, 0.0), in_pair(nsam + 1, 0) {}
+    double share() const { return bases_with_data / bases_seen; }
+};
+
+constexpr double kGiveUpMissing = 2000000.0;   // a sample without data for this long is not waited for
+constexpr double kTiny = 1e-6;
+
+}  // namespace
+
+void Segment::pack_lookahead(LookaheadArrays& out) const {
+    const size_t rows = pieces_.size();
+    const int nsam = (int)nsam_;
+    const int slots = std::max(1, nsam / 2);
+    out.max_doubletons = slots;
+    out.first_singleton_distance.assign(rows * nsam, 0.0);
+    out.relative_mutation_rate.assign(rows * nsam, 0.0);
+    out.is_singleton_unphased.assign(rows * nsam, 0);
+    out.n_doubletons.assign(rows, 0);
+    out.doubleton_idx.assign(rows * slots * 4, 0);
+    out.doubleton_dist.assign(rows * slots * 2, 0.0);
+    out.first_split_distance.assign(rows, -1.0);
+    out.split_alleles.assign(rows * nsam, 0);
+    out.split_count.assign(rows, 0);
+
+    const size_t ngeno = genotypes_.size() / nsam_;
+    std::vector<SiteClass> cls(ngeno);
+    for (size_t g = 0; g < ngeno; ++g) cls[g] = classify(&genotypes_[g * nsam_], nsam);
+
+    for (size_t here = 0; here < rows; ++here) {
+        Ahead st(nsam);
+        const long long origin = pieces_[here].first;
+        uint32_t last_looked_at = pieces_[here].geno;
+        for (size_t i = here; i < rows; ++i) {
+            const SegPiece& pc = pieces_[i];
+            const SiteClass& c = cls[pc.geno];
+            const int8_t* g = &genotypes_[(size_t)pc.geno * nsam_];
+            last_looked_at = pc.geno;
+            // samples without data: the streak of bases over which somebody was missing, and giving up on samples
+            if (c.absent > 0) {
+                st.missing_streak += (double)pc.bases;
+                if (st.missing_streak > kGiveUpMissing)
+                    for (int j = 0; j < nsam; ++j) {
+                        if (!((c.no_data >> j) & 1)) continue;
+                        if (st.next_private[j] == 0) {
+                            // marked "none seen" by a negative distance; when most of the way was missing, by -tiny
+                            double mark = -(double)(pc.first - origin) - kTiny;
+                            st.last_private = -mark;
+                            if (mark < 0.5 * st.missing_streak) mark = -kTiny;
+                            st.next_private[j] = mark;
+                            st.data_share[j] = st.share();
+                            ++st.have_private;
+                        }
+                        if (!st.in_pair[j]) { st.in_pair[j] = 1; ++st.samples_in_pairs; }
+                    }
+            } else {
+                st.missing_streak = 0.0;
+            }
+            st.bases_seen += (double)pc.bases * nsam;
+            st.bases_with_data += (double)pc.bases * (nsam - c.absent);
+            if (st.missing_streak > kGiveUpMissing) continue;
+            st.reach = (double)(pc.first + pc.bases - origin) + 0.5;
+
+            if (c.carriers == 1) {
+                const int j = c.first;
+                if (st.next_private[j] == 0) {
+                    st.next_private[j] = st.reach;
+                    st.data_share[j] = st.share();
+                    st.last_private = st.reach;
+                    ++st.have_private;
+                    if ((c.unphased >> j) & 1) {      // either haplotype of the individual may carry it
+                        st.next_private[j + 1] = st.reach;
+                        st.data_share[j + 1] = st.data_share[j];
+                        ++st.have_private;
+                        ++st.have_private_unphased;
                     }
                 }
             } else {
-                for (Doubleton& d : doubleton) {
-                    int a1 = b.allele_state[d.s1], a2 = b.allele_state[d.s2];
-                    if (((d.s1 | 1) == d.s2 && a1 == 2) || ((a1 + a2 == 1) && ((a1 | a2) == 1))) d.incompatible = true;
-                    if (num_var == 2 && d.s1 == s1 && d.s2 == s2) {
-                        have_doubleton = true;
-                        if (!d.incompatible) d.last = distance;
+                bool known = false;
+                for (SharedPair& p : st.pairs) {
+                    const int ga = g[p.a], gb = g[p.b];
+                    const bool same_individual_het = ((p.a | 1) == p.b) && ga == 2;
+                    const bool differ = (ga + gb == 1) && ((ga | gb) == 1);
+                    if (same_individual_het || differ) p.refuted = true;
+                    if (c.carriers == 2 && p.a == c.first && p.b == c.second) {
+                        known = true;
+                        if (!p.refuted) p.last_seen = st.reach;
                     }
                 }
+                if (c.carriers == 2 && !known && g[c.first] > -1 && g[c.second] > -1) {
+                    // a new shared mutation; with unphased carriers either haplotype may be the free one
+                    const int ua = g[c.first] == 2, ub = g[c.second] == 2;
+                    bool placed = false;
+                    for (int da = 0; da <= ua && !placed; ++da)
+                        for (int db = 0; db <= ub && !placed; ++db)
+                            if (!st.in_pair[c.first + da] && !st.in_pair[c.second + db]) {
+                                st.pairs.push_back(SharedPair{c.first, c.second, st.reach, st.reach, ua != 0, ub != 0, false});
+                                st.in_pair[c.first + da] = 1;
+                                st.in_pair[c.second + db] = 1;
+                                st.samples_in_pairs += 2;
+                                placed = true;
+                            }
+                }
             }
-            if (num_var == 2 && !have_doubleton && b.allele_state[s1] > -1 && b.allele_state[s2] > -1) {
-                for (int d1 = 0; d1 <= (b.allele_state[s1] == 2); d1++)
-                    for (int d2 = 0; d2 <= (b.allele_state[s2] == 2); d2++)
-                        if (!found_doubleton[s1 + d1] && !found_doubleton[s2 + d2]) {
-                            doubleton.push_back(Doubleton{s1, s2, distance, distance, b.allele_state[s1] == 2,
-                                                          b.allele_state[s2] == 2, false});
-                            found_doubleton[s1 + d1] = true; num_doubleton_sequences++;
-                            found_doubleton[s2 + d2] = true; num_doubleton_sequences++;
-                            d1 = 1; d2 = 1;
-                        }
+            if (st.split_at == -1.0 && c.carriers > 2 && nsam - c.carriers > 2) {
+                st.split_at = st.reach;
+                st.split_row = pc.geno;
+                st.split_minor = std::min(c.carriers, nsam - c.carriers);
             }
-            if (first_split_distance == -1 && num_var > 2 && nsam - num_var > 2) {
-                first_split_distance = distance;
-                split_alleles = b.allele_state;
-                split_count = std::min(num_var, nsam - num_var);
+            if (st.have_private == nsam) {
+                if (st.samples_in_pairs >= nsam - 1) break;
+                if (st.reach > (2 + st.have_private_unphased) * st.last_private) break;     // far beyond the last one
             }
-            if ((num_singletons == nsam) && num_doubleton_sequences >= nsam - 1) break;
-            if ((num_singletons == nsam) && distance > (2 + num_unphased_singletons) * last_singleton_distance) break;
         }
-        if (num_singletons < nsam)
-            for (int j = 0; j < nsam; j++)
-                if (fsd[j] == 0) { fsd[j] = -distance; rmr[j] = tl_missing / tl; }
-        unph.resize(nsam, 0);
+        // ran off the data before every sample had its own mutation: "none within <reach>"
+        if (st.have_private < nsam)
+            for (int j = 0; j < nsam; ++j)
+                if (st.next_private[j] == 0) { st.next_private[j] = -st.reach; st.data_share[j] = st.share(); }
+
+        const SiteClass& lastc = cls[last_looked_at];
         for (int j = 0; j < nsam; ++j) {
-            out.first_singleton_distance[cur * nsam + j] = fsd[j];
-            out.relative_mutation_rate[cur * nsam + j] = rmr[j];
-            out.is_singleton_unphased[cur * nsam + j] = (int8_t)unph[j];
-            out.split_alleles[cur * nsam + j] = (int8_t)split_alleles[j];
+            out.first_singleton_distance[here * nsam + j] = st.next_private[j];
+            out.relative_mutation_rate[here * nsam + j] = st.data_share[j];
+            out.is_singleton_unphased[here * nsam + j] = (int8_t)((lastc.unphased >> j) & 1);
+            if (st.split_at != -1.0) out.split_alleles[here * nsam + j] = genotypes_[(size_t)st.split_row * nsam_ + j];
         }
-        if ((int)doubleton.size() > D) throw InvalidSeg("Internal error - more doubletons than sequence pairs");
-        out.n_doubletons[cur] = (int32_t)doubleton.size();
-        for (size_t k = 0; k < doubleton.size(); ++k) {
-            int8_t* di = &out.doubleton_idx[(cur * D + k) * 4];
-            di[0] = (int8_t)doubleton[k].s1; di[1] = (int8_t)doubleton[k].s2;
-            di[2] = doubleton[k].u1; di[3] = doubleton[k].u2;
-            out.doubleton_dist[(cur * D + k) * 2] = doubleton[k].first;
-            out.doubleton_dist[(cur * D + k) * 2 + 1] = doubleton[k].last;
+        if ((int)st.pairs.size() > slots) throw InvalidSeg("Internal error - more doubletons than sequence pairs");
+        out.n_doubletons[here] = (int32_t)st.pairs.size();
+        for (size_t k = 0; k < st.pairs.size(); ++k) {
+            const SharedPair& p = st.pairs[k];
+            int8_t* idx = &out.doubleton_idx[(here * slots + k) * 4];
+            idx[0] = (int8_t)p.a; idx[1] = (int8_t)p.b; idx[2] = p.a_unphased; idx[3] = p.b_unphased;
+            out.doubleton_dist[(here * slots + k) * 2] = p.first_seen;
+            out.doubleton_dist[(here * slots + k) * 2 + 1] = p.last_seen;
         }
-        out.first_split_distance[cur] = first_split_distance;
-        out.split_count[cur] = split_count;
+        out.first_split_distance[here] = st.split_at;
+        out.split_count[here] = st.split_minor;
     }
 }

@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <string_view>
 #include <vector>
 
 // ---- exception taxonomy (exception.hpp:32-51, pfparam.hpp:42-93, segdata.hpp:41-81) ----
@@ -115,14 +116,12 @@ struct HostModel {
 
 enum Segment_State { SEGMENT_INVARIANT, SEGMENT_MISSING, SEGMENT_INVARIANT_PARTIAL };   // segdata.hpp:84
 
-struct SegDatum {
-    long long segment_start, segment_length;
-    Segment_State segment_state;
-    std::vector<int> allele_state;
-    bool all_alleles_missing() const {
-        for (int a : allele_state) if (a != -1) return false;
-        return true;
-    }
+// One row of the resident table: `bases` bases starting at file position `first`; rows cut from one over-long file
+// row share a genotype row.
+struct SegPiece {
+    long long first, bases;
+    Segment_State kind;
+    uint32_t geno;               // row of the genotype table
 };
 
 // per-row arrays of Segment::set_lookahead in the layout of pf_lookahead (include/smcsmc_pf.h)
@@ -133,27 +132,29 @@ struct LookaheadArrays {
     std::vector<int32_t> n_doubletons, split_count;
 };
 
-class Segment {   // segdata.hpp:86-177
+class Segment {   // the .seg input (counterpart of segdata.hpp:86-177)
   public:
     Segment(std::string file_name, size_t nsam, double seqlen, double num_of_mut, long long data_start = 1,
             double max_segment_length = 1e99);
     bool empty_file() const { return empty_file_; }
-    const std::vector<SegDatum>& buffer() const { return buffer_; }
-    // arrays for pf_load_segments (coordinates relative to data_start; read_new_line semantics)
+    size_t rows() const { return pieces_.size(); }
+    // arrays for pf_load_segments (coordinates relative to data_start) with the per-row recording limit
     void pack(const std::vector<double>& lags, std::vector<double>& start, std::vector<double>& length,
               std::vector<int8_t>& state, std::vector<int8_t>& alleles, std::vector<int32_t>& max_record_epoch) const;
-    void pack_lookahead(LookaheadArrays& out) const;   // set_lookahead (segdata.cpp:225-410) for every row
+    // arrays for pf_load_lookahead: what Segment::set_lookahead (segdata.cpp:225-410) yields at every row
+    void pack_lookahead(LookaheadArrays& out) const;
   private:
-    void prepare();
-    std::vector<int> extract_field_VARIANT(const std::string& field);
+    void read_file();
+    uint32_t add_genotype(std::string_view field);
+    bool no_data_in(const SegPiece& p) const;
     std::string file_name_;
     size_t nsam_;
     long long data_start_;
     double seqlen_, max_segment_length_;
     bool empty_file_ = false;
-    double num_of_expected_mutations_ = 0;
-    int number_of_fields_ = -1;
-    std::vector<SegDatum> buffer_;
+    int field_width_ = -1;                 // characters in the genotype column, fixed by the first row
+    std::vector<SegPiece> pieces_;
+    std::vector<int8_t> genotypes_;        // [genotype row][nsam]: -1 missing, 0, 1, 2 unphased heterozygote
 };
 
 int max_epoch_to_update(const std::vector<double>& lags, double distance_to_mutation);   // smcsmc.cpp:266-275

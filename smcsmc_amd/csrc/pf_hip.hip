@@ -1039,7 +1039,7 @@ __device__ __forceinline__ void records_contrib(AccT<P>& acc, const KArgs& A, co
                 if (inwin) {
                     unsigned long long ref = (unsigned long long)__double_as_longlong(f3);
                     unsigned pstart = (unsigned)(ref & 0xffffffffu), np_ = (unsigned)(ref >> 32);
-                    if (A.pidx[a] - pstart > A.pcap) A.ctrl->err = ERR_LOG_OVERFLOW;
+                    if (A.pidx[a] - pstart > A.pcap || np_ > A.pcap) { if (!A.ctrl->err) A.ctrl->err = ERR_LOG_OVERFLOW; np_ = 0; }
                     for (unsigned j = 0; j < np_; ++j) {
                         const double* q = A.plog + ((size_t)a * A.pcap + ((pstart + j) % A.pcap)) * 3;
                         long long tag = __double_as_longlong(q[0]);
@@ -1084,6 +1084,9 @@ __device__ __forceinline__ void count_run(AccT<P>& acc, const KArgs& A, int sp, 
     int q0 = rst[i];
     int q1 = i + 1 < nr ? rst[i + 1] : (int)Np;
     long long a = ran[i];
+    // a ledger ring that has overflowed (reported by k_decide, ERR_GEN_OVERFLOW) aliases generations: whatever is
+    // read then must at least stay inside the arrays and every loop must stay bounded until the host sees the error
+    if (q1 <= q0 || q1 > (int)Np || q0 < 0 || a < 0 || a >= Np) return;
     // posterior mass of the descendants of (g, a): difference of the inclusive posterior scan
     const double* offp = A.chunk_offp2[sp];
     const double* scp_ = A.scanp2[sp];
@@ -1093,7 +1096,7 @@ __device__ __forceinline__ void count_run(AccT<P>& acc, const KArgs& A, int sp, 
     if (!(w > 0.0)) return;
     unsigned k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
     unsigned k1 = A.gstart[(size_t)((g + 1) % A.Gcap) * Np + a];
-    if (A.widx[a] - k0 > A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;
+    if (A.widx[a] - k0 > A.cap || k1 - k0 > A.cap) { if (!A.ctrl->err) A.ctrl->err = ERR_LOG_OVERFLOW; return; }
     records_contrib<NI, P>(acc, A, W, L, w, a, k0, k1);
 }
 
@@ -1199,7 +1202,7 @@ __device__ __forceinline__ void count_body(const KArgs& A, int sp, int e0, const
                 unsigned k1 = A.snap_widx[sp][a];
                 if (w == 0.0) continue;
                 stretch_contrib<NI, P>(acc, A, W, L, w, xm, PF_INF, S, ml);
-                if (k1 - k0 > A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;
+                if (k1 - k0 > A.cap) { if (!A.ctrl->err) A.ctrl->err = ERR_LOG_OVERFLOW; continue; }
                 records_contrib<NI, P>(acc, A, W, L, w, a, k0, k1);
             } else {
                 const int nr = s_off[lo_i + 1] - s_off[lo_i];
@@ -1942,8 +1945,9 @@ struct pf_handle {
     bool finished = false;
     bool fin_pending = false;     // k_count partials not yet folded into the totals
     Windows step_windows;         // windows of the step being processed
-    bool force_lds = false;       // SMCSMC_PF_FORCE_LDS=1: use the LDS-tree kernel for every n (testing)
-    bool no_fuse = false;         // SMCSMC_PF_NO_FUSE=1: always run k_resample as its own kernel (testing)
+    bool force_lds = false;       // pf_params.debug & PF_DEBUG_FORCE_LDS: use the LDS-tree kernel for every n (testing)
+    bool no_fuse = false;         // PF_DEBUG_NO_FUSE: always run k_resample as its own kernel (testing)
+    bool no_count = false;        // PF_DEBUG_NO_COUNT: no lagged counting, no ledger upkeep (profiling)
     // timing
     int timing_period = 0;
     struct Span { hipEvent_t a, b; int k; };
@@ -1979,11 +1983,6 @@ int pf_device_count(void) {
 }
 
 void pf_destroy(pf_handle* h);
-
-static long long env_ll(const char* name, long long dflt) {
-    const char* v = getenv(name);
-    return v ? atoll(v) : dflt;
-}
 
 // per-epoch, per-population tables of a structured model (scrm Model::population_size / migration_rate /
 // single_mig_pop), prepared exactly as the oracle's fill_model does
@@ -2086,8 +2085,9 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
         if (gen_cap > 0x7fffffffLL / 2) gen_cap = 0x7fffffffLL / 2;
         h->max_trace_events = (int)gen_cap;
     }
-    h->force_lds = env_ll("SMCSMC_PF_FORCE_LDS", 0) != 0;
-    h->no_fuse = env_ll("SMCSMC_PF_NO_FUSE", 0) != 0;
+    h->force_lds = (p->debug & PF_DEBUG_FORCE_LDS) != 0;
+    h->no_fuse = (p->debug & PF_DEBUG_NO_FUSE) != 0;
+    h->no_count = (p->debug & PF_DEBUG_NO_COUNT) != 0;
     h->h_lags.assign(m->lags, m->lags + E);
     h->h_counted_to.assign(E, 0.0);
     h->h_L = m->loci_length;
@@ -2204,7 +2204,7 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     rc |= dalloc(h, &A.log, (size_t)Np * A.cap * A.RS);
     if (P > 1) {
         // a genealogy update leaves one piece per (epoch, population) stretch of its path: a handful per record
-        A.pcap = (unsigned)env_ll("SMCSMC_PF_PIECE_CAP", 4 * log_cap);
+        A.pcap = (unsigned)(p->piece_cap > 0 ? p->piece_cap : 4 * log_cap);
         rc |= dalloc(h, &A.plog, (size_t)Np * A.pcap * 3);
         rc |= dalloc(h, &A.pidx, Np);
     }
@@ -2249,7 +2249,17 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
 pf_handle* pf_create(const pf_model* m, const pf_params* p, int device) {
     // with -arg (flags bit 1) nothing may be overwritten: rings sized for a whole chunk by default
     const bool trees = p && (p->flags & 2);
-    return create_impl(m, p, device, env_ll("SMCSMC_PF_LOG_CAP", trees ? 131072 : 16384), env_ll("SMCSMC_PF_GEN_CAP", trees ? 131072 : 8192));
+    if (!m || !p) { g_err = "pf_create: null model or parameters"; return nullptr; }
+    if (p->log_cap < 0 || p->gen_cap < 0 || p->piece_cap < 0 || p->log_cap > 0x7fffffffLL || p->piece_cap > 0x7fffffffLL) {
+        g_err = "pf_create: ring capacities out of range";
+        return nullptr;
+    }
+    if ((p->gen_cap > 0 && p->gen_cap < 4) || (p->log_cap > 0 && p->log_cap < 4)) {
+        g_err = "pf_create: log_cap and gen_cap must be at least 4";
+        return nullptr;
+    }
+    return create_impl(m, p, device, p->log_cap > 0 ? p->log_cap : (trees ? 131072 : 16384),
+                       p->gen_cap > 0 ? p->gen_cap : (trees ? 131072 : 8192));
 }
 
 void pf_destroy(pf_handle* h) {
@@ -2322,8 +2332,8 @@ int pf_sync(pf_handle* h) {
     HIPCHK(hipMemcpy(&c, h->A.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
     if (c.err) {
         const char* msg = "unknown device error";
-        if (c.err == ERR_LOG_OVERFLOW) msg = "event log ring overflow (raise SMCSMC_PF_LOG_CAP)";
-        if (c.err == ERR_GEN_OVERFLOW) msg = "generation ledger overflow (raise SMCSMC_PF_GEN_CAP)";
+        if (c.err == ERR_LOG_OVERFLOW) msg = "event log ring overflow (raise pf_params.log_cap)";
+        if (c.err == ERR_GEN_OVERFLOW) msg = "generation ledger overflow (raise pf_params.gen_cap)";
         if (c.err == ERR_ZERO_PROB) msg = "Zero or negative probabilities";   /* pc.cpp:428-429 */
         if (c.err == ERR_MIG_OVERFLOW) msg = "too many migration events on one local tree";
         if (c.err == ERR_MP_INTERNAL) msg = "structured-model genealogy update: coalescence partners inconsistent";
@@ -2462,7 +2472,7 @@ static int launch_decide(pf_handle* h, long long s, int mode, const Windows& W) 
         Timed tm(h, 1, t);
         hipLaunchKernelGGL(k_decide, dim3(h->nblocks + 1), dim3(PF_BS), 0, h->stream, h->A, s, mode, W, h->nblocks);
     }
-    if (!getenv("SMCSMC_PF_DEBUG_NOCOUNT")) {
+    if (!h->no_count) {
         h->ev_dec = next_sync_event(h);
         hipEventRecord(h->ev_dec, h->stream);
     }
@@ -2470,7 +2480,7 @@ static int launch_decide(pf_handle* h, long long s, int mode, const Windows& W) 
 }
 
 static int launch_count(pf_handle* h, long long s, const Windows& W) {
-    if (getenv("SMCSMC_PF_DEBUG_NOCOUNT")) return 0;
+    if (h->no_count) return 0;
     const int first = W.first;
     if (first >= h->E) return 0;
     const bool t = timing_on(h, s);
@@ -2501,7 +2511,7 @@ static int launch_count(pf_handle* h, long long s, const Windows& W) {
 // ancestor-ledger maintenance of this step (no-op unless the step resampled); closes the step on the counting stream
 static int launch_ledger(pf_handle* h, long long s) {
     (void)s;
-    if (getenv("SMCSMC_PF_DEBUG_NOCOUNT")) return 0;
+    if (h->no_count) return 0;
     if (h->ev_dec) hipStreamWaitEvent(h->cstream, h->ev_dec, 0);
     hipLaunchKernelGGL(k_ledger, dim3(h->nblocks + PF_LEDGER_BLOCKS), dim3(PF_BS), 0, h->cstream, h->A, h->nblocks);
     h->ev_cnt = next_sync_event(h);
@@ -2853,9 +2863,10 @@ int64_t pf_sample_tree_events(pf_handle* h, int32_t* kind, double* pos, double* 
     Ctrl c;
     HIPCHK(hipMemcpy(&c, h->A.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
     const long long Np = h->Np;
-    // the one-particle systematic draw of resample(..., NULL, 1): the particle whose cumulative weight passes U * total
+    // the one-particle systematic draw of resample(..., NULL, 1): the particle whose cumulative pilot weight
+    // (pilotWeight(), pc.cpp:256-262) passes U * total
     std::vector<double> w(Np);
-    HIPCHK(hipMemcpy(w.data(), h->A.st[c.cur].w_post, Np * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(w.data(), h->A.st[c.cur].w_pilot, Np * 8, hipMemcpyDeviceToHost));
     double total = 0.0;
     for (double v : w) total += v;
     const double u = philox_uniform_host((unsigned long long)h->A.seed, 0xFFFFFFFFu, 1, (unsigned long long)c.n_resample);

@@ -47,7 +47,12 @@ class _Model(C.Structure):
 
 class _Params(C.Structure):
     _fields_ = [("np", C.c_int64), ("ess_fraction", C.c_double), ("seed", C.c_uint64),
-                ("max_trace_events", C.c_int32), ("flags", C.c_int32)]
+                ("max_trace_events", C.c_int32), ("flags", C.c_int32),
+                ("log_cap", C.c_int64), ("gen_cap", C.c_int64), ("piece_cap", C.c_int64),
+                ("debug", C.c_int32), ("reserved", C.c_int32)]
+
+
+DEBUG_FORCE_LDS, DEBUG_NO_FUSE, DEBUG_NO_COUNT = 1, 2, 4
 
 
 class _Segments(C.Structure):
@@ -242,7 +247,7 @@ KERNEL_CLASSES = ("extend", "decide", "count", "resample")
 
 class ParticleFilter:
     def __init__(self, model, np_particles, ess_fraction=0.5, seed=1, max_trace_events=64, device=0, local_recomb=False,
-                 record_trees=False):
+                 record_trees=False, log_cap=0, gen_cap=0, piece_cap=0, debug=0):
         self.L = load_library()
         m = model
         self._ct = np.ascontiguousarray(m["change_times"], dtype=np.float64)
@@ -261,7 +266,8 @@ class ParticleFilter:
         _attach_structure(self, self._model, m, E, P)
         self.loci_length = float(m["loci_length"])
         self._params = _Params(self.Np, float(ess_fraction), int(seed), self.max_trace_events,
-                               (1 if local_recomb else 0) | (2 if record_trees else 0))
+                               (1 if local_recomb else 0) | (2 if record_trees else 0),
+                               int(log_cap), int(gen_cap), int(piece_cap), int(debug), 0)
         self.h = self.L.pf_create(C.byref(self._model), C.byref(self._params), int(device))
         if not self.h:
             raise PfError(_err(self.L))

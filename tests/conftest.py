@@ -26,3 +26,14 @@ def hiplib():
     if not os.path.exists(pf.LIB_PATH):
         build.build_lib()
     return pf.load_library()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def built_binary():
+    """bin/smcsmc is a build product (git-ignored): every session builds it from the sources it is about to test
+    (make compares time stamps, so this is a no-op when it is current) and fails -- not skips -- when that fails."""
+    from smcsmc_amd import build
+    build.build_all()
+    path = os.path.join(ROOT, "bin", "smcsmc")
+    assert os.path.exists(path), "bin/smcsmc was not produced by smcsmc_amd.build.build_all()"
+    return path

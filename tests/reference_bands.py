@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""Runs the reference's own regression configurations (tests/golden/reference_bands.json, generated from
+test/old/newtests/test_const_pop_size.py and test_two_pops.py) through bin/smcsmc on a GPU and reports, per target, the
+reference's acceptance band, this build's estimate at the reference's seed, and mean / spread / fraction inside the band
+over several seeds.
+
+    python tests/reference_bands.py --seeds 10 --out profiles/round2/reference_bands        (GPU box)
+
+Writes <out>.json (every estimate) and <out>.md (the pass/fail table DESIGN.md section 6 quotes).
+Nothing here reads /root/reference: the bands, flags and data files are committed fixtures.
+"""
+import argparse
+import gzip
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+BIN = os.path.join(ROOT, "bin", "smcsmc")
+
+
+def load_cases():
+    return json.load(open(os.path.join(GOLD, "reference_bands.json")))["cases"]
+
+
+def seg_path(case, tmpdir):
+    """The committed data file of a case; .gz fixtures are unpacked into tmpdir (the binary reads plain text)."""
+    src = os.path.join(GOLD, "seg", case["data"])
+    if not src.endswith(".gz"):
+        return src
+    dst = os.path.join(tmpdir, case["data"][:-3])
+    if not os.path.exists(dst):
+        with gzip.open(src, "rb") as f, open(dst, "wb") as g:
+            shutil.copyfileobj(f, g)
+    return dst
+
+
+def argv_for(case, seed, seg, prefix, extra=()):
+    out = []
+    toks = list(case["binary_argv"])
+    i = 0
+    while i < len(toks):
+        t = toks[i]
+        if t == "-seed":
+            out += ["-seed", str(seed)]
+            i += 2
+            while i < len(toks) and not toks[i].startswith("-"):
+                i += 1
+            continue
+        out.append(seg if t == "@SEG@" else t)
+        i += 1
+    return [BIN] + out + ["-EM", str(case["em_iterations"])] + list(extra) + ["-o", prefix]
+
+
+def read_estimates(path):
+    """{(type, epoch, from, to): value} of the last iteration: Ne for Coal rows, Rate otherwise (test_generic.py:307-365)."""
+    rows = [ln.split() for ln in open(path).read().splitlines()[1:] if ln.strip()]
+    last = max(int(r[0]) for r in rows)
+    est = {}
+    for r in rows:
+        if int(r[0]) != last:
+            continue
+        typ = r[4]
+        key = (typ, int(r[1]), int(r[5]), int(r[6]))
+        est[key] = float(r[10]) if typ == "Coal" else float(r[9])
+    return est
+
+
+def target_key(t):
+    if t["type"] == "Coal":
+        return ("Coal", t["epoch"], t["pop"], -1)
+    if t["type"] == "Migr":
+        return ("Migr", t["epoch"], t["from_pop"], t["to_pop"])
+    return (t["type"], -1, -1, -1)
+
+
+def target_label(t):
+    if t["type"] == "Coal":
+        return "Ne epoch %d pop %d" % (t["epoch"], t["pop"])
+    if t["type"] == "Migr":
+        return "Migr %d->%d epoch %d" % (t["from_pop"], t["to_pop"], t["epoch"])
+    return t["type"]
+
+
+def run_case(case, seed, tmpdir, extra=(), timeout=900):
+    seg = seg_path(case, tmpdir)
+    prefix = os.path.join(tmpdir, "%s_s%d" % (case["name"], seed))
+    r = subprocess.run(argv_for(case, seed, seg, prefix, extra), capture_output=True, text=True, timeout=timeout)
+    if r.returncode != 0:
+        raise RuntimeError("%s seed %d: %s" % (case["name"], seed, r.stderr[-400:]))
+    est = read_estimates(prefix + ".out")
+    for suffix in (".out", ".log", ".recomb.gz"):
+        try:
+            os.unlink(prefix + suffix)
+        except OSError:
+            pass
+    return est
+
+
+def in_band(t, v):
+    return t["min"] <= v <= t["max"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, default=10)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "reference_bands"))
+    ap.add_argument("--extra", default="", help="extra binary flags for every run (bisecting)")
+    args = ap.parse_args()
+    cases = [c for c in load_cases() if not args.only or c["name"] in args.only.split(",")]
+    tmpdir = tempfile.mkdtemp(prefix="refbands_")
+    result = []
+    md = ["| configuration | target | reference band | at the reference's seed | mean over %d seeds | sd | inside band |" % args.seeds,
+          "|---|---|---|---|---|---|---|"]
+    for c in cases:
+        ref_seed = int(c["seed"][0])
+        seeds = [ref_seed] + [s for s in range(1, args.seeds + 2) if s != ref_seed][:args.seeds - 1]
+        ests = []
+        for s in seeds:
+            ests.append(run_case(c, s, tmpdir, args.extra.split()))
+            print("%s seed %d done" % (c["name"], s), flush=True)
+        for t in c["targets"]:
+            k = target_key(t)
+            vals = np.array([e.get(k, np.nan) for e in ests])
+            n_in = int(sum(in_band(t, v) for v in vals))
+            result.append(dict(case=c["name"], target=target_label(t), band=[t["min"], t["max"]], truth=t.get("truth"),
+                               seeds=seeds, values=vals.tolist(), at_reference_seed=float(vals[0]),
+                               mean=float(np.nanmean(vals)), sd=float(np.nanstd(vals)), inside=n_in))
+            md.append("| %s | %s | %.4g – %.4g | %.4g %s | %.4g | %.2g | %d / %d |" % (
+                c["name"], target_label(t), t["min"], t["max"], vals[0], "ok" if in_band(t, vals[0]) else "**out**",
+                np.nanmean(vals), np.nanstd(vals), n_in, len(vals)))
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    json.dump(result, open(args.out + ".json", "w"), indent=1)
+    open(args.out + ".md", "w").write("\n".join(md) + "\n")
+    print("\n".join(md))
+    shutil.rmtree(tmpdir, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -418,17 +418,15 @@ def test_reference_regression_data_set_constant_size(hiplib, tmp_path):
 # ---------------------------------------------------------------- local recombination map (.recomb.gz)
 
 @pytest.mark.parametrize("n,E,Np,force_lds", [(4, 8, 600, False), (2, 4, 300, False), (6, 8, 256, True)])
-def test_local_recombination_map_parity(oracle, hiplib, n, E, Np, force_lds, monkeypatch):
+def test_local_recombination_map_parity(oracle, hiplib, n, E, Np, force_lds):
     """record_local_recomb_events (count.cpp:559-613): the 100-bp differential opportunity and the per-sample / time /
     log-time counts equal the oracle's (sums of the same terms in another order: relative 1e-9 of the column scale)."""
     from smcsmc_amd import ParticleFilter
-    if force_lds:
-        monkeypatch.setenv("SMCSMC_PF_FORCE_LDS", "1")
     model = cases.make_model(n=n, E=E, L=1.0e5)
     segs = cases.make_segments(model, seed=40 + n, max_seg_len=5000)
     o = oracle.Oracle(model, Np, seed=3); o.enable_local_recomb(); o.init_prior(0.0)
     o.run(o.pack_segments(model, segs))
-    g = ParticleFilter(model, Np, seed=3, local_recomb=True)
+    g = ParticleFilter(model, Np, seed=3, local_recomb=True, debug=1 if force_lds else 0)
     g.init_prior(0.0); g.load_segments(segs); g.run(); g.finish()
     assert _bits([o.logl()])[0] == _bits([g.logl()])[0]
     lo, lg = o.local_recomb(model["loci_length"]), g.local_recomb()
@@ -665,20 +663,18 @@ def _replay_tree_events(n, kind, pos, height, desc):
 
 @pytest.mark.parametrize("n,Np,force_lds,bias", [(4, 300, False, False), (6, 200, False, False), (5, 150, True, False), (2, 100, False, False),
                                                  (8, 200, False, True), (7, 120, True, True)])
-def test_tree_dump_of_the_sampled_particle(oracle, hiplib, n, Np, force_lds, bias, monkeypatch):
+def test_tree_dump_of_the_sampled_particle(oracle, hiplib, n, Np, force_lds, bias):
     """-arg (pc.cpp:515-555): replaying the dumped events of the drawn particle's history from the first position on must
     end in that particle's own local tree (node heights and the samples below each node); every recombination is
     followed by its coalescence at the same position, above the cut; the descendants of a coalescence contain those of
     its recombination."""
     from smcsmc_amd import ParticleFilter, outfile
-    if force_lds:
-        monkeypatch.setenv("SMCSMC_PF_FORCE_LDS", "1")
-    monkeypatch.setenv("SMCSMC_PF_LOG_CAP", "8192"); monkeypatch.setenv("SMCSMC_PF_GEN_CAP", "4096")
     model = cases.make_model(n=n, E=8, L=1.5e5)
     segs = cases.make_segments(model, seed=80 + n, max_seg_len=5000)
     if bias:
         model = dict(model, bias_heights=[400.0], bias_strengths=[4.0, 1.0], application_delays=np.full(8, 3000.0))
-    g = ParticleFilter(model, Np, seed=4, max_trace_events=0, record_trees=True)
+    g = ParticleFilter(model, Np, seed=4, max_trace_events=0, record_trees=True, log_cap=8192, gen_cap=4096,
+                       debug=1 if force_lds else 0)
     g.init_prior(segs["start"][0]); g.load_segments(segs); g.run(); g.finish()
     assert g.trace()["resampled"].sum() > 3
     part, kind, pos, hgt, desc = g.sample_tree_events()
@@ -723,9 +719,8 @@ def test_binary_writes_the_tree_dump(hiplib, tmp_path):
     seg = os.path.join(root, "tests", "golden", "seg", "constpopsize_first3000.seg")
     L = 1000000
     core = ("-N0 10000 -t %g -r %g %d -eN 0 1 -eN 0.01 1 -eN 0.25 1 -eN 1 1" % (4e4 * 2.5e-8 * L, 4e4 * 1e-8 * L, L)).split()
-    env = dict(os.environ, SMCSMC_PF_LOG_CAP="16384", SMCSMC_PF_GEN_CAP="8192")
     r = subprocess.run([binary] + core + ["-nsam", "2", "-Np", "200", "-EM", "0", "-tmax", "4", "-lag", "20000", "-seed", "4",
-                                          "-arg", "-seg", seg, "-o", str(tmp_path / "arg")], capture_output=True, text=True, env=env)
+                                          "-arg", "-seg", seg, "-o", str(tmp_path / "arg")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     text = gzip.open(tmp_path / "arg.trees.gz", "rt").read()
     lines = text.splitlines()
@@ -737,14 +732,9 @@ def test_binary_writes_the_tree_dump(hiplib, tmp_path):
                  nsam=2, loci_length=float(L), mutation_rate=m["mutation_rate"], recombination_rate=m["recombination_rate"])
     S = segmod.Segments(seg, 2, L, max_segment_length=int(2.0 / (m["recombination_rate"] * 4 * m["N0"])))
     segs = S.pack(model["lags"])
-    for k, v in (("SMCSMC_PF_LOG_CAP", "16384"), ("SMCSMC_PF_GEN_CAP", "8192")):
-        os.environ[k] = v
-    try:
-        g = ParticleFilter(model, 200, seed=4, max_trace_events=0, local_recomb=True, record_trees=True)
-        g.init_prior(segs["start"][0]); g.load_segments(segs); g.run(); g.finish()
-        _, kind, pos, hgt, desc = g.sample_tree_events()
-    finally:
-        os.environ.pop("SMCSMC_PF_LOG_CAP"); os.environ.pop("SMCSMC_PF_GEN_CAP")
+    g = ParticleFilter(model, 200, seed=4, max_trace_events=0, local_recomb=True, record_trees=True, log_cap=16384, gen_cap=8192)
+    g.init_prior(segs["start"][0]); g.load_segments(segs); g.run(); g.finish()
+    _, kind, pos, hgt, desc = g.sample_tree_events()
     assert outfile.trees_text(kind, pos, hgt, desc, start_position=1.0) == text
 
 
@@ -760,7 +750,7 @@ def test_binary_flag_combinations(hiplib, tmp_path):
     L = 1000000
     core = ("-N0 10000 -t %g -r %g %d -eN 0 1 -eN 0.01 1 -eN 0.25 1 -eN 1 1" % (4e4 * 2.5e-8 * L, 4e4 * 1e-8 * L, L)).split()
     common = ["-nsam", "2", "-seg", seg, "-Np", "300", "-tmax", "4", "-seed", "3"]
-    env = dict(os.environ, SMCSMC_PF_LOG_CAP="32768", SMCSMC_PF_GEN_CAP="16384")
+    env = dict(os.environ)
     runs = {
         "plain": [],
         "apf_bias": ["-apf", "2", "-bias_heights", "400", "-bias_strengths", "3", "1"],
