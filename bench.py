@@ -58,22 +58,7 @@ def build_workload(args, seed):
         seg = simulate.simulate_seg(n, L, mu, rho, ct, ps, seed=seed)
         np.savez(cache, **seg)
     max_seg_len = int(2.0 / (rho * 4 * N0))        # pfparam.cpp:364
-    S = segmod.Segments.__new__(segmod.Segments)
-    S.file_name = "<bench>"; S.nsam = n; S.seqlen = L; S.data_start = 1
-    S.max_segment_length = max_seg_len; S.empty_file = False; S._nfields = None
-    rows = []
-    for s, l, a in zip(seg["start"], seg["length"], seg["alleles"]):
-        s = int(s); l = int(l); end = s + l
-        while True:
-            if l > max_seg_len:
-                l = max_seg_len; st = segmod.SEGMENT_INVARIANT_PARTIAL
-            else:
-                st = segmod.SEGMENT_INVARIANT
-            rows.append((s, l, st, a))
-            s += l; l = end - s
-            if not s < end:
-                break
-    S.rows = rows
+    S = segmod.Segments.from_sites(seg["start"], seg["length"], seg["alleles"], n, L, max_segment_length=max_seg_len)
     return model, S.pack(lags)
 
 

@@ -25,7 +25,7 @@ static void dump_model_json(const PfParam& p) {
     cout << setprecision(17);
     cout << "{\"N0\": " << m.N0 << ", \"nsam\": " << m.nsam << ", \"npop\": " << m.npop << ", \"loci_length\": " << m.loci_length
          << ", \"mutation_rate\": " << m.mutation_rate << ", \"recombination_rate\": " << m.recombination_rate
-         << ", \"vb\": " << (m.vb ? "true" : "false") << ", \"seed\": " << m.seed << ", \"Np\": " << p.N
+         << ", \"vb\": " << (m.vb ? "true" : "false") << ", \"seed\": " << m.seed << ", \"Np\": " << p.particles
          << ", \"change_times\": [";
     for (size_t e = 0; e < m.change_times.size(); ++e) cout << (e ? ", " : "") << m.change_times[e];
     cout << "], \"pop_sizes\": [";
@@ -48,8 +48,8 @@ static void dump_model_json(const PfParam& p) {
     }
     cout << "], \"sample_pops\": [";
     for (size_t k = 0; k < m.sample_pops.size(); ++k) cout << (k ? ", " : "") << m.sample_pops[k];
-    cout << "], \"record_event_in_epoch\": [";
-    for (size_t k = 0; k < p.record_event_in_epoch.size(); ++k) cout << (k ? ", " : "") << p.record_event_in_epoch[k];
+    cout << "], \"record_mask\": [";
+    for (size_t k = 0; k < p.record_mask.size(); ++k) cout << (k ? ", " : "") << p.record_mask[k];
     cout << "], \"guide_positions\": [";
     for (size_t k = 0; k < p.guide_positions.size(); ++k) cout << (k ? ", " : "") << p.guide_positions[k];
     cout << "], \"guide_rates\": [";
@@ -61,7 +61,7 @@ static void dump_model_json(const PfParam& p) {
 
 static void dump_lookahead_json(const PfParam& p) {
     LookaheadArrays la;
-    p.Segfile->pack_lookahead(la);
+    p.segments->pack_lookahead(la);
     const size_t S = la.n_doubletons.size();
     const int n = p.model.nsam, D = la.max_doubletons;
     cout << setprecision(17) << "{\"max_doubletons\": " << D << ", \"rows\": [";
@@ -82,6 +82,28 @@ static void dump_lookahead_json(const PfParam& p) {
         for (int j = 0; j < n; ++j) cout << (j ? ", " : "") << (int)la.split_alleles[i * n + j];
         cout << "], \"split_count\": " << la.split_count[i] << "}";
     }
+    cout << "]}" << endl;
+}
+
+// -dumpsegments: the arrays pf_load_segments would receive, with the constant -lag or the reference's uncalibrated
+// per-epoch default 4 / (rho * top of epoch) (count.cpp:230-247) as lags -- no device needed
+static void dump_segments_json(const PfParam& p) {
+    const HostModel& M = p.model;
+    const size_t E = M.change_times.size();
+    std::vector<double> lags(E, 20000.0);
+    for (size_t e = 0; e < E && E > 1; ++e)
+        lags[e] = p.lag > 0 ? p.lag : 4.0 / (M.recombination_rate * M.change_times[std::min(e + 1, E - 1)]);
+    std::vector<double> start, length;
+    std::vector<int8_t> state, alleles;
+    std::vector<int32_t> limit;
+    p.segments->pack(lags, start, length, state, alleles, limit);
+    cout << setprecision(17) << "{\"nsam\": " << M.nsam << ", \"lags\": [";
+    for (size_t e = 0; e < E; ++e) cout << (e ? ", " : "") << lags[e];
+    auto list = [&](const char* name, auto&& v) {
+        cout << "], \"" << name << "\": [";
+        for (size_t k = 0; k < v.size(); ++k) cout << (k ? ", " : "") << (double)v[k];
+    };
+    list("start", start); list("length", length); list("state", state); list("alleles", alleles); list("max_record_epoch", limit);
     cout << "]}" << endl;
 }
 
@@ -130,15 +152,15 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
     pm.flags = (P.ancestral_aware ? 1 : 0) | (P.dephase ? 2 : 0);
     pm.loci_length = M.loci_length; pm.mutation_rate = M.mutation_rate; pm.recombination_rate = M.recombination_rate;
     pm.change_times = M.change_times.data(); pm.pop_sizes = pop_sizes.data();
-    pm.record_flags = P.record_event_in_epoch.data();
+    pm.record_flags = P.record_mask.data();
 
     // lags: CountModel::init_lags (count.cpp:230-247) then reset_lag with the calibrated survival (261-265)
     std::vector<double> lags(E);
     if (E == 1) lags[0] = 20000;
     else
         for (int e = 0; e < E; ++e) {
-            double top_t = e == E - 1 ? M.change_times[E - 1] : M.change_times[e + 1];
-            lags[e] = P.lag > 0 ? P.lag : 4.0 / (M0.recombination_rate * top_t);   // CountModel keeps its initial model
+            double tmax = e == E - 1 ? M.change_times[E - 1] : M.change_times[e + 1];
+            lags[e] = P.lag > 0 ? P.lag : 4.0 / (M0.recombination_rate * tmax);   // CountModel keeps its initial model
         }
     // calculate_median_survival_distances is always run by the reference (smcsmc.cpp:287); its result feeds the
     // lags (when calibrating) and the application delays of the importance weights (smcsmc.cpp:306-307)
@@ -184,7 +206,7 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
     std::vector<double> start, length;
     std::vector<int8_t> state, alleles;
     std::vector<int32_t> mre;
-    P.Segfile->pack(lags, start, length, state, alleles, mre);
+    P.segments->pack(lags, start, length, state, alleles, mre);
     pf_segments sg = {(int64_t)start.size(), start.data(), length.data(), state.data(), alleles.data(), mre.data()};
 
     // auxiliary particle filter: look-ahead per row + terminal branch length quantiles (smcsmc.cpp:288, 128-166)
@@ -192,8 +214,8 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
     std::vector<double> tbl_lengths;
     double mean_tbl = 0;
     const double tbl_quantiles[7] = {0.001, 0.003, 0.01, 0.03, 0.1, 0.5, 0.95};
-    if (P.auxiliary_particle_filter > 0) {
-        if (P.Segfile->empty_file()) throw Unsupported("-apf without -seg data");
+    if (P.apf_level > 0) {
+        if (P.segments->empty_file()) throw Unsupported("-apf without -seg data");
         cout << "Calculating terminal branch length quantiles..." << endl;
         tbl_lengths.resize((size_t)M.nsam * 7);
         pf_check(pf_terminal_branch_quantiles(&pm, 1, 1000000, tbl_quantiles, 7, tbl_lengths.data(), &mean_tbl, device));
@@ -202,12 +224,12 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
             for (int q = 0; q < 7; ++q) cout << " [" << tbl_quantiles[q] << ":] " << tbl_lengths[(size_t)i * 7 + q];
             cout << endl;
         }
-        P.Segfile->pack_lookahead(la);
+        P.segments->pack_lookahead(la);
     }
 
     pf_params pp;
     memset(&pp, 0, sizeof(pp));
-    pp.np = (int64_t)P.N; pp.ess_fraction = P.ESS_fraction; pp.seed = base_seed(M) + 1000ull * (uint64_t)P.EMcounter;   // same rule as smcsmc_amd/em.py: seed + 1000 * iteration + chunk
+    pp.np = (int64_t)P.particles; pp.ess_fraction = P.ess_fraction; pp.seed = base_seed(M) + 1000ull * (uint64_t)P.em_iteration;   // same rule as smcsmc_amd/em.py: seed + 1000 * iteration + chunk
     pp.max_trace_events = 0;
     pp.flags = 1;          // the local recombination map is always recorded (smcsmc.cpp:376-383)
     if (P.record_trees) {
@@ -218,7 +240,7 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
         auto pow2_at_least = [](double v) { long long c = 16384; while ((double)c < v) c <<= 1; return c; };
         const long long log_cap = pow2_at_least(1.4 * (double)start.size());
         const long long gen_cap = pow2_at_least((double)start.size() + 2.0);
-        const double gib = ((double)P.N * (double)log_cap * (5.0 + M.nsam - 1) * 8.0 + (double)gen_cap * (double)P.N * 20.0) / (1024.0 * 1024.0 * 1024.0);
+        const double gib = ((double)P.particles * (double)log_cap * (5.0 + M.nsam - 1) * 8.0 + (double)gen_cap * (double)P.particles * 20.0) / (1024.0 * 1024.0 * 1024.0);
         clog << " -arg: event log of " << log_cap << " records per particle, " << gen_cap << " generations (" << fixed << setprecision(1)
              << gib << " GiB)" << setprecision(6) << scientific << endl;
         pp.log_cap = log_cap;
@@ -228,10 +250,10 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
     if (!h) throw std::runtime_error(pf_last_error());
     try {
         pf_check(pf_load_segments(h, &sg));
-        if (P.auxiliary_particle_filter > 0) {
+        if (P.apf_level > 0) {
             pf_lookahead pl;
             memset(&pl, 0, sizeof(pl));
-            pl.level = P.auxiliary_particle_filter; pl.max_doubletons = la.max_doubletons; pl.n_quantiles = 7; pl.n = sg.n;
+            pl.level = P.apf_level; pl.max_doubletons = la.max_doubletons; pl.n_quantiles = 7; pl.n = sg.n;
             pl.first_singleton_distance = la.first_singleton_distance.data();
             pl.relative_mutation_rate = la.relative_mutation_rate.data();
             pl.is_singleton_unphased = la.is_singleton_unphased.data();
@@ -260,12 +282,12 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
         const double* tail = &packed[packed.size() - 4];
         clog << "Got to end of sequence; resampled " << (long long)tail[2] << " times" << endl;
         clog << " Inference step completed." << endl;
-        if (P.record_resample_file) {
+        if (P.write_resample) {
             std::vector<double> ess(done);
             std::vector<int32_t> flag(done);
             pf_check(pf_get_trace(h, nullptr, ess.data(), flag.data(), nullptr, done));
             for (int64_t s = 0; s < done; ++s)
-                if (flag[s]) P.append_resample_file(std::min(start[s] + length[s], M.loci_length), ess[s]);
+                if (flag[s]) P.write_resample_row(std::min(start[s] + length[s], M.loci_length), ess[s]);
         }
         // <prefix>.recomb.gz (smcsmc.cpp:376-383): CountModel::dump_local_recomb_logs (count.cpp:616-654)
         {
@@ -288,14 +310,14 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
                 std::string text;
                 text.reserve((size_t)(i1 - i0) * (24 + 12 * (M.nsam + 3)) + 256);
                 char buf[64];
-                if (t == 0 && P.EMcounter == 0) {
+                if (t == 0 && P.em_iteration == 0) {
                     text += "iter\tlocus\tsize\topp_per_nt";
                     for (int sdx = 0; sdx < M.nsam; ++sdx) { snprintf(buf, sizeof buf, "\t%d", sdx + 1); text += buf; }
                     text += "\ttime\tlog_time\n";
                 }
                 for (int64_t idx = i0; idx < i1; ++idx) {
                     // same characters as operator<< with fixed/setprecision(0) and scientific/setprecision(5)
-                    int len = snprintf(buf, sizeof buf, "%zu\t%.0f\t%.0f\t%.5e", P.EMcounter, idx * 100.0 + P.start_position, 100.0,
+                    int len = snprintf(buf, sizeof buf, "%zu\t%.0f\t%.0f\t%.5e", P.em_iteration, idx * 100.0 + P.start_position, 100.0,
                                        cumopp[idx] / 100.0);
                     text.append(buf, (size_t)len);
                     for (int k = 0; k < M.nsam + 2; ++k) {
@@ -321,7 +343,7 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
             for (auto& th : pool) th.join();
             bool ok = true;
             for (int t = 0; t < nthr; ++t) ok = ok && zrc[t] == 0;
-            FILE* fz = ok ? fopen(P.recombination_map_NAME.c_str(), "ab") : nullptr;
+            FILE* fz = ok ? fopen(P.recomb_map_path.c_str(), "ab") : nullptr;
             if (fz) {
                 for (int t = 0; t < nthr; ++t) fwrite(member[t].data(), 1, member[t].size(), fz);
                 fclose(fz);
@@ -351,7 +373,7 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
                     for (int b = 0; (m >> b) != 0; ++b) text += ((m >> b) & 1u) ? '1' : '0';
                 text += '\n';
             }
-            gzFile gz = gzopen(P.tree_NAME.c_str(), "wb");
+            gzFile gz = gzopen(P.trees_path.c_str(), "wb");
             if (gz) { gzwrite(gz, text.data(), (unsigned)text.size()); gzclose(gz); }
         }
         // log_counts (count.cpp:66-158) with the prior pseudo-counts of init_coal_and_recomb (count.cpp:161-193)
@@ -375,7 +397,7 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
                     const size_t k = (size_t)e * NP + a;
                     double opp = co[k] + 1.0, count = cc[k] + 1.0 / (2.0 * M0.pop_sizes[e][a]), weight = cw[k] + 1.0;
                     double pop_size = 1.0 / (2.0 * (count / opp));
-                    if (P.useCap && pop_size >= P.Ne_cap) pop_size = P.Ne_cap;
+                    if (P.cap_sizes && pop_size >= P.size_cap) pop_size = P.size_cap;
                     new_sizes[e][a] = pop_size;
                     clog << " Setting size of population " << a << " @ " << setw(8) << M.change_times[e] << " to " << setw(8)
                          << pop_size << " ( 0.5 * " << opp << " / " << count << "; post-lag ESS " << 1.0 / (weight / opp)
@@ -396,7 +418,7 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
         for (int e = 0; e < E; ++e)
             for (int a = 0; a < NP; ++a) {
                 const size_t k = (size_t)e * NP + a;
-                P.appendToOutFile(P.EMcounter, e, M.change_times[e], epoch_end(e), "Coal", a, -1, co[k] + 1.0,
+                P.write_out_row(P.em_iteration, e, M.change_times[e], epoch_end(e), "Coal", a, -1, co[k] + 1.0,
                                   cc[k] + 1.0 / (2.0 * M0.pop_sizes[e][a]), cw[k] + 1.0);
             }
         // recombination is booked on population 0 only (count.cpp:534-539); the report sums the epochs (84-113)
@@ -406,7 +428,7 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
             rcount += rc[e] + M0.recombination_rate;
             rweight += rw[e] + 1.0;
         }
-        P.appendToOutFile(P.EMcounter, -1, 0.0, 1e+99, "Recomb", -1, -1, ropp, rcount, rweight);
+        P.write_out_row(P.em_iteration, -1, 0.0, 1e+99, "Recomb", -1, -1, ropp, rcount, rweight);
         if (NP > 1) {
             // migration rows with the pseudo-counts of init_migr (count.cpp:196-227)
             const double* mc = &packed[3 * EP + 3 * E]; const double* mo = mc + EP * NP; const double* mw = mo + EP;
@@ -415,14 +437,14 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
                     for (int b = 0; b < NP; ++b)
                         if (a != b) {
                             const size_t k = (size_t)e * NP + a;
-                            P.appendToOutFile(P.EMcounter, e, M.change_times[e], epoch_end(e), "Migr", a, b, mo[k] + 1.0,
+                            P.write_out_row(P.em_iteration, e, M.change_times[e], epoch_end(e), "Migr", a, b, mo[k] + 1.0,
                                               mc[k * NP + b] + M0.mig_rates[e][(size_t)a * NP + b], mw[k] + 1.0);
                         }
         }
         double dopp = tail[0], dcount = tail[1], nres = tail[2], logl = tail[3];
-        P.appendToOutFile(P.EMcounter, -1, 0.0, 1e+99, "Delay", -1, -1, dopp, dcount / (double)P.N, dopp);
-        P.appendToOutFile(P.EMcounter, -1, 0.0, 1e+99, "Resamp", -1, -1, dopp, nres, dopp);
-        P.appendToOutFile(P.EMcounter, -1, 0, 1e+99, "LogL", -1, -1, 1.0, logl, 1.0);   // smcsmc.cpp:391
+        P.write_out_row(P.em_iteration, -1, 0.0, 1e+99, "Delay", -1, -1, dopp, dcount / (double)P.particles, dopp);
+        P.write_out_row(P.em_iteration, -1, 0.0, 1e+99, "Resamp", -1, -1, dopp, nres, dopp);
+        P.write_out_row(P.em_iteration, -1, 0, 1e+99, "LogL", -1, -1, 1.0, logl, 1.0);   // smcsmc.cpp:391
         clog << " Estimated log likelihood: " << logl << endl;
     } catch (...) {
         pf_destroy(h);
@@ -435,18 +457,19 @@ int main(int argc, char* argv[]) {
     try {
         PfParam P;
         P.parse(argc, argv);
-        if (P.version()) { P.printVersion(&std::cout); return EXIT_SUCCESS; }
-        if (P.help()) { P.printHelp(); return EXIT_SUCCESS; }
+        if (P.version()) { P.print_version(&std::cout); return EXIT_SUCCESS; }
+        if (P.help()) { P.print_help(); return EXIT_SUCCESS; }
         if (P.dump_model) { dump_model_json(P); return EXIT_SUCCESS; }
         if (P.dump_lookahead) { dump_lookahead_json(P); return EXIT_SUCCESS; }
-        P.outFileHeader();
+        if (P.dump_segments) { dump_segments_json(P); return EXIT_SUCCESS; }
+        P.write_out_header();
         const HostModel initial_model = P.model;        // what CountModel is constructed from (smcsmc.cpp:77)
-        for (int i = 0; i <= P.EM_steps; i++) {
+        for (int i = 0; i <= P.em_iterations; i++) {
             clog << "EM step " << i << endl;
             pfARG_core(P, initial_model);
             // the model the next E-step runs under (Model::addPopulationSize / addMigrationRate / setRecombinationRate)
             P.model.pop_sizes = P.next_sizes; P.model.mig_rates = P.next_mig; P.model.recombination_rate = P.next_rho;
-            P.EMcounter++;
+            P.em_iteration++;
             clog << "End of EM step " << i << endl;
         }
         return P.log();

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <iomanip>
 #include <iostream>
 #include <map>
@@ -212,94 +213,119 @@ void HostModel::parse(const std::vector<std::string>& tok) {
 
 void HostModel::finalize() {}
 
-// ------------------------------------------------------------------ PfParam (pfparam.cpp:51-180)
+// ------------------------------------------------------------------ driver options
+// The flags the binary itself consumes are one table: name, operand kind, help text, what to do with the operand.
+// Everything that is not in the table belongs to the scrm-style model description and is handed to HostModel::parse
+// (the reference's two-stage scheme, pfparam.cpp:63-169).  Names, defaults, ranges and user-visible strings are the
+// contract; -help is printed from the same table.
+namespace {
+
+// "a" or "a-b" (closed, 0-based)
+EpochRange epoch_range(const std::string& flag, const std::string& text) {
+    const size_t dash = text.find('-', 1);
+    EpochRange r;
+    r.first = convert<int>(flag, text.substr(0, dash));
+    r.last = dash == std::string::npos ? r.first : convert<int>(flag, text.substr(dash + 1));
+    return r;
+}
+
+struct DriverOption {
+    const char* name;
+    const char* operand;     // "INT" / "FLT" / "STR", or "" for a switch
+    const char* group;       // help section; nullptr: not listed
+    const char* help;
+    std::function<void(PfParam&, const std::string&)> apply;
+};
+
+const std::vector<DriverOption>& driver_options() {
+    static const std::vector<DriverOption> table = {
+        {"-Np", "INT", "Options", "Number of particles [ 100 ]",
+         [](PfParam& p, const std::string& v) { p.particles = convert<size_t>("-Np", v); }},
+        {"-nsam", "INT", "Options", "Number of haplotypes [ 2 ]",
+         [](PfParam& p, const std::string& v) { p.nsam = convert<size_t>("-nsam", v); }},
+        {"-seg", "STR", "Options", "Data file in seg format [ Chrom1.seg ]", [](PfParam& p, const std::string& v) { p.seg_path = v; }},
+        {"-o", "STR", "Options", "Prefix for output files", [](PfParam& p, const std::string& v) { p.out_prefix = v; }},
+        {"-EM", "INT", "Options", "EM iterations [ 0 ]",
+         [](PfParam& p, const std::string& v) { p.em_iterations = convert<int>("-EM", v); }},
+        {"-startpos", "INT", "Options", "First nucleotide position to analyze [ 1 ]",
+         [](PfParam& p, const std::string& v) { p.start_position = convert<double>("-startpos", v); if (p.start_position < 1) throw OutOfRange("-startpos", v); }},
+        {"-apf", "INT", "Options", "Use auxiliary particle filter [ 0 ]; 1 singletons, 2 + doubletons, 3 + splits, 4 n-choose-k split factor",
+         [](PfParam& p, const std::string& v) { p.apf_level = convert<int>("-apf", v); if (p.apf_level < 0 || p.apf_level > 4) throw OutOfRange("-apf", v); }},
+        {"-guide", "STR", "Options", "Recombination guide file (locus, size, rate, relative rate per sample)",
+         [](PfParam& p, const std::string& v) { p.guide_path = v; }},
+        {"-arg", "", "Options", "Sample a posterior ARG; write *.trees.gz", [](PfParam& p, const std::string&) { p.record_trees = true; }},
+        {"-log", "", "Options", "Generate *.log file", [](PfParam& p, const std::string&) { p.write_log_file = true; }},
+        {"-v", "", "Options", "Display timestamp and versions", [](PfParam& p, const std::string&) { p.want_version = true; }},
+        {"-version", "", nullptr, "", [](PfParam& p, const std::string&) { p.want_version = true; }},
+        {"-h", "", nullptr, "", [](PfParam& p, const std::string&) { p.want_help = true; }},
+        {"-help", "", nullptr, "", [](PfParam& p, const std::string&) { p.want_help = true; }},
+        {"-dephase", "", "Inference tuning", "Dephase heterozygous sites [ false ]", [](PfParam& p, const std::string&) { p.dephase = true; }},
+        {"-calibrate_lag", "FLT", "Inference tuning", "Lag before extracting events (multiple of survival time) [ 2 ]",
+         [](PfParam& p, const std::string& v) { p.calibrate_lag = true; p.lag_fraction = convert<double>("-calibrate_lag", v); if (p.lag_fraction < 0.0) throw OutOfRange("-calibrate_lag", v); }},
+        {"-lag", "FLT", "Inference tuning", "Constant lag (bp); disables calibration",
+         [](PfParam& p, const std::string& v) { p.lag = convert<double>("-lag", v); p.calibrate_lag = false; }},
+        {"-delay", "FLT", "Inference tuning", "Delay of importance weights (multiple of survival time) [ 0.5 ]",
+         [](PfParam& p, const std::string& v) { p.delay = convert<double>("-delay", v); if (p.delay < 0.0) throw OutOfRange("-delay", v); }},
+        {"-delay_coal", "", "Inference tuning", "Delay by the coalescence height instead of the recombination height",
+         [](PfParam& p, const std::string&) { p.delay_type = 1; }},
+        {"-delay_migr", "", "Inference tuning", "Delay by the first coalescence or migration height",
+         [](PfParam& p, const std::string&) { p.delay_type = 2; }},
+        {"-tmax", "FLT", "Inference tuning", "Maximum tree height, in unit of 4N0 [ 2 ]",
+         [](PfParam& p, const std::string& v) { p.tmax = convert<double>("-tmax", v); }},
+        {"-p", "STR", "Inference tuning", "Pattern of time segments, e.g. 1*3+15*4+1",
+         [](PfParam& p, const std::string& v) { p.pattern = v; }},
+        {"-ESS", "FLT", "Inference tuning", "Fractional ESS threshold for resampling [ 0.5 ]",
+         [](PfParam& p, const std::string& v) { p.ess_fraction = convert<double>("-ESS", v); p.ess_is_default = false; if (p.ess_fraction > 1.0 || p.ess_fraction < 0.0) throw OutOfRange("-ESS", v); }},
+        {"-xr", "INT", "Inference tuning", "Epoch or epoch range to exclude from recombination EM (0-based, closed)",
+         [](PfParam& p, const std::string& v) { p.exclude_recomb.push_back(epoch_range("-xr", v)); }},
+        {"-xc", "INT", "Inference tuning", "Epoch or epoch range (e.g. 0-10) to exclude from coalescent/migration EM",
+         [](PfParam& p, const std::string& v) { p.exclude_coalmigr.push_back(epoch_range("-xc", v)); }},
+        {"-cap", "FLT", "Inference tuning", "Upper bound on effective population sizes in the in-binary M-step",
+         [](PfParam& p, const std::string& v) { p.size_cap = convert<double>("-cap", v); p.cap_sizes = true; }},
+        {"-ancestral_aware", "", "Inference tuning", "Ancestral allele is 0", [](PfParam& p, const std::string&) { p.ancestral_aware = true; }},
+        {"-record_ess", "", "Inference tuning", "Generate *.resample file", [](PfParam& p, const std::string&) { p.write_resample = true; }},
+        // not reference flags: print what the host side made of the input, as JSON, and exit (used by the tests)
+        {"-dumpmodel", "", nullptr, "", [](PfParam& p, const std::string&) { p.dump_model = true; }},
+        {"-dumplookahead", "", nullptr, "", [](PfParam& p, const std::string&) { p.dump_lookahead = true; }},
+        {"-dumpsegments", "", nullptr, "", [](PfParam& p, const std::string&) { p.dump_segments = true; }},
+    };
+    return table;
+}
+
+const DriverOption* find_option(const std::string& name) {
+    static const std::map<std::string, const DriverOption*> index = [] {
+        std::map<std::string, const DriverOption*> m;
+        for (const DriverOption& o : driver_options()) m[o.name] = &o;
+        return m;
+    }();
+    auto it = index.find(name);
+    return it == index.end() ? nullptr : it->second;
+}
+
+}  // namespace
+
 void PfParam::parse(int argc, char* argv[]) {
-    std::vector<std::string> argv_(argv + 1, argv + argc);
-    if (argv_.empty()) { help_ = true; return; }
+    if (argc <= 1) { want_help = true; return; }
     cmdline = argv[0];
-    for (int i = 1; i < argc; ++i) cmdline += std::string(" ") + argv[i];
-    default_num_mut = 1e-8 * 40000 * default_loci_length;   // pfparam.cpp:195-198
-    size_t i = 0;
-    auto next = [&](const string& flag) -> const string& {
-        if (i + 1 >= argv_.size()) throw NotEnoughArg(flag);
-        return argv_[++i];
-    };
-    auto read_range = [&](const string& flag, int& last) -> int {   // pfparam.hpp readRange: "a" or "a-b"
-        const string& v = next(flag);
-        size_t dash = v.find('-', 1);
-        int first;
-        if (dash == string::npos) { first = convert<int>(flag, v); last = first; }
-        else { first = convert<int>(flag, v.substr(0, dash)); last = convert<int>(flag, v.substr(dash + 1)); }
-        return first;
-    };
-    for (; i < argv_.size(); ++i) {
-        const string a = argv_[i];
-        if (a == "-Np") N = convert<size_t>(a, next(a));
-        else if (a == "-nsam") default_nsam = convert<size_t>(a, next(a));
-        else if (a == "-ESS") {
-            const string& v = next(a);
-            ESS_fraction = convert<double>(a, v);
-            ESS_default_bool = false;
-            if (ESS_fraction > 1.0 || ESS_fraction < 0.0) throw OutOfRange("-ESS", v);
-        } else if (a == "-arg") record_trees = true;
-        else if (a == "-EM") EM_steps = convert<int>(a, next(a));
-        else if (a == "-xr" || a == "-xc") {
-            int last_epoch;
-            int first_epoch = read_range(a, last_epoch);
-            last_epoch++;
-            for (int e = 0; e < last_epoch; e++) {
-                if ((int)record_event_in_epoch.size() <= e)
-                    record_event_in_epoch.push_back(RECORD_COALMIGR_EVENT | RECORD_RECOMB_EVENT);
-                if (e >= first_epoch) {
-                    if (a == "-xc") record_event_in_epoch[e] &= ~RECORD_COALMIGR_EVENT;
-                    else record_event_in_epoch[e] &= ~RECORD_RECOMB_EVENT;
-                }
-            }
-        } else if (a == "-cap") { Ne_cap = convert<double>(a, next(a)); useCap = true; }
-        else if (a == "-tmax") top_t = convert<double>(a, next(a));
-        else if (a == "-p") pattern = next(a);
-        else if (a == "-seg") input_SegmentDataFileName = next(a);
-        else if (a == "-guide") input_RecombinationBiasFileName = next(a);
-        else if (a == "-startpos") {
-            const string& v = next(a);
-            start_position = convert<double>(a, v);
-            if (start_position < 1) throw OutOfRange("-startpos", v);
-        } else if (a == "-lag") { lag = convert<double>(a, next(a)); calibrate_lag = false; }
-        else if (a == "-calibrate_lag") {
-            const string& v = next(a);
-            calibrate_lag = true;
-            lag_fraction = convert<double>(a, v);
-            if (lag_fraction < 0.0) throw OutOfRange("-calibrate_lag", v);
-        } else if (a == "-delay") {
-            const string& v = next(a);
-            delay = convert<double>(a, v);
-            if (delay < 0.0) throw OutOfRange("-delay", v);
-        } else if (a == "-delay_coal") delay_type = 1;      // RESAMPLE_DELAY_COAL
-        else if (a == "-delay_migr") delay_type = 2;       // RESAMPLE_DELAY_COALMIGR
-        else if (a == "-ancestral_aware") ancestral_aware = true;
-        else if (a == "-dephase") dephase = true;
-        else if (a == "-apf") {
-            const string& v = next(a);
-            auxiliary_particle_filter = convert<int>(a, v);
-            if (auxiliary_particle_filter < 0 || auxiliary_particle_filter > 4) throw OutOfRange("-apf", v);
-        } else if (a == "-o") out_NAME_prefix = next(a);
-        else if (a == "-log") log_bool = true;
-        else if (a == "-record_ess") record_resample_file = true;
-        else if (a == "-dumpmodel") dump_model = true;      // not a reference flag: prints the parsed tables as JSON
-        else if (a == "-dumplookahead") dump_lookahead = true;   // not a reference flag: prints set_lookahead per row as JSON
-        else if (a == "-h" || a == "-help") help_ = true;
-        else if (a == "-v" || a == "-version") version_ = true;
-        else { scrm_tokens.push_back(a); scrm_input += a + " "; }
+    for (int k = 1; k < argc; ++k) cmdline += std::string(" ") + argv[k];
+    nodata_theta = 1e-8 * 40000 * 2e7;          // no -seg: expected mutations of the reference's default locus (pfparam.cpp:195-198)
+    for (int k = 1; k < argc; ++k) {
+        const std::string token = argv[k];
+        const DriverOption* opt = find_option(token);
+        if (!opt) { model_tokens.push_back(token); continue; }      // part of the model description
+        if (opt->operand[0] == '\0') { opt->apply(*this, ""); continue; }
+        if (k + 1 >= argc) throw NotEnoughArg(token);
+        opt->apply(*this, argv[++k]);
     }
-    if (help_ || version_) return;
+    if (want_help || want_version) return;
     finalize();
     clog << "Command line:-" << endl << cmdline << endl;
 }
 
-// RecombinationBias::parse_recomb_bias_file and operator>>(RecombBiasSegment) (pfparam.hpp:124-198): tab-separated
+// RecombinationBias::read_guide_file and operator>>(RecombBiasSegment) (pfparam.hpp:124-198): tab-separated
 // `locus size recomb_rate 1 .. n`, 0-based, no gaps, plain or gzipped; the records that start inside the locus are
 // the ones the model takes (set_model_rates, pfparam.hpp:202-212)
-void PfParam::parse_recomb_bias_file(const std::string& filename) {
+void PfParam::read_guide_file(const std::string& filename) {
     gzFile in = gzopen(filename.c_str(), "rb");          // reads plain text as well
     if (!in) {
         cout << "Problem opening file " << filename << endl;
@@ -339,9 +365,9 @@ void PfParam::parse_recomb_bias_file(const std::string& filename) {
         } catch (...) {
             throw InvalidInput("Problem reading or parsing recombination guide file");
         }
-        if (leaf.size() != default_nsam) {
+        if (leaf.size() != nsam) {
             cerr << "Problem on record at position " << locus << " with " << leaf.size() << " leaf columns; expected "
-                 << default_nsam << endl;
+                 << nsam << endl;
             throw InvalidInput("Did not find expected number of leaf columns");
         }
         if (locus != end) {
@@ -362,7 +388,7 @@ void PfParam::parse_recomb_bias_file(const std::string& filename) {
 // a bare number = one group of that many.  The n atomic boundaries are t_i = 0.1 exp(i/(n-1) log(1 + 10 tmax)) - 0.1
 // (i = 0..n-1, so t_0 = 0 and t_{n-1} = tmax); every group starts an epoch, written as "-eN <t/2> 1" with the six
 // decimals of std::to_string.  Fewer than two atomic intervals: no epochs.
-std::vector<std::string> expand_pattern(const std::string& pattern, double top_t) {
+std::vector<std::string> expand_pattern(const std::string& pattern, double tmax) {
     const char* expr = pattern.c_str();
     auto number = [&]() -> size_t {
         if (!isdigit((unsigned char)*expr)) throw PatternDigitsExpected(std::string(expr));
@@ -390,7 +416,7 @@ std::vector<std::string> expand_pattern(const std::string& pattern, double top_t
     if (num_seg < 2) return out;
     std::vector<double> t_i(num_seg);
     for (size_t i = 0; i < num_seg; ++i)
-        t_i[i] = 0.1 * exp((double)i / (double)(num_seg - 1) * log(1 + 10 * top_t)) - 0.1;
+        t_i[i] = 0.1 * exp((double)i / (double)(num_seg - 1) * log(1 + 10 * tmax)) - 0.1;
     size_t index = 0;
     for (size_t g = 0; g < groups.size(); ++g)
         for (size_t i = 0; i < groups[g]; ++i) {
@@ -404,45 +430,50 @@ std::vector<std::string> expand_pattern(const std::string& pattern, double top_t
 
 // pfparam.cpp:321-380
 void PfParam::finalize() {
-    ESSthreshold = N * ESS_fraction;
-    outFileName = out_NAME_prefix + ".out";
-    log_NAME = out_NAME_prefix + ".log";
-    recombination_map_NAME = out_NAME_prefix + ".recomb.gz";
-    tree_NAME = out_NAME_prefix + ".trees.gz";
-    resample_NAME = out_NAME_prefix + ".resample";
-    if (!input_RecombinationBiasFileName.empty() && auxiliary_particle_filter > 0)
+    out_path = out_prefix + ".out";
+    log_path = out_prefix + ".log";
+    recomb_map_path = out_prefix + ".recomb.gz";
+    trees_path = out_prefix + ".trees.gz";
+    resample_path = out_prefix + ".resample";
+    if (!guide_path.empty() && apf_level > 0)
         throw std::invalid_argument("Recombination guiding and auxiliary particle filters cannot currently be used together");
-    if (!dump_model && !dump_lookahead) {
-        remove(outFileName.c_str());
-        remove(log_NAME.c_str());
-        remove(recombination_map_NAME.c_str());
-        if (record_resample_file) remove(resample_NAME.c_str());
+    if (!dump_model && !dump_lookahead && !dump_segments) {
+        remove(out_path.c_str());
+        remove(log_path.c_str());
+        remove(recomb_map_path.c_str());
+        if (write_resample) remove(resample_path.c_str());
     }
-    if (record_trees && !dump_model && !dump_lookahead) remove(tree_NAME.c_str());
+    if (record_trees && !dump_model && !dump_lookahead && !dump_segments) remove(trees_path.c_str());
     if (!pattern.empty()) {
         // pfparam.cpp:292-295: the epochs of the pattern are appended to the scrm arguments
-        for (const std::string& tok : expand_pattern(pattern, top_t)) scrm_tokens.push_back(tok);
+        for (const std::string& tok : expand_pattern(pattern, tmax)) model_tokens.push_back(tok);
     }
-    model.nsam = (int)default_nsam;
-    model.parse(scrm_tokens);
-    if (!input_RecombinationBiasFileName.empty()) {
-        parse_recomb_bias_file(input_RecombinationBiasFileName);
+    model.nsam = (int)nsam;
+    model.parse(model_tokens);
+    if (!guide_path.empty()) {
+        read_guide_file(guide_path);
     }
-    default_loci_length = model.loci_length;
-    if (model.change_times.back() >= top_t * 40000)
+    if (model.change_times.back() >= tmax * 40000)
         throw std::invalid_argument("Problem: -tmax must be larger than bottom of final epoch");
     if (!model.bias_heights.empty() || !model.bias_strengths.empty()) {
         if (model.bias_strengths.size() != model.bias_heights.size() + 1)
             throw std::invalid_argument("-bias_strengths should have one more value than -bias_heights");
         if (model.bias_heights.size() > 8) throw Unsupported("more than 8 bias heights");
     }
-    while (record_event_in_epoch.size() < model.change_times.size())
-        record_event_in_epoch.push_back(RECORD_COALMIGR_EVENT | RECORD_RECOMB_EVENT);
-    if (record_event_in_epoch.size() > model.change_times.size())
-        throw OutOfEpochRange(to_string(record_event_in_epoch.size() - 1), to_string(model.change_times.size() - 1));
-    int max_seg_len = (int)(max_segment_length_factor / (model.recombination_rate * 4 * model.N0));
+    // which events are recorded per epoch: everything, minus the -xr / -xc ranges
+    const int E = (int)model.change_times.size();
+    record_mask.assign((size_t)E, RECORD_COALMIGR | RECORD_RECOMB);
+    auto exclude = [&](const std::vector<EpochRange>& ranges, int bit) {
+        for (const EpochRange& r : ranges) {
+            if (r.last >= E) throw OutOfEpochRange(to_string(r.last), to_string(E - 1));
+            for (int e = std::max(0, r.first); e <= r.last; ++e) record_mask[(size_t)e] &= ~bit;
+        }
+    };
+    exclude(exclude_recomb, RECORD_RECOMB);
+    exclude(exclude_coalmigr, RECORD_COALMIGR);
+    int max_seg_len = (int)(row_cap_factor / (model.recombination_rate * 4 * model.N0));
     if (!dump_model)
-        Segfile = new Segment(input_SegmentDataFileName, default_nsam, model.loci_length, default_num_mut,
+        segments = new Segment(seg_path, nsam, model.loci_length, nodata_theta,
                               (long long)start_position, max_seg_len);
 }
 
@@ -456,17 +487,17 @@ std::string format_double(double d, double scientific_bound, int precision) {   
     return o.str();
 }
 
-void PfParam::outFileHeader() {   // pfparam.cpp:459-479
-    ofstream f(outFileName.c_str(), ios::binary);
+void PfParam::write_out_header() {   // pfparam.cpp:459-479
+    ofstream f(out_path.c_str(), ios::binary);
     const int f1 = 6, f2 = 14;
     f << setw(f1) << "Iter" << " " << setw(f1) << "Epoch" << " " << setw(f2) << "Start" << " " << setw(f2) << "End" << " "
       << setw(f1) << "Type" << " " << setw(f1) << "From" << " " << setw(f1) << "To" << " " << setw(f2) << "Opp" << " "
       << setw(f2) << "Count" << " " << setw(f2) << "Rate" << " " << setw(f2) << "Ne" << " " << setw(f2) << "ESS" << endl;
 }
 
-void PfParam::appendToOutFile(size_t EMstep, int epoch, double epochBegin, double epochEnd, string eventType, int from_pop,
+void PfParam::write_out_row(size_t EMstep, int epoch, double epochBegin, double epochEnd, string eventType, int from_pop,
                               int to_pop, double opportunity, double count, double weight) {   // pfparam.cpp:500-527
-    ofstream f(outFileName.c_str(), ios::out | ios::app | ios::binary);
+    ofstream f(out_path.c_str(), ios::out | ios::app | ios::binary);
     const int f1 = 6;
     f << setw(f1) << EMstep << " " << setw(f1) << epoch << " " << format_double(epochBegin) << " " << format_double(epochEnd) << " "
       << setw(f1) << eventType << " " << setw(f1) << from_pop << " " << setw(f1) << to_pop << " " << format_double(opportunity)
@@ -475,58 +506,45 @@ void PfParam::appendToOutFile(size_t EMstep, int epoch, double epochBegin, doubl
       << format_double(1.0 / (weight / opportunity + 1e-10), 1.0, 3) << endl;
 }
 
-void PfParam::append_resample_file(double position, double ESS) const {   // pfparam.cpp:530-538
-    if (!record_resample_file) return;
-    ofstream f(resample_NAME.c_str(), ios::out | ios::app | ios::binary);
+void PfParam::write_resample_row(double position, double ESS) const {   // pfparam.cpp:530-538
+    if (!write_resample) return;
+    ofstream f(resample_path.c_str(), ios::out | ios::app | ios::binary);
     f << (int)position << "\t" << ESS << endl;
 }
 
-void PfParam::printVersion(std::ostream* o) {   // pfparam.cpp:588-592
+void PfParam::print_version(std::ostream* o) {   // pfparam.cpp:588-592
     (*o) << "Program was compiled on: " << __DATE__ << endl;
     (*o) << "smcsmc version: " << SMCSMC_VERSION << endl;
     (*o) << "scrm version:   " << "none(hip-native-smc-prime)" << endl;
 }
 
-void PfParam::printHelp() {   // pfparam.cpp:541-585
+void PfParam::print_help() {
     cout << "smcsmc (MI355X build) -- particle filter for demographic inference -- Version " << SMCSMC_VERSION << endl;
-    cout << "Options:" << endl;
-    auto opt = [](const char* f, const char* t, const string& d) {
-        cout << setw(15) << f << setw(8) << t << "  --  " << d << endl;
-    };
-    opt("-Np", "INT", "Number of particles [ 100 ]");
-    opt("-seg", "STR", "Data file in seg format [ Chrom1.seg ]");
-    opt("-o", "STR", "Prefix for output files");
-    opt("-EM", "INT", "EM iterations [ 0 ]");
-    opt("-startpos", "INT", "First nucleotide position to analyze [ 1 ]");
-    opt("-apf", "INT", "Use auxiliary particle filter [ 0 ]; 1 singletons, 2 + doubletons, 3 + splits, 4 n-choose-k split factor");
-    opt("-log", " ", "Generate *.log file");
-    opt("-v", " ", "Display timestamp and versions");
-    cout << endl << "Inference tuning:" << endl;
-    opt("-dephase", " ", "Dephase heterozygous sites [ false ]");
-    opt("-calibrate_lag", "FLT", "Lag before extracting events (multiple of survival time) [ 2 ]");
-    opt("-lag", "FLT", "Constant lag (bp); disables calibration");
-    opt("-tmax", "FLT", "Maximum tree height, in unit of 4N0 [ 2 ]");
-    opt("-ESS", "FLT", "Fractional ESS threshold for resampling [ 0.5 ]");
-    opt("-xr", "INT", "Epoch or epoch range to exclude from recombination EM (0-based, closed)");
-    opt("-xc", "INT", "Epoch or epoch range (e.g. 0-10) to exclude from coalescent/migration EM");
-    opt("-ancestral_aware", " ", "Ancestral allele is 0");
-    opt("-record_ess", " ", "Generate *.resample file");
-    cout << endl << "Model (scrm-style): -N0 -t -r -I -eN -en -eM -ema -ej -seed -l 0 -vb" << endl;
+    const char* section = nullptr;
+    for (const DriverOption& o : driver_options()) {
+        if (!o.group) continue;
+        if (!section || strcmp(section, o.group) != 0) {
+            cout << (section ? "\n" : "") << o.group << ":" << endl;
+            section = o.group;
+        }
+        cout << setw(15) << o.name << setw(8) << (o.operand[0] ? o.operand : " ") << "  --  " << o.help << endl;
+    }
+    cout << endl << "Model (scrm-style): -N0 -t -r -I -eN -en -eM -em -ema -ej -seed -l 0 -vb -bias_heights -bias_strengths" << endl;
 }
 
-void PfParam::writeLog(ostream* w) {   // pfparam.cpp:403-456
+void PfParam::write_log_text(ostream* w) {   // pfparam.cpp:403-456
     (*w) << "###########################\n";
     (*w) << "#        smcsmc log       #\n";
     (*w) << "###########################\n";
-    printVersion(w);
+    print_version(w);
     (*w) << "smcsmc parameters: \n";
-    (*w) << "Segment Data file: " << (input_SegmentDataFileName.empty() ? "empty" : input_SegmentDataFileName.c_str()) << "\n";
-    (*w) << "Recombination bias file: " << (input_RecombinationBiasFileName.empty() ? "None" : input_RecombinationBiasFileName.c_str()) << "\n";
-    (*w) << setw(15) << " EM steps =" << setw(10) << EM_steps << "\n";
+    (*w) << "Segment Data file: " << (seg_path.empty() ? "empty" : seg_path.c_str()) << "\n";
+    (*w) << "Recombination bias file: " << (guide_path.empty() ? "None" : guide_path.c_str()) << "\n";
+    (*w) << setw(15) << " EM steps =" << setw(10) << em_iterations << "\n";
     if (lag > 0) (*w) << setw(15) << "Constant lag =" << setw(10) << lag << "\n";
-    (*w) << setw(15) << "N =" << setw(10) << N << "\n";
-    (*w) << setw(15) << "ESS =" << setw(10) << ESS_fraction;
-    if (ESS_default_bool) (*w) << " (by default)";
+    (*w) << setw(15) << "N =" << setw(10) << particles << "\n";
+    (*w) << setw(15) << "ESS =" << setw(10) << ess_fraction;
+    if (ess_is_default) (*w) << " (by default)";
     (*w) << "\n";
     (*w) << "scrm model parameters: \n";
     (*w) << setw(17) << "Extract window =" << setw(10) << model.window_length_seq << "\n";
@@ -540,14 +558,14 @@ void PfParam::writeLog(ostream* w) {   // pfparam.cpp:403-456
         for (int p = 0; p < model.npop; p++) (*w) << " | " << setw(10) << model.pop_sizes[e][p];
         (*w) << "\n";
     }
-    (*w) << "Out file is saved in file: " << outFileName << "\n";
+    (*w) << "Out file is saved in file: " << out_path << "\n";
 }
 
 int PfParam::log() {   // pfparam.cpp:392-400
-    if (log_bool) {
-        ofstream f(log_NAME.c_str(), ios::out | ios::app | ios::binary);
-        writeLog(&f);
+    if (write_log_file) {
+        ofstream f(log_path.c_str(), ios::out | ios::app | ios::binary);
+        write_log_text(&f);
     }
-    writeLog(&std::cout);
+    write_log_text(&std::cout);
     return 0;
 }

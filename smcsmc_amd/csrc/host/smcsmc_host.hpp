@@ -88,7 +88,7 @@ struct Unsupported : InvalidInput {
     explicit Unsupported(std::string s) : InvalidInput(s) { throwMsg = "Not supported by this build: " + s; }
 };
 
-std::vector<std::string> expand_pattern(const std::string& pattern, double top_t);
+std::vector<std::string> expand_pattern(const std::string& pattern, double tmax);
 
 // ---- the model tables handed to the device (what scrm's Model holds after Param::parse) ----
 struct HostModel {
@@ -159,62 +159,67 @@ class Segment {   // the .seg input (counterpart of segdata.hpp:86-177)
 
 int max_epoch_to_update(const std::vector<double>& lags, double distance_to_mutation);   // smcsmc.cpp:266-275
 
-class PfParam {   // pfparam.hpp:225-446
-  public:
-    static const int RECORD_RECOMB_EVENT = 1;
-    static const int RECORD_COALMIGR_EVENT = 2;
-    void parse(int argc, char* argv[]);
-    bool help() const { return help_; }
-    bool version() const { return version_; }
-    void printHelp();
-    void printVersion(std::ostream* out);
-    void outFileHeader();
-    void appendToOutFile(size_t EMstep, int epoch, double epochBegin, double epochEnd, std::string eventType, int from_pop,
-                         int to_pop, double opportunity, double count, double weight);
-    void append_resample_file(double position, double ESS) const;
-    int log();
-    void writeLog(std::ostream* out);
+struct EpochRange { int first = 0, last = 0; };     // closed, 0-based (-xr / -xc)
 
-    size_t N = 100;
-    int EM_steps = 0;
-    double ESS_fraction = 0.5;
-    bool ESS_default_bool = true;
-    double ESSthreshold = 50;
+// Options of the driver, the parsed model and the output files of one run (the role of the reference's PfParam,
+// pfparam.hpp:225-446).  Flags are applied from one table (pfparam.cpp: driver_options()).
+class PfParam {
+  public:
+    static const int RECORD_RECOMB = 1;        // bits of record_mask (pfparam.hpp:279-281)
+    static const int RECORD_COALMIGR = 2;
+    void parse(int argc, char* argv[]);
+    bool help() const { return want_help; }
+    bool version() const { return want_version; }
+    void print_help();
+    void print_version(std::ostream* out);
+    void write_out_header();
+    void write_out_row(size_t iteration, int epoch, double epoch_begin, double epoch_end, std::string event_type, int from_pop,
+                       int to_pop, double opportunity, double count, double weight);
+    void write_resample_row(double position, double ess) const;
+    int log();
+    void write_log_text(std::ostream* out);
+    void read_guide_file(const std::string& filename);
+
+    // ---- options (defaults are the reference's, pfparam.cpp:193-255)
+    size_t particles = 100;
+    int em_iterations = 0;
+    double ess_fraction = 0.5;
+    bool ess_is_default = true;
     double lag = 0;
     bool calibrate_lag = true;
     double lag_fraction = 2.0;
     double delay = 0.5;
-    int delay_type = 0;          // ResampleDelayType: 0 recombination (default), 1 coalescence, 2 coal/migr
+    int delay_type = 0;          // 0 recombination height (default), 1 coalescence, 2 coalescence or migration
     bool ancestral_aware = false, dephase = false;
-    int auxiliary_particle_filter = 0;
+    int apf_level = 0;
     double start_position = 1;
-    double top_t = 2;
-    bool useCap = false;
-    double Ne_cap = 200000;
-    bool log_bool = true, record_resample_file = false, record_trees = false, dump_model = false, dump_lookahead = false;
-    size_t default_nsam = 2;
-    double default_loci_length = 2e7;
-    double default_num_mut = 0;
-    double max_segment_length_factor = 2.0;
-    std::string out_NAME_prefix = "smcsmc", input_SegmentDataFileName, input_RecombinationBiasFileName, pattern;
-    std::string outFileName, log_NAME, recombination_map_NAME, resample_NAME, tree_NAME;
-    std::vector<int> record_event_in_epoch;
-    std::vector<std::string> scrm_tokens;
-    std::string scrm_input;
+    double tmax = 2;
+    bool cap_sizes = false;
+    double size_cap = 200000;
+    bool write_log_file = true, write_resample = false, record_trees = false;
+    bool dump_model = false, dump_lookahead = false, dump_segments = false;
+    bool want_help = false, want_version = false;
+    size_t nsam = 2;
+    double nodata_theta = 0;
+    double row_cap_factor = 2.0;     // rows longer than this many expected recombination distances are cut
+    std::string out_prefix = "smcsmc", seg_path, guide_path, pattern;
+    std::vector<EpochRange> exclude_recomb, exclude_coalmigr;
+    // ---- derived
+    std::string out_path, log_path, recomb_map_path, resample_path, trees_path;
+    std::vector<int> record_mask;    // per epoch
+    std::vector<std::string> model_tokens;
     HostModel model;
-    Segment* Segfile = nullptr;
-    size_t EMcounter = 0;
+    Segment* segments = nullptr;
+    size_t em_iteration = 0;
     // result of the M-step of the last E-step (CountModel::reset_model_parameters)
     std::vector<std::vector<double>> next_sizes, next_mig;
     double next_rho = 0;
     std::string cmdline;
     // recombination guide (RecombinationBias, pfparam.hpp:152-223): segment starts, sampling rates, relative leaf rates
     std::vector<double> guide_positions, guide_rates, guide_leaf_rates;
-    void parse_recomb_bias_file(const std::string& filename);
 
   private:
     void finalize();
-    bool help_ = false, version_ = false;
 };
 
 std::string format_double(double d, double scientific_bound = 0.1, int precision = 2);   // pfparam.cpp:482-497

@@ -7,14 +7,13 @@ trip of the sufficient statistics (the reduction is the ordered sum of smcsmc_am
 torch.distributed is initialised).
 
   PopulationModel          the fields of populationmodels.Population the path needs, front-end units
-    .core_command_line()   populationmodels.py:300-437 (argv of the next iteration's E-step)
+    .core_command_line()   argv of the next iteration's E-step (what populationmodels.py:300-437 builds)
     .device_model()        model tables for ParticleFilter (generations, per generation rates)
   counts_to_data()         .out rows as the front-end's parse_outfile reads them (model.py:865-911)
   m_step()                 Smcsmc.m_step, model.py:989-1048 (plain and variational-Bayes pseudo-counts)
   run_em()                 Smcsmc.do_iteration for all iterations, chunks sharded over ranks
 """
 import copy
-import itertools
 
 import numpy as np
 
@@ -46,61 +45,59 @@ class PopulationModel:
         self.migration_event_counts = [[[1e10] * P for _ in range(P)] for _ in range(E)]
         assert len(self.population_sizes) == E and len(self.migration_rates) == E and self.change_points[0] == 0.0
 
-    # populationmodels.py:272-298 (samples all taken at time 0)
-    def _sample_options(self):
+    # ---- the scrm-style command line of an E-step.  The token sequence and the number formatting are contract (the
+    # binary parses them; the reference builds the same string in populationmodels.py:272-437 and
+    # tests/golden/cmdlines.json holds its output); it is assembled here from per-epoch directives.
+    def _sample_tokens(self):
         if self.num_populations == 1:
-            return ""
-        sizes = [sum(1 for q in self.sample_populations if q == pop) for pop in range(1, self.num_populations + 1)]
-        return "-I {} {}".format(self.num_populations, " ".join(map(str, sizes)))
+            return []
+        per_pop = np.bincount(np.asarray(self.sample_populations, int), minlength=self.num_populations + 1)[1:]
+        return ["-I", self.num_populations] + per_pop.tolist()
 
-    # populationmodels.py:301-404
-    def _popsize_migration_options(self, vb):
+    def _size_tokens(self, epoch, vb):
+        """-eN t x when all populations share a size, else one -en t pop x per population; -vb appends the event count."""
+        when = self.change_points[epoch]
+        sizes = self.population_sizes[epoch]
+        counts = self.population_event_counts[epoch]
+        if all(x == sizes[0] for x in sizes):
+            return ["-eN", when, sizes[0]] + ([counts[0]] if vb else [])
+        out = []
+        for k, x in enumerate(sizes):
+            out += ["-en", when, k + 1, x] + ([counts[k]] if vb else [])
+        return out
+
+    def _migration_tokens(self, epoch, vb):
+        """-eM t M (M = (P-1) m) when every off-diagonal rate is m, else the full matrix with -ema."""
         P = self.num_populations
-        expression = []
-        if vb:
-            expression.append("-vb")
-        for i, time in enumerate(self.change_points):
-            popsizes = self.population_sizes[i]
-            if len(set(popsizes)) == 1:
+        if P == 1:
+            return []
+        when = self.change_points[epoch]
+        rates = self.migration_rates[epoch]
+        counts = self.migration_event_counts[epoch]
+        off_diagonal = [rates[a][b] for a in range(P) for b in range(P) if a != b]
+        if all(m == off_diagonal[0] for m in off_diagonal):
+            # the reference's total includes the diagonal counts
+            return ["-eM", when, off_diagonal[0] * (P - 1)] + ([sum(sum(row) for row in counts)] if vb else [])
+        out = ["-ema", when]
+        for a in range(P):
+            for b in range(P):
+                out.append(rates[a][b])
                 if vb:
-                    expression.append("-eN {} {} {}".format(time, popsizes[0], self.population_event_counts[i][0]))
-                else:
-                    expression.append("-eN {} {}".format(time, popsizes[0]))
-            else:
-                for idx, popsize in enumerate(popsizes):
-                    if vb:
-                        expression.append("-en {} {} {} {}".format(time, idx + 1, popsize, self.population_event_counts[i][idx]))
-                    else:
-                        expression.append("-en {} {} {}".format(time, idx + 1, popsize))
-            mm = self.migration_rates[i]
-            all_rates = set(mm[j][k] for j, k in itertools.product(range(P), range(P)) if j != k)
-            if len(all_rates) == 1:
-                rate = all_rates.pop()
-                total_rate = rate * (P - 1)
-                total_count = sum(self.migration_event_counts[i][j][k] for j, k in itertools.product(range(P), range(P)))
-                if vb:
-                    expression.append("-eM {} {} {}".format(time, total_rate, total_count))
-                else:
-                    expression.append("-eM {} {}".format(time, total_rate))
-            elif len(all_rates) > 1:
-                expression.append("-ema {}".format(time))
-                for j in range(P):
-                    for k in range(P):
-                        if vb:
-                            expression.append("{} {}".format(mm[j][k], self.migration_event_counts[i][j][k]))
-                        else:
-                            expression.append("{}".format(mm[j][k]))
-            if self.migration_commands[i] is not None:
-                expression.append(self.migration_commands[i])
-        return " ".join(expression)
+                    out.append(counts[a][b])
+        return out
 
-    # populationmodels.py:406-437
     def core_command_line(self, vb=False):
-        mutations = 4 * self.N0 * self.mutation_rate * self.sequence_length
-        recombinations = 4 * self.N0 * self.recombination_rate * self.sequence_length
-        return "-N0 {N0} -t {muts} -r {recs} {seqlen} {sample} {popmigr}".format(
-            N0=self.N0, muts=mutations, recs=recombinations, seqlen=self.sequence_length,
-            sample=self._sample_options(), popmigr=self._popsize_migration_options(vb))
+        scale = 4 * self.N0
+        tokens = ["-N0", self.N0, "-t", scale * self.mutation_rate * self.sequence_length,
+                  "-r", scale * self.recombination_rate * self.sequence_length, self.sequence_length]
+        # the reference's template leaves the sample field empty for one population (two spaces in a row)
+        head = " ".join(str(t) for t in tokens) + " " + " ".join(str(t) for t in self._sample_tokens()) + " "
+        body = ["-vb"] if vb else []
+        for epoch in range(len(self.change_points)):
+            body += self._size_tokens(epoch, vb) + self._migration_tokens(epoch, vb)
+            if self.migration_commands[epoch] is not None:
+                body.append(self.migration_commands[epoch])
+        return head + " ".join(str(t) for t in body)
 
     def device_model(self, lags=None, vb=False, **extra):
         """Model tables for ParticleFilter: generations and per-generation rates, -ej commands as joins."""
@@ -179,31 +176,42 @@ def add_data(total, data):
     return total
 
 
+def _posterior_mean_rate(count, opportunity, prior):
+    """Rate estimate of one event class from summed statistics: count / opportunity, with the Gamma(shape, rate) prior
+    pseudo-counts of the variational-Bayes update folded in (model.py:997-1001: the shape adds to both).  Returns the
+    rate and the count it was computed from."""
+    rate_term, shape_term = prior
+    count = count + shape_term
+    return count / (opportunity + rate_term + shape_term), count
+
+
 def m_step(pop, data, vb=False, vb_dirichlet=None, maxNE=1e99, infer_recomb=True):
-    """Smcsmc.m_step (model.py:989-1048): updates `pop` in place from the summed statistics."""
-    vb_dirichlet = vb_dirichlet or {"ne": [1.0, 1.0], "migr": [1.0, 1.0]}
-    E, P = len(pop.change_points), pop.num_populations
-    for epoch in range(E):
+    """The M-step of the front-end (Smcsmc.m_step, model.py:989-1048) on statistics summed over chunks: updates `pop`
+    in place.  Ne = 1 / (2 * coalescence rate), capped at maxNE; migration rates go back to units of 4 N0 m; the
+    counts behind every estimate are kept for the next -vb command line."""
+    flat = (1e-30, 0.0)                          # plain EM: a vanishing guard against empty opportunities
+    priors = {"Coal": flat, "Migr": flat}
+    if vb:
+        given = vb_dirichlet or {"ne": [1.0, 1.0], "migr": [1.0, 1.0]}
+        priors = {"Coal": tuple(given["ne"]), "Migr": tuple(given["migr"])}
+    P = pop.num_populations
+    size_cap = maxNE / pop.N0
+    for epoch in range(len(pop.change_points)):
         for a in range(P):
-            key = ("Coal", epoch, a, -1, -1)
-            c0, c1 = vb_dirichlet["ne"] if vb else (1e-30, 0.0)
-            count, opp = data[(key, "Count")] + c1, data[(key, "Opp")] + c0 + c1
-            rate = count / opp
-            pop.population_sizes[epoch][a] = min(maxNE / pop.N0, 1.0 / (2.0 * rate * pop.N0))
+            stat = ("Coal", epoch, a, -1, -1)
+            rate, count = _posterior_mean_rate(data[(stat, "Count")], data[(stat, "Opp")], priors["Coal"])
+            pop.population_sizes[epoch][a] = min(size_cap, 1.0 / (2.0 * rate * pop.N0))
             pop.population_event_counts[epoch][a] = count
-    for epoch in range(E):
-        for a in range(P):
             for b in range(P):
-                if a != b:
-                    key = ("Migr", epoch, a, b, -1)
-                    c0, c1 = vb_dirichlet["migr"] if vb else (1e-30, 0.0)
-                    count, opp = data[(key, "Count")] + c1, data[(key, "Opp")] + c0 + c1
-                    rate = count / opp
-                    pop.migration_rates[epoch][a][b] = rate * 4 * pop.N0
-                    pop.migration_event_counts[epoch][a][b] = count
+                if b == a:
+                    continue
+                stat = ("Migr", epoch, a, b, -1)
+                rate, count = _posterior_mean_rate(data[(stat, "Count")], data[(stat, "Opp")], priors["Migr"])
+                pop.migration_rates[epoch][a][b] = rate * 4 * pop.N0
+                pop.migration_event_counts[epoch][a][b] = count
     if infer_recomb:
-        key = ("Recomb", -1, -1, -1, -1)
-        pop.recombination_rate = data[(key, "Count")] / data[(key, "Opp")]
+        stat = ("Recomb", -1, -1, -1, -1)
+        pop.recombination_rate = data[(stat, "Count")] / data[(stat, "Opp")]
     return pop
 
 

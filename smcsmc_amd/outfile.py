@@ -110,27 +110,24 @@ def trees_text(kind, pos, height, desc, start_position=1.0):
 
 
 def parse_outfile(path_or_text, is_text=False):
-    """Same reduction keys and the same Wt reconstruction as model.py:865-911."""
+    """Reads a `.out` table back into summed statistics keyed ((Type, Epoch, From, To, -1), field) with fields Opp,
+    Count, Wt, Start, End -- the dictionary the front-end's M-step works on (model.py:865-911).  Columns are found by
+    their header names; a file holds one iteration; the weight column is rebuilt from the printed post-lag ESS as
+    max(0, 1/ESS - 1e-10) * Opp (the inverse of how pfparam.cpp:524 prints it)."""
     text = path_or_text if is_text else open(path_or_text).read()
-    lines = text.splitlines()
-    header = lines[0].split()
+    rows = [ln.split() for ln in text.splitlines() if ln.strip()]
+    column = {name: k for k, name in enumerate(rows[0])}
+    body = rows[1:]
+    if len({int(r[column["Iter"]]) for r in body}) > 1:
+        raise ValueError("Found multiple iterations in .out file; expected only one")
     data = defaultdict(float)
-    iters = set()
-    for line in lines[1:]:
-        if not line.strip():
-            continue
-        elts = dict(zip(header, line.split()))
-        for name in ("Iter", "Epoch", "From", "To"):
-            elts[name] = int(elts[name])
-        for name in ("Start", "End", "Opp", "Count", "Rate", "Ne", "ESS"):
-            elts[name] = float(elts[name])
-        iters.add(elts["Iter"])
-        if len(iters) > 1:
-            raise ValueError("Found multiple iterations in .out file; expected only one")
-        key = (elts["Type"], elts["Epoch"], elts["From"], elts["To"], -1)
-        data[(key, "Opp")] += elts["Opp"]
-        data[(key, "Count")] += elts["Count"]
-        data[(key, "Wt")] += max(0.0, (1.0 / elts["ESS"] - 1e-10)) * elts["Opp"]
-        data[(key, "Start")] = elts["Start"]
-        data[(key, "End")] = elts["End"]
+    for r in body:
+        stat = (r[column["Type"]], int(r[column["Epoch"]]), int(r[column["From"]]), int(r[column["To"]]), -1)
+        opportunity = float(r[column["Opp"]])
+        data[(stat, "Opp")] += opportunity
+        data[(stat, "Count")] += float(r[column["Count"]])
+        data[(stat, "Wt")] += max(0.0, 1.0 / float(r[column["ESS"]]) - 1e-10) * opportunity
+        data[(stat, "Start")] = float(r[column["Start"]])
+        data[(stat, "End")] = float(r[column["End"]])
+        float(r[column["Rate"]]); float(r[column["Ne"]])          # present and numeric, not used
     return data

@@ -1,10 +1,11 @@
-"""Host-side .seg handling, mirroring the reference's Segment class
-(/root/reference/src/segdata.cpp, segdata.hpp) -- same names, same error behaviour.
+"""Host-side .seg handling for the Python binding: the same row table and per-row quantities as the C++ reader of
+the drop-in binary (smcsmc_amd/csrc/host/segdata.cpp), built on numpy arrays.
 
-  read_seg / prepare     Segment::prepare            segdata.cpp:55-166
-  iterate rows           Segment::read_new_line      segdata.cpp:182-222
-  distance_to_mutation   Segment::set_lookahead      segdata.cpp:234-262 (the part used without -apf)
-  max_epoch_to_update    smcsmc.cpp:266-275
+Contract (reference: src/segdata.cpp, smcsmc.cpp:266-275): the .seg text format with its error
+messages, the splitting of over-long rows, the window selected by data_start / seqlen, the per-row recording limit
+and the look-ahead summaries of the auxiliary particle filter.  The representation is this module's own: a row table
+of four arrays (`first`, `bases`, `kind`, `genotype`), a per-row classification computed once, and a forward scan
+over those classes for the look-ahead.
 """
 import math
 
@@ -13,51 +14,66 @@ import numpy as np
 SEGMENT_INVARIANT, SEGMENT_MISSING, SEGMENT_INVARIANT_PARTIAL = 0, 1, 2   # segdata.hpp:84
 
 
-class InvalidSeg(ValueError):            # segdata.hpp:41-45
+class InvalidSeg(ValueError):
     pass
 
 
-class InvalidInputFile(InvalidSeg):      # segdata.hpp:48-54
+class InvalidInputFile(InvalidSeg):
     def __init__(self, s):
         super().__init__("Invalid input file: " + s)
 
 
-class WrongNumberOfEntry(InvalidSeg):    # segdata.hpp:57-63
+class WrongNumberOfEntry(InvalidSeg):
     def __init__(self, s):
         super().__init__("Number of variant site is wrong: " + s)
 
 
-class InvalidSegmentStartPosition(InvalidSeg):   # segdata.hpp:66-72
+class InvalidSegmentStartPosition(InvalidSeg):
     def __init__(self, line, pos):
         super().__init__("Segment start position at:" + line + " expect " + pos)
 
 
-class NoDataError(InvalidSeg):           # segdata.hpp:75-81
+class NoDataError(InvalidSeg):
     def __init__(self, name, start, end):
         super().__init__("No data found in file %s between positions %d and %d" % (name, start, end))
 
 
-_CODE = {".": -1, "/": 2, "0": 0, "1": 1}
+_GENOTYPE_CODE = np.full(256, 99, np.int8)
+for _ch, _v in ((".", -1), ("0", 0), ("1", 1), ("/", 2)):
+    _GENOTYPE_CODE[ord(_ch)] = _v
 
 
-def _strtol(s):
-    """C strtol prefix parse: returns (value, rest)."""
-    i = 0
-    while i < len(s) and s[i] in " \t":
-        i += 1
-    j = i
-    if j < len(s) and s[j] in "+-":
-        j += 1
-    k = j
-    while k < len(s) and s[k].isdigit():
+def _leading_int(text):
+    """(value, whole): the integer a field starts with ("521.0" -> 521) and whether that was the whole field."""
+    t = text.lstrip(" +")
+    k = 1 if t[:1] == "-" else 0
+    while k < len(t) and t[k].isdigit():
         k += 1
-    if k == j:
-        return 0, s
-    return int(s[i:k]), s[k:]
+    digits = t[:k]
+    if digits in ("", "-"):
+        return 0, len(t) == 0            # an empty field reads as 0
+    return int(digits), k == len(t)
+
+
+def split_long_rows(first, bases, cap):
+    """Cuts rows longer than `cap` bases into capped pieces followed by the remainder.  Returns (first, bases, kind,
+    source row) of the pieces; capped pieces are INVARIANT_PARTIAL (no site at their end), a row of zero bases stays
+    one empty piece."""
+    first = np.asarray(first, np.int64)
+    bases = np.asarray(bases, np.int64)
+    cap = int(min(cap, 2 ** 62))
+    pieces = np.maximum(1, -(-bases // cap))                 # ceil, at least one
+    src = np.repeat(np.arange(len(first)), pieces)
+    nth = np.arange(len(src)) - np.repeat(np.cumsum(pieces) - pieces, pieces)
+    last = nth == pieces[src] - 1
+    p_first = first[src] + nth * cap
+    p_bases = np.where(last, bases[src] - nth * cap, cap)
+    kind = np.where(last, SEGMENT_INVARIANT, SEGMENT_INVARIANT_PARTIAL).astype(np.int8)
+    return p_first, p_bases, kind, src
 
 
 class Segments:
-    """The buffered SegDatum list plus the per-row quantities the filter consumes."""
+    """The resident row table of one chunk."""
 
     def __init__(self, file_name, nsam, seqlen, data_start=1, max_segment_length=1e99, num_of_mut=None):
         self.file_name = file_name
@@ -65,299 +81,327 @@ class Segments:
         self.seqlen = float(seqlen)
         self.data_start = int(data_start)
         self.max_segment_length = max_segment_length
-        self.rows = []        # (segment_start, segment_length, state, alleles) in file coordinates
         self.empty_file = not file_name
-        self._nfields = None
         if self.empty_file:
-            # no-data mode (segdata.cpp:36-43, 175-178, 454-461)
-            h = sum(1.0 / i for i in range(1, self.nsam))
-            self.num_of_expected_mutations = h * num_of_mut
-            seglen = math.ceil(int(self.seqlen) / self.num_of_expected_mutations)
-            pos = 0
-            while pos < self.seqlen:
-                self.rows.append((pos + self.data_start, seglen, SEGMENT_MISSING, [-1] * self.nsam))
-                pos += seglen
+            # no -seg: pseudo rows without data, ceil(L / (theta * H(n-1))) bases each
+            harmonic = sum(1.0 / i for i in range(1, self.nsam))
+            step = max(1, math.ceil(int(self.seqlen) / (harmonic * num_of_mut)))
+            self.first = np.arange(0, int(math.ceil(self.seqlen)), step, dtype=np.int64) + self.data_start
+            self.bases = np.full(len(self.first), step, np.int64)
+            self.kind = np.full(len(self.first), SEGMENT_MISSING, np.int8)
+            self.genotype = np.full((len(self.first), self.nsam), -1, np.int8)
         else:
-            self._prepare()
+            self._read(file_name)
 
-    # segdata.cpp:413-451
-    def _extract_field_variant(self, field):
-        if self.nsam > len(field):
-            raise WrongNumberOfEntry(field)
-        if self._nfields is None:
-            self._nfields = len(field)
-        elif self._nfields != len(field):
-            raise WrongNumberOfEntry(field)
-        out = []
-        for i in range(self.nsam):
-            ch = field[i]
-            if ch not in _CODE:
-                raise InvalidSeg("Unknown character found in .seg file; expect one of '.', '/', '0' or '1'.")
-            out.append(_CODE[ch])
-            if out[i] == -1 and i % 2 == 1 and out[i - 1] != -1:
-                raise InvalidSeg("Found inconsistent unphased heterozygous marks")
-        return out
+    @classmethod
+    def from_sites(cls, first, bases, genotype, nsam, seqlen, data_start=1, max_segment_length=1e99):
+        """A table from in-memory site data (what a simulator produces): rows are split like rows read from a file."""
+        self = cls.__new__(cls)
+        self.file_name = "<memory>"
+        self.nsam = int(nsam); self.seqlen = float(seqlen); self.data_start = int(data_start)
+        self.max_segment_length = max_segment_length
+        self.empty_file = False
+        self._finish(np.asarray(first, np.int64), np.asarray(bases, np.int64),
+                     np.asarray(genotype, np.int8).reshape(-1, self.nsam))
+        return self
 
-    # segdata.cpp:55-166
-    def _prepare(self):
+    @classmethod
+    def from_pieces(cls, first, bases, kind, genotype, nsam, seqlen, data_start=1):
+        """A table from rows that are already cut (e.g. a slice of another table)."""
+        self = cls.__new__(cls)
+        self.file_name = "<memory>"
+        self.nsam = int(nsam); self.seqlen = float(seqlen); self.data_start = int(data_start)
+        self.max_segment_length = 1e99
+        self.empty_file = False
+        self.first = np.asarray(first, np.int64); self.bases = np.asarray(bases, np.int64)
+        self.kind = np.asarray(kind, np.int8); self.genotype = np.asarray(genotype, np.int8).reshape(-1, self.nsam)
+        return self
+
+    # ---- reading
+    def _decode(self, field, width):
+        if len(field) < self.nsam:
+            raise WrongNumberOfEntry(field)
+        if width[0] is None:
+            width[0] = len(field)
+        elif width[0] != len(field):
+            raise WrongNumberOfEntry(field)
+        g = _GENOTYPE_CODE[np.frombuffer(field[:self.nsam].encode("latin-1"), np.uint8)]
+        if (g == 99).any():
+            raise InvalidSeg("Unknown character found in .seg file; expect one of '.', '/', '0' or '1'.")
+        # the second haplotype of an individual cannot be missing when the first is not
+        second = g[1::2]
+        if ((second == -1) & (g[0:2 * len(second):2] != -1)).any():
+            raise InvalidSeg("Found inconsistent unphased heterozygous marks")
+        return g
+
+    def _read(self, path):
         try:
-            f = open(self.file_name, "r")
+            f = open(path, "r")
         except OSError:
-            raise InvalidInputFile(self.file_name)
-        next_start_pos = -1
+            raise InvalidInputFile(path)
+        first, bases, geno = [], [], []
+        width = [None]
+        expected = None
+        window_end = self.data_start + self.seqlen
         with f:
             for raw in f:
                 line = raw.rstrip("\n")
-                if len(line) == 0:
-                    break                      # the first empty line ends the file
+                if not line:
+                    break                                  # an empty line ends the data
                 if line[0] == "#":
                     continue
-                cols = line.split("\t")
-                if len(cols) < 3:
+                field = line.split("\t")
+                if field[-1] == "" and len(field) > 1:
+                    field.pop()                            # a tab at the very end opens no field
+                if len(field) < 3:
                     raise InvalidSeg("Require 3 or 6 columns")
-                new_seg_start, rest = _strtol(line)
-                if not rest.startswith("\t"):
-                    raise InvalidSegmentStartPosition(line, str(new_seg_start))
-                new_seg_len, _ = _strtol(cols[1])    # trailing ".0" tolerated (segdata.cpp:85-86)
-                if cols[2] in ("T", "F"):
-                    if len(cols) != 6:
+                at, whole = _leading_int(field[0])
+                if not whole:
+                    raise InvalidSegmentStartPosition(line, str(at))
+                count, _ = _leading_int(field[1])
+                if field[2] in ("T", "F"):
+                    if len(field) != 6:
                         raise InvalidSeg("Require 6 (or 3) columns")
-                    if cols[3] not in ("T", "F"):
+                    if field[3] not in ("T", "F"):
                         raise InvalidSeg("Expected T or F in .seg file column 3 and 4")
-                    _, rest5 = _strtol(cols[4])
-                    if rest5 != "" or cols[4] == "":
+                    if field[4] != "" and not _leading_int(field[4])[1]:
                         raise InvalidSeg("Bad chromosome (not an integer) in column 5")
-                    allele = self._extract_field_variant(cols[5])
+                    g = self._decode(field[5], width)
                 else:
-                    if len(cols) != 3:
+                    if len(field) != 3:
                         raise InvalidSeg("Require 3 (or 6) columns")
-                    allele = self._extract_field_variant(cols[2])
-                if next_start_pos > -1 and next_start_pos != new_seg_start:
+                    g = self._decode(field[2], width)
+                if expected is not None and at != expected:
                     raise InvalidSeg("Segments are not consecutive")
-                next_start_pos = new_seg_start + new_seg_len
-                if new_seg_start >= self.data_start + self.seqlen:
+                expected = at + count
+                if at >= window_end:
                     break
-                if new_seg_start + new_seg_len > self.data_start:
-                    # split over-long segments (segdata.cpp:125-144)
-                    while True:
-                        if new_seg_len > self.max_segment_length:
-                            new_seg_len = int(self.max_segment_length)
-                            state = SEGMENT_INVARIANT_PARTIAL
-                        else:
-                            state = SEGMENT_INVARIANT
-                        if new_seg_start + new_seg_len > self.data_start:
-                            self.rows.append((new_seg_start, new_seg_len, state, allele))
-                        new_seg_start += new_seg_len
-                        new_seg_len = next_start_pos - new_seg_start
-                        if not (new_seg_start < next_start_pos):
-                            break
-        if len(self.rows) == 0:
-            raise NoDataError(self.file_name, self.data_start, int(self.data_start + self.seqlen))
+                first.append(at); bases.append(count); geno.append(g)
+        self._finish(np.array(first, np.int64), np.array(bases, np.int64),
+                     np.array(geno, np.int8).reshape(-1, self.nsam))
+        if len(self.first) == 0:
+            raise NoDataError(path, self.data_start, int(window_end))
 
+    def _finish(self, first, bases, genotype):
+        p_first, p_bases, kind, src = split_long_rows(first, bases, self.max_segment_length)
+        keep = p_first + p_bases > self.data_start         # pieces that end before the window are dropped
+        self.first, self.bases, self.kind = p_first[keep], p_bases[keep], kind[keep]
+        self.genotype = genotype[src[keep]]
+
+    # ---- views
     def __len__(self):
-        return len(self.rows)
+        return len(self.first)
 
-    # segdata.cpp:182-222 + 234-262 + smcsmc.cpp:266-275
+    @property
+    def rows(self):
+        """(first, bases, kind, genotype list) per row, file coordinates."""
+        return [(int(a), int(b), int(k), [int(v) for v in g])
+                for a, b, k, g in zip(self.first, self.bases, self.kind, self.genotype)]
+
     def pack(self, lags):
         """Arrays handed to the filter: coordinates relative to data_start (first base = 0)."""
-        n = len(self.rows)
-        start = np.zeros(n)
-        length = np.zeros(n)
-        state = np.zeros(n, np.int8)
-        alleles = np.zeros((n, self.nsam), np.int8)
-        cur = 0.0
-        for i, (s, l, st, al) in enumerate(self.rows):
-            ns = s - self.data_start
-            ne = ns + l
-            if ns < 0:
-                ns = 0
-            if ns > cur:
-                raise InvalidSeg("Internal error - segment computation problem (start)")
-            if ne < 0:
-                raise InvalidSeg("Internal error - segment computation problem (end)")
-            start[i] = ns
-            length[i] = ne - ns
-            state[i] = st
-            alleles[i] = al
-            cur = ne
-        fstart = np.array([r[0] for r in self.rows], dtype=np.int64)
-        flen = np.array([r[1] for r in self.rows], dtype=np.int64)
-        dist = distance_to_mutation(fstart, flen, alleles)
+        lo = np.maximum(0, self.first - self.data_start)
+        hi = self.first + self.bases - self.data_start
+        dist = distance_to_mutation(self.first, self.bases, self.genotype)
         if self.empty_file:
-            dist[:] = 0.0     # no-data mode never calls set_lookahead (segdata.cpp:189-191)
-        mre = np.array([max_epoch_to_update(lags, d) for d in dist], np.int32)
-        return {"start": start, "length": length, "state": state, "alleles": alleles,
-                "max_record_epoch": mre, "distance_to_mutation": dist}
+            dist[:] = 0.0                                  # pseudo rows never limit the recording
+        mre = max_epoch_to_update_rows(lags, dist)
+        return {"start": lo.astype(np.float64), "length": (hi - lo).astype(np.float64), "state": self.kind.copy(),
+                "alleles": self.genotype.copy(), "max_record_epoch": mre, "distance_to_mutation": dist}
+
+    def lookahead(self):
+        return pack_lookahead(self, self.nsam)
 
 
 def distance_to_mutation(fstart, flen, alleles):
-    """segdata.cpp:234-262: 0 for rows carrying data; inside an all-missing run the smaller of the
-    distance back to the start of the run and forward to the end of the next row with data."""
+    """Per row: 0 if it carries data, else the smaller of the distance back to the first row of its data-free run and
+    forward to the end of the next row with data."""
+    fstart = np.asarray(fstart, np.int64); flen = np.asarray(flen, np.int64)
     n = len(fstart)
-    missing = (alleles == -1).all(axis=1)
-    dist = np.zeros(n)
-    # next row with data at or after i
-    nxt = np.full(n, -1, np.int64)
-    last = -1
-    for i in range(n - 1, -1, -1):
-        if not missing[i]:
-            last = i
-        nxt[i] = last
-    run_start = 0
-    for i in range(n):
-        if not missing[i]:
-            run_start = i + 1
-            continue
-        back = float(fstart[i] - fstart[run_start]) if run_start <= i else 0.0
-        d = back
-        if nxt[i] >= 0:
-            fwd = float(fstart[nxt[i]] + flen[nxt[i]] - fstart[i])
-            d = min(d, fwd)
-        dist[i] = d
-    return dist
+    blank = (np.asarray(alleles) == -1).all(axis=1)
+    idx = np.arange(n)
+    # index of the first row of the current data-free run: last index that is blank with a non-blank predecessor
+    run_open = blank & ~np.concatenate(([False], blank[:-1]))
+    run_first = np.maximum.accumulate(np.where(run_open, idx, 0))
+    back = (fstart - fstart[run_first]).astype(np.float64)
+    # end of the next row with data at or after each row
+    ends = np.where(~blank, fstart + flen, np.iinfo(np.int64).max)
+    nxt_end = np.minimum.accumulate(ends[::-1])[::-1] if n else ends
+    # minimum.accumulate picks the smallest end, which is the nearest because ends increase along the file
+    fwd = np.where(nxt_end == np.iinfo(np.int64).max, np.inf, (nxt_end - fstart).astype(np.float64))
+    return np.where(blank, np.minimum(back, fwd), 0.0)
 
 
 def max_epoch_to_update(lags, distance):
-    """smcsmc.cpp:266-275"""
-    epoch = 0
-    while epoch < len(lags) and distance < 0.5 * lags[epoch]:
-        epoch += 1
-    return epoch - 1
+    """Last epoch of the leading run whose half lag still exceeds the distance to data (-1: none)."""
+    last = -1
+    for e, lag in enumerate(lags):
+        if not distance < 0.5 * lag:
+            break
+        last = e
+    return last
+
+
+def max_epoch_to_update_rows(lags, dist):
+    ok = np.asarray(dist)[:, None] < 0.5 * np.asarray(lags, float)[None, :]
+    lead = np.cumprod(ok, axis=1).sum(axis=1)
+    return (lead - 1).astype(np.int32)
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# Auxiliary particle filter look-ahead (Segment::set_lookahead, segdata.cpp:225-410)
+# Look-ahead of the auxiliary particle filter (what Segment::set_lookahead, segdata.cpp:225-410, yields per row)
 
-MAX_MISSING_DATA = 2000000          # segdata.cpp:244
+GIVE_UP_MISSING = 2000000.0          # a sample without data for this many bases is not waited for
 TBL_QUANTILES = (0.001, 0.003, 0.01, 0.03, 0.1, 0.5, 0.95)   # smcsmc.cpp:134
 
 
-def set_lookahead(rows, cur, nsam):
-    """Look-ahead summary for the row `cur` of the buffered SegDatum list (file coordinates), a line-by-line
-    restatement of segdata.cpp:225-410: distance to the first singleton per lineage (negative: none seen within
-    that distance), relative mutation rate under missing data, the doubletons (cherry evidence) with first and
-    last evidence distances, and the first split."""
-    fsd = [0.0] * nsam
-    rmr = [0.0] * nsam
-    doubleton = []            # [s1, s2, first_evidence, last_evidence, unphased_1, unphased_2, incompatible]
-    first_split_distance = -1
-    split_alleles = [0] * nsam
-    split_count = 0
-    found_doubleton = [False] * (nsam + 1)
-    num_singletons = num_unphased_singletons = num_doubleton_sequences = 0
-    tl = 0.1
-    tl_missing = 0.1
-    total_current_missing = 0.0
-    last_singleton_distance = 0.0
-    distance = 0.0
-    unph = [False] * nsam
-    start0 = rows[cur][0]
-    for i in range(cur, len(rows)):
-        seg_start, seg_len, _, al = rows[i]
-        num_var = num_missing = 0
-        s1 = s2 = -1
-        unph = []
+class _SiteClass:
+    """What the scan needs to know about one genotype row."""
+    __slots__ = ("carriers", "absent", "first", "second", "unphased", "no_data")
+
+    def __init__(self, g):
+        n = len(g)
+        self.carriers = 0; self.absent = 0; self.first = -1; self.second = -1
+        self.unphased = [False] * n
+        self.no_data = []
         j = 0
-        while j < nsam:
-            unph.append(False)
-            if al[j] > 0:
-                num_var += 1
-                if num_var == 1:
-                    s1 = j
-                if num_var == 2:
-                    s2 = j
-                if al[j] == 2:
-                    unph[j] = True
-                    unph.append(True)
-                    j += 1          # skip the second allele of an unphased het
-            if j < nsam and al[j] == -1:
-                num_missing += 1
-                if num_missing == 1:
-                    total_current_missing += seg_len
-                if total_current_missing > MAX_MISSING_DATA:
-                    if fsd[j] == 0:
-                        eps = 1e-6
-                        fsd[j] = -(seg_start - start0) - eps
-                        last_singleton_distance = -fsd[j]
-                        if fsd[j] < 0.5 * total_current_missing:
-                            fsd[j] = -eps
-                        rmr[j] = tl_missing / tl
-                        num_singletons += 1
-                    if not found_doubleton[j]:
-                        found_doubleton[j] = True
-                        num_doubleton_sequences += 1
+        while j < n:
+            if g[j] > 0:
+                self.carriers += 1
+                if self.carriers == 1:
+                    self.first = j
+                elif self.carriers == 2:
+                    self.second = j
+                if g[j] == 2:                 # unphased pair: the partner haplotype is not looked at as a carrier
+                    self.unphased[j] = True
+                    j += 1
+            if j < n and g[j] == -1:          # sees the partner of an unphased pair
+                self.absent += 1
+                self.no_data.append(j)
             j += 1
-        if num_missing == 0:
-            total_current_missing = 0.0
-        tl += seg_len * nsam
-        tl_missing += seg_len * (nsam - num_missing)
-        if total_current_missing > MAX_MISSING_DATA:
-            continue
-        have_doubleton = False
-        distance = seg_start + seg_len - start0 + 0.5
-        if num_var == 1:
-            if fsd[s1] == 0:
-                fsd[s1] = distance
-                rmr[s1] = tl_missing / tl
-                num_singletons += 1
-                last_singleton_distance = fsd[s1]
-                if unph[s1]:
-                    fsd[s1 + 1] = distance
-                    rmr[s1 + 1] = rmr[s1]
-                    num_singletons += 1
-                    num_unphased_singletons += 1
+
+
+def _as_table(rows, nsam):
+    if isinstance(rows, Segments):
+        return rows.first, rows.bases, rows.genotype
+    first = np.array([r[0] for r in rows], np.int64)
+    bases = np.array([r[1] for r in rows], np.int64)
+    geno = np.array([r[3] for r in rows], np.int8).reshape(len(rows), nsam)
+    return first, bases, geno
+
+
+def _scan(first, bases, geno, cls, here, nsam):
+    next_private = [0.0] * nsam
+    data_share = [0.0] * nsam
+    pairs = []                       # [a, b, first_seen, last_seen, a_unphased, b_unphased, refuted]
+    in_pair = [False] * (nsam + 1)
+    split_at, split_row, split_minor = -1, None, 0
+    have_private = have_private_unphased = samples_in_pairs = 0
+    seen = with_data = 0.1
+    streak = last_private = reach = 0.0
+    origin = int(first[here])
+    last_cls = cls[here]
+    for i in range(here, len(first)):
+        c = cls[i]
+        last_cls = c
+        nb = int(bases[i])
+        if c.absent:
+            streak += nb
+            if streak > GIVE_UP_MISSING:
+                for j in c.no_data:
+                    if next_private[j] == 0:
+                        mark = -(int(first[i]) - origin) - 1e-6
+                        last_private = -mark
+                        if mark < 0.5 * streak:
+                            mark = -1e-6
+                        next_private[j] = mark
+                        data_share[j] = with_data / seen
+                        have_private += 1
+                    if not in_pair[j]:
+                        in_pair[j] = True
+                        samples_in_pairs += 1
         else:
-            for d in doubleton:
-                a1, a2 = al[d[0]], al[d[1]]
-                if ((d[0] | 1) == d[1] and a1 == 2) or ((a1 + a2 == 1) and ((a1 | a2) == 1)):
-                    d[6] = True
-                if num_var == 2 and d[0] == s1 and d[1] == s2:
-                    have_doubleton = True
-                    if not d[6]:
-                        d[3] = distance
-        if num_var == 2 and not have_doubleton and al[s1] > -1 and al[s2] > -1:
-            done = False
-            for d1 in range(0, (1 if al[s1] == 2 else 0) + 1):
-                for d2 in range(0, (1 if al[s2] == 2 else 0) + 1):
-                    if done:
-                        continue
-                    if not found_doubleton[s1 + d1] and not found_doubleton[s2 + d2]:
-                        doubleton.append([s1, s2, distance, distance, al[s1] == 2, al[s2] == 2, False])
-                        found_doubleton[s1 + d1] = True
-                        num_doubleton_sequences += 1
-                        found_doubleton[s2 + d2] = True
-                        num_doubleton_sequences += 1
-                        done = True
-        if first_split_distance == -1 and num_var > 2 and nsam - num_var > 2:
-            first_split_distance = distance
-            split_alleles = list(al)
-            split_count = min(num_var, nsam - num_var)
-        if num_singletons == nsam and num_doubleton_sequences >= nsam - 1:
-            break
-        if num_singletons == nsam and distance > (2 + num_unphased_singletons) * last_singleton_distance:
-            break
-    if num_singletons < nsam:
+            streak = 0.0
+        seen += nb * nsam
+        with_data += nb * (nsam - c.absent)
+        if streak > GIVE_UP_MISSING:
+            continue
+        reach = int(first[i]) + nb - origin + 0.5
+        g = geno[i]
+        if c.carriers == 1:
+            j = c.first
+            if next_private[j] == 0:
+                next_private[j] = reach
+                data_share[j] = with_data / seen
+                last_private = reach
+                have_private += 1
+                if c.unphased[j]:
+                    next_private[j + 1] = reach
+                    data_share[j + 1] = data_share[j]
+                    have_private += 1
+                    have_private_unphased += 1
+        else:
+            known = False
+            for p in pairs:
+                ga, gb = int(g[p[0]]), int(g[p[1]])
+                if ((p[0] | 1) == p[1] and ga == 2) or (ga + gb == 1 and (ga | gb) == 1):
+                    p[6] = True
+                if c.carriers == 2 and p[0] == c.first and p[1] == c.second:
+                    known = True
+                    if not p[6]:
+                        p[3] = reach
+            if c.carriers == 2 and not known and g[c.first] > -1 and g[c.second] > -1:
+                ua, ub = int(g[c.first] == 2), int(g[c.second] == 2)
+                free = [(da, db) for da in range(ua + 1) for db in range(ub + 1)
+                        if not in_pair[c.first + da] and not in_pair[c.second + db]]
+                if free:
+                    da, db = free[0]
+                    pairs.append([c.first, c.second, reach, reach, bool(ua), bool(ub), False])
+                    in_pair[c.first + da] = True
+                    in_pair[c.second + db] = True
+                    samples_in_pairs += 2
+        if split_at == -1 and c.carriers > 2 and nsam - c.carriers > 2:
+            split_at, split_row, split_minor = reach, i, min(c.carriers, nsam - c.carriers)
+        if have_private == nsam:
+            if samples_in_pairs >= nsam - 1:
+                break
+            if reach > (2 + have_private_unphased) * last_private:
+                break
+    if have_private < nsam:
         for j in range(nsam):
-            if fsd[j] == 0:
-                fsd[j] = -distance
-                rmr[j] = tl_missing / tl
-    unph = (list(unph) + [False] * nsam)[:nsam]
-    return dict(first_singleton_distance=fsd, relative_mutation_rate=rmr, is_singleton_unphased=unph,
-                doubleton=doubleton, first_split_distance=first_split_distance, split_alleles=split_alleles,
-                split_count=split_count)
+            if next_private[j] == 0:
+                next_private[j] = -reach
+                data_share[j] = with_data / seen
+    return dict(first_singleton_distance=next_private, relative_mutation_rate=data_share,
+                is_singleton_unphased=list(last_cls.unphased), doubleton=pairs, first_split_distance=split_at,
+                split_alleles=[int(v) for v in geno[split_row]] if split_row is not None else [0] * nsam,
+                split_count=split_minor)
+
+
+def set_lookahead(rows, cur, nsam):
+    """Look-ahead summary at row `cur`: distance to the next mutation private to each sample (negative: none within
+    that distance) with the share of bases that had data, the sample pairs that next share a mutation (first / last
+    evidence), and the first split into two groups of at least three."""
+    first, bases, geno = _as_table(rows, nsam)
+    cls = [None] * len(first)
+    for i in range(cur, len(first)):
+        cls[i] = _SiteClass(geno[i])
+    return _scan(first, bases, geno, cls, cur, nsam)
 
 
 def pack_lookahead(rows, nsam):
     """Per-row look-ahead arrays in the layout of pf_lookahead (include/smcsmc_pf.h)."""
-    S = len(rows)
+    first, bases, geno = _as_table(rows, nsam)
+    S = len(first)
     D = max(1, nsam // 2)
     out = dict(first_singleton_distance=np.zeros((S, nsam)), relative_mutation_rate=np.zeros((S, nsam)),
                is_singleton_unphased=np.zeros((S, nsam), np.int8), n_doubletons=np.zeros(S, np.int32),
                doubleton_idx=np.zeros((S, D, 4), np.int8), doubleton_dist=np.zeros((S, D, 2)),
                first_split_distance=np.full(S, -1.0), split_alleles=np.zeros((S, nsam), np.int8),
                split_count=np.zeros(S, np.int32), max_doubletons=D)
+    cls = [_SiteClass(g) for g in geno]
     for i in range(S):
-        la = set_lookahead(rows, i, nsam)
+        la = _scan(first, bases, geno, cls, i, nsam)
         out["first_singleton_distance"][i] = la["first_singleton_distance"]
         out["relative_mutation_rate"][i] = la["relative_mutation_rate"]
         out["is_singleton_unphased"][i] = la["is_singleton_unphased"]

@@ -37,21 +37,7 @@ def make_segments(model, seed=1, unphased=False, missing_block=None, max_seg_len
         for c in cols:
             al[rows, c] = -1
     seg["alleles"] = al
-    S = segmod.Segments.__new__(segmod.Segments)
-    S.file_name = "<memory>"; S.nsam = n; S.seqlen = float(L); S.data_start = 1
-    S.max_segment_length = max_seg_len or 1e99; S.empty_file = False; S._nfields = None
-    S.rows = []
-    for s, l, a in zip(seg["start"], seg["length"], seg["alleles"]):
-        s = int(s); l = int(l); end = s + l
-        while True:   # same splitting rule as Segments._prepare
-            if l > S.max_segment_length:
-                l = int(S.max_segment_length); st = segmod.SEGMENT_INVARIANT_PARTIAL
-            else:
-                st = segmod.SEGMENT_INVARIANT
-            S.rows.append((s, l, st, list(map(int, a))))
-            s += l; l = end - s
-            if not s < end:
-                break
+    S = segmod.Segments.from_sites(seg["start"], seg["length"], seg["alleles"], n, L, max_segment_length=max_seg_len or 1e99)
     return S.pack(model["lags"])
 
 

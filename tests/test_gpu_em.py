@@ -61,11 +61,8 @@ def test_in_process_em_loop(hiplib):
     chunks = []
     for seed in (11, 12):
         packed = cases.make_segments(truth, seed=seed, max_seg_len=5000)
-        S = segmod.Segments.__new__(segmod.Segments)
-        S.file_name = "<memory>"; S.nsam = n; S.seqlen = L; S.data_start = 1; S.max_segment_length = 5000
-        S.empty_file = False; S._nfields = None
-        S.rows = [(int(s) + 1, int(l), int(st), list(map(int, a)))
-                  for s, l, st, a in zip(packed["start"], packed["length"], packed["state"], packed["alleles"])]
+        S = segmod.Segments.from_pieces(packed["start"].astype(np.int64) + 1, packed["length"].astype(np.int64), packed["state"],
+                                        packed["alleles"], n, L)
         chunks.append(S)
     cp = list(np.array(truth["change_times"]) / 4e4)
     pop = em.PopulationModel(N0=10000, sequence_length=L, num_samples=n, change_points=cp,
@@ -92,11 +89,8 @@ def test_guided_em_loop(hiplib):
     chunks = []
     for seed in (21, 22):
         packed = cases.make_segments(truth, seed=seed, max_seg_len=5000)
-        S = segmod.Segments.__new__(segmod.Segments)
-        S.file_name = "<memory>"; S.nsam = n; S.seqlen = L; S.data_start = 1; S.max_segment_length = 5000
-        S.empty_file = False; S._nfields = None
-        S.rows = [(int(s) + 1, int(l), int(st), list(map(int, a)))
-                  for s, l, st, a in zip(packed["start"], packed["length"], packed["state"], packed["alleles"])]
+        S = segmod.Segments.from_pieces(packed["start"].astype(np.int64) + 1, packed["length"].astype(np.int64), packed["state"],
+                                        packed["alleles"], n, L)
         chunks.append(S)
     cp = list(np.array(truth["change_times"]) / 4e4)
     pop = em.PopulationModel(N0=10000, sequence_length=L, num_samples=n, change_points=cp, population_sizes=[[1.0]] * 6)
