@@ -176,6 +176,7 @@ def main():
     ap.add_argument("--timing-period", type=int, default=16, help="time every k-th segment's kernels with HIP events")
     ap.add_argument("--no-local-recomb", action="store_true",
                     help="do not record the 100-bp local recombination map (the binary always records it, smcsmc.cpp:376-383)")
+    ap.add_argument("--debug", type=int, default=0, help="pf_params.debug bits (include/smcsmc_pf.h): 4 no counting, 8 two launches per row")
     ap.add_argument("--chunks-per-gpu", type=int, default=1,
                     help="independent chunks filtered concurrently on each GPU (one host thread + stream each); "
                          "1 = the headline single-chunk configuration")
@@ -203,7 +204,7 @@ def main():
     for k in range(C):
         model, segs = build_workload(args, seed=args.seed + rank * C + k)     # independent chunks
         f = ParticleFilter(model, args.np, ess_fraction=0.5, seed=args.seed + 1000 * (rank * C + k), max_trace_events=0,
-                           device=dev, local_recomb=not args.no_local_recomb)
+                           device=dev, local_recomb=not args.no_local_recomb, debug=args.debug)
         f.load_segments(segs)
         chunks.append((f, segs))
     pf, segs = chunks[0]

@@ -89,6 +89,7 @@ typedef struct pf_params {
 #define PF_DEBUG_FORCE_LDS 1     /* run the LDS-tree kernels whatever nsam is */
 #define PF_DEBUG_NO_FUSE   2     /* complete every row with the stand-alone k_resample (two-stream pipeline) */
 #define PF_DEBUG_NO_COUNT  4     /* profiling: skip the lagged counting and the ledger upkeep */
+#define PF_DEBUG_TWO_LAUNCH 8    /* rows as two launches (extend + decide) instead of the single-launch pipeline */
 
 typedef struct pf_segments {
     int64_t n;
@@ -186,6 +187,9 @@ int pf_get_particles(pf_handle* h, double* w_post, double* w_pilot, double* heig
  * total milliseconds and launch count for kernel class k (0 extend, 1 decide, 2 count, 3 resample) */
 int pf_get_kernel_time(pf_handle* h, int k, double* ms, int64_t* launches);
 int pf_set_timing(pf_handle* h, int enable);
+/* profiling builds of the library (-DPF_STAMPS) only: out == NULL enables wall-clock stamps (100 MHz ticks) of the phases of
+ * the extend workgroups for the first `rows` rows; out != NULL copies them back as [rows][wavefronts][16] */
+int pf_debug_stamps(pf_handle* h, int64_t rows, uint64_t* out);
 /* bookkeeping for the roofline: records appended to the event log, bytes of particle state */
 int pf_get_stats(pf_handle* h, int64_t* n_records, int64_t* state_bytes_per_particle, int64_t* n_resamples);
 

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(PF_BS) void k_init(KArgs A, double initial_position
     if (p == 0) {
         Ctrl* c = A.ctrl;
         c->cur_pos = initial_position;
-        c->logl = 0; c->inv_T = 1; c->T = 1; c->flag = 0; c->cur = 0; c->gen = 0; c->n_resample = 0;
+        c->logl = 0; c->inv_T = 1; c->T = 1; c->flag = 0; c->cur = 0; c->gen = 0; c->n_resample = 0; c->lver = 0;
         c->first_epoch = A.E; c->err = 0; c->delayed_opp = 0; c->delayed_count = 0; c->count_active = 0; c->end_seq = 0;
         c->g_retain = 0; c->pending_fin = 0; c->nbx_used = A.nbx; c->gen_prev = 0; c->nres_prev = 0;
         for (int e = 0; e < A.E; ++e) { c->counted_to[e] = 0; c->update_to[e] = 0; c->g_lo[e] = 0; c->g_hi[e] = 0; }
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(PF_BS) void k_init(KArgs A, double initial_position
         if (A.g_K > 1 && A.g_pos[1] < A.L) ln.L = A.g_pos[1];
     }
     double nb = sample_next_base(ln, 0.0);
-    DState& st = A.st[0];
+    const DState st = A.st0;
     for (int r = 0; r < n - 1; ++r) {
         st.S[(size_t)r * A.Np + p] = LS(ln, r);
         st.C[(size_t)(2 * r) * A.Np + p] = LC(ln, r, 0);
@@ -128,13 +128,13 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
     bool has_pending = false;
     const Ctrl* c = A.ctrl;
     const int n = A.n;
-    const int cur = c->cur;
+    const int cur = __builtin_amdgcn_readfirstlane(c->cur);
     const long long p = (long long)blockIdx.x * PF_BS + threadIdx.x;
     const bool active = p < A.Np;
     const int lane = threadIdx.x & 63;
     double w_post = 0.0, w_pilot = 0.0;
     if (active) {
-        DState& st = A.st[cur];
+        const DState st = state_slot(A, cur);
         Lane ln = make_lane(A, m, p);
         for (int r = 0; r < n - 1; ++r) {
             LS(ln, r) = st.S[(size_t)r * A.Np + p];
@@ -332,6 +332,148 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
     }
 }
 
+#ifdef PF_STAMPS
+#define PF_STAMP(k) do { if (A.stamps && (threadIdx.x & 63) == 0 && s < A.stamp_rows)                                   \
+        A.stamps[((size_t)s * A.nc + (size_t)(((long long)blockIdx.x * PF_BS + threadIdx.x) >> 6)) * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define PF_STAMP(k) do {} while (0)
+#endif
+
+// ---- decision on a finished row, made redundantly by every workgroup that needs it (single-launch pipeline) --------
+// normalize_probability (pc.cpp:420-438) and the ESS test of resample (pc.cpp:247-283) from the per-wavefront partials
+// the row's extend workgroups left in ring slot `slot`: the level-2 / level-3 part of the canonical radix-64 reduction,
+// operation for operation what k_decide does, so T, S1, ESS, the flag and the uniform are bit-identical everywhere.
+#define PF_PIPE_STAGE 16        // wavefronts of pilot scans staged per workgroup for the parent search
+struct RowDecision { double T, S1, S2, ess, inv, u; int flag; };
+struct PipeLds {                // carved from the dynamic LDS of k_pipe behind the epoch tables
+    double* l2s;                // [ncpad] level-2 inclusive scan of the per-wavefront pilot totals
+    double* pmx;                // [ncpad + 1] pmx[ch] = largest pilot prefix sum before wavefront ch (pmx[ch + 1]: up to its end)
+    double* l2_post; double* l2_sq; double* l2_tot;   // [64] each
+    double* wredd;              // [PF_BS / 64]
+    double* stage;              // [PF_PIPE_STAGE * 64]
+    int* slo;                   // [PF_BS]
+    int* wint;                  // [3 * PF_BS / 64]
+};
+__host__ __device__ inline size_t pipe_lds_doubles(int nc) {
+    const size_t ncpad = ((size_t)nc + 63) / 64 * 64;
+    return ncpad + (ncpad + 1) + 3 * 64 + PF_BS / 64 + (size_t)PF_PIPE_STAGE * 64 + (PF_BS + 3 * (PF_BS / 64) + 1) / 2 + 2;
+}
+__device__ __forceinline__ PipeLds pipe_carve(double* base, int nc) {
+    const size_t ncpad = ((size_t)nc + 63) / 64 * 64;
+    PipeLds q;
+    q.l2s = base; base += ncpad;
+    q.pmx = base; base += ncpad + 1;
+    q.l2_post = base; base += 64; q.l2_sq = base; base += 64; q.l2_tot = base; base += 64;
+    q.wredd = base; base += PF_BS / 64;
+    q.stage = base; base += (size_t)PF_PIPE_STAGE * 64;
+    q.slo = (int*)base; q.wint = q.slo + PF_BS;
+    return q;
+}
+__device__ __forceinline__ double pipe_chunk_offset(const PipeLds& q, int ch) {
+    double run = 0.0;
+    const int gq = ch / 64;
+    for (int g = 0; g < gq; ++g) run = run + q.l2_tot[g];
+    double off = (ch % 64 == 0) ? 0.0 : q.l2s[ch - 1];
+    return run + off;
+}
+// every thread of the workgroup calls this (it contains barriers); WANT_TABLE: also the prefix maxima the offspring
+// table / parent search need (only computed when the row resamples)
+// the partials a thread needs first, requested before anything else so that their memory round trip overlaps the
+// particle's own loads (what the previous launch wrote comes from another XCD's L2: about a microsecond)
+struct RowPre { double vp = 0.0, vs = 0.0, vl = 0.0, last1 = 0.0; bool have = false; };
+__device__ __forceinline__ RowPre row_preload(const KArgs& A, int slot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nc = A.nc, ch = wave * 64 + lane;
+    RowPre r;
+    r.have = true;
+    if (ch < nc) {
+        r.vp = A.rg_cpost[(size_t)slot * nc + ch];
+        r.vs = A.rg_csq[(size_t)slot * nc + ch];
+        r.vl = A.rg_cpil[(size_t)slot * nc + ch];
+    }
+    r.last1 = A.ctrl->last1[slot];
+    return r;
+}
+template <bool WANT_TABLE>
+__device__ __forceinline__ RowDecision decide_row(const KArgs& A, const PipeLds& q, int slot, long long n_res, RowPre pre = RowPre()) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = PF_BS / 64;
+    const int nc = A.nc;
+    const int ng = (nc + 63) / 64;
+    const double* cpost = A.rg_cpost + (size_t)slot * nc;
+    const double* csq = A.rg_csq + (size_t)slot * nc;
+    const double* cpil = A.rg_cpil + (size_t)slot * nc;
+    const double* cmx1 = A.rg_cmx1 + (size_t)slot * nc;
+    const double last_scan1 = pre.have ? pre.last1 : A.ctrl->last1[slot];
+    for (int g = wave; g < ng; g += nwaves) {
+        int ch = g * 64 + lane;
+        const bool first = pre.have && g == wave;
+        double vp = first ? pre.vp : (ch < nc ? cpost[ch] : 0.0);
+        double vs = first ? pre.vs : (ch < nc ? csq[ch] : 0.0);
+        double vl = first ? pre.vl : (ch < nc ? cpil[ch] : 0.0);
+        double rp = wave_tree_sum(vp);
+        double rs = wave_tree_sum(vs);
+        double sc = wave_hs_scan(vl, lane);
+        if (ch < nc) q.l2s[ch] = sc;
+        if (lane == 63) { q.l2_post[g] = rp; q.l2_sq[g] = rs; q.l2_tot[g] = sc; }
+    }
+    __syncthreads();
+    RowDecision d;
+    {
+        double vp = lane < ng ? q.l2_post[lane] : 0.0;
+        double vs = lane < ng ? q.l2_sq[lane] : 0.0;
+        d.T = wave_tree_sum(vp);
+        d.S2 = wave_tree_sum(vs);
+    }
+    d.S1 = pipe_chunk_offset(q, nc - 1) + last_scan1;   // inclusive scan at the last particle (= oracle incl[N-1])
+    d.ess = (d.S1 * d.S1) / d.S2;
+    d.flag = (d.ess < A.ess_threshold - 1e-6) ? 1 : 0;
+    d.inv = 1.0 / d.T;
+    d.u = d.flag ? philox_uniform(A.seed, 0xFFFFFFFFu, 1, (unsigned long long)n_res) : 0.0;
+    if (WANT_TABLE && d.flag) {
+        // pmx[ch] = max over wavefronts c' < ch of (chunk_off[c'] + mx1[c']): the running maximum that makes the offspring
+        // table monotone is taken on the prefix sums (lo_raw is monotone in its argument), as in k_decide
+        const int perc = (nc + PF_BS - 1) / PF_BS;
+        const int c0 = tid * perc, c1 = c0 + perc < nc ? c0 + perc : nc;
+        double run = 0.0;
+        for (int ch = c0; ch < c1; ++ch) { double vch = pipe_chunk_offset(q, ch) + cmx1[ch]; run = vch > run ? vch : run; }
+        double scd = wave_max_scan_d(run, lane);
+        if (lane == 63) q.wredd[wave] = scd;
+        __syncthreads();
+        double pre = 0.0;
+        for (int w = 0; w < wave; ++w) pre = q.wredd[w] > pre ? q.wredd[w] : pre;
+        double before = __shfl_up(scd, 1, 64);
+        if (lane > 0) pre = before > pre ? before : pre;
+        run = pre;
+        for (int ch = c0; ch < c1; ++ch) {
+            q.pmx[ch] = run;
+            double vch = pipe_chunk_offset(q, ch) + cmx1[ch];
+            run = vch > run ? vch : run;
+        }
+        if (c1 == nc && c0 < c1) q.pmx[nc] = run;
+        __syncthreads();
+    }
+    return d;
+}
+// final offspring offset from the (running-maximum) pilot prefix sum v: #{ j in [0,N) : (j+u) * S1 < N * v }  (pc.cpp:491
+// scaled by N*S1: no division), guess plus exact predicate correction -- the arithmetic of k_decide's lo_at
+__device__ __forceinline__ int pipe_lo_from(double v, double dn, long long Np, double S1, double invS1, double u) {
+    double rhs = dn * v;
+    double guess = floor(rhs * invS1 - u);
+    long long g = guess < 0 ? 0 : (guess > dn ? Np : (long long)guess);
+    while (g > 0 && !((((double)(g - 1)) + u) * S1 < rhs)) --g;
+    while (g < Np && ((((double)g) + u) * S1 < rhs)) ++g;
+    return (int)g;
+}
+
+// what the single-launch pipeline tells the extend workgroups about their row
+struct PipeRow {
+    int complete;          // the previous row has to be completed on load (0 for the first row of a pf_run call)
+    int extend;            // 0: completion only (flush at the end of a pf_run call)
+    int slot_prev;         // state ring slot to read (the general double-buffer index when !complete)
+    int slot_out;          // slot to write
+    double pos_prev;       // end of the previous row
+};
+
 // ------------------------------------------------------------------ k_extend_reg
 // Same computation as k_extend with the local tree held in registers (pf_tree_reg.h); used for
 // n <= 8.  LDS only carries the two epoch tables.
@@ -341,14 +483,59 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
 // EXACT: the number of haplotypes equals NM, so every `r < n - 1` guard of the unrolled tree loops is decided at
 // compile time (the guards are compare + exec-mask instructions, and instructions are what the time is made of)
 // TREES: -arg, the records also carry the descendants of the node each update creates
-template <int NM, bool BIASED, bool EXACT = false, bool TREES = false>
-__device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int fuse) {
+// PIPE: single-launch pipeline (k_pipe).  The workgroup takes the decision on the previous row itself (decide_row),
+// derives the offspring offsets of its own particles and finds the parent of each of its slots by a two-level search
+// over the pilot prefix sums -- no offspring / parent table from an earlier kernel is read --, reads the previous row
+// from one slot of the state ring and writes this row into the next, and leaves the offspring table for the ledger.
+template <int NM, bool BIASED, bool EXACT = false, bool TREES = false, bool PIPE = false>
+__device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int fuse, PipeRow PR = PipeRow()) {
     extern __shared__ double smem[];
     double* sT = smem;                            // epoch starts and ...
     double* sH = smem + PF_EPAD;                  // ... cumulative coalescence intensity there, both padded with +inf (r_search4)
     double* sI = sH + PF_EPAD;
     double* sBH = sI + A.E;                       // bias band boundaries / strengths (focused sampling)
     double* sBS = sBH + (PF_BIAS_MAX + 2);
+    const Ctrl* c = A.ctrl;
+    const int n = EXACT ? NM : A.n;
+    const long long p = (long long)blockIdx.x * PF_BS + threadIdx.x;
+    const bool active = p < A.Np;
+    const int lane = threadIdx.x & 63;
+    // PIPE: everything the prologue and the particle itself need from memory is requested first, in one round trip: the
+    // partials of the decision, this slot's own state of the previous row (what most rows continue from, and what the
+    // old slot's closing record needs when the row resampled) -- a copy reloads from its parent afterwards.
+    PF_STAMP(0);
+    RowPre pre;
+    RTree<NM> t0;
+    double o_wpost = 0.0, o_wpilot = 0.0, o_next = 0.0, o_xmark = 0.0, o_Ltree = 0.0, o_sm = 0.0, o_ebuf = 0.0;
+    int o_ml = 0;
+    unsigned o_widx = 0;
+    unsigned long long o_ctr = 0;
+    long long o_nres = 0; int o_bflag = 0, o_bgen = 0;
+    if constexpr (PIPE) {
+        const int fs = __builtin_amdgcn_readfirstlane(PR.slot_prev >= 0 ? PR.slot_prev : c->cur);
+        if (PR.complete) {
+            pre = row_preload(A, fs);
+            const Ctrl::RowInfo& before = c->ri[(fs + 3) & 3];     // the row before it, published by the previous launch
+            o_nres = before.n_res; o_bflag = before.flag; o_bgen = before.gen;
+        }
+        if (active) {
+            const DState own = state_slot(A, fs);
+#pragma unroll
+            for (int r = 0; r < RTree<NM>::NI; ++r) {
+                t0.S[r] = 0.0; t0.C0[r] = 0; t0.C1[r] = 0;
+                if (r < n - 1) {
+                    t0.S[r] = own.S[(size_t)r * A.Np + p];
+                    t0.C0[r] = own.C[(size_t)(2 * r) * A.Np + p];
+                    t0.C1[r] = own.C[(size_t)(2 * r + 1) * A.Np + p];
+                }
+            }
+            o_wpost = own.w_post[p]; o_wpilot = own.w_pilot[p]; o_next = own.next_base[p]; o_xmark = own.x_mark[p];
+            o_ml = own.mark_limit[p]; o_Ltree = own.Ltree[p];
+            o_widx = PR.complete ? A.rg_widx[(size_t)fs * A.Np + p] : A.widx[p];
+            o_ctr = A.rng_ctr[p]; o_ebuf = A.ebuf[p];
+            if (PR.complete) o_sm = A.rg_scan1m[(size_t)fs * A.Np + p];
+        }
+    }
     for (int e = threadIdx.x; e < PF_EPAD; e += blockDim.x) {
         sT[e] = e < A.E ? A.T[e] : PF_INF;
         sH[e] = e < A.E ? A.Hc[e] : PF_INF;
@@ -358,33 +545,166 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
         sBH[threadIdx.x] = A.bias_H[threadIdx.x];
         if (threadIdx.x < PF_BIAS_MAX + 1) sBS[threadIdx.x] = A.bias_S[threadIdx.x];
     }
-    __syncthreads();
-    const Ctrl* c = A.ctrl;
-    const int n = EXACT ? NM : A.n;
-    const int cur = c->cur;
-    const long long p = (long long)blockIdx.x * PF_BS + threadIdx.x;
-    const bool active = p < A.Np;
-    const int lane = threadIdx.x & 63;
+    // ---- what completing the previous row needs ----
+    int cur = 0, from_slot = 0;
+    bool completing = false, gather = false;
+    double inv = 1.0, S1v = 0.0, pos_prev = 0.0;
+    int lo_p = 0, lo_p1 = 0;
+    bool first_copy = true;
+    long long a = p;
+    int G_end = 0, ev = 0;
+    if constexpr (PIPE) {
+        PipeLds q = pipe_carve(sBS + (PF_BIAS_MAX + 1), A.nc);
+        cur = PR.slot_out; from_slot = PR.slot_prev >= 0 ? PR.slot_prev : c->cur;
+        completing = PR.complete != 0;
+        pos_prev = PR.pos_prev;
+        if (completing) {
+            const int row_slot = from_slot;                        // ring slot of the row being completed
+            const long long n_res = o_nres + o_bflag;
+            G_end = o_bgen + o_bflag;
+            ev = (int)n_res;
+            PF_STAMP(1);
+            RowDecision d = decide_row<true>(A, q, row_slot, n_res, pre);
+            PF_STAMP(2);
+            inv = d.inv; S1v = d.S1;
+            gather = d.flag != 0;
+            if (gather) {
+                const double dn = (double)A.Np;
+                const double invS1 = 1.0 / d.S1;
+                const double* sm = A.rg_scan1m + (size_t)row_slot * A.Np;
+                const int wave = threadIdx.x >> 6;
+                int ch_own = (int)(p >> 6);
+                double coff_own = 0.0, v_own = 0.0;
+                int lo_next = 0;
+                if (active) {
+                    coff_own = pipe_chunk_offset(q, ch_own);
+                    double w = coff_own + o_sm;
+                    v_own = q.pmx[ch_own] > w ? q.pmx[ch_own] : w;          // largest pilot prefix sum up to particle p
+                    lo_next = p + 1 < A.Np ? pipe_lo_from(v_own, dn, A.Np, d.S1, invS1, d.u) : (int)A.Np;
+                    q.slo[threadIdx.x] = lo_next;
+                }
+                // ---- parent of slot p: the first particle a with (p+u) * S1 < N * (largest prefix sum up to a) ----
+                const double lhs = ((double)p + d.u) * d.S1;
+                int pch = 0;
+                if (active) {
+                    int lo_c = 0, hi_c = A.nc - 1;
+                    while (lo_c < hi_c) {
+                        int mid = (lo_c + hi_c) >> 1;
+                        if (lhs < dn * q.pmx[mid + 1]) hi_c = mid; else lo_c = mid + 1;
+                    }
+                    pch = lo_c;
+                }
+                int cmin = active ? pch : 0x7fffffff, cmax = active ? pch : -1;
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) {
+                    int o1 = __shfl_xor(cmin, m, 64), o2 = __shfl_xor(cmax, m, 64);
+                    cmin = o1 < cmin ? o1 : cmin; cmax = o2 > cmax ? o2 : cmax;
+                }
+                if (lane == 0) { q.wint[wave] = cmin; q.wint[PF_BS / 64 + wave] = cmax; }
+                __syncthreads();
+                if (active) lo_p1 = lo_next;
+                if (active) {
+                    if (threadIdx.x > 0) lo_p = q.slo[threadIdx.x - 1];
+                    else lo_p = p > 0 ? pipe_lo_from(q.pmx[ch_own], dn, A.Np, d.S1, invS1, d.u) : 0;
+                }
+                cmin = q.wint[0]; cmax = q.wint[PF_BS / 64];
+                for (int w = 1; w < PF_BS / 64; ++w) {
+                    cmin = q.wint[w] < cmin ? q.wint[w] : cmin;
+                    cmax = q.wint[PF_BS / 64 + w] > cmax ? q.wint[PF_BS / 64 + w] : cmax;
+                }
+                // survivors of this workgroup (the ledger positions the run list of the ending generation with them)
+                {
+                    unsigned long long bal = __ballot(active && lo_p1 > lo_p);
+                    if (lane == 0) q.wint[2 * (PF_BS / 64) + wave] = __popcll(bal);
+                }
+                int nst = cmax - cmin + 1;
+                if (nst > PF_PIPE_STAGE) nst = PF_PIPE_STAGE;
+                if (nst < 0) nst = 0;
+                for (int idx = threadIdx.x; idx < nst * 64; idx += PF_BS) {
+                    long long src = (long long)cmin * 64 + idx;
+                    q.stage[idx] = src < A.Np ? sm[src] : PF_INF;
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    int tot = 0;
+                    for (int w = 0; w < PF_BS / 64; ++w) tot += q.wint[2 * (PF_BS / 64) + w];
+                    A.rg_blkcnt[(size_t)row_slot * A.nbx + blockIdx.x] = tot;
+                }
+                if (active) {
+                    const double coff_p = pipe_chunk_offset(q, pch);
+                    const double pm_p = q.pmx[pch];
+                    const bool staged = pch - cmin < nst;
+                    auto val_at = [&](int l) -> double {           // largest prefix sum up to particle pch*64 + l
+                        long long idx = (long long)pch * 64 + l;
+                        double smv = staged ? q.stage[(pch - cmin) * 64 + l] : (idx < A.Np ? sm[idx] : PF_INF);
+                        double w = coff_p + smv;
+                        return pm_p > w ? pm_p : w;
+                    };
+                    int lo_l = 0, hi_l = 63;
+                    while (lo_l < hi_l) {
+                        int mid = (lo_l + hi_l) >> 1;
+                        if (lhs < dn * val_at(mid)) hi_l = mid; else lo_l = mid + 1;
+                    }
+                    a = (long long)pch * 64 + lo_l;
+                    if (a > A.Np - 1) a = A.Np - 1;
+                    // slot p is the first copy of a (it keeps a's next recombination position) iff it equals a's offset
+                    const int la = (int)(a & 63);
+                    if (p == 0 || a == 0) first_copy = (p == 0);
+                    else {
+                        double vprev = la > 0 ? val_at(la - 1) : pm_p;      // largest prefix sum up to a - 1
+                        if (a != (long long)pch * 64 + lo_l) {             // clamped: recompute on the true chunk of a - 1
+                            long long am = a - 1;
+                            int chm = (int)(am >> 6);
+                            double w = pipe_chunk_offset(q, chm) + sm[am];
+                            vprev = q.pmx[chm] > w ? q.pmx[chm] : w;
+                        }
+                        first_copy = ((((double)(p - 1)) + d.u) * d.S1 < dn * vprev);
+                    }
+                    // the offspring table of the generation that ends here, for the ledger (launch s + 1) and -arg
+                    int* lo_tab = A.lo + (size_t)(G_end % A.Gcap) * (A.Np + 1);
+                    lo_tab[p] = lo_p;
+                    if (p == A.Np - 1) lo_tab[A.Np] = (int)A.Np;
+                }
+            }
+        }
+    } else {
+        cur = c->cur;
+        completing = fuse != 0;
+        gather = fuse && c->flag;
+        from_slot = gather ? (cur ^ 1) : cur;
+        __syncthreads();
+    }
+    if constexpr (PIPE) __syncthreads();
+    PF_STAMP(3);
+    // wave-uniform slots: indexed kernel arguments stay scalar loads (a lane-varying index would put them on the stack)
+    cur = __builtin_amdgcn_readfirstlane(cur);
+    from_slot = __builtin_amdgcn_readfirstlane(from_slot);
     double w_post = 0.0, w_pilot = 0.0;
     bool has_pending = false;
     if (active) {
-        const DState& st = A.st[cur];
-        const bool gather = fuse && c->flag;              // the previous row resampled: this slot starts as a copy of its parent
-        const DState& from = gather ? A.st[cur ^ 1] : st;
-        const long long a = gather ? (long long)A.parent[p] : p;
-        // offspring offsets of this slot (as the old particle) and of its parent: requested with the parent index and
-        // with the parent's state, not after them (each dependent request is a memory round trip of about 1 us)
-        const int* lo_tab = A.lo + (size_t)((c->gen - 1 + A.Gcap) % A.Gcap) * (A.Np + 1);
-        int lo_p = 0, lo_p1 = 0, lo_a = 0;
-        if (gather) { lo_p = lo_tab[p]; lo_p1 = lo_tab[p + 1]; lo_a = lo_tab[a]; }
+        const DState st = state_slot(A, cur);
+        const DState from = state_slot(A, from_slot);
+        if constexpr (!PIPE) {
+            a = gather ? (long long)A.parent[p] : p;
+            // offspring offsets of this slot (as the old particle) and of its parent: requested with the parent index and
+            // with the parent's state, not after them (each dependent request is a memory round trip of about 1 us)
+            const int* lo_tab = A.lo + (size_t)((c->gen - 1 + A.Gcap) % A.Gcap) * (A.Np + 1);
+            if (gather) { lo_p = lo_tab[p]; lo_p1 = lo_tab[p + 1]; first_copy = (p == lo_tab[a]); }
+            inv = c->inv_T; S1v = c->S1; pos_prev = c->cur_pos;
+            G_end = c->gen - 1; ev = (int)c->n_resample - 1;
+        }
         RTree<NM> t;
+        const bool reload = !PIPE || gather;           // PIPE: the slot's own state is already in registers
+        if (!reload) t = t0;
+        else {
 #pragma unroll
-        for (int r = 0; r < RTree<NM>::NI; ++r) {
-            t.S[r] = 0.0; t.C0[r] = 0; t.C1[r] = 0;
-            if (r < n - 1) {
-                t.S[r] = from.S[(size_t)r * A.Np + a];
-                t.C0[r] = from.C[(size_t)(2 * r) * A.Np + a];
-                t.C1[r] = from.C[(size_t)(2 * r + 1) * A.Np + a];
+            for (int r = 0; r < RTree<NM>::NI; ++r) {
+                t.S[r] = 0.0; t.C0[r] = 0; t.C1[r] = 0;
+                if (r < n - 1) {
+                    t.S[r] = from.S[(size_t)r * A.Np + a];
+                    t.C0[r] = from.C[(size_t)(2 * r) * A.Np + a];
+                    t.C1[r] = from.C[(size_t)(2 * r + 1) * A.Np + a];
+                }
             }
         }
         RCtx cx;
@@ -399,7 +719,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
         if (BIASED) {
             ds.pos = st.dpos + p; ds.fac = st.dfac + p; ds.delta = st.ddelta + p; ds.k = st.dk + p; ds.Np = A.Np;
             ds.count = from.dcount[a]; ds.total = from.total_delayed[a];
-            if (gather)        // the copy constructor copies the pending factors (particle.cpp:122-123)
+            if (gather || PIPE)   // the copy constructor copies the pending factors (particle.cpp:122-123); the ring moves them every row
                 for (int k = 0; k < ds.count; ++k) {
                     st.dpos[(size_t)k * A.Np + p] = from.dpos[(size_t)k * A.Np + a];
                     st.dfac[(size_t)k * A.Np + p] = from.dfac[(size_t)k * A.Np + a];
@@ -407,69 +727,82 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
                     st.dk[(size_t)k * A.Np + p] = from.dk[(size_t)k * A.Np + a];
                 }
         }
-        w_post = from.w_post[a];
-        w_pilot = from.w_pilot[a];
-        double next_base = from.next_base[a];
-        double x_mark = from.x_mark[a];
-        int mark_limit = from.mark_limit[a];
-        cx.Ltree = from.Ltree[a];
-        cx.ctr = A.rng_ctr[p];
-        cx.ebuf = A.ebuf[p];
-        unsigned widx = A.widx[p];
-        if (fuse) {
-            const double inv = c->inv_T;
-            if (p == 0) { Ctrl* cw = A.ctrl; cw->gen_prev = c->gen; cw->nres_prev = c->n_resample; }
+        double next_base, x_mark;
+        int mark_limit;
+        unsigned widx;
+        if (reload) {
+            w_post = from.w_post[a];
+            w_pilot = from.w_pilot[a];
+            next_base = from.next_base[a];
+            x_mark = from.x_mark[a];
+            mark_limit = from.mark_limit[a];
+            cx.Ltree = from.Ltree[a];
+        } else {
+            w_post = o_wpost; w_pilot = o_wpilot; next_base = o_next; x_mark = o_xmark; mark_limit = o_ml; cx.Ltree = o_Ltree;
+        }
+        if constexpr (PIPE) { cx.ctr = o_ctr; cx.ebuf = o_ebuf; widx = o_widx; }
+        else { cx.ctr = A.rng_ctr[p]; cx.ebuf = A.ebuf[p]; widx = A.widx[p]; }
+        if (completing) {
+            if (!PIPE && p == 0) { Ctrl* cw = A.ctrl; cw->gen_prev = c->gen; cw->nres_prev = c->n_resample; }
             if (!gather) {
                 w_post *= inv;                             // normalize_probability, pc.cpp:435-437
                 w_pilot *= inv;
             } else {
-                const int G = c->gen - 1;                  // the generation that ended with the previous row
-                const double pos = c->cur_pos;
+                const int G = G_end;                       // the generation that ended with the previous row
+                const double pos = pos_prev;
                 const DState& src = from;
                 // role of the old slot p: close its stretch if it has offspring
                 if (lo_p1 > lo_p) {
                     double* rec = rec_ptr(A, p, widx);
-                    rec[0] = src.x_mark[p];
+                    rec[0] = PIPE ? o_xmark : src.x_mark[p];
                     rec[1] = pos;
                     rec[2] = 0.0; rec[3] = 0.0;
-                    rec[4] = __longlong_as_double((long long)make_meta(1, src.mark_limit[p], -1, n));
-                    for (int r = 0; r < n - 1; ++r) rec[5 + r] = src.S[(size_t)r * A.Np + p];
+                    rec[4] = __longlong_as_double((long long)make_meta(1, PIPE ? o_ml : src.mark_limit[p], -1, n));
+                    if constexpr (PIPE) {
+#pragma unroll
+                        for (int r = 0; r < RTree<NM>::NI; ++r) if (r < n - 1) rec[5 + r] = t0.S[r];
+                    } else {
+                        for (int r = 0; r < n - 1; ++r) rec[5 + r] = src.S[(size_t)r * A.Np + p];
+                    }
                     ++widx;
                 }
                 A.gstart[(size_t)((G + 1) % A.Gcap) * A.Np + p] = widx;
                 // role of the new slot p: weights of the copy (pc.cpp:350-351), fresh position for all but the first
-                int ev = (int)c->n_resample - 1;
                 if (ev < A.max_trace_events) A.ev_parents[(size_t)ev * A.Np + p] = (int)a;
                 double wp = w_post * inv;
                 double wq = w_pilot * inv;
-                double sumn = c->S1 * inv;
+                double sumn = S1v * inv;
                 double adj = sumn / ((double)A.Np * wq);
                 w_post = wp * adj;
                 w_pilot = wq * adj;
                 x_mark = pos;
-                if (p != lo_a && pos < A.L) next_base = r_sample_next_base<false>(cx, pos);     // pc.cpp:357-368
+                if (!first_copy && pos < A.L) next_base = r_sample_next_base<false>(cx, pos);     // pc.cpp:357-368
             }
         }
 
+        PF_STAMP(4);
+        const bool do_extend = !PIPE || PR.extend != 0;
         const int8_t* data = A.seg_alleles + (size_t)s * n;
-        const double seg_end = A.seg_start[s] + A.seg_len[s];
+        const double seg_end = do_extend ? A.seg_start[s] + A.seg_len[s] : 0.0;
         const double extend_to = seg_end < A.L ? seg_end : A.L;
-        const int limit = A.seg_limit[s];
+        const int limit = do_extend ? A.seg_limit[s] : 0;
         unsigned one_mask = 0, zero_mask = 0, present_mask = 0, two_mask = 0;
         int missing = 0;
-        for (int i = 0; i < n; ++i) {
-            int d = data[i];
-            missing += d == -1;
-            if (d == 1) one_mask |= 1u << i;
-            if (d == 0) zero_mask |= 1u << i;
-            if (d == 2) two_mask |= 1u << i;
-            if (d >= 0) present_mask |= 1u << i;
-        }
+        if (do_extend)
+            for (int i = 0; i < n; ++i) {
+                int d = data[i];
+                missing += d == -1;
+                if (d == 1) one_mask |= 1u << i;
+                if (d == 0) zero_mask |= 1u << i;
+                if (d == 2) two_mask |= 1u << i;
+                if (d >= 0) present_mask |= 1u << i;
+            }
         int leaf_status = 0;
         if (missing == 0) leaf_status = 1;
         if (missing == n) leaf_status = -1;
 
-        double updated_to = c->cur_pos;
+        double updated_to = (PIPE && completing) ? pos_prev : c->cur_pos;
+        if (!do_extend) updated_to = extend_to;             // completion only: the loop below does not run
         double B;
         if (leaf_status == -1) B = 0;
         else if (leaf_status == 1) B = cx.Ltree;
@@ -530,10 +863,11 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
             }
         }
 
+        PF_STAMP(5);
         if (BIASED) {
             // apply the factors that fell due during this extension (particle.cpp:910-916)
             for (;;) {
-                if (ds.count == 0) break;
+                if (ds.count == 0 || !do_extend) break;
                 double pm = ds.pos[0];
                 for (int i = 1; i < ds.count; ++i) { double pi = ds.pos[(size_t)i * ds.Np]; if (pi < pm) pm = pi; }
                 if (!(pm < extend_to)) break;
@@ -544,7 +878,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
             if (cx.gK > 0) st.ridx[p] = cx.ridx;
             has_pending = ds.count > 0;
         }
-        if (A.seg_state[s] == 0) {
+        if (do_extend && A.seg_state[s] == 0) {
             const bool dephase = A.flags & 2;
             const bool anc = A.flags & 1;
             unsigned het_pairs = 0;
@@ -586,6 +920,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
             w_pilot *= lik;
         }
 
+        PF_STAMP(6);
 #pragma unroll
         for (int r = 0; r < RTree<NM>::NI; ++r)
             if (r < n - 1) {
@@ -601,29 +936,58 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
         st.Ltree[p] = cx.Ltree;
         A.rng_ctr[p] = cx.ctr;
         A.ebuf[p] = cx.ebuf;
-        A.widx[p] = widx;
+        if constexpr (PIPE) {
+            A.rg_widx[(size_t)cur * A.Np + p] = widx;
+            if (!do_extend) A.widx[p] = widx;              // the state goes back to the general kernels
+        } else {
+            A.widx[p] = widx;
+        }
         if (TREES && widx >= A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;       // -arg keeps every record
+        if constexpr (!PIPE) {
 #pragma unroll
-        for (int r = 0; r < RTree<NM>::NI; ++r) if (r < n - 1) A.snap_S[A.sp][(size_t)r * A.Np + p] = t.S[r];
-        A.snap_w[A.sp][p] = w_post; A.snap_xm[A.sp][p] = x_mark; A.snap_ml[A.sp][p] = mark_limit; A.snap_widx[A.sp][p] = widx;
+            for (int r = 0; r < RTree<NM>::NI; ++r) if (r < n - 1) A.snap_S[A.sp][(size_t)r * A.Np + p] = t.S[r];
+            A.snap_w[A.sp][p] = w_post; A.snap_xm[A.sp][p] = x_mark; A.snap_ml[A.sp][p] = mark_limit; A.snap_widx[A.sp][p] = widx;
+        }
     }
+    PF_STAMP(7);
     double sp = wave_tree_sum(w_post);
     double sq = wave_tree_sum(w_pilot * w_pilot);
     double sc = wave_hs_scan(w_pilot, lane);
     double scp = wave_hs_scan(w_post, lane);
     double scm = wave_max_scan_d(sc, lane);     // running max of the pilot scan (a parallel FP scan need not be monotone)
     long long chunk = p >> 6;
-    if (active) { A.scan1[p] = sc; A.scanp2[A.sp][p] = scp; A.scan1m[p] = scm; }
-    if (lane == 63 && chunk < (A.Np + 63) / 64) {
-        A.chunk_post[chunk] = sp;
-        A.chunk_sq[chunk] = sq;
-        A.chunk_pil[chunk] = sc;
-        A.chunk_pp[chunk] = scp;
-        A.chunk_mx1[chunk] = scm;
-    }
-    if (BIASED) {
-        unsigned long long pend = __ballot(has_pending);
-        if (lane == 0 && chunk < (A.Np + 63) / 64) A.chunk_dpend[chunk] = __popcll(pend);
+    PF_STAMP(8);
+    if constexpr (PIPE) {
+        const size_t ro = (size_t)cur * A.Np, co = (size_t)cur * A.nc;
+        if (active) { A.rg_scan1[ro + p] = sc; A.rg_scanp[ro + p] = scp; A.rg_scan1m[ro + p] = scm; }
+        if (p == A.Np - 1) A.ctrl->last1[cur] = sc;
+        if (lane == 63 && chunk < A.nc) {
+            A.rg_cpost[co + chunk] = sp;
+            A.rg_csq[co + chunk] = sq;
+            A.rg_cpil[co + chunk] = sc;
+            A.rg_cpp[co + chunk] = scp;
+            A.rg_cmx1[co + chunk] = scm;
+        }
+        if (BIASED) {
+            unsigned long long pend = __ballot(has_pending);
+            if (lane == 0 && chunk < A.nc) {
+                A.rg_dpend[co + chunk] = __popcll(pend);
+                if (!PR.extend) A.chunk_dpend[chunk] = __popcll(pend);     // the state goes back to the general kernels
+            }
+        }
+    } else {
+        if (active) { A.scan1[p] = sc; A.scanp2[A.sp][p] = scp; A.scan1m[p] = scm; }
+        if (lane == 63 && chunk < (A.Np + 63) / 64) {
+            A.chunk_post[chunk] = sp;
+            A.chunk_sq[chunk] = sq;
+            A.chunk_pil[chunk] = sc;
+            A.chunk_pp[chunk] = scp;
+            A.chunk_mx1[chunk] = scm;
+        }
+        if (BIASED) {
+            unsigned long long pend = __ballot(has_pending);
+            if (lane == 0 && chunk < (A.Np + 63) / 64) A.chunk_dpend[chunk] = __popcll(pend);
+        }
     }
 }
 
@@ -1074,11 +1438,39 @@ __device__ __forceinline__ void records_contrib(AccT<P>& acc, const KArgs& A, co
     }
 }
 
+// Where a count step finds the particles of its row and the ancestor maps in force.  The general kernels keep these by
+// step parity (snapshots written by k_extend) and update the run lists in place; the single-launch pipeline reads the
+// row's slot of the state ring and the run-list copy that was in force for the row.
+struct RunLists { int* st; int* anc; int* nruns; };
+struct CountSrc {
+    const double* w; const double* S; const double* xm; const int* ml; const unsigned* widx;   // the row's live particles
+    const unsigned* widx_live;                    // records appended per slot as of now (ring-overwrite check)
+    const double* scanp; const double* offp;      // posterior scan inside the wavefronts, exclusive offsets of the wavefronts
+    RunLists lists;
+    double inv; int G, g_lo, g_hi;                // normalisation of the row, its generation, generations of the epoch's window
+};
+__device__ __forceinline__ RunLists run_lists(const KArgs& A, int ver) {
+    RunLists r;
+    r.st = ver ? A.run_st2 : A.run_st; r.anc = ver ? A.run_anc2 : A.run_anc; r.nruns = ver ? A.nruns2 : A.nruns;
+    return r;
+}
+__device__ __forceinline__ CountSrc count_src_parity(const KArgs& A, int sp, int e) {
+    const Ctrl* c = A.ctrl;
+    CountSrc q;
+    q.w = A.snap_w[sp]; q.S = A.snap_S[sp]; q.xm = A.snap_xm[sp]; q.ml = A.snap_ml[sp]; q.widx = A.snap_widx[sp];
+    q.widx_live = A.widx;
+    q.scanp = A.scanp2[sp]; q.offp = A.chunk_offp2[sp];
+    q.lists = run_lists(A, c->lver);
+    q.inv = c->step[sp].inv_T; q.G = c->step[sp].G;
+    q.g_lo = e < A.E ? c->g_lo[e] : 0; q.g_hi = e < A.E ? c->g_hi[e] : 0;
+    return q;
+}
+
 #define PF_CNT_TILE 2048      // generations whose run counts are staged in LDS at a time
 #define PF_CNT_WIDE 128       // run lists longer than this are strided over by the whole grid column
 
 template <int NI, int P>
-__device__ __forceinline__ void count_run(AccT<P>& acc, const KArgs& A, int sp, const Win& W, const LMap& L, int g, long long i,
+__device__ __forceinline__ void count_run(AccT<P>& acc, const KArgs& A, const CountSrc& Q, const Win& W, const LMap& L, int g, long long i,
                                           int nr, const int* rst, const int* ran, double inv) {
     const long long Np = A.Np;
     int q0 = rst[i];
@@ -1088,39 +1480,35 @@ __device__ __forceinline__ void count_run(AccT<P>& acc, const KArgs& A, int sp, 
     // read then must at least stay inside the arrays and every loop must stay bounded until the host sees the error
     if (q1 <= q0 || q1 > (int)Np || q0 < 0 || a < 0 || a >= Np) return;
     // posterior mass of the descendants of (g, a): difference of the inclusive posterior scan
-    const double* offp = A.chunk_offp2[sp];
-    const double* scp_ = A.scanp2[sp];
+    const double* offp = Q.offp;
+    const double* scp_ = Q.scanp;
     double hi = offp[(q1 - 1) >> 6] + scp_[q1 - 1];
     double lo = q0 > 0 ? offp[(q0 - 1) >> 6] + scp_[q0 - 1] : 0.0;
     double w = (hi - lo) * inv;
     if (!(w > 0.0)) return;
     unsigned k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
     unsigned k1 = A.gstart[(size_t)((g + 1) % A.Gcap) * Np + a];
-    if (A.widx[a] - k0 > A.cap || k1 - k0 > A.cap) { if (!A.ctrl->err) A.ctrl->err = ERR_LOG_OVERFLOW; return; }
+    if (Q.widx_live[a] - k0 > A.cap || k1 - k0 > A.cap) { if (!A.ctrl->err) A.ctrl->err = ERR_LOG_OVERFLOW; return; }
     records_contrib<NI, P>(acc, A, W, L, w, a, k0, k1);
 }
 
 // The body of k_count for the workgroup (bx, by) of a column of nbxg workgroups; `sp` = parity of the step whose
 // weights and snapshot it reads.  Called from k_count and from the count workgroups of k_row.
 template <int NM, int P, bool EXACT = false>
-__device__ __forceinline__ void count_body(const KArgs& A, int sp, int e0, const Windows& Wn, int bx, int by, int nbxg) {
+__device__ __forceinline__ void count_body(const KArgs& A, const CountSrc& Q, int e, double win_a, double win_b, int bx, int nbxg) {
     constexpr int NI = NM - 1;
     using AC = AccT<P>;
     __shared__ AC red[PF_BS / 64];
     __shared__ int s_off[PF_CNT_TILE + 1];
     __shared__ int s_wsum[PF_BS / 64];
-    const Ctrl* c = A.ctrl;
-    const int e = e0 + by;
-    const int first = Wn.first;
-    if (e < first || e >= A.E) return;
     const long long Np = A.Np;
     const int n = EXACT ? NM : A.n;
-    const int G = c->step[sp].G;                        // the generation the weights belong to
-    const double inv = c->step[sp].inv_T;
+    const int G = Q.G;                                  // the generation the weights belong to
+    const double inv = Q.inv;
     Win W;
     W.e = e; W.rf = A.recflags[e];
     W.T0 = A.T[e]; W.T1 = e + 1 < A.E ? A.T[e + 1] : PF_INF;
-    W.a_e = Wn.a[e]; W.b_e = Wn.b[e];
+    W.a_e = win_a; W.b_e = win_b;
     W.end_seq = (A.L == W.b_e);
     __shared__ double s_lbins[PF_LBINS];
     LMap L;
@@ -1129,7 +1517,7 @@ __device__ __forceinline__ void count_body(const KArgs& A, int sp, int e0, const
         for (int k = threadIdx.x; k < PF_LBINS; k += PF_BS) s_lbins[k] = 0.0;
         __syncthreads();
     }
-    const int g_lo = c->g_lo[e], g_hi = c->g_hi[e];
+    const int g_lo = Q.g_lo, g_hi = Q.g_hi;
     const int lane = threadIdx.x & 63;
     const long long gtid = (long long)bx * PF_BS + threadIdx.x;
     const long long nthreads = (long long)nbxg * PF_BS;
@@ -1155,7 +1543,7 @@ __device__ __forceinline__ void count_body(const KArgs& A, int sp, int e0, const
             int v = 0;
             if (idx < ntile) {
                 int g = tile_hi - idx;
-                v = g == G ? (int)Np : A.nruns[g % A.Gcap];
+                v = g == G ? (int)Np : Q.lists.nruns[g % A.Gcap];
             }
             loc[k] = v;
             lsum += v;
@@ -1192,23 +1580,23 @@ __device__ __forceinline__ void count_body(const KArgs& A, int sp, int e0, const
             if (g == G) {
                 // live particle: its own weight, its open stretch, the records it wrote this generation
                 const long long a = i;
-                double w = A.snap_w[sp][a] * inv;
+                double w = Q.w[a] * inv;
                 double S[NI];
 #pragma unroll
-                for (int r = 0; r < NI; ++r) S[r] = r < n - 1 ? A.snap_S[sp][(size_t)r * Np + a] : 0.0;
-                double xm = A.snap_xm[sp][a];
-                int ml = A.snap_ml[sp][a];
+                for (int r = 0; r < NI; ++r) S[r] = r < n - 1 ? Q.S[(size_t)r * Np + a] : 0.0;
+                double xm = Q.xm[a];
+                int ml = Q.ml[a];
                 unsigned k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
-                unsigned k1 = A.snap_widx[sp][a];
+                unsigned k1 = Q.widx[a];
                 if (w == 0.0) continue;
                 stretch_contrib<NI, P>(acc, A, W, L, w, xm, PF_INF, S, ml);
                 if (k1 - k0 > A.cap) { if (!A.ctrl->err) A.ctrl->err = ERR_LOG_OVERFLOW; continue; }
                 records_contrib<NI, P>(acc, A, W, L, w, a, k0, k1);
             } else {
                 const int nr = s_off[lo_i + 1] - s_off[lo_i];
-                const int* rst = A.run_st + (size_t)(g % A.Gcap) * Np;
-                const int* ran = A.run_anc + (size_t)(g % A.Gcap) * Np;
-                count_run<NI, P>(acc, A, sp, W, L, g, i, nr, rst, ran, inv);
+                const int* rst = Q.lists.st + (size_t)(g % A.Gcap) * Np;
+                const int* ran = Q.lists.anc + (size_t)(g % A.Gcap) * Np;
+                count_run<NI, P>(acc, A, Q, W, L, g, i, nr, rst, ran, inv);
             }
         }
     }
@@ -1235,7 +1623,9 @@ __device__ __forceinline__ void count_body(const KArgs& A, int sp, int e0, const
 
 template <int NM, int P>
 __global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0, Windows Wn) {
-    count_body<NM, P>(A, A.sp, e0, Wn, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+    const int e = e0 + (int)blockIdx.y;
+    if (e < Wn.first || e >= A.E) return;
+    count_body<NM, P>(A, count_src_parity(A, A.sp, e), e, Wn.a[e], Wn.b[e], (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ------------------------------------------------------------------ k_row
@@ -1249,7 +1639,9 @@ __global__ __launch_bounds__(PF_BS) void k_row(KArgs A, long long s, int fuse, i
         extend_reg_body<NM, BIASED, EXACT, TREES>(A, s, fuse);
     } else {
         const int idx = (int)blockIdx.x - nb;
-        count_body<NM, 1, EXACT>(A, A.sp ^ 1, count_first, Wprev, idx % nb, idx / nb, nb);
+        const int e = count_first + idx / nb;
+        if (e < Wprev.first || e >= A.E) return;
+        count_body<NM, 1, EXACT>(A, count_src_parity(A, A.sp ^ 1, e), e, Wprev.a[e], Wprev.b[e], idx % nb, nb);
     }
 }
 
@@ -1268,16 +1660,14 @@ __global__ void k_count_fin(KArgs A) {
 #define PF_LEDGER_MAXT 1024   // largest workgroup the ledger code is launched with
 #define PF_LEDGER_NEW 64      // the newest generations (long run lists) are re-based by a whole workgroup each
 
-__device__ void ledger_update(const KArgs& A, int lb, int nlb, int G) {
+__device__ __forceinline__ void ledger_update(const KArgs& A, int lb, int nlb, int G, int g_ret, RunLists src, RunLists dst) {
     __shared__ int scnt[PF_LEDGER_PER * (PF_LEDGER_MAXT / 64)], sexc[PF_LEDGER_PER * (PF_LEDGER_MAXT / 64)];
     __shared__ int stot;
-    const Ctrl* c = A.ctrl;
     const long long Np = A.Np;
     const int* lo = A.lo + (size_t)(G % A.Gcap) * (Np + 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NT = (int)blockDim.x, NW = NT >> 6;
     const int NCNT = PF_LEDGER_PER * NW;                 // <= 128: scanned by one wavefront, two counts per lane
-    const int g_ret = c->g_retain;
     // ---- pass 1: workgroup per generation, newest PF_LEDGER_NEW generations (G itself: written by k_decide) ----
     // Compaction of a tile of PF_LEDGER_PER * blockDim.x runs with coalesced traffic only: element i of the tile
     // belongs to (round j, wavefront, lane) = (i / NT, (i % NT) / 64, i % 64).  All starts and ancestors of the tile
@@ -1289,9 +1679,11 @@ __device__ void ledger_update(const KArgs& A, int lb, int nlb, int G) {
     for (int k = 1 + lb; k < PF_LEDGER_NEW; k += nlb) {
         const int g = G - k;
         if (g < g_ret) break;
-        int* rst = A.run_st + (size_t)(g % A.Gcap) * Np;
-        int* ran = A.run_anc + (size_t)(g % A.Gcap) * Np;
-        const int nr = A.nruns[g % A.Gcap];
+        const int* rst = src.st + (size_t)(g % A.Gcap) * Np;
+        const int* ran = src.anc + (size_t)(g % A.Gcap) * Np;
+        int* wst = dst.st + (size_t)(g % A.Gcap) * Np;
+        int* wan = dst.anc + (size_t)(g % A.Gcap) * Np;
+        const int nr = src.nruns[g % A.Gcap];
         int out_base = 0;
         for (int tile0 = 0; tile0 < nr; tile0 += PF_LEDGER_PER * NT) {
             int ns[PF_LEDGER_PER], an[PF_LEDGER_PER], nx[PF_LEDGER_PER];
@@ -1343,22 +1735,24 @@ __device__ void ledger_update(const KArgs& A, int lb, int nlb, int G) {
                 const unsigned long long bal = __ballot(kp);
                 if (kp) {
                     const int pos = out_base + sexc[j * NW + wave] + __popcll(bal & ((1ULL << lane) - 1ULL));
-                    rst[pos] = ns[j];
-                    ran[pos] = an[j];
+                    wst[pos] = ns[j];
+                    wan[pos] = an[j];
                 }
             }
             out_base += stot;
             __syncthreads();                 // the count arrays are reused by the next tile
         }
-        if (tid == 0) A.nruns[g % A.Gcap] = out_base;
+        if (tid == 0) dst.nruns[g % A.Gcap] = out_base;
     }
     // ---- pass 2: wavefront per generation for everything older (short lists, no workgroup barriers) ----
     const int wl = lb * NW + wave;
     const int nwl = nlb * NW;
     for (int g = G - PF_LEDGER_NEW - wl; g >= g_ret; g -= nwl) {
-        int* rst = A.run_st + (size_t)(g % A.Gcap) * Np;
-        int* ran = A.run_anc + (size_t)(g % A.Gcap) * Np;
-        const int nr = A.nruns[g % A.Gcap];
+        const int* rst = src.st + (size_t)(g % A.Gcap) * Np;
+        const int* ran = src.anc + (size_t)(g % A.Gcap) * Np;
+        int* wst = dst.st + (size_t)(g % A.Gcap) * Np;
+        int* wan = dst.anc + (size_t)(g % A.Gcap) * Np;
+        const int nr = src.nruns[g % A.Gcap];
         int base = 0;
         for (int off = 0; off < nr; off += 64) {
             int i = off + lane;
@@ -1375,10 +1769,10 @@ __device__ void ledger_update(const KArgs& A, int lb, int nlb, int G) {
             unsigned long long bal = __ballot(keep);
             int pos = __popcll(bal & ((1ULL << lane) - 1ULL));
             // all 64 lanes loaded their inputs before anyone stores (stores depend on the ballot)
-            if (keep) { rst[base + pos] = ns; ran[base + pos] = anc; }
+            if (keep) { wst[base + pos] = ns; wan[base + pos] = anc; }
             base += __popcll(bal);
         }
-        if (lane == 0) A.nruns[g % A.Gcap] = base;
+        if (lane == 0) dst.nruns[g % A.Gcap] = base;
     }
 }
 
@@ -1388,43 +1782,199 @@ __device__ void ledger_update(const KArgs& A, int lb, int nlb, int G) {
 // maps of all retained generations onto the new slots (st' = lo[st], empty runs dropped).  Only k_count reads
 // these lists, so the whole maintenance lives on the counting stream, off the filter's critical path.
 // body of k_ledger for workgroup bx of nbt; `sp` = parity of the step whose resampling it follows up
+// run list of the generation Gx that ends with a resampling: its survivors, in slot order (start = lo[a], ancestor = a).
+// Position = survivors in earlier workgroups (blkcnt, counted where the offspring table was made) + rank inside this one.
+__device__ __forceinline__ void ledger_new_list(const KArgs& A, RunLists dst, const int* blkcnt, int nblocks, int bx, int Gx) {
+    const long long Np = A.Np;
+    const long long i = (long long)bx * PF_BS + threadIdx.x;
+    __shared__ int wsum[PF_BS / 64];
+    const int* lox = A.lo + (size_t)(Gx % A.Gcap) * (Np + 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int l0 = 0, l1 = 0;
+    if (i < Np) { l0 = lox[i]; l1 = lox[i + 1]; }
+    const bool surv = l1 > l0;
+    unsigned long long bal = __ballot(surv);
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __shared__ int sblk[1024];
+    for (int b = threadIdx.x; b < nblocks; b += PF_BS) sblk[b] = blkcnt[b];
+    __syncthreads();
+    int base = 0;
+    for (int b = 0; b < bx; ++b) base += sblk[b];
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    if (surv) {
+        int pos = base + __popcll(bal & ((1ULL << lane) - 1ULL));
+        dst.st[(size_t)(Gx % A.Gcap) * Np + pos] = l0;
+        dst.anc[(size_t)(Gx % A.Gcap) * Np + pos] = (int)i;
+    }
+    if (bx == nblocks - 1 && threadIdx.x == PF_BS - 1) {
+        int tot = base + __popcll(bal);           // base already holds the earlier wavefronts of this workgroup
+        dst.nruns[Gx % A.Gcap] = tot;
+    }
+}
+
 __device__ __forceinline__ void ledger_body(const KArgs& A, int sp, int nblocks, int bx, int nbt) {
     const Ctrl* c = A.ctrl;
     if (!c->step[sp].flag) return;
     const int Gx = c->step[sp].G;
+    const RunLists lists = run_lists(A, c->lver);       // the general kernels re-base in place
     if (bx >= nblocks) {
-        ledger_update(A, bx - nblocks, nbt - nblocks, Gx);
+        ledger_update(A, bx - nblocks, nbt - nblocks, Gx, c->g_retain, lists, lists);
         return;
     }
-    const long long Np = A.Np;
-    const long long i = (long long)bx * PF_BS + threadIdx.x;
-    {
-        // run list of the generation that ends here: its survivors, in slot order (start = lo[a], ancestor = a).
-        // Position = survivors in earlier workgroups (k_decide's blkcnt) + rank inside this workgroup.
-        __shared__ int wsum[PF_BS / 64];
-        const int* lox = A.lo + (size_t)(Gx % A.Gcap) * (Np + 1);
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        int l0 = 0, l1 = 0;
-        if (i < Np) { l0 = lox[i]; l1 = lox[i + 1]; }
-        const bool surv = l1 > l0;
-        unsigned long long bal = __ballot(surv);
-        if (lane == 0) wsum[wave] = __popcll(bal);
-        __shared__ int sblk[1024];
-        for (int b = threadIdx.x; b < nblocks; b += PF_BS) sblk[b] = A.blkcnt2[sp][b];
-        __syncthreads();
-        int base = 0;
-        for (int b = 0; b < bx; ++b) base += sblk[b];
-        for (int w = 0; w < wave; ++w) base += wsum[w];
-        if (surv) {
-            int pos = base + __popcll(bal & ((1ULL << lane) - 1ULL));
-            A.run_st[(size_t)(Gx % A.Gcap) * Np + pos] = l0;
-            A.run_anc[(size_t)(Gx % A.Gcap) * Np + pos] = (int)i;
-        }
-        if (bx == nblocks - 1 && threadIdx.x == PF_BS - 1) {
-            int tot = base + __popcll(bal);           // base already holds the earlier wavefronts of this workgroup
-            A.nruns[Gx % A.Gcap] = tot;
-        }
+    ledger_new_list(A, lists, A.blkcnt2[sp], nblocks, bx, Gx);
+}
+
+// ------------------------------------------------------------------ k_pipe: one launch per row
+// The single-launch pipeline of the register-tree kernels (one population, n <= 8, no look-ahead).  Launch s carries
+//   X(s)    workgroups [0, nb): extend the particles over row s.  On load they complete row s-1 themselves: decision
+//           (decide_row), offspring offsets, parent search, gather or normalisation -- nothing from k_decide is read;
+//   B(s-1)  one workgroup: the bookkeeping of row s-1 (log-likelihood, traces, generations of the count windows,
+//           posterior-scan offsets), published in Ctrl::ri[(s-1) & 3];
+//   L(s-2)  ledger upkeep after the resampling of row s-2: reads the run lists in force, writes the other copy;
+//   C(s-2)  the lagged counts of row s-2 from the lists in force for that row and its slot of the state ring.
+// What a role reads was written by an earlier launch (stream order) or is private to it; nothing waits inside the
+// launch.  The decide kernel and its two dependent kernel boundaries per row are gone from the critical path.
+struct PipeLaunch {
+    PipeRow row;
+    int nb;                // extend workgroups
+    int b_slot;            // ring slot of the row whose bookkeeping is due (-1: none)
+    long long b_row;       // its row index (traces)
+    double b_pos;          // its end position
+    int b_set_cur;         // >= 0: the general kernels take over after this launch, with this state slot
+    int lc_slot;           // ring slot of the row whose ledger upkeep and counts are due (-1: none)
+    int live_slot;         // newest complete slot of the per-slot record counters (ring-overwrite check)
+    int nL;                // ledger workgroups
+};
+
+__global__ void k_pipe_seed(KArgs A, int slot) {
+    Ctrl* c = A.ctrl;
+    Ctrl::RowInfo& r = c->ri[slot];
+    r.n_res = c->n_resample; r.gen = c->gen; r.flag = 0; r.lver = c->lver; r.g_retain = c->g_retain; r.first = A.E;
+    r.inv_T = 1.0; r.T = 1.0; r.S1 = 0.0; r.u = 0.0; r.pos = c->cur_pos;
+}
+
+template <bool BIASED>
+__device__ __forceinline__ void pipe_bookkeeping(const KArgs& A, const PipeLds& q, const PipeLaunch& PL, const Windows& W) {
+    Ctrl* c = A.ctrl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = PF_BS / 64;
+    const int E = A.E, nc = A.nc, ng = (nc + 63) / 64;
+    const int slot = PL.b_slot;
+    const long long n_res = c->n_resample;        // as the bookkeeping of the previous row left them (previous launch)
+    const int G = c->gen;
+    RowDecision d = decide_row<false>(A, q, slot, n_res);
+    __syncthreads();
+    // exclusive offsets of the posterior scan of the row's wavefronts: the counts turn differences of that scan into
+    // the posterior mass of a particle's descendants
+    const double* cpp = A.rg_cpp + (size_t)slot * nc;
+    for (int g = wave; g < ng; g += nwaves) {
+        int ch = g * 64 + lane;
+        double vq = ch < nc ? cpp[ch] : 0.0;
+        double scq = wave_hs_scan(vq, lane);
+        if (ch < nc) q.pmx[ch] = scq;
+        if (lane == 63) q.l2_post[g] = scq;
     }
+    __syncthreads();
+    for (int ch = tid; ch < nc; ch += PF_BS) {
+        double runp = 0.0;
+        for (int g = 0; g < ch / 64; ++g) runp = runp + q.l2_post[g];
+        double offp = (ch % 64 == 0) ? 0.0 : q.pmx[ch - 1];
+        A.rg_coffp[(size_t)slot * nc + ch] = runp + offp;
+    }
+    Ctrl::RowInfo& r = c->ri[slot];
+    // generations that hold the ends of the row's count windows (both monotone along the sweep)
+    // (the windows are a kernel argument: indexed with a uniform epoch so that they are read with scalar loads)
+    for (int e = 0; e < E; ++e) {
+        const double wa = W.a[e], wb = W.b[e];
+        if (tid != e) continue;
+        int g = c->g_lo[e];
+        while (g < G && A.gen_x0[(g + 1) % A.Gcap] <= wa) ++g;
+        c->g_lo[e] = g;
+        int h = c->g_hi[e];
+        if (e >= W.first) {
+            if (h < g) h = g;
+            while (h < G && A.gen_x0[(h + 1) % A.Gcap] < wb) ++h;
+            c->g_hi[e] = h;
+        }
+        r.g_lo[e] = g; r.g_hi[e] = h; r.wa[e] = wa; r.wb[e] = wb;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int gr = c->g_lo[0];
+        for (int e = 1; e < E; ++e) gr = c->g_lo[e] < gr ? c->g_lo[e] : gr;
+        c->g_retain = gr;
+        c->delayed_opp += W.b[E - 1] - W.a[E - 1];
+        if (BIASED) {
+            long long npend = 0;      // update_delayed_weight_count (count.cpp:395-397)
+            for (int k = 0; k < nc; ++k) npend += A.rg_dpend[(size_t)slot * nc + k];
+            c->delayed_count += (double)npend * (W.b[E - 1] - W.a[E - 1]);
+        }
+        c->first_epoch = W.first;
+        c->count_active = W.first < E;
+        if (W.first < E) c->pending_fin = 1;
+        c->nbx_used = A.nbx;
+        if (!(d.T > 0.0)) c->err = ERR_ZERO_PROB;
+        double logl = c->logl + dlog(d.T);
+        c->logl = logl;
+        const long long row = PL.b_row;
+        A.tr_T[row] = d.T; A.tr_ess[row] = d.ess; A.tr_flag[row] = d.flag; A.tr_logl[row] = logl;
+        c->cur_pos = PL.b_pos;
+        c->T = d.T; c->inv_T = d.inv; c->S1 = d.S1; c->S2 = d.S2; c->ess = d.ess; c->u = d.u; c->flag = 0;
+        r.T = d.T; r.inv_T = d.inv; r.S1 = d.S1; r.u = d.u; r.pos = PL.b_pos;
+        r.n_res = n_res; r.gen = G; r.flag = d.flag; r.g_retain = gr; r.first = W.first; r.lver = c->lver;
+        if (d.flag) {
+            int ev = (int)n_res;
+            if (ev < A.max_trace_events) A.ev_seg[ev] = (int)row;
+            c->gen = G + 1;
+            A.gen_x0[(G + 1) % A.Gcap] = PL.b_pos;
+            c->n_resample = n_res + 1;
+            c->lver ^= 1;                    // the ledger upkeep of this row (next launch) writes the other copy
+            if (G + 1 - gr >= A.Gcap - 1) c->err = ERR_GEN_OVERFLOW;
+            if (A.rec_trees && G + 2 >= A.Gcap) c->err = ERR_GEN_OVERFLOW;      // -arg keeps every generation
+        }
+        c->gen_prev = c->gen; c->nres_prev = c->n_resample;
+        if (PL.b_set_cur >= 0) c->cur = PL.b_set_cur;
+    }
+}
+
+template <int NM, bool BIASED, bool EXACT, bool TREES>
+__global__ __launch_bounds__(PF_BS) void k_pipe(KArgs A, long long s, PipeLaunch PL, Windows Wb) {
+    const int bx = (int)blockIdx.x;
+    const int nb = PL.nb;
+    if (bx < nb) {
+        if (PL.row.extend || PL.row.complete) extend_reg_body<NM, BIASED, EXACT, TREES, true>(A, s, 0, PL.row);
+        return;
+    }
+    if (bx == nb) {
+        if (PL.b_slot < 0) return;
+        extern __shared__ double smem[];
+        PipeLds q = pipe_carve(smem + (2 * PF_EPAD + A.E + 2 * PF_BIAS_MAX + 3), A.nc);
+        pipe_bookkeeping<BIASED>(A, q, PL, Wb);
+        return;
+    }
+    if (PL.lc_slot < 0) return;
+    const Ctrl* c = A.ctrl;
+    const Ctrl::RowInfo& r = c->ri[PL.lc_slot];
+    const int lb = bx - (nb + 1);
+    if (lb < PL.nL) {
+        if (!r.flag) return;
+        const RunLists src = run_lists(A, r.lver), dst = run_lists(A, r.lver ^ 1);
+        if (lb < nb) ledger_new_list(A, dst, A.rg_blkcnt + (size_t)PL.lc_slot * A.nbx, nb, lb, r.gen);
+        else ledger_update(A, lb - nb, PL.nL - nb, r.gen, r.g_retain, src, dst);
+        return;
+    }
+    const int idx = lb - PL.nL;
+    const int e = r.first + idx / nb;
+    if (e >= A.E) return;
+    const DState st = state_slot(A, PL.lc_slot);
+    CountSrc Q;
+    Q.w = st.w_post; Q.S = st.S; Q.xm = st.x_mark; Q.ml = st.mark_limit;
+    Q.widx = A.rg_widx + (size_t)PL.lc_slot * A.Np;
+    Q.widx_live = A.rg_widx + (size_t)PL.live_slot * A.Np;
+    Q.scanp = A.rg_scanp + (size_t)PL.lc_slot * A.Np;
+    Q.offp = A.rg_coffp + (size_t)PL.lc_slot * A.nc;
+    Q.lists = run_lists(A, r.lver);
+    Q.inv = r.inv_T; Q.G = r.gen; Q.g_lo = r.g_lo[e]; Q.g_hi = r.g_hi[e];
+    count_body<NM, 1, EXACT>(A, Q, e, r.wa[e], r.wb[e], idx % nb, nb);
 }
 
 __global__ __launch_bounds__(PF_BS) void k_ledger(KArgs A, int nblocks) {
@@ -1457,7 +2007,7 @@ __global__ __launch_bounds__(PF_BS) void k_resample(KArgs A, long long s, int nb
     const double inv = c->inv_T;
     if (!c->flag) {
         if (i >= Np) return;
-        DState& st = A.st[c->cur];
+        const DState st = state_slot(A, __builtin_amdgcn_readfirstlane(c->cur));
         st.w_post[i] *= inv;
         st.w_pilot[i] *= inv;
         return;
@@ -1465,8 +2015,8 @@ __global__ __launch_bounds__(PF_BS) void k_resample(KArgs A, long long s, int nb
     if (i >= Np) return;
     const int n = A.n;
     const int G = c->gen - 1;                  // the generation that ends here (k_decide already advanced gen)
-    const DState& src = A.st[c->cur ^ 1];
-    DState& dst = A.st[c->cur];
+    const DState src = state_slot(A, __builtin_amdgcn_readfirstlane(c->cur ^ 1));
+    const DState dst = state_slot(A, __builtin_amdgcn_readfirstlane(c->cur));
     const int* lo = A.lo + (size_t)(G % A.Gcap) * (Np + 1);
     const double pos = c->cur_pos;
     // ---- role 1: old slot i closes its stretch if it has offspring ----
@@ -1553,7 +2103,7 @@ __global__ __launch_bounds__(PF_BS) void k_partials(KArgs A) {
     const long long p = (long long)blockIdx.x * PF_BS + threadIdx.x;
     const bool active = p < A.Np;
     const int lane = threadIdx.x & 63;
-    const DState& st = A.st[c->cur];
+    const DState st = state_slot(A, __builtin_amdgcn_readfirstlane(c->cur));
     double w_post = active ? st.w_post[p] : 0.0;
     double w_pilot = active ? st.w_pilot[p] : 0.0;
     if (active) {
@@ -1705,7 +2255,7 @@ __global__ __launch_bounds__(PF_BS) void k_lookahead(KArgs A, long long row) {
     const int lane = threadIdx.x & 63;
     double w_pilot = 0.0;
     if (active) {
-        DState& st = A.st[c->cur];
+        const DState st = state_slot(A, __builtin_amdgcn_readfirstlane(c->cur));
         Lane ln = make_lane(A, m, p);
         for (int r = 0; r < n - 1; ++r) {
             LS(ln, r) = st.S[(size_t)r * A.Np + p];
@@ -1948,6 +2498,9 @@ struct pf_handle {
     bool force_lds = false;       // pf_params.debug & PF_DEBUG_FORCE_LDS: use the LDS-tree kernel for every n (testing)
     bool no_fuse = false;         // PF_DEBUG_NO_FUSE: always run k_resample as its own kernel (testing)
     bool no_count = false;        // PF_DEBUG_NO_COUNT: no lagged counting, no ledger upkeep (profiling)
+    bool two_launch_rows = false; // PF_DEBUG_TWO_LAUNCH: the round-1 row pipeline (k_row + k_decide_ledger) instead of k_pipe
+    bool pipe = false;            // the single-launch pipeline applies (one population, n <= 8; rings allocated)
+    size_t smem_pipe = 0;
     // timing
     int timing_period = 0;
     struct Span { hipEvent_t a, b; int k; };
@@ -2088,6 +2641,7 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     h->force_lds = (p->debug & PF_DEBUG_FORCE_LDS) != 0;
     h->no_fuse = (p->debug & PF_DEBUG_NO_FUSE) != 0;
     h->no_count = (p->debug & PF_DEBUG_NO_COUNT) != 0;
+    h->two_launch_rows = (p->debug & PF_DEBUG_TWO_LAUNCH) != 0;
     h->h_lags.assign(m->lags, m->lags + E);
     h->h_counted_to.assign(E, 0.0);
     h->h_L = m->loci_length;
@@ -2148,30 +2702,34 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
         hipMemcpy(dad, m->application_delays, E * 8, hipMemcpyHostToDevice);
         A.app_delays = dad;
     }
-    for (int b = 0; b < 2; ++b) {
-        rc |= dalloc(h, &A.st[b].S, (size_t)(n - 1) * Np);
-        rc |= dalloc(h, &A.st[b].C, (size_t)2 * (n - 1) * Np);
-        rc |= dalloc(h, &A.st[b].w_post, Np);
-        rc |= dalloc(h, &A.st[b].w_pilot, Np);
-        rc |= dalloc(h, &A.st[b].next_base, Np);
-        rc |= dalloc(h, &A.st[b].x_mark, Np);
-        rc |= dalloc(h, &A.st[b].Ltree, Np);
-        rc |= dalloc(h, &A.st[b].mark_limit, Np);
+    h->pipe = P == 1 && n <= 8 && Np <= 131072;      // beyond that the decision tables outgrow the default dynamic LDS
+    {
+        const size_t K = h->pipe ? 4 : 2;               // copies of the particle state (KArgs::st0)
+        A.nslots = (int)K;
+        DState& st = A.st0;
+        rc |= dalloc(h, &st.S, K * (size_t)(n - 1) * Np);
+        rc |= dalloc(h, &st.C, K * (size_t)2 * (n - 1) * Np);
+        rc |= dalloc(h, &st.w_post, K * Np);
+        rc |= dalloc(h, &st.w_pilot, K * Np);
+        rc |= dalloc(h, &st.next_base, K * Np);
+        rc |= dalloc(h, &st.x_mark, K * Np);
+        rc |= dalloc(h, &st.Ltree, K * Np);
+        rc |= dalloc(h, &st.mark_limit, K * Np);
         if (P > 1) {
-            rc |= dalloc(h, &A.st[b].Pn, (size_t)(n - 1) * Np);
-            rc |= dalloc(h, &A.st[b].nm, Np);
-            rc |= dalloc(h, &A.st[b].Mt, (size_t)PF_MMAX * Np);
-            rc |= dalloc(h, &A.st[b].Mb, (size_t)PF_MMAX * Np);
-            rc |= dalloc(h, &A.st[b].Mq, (size_t)PF_MMAX * Np);
+            rc |= dalloc(h, &st.Pn, K * (size_t)(n - 1) * Np);
+            rc |= dalloc(h, &st.nm, K * Np);
+            rc |= dalloc(h, &st.Mt, K * (size_t)PF_MMAX * Np);
+            rc |= dalloc(h, &st.Mb, K * (size_t)PF_MMAX * Np);
+            rc |= dalloc(h, &st.Mq, K * (size_t)PF_MMAX * Np);
         }
-        if (m->n_rate_segments > 0) rc |= dalloc(h, &A.st[b].ridx, Np);
+        if (m->n_rate_segments > 0) rc |= dalloc(h, &st.ridx, K * Np);
         if (m->n_bias_heights > 0 || m->n_rate_segments > 0) {
-            rc |= dalloc(h, &A.st[b].total_delayed, Np);
-            rc |= dalloc(h, &A.st[b].dcount, Np);
-            rc |= dalloc(h, &A.st[b].dpos, (size_t)PF_DCAP * Np);
-            rc |= dalloc(h, &A.st[b].dfac, (size_t)PF_DCAP * Np);
-            rc |= dalloc(h, &A.st[b].ddelta, (size_t)PF_DCAP * Np);
-            rc |= dalloc(h, &A.st[b].dk, (size_t)PF_DCAP * Np);
+            rc |= dalloc(h, &st.total_delayed, K * Np);
+            rc |= dalloc(h, &st.dcount, K * Np);
+            rc |= dalloc(h, &st.dpos, K * (size_t)PF_DCAP * Np);
+            rc |= dalloc(h, &st.dfac, K * (size_t)PF_DCAP * Np);
+            rc |= dalloc(h, &st.ddelta, K * (size_t)PF_DCAP * Np);
+            rc |= dalloc(h, &st.dk, K * (size_t)PF_DCAP * Np);
         }
     }
     if (p->flags & 1) {
@@ -2217,6 +2775,18 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     rc |= dalloc(h, &A.run_anc, (size_t)A.Gcap * Np);
     rc |= dalloc(h, &A.nruns, A.Gcap);
     const size_t nc = (size_t)((Np + 63) / 64);
+    A.nc = (int)nc;
+    if (h->pipe) {
+        rc |= dalloc(h, &A.run_st2, (size_t)A.Gcap * Np);
+        rc |= dalloc(h, &A.run_anc2, (size_t)A.Gcap * Np);
+        rc |= dalloc(h, &A.nruns2, A.Gcap);
+        rc |= dalloc(h, &A.rg_scan1, 4 * (size_t)Np); rc |= dalloc(h, &A.rg_scan1m, 4 * (size_t)Np);
+        rc |= dalloc(h, &A.rg_scanp, 4 * (size_t)Np); rc |= dalloc(h, &A.rg_widx, 4 * (size_t)Np);
+        rc |= dalloc(h, &A.rg_cpost, 4 * nc); rc |= dalloc(h, &A.rg_csq, 4 * nc); rc |= dalloc(h, &A.rg_cpil, 4 * nc);
+        rc |= dalloc(h, &A.rg_cpp, 4 * nc); rc |= dalloc(h, &A.rg_cmx1, 4 * nc); rc |= dalloc(h, &A.rg_coffp, 4 * nc);
+        rc |= dalloc(h, &A.rg_dpend, 4 * nc); rc |= dalloc(h, &A.rg_blkcnt, 4 * (size_t)h->nblocks);
+        h->smem_pipe = ((size_t)(2 * PF_EPAD + E + 2 * PF_BIAS_MAX + 3) + pipe_lds_doubles((int)nc)) * 8;
+    }
     rc |= dalloc(h, &A.chunk_post, nc); rc |= dalloc(h, &A.chunk_sq, nc); rc |= dalloc(h, &A.chunk_pil, nc);
     rc |= dalloc(h, &A.scan1, Np); rc |= dalloc(h, &A.chunk_off, nc); rc |= dalloc(h, &A.l2scan, nc);
     rc |= dalloc(h, &A.scan1m, Np); rc |= dalloc(h, &A.chunk_mx1, nc);
@@ -2638,10 +3208,87 @@ static int run_single_stream(pf_handle* h, long long s_begin, long long s_end) {
     return 0;
 }
 
+// The single-launch pipeline (k_pipe): per row ONE launch on one stream, see the kernel's header.  Rows [s_begin, s_end)
+// are followed by two flush launches (completion of the last row with the bookkeeping / ledger / counts still owed)
+// after which the handle's state is in the form the general kernels expect.
+template <int NM, bool BIASED>
+static void launch_pipe(pf_handle* h, long long s, const PipeLaunch& PL, int ncount_wg, const Windows& Wb) {
+    const dim3 grid((unsigned)(PL.nb + 1 + PL.nL + ncount_wg)), blk(PF_BS);
+    if (h->A.rec_trees)
+        hipLaunchKernelGGL((k_pipe<NM, BIASED, false, true>), grid, blk, h->smem_pipe, h->stream, h->A, s, PL, Wb);
+    else if (h->n == NM)
+        hipLaunchKernelGGL((k_pipe<NM, BIASED, true, false>), grid, blk, h->smem_pipe, h->stream, h->A, s, PL, Wb);
+    else
+        hipLaunchKernelGGL((k_pipe<NM, BIASED, false, false>), grid, blk, h->smem_pipe, h->stream, h->A, s, PL, Wb);
+}
+
+static int run_pipeline(pf_handle* h, long long s_begin, long long s_end) {
+    if (s_begin >= s_end) return 0;
+    const bool biased = h->A.n_bias > 0 || h->A.g_K > 0;
+    const int nb = h->nblocks, E = h->E;
+    // whatever the two-stream kernels of an earlier call left on the counting stream must be done first
+    if (h->ev_cnt) { hipStreamWaitEvent(h->stream, h->ev_cnt, 0); h->ev_cnt = nullptr; }
+    hipLaunchKernelGGL(k_pipe_seed, dim3(1), dim3(1), 0, h->stream, h->A, (int)((s_begin + 3) & 3));
+    Windows W1 = no_windows(h), W2 = no_windows(h);      // windows of rows s-1 and s-2
+    long long last = s_begin - 1;                        // last row extended so far
+    const int nL_full = nb + std::max(16, std::min(PF_LEDGER_BLOCKS, 192));
+    auto dispatch = [&](long long s, const PipeLaunch& PL, int ncount_wg, const Windows& Wb) {
+        if (h->n <= 4 && biased) launch_pipe<4, true>(h, s, PL, ncount_wg, Wb);
+        else if (h->n <= 4) launch_pipe<4, false>(h, s, PL, ncount_wg, Wb);
+        else if (biased) launch_pipe<8, true>(h, s, PL, ncount_wg, Wb);
+        else launch_pipe<8, false>(h, s, PL, ncount_wg, Wb);
+    };
+    // one launch: extend row s (or only complete row s-1 / nothing), bookkeeping of row s-1, ledger + counts of row s-2
+    auto launch = [&](long long s, bool extend, bool have_b, bool have_lc, int set_cur) -> int {
+        PipeLaunch PL;
+        memset(&PL, 0, sizeof(PL));
+        PL.nb = nb;
+        PL.row.extend = extend ? 1 : 0;
+        PL.row.complete = (s > s_begin && s - 1 <= last && (extend || have_b)) ? 1 : 0;
+        if (!extend && !have_b) PL.row.complete = 0;
+        PL.row.slot_prev = PL.row.complete ? (int)((s - 1) & 3) : -1;
+        PL.row.slot_out = (int)(s & 3);
+        PL.row.pos_prev = s > s_begin ? seg_pos(h, s - 1) : 0.0;
+        PL.b_slot = have_b ? (int)((s - 1) & 3) : -1;
+        PL.b_row = s - 1;
+        PL.b_pos = have_b ? seg_pos(h, s - 1) : 0.0;
+        PL.b_set_cur = set_cur;
+        PL.lc_slot = (have_lc && !h->no_count) ? (int)((s - 2) & 3) : -1;
+        PL.live_slot = (int)((s - 1) & 3);
+        PL.nL = PL.lc_slot >= 0 ? nL_full : 0;
+        const int ncount_wg = (PL.lc_slot >= 0 && W2.first < E) ? nb * (E - W2.first) : 0;
+        if (ncount_wg > 0) h->fin_pending = true;
+        const bool t = extend && timing_on(h, s);
+        {
+            Timed tm(h, 0, t);
+            if (!extend) h->k_launches[0] -= 1;          // flush launches are not rows
+            dispatch(s, PL, ncount_wg, W1);
+        }
+        return check_launch("k_pipe");
+    };
+    long long s = s_begin;
+    for (; s < s_end; ++s) {
+        if (launch(s, true, s > s_begin, s > s_begin + 1, -1)) return -1;
+        last = s;
+        W2 = W1;
+        W1 = host_windows(h, seg_pos(h, s), false);
+        h->step_windows = W1;
+        h->seg_done = s + 1;
+        if ((s & 1023) == 1023) trim_spans(h);
+        if (h->h_seg_start[s] + h->h_seg_len[s] >= h->h_L) { ++s; break; }      // smcsmc.cpp:353-356
+    }
+    // flush 1: complete row `last` into the next ring slot (the general kernels continue from there), its bookkeeping,
+    // ledger + counts of the row before it; flush 2: ledger + counts of row `last`
+    if (launch(last + 1, false, true, last - 1 >= s_begin, (int)((last + 1) & 3))) return -1;
+    W2 = W1;
+    if (launch(last + 2, false, false, true, -1)) return -1;
+    return 0;
+}
+
 int pf_run(pf_handle* h, int64_t s_begin, int64_t s_end) {
     HIPCHK(hipSetDevice(h->device));
     if (s_begin < 0 || s_end > h->n_segs) { g_err = "segment range out of bounds"; return -1; }
-    if (extend_can_fuse(h)) return run_single_stream(h, s_begin, s_end);
+    if (extend_can_fuse(h)) return (h->pipe && !h->two_launch_rows) ? run_pipeline(h, s_begin, s_end) : run_single_stream(h, s_begin, s_end);
     for (long long s = s_begin; s < s_end; ++s) {
         h->step_windows = host_windows(h, seg_pos(h, s), false);
         h->A.sp = (int)(s & 1);
@@ -2744,7 +3391,7 @@ int pf_get_migrations(pf_handle* h, int32_t* n_events, double* times, int8_t* br
     if (h->P < 2) { g_err = "pf_get_migrations: the model has one population"; return -1; }
     Ctrl c;
     HIPCHK(hipMemcpy(&c, h->A.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
-    const DState& st = h->A.st[c.cur];
+    const DState st = state_slot(h->A, c.cur);
     const long long Np = h->Np;
     const int n = h->n;
     std::vector<int> nm(Np);
@@ -2794,7 +3441,7 @@ int pf_get_particles(pf_handle* h, double* w_post, double* w_pilot, double* heig
     if (pf_sync(h)) return -1;
     Ctrl c;
     HIPCHK(hipMemcpy(&c, h->A.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
-    const DState& st = h->A.st[c.cur];
+    const DState st = state_slot(h->A, c.cur);
     const long long Np = h->Np;
     const int n = h->n;
     if (w_post) HIPCHK(hipMemcpy(w_post, st.w_post, Np * 8, hipMemcpyDeviceToHost));
@@ -2866,7 +3513,7 @@ int64_t pf_sample_tree_events(pf_handle* h, int32_t* kind, double* pos, double* 
     // the one-particle systematic draw of resample(..., NULL, 1): the particle whose cumulative pilot weight
     // (pilotWeight(), pc.cpp:256-262) passes U * total
     std::vector<double> w(Np);
-    HIPCHK(hipMemcpy(w.data(), h->A.st[c.cur].w_pilot, Np * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(w.data(), state_slot(h->A, c.cur).w_pilot, Np * 8, hipMemcpyDeviceToHost));
     double total = 0.0;
     for (double v : w) total += v;
     const double u = philox_uniform_host((unsigned long long)h->A.seed, 0xFFFFFFFFu, 1, (unsigned long long)c.n_resample);
@@ -2917,6 +3564,23 @@ int64_t pf_sample_tree_events(pf_handle* h, int32_t* kind, double* pos, double* 
 }
 
 int pf_set_timing(pf_handle* h, int period) { h->timing_period = period; return 0; }
+
+// profiling builds (-DPF_STAMPS): wall-clock stamps (100 MHz) of the phases of the extend workgroups, one set per row and
+// wavefront; a regular build records nothing
+int pf_debug_stamps(pf_handle* h, int64_t rows, uint64_t* out) {
+    HIPCHK(hipSetDevice(h->device));
+    if (rows > 0 && !out) {
+        unsigned long long* buf = nullptr;
+        if (dalloc(h, &buf, (size_t)rows * h->A.nc * 16)) return -1;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->A.stamps = buf; h->A.stamp_rows = rows;
+        return 0;
+    }
+    if (!h->A.stamps) { g_err = "pf_debug_stamps: not enabled"; return -1; }
+    if (pf_sync(h)) return -1;
+    HIPCHK(hipMemcpy(out, h->A.stamps, (size_t)std::min<long long>(rows, h->A.stamp_rows) * h->A.nc * 16 * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
 
 int pf_get_kernel_time(pf_handle* h, int k, double* ms, int64_t* launches) {
     if (k < 0 || k > 3) return -1;
@@ -3012,8 +3676,8 @@ static int test_reduce_impl(const double* x, int64_t n, double* out_sum, double*
     rc |= pf_load_segments(h, &sg);
     rc |= pf_init_prior(h, 0.0);
     if (!rc) {
-        hipMemcpyAsync(h->A.st[0].w_post, x, n * 8, hipMemcpyHostToDevice, h->stream);
-        hipMemcpyAsync(h->A.st[0].w_pilot, x, n * 8, hipMemcpyHostToDevice, h->stream);
+        hipMemcpyAsync(h->A.st0.w_post, x, n * 8, hipMemcpyHostToDevice, h->stream);
+        hipMemcpyAsync(h->A.st0.w_pilot, x, n * 8, hipMemcpyHostToDevice, h->stream);
         hipLaunchKernelGGL(k_partials, dim3(h->nblocks), dim3(PF_BS), 0, h->stream, h->A);
         // override u by running k_decide in mode 0 and then patching: simpler -- write u after the fact
         hipLaunchKernelGGL(k_decide, dim3(h->nblocks + 1), dim3(PF_BS), 0, h->stream, h->A, (long long)0, lo ? 0 : 1, no_windows(h), h->nblocks);
@@ -3060,8 +3724,7 @@ int pf_load_lookahead(pf_handle* h, const pf_lookahead* la) {
     rc |= dalloc(h, &nd, S); rc |= dalloc(h, &didx, (size_t)S * D * 4); rc |= dalloc(h, &ddist, (size_t)S * D * 2);
     rc |= dalloc(h, &split, S); rc |= dalloc(h, &sal, (size_t)S * n); rc |= dalloc(h, &sk, S);
     rc |= dalloc(h, &q, Q); rc |= dalloc(h, &tbl, (size_t)n * Q);
-    for (int b = 0; b < 2; ++b)
-        if (!A.st[b].lookahead) rc |= dalloc(h, &A.st[b].lookahead, h->Np);
+    if (!A.st0.lookahead) rc |= dalloc(h, &A.st0.lookahead, (size_t)A.nslots * h->Np);
     if (rc) return -1;
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(fsd, la->first_singleton_distance, (size_t)S * n * 8, hipMemcpyHostToDevice));
@@ -3075,8 +3738,8 @@ int pf_load_lookahead(pf_handle* h, const pf_lookahead* la) {
     HIPCHK(hipMemcpy(sk, la->split_count, (size_t)S * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(q, la->quantiles, (size_t)Q * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(tbl, la->tbl_lengths, (size_t)n * Q * 8, hipMemcpyHostToDevice));
-    std::vector<double> ones(h->Np, 1.0);
-    for (int b = 0; b < 2; ++b) HIPCHK(hipMemcpy(A.st[b].lookahead, ones.data(), h->Np * 8, hipMemcpyHostToDevice));
+    std::vector<double> ones((size_t)A.nslots * h->Np, 1.0);
+    HIPCHK(hipMemcpy(A.st0.lookahead, ones.data(), ones.size() * 8, hipMemcpyHostToDevice));
     A.apf = la->level; A.la_D = D; A.la_Q = Q;
     A.la_fsd = fsd; A.la_rmr = rmr; A.la_unph = unph; A.la_nd = nd; A.la_didx = didx; A.la_ddist = ddist;
     A.la_split = split; A.la_salleles = sal; A.la_sk = sk; A.la_q = q; A.la_tbl = tbl;

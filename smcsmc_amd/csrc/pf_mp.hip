@@ -59,7 +59,7 @@ __device__ __forceinline__ void mp_report(const KArgs& A, const MLane& ml) {
 __device__ __forceinline__ double piece_ref(unsigned pstart, unsigned npieces) {
     return __longlong_as_double((long long)((unsigned long long)pstart | ((unsigned long long)npieces << 32)));
 }
-__device__ __forceinline__ void store_mp_state(const KArgs& A, DState& st, const Lane& ln, const MLane& ml, long long p) {
+__device__ __forceinline__ void store_mp_state(const KArgs& A, const DState& st, const Lane& ln, const MLane& ml, long long p) {
     const int n = A.n;
     for (int r = 0; r < n - 1; ++r) st.Pn[(size_t)r * A.Np + p] = LPn(ml, r);
     st.nm[p] = ml.nm;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(PF_BS) void k_init_mp(KArgs A, double initial_posit
     if (p == 0) {
         Ctrl* c = A.ctrl;
         c->cur_pos = initial_position;
-        c->logl = 0; c->inv_T = 1; c->T = 1; c->flag = 0; c->cur = 0; c->gen = 0; c->n_resample = 0;
+        c->logl = 0; c->inv_T = 1; c->T = 1; c->flag = 0; c->cur = 0; c->gen = 0; c->n_resample = 0; c->lver = 0;
         c->first_epoch = A.E; c->err = 0; c->delayed_opp = 0; c->delayed_count = 0; c->count_active = 0; c->end_seq = 0;
         c->g_retain = 0; c->pending_fin = 0; c->nbx_used = A.nbx; c->gen_prev = 0; c->nres_prev = 0;
         for (int e = 0; e < A.E; ++e) { c->counted_to[e] = 0; c->update_to[e] = 0; c->g_lo[e] = 0; c->g_hi[e] = 0; }
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(PF_BS) void k_init_mp(KArgs A, double initial_posit
     });
     mp_report(A, ml);
     double nb = sample_next_base_guided(ln, 0.0, A.g_K, A.g_pos, A.g_rho, 0);
-    DState& st = A.st[0];
+    const DState st = A.st0;
     for (int r = 0; r < n - 1; ++r) {
         st.S[(size_t)r * A.Np + p] = LS(ln, r);
         st.C[(size_t)(2 * r) * A.Np + p] = LC(ln, r, 0);
@@ -122,8 +122,8 @@ __global__ __launch_bounds__(PF_BS) void k_init_mp(KArgs A, double initial_posit
     st.x_mark[p] = 0.0;
     st.Ltree[p] = ln.Ltree;
     st.mark_limit[p] = A.E - 1;
-    if (A.n_bias > 0 || A.g_K > 0) { A.st[0].total_delayed[p] = 1.0; A.st[0].dcount[p] = 0; }
-    if (A.g_K > 0) A.st[0].ridx[p] = 0;
+    if (A.n_bias > 0 || A.g_K > 0) { A.st0.total_delayed[p] = 1.0; A.st0.dcount[p] = 0; }
+    if (A.g_K > 0) A.st0.ridx[p] = 0;
     A.rng_ctr[p] = ln.ctr;
     A.ebuf[p] = ln.ebuf;
     A.widx[p] = widx;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
     __syncthreads();
     const Ctrl* c = A.ctrl;
     const int n = A.n;
-    const int cur = c->cur;
+    const int cur = __builtin_amdgcn_readfirstlane(c->cur);
     const long long p = (long long)blockIdx.x * PF_BS + threadIdx.x;
     const bool active = p < A.Np;
     const int lane = threadIdx.x & 63;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
     const bool biased = BIASED && (A.n_bias > 0 || guided);          // a guide alone runs with one band of strength 1
     bool has_pending = false;
     if (active) {
-        DState& st = A.st[cur];
+        const DState st = state_slot(A, cur);
         Lane ln = make_lane(A, m, p);
         MLane ml = make_mlane(A, mm);
         DStore ds;

@@ -6,6 +6,7 @@
 #include <cstdint>
 
 #define PF_EMAX 64
+#define PF_MMAX_SLOT 96       // = PF_MMAX of pf_mp.h: migration events per local tree (stride of the per-event state arrays)
 #define PF_DCAP 32            // pending delayed factors per particle (the reference's heap is unbounded)
 #define PF_BIAS_MAX 8         // interior bias heights
 #define PF_DECIDE_TAB 16384   // offspring / parent tables fit LDS (16-bit entries) up to this many particles
@@ -65,6 +66,22 @@ struct Ctrl {
     struct StepInfo { double inv_T; int G; int flag; } step[2];
     int gen_prev;          // generation index as of the end of the last k_resample (stable during k_decide)
     int nbx_used;
+    int lver;              // which of the two copies of the run lists is in force (the single-launch pipeline writes the
+                           // re-based lists into the other copy; every other kernel updates them in place)
+    // Single-launch row pipeline (k_pipe): everything a later launch needs to know about row r, in slot r & 3.
+    // Written by the bookkeeping workgroup of launch r + 1, read by launches r + 2 and r + 3.
+    struct RowInfo {
+        double T, inv_T, S1, u, pos;
+        long long n_res;       // resampling events before this row's decision (= index of its uniform)
+        int gen;               // generation the row's particles belong to
+        int flag;              // the row ended with a resampling
+        int g_retain, first;
+        int lver;              // run-list copy in force for this row's counts (before its own re-basing)
+        int pad;
+        double wa[PF_EMAX], wb[PF_EMAX];   // count windows of the row (count.cpp:363-385)
+        int g_lo[PF_EMAX], g_hi[PF_EMAX];
+    } ri[4];
+    double last1[4];       // pilot scan value at the last particle of the row in ring slot k (= oracle incl[N-1] minus chunk offset)
 };
 
 struct KArgs {
@@ -116,8 +133,13 @@ struct KArgs {
     const double* app_delays;
     int* chunk_dpend;              // [nc] particles with pending delayed factors, per wavefront
     double delayed_count_unused;
-    // state
-    DState st[2];
+    // state: every array of DState holds `nslots` copies back to back and st0 points at copy 0 (state_slot() below gives
+    // copy k).  Copies 0 and 1 are the double buffer of the general kernels; the single-launch pipeline uses four as a
+    // ring indexed by row & 3 (a row's raw weights, tree and stretch stay readable for the counts two launches later).
+    // Pointer arithmetic instead of an array of structs: a kernel argument indexed at run time would be copied to the
+    // stack.
+    DState st0;
+    int nslots;
     unsigned long long* rng_ctr;   // slot-owned
     double* ebuf;                  // slot-owned
     unsigned* widx;                // slot-owned: records ever appended by this slot
@@ -137,6 +159,19 @@ struct KArgs {
     int* run_st;                   // [Gcap][Np]
     int* run_anc;                  // [Gcap][Np]
     int* nruns;                    // [Gcap]
+    int* run_st2;                  // second copy of the three (Ctrl::lver), allocated for the single-launch pipeline
+    int* run_anc2;
+    int* nruns2;
+    // rings of the single-launch pipeline, slot = row & 3: per-particle scans [4][Np], per-wavefront partials [4][nc],
+    // survivors per workgroup [4][nblocks], records appended per slot [4][Np]
+    double* rg_scan1; double* rg_scan1m; double* rg_scanp;
+    double* rg_cpost; double* rg_csq; double* rg_cpil; double* rg_cpp; double* rg_cmx1; double* rg_coffp;
+    int* rg_dpend; int* rg_blkcnt;
+    unsigned* rg_widx;
+    int nc;                        // wavefronts = (Np + 63) / 64
+    // profiling builds (-DPF_STAMPS): wall-clock stamps of the extend workgroups' phases, [rows][nc][16]; null otherwise
+    unsigned long long* stamps;
+    long long stamp_rows;
     // per-wavefront partials written by k_extend
     double* chunk_post;            // [nc]
     double* chunk_sq;
@@ -178,6 +213,20 @@ struct KArgs {
     int max_trace_events;
     Ctrl* ctrl;
 };
+
+// copy k of the particle state (see KArgs::st0); fields that are not allocated stay unusable, as in st0
+__host__ __device__ inline DState state_slot(const KArgs& A, int k) {
+    DState d = A.st0;
+    const size_t K = (size_t)k, Np = (size_t)A.Np, n1 = (size_t)(A.n - 1);
+    d.S += K * n1 * Np; d.C += K * 2 * n1 * Np;
+    d.w_post += K * Np; d.w_pilot += K * Np; d.next_base += K * Np; d.x_mark += K * Np; d.Ltree += K * Np; d.mark_limit += K * Np;
+    d.total_delayed += K * Np; d.dcount += K * Np;
+    d.dpos += K * PF_DCAP * Np; d.dfac += K * PF_DCAP * Np; d.ddelta += K * PF_DCAP * Np; d.dk += K * PF_DCAP * Np;
+    d.ridx += K * Np; d.lookahead += K * Np;
+    d.Pn += K * n1 * Np; d.nm += K * Np;
+    d.Mt += K * PF_MMAX_SLOT * Np; d.Mb += K * PF_MMAX_SLOT * Np; d.Mq += K * PF_MMAX_SLOT * Np;
+    return d;
+}
 
 // Count windows of one step (count.cpp:363-385).  The rule depends only on segment positions and lags,
 // so the host evaluates it (host_first_epoch) and hands the result to the kernels by value.

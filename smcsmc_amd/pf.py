@@ -52,7 +52,7 @@ class _Params(C.Structure):
                 ("debug", C.c_int32), ("reserved", C.c_int32)]
 
 
-DEBUG_FORCE_LDS, DEBUG_NO_FUSE, DEBUG_NO_COUNT = 1, 2, 4
+DEBUG_FORCE_LDS, DEBUG_NO_FUSE, DEBUG_NO_COUNT, DEBUG_TWO_LAUNCH = 1, 2, 4, 8
 
 
 class _Segments(C.Structure):

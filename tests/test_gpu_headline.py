@@ -97,7 +97,7 @@ def test_c5_shape_at_its_own_particle_count(oracle, hiplib):
     assert co["mig_count"].sum() > 0
 
 
-@pytest.mark.parametrize("n,E,Np,P,debug", [(4, 8, 500, 1, 0), (4, 8, 500, 1, 2), (6, 8, 320, 1, 1), (4, 6, 300, 2, 0)])
+@pytest.mark.parametrize("n,E,Np,P,debug", [(4, 8, 500, 1, 0), (4, 8, 500, 1, 8), (4, 8, 500, 1, 2), (6, 8, 320, 1, 1), (4, 6, 300, 2, 0)])
 def test_rings_wrap_many_times(oracle, hiplib, n, E, Np, P, debug):
     """Event log of 64 records per slot, ledger of 32 generations (the defaults are 16 384 and 8 192; a C3 sweep wraps
     them about 6 and 10 times): both wrap more than ten times here and nothing changes -- every compared quantity is

@@ -384,37 +384,6 @@ def test_binary_auxiliary_particle_filter(hiplib, tmp_path):
     assert outfile.outfile_text(model, g.counts(), 300) == open(tmp_path / "apf.out").read()
 
 
-def test_reference_regression_data_set_constant_size(hiplib, tmp_path):
-    """The reference's constant-size regression configuration (test/old/newtests/test_const_pop_size.py:15-49:
-    testdata/constpopsize.seg, 10 Mb of real scrm data, truth N = 1e4, rho = 1e-8; lag 2, Np 1000, bias heights [400],
-    strengths [3, 1], tmax 4, one E-step from the truth).  Asserted here: every well-informed epoch within 4 % of the
-    truth, the recombination rate within 1.5 %, and seed-to-seed agreement within 1.5 %.  (The reference's own
-    acceptance bands for this data set are +-1 % wide and centred up to 2.5 % away from these values: DESIGN.md 6.)"""
-    import os
-    import subprocess
-    from smcsmc_amd import outfile
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    binary = os.path.join(root, "bin", "smcsmc")
-    seg = os.path.join(root, "tests", "golden", "seg", "constpopsize.seg")
-    L = 10000000
-    core = ("-N0 10000 -t %g -r %g %d -eN 0 1 -eN 0.01 1 -eN 0.25 1 -eN 0.5 1 -eN 1 1 -eN 1.5 1"
-            % (4e4 * 2.5e-8 * L, 4e4 * 1e-8 * L, L)).split()
-    est = []
-    for seed in (1, 2):
-        r = subprocess.run([binary] + core + ["-nsam", "2", "-Np", "1000", "-EM", "0", "-tmax", "4", "-calibrate_lag", "2",
-                                              "-seed", str(seed), "-bias_heights", "400", "-bias_strengths", "3", "1",
-                                              "-seg", seg, "-o", str(tmp_path / ("r%d" % seed))], capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr
-        d = outfile.parse_outfile(str(tmp_path / ("r%d.out" % seed)))
-        ne = [d[(("Coal", e, 0, -1, -1), "Opp")] / (2 * d[(("Coal", e, 0, -1, -1), "Count")]) for e in range(1, 6)]
-        rec = d[(("Recomb", -1, -1, -1, -1), "Count")] / d[(("Recomb", -1, -1, -1, -1), "Opp")]
-        est.append(ne + [rec * 1e12])
-    est = np.array(est)
-    assert (np.abs(est[:, :5] / 1e4 - 1) < 0.04).all(), est
-    assert (np.abs(est[:, 5] / 1e4 - 1) < 0.015).all(), est
-    assert (np.abs(est[0] / est[1] - 1) < 0.015).all(), est
-
-
 # ---------------------------------------------------------------- local recombination map (.recomb.gz)
 
 @pytest.mark.parametrize("n,E,Np,force_lds", [(4, 8, 600, False), (2, 4, 300, False), (6, 8, 256, True)])
