@@ -26,6 +26,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+_LAG_CACHE = {}
+
+
+def cpu_model_name():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def workload_label(args):
+    return "Np=%d, %s, %.0f Mb" % (args.np, "%d diploids" % (args.nsam // 2) + ("" if args.pops == 1 else " from %d populations" % args.pops),
+                                  args.length / 1e6)
 
 
 def build_workload(args, seed):
@@ -35,8 +51,9 @@ def build_workload(args, seed):
     N0, mu, rho = 1e4, 2.5e-8, 1e-8
     ct = simulate.default_epochs(E)
     ps = np.full(E, N0)
-    # the reference's uncalibrated per-epoch lag 4/(rho*top_t) (count.cpp:240-245); the calibrated
-    # default needs the 1e6-tree prior simulation (smcsmc.cpp:169-263), reported separately
+    # the reference's uncalibrated per-epoch lag 4/(rho*top_t) (count.cpp:240-245); replaced below by the calibrated
+    # lags the binary uses by default (-calibrate_lag 2: twice the median survival distance, smcsmc.cpp:169-263,
+    # count.cpp:261-265), whose calibration is timed separately
     lags = np.array([4.0 / (rho * (ct[e + 1] if e + 1 < E else ct[-1])) for e in range(E)]) if E > 1 else np.array([20000.0])
     model = dict(change_times=ct, pop_sizes=ps, lags=lags, nsam=n, loci_length=L, mutation_rate=mu,
                  recombination_rate=rho)
@@ -59,6 +76,13 @@ def build_workload(args, seed):
         np.savez(cache, **seg)
     max_seg_len = int(2.0 / (rho * 4 * N0))        # pfparam.cpp:364
     S = segmod.Segments.from_sites(seg["start"], seg["length"], seg["alleles"], n, L, max_segment_length=max_seg_len)
+    if not getattr(args, "uncalibrated_lags", False):
+        from smcsmc_amd import pf as pfmod
+        key = (n, E, args.pops)
+        if key not in _LAG_CACHE:          # model-only: once per process
+            _LAG_CACHE[key] = pfmod.calibrated_lags(model, lag_fraction=2.0, device=getattr(args, "device", 0))
+        lags = _LAG_CACHE[key]
+        model["lags"] = lags
     return model, S.pack(lags)
 
 
@@ -80,20 +104,32 @@ def cpu_baseline(args, model, segs):
     si = o.pack_segments(model, sub)
     t0 = time.perf_counter()
     done = 0
+    spent_counting = 0.0
+    distinct = []
     for s in range(nseg):
         o.update_segment(si, s)
         pos = min(sub["start"][s] + sub["length"][s], model["loci_length"])
         o.count(pos)
         o.resample(pos)
         done += 1
-        if time.perf_counter() - t0 > args.cpu_seconds:
+        if s % 25 == 24:
+            # particles in distinct states: what the reference's multiplicity records (particle.cpp:831-857) would hold
+            # instead of Np expanded copies (not part of the timed work)
+            tc = time.perf_counter()
+            pa = o.particles()
+            key = np.concatenate([pa["heights"].reshape(args.np, -1), pa["next_base"].reshape(args.np, 1)], axis=1)
+            distinct.append(len(np.unique(key, axis=0)))
+            spent_counting += time.perf_counter() - tc
+        if time.perf_counter() - t0 - spent_counting > args.cpu_seconds:
             break
-    dt = time.perf_counter() - t0
+    dt = time.perf_counter() - t0 - spent_counting
     st = o.stats()
     o.close()
-    return {"value": done / dt, "unit": "segments/s", "cores": 1, "kind": "port",
+    return {"value": done / dt, "unit": "segments/s", "cores": 1, "kind": "port", "cpu": cpu_model_name(),
             "sample": "first %d segments of the same workload (Np=%d), %.1f s, single thread, oracle/libsmc_oracle.so "
-                      "(-O3 -DNDEBUG); %d genealogy updates" % (done, args.np, dt, st["recombinations"])}
+                      "(-O3 -DNDEBUG); %d genealogy updates; %.0f of the %d particles in distinct states on average "
+                      "(the reference keeps one record per distinct state, the port expands them)"
+                      % (done, args.np, dt, st["recombinations"], float(np.mean(distinct)) if distinct else float(args.np), args.np)}
 
 
 def cpu_worker(path):
@@ -148,7 +184,7 @@ def cpu_baseline_all_cores(args, model, segs):
                 rates.append(r["done"] / r["dt"])
             except Exception:
                 pass
-    return {"value": float(sum(rates)), "unit": "segments/s", "cores": len(rates), "kind": "port",
+    return {"value": float(sum(rates)), "unit": "segments/s", "cores": len(rates), "kind": "port", "cpu": cpu_model_name(),
             "sample": "%d concurrent single-threaded oracle processes, each the first segments of the same workload "
                       "(Np=%d) for %.0f s; aggregate rate" % (len(rates), args.np, args.cpu_seconds)}
 
@@ -176,6 +212,8 @@ def main():
     ap.add_argument("--timing-period", type=int, default=16, help="time every k-th segment's kernels with HIP events")
     ap.add_argument("--no-local-recomb", action="store_true",
                     help="do not record the 100-bp local recombination map (the binary always records it, smcsmc.cpp:376-383)")
+    ap.add_argument("--uncalibrated-lags", action="store_true",
+                    help="the reference's uncalibrated lags 4/(rho*top_t) instead of the calibrated default of the binary")
     ap.add_argument("--debug", type=int, default=0, help="pf_params.debug bits (include/smcsmc_pf.h): 4 no counting, 8 two launches per row")
     ap.add_argument("--chunks-per-gpu", type=int, default=1,
                     help="independent chunks filtered concurrently on each GPU (one host thread + stream each); "
@@ -200,6 +238,7 @@ def main():
     import threading
     C = max(1, args.chunks_per_gpu)
     dev = local_rank if world > 1 else 0
+    args.device = dev
     chunks = []
     for k in range(C):
         model, segs = build_workload(args, seed=args.seed + rank * C + k)     # independent chunks
@@ -290,7 +329,7 @@ def main():
             if pmc["shape"] == {"nsam": args.nsam, "np": args.np, "epochs": args.epochs, "pops": args.pops}:
                 traffic = pmc["traffic_bytes_per_launch"]
         out = {
-            "metric": "genome segments/sec per EM iteration (Np=10000, 2 diploids, 100 Mb)",
+            "metric": "genome segments/sec per EM iteration (%s)" % workload_label(args),
             "value": value, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt_max / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -301,7 +340,7 @@ def main():
                        "segments_per_chunk": n_segments, "nsam": args.nsam, "np": args.np,
                        "sequence_length": args.length, "epochs": args.epochs,
                        "parallelism": "%d chunk(s) per gpu x %d gpu(s)" % (C, world), "log_likelihood_sum": logl_sum},
-            "roofline": {"bound": "hbm", "kernel": "k_row (extend workgroups; the counts of the previous row ride along)" if args.pops == 1 and args.nsam <= 8 else "k_extend", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_pipe (one launch per row: extend workgroups; bookkeeping, ledger and counts ride along)" if args.pops == 1 and args.nsam <= 8 and not (args.debug & 8) else ("k_row" if args.pops == 1 and args.nsam <= 8 else "k_extend_mp" if args.pops > 1 else "k_extend"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_us": avg_ext_us,
                          "kernel_ms_estimate": {k: v[0] for k, v in kt.items()},

@@ -17,6 +17,7 @@
 
 #include "../../../include/smcsmc_pf.h"
 #include "smcsmc_host.hpp"
+#include "mgpu.hpp"
 
 using namespace std;
 
@@ -118,14 +119,23 @@ static uint64_t base_seed(const HostModel& M) {
     return M.seed_set ? M.seed : from_clock;
 }
 
+static void report_counts(PfParam& P, const HostModel& M0, const std::vector<double>& packed, double chunks);
+
+// what the chunks of one E-step share: the lag calibration depends on the model only (done once per iteration), and
+// every chunk hands its raw sufficient statistics back instead of writing the rows itself
+struct ChunkJob {
+    const std::vector<double>* survival = nullptr;     // median survival distances per epoch, or null: calibrate here
+    std::vector<double>* survival_out = nullptr;       // receives them when they were calibrated here
+    std::vector<double>* packed_out = nullptr;         // PF_COUNTS_LEN2 doubles, raw sums (no pseudo-counts)
+    uint64_t seed_offset = 0;                          // + chunk index, the rule of smcsmc_amd/em.py
+};
+
 // pfARG_core (smcsmc.cpp:278-401): one E-step over the chunk
-static void pfARG_core(PfParam& P, const HostModel& M0) {
+static void pfARG_core(PfParam& P, const HostModel& M0, int device, const ChunkJob* job = nullptr) {
     HostModel& M = P.model;
     const int E = (int)M.change_times.size();
     const int NP = M.npop;
     if (NP > 4) throw Unsupported("models with more than four populations");
-    int device = 0;
-    if (const char* d = getenv("SMCSMC_DEVICE")) device = atoi(d);
 
     std::vector<double> pop_sizes((size_t)E * NP), mig_rates((size_t)E * NP * NP), single_mig((size_t)E * NP * NP);
     for (int e = 0; e < E; ++e)
@@ -167,12 +177,14 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
     const bool biased = !M.bias_heights.empty();
     const bool guided = !P.guide_positions.empty();          // the calibration runs at the true rate (smcsmc.cpp:287-291)
     std::vector<double> med(E, 0.0), app_delays(E, 0.0);
-    if (P.calibrate_lag || biased || guided) {
+    if (job && job->survival && !job->survival->empty()) med = *job->survival;
+    else if (P.calibrate_lag || biased || guided) {
         int64_t trees = 0;
         pm.lags = lags.data();
         pf_check(pf_median_survival(&pm, 1, 200, 1000000, med.data(), &trees, device));
         for (int e = 0; e < E; ++e) clog << " Epoch " << e << ": survival distance " << med[e] << endl;
     }
+    if (job && job->survival_out) *job->survival_out = med;
     if (P.calibrate_lag)
         for (int e = 0; e < E; ++e) lags[e] = med[e] * P.lag_fraction;      // reset_lag, count.cpp:261-265
     if (biased || guided) {
@@ -229,7 +241,8 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
 
     pf_params pp;
     memset(&pp, 0, sizeof(pp));
-    pp.np = (int64_t)P.particles; pp.ess_fraction = P.ess_fraction; pp.seed = base_seed(M) + 1000ull * (uint64_t)P.em_iteration;   // same rule as smcsmc_amd/em.py: seed + 1000 * iteration + chunk
+    pp.np = (int64_t)P.particles; pp.ess_fraction = P.ess_fraction;
+    pp.seed = base_seed(M) + 1000ull * (uint64_t)P.em_iteration + (job ? job->seed_offset : 0);   // same rule as smcsmc_amd/em.py: seed + 1000 * iteration + chunk
     pp.max_trace_events = 0;
     pp.flags = 1;          // the local recombination map is always recorded (smcsmc.cpp:376-383)
     if (P.record_trees) {
@@ -282,6 +295,11 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
         const double* tail = &packed[packed.size() - 4];
         clog << "Got to end of sequence; resampled " << (long long)tail[2] << " times" << endl;
         clog << " Inference step completed." << endl;
+        if (job && job->packed_out) {        // a chunk of a multi-chunk E-step: the statistics go to the reduction
+            *job->packed_out = packed;
+            pf_destroy(h);
+            return;
+        }
         if (P.write_resample) {
             std::vector<double> ess(done);
             std::vector<int32_t> flag(done);
@@ -376,81 +394,160 @@ static void pfARG_core(PfParam& P, const HostModel& M0) {
             gzFile gz = gzopen(P.trees_path.c_str(), "wb");
             if (gz) { gzwrite(gz, text.data(), (unsigned)text.size()); gzclose(gz); }
         }
-        // log_counts (count.cpp:66-158) with the prior pseudo-counts of init_coal_and_recomb (count.cpp:161-193)
-        const size_t EP = (size_t)E * NP;
-        const double* cc = &packed[0]; const double* co = &packed[EP]; const double* cw = &packed[2 * EP];
-        const double* rc = &packed[3 * EP]; const double* ro = &packed[3 * EP + E]; const double* rw = &packed[3 * EP + 2 * E];
-        auto epoch_end = [&](int e) { return e == E - 1 ? 1e+99 : M.change_times[e + 1]; };
-        // reset_model_parameters (count.cpp:44-63, forced at the end of every E-step, smcsmc.cpp:385-386): the M-step
-        // of the in-binary EM.  Totals include the prior pseudo-counts of CountModel::init, which come from the
-        // model the CountModel was constructed with (the initial one, smcsmc.cpp:77).
-        {
-            clog << " MODEL IS RESET at base " << M.loci_length << endl;
-            double ro_ = 0, rc_ = 0, rw_ = 0;
-            for (int e = 0; e < E; ++e) { ro_ += ro[e] + 1.0; rc_ += rc[e] + M0.recombination_rate; rw_ += rw[e] + 1.0; }
-            std::vector<std::vector<double>> new_sizes = M.pop_sizes, new_mig = M.mig_rates;
-            const double new_rho = rc_ / ro_;                                     // reset_recomb_rate, count.cpp:296-313
-            clog << " Setting recombination rate to " << new_rho << " ( " << rc_ << " / " << ro_ << "; post-lag ESS "
-                 << 1.0 / (rw_ / ro_) << " )" << endl;
-            for (int e = 0; e < E; ++e)                                           // reset_Ne, count.cpp:267-293
-                for (int a = 0; a < NP; ++a) {
-                    const size_t k = (size_t)e * NP + a;
-                    double opp = co[k] + 1.0, count = cc[k] + 1.0 / (2.0 * M0.pop_sizes[e][a]), weight = cw[k] + 1.0;
-                    double pop_size = 1.0 / (2.0 * (count / opp));
-                    if (P.cap_sizes && pop_size >= P.size_cap) pop_size = P.size_cap;
-                    new_sizes[e][a] = pop_size;
-                    clog << " Setting size of population " << a << " @ " << setw(8) << M.change_times[e] << " to " << setw(8)
-                         << pop_size << " ( 0.5 * " << opp << " / " << count << "; post-lag ESS " << 1.0 / (weight / opp)
-                         << " )" << endl;
-                }
-            if (NP > 1) {                                                         // reset_mig_rate, count.cpp:327-352
-                const double* mc = &packed[3 * EP + 3 * E]; const double* mo = mc + EP * NP;
-                for (int e = 0; e < E; ++e)
-                    for (int a = 0; a < NP; ++a)
-                        for (int b = 0; b < NP; ++b)
-                            if (a != b) {
-                                const size_t k = (size_t)e * NP + a;
-                                new_mig[e][(size_t)a * NP + b] = (mc[k * NP + b] + M0.mig_rates[e][(size_t)a * NP + b]) / (mo[k] + 1.0);
-                            }
-            }
-            P.next_sizes = new_sizes; P.next_mig = new_mig; P.next_rho = new_rho;
-        }
-        for (int e = 0; e < E; ++e)
-            for (int a = 0; a < NP; ++a) {
-                const size_t k = (size_t)e * NP + a;
-                P.write_out_row(P.em_iteration, e, M.change_times[e], epoch_end(e), "Coal", a, -1, co[k] + 1.0,
-                                  cc[k] + 1.0 / (2.0 * M0.pop_sizes[e][a]), cw[k] + 1.0);
-            }
-        // recombination is booked on population 0 only (count.cpp:534-539); the report sums the epochs (84-113)
-        double ropp = 0, rcount = 0, rweight = 0;
-        for (int e = 0; e < E; ++e) {
-            ropp += ro[e] + 1.0;
-            rcount += rc[e] + M0.recombination_rate;
-            rweight += rw[e] + 1.0;
-        }
-        P.write_out_row(P.em_iteration, -1, 0.0, 1e+99, "Recomb", -1, -1, ropp, rcount, rweight);
-        if (NP > 1) {
-            // migration rows with the pseudo-counts of init_migr (count.cpp:196-227)
-            const double* mc = &packed[3 * EP + 3 * E]; const double* mo = mc + EP * NP; const double* mw = mo + EP;
-            for (int e = 0; e < E; ++e)
-                for (int a = 0; a < NP; ++a)
-                    for (int b = 0; b < NP; ++b)
-                        if (a != b) {
-                            const size_t k = (size_t)e * NP + a;
-                            P.write_out_row(P.em_iteration, e, M.change_times[e], epoch_end(e), "Migr", a, b, mo[k] + 1.0,
-                                              mc[k * NP + b] + M0.mig_rates[e][(size_t)a * NP + b], mw[k] + 1.0);
-                        }
-        }
-        double dopp = tail[0], dcount = tail[1], nres = tail[2], logl = tail[3];
-        P.write_out_row(P.em_iteration, -1, 0.0, 1e+99, "Delay", -1, -1, dopp, dcount / (double)P.particles, dopp);
-        P.write_out_row(P.em_iteration, -1, 0.0, 1e+99, "Resamp", -1, -1, dopp, nres, dopp);
-        P.write_out_row(P.em_iteration, -1, 0, 1e+99, "LogL", -1, -1, 1.0, logl, 1.0);   // smcsmc.cpp:391
-        clog << " Estimated log likelihood: " << logl << endl;
+        report_counts(P, M0, packed, 1.0);
     } catch (...) {
         pf_destroy(h);
         throw;
     }
     pf_destroy(h);
+}
+
+// log_counts + reset_model_parameters (count.cpp:44-158, 267-352) on the statistics of one E-step summed over `chunks`
+// chunks: the rows of <prefix>.out and the in-binary M-step.  Every chunk brings the prior pseudo-counts of
+// CountModel::init (count.cpp:161-227), as each chunk's own .out does when the front-end adds them up (model.py:1176-1184).
+static void report_counts(PfParam& P, const HostModel& M0, const std::vector<double>& packed, double chunks) {
+    const double K = chunks;
+    // log_counts (count.cpp:66-158) with the prior pseudo-counts of init_coal_and_recomb (count.cpp:161-193)
+    HostModel& M = P.model;
+    const int E = (int)M.change_times.size();
+    const int NP = M.npop;
+    const double* tail = &packed[packed.size() - 4];
+    const size_t EP = (size_t)E * NP;
+    const double* cc = &packed[0]; const double* co = &packed[EP]; const double* cw = &packed[2 * EP];
+    const double* rc = &packed[3 * EP]; const double* ro = &packed[3 * EP + E]; const double* rw = &packed[3 * EP + 2 * E];
+    auto epoch_end = [&](int e) { return e == E - 1 ? 1e+99 : M.change_times[e + 1]; };
+    // reset_model_parameters (count.cpp:44-63, forced at the end of every E-step, smcsmc.cpp:385-386): the M-step
+    // of the in-binary EM.  Totals include the prior pseudo-counts of CountModel::init, which come from the
+    // model the CountModel was constructed with (the initial one, smcsmc.cpp:77).
+    {
+        clog << " MODEL IS RESET at base " << M.loci_length << endl;
+        double ro_ = 0, rc_ = 0, rw_ = 0;
+        for (int e = 0; e < E; ++e) { ro_ += ro[e] + K; rc_ += rc[e] + K * M0.recombination_rate; rw_ += rw[e] + K; }
+        std::vector<std::vector<double>> new_sizes = M.pop_sizes, new_mig = M.mig_rates;
+        const double new_rho = rc_ / ro_;                                     // reset_recomb_rate, count.cpp:296-313
+        clog << " Setting recombination rate to " << new_rho << " ( " << rc_ << " / " << ro_ << "; post-lag ESS "
+             << 1.0 / (rw_ / ro_) << " )" << endl;
+        for (int e = 0; e < E; ++e)                                           // reset_Ne, count.cpp:267-293
+            for (int a = 0; a < NP; ++a) {
+                const size_t k = (size_t)e * NP + a;
+                double opp = co[k] + K, count = cc[k] + K / (2.0 * M0.pop_sizes[e][a]), weight = cw[k] + K;
+                double pop_size = 1.0 / (2.0 * (count / opp));
+                if (P.cap_sizes && pop_size >= P.size_cap) pop_size = P.size_cap;
+                new_sizes[e][a] = pop_size;
+                clog << " Setting size of population " << a << " @ " << setw(8) << M.change_times[e] << " to " << setw(8)
+                     << pop_size << " ( 0.5 * " << opp << " / " << count << "; post-lag ESS " << 1.0 / (weight / opp)
+                     << " )" << endl;
+            }
+        if (NP > 1) {                                                         // reset_mig_rate, count.cpp:327-352
+            const double* mc = &packed[3 * EP + 3 * E]; const double* mo = mc + EP * NP;
+            for (int e = 0; e < E; ++e)
+                for (int a = 0; a < NP; ++a)
+                    for (int b = 0; b < NP; ++b)
+                        if (a != b) {
+                            const size_t k = (size_t)e * NP + a;
+                            new_mig[e][(size_t)a * NP + b] = (mc[k * NP + b] + K * M0.mig_rates[e][(size_t)a * NP + b]) / (mo[k] + K);
+                        }
+        }
+        P.next_sizes = new_sizes; P.next_mig = new_mig; P.next_rho = new_rho;
+    }
+    for (int e = 0; e < E; ++e)
+        for (int a = 0; a < NP; ++a) {
+            const size_t k = (size_t)e * NP + a;
+            P.write_out_row(P.em_iteration, e, M.change_times[e], epoch_end(e), "Coal", a, -1, co[k] + K,
+                              cc[k] + K / (2.0 * M0.pop_sizes[e][a]), cw[k] + K);
+        }
+    // recombination is booked on population 0 only (count.cpp:534-539); the report sums the epochs (84-113)
+    double ropp = 0, rcount = 0, rweight = 0;
+    for (int e = 0; e < E; ++e) {
+        ropp += ro[e] + K;
+        rcount += rc[e] + K * M0.recombination_rate;
+        rweight += rw[e] + K;
+    }
+    P.write_out_row(P.em_iteration, -1, 0.0, 1e+99, "Recomb", -1, -1, ropp, rcount, rweight);
+    if (NP > 1) {
+        // migration rows with the pseudo-counts of init_migr (count.cpp:196-227)
+        const double* mc = &packed[3 * EP + 3 * E]; const double* mo = mc + EP * NP; const double* mw = mo + EP;
+        for (int e = 0; e < E; ++e)
+            for (int a = 0; a < NP; ++a)
+                for (int b = 0; b < NP; ++b)
+                    if (a != b) {
+                        const size_t k = (size_t)e * NP + a;
+                        P.write_out_row(P.em_iteration, e, M.change_times[e], epoch_end(e), "Migr", a, b, mo[k] + K,
+                                          mc[k * NP + b] + K * M0.mig_rates[e][(size_t)a * NP + b], mw[k] + K);
+                    }
+    }
+    double dopp = tail[0], dcount = tail[1], nres = tail[2], logl = tail[3];
+    P.write_out_row(P.em_iteration, -1, 0.0, 1e+99, "Delay", -1, -1, dopp, dcount / (double)P.particles, dopp);
+    P.write_out_row(P.em_iteration, -1, 0.0, 1e+99, "Resamp", -1, -1, dopp, nres, dopp);
+    P.write_out_row(P.em_iteration, -1, 0, 1e+99, "LogL", -1, -1, 1.0, logl, 1.0);   // smcsmc.cpp:391
+    clog << " Estimated log likelihood: " << logl << endl;
+}
+
+// ---- several chunks in one process -------------------------------------------------------------------------------
+// The data-parallel layer of the reference is one OS process per chromosome chunk and a sum of the chunks' .out files in
+// Python (smcsmc/model.py:563-662, 1050-1100, 1176-1184).  Here: K chunks of the window are dealt to R host threads
+// ("ranks", rank r takes chunks r, r + R, ...), rank r drives device r mod G; every rank filters its chunks from a fresh
+// prior (chunks are independent, smcsmc.cpp:296), then ONE all-gather of the packed statistics (mgpu.cpp: RCCL over xGMI
+// when every rank has its own device) and a sum in chunk order on every rank -- bit-identical for any R and G.
+static void run_chunks(PfParam& P, const HostModel& M0) {
+    const int K = P.chunks;
+    int G = P.devices > 0 ? P.devices : visible_devices();
+    if (G < 1) throw std::runtime_error("no HIP device available (there is no CPU fallback)");
+    if (G > visible_devices()) throw std::runtime_error("-devices exceeds the devices visible to this process");
+    int R = P.ranks > 0 ? P.ranks : std::min(G, K);
+    if (R > K) R = K;
+    std::string transport = P.reduce_transport.empty() ? (R <= G ? "rccl" : "host") : P.reduce_transport;
+    std::vector<int> device_of_rank(R);
+    for (int r = 0; r < R; ++r) device_of_rank[r] = r % G;
+    const int E = (int)P.model.change_times.size();
+    const size_t LEN = (size_t)PF_COUNTS_LEN2(E, P.model.npop);
+    const int slots = (K + R - 1) / R;                          // chunks per rank (the last ranks may hold one fewer)
+    CountAllGather exchange(R, device_of_rank, (size_t)slots * LEN, transport);
+    clog << " " << K << " chunks on " << R << " rank(s), " << G << " device(s); statistics exchanged by " << exchange.transport() << endl;
+    // the window [startpos, startpos + L) in K pieces
+    const double L = P.model.loci_length;
+    std::vector<long long> first(K + 1);
+    for (int c = 0; c <= K; ++c) first[c] = (long long)P.start_position + (long long)std::floor(L * c / K);
+    std::vector<std::vector<double>> mine(R, std::vector<double>((size_t)slots * LEN, 0.0));
+    std::vector<std::vector<double>> all(R, std::vector<double>((size_t)R * slots * LEN, 0.0));
+    std::vector<std::string> failure(R);
+    auto rank_main = [&](int r) {
+        try {
+            std::vector<double> survival;
+            for (int c = r, slot = 0; c < K; c += R, ++slot) {
+                PfParam Pc = P;                                 // same flags and model, its own piece of the data
+                Pc.model.loci_length = (double)(first[c + 1] - first[c]);
+                Pc.start_position = (double)first[c];
+                Segment table(P.seg_path, P.nsam, Pc.model.loci_length, P.nodata_theta, first[c], P.segment_cap());
+                Pc.segments = &table;
+                std::vector<double> packed;
+                ChunkJob job;
+                job.survival = &survival; job.survival_out = &survival; job.packed_out = &packed; job.seed_offset = (uint64_t)c;
+                pfARG_core(Pc, M0, device_of_rank[r], &job);
+                std::copy(packed.begin(), packed.end(), mine[r].begin() + (size_t)slot * LEN);
+            }
+            exchange.all_gather(r, mine[r].data(), all[r].data());
+        } catch (const std::exception& e) {
+            failure[r] = e.what();
+            // the other ranks still wait at the exchange: contribute zeros so that they can leave and report
+            try { exchange.all_gather(r, mine[r].data(), all[r].data()); } catch (...) {}
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int r = 1; r < R; ++r) pool.emplace_back(rank_main, r);
+    rank_main(0);
+    for (auto& t : pool) t.join();
+    for (int r = 0; r < R; ++r) if (!failure[r].empty()) throw std::runtime_error("chunk rank " + std::to_string(r) + ": " + failure[r]);
+    // every rank now holds every chunk's statistics: chunk c sits in rank c mod R, slot c / R.  Sum in chunk order.
+    std::vector<double> total(LEN, 0.0);
+    for (int c = 0; c < K; ++c) {
+        const double* q = &all[0][((size_t)(c % R) * slots + (size_t)(c / R)) * LEN];
+        for (size_t k = 0; k < LEN; ++k) total[k] += q[k];
+    }
+    for (int r = 1; r < R; ++r)                                   // all ranks received the same bytes
+        if (memcmp(all[r].data(), all[0].data(), all[0].size() * sizeof(double)) != 0)
+            throw std::runtime_error("the ranks disagree on the gathered statistics");
+    report_counts(P, M0, total, (double)K);
 }
 
 int main(int argc, char* argv[]) {
@@ -466,7 +563,10 @@ int main(int argc, char* argv[]) {
         const HostModel initial_model = P.model;        // what CountModel is constructed from (smcsmc.cpp:77)
         for (int i = 0; i <= P.em_iterations; i++) {
             clog << "EM step " << i << endl;
-            pfARG_core(P, initial_model);
+            int device = 0;
+            if (const char* d = getenv("SMCSMC_DEVICE")) device = atoi(d);      // which device a single-chunk run uses
+            if (P.chunks > 1 || P.ranks > 1) run_chunks(P, initial_model);
+            else pfARG_core(P, initial_model, device);
             // the model the next E-step runs under (Model::addPopulationSize / addMigrationRate / setRecombinationRate)
             P.model.pop_sizes = P.next_sizes; P.model.mig_rates = P.next_mig; P.model.recombination_rate = P.next_rho;
             P.em_iteration++;

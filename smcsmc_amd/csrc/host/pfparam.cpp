@@ -284,6 +284,15 @@ const std::vector<DriverOption>& driver_options() {
          [](PfParam& p, const std::string& v) { p.size_cap = convert<double>("-cap", v); p.cap_sizes = true; }},
         {"-ancestral_aware", "", "Inference tuning", "Ancestral allele is 0", [](PfParam& p, const std::string&) { p.ancestral_aware = true; }},
         {"-record_ess", "", "Inference tuning", "Generate *.resample file", [](PfParam& p, const std::string&) { p.write_resample = true; }},
+        // not reference flags: several chunks of the window in one process, on one or several devices (main.cpp: run_chunks)
+        {"-chunks", "INT", "Several chunks", "Cut the window into this many chunks, filtered independently; statistics summed in chunk order [ 1 ]",
+         [](PfParam& p, const std::string& v) { p.chunks = convert<int>("-chunks", v); if (p.chunks < 1) throw OutOfRange("-chunks", v); }},
+        {"-ranks", "INT", "Several chunks", "Host threads filtering chunks concurrently (rank r takes chunks r, r + ranks, ...) [ number of devices ]",
+         [](PfParam& p, const std::string& v) { p.ranks = convert<int>("-ranks", v); if (p.ranks < 1) throw OutOfRange("-ranks", v); }},
+        {"-devices", "INT", "Several chunks", "Devices to use (rank r drives device r mod devices) [ all visible ]",
+         [](PfParam& p, const std::string& v) { p.devices = convert<int>("-devices", v); if (p.devices < 1) throw OutOfRange("-devices", v); }},
+        {"-reduce", "STR", "Several chunks", "Exchange of the statistics between ranks: rccl (one device per rank) or host [ rccl when possible ]",
+         [](PfParam& p, const std::string& v) { p.reduce_transport = v; }},
         // not reference flags: print what the host side made of the input, as JSON, and exit (used by the tests)
         {"-dumpmodel", "", nullptr, "", [](PfParam& p, const std::string&) { p.dump_model = true; }},
         {"-dumplookahead", "", nullptr, "", [](PfParam& p, const std::string&) { p.dump_lookahead = true; }},
@@ -471,11 +480,13 @@ void PfParam::finalize() {
     };
     exclude(exclude_recomb, RECORD_RECOMB);
     exclude(exclude_coalmigr, RECORD_COALMIGR);
-    int max_seg_len = (int)(row_cap_factor / (model.recombination_rate * 4 * model.N0));
+    int max_seg_len = (int)segment_cap();
     if (!dump_model)
         segments = new Segment(seg_path, nsam, model.loci_length, nodata_theta,
                               (long long)start_position, max_seg_len);
 }
+
+double PfParam::segment_cap() const { return (double)(int)(row_cap_factor / (model.recombination_rate * 4 * model.N0)); }
 
 // ------------------------------------------------------------------ writers
 std::string format_double(double d, double scientific_bound, int precision) {   // pfparam.cpp:482-497

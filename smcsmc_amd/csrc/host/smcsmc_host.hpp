@@ -204,6 +204,9 @@ class PfParam {
     double row_cap_factor = 2.0;     // rows longer than this many expected recombination distances are cut
     std::string out_prefix = "smcsmc", seg_path, guide_path, pattern;
     std::vector<EpochRange> exclude_recomb, exclude_coalmigr;
+    int chunks = 1, ranks = 0, devices = 0;          // several chunks in one process (main.cpp: run_chunks)
+    std::string reduce_transport;                    // "rccl" / "host" / "" = choose
+    double segment_cap() const;                      // rows longer than this many bases are cut (pfparam.cpp:364)
     // ---- derived
     std::string out_path, log_path, recomb_map_path, resample_path, trees_path;
     std::vector<int> record_mask;    // per epoch

@@ -8,16 +8,40 @@ rank order on every rank, so the result is bit-identical on all ranks and for an
 import numpy as np
 
 COUNT_KEYS = ("coal_count", "coal_opp", "coal_weight", "rec_count", "rec_opp", "rec_weight")
+# structured models carry the migration statistics behind them, in the order of PF_COUNTS_LEN2 (include/smcsmc_pf.h):
+#   coal_{count,opp,weight}[E][P]  rec_{count,opp,weight}[E]  mig_count[E][P][P]  mig_{opp,weight}[E][P]  4 scalars
+MIGRATION_KEYS = ("mig_count", "mig_opp", "mig_weight")
+SCALAR_KEYS = ("delayed_opp", "delayed_count", "resample_count", "logl")
+
+
+def packed_length(E, P=1):
+    """PF_COUNTS_LEN2(E, P)."""
+    return 6 * E + 4 if P == 1 else 3 * E * P + 3 * E + E * P * P + 2 * E * P + 4
 
 
 def pack_counts(counts):
-    return np.concatenate([np.asarray(counts[k], dtype=np.float64) for k in COUNT_KEYS] +
-                          [[counts["delayed_opp"], counts["delayed_count"], counts["resample_count"], counts["logl"]]])
+    """The CountModel of one rank as the flat buffer of pf_get_counts (one or several populations: the migration
+    statistics are part of it whenever the dictionary has them)."""
+    keys = COUNT_KEYS + (MIGRATION_KEYS if "mig_count" in counts else ())
+    return np.concatenate([np.asarray(counts[k], dtype=np.float64).reshape(-1) for k in keys] +
+                          [[counts[k] for k in SCALAR_KEYS]])
 
 
-def unpack_counts(packed, E):
-    out = {k: np.array(packed[i * E:(i + 1) * E]) for i, k in enumerate(COUNT_KEYS)}
-    out["delayed_opp"], out["delayed_count"], out["resample_count"], out["logl"] = (float(v) for v in packed[6 * E:6 * E + 4])
+def unpack_counts(packed, E, P=1):
+    packed = np.asarray(packed, dtype=np.float64)
+    assert len(packed) == packed_length(E, P), (len(packed), E, P)
+    shapes = [("coal_count", (E, P)), ("coal_opp", (E, P)), ("coal_weight", (E, P)),
+              ("rec_count", (E,)), ("rec_opp", (E,)), ("rec_weight", (E,))]
+    if P > 1:
+        shapes += [("mig_count", (E, P, P)), ("mig_opp", (E, P)), ("mig_weight", (E, P))]
+    out, at = {}, 0
+    for name, shape in shapes:
+        size = int(np.prod(shape))
+        block = packed[at:at + size].copy()
+        out[name] = block if P == 1 else block.reshape(shape)
+        at += size
+    for name in SCALAR_KEYS:
+        out[name] = float(packed[at]); at += 1
     return out
 
 

@@ -1,0 +1,54 @@
+"""Several chunks in one process (bin/smcsmc -chunks K -ranks R): the native counterpart of the front-end's process farm
+and file sum (smcsmc/model.py:1050-1100, 1176-1184).  The statistics are exchanged once per E-step (RCCL all-gather when
+every rank has a device of its own, host memory otherwise) and summed in chunk order, so the result may not depend on how
+many ranks shared the work."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "bin", "smcsmc")
+SEG = os.path.join(ROOT, "tests", "golden", "seg", "constpopsize.seg")
+L = 4000000
+CORE = ("-N0 10000 -t %g -r %g %d -eN 0 1 -eN 0.01 1 -eN 0.25 1 -eN 1 1" % (4e4 * 2.5e-8 * L, 4e4 * 1e-8 * L, L)).split()
+COMMON = ["-nsam", "2", "-seg", SEG, "-Np", "300", "-tmax", "4", "-lag", "30000", "-seed", "5"]
+
+
+def _run(tmp_path, name, extra):
+    r = subprocess.run([BIN] + CORE + COMMON + extra + ["-o", str(tmp_path / name)], capture_output=True, text=True)
+    assert r.returncode == 0, (name, r.stderr[-400:])
+    return open(tmp_path / (name + ".out")).read(), r.stderr
+
+
+def _rows(text):
+    rows = [ln.split() for ln in text.splitlines()[1:]]
+    return {(r[4], int(r[1]), int(r[5]), int(r[6])): (float(r[7]), float(r[8])) for r in rows if r[0] == rows[-1][0]}
+
+
+def test_chunk_statistics_do_not_depend_on_the_ranks(hiplib, tmp_path):
+    one, log1 = _run(tmp_path, "r1", ["-chunks", "4", "-ranks", "1"])
+    assert "exchanged by rccl" in log1                      # one rank, one device: the RCCL all-gather runs (world 1)
+    two, log2 = _run(tmp_path, "r2", ["-chunks", "4", "-ranks", "2", "-reduce", "host"])
+    four, _ = _run(tmp_path, "r4", ["-chunks", "4", "-ranks", "4", "-reduce", "host"])
+    assert "2 rank(s)" in log2
+    assert one == two == four                               # bit-identical .out files
+    d = _rows(one)
+    # four chunks bring four sets of prior pseudo-counts (count.cpp:161-227), as four .out files added up would
+    assert d[("LogL", -1, -1, -1)][0] == 1.0 and d[("Coal", 3, 0, -1)][0] > 4.0
+    # and the sum is that of the chunks filtered one at a time with the same seeds (same data window, same per-bp rates)
+    single = _rows(_run(tmp_path, "whole", [])[0])
+    assert abs(d[("LogL", -1, -1, -1)][1] / single[("LogL", -1, -1, -1)][1] - 1) < 0.02     # chunk starts from fresh priors cost little
+    assert abs(d[("Recomb", -1, -1, -1)][1] / single[("Recomb", -1, -1, -1)][1] - 1) < 0.1
+
+
+def test_chunked_em_iterations(hiplib, tmp_path):
+    """-EM with several chunks: the M-step works on the summed statistics, every iteration re-filters all chunks."""
+    text, _ = _run(tmp_path, "em", ["-chunks", "2", "-ranks", "2", "-reduce", "host", "-EM", "1"])
+    iters = sorted({int(ln.split()[0]) for ln in text.splitlines()[1:]})
+    assert iters == [0, 1]
+    ll = [float(ln.split()[8]) for ln in text.splitlines()[1:] if ln.split()[4] == "LogL"]
+    assert len(ll) == 2 and all(np.isfinite(ll))
