@@ -117,8 +117,7 @@ def cpu_baseline(args, model, segs):
             # instead of Np expanded copies (not part of the timed work)
             tc = time.perf_counter()
             pa = o.particles()
-            key = np.concatenate([pa["heights"].reshape(args.np, -1), pa["next_base"].reshape(args.np, 1)], axis=1)
-            distinct.append(len(np.unique(key, axis=0)))
+            distinct.append(len(np.unique(pa["heights"].reshape(args.np, -1), axis=0)))      # distinct local trees
             spent_counting += time.perf_counter() - tc
         if time.perf_counter() - t0 - spent_counting > args.cpu_seconds:
             break
@@ -127,8 +126,8 @@ def cpu_baseline(args, model, segs):
     o.close()
     return {"value": done / dt, "unit": "segments/s", "cores": 1, "kind": "port", "cpu": cpu_model_name(),
             "sample": "first %d segments of the same workload (Np=%d), %.1f s, single thread, oracle/libsmc_oracle.so "
-                      "(-O3 -DNDEBUG); %d genealogy updates; %.0f of the %d particles in distinct states on average "
-                      "(the reference keeps one record per distinct state, the port expands them)"
+                      "(-O3 -DNDEBUG); %d genealogy updates; %.0f distinct local trees among the %d particles on average "
+                      "(a lower bound on the records the reference's multiplicity representation keeps; the port expands them)"
                       % (done, args.np, dt, st["recombinations"], float(np.mean(distinct)) if distinct else float(args.np), args.np)}
 
 

@@ -11,3 +11,4 @@ ARGS="$REPO/bench.py --length 1e7 --steps 1 --warmup 0 --no-cpu $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_${TAG}_stats -o stats -- python3 $ARGS > $REPO/gpurun_out/prof_${TAG}_stats.json
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $REPO/gpurun_out/prof_${TAG}_fetch -o fetch -- python3 $ARGS > /dev/null
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $REPO/gpurun_out/prof_${TAG}_write -o write -- python3 $ARGS > /dev/null
+cd $REPO && python3 profiles/summarize.py gpurun_out/prof_${TAG} gpurun_out/sum_${TAG}

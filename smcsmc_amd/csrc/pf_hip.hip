@@ -332,12 +332,21 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
     }
 }
 
+// A wave-uniform value moved into vector registers on purpose.  The extend kernels are short of scalar registers (the
+// argument block alone is ~240 of them; spilled ones come back through v_readlane inside the update loop, with the
+// s_nop padding that follows), while only a third of the vector file is in use: the handful of scalars the update loop
+// reads on every trip live in VGPRs instead.
+__device__ __forceinline__ double in_vgpr(double x) { double y; asm("v_mov_b64 %0, %1" : "=v"(y) : "s"(x)); return y; }
+__device__ __forceinline__ unsigned long long in_vgpr(unsigned long long x) { unsigned long long y; asm("v_mov_b64 %0, %1" : "=v"(y) : "s"(x)); return y; }
+
 #ifdef PF_STAMPS
 #define PF_STAMP(k) do { if (A.stamps && (threadIdx.x & 63) == 0 && s < A.stamp_rows)                                   \
         A.stamps[((size_t)s * A.nc + (size_t)(((long long)blockIdx.x * PF_BS + threadIdx.x) >> 6)) * 16 + (k)] = wall_clock64(); } while (0)
 #else
 #define PF_STAMP(k) do {} while (0)
 #endif
+
+__device__ __forceinline__ int gridDim_particles(const KArgs& A) { return (int)((A.Np + PF_BS - 1) / PF_BS); }
 
 // ---- decision on a finished row, made redundantly by every workgroup that needs it (single-launch pipeline) --------
 // normalize_probability (pc.cpp:420-438) and the ESS test of resample (pc.cpp:247-283) from the per-wavefront partials
@@ -628,7 +637,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
                 if (threadIdx.x == 0) {
                     int tot = 0;
                     for (int w = 0; w < PF_BS / 64; ++w) tot += q.wint[2 * (PF_BS / 64) + w];
-                    A.rg_blkcnt[(size_t)row_slot * A.nbx + blockIdx.x] = tot;
+                    A.rg_blkcnt[(size_t)row_slot * gridDim_particles(A) + blockIdx.x] = tot;
                 }
                 if (active) {
                     const double coff_p = pipe_chunk_offset(q, pch);
@@ -708,8 +717,9 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
             }
         }
         RCtx cx;
-        cx.T = sT; cx.I = sI; cx.H = sH; cx.E = A.E; cx.n = n; cx.L = A.L; cx.mu = A.mu; cx.rho = A.rho;
-        cx.seed = A.seed; cx.slot = (unsigned)p; cx.stream = 0;
+        const double v_L = in_vgpr(A.L), v_mu = in_vgpr(A.mu), v_rho = in_vgpr(A.rho);
+        cx.T = sT; cx.I = sI; cx.H = sH; cx.E = A.E; cx.n = n; cx.L = v_L; cx.mu = v_mu; cx.rho = v_rho;
+        cx.seed = in_vgpr(A.seed); cx.slot = (unsigned)p; cx.stream = 0;
         cx.nb = A.n_bias + 1; cx.bH = sBH; cx.bS = sBS; cx.last_iw = 1.0;
         cx.want_desc = A.lmap_opp != nullptr || TREES; cx.want_desc_new = TREES; cx.last_desc = 0; cx.last_desc_new = 0;
         cx.vbc = A.vb_coal; cx.upd_fac = 1.0;
@@ -776,7 +786,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
                 w_post = wp * adj;
                 w_pilot = wq * adj;
                 x_mark = pos;
-                if (!first_copy && pos < A.L) next_base = r_sample_next_base<false>(cx, pos);     // pc.cpp:357-368
+                if (!first_copy && pos < v_L) next_base = r_sample_next_base<false>(cx, pos);     // pc.cpp:357-368
             }
         }
 
@@ -784,7 +794,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
         const bool do_extend = !PIPE || PR.extend != 0;
         const int8_t* data = A.seg_alleles + (size_t)s * n;
         const double seg_end = do_extend ? A.seg_start[s] + A.seg_len[s] : 0.0;
-        const double extend_to = seg_end < A.L ? seg_end : A.L;
+        const double extend_to = seg_end < v_L ? seg_end : v_L;
         const int limit = do_extend ? A.seg_limit[s] : 0;
         unsigned one_mask = 0, zero_mask = 0, present_mask = 0, two_mask = 0;
         int missing = 0;
@@ -810,14 +820,14 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
 
         while (updated_to < extend_to) {
             double new_to = extend_to < next_base ? extend_to : next_base;
-            double f = fastexp(-A.mu * B * (new_to - updated_to));
+            double f = fastexp(-v_mu * B * (new_to - updated_to));
             w_post *= f;
             w_pilot *= f;
             if (BIASED && cx.gK > 0) {
                 // importance_weight_over_segment (particle.cpp:1138-1181): true over guide rate for the stretch
                 // without recombination
                 double dist = new_to - updated_to;
-                double target_rate = dist * A.rho * cx.Ltree;
+                double target_rate = dist * v_rho * cx.Ltree;
                 double sampled_rate = dist * cx.grho[cx.ridx] * cx.Ltree;
                 double iws = fastexp(sampled_rate - target_rate);
                 w_post *= iws;
@@ -899,7 +909,7 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
             double norm = 1.0 / (double)ncfg;
             double lik = 0;
             for (;;) {
-                lik += r_site_lik(t, n, A.mu, one_mask, zero_mask, anc);
+                lik += r_site_lik(t, n, v_mu, one_mask, zero_mask, anc);
                 if (ncfg == 1) break;
                 bool more = false;
                 for (int i = 0; i + 1 < n; i += 2) {
@@ -1844,6 +1854,7 @@ struct PipeLaunch {
     int lc_slot;           // ring slot of the row whose ledger upkeep and counts are due (-1: none)
     int live_slot;         // newest complete slot of the per-slot record counters (ring-overwrite check)
     int nL;                // ledger workgroups
+    int ncw;               // count workgroups per epoch
 };
 
 __global__ void k_pipe_seed(KArgs A, int slot) {
@@ -1958,12 +1969,12 @@ __global__ __launch_bounds__(PF_BS) void k_pipe(KArgs A, long long s, PipeLaunch
     if (lb < PL.nL) {
         if (!r.flag) return;
         const RunLists src = run_lists(A, r.lver), dst = run_lists(A, r.lver ^ 1);
-        if (lb < nb) ledger_new_list(A, dst, A.rg_blkcnt + (size_t)PL.lc_slot * A.nbx, nb, lb, r.gen);
+        if (lb < nb) ledger_new_list(A, dst, A.rg_blkcnt + (size_t)PL.lc_slot * gridDim_particles(A), nb, lb, r.gen);
         else ledger_update(A, lb - nb, PL.nL - nb, r.gen, r.g_retain, src, dst);
         return;
     }
     const int idx = lb - PL.nL;
-    const int e = r.first + idx / nb;
+    const int e = r.first + idx / PL.ncw;
     if (e >= A.E) return;
     const DState st = state_slot(A, PL.lc_slot);
     CountSrc Q;
@@ -1974,7 +1985,7 @@ __global__ __launch_bounds__(PF_BS) void k_pipe(KArgs A, long long s, PipeLaunch
     Q.offp = A.rg_coffp + (size_t)PL.lc_slot * A.nc;
     Q.lists = run_lists(A, r.lver);
     Q.inv = r.inv_T; Q.G = r.gen; Q.g_lo = r.g_lo[e]; Q.g_hi = r.g_hi[e];
-    count_body<NM, 1, EXACT>(A, Q, e, r.wa[e], r.wb[e], idx % nb, nb);
+    count_body<NM, 1, EXACT>(A, Q, e, r.wa[e], r.wb[e], idx % PL.ncw, PL.ncw);
 }
 
 __global__ __launch_bounds__(PF_BS) void k_ledger(KArgs A, int nblocks) {
@@ -2798,6 +2809,8 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
         rc |= dalloc(h, &A.snap_w[b], Np); rc |= dalloc(h, &A.snap_S[b], (size_t)(n - 1) * Np);
         rc |= dalloc(h, &A.snap_xm[b], Np); rc |= dalloc(h, &A.snap_ml[b], Np); rc |= dalloc(h, &A.snap_widx[b], Np);
     }
+    // accumulators of the count workgroups per epoch (measured: four times as many count workgroups per epoch in the row
+    // pipeline made a row 15 % slower -- the launch then holds 5 000 workgroups of 30 KB LDS each, four rounds of the chip)
     A.nbx = h->nblocks;
     rc |= dalloc(h, &A.totals, (size_t)A.ncol * E);
     rc |= dalloc(h, &A.partial, (size_t)E * A.nbx * A.ncol);
@@ -3257,7 +3270,8 @@ static int run_pipeline(pf_handle* h, long long s_begin, long long s_end) {
         PL.lc_slot = (have_lc && !h->no_count) ? (int)((s - 2) & 3) : -1;
         PL.live_slot = (int)((s - 1) & 3);
         PL.nL = PL.lc_slot >= 0 ? nL_full : 0;
-        const int ncount_wg = (PL.lc_slot >= 0 && W2.first < E) ? nb * (E - W2.first) : 0;
+        PL.ncw = h->A.nbx;
+        const int ncount_wg = (PL.lc_slot >= 0 && W2.first < E) ? PL.ncw * (E - W2.first) : 0;
         if (ncount_wg > 0) h->fin_pending = true;
         const bool t = extend && timing_on(h, s);
         {
