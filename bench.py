@@ -322,10 +322,10 @@ def main():
         # HBM traffic of the same kernel from the PMC counters: collected by profiles/collect_round1.sh in separate
         # rocprofv3 passes (counters cannot be read from inside this process) and kept under profiles/
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "round1", "v9_pmc_k_row.json")
-        if os.path.exists(pmc_path):
+        import glob
+        for pmc_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round2", "*_pmc_k_*.json"))):
             pmc = json.load(open(pmc_path))
-            if pmc["shape"] == {"nsam": args.nsam, "np": args.np, "epochs": args.epochs, "pops": args.pops}:
+            if pmc.get("shape") == {"nsam": args.nsam, "np": args.np, "epochs": args.epochs, "pops": args.pops}:
                 traffic = pmc["traffic_bytes_per_launch"]
         out = {
             "metric": "genome segments/sec per EM iteration (%s)" % workload_label(args),
