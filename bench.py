@@ -7,7 +7,7 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JS
     inputs (segments, model tables) already resident in HBM when the timed region starts.
   * workload at N=1: BASELINE.json configs[2] -- 2 diploids (4 haplotypes), 100 Mb, Np=10000,
     E=32 epochs, N0=1e4, mu=2.5e-8, rho=1e-8, data from the in-repo SMC'
-    simulator (seeded).  N>1: one such chunk per GPU (weak scaling: chunks are independent,
+    simulator on the device (k_simulate, seeded; --host-data: the numpy one of round 1).  N>1: one such chunk per GPU (weak scaling: chunks are independent,
     smcsmc/model.py:563-662), then one RCCL all-gather of the packed CountModel buffers summed
     in rank order (deterministic), the functional equivalent of smcsmc/model.py:1176-1184.
   * value = (segments processed by all ranks over K steps) / (max over ranks of the timed wall time).
@@ -67,13 +67,18 @@ def build_workload(args, seed):
         sm[split, 1:, 0] = 1.0
         model.update(n_pops=P, pop_sizes=np.repeat(ps[:, None], P, axis=1), mig_rates=mr, single_mig=sm,
                      sample_pops=[i * P // n for i in range(n)])
-    cache = "/tmp/smcsmc_bench_n%d_L%d_E%d_s%d.npz" % (n, int(L), E, seed)
-    if os.path.exists(cache):
-        z = np.load(cache)
-        seg = {k: z[k] for k in ("start", "length", "alleles")}
+    if getattr(args, "host_data", False):
+        # the numpy simulator of smcsmc_amd/simulate.py (independent of the device code; minutes for 100 Mb, cached)
+        cache = "/tmp/smcsmc_bench_n%d_L%d_E%d_s%d.npz" % (n, int(L), E, seed)
+        if os.path.exists(cache):
+            z = np.load(cache)
+            seg = {k: z[k] for k in ("start", "length", "alleles")}
+        else:
+            seg = simulate.simulate_seg(n, L, mu, rho, ct, ps, seed=seed)
+            np.savez(cache, **seg)
     else:
-        seg = simulate.simulate_seg(n, L, mu, rho, ct, ps, seed=seed)
-        np.savez(cache, **seg)
+        # generated on the device (k_simulate: one lane per chunk, the filter's own SMC' transition), seeded
+        seg = simulate.simulate_seg_device(n, L, mu, rho, ct, ps, seed=seed, nchunks=1, device=getattr(args, "device", 0))[0]
     max_seg_len = int(2.0 / (rho * 4 * N0))        # pfparam.cpp:364
     S = segmod.Segments.from_sites(seg["start"], seg["length"], seg["alleles"], n, L, max_segment_length=max_seg_len)
     if not getattr(args, "uncalibrated_lags", False):
@@ -211,6 +216,8 @@ def main():
     ap.add_argument("--timing-period", type=int, default=16, help="time every k-th segment's kernels with HIP events")
     ap.add_argument("--no-local-recomb", action="store_true",
                     help="do not record the 100-bp local recombination map (the binary always records it, smcsmc.cpp:376-383)")
+    ap.add_argument("--host-data", action="store_true",
+                    help="synthetic data from the numpy simulator (round-1 inputs) instead of the device-side simulator")
     ap.add_argument("--uncalibrated-lags", action="store_true",
                     help="the reference's uncalibrated lags 4/(rho*top_t) instead of the calibrated default of the binary")
     ap.add_argument("--debug", type=int, default=0, help="pf_params.debug bits (include/smcsmc_pf.h): 4 no counting, 8 two launches per row")

@@ -200,6 +200,13 @@ int pf_get_stats(pf_handle* h, int64_t* n_records, int64_t* state_bytes_per_part
 int pf_median_survival(const pf_model* model, uint64_t seed, int32_t min_events, int64_t max_trees, double* median_out,
                        int64_t* trees_used, int device);
 
+/* Synthetic data next to the path (the reference shells out to scrm and converts, populationmodels.py:440-577): `nchunks`
+ * independent chunks of the model's length under the same SMC' process the filter simulates, one population; per chunk
+ * ascending continuous site positions pos[c*max_sites + k] and carrier masks (bit i = sample i carries the mutation).
+ * n_sites[c] < 0 means more than max_sites sites were drawn (the first max_sites are returned). */
+int pf_simulate_sites(const pf_model* model, uint64_t seed, int32_t nchunks, int64_t max_sites, double* pos, uint32_t* masks,
+                      int64_t* n_sites, int device);
+
 /* unit-level entry points used by the parity tests (device implementations of the math and
  * of the canonical reductions; each runs one small kernel on the handle-independent default stream) */
 int pf_test_math(const double* x, int64_t n, double* out_exp, double* out_log, double* out_fastexp, int device);

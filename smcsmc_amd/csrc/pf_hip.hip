@@ -2471,6 +2471,76 @@ __global__ void k_test_uniform(unsigned long long seed, unsigned slot, unsigned 
     if (i < n) o[i] = philox_uniform(seed, slot, stream, first + (unsigned long long)i);
 }
 
+// ------------------------------------------------------------------ k_simulate: synthetic data on the device
+// The `.seg` producer next to the path (the reference shells out to scrm and converts its
+// output, populationmodels.py:440-577).  One lane = one independent chromosome chunk: a prior tree, then along the
+// sequence the same SMC' transition the filter simulates (genealogy_update), and between recombinations mutations
+// dropped as a Poisson process of rate mu * tree length, each on a branch drawn in proportion to its length
+// (sample_point) -- the carriers are the samples below it.  Output per chunk: site positions (continuous, ascending)
+// and carrier masks; the host rounds them to bases and writes rows.  Its own Philox stream (3).
+__global__ __launch_bounds__(PF_BS) void k_simulate(KArgs A, unsigned long long seed, int nchunks, long long max_sites,
+                                                    double* pos_out, unsigned* mask_out, long long* n_out) {
+    extern __shared__ double smem[];
+    Smem m = carve(smem, A.n, A.E);
+    load_model(A, m);
+    __syncthreads();
+    const long long r = (long long)blockIdx.x * PF_BS + threadIdx.x;
+    if (r >= nchunks) return;
+    const int n = A.n;
+    Lane ln = make_lane(A, m, r);
+    ln.seed = seed;
+    ln.stream = 3;
+    ln.ebuf = -dlog(uni(ln));
+    int root = 0;
+    for (int i = 1; i < n; ++i) {            // Forest::buildInitialTree: the leaves join one at a time (as k_calibrate)
+        int ni = i - 1;
+        double tc = coalesce_up(ln, [&](int k) { return LS(ln, k); }, ni, i, 0.0);
+        int pr = -1, ps = 0;
+        int k = lineages_at(ln, ni, tc, -1, &pr, &ps);
+        bool above_root = (ni == 0) || (tc >= LS(ln, ni - 1));
+        int kk = above_root ? 1 : k;
+        double u = uni(ln);
+        int idx = min((int)(u * (double)kk), kk - 1);
+        if (above_root) insert_node(ln, ni, tc, i, -1, 0, root);
+        else { lineages_at(ln, ni, tc, idx, &pr, &ps); insert_node(ln, ni, tc, i, pr, ps, root); }
+        root = n + ni;
+    }
+    ln.Ltree = tree_length(ln, n);
+    double* tmp = m.t0 + threadIdx.x;        // per-lane LDS column for the descendant masks
+    double* pos = pos_out + (size_t)r * max_sites;
+    unsigned* msk = mask_out + (size_t)r * max_sites;
+    long long ns = 0;
+    double x = 0.0;
+    double next_rec = sample_next_base(ln, 0.0);
+    double next_mut = x + (-dlog(uni(ln))) / (A.mu * ln.Ltree);
+    bool overflow = false;
+    while (x < A.L) {
+        if (next_mut < next_rec && next_mut < A.L) {
+            // a mutation on the current tree: a uniform point of the tree picks the branch
+            int rp = 0, sb = 0;
+            double h;
+            ln.uqn = 0;
+            sample_point(ln, &rp, &sb, &h);
+            const unsigned carriers = lane_desc_mask(ln, LC(ln, rp, sb), tmp);
+            if (ns < max_sites) { pos[ns] = next_mut; msk[ns] = carriers; }
+            else overflow = true;
+            ++ns;
+            x = next_mut;
+            next_mut = x + (-dlog(uni(ln))) / (A.mu * ln.Ltree);
+            continue;
+        }
+        x = next_rec;
+        if (!(x < A.L)) break;
+        double h, tc, sp;
+        bool changed;
+        genealogy_update(ln, &h, &tc, &sp, &changed);
+        ln.uqn = 0;                           // what is left of the update's uniforms is not reused
+        next_rec = sample_next_base(ln, x);
+        next_mut = x + (-dlog(uni(ln))) / (A.mu * ln.Ltree);     // memoryless: redrawn under the new tree length
+    }
+    n_out[r] = overflow ? -ns : ns;
+}
+
 // ------------------------------------------------------------------ host side
 static thread_local std::string g_err;
 const char* pf_last_error(void) { return g_err.c_str(); }
@@ -3957,4 +4027,50 @@ int pf_median_survival(const pf_model* m, uint64_t seed, int32_t min_events, int
     for (int e = 0; e < E; ++e)
         if (median_out[e] < 0) median_out[e] = e > 0 ? median_out[e - 1] : earliest;
     return 0;
+}
+
+// Synthetic data for `nchunks` independent chunks of the model's length (one population): site positions and carrier
+// masks per chunk (k_simulate).  n_sites[c] < 0: more than max_sites sites (the first max_sites are valid).
+int pf_simulate_sites(const pf_model* m, uint64_t seed, int32_t nchunks, int64_t max_sites, double* pos, uint32_t* masks,
+                      int64_t* n_sites, int device) {
+    if (test_setup(device)) return -1;
+    if (m->n_pops != 1 || m->nsam < 2 || m->nsam > PF_NMAX || m->n_epochs < 1 || m->n_epochs > PF_EMAX || nchunks < 1 || max_sites < 1) {
+        g_err = "pf_simulate_sites: one population, 2..16 haplotypes, 1..64 epochs";
+        return -1;
+    }
+    const int E = m->n_epochs, n = m->nsam;
+    KArgs A;
+    memset(&A, 0, sizeof(A));
+    A.E = E; A.n = n; A.P = 1; A.L = m->loci_length; A.mu = m->mutation_rate; A.rho = m->recombination_rate;
+    double *dT, *dI, *dHc, *dpos; int* dRF; unsigned* dmask; long long* dn;
+    HIPCHK(hipMalloc(&dT, E * 8)); HIPCHK(hipMalloc(&dI, E * 8)); HIPCHK(hipMalloc(&dHc, E * 8)); HIPCHK(hipMalloc(&dRF, E * 4));
+    HIPCHK(hipMalloc(&dpos, (size_t)nchunks * max_sites * 8)); HIPCHK(hipMalloc(&dmask, (size_t)nchunks * max_sites * 4));
+    HIPCHK(hipMalloc(&dn, (size_t)nchunks * 8));
+    std::vector<double> inv2N(E);
+    for (int e = 0; e < E; ++e) inv2N[e] = 1.0 / (2.0 * m->pop_sizes[e]);
+    std::vector<int> rf(E, 3);
+    const std::vector<double> Hc = cumulative_intensity(m->change_times, inv2N, E);
+    HIPCHK(hipMemcpy(dT, m->change_times, E * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dI, inv2N.data(), E * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dHc, Hc.data(), E * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dRF, rf.data(), E * 4, hipMemcpyHostToDevice));
+    A.T = dT; A.inv2N = dI; A.Hc = dHc; A.recflags = dRF;
+    const size_t smem = smem_bytes(n, E);
+    if (smem > 64 * 1024) hipFuncSetAttribute((const void*)k_simulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(k_simulate, dim3((unsigned)((nchunks + PF_BS - 1) / PF_BS)), dim3(PF_BS), smem, 0, A, (unsigned long long)seed,
+                       (int)nchunks, (long long)max_sites, dpos, dmask, dn);
+    int rc = check_launch("k_simulate");
+    if (!rc && hipDeviceSynchronize() != hipSuccess) { g_err = "k_simulate failed"; rc = -1; }
+    if (!rc) {
+        std::vector<long long> hn(nchunks);
+        HIPCHK(hipMemcpy(hn.data(), dn, (size_t)nchunks * 8, hipMemcpyDeviceToHost));
+        for (int c = 0; c < nchunks; ++c) {
+            n_sites[c] = hn[c];
+            const long long k = std::min<long long>(std::llabs(hn[c]), max_sites);
+            HIPCHK(hipMemcpy(pos + (size_t)c * max_sites, dpos + (size_t)c * max_sites, (size_t)k * 8, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(masks + (size_t)c * max_sites, dmask + (size_t)c * max_sites, (size_t)k * 4, hipMemcpyDeviceToHost));
+        }
+    }
+    hipFree(dT); hipFree(dI); hipFree(dHc); hipFree(dRF); hipFree(dpos); hipFree(dmask); hipFree(dn);
+    return rc;
 }

@@ -94,7 +94,7 @@ EXPORTS = [
     "pf_terminal_branch_quantiles",
     "pf_update_segment", "pf_count", "pf_resample", "pf_run", "pf_finish", "pf_sync",
     "pf_num_segments_done", "pf_logl", "pf_get_counts", "pf_get_trace", "pf_get_resample_events",
-    "pf_get_particles", "pf_get_migrations", "pf_get_local_recomb", "pf_sample_tree_events", "pf_get_kernel_time", "pf_set_timing", "pf_get_stats", "pf_debug_stamps",
+    "pf_get_particles", "pf_get_migrations", "pf_get_local_recomb", "pf_sample_tree_events", "pf_get_kernel_time", "pf_set_timing", "pf_get_stats", "pf_debug_stamps", "pf_simulate_sites",
     "pf_median_survival", "pf_test_math", "pf_test_div", "pf_test_uniform", "pf_test_reduce", "pf_test_systematic",
 ]
 
@@ -439,6 +439,30 @@ def median_survival(model, seed=1, min_events=200, max_trees=1000000, device=0):
                             C.byref(trees), int(device)) < 0:
         raise PfError(_err(L))
     return out, trees.value
+
+
+def simulate_sites(model, seed=1, nchunks=1, max_sites=None, device=0):
+    """Synthetic data on the device (k_simulate): for each of `nchunks` independent chunks of the model's length the
+    ascending site positions and carrier masks.  Returns a list of (positions, masks)."""
+    L = load_library()
+    L.pf_simulate_sites.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.pf_simulate_sites.restype = C.c_int
+    mod, keep = _pack_model(model)
+    n = mod.nsam
+    if max_sites is None:
+        # expected sites 4 N mu H(n-1) L with the largest population size, with ample room
+        harmonic = sum(1.0 / i for i in range(1, n))
+        nmax = float(np.max(np.asarray(model["pop_sizes"], float)))
+        max_sites = int(2.0 * 4.0 * nmax * model["mutation_rate"] * harmonic * model["loci_length"]) + 4096
+    pos = np.zeros((nchunks, max_sites))
+    masks = np.zeros((nchunks, max_sites), np.uint32)
+    cnt = np.zeros(nchunks, np.int64)
+    if L.pf_simulate_sites(C.byref(mod), int(seed), int(nchunks), int(max_sites), pos.ctypes.data, masks.ctypes.data,
+                           cnt.ctypes.data, int(device)) < 0:
+        raise PfError(_err(L))
+    if (cnt < 0).any():
+        raise PfError("pf_simulate_sites: more than max_sites sites in a chunk")
+    return [(pos[c, :cnt[c]].copy(), masks[c, :cnt[c]].copy()) for c in range(nchunks)]
 
 
 def terminal_branch_quantiles(model, seed=1, n_trees=1000000, quantiles=None, device=0):

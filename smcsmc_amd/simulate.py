@@ -175,7 +175,12 @@ def simulate_seg(n, L, mu, rho, change_times, pop_sizes, seed=1, missing=()):
         parent[c] = p_old
         parent[b] = p_old
 
-    # ---- .seg rows (convert_scrm_to_seg conventions) ----
+    return sites_to_seg(positions, patterns, n, L, missing)
+
+
+def sites_to_seg(positions, patterns, n, L, missing=()):
+    """.seg rows from ascending site positions and 0/1 patterns, with the conventions of convert_scrm_to_seg
+    (populationmodels.py:502-577): integer positions int(x+0.5), a leading position 1, a trailing all-missing row."""
     ipos = [1]
     rows = []
     for ppos, pat in zip(positions, patterns):
@@ -188,7 +193,7 @@ def simulate_seg(n, L, mu, rho, change_times, pop_sizes, seed=1, missing=()):
     for idx in range(len(ipos) - 1):
         start.append(ipos[idx])
         length.append(ipos[idx + 1] - ipos[idx])
-        a = rows[idx].copy()
+        a = np.array(rows[idx], np.int8).copy()
         for m in missing:
             a[m] = -1
         alleles.append(a)
@@ -197,6 +202,21 @@ def simulate_seg(n, L, mu, rho, change_times, pop_sizes, seed=1, missing=()):
     alleles.append(-np.ones(n, dtype=np.int8))
     return {"start": np.array(start, np.int64), "length": np.array(length, np.int64),
             "alleles": np.array(alleles, np.int8).reshape(-1, n)}
+
+
+def simulate_seg_device(n, L, mu, rho, change_times, pop_sizes, seed=1, nchunks=1, device=0, missing=()):
+    """The same data model simulated on the GPU (k_simulate: one lane per chunk, the filter's own SMC' transition,
+    Philox stream 3): a list of `nchunks` independent chunks in the format of simulate_seg.  A 100 Mb chunk of two
+    diploids takes well under a second; the chunks of a call run side by side."""
+    from . import pf
+    change_times = np.asarray(change_times, float)
+    model = dict(change_times=change_times, pop_sizes=np.asarray(pop_sizes, float), lags=np.ones(len(change_times)), nsam=int(n),
+                 loci_length=float(L), mutation_rate=float(mu), recombination_rate=float(rho))
+    out = []
+    for pos, masks in pf.simulate_sites(model, seed=seed, nchunks=nchunks, device=device):
+        pats = ((masks[:, None] >> np.arange(n)[None, :]) & 1).astype(np.int8)
+        out.append(sites_to_seg(pos, pats, n, L, missing))
+    return out
 
 
 def write_seg(path, seg):

@@ -1,0 +1,51 @@
+"""The device-side data simulator (k_simulate / pf_simulate_sites): synthetic `.seg` data from the same SMC' process the
+filter simulates (the reference shells out to scrm, populationmodels.py:440-577)."""
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_simulator_matches_coalescent_expectations(hiplib):
+    from smcsmc_amd import simulate
+    n, L, N0, mu, rho = 4, 2.0e6, 1e4, 2.5e-8, 1e-8
+    ct = simulate.default_epochs(8)
+    chunks = simulate.simulate_seg_device(n, L, mu, rho, ct, np.full(8, N0), seed=11, nchunks=24)
+    assert len(chunks) == 24
+    # segregating sites: E[S] = 4 N mu L H(n-1); the chunks are independent replicates
+    S = np.array([len(c["start"]) - 1 for c in chunks], float)
+    expect = 4 * N0 * mu * L * (1 + 0.5 + 1.0 / 3)
+    assert abs(S.mean() / expect - 1) < 0.04, (S.mean(), expect)
+    assert S.std() > 0.005 * expect and len({int(v) for v in S}) > 12          # replicates differ
+    # site frequency spectrum: E[xi_i] proportional to 1/i
+    al = np.concatenate([c["alleles"][:-1] for c in chunks])
+    assert set(np.unique(al)) <= {0, 1}
+    k = al.sum(axis=1)
+    assert k.min() >= 1 and k.max() <= n - 1
+    sfs = np.array([(k == i).sum() for i in (1, 2, 3)], float)
+    np.testing.assert_allclose(sfs / sfs.sum(), np.array([1, 0.5, 1.0 / 3]) / (11.0 / 6), atol=0.012)
+    # rows are well formed: consecutive, last row all missing and reaching the end
+    c0 = chunks[0]
+    assert (c0["start"][1:] == c0["start"][:-1] + c0["length"][:-1]).all() and c0["start"][0] == 1
+    assert (c0["alleles"][-1] == -1).all() and c0["start"][-1] + c0["length"][-1] == int(L)
+    # linkage: neighbouring sites share their tree more often than distant ones (recombination is simulated)
+    same_near = (al[1:] == al[:-1]).all(axis=1).mean()
+    same_far = (al[200:] == al[:-200]).all(axis=1).mean()
+    assert same_near > same_far + 0.05
+
+
+def test_device_simulator_is_reproducible_and_feeds_the_filter(hiplib, oracle):
+    from smcsmc_amd import ParticleFilter, segments as segmod, simulate
+    model = cases.make_model(n=4, E=8, L=3e5)
+    a = simulate.simulate_seg_device(4, 3e5, 2.5e-8, 1e-8, model["change_times"], model["pop_sizes"], seed=5, nchunks=2)
+    b = simulate.simulate_seg_device(4, 3e5, 2.5e-8, 1e-8, model["change_times"], model["pop_sizes"], seed=5, nchunks=2)
+    for x, y in zip(a, b):
+        assert all((x[k] == y[k]).all() for k in x)
+    assert len(a[0]["start"]) != len(a[1]["start"]) or (a[0]["start"] != a[1]["start"]).any()
+    segs = segmod.Segments.from_sites(a[0]["start"], a[0]["length"], a[0]["alleles"], 4, 3e5, max_segment_length=5000).pack(model["lags"])
+    g = ParticleFilter(model, 500, seed=3); g.init_prior(0.0); g.load_segments(segs); g.run(); g.finish()
+    o = oracle.Oracle(model, 500, seed=3); o.init_prior(0.0); o.run(o.pack_segments(model, segs))
+    assert np.float64(g.logl()).view(np.uint64) == np.float64(o.logl()).view(np.uint64)
+    assert np.isfinite(g.logl()) and g.logl() < 0
