@@ -32,6 +32,9 @@
  *      interval; same distribution, and the arithmetic the device uses.  One opportunity record per interval is
  *      still written, between the cut height and the time found.
  *   D13 one population: the four uniforms of a genealogy update are the halves of two consecutive Philox blocks
+ *   D14 structured models: the walk of the floating lineage compares its budget with differences of per-population
+ *      cumulative intensities once per stretch between two changes of the configuration (node, migration event on
+ *      the tree, fixed-time move) instead of once per epoch; same distribution (mp_coalesce below)
  *   (D7-D11, R1, R2: DESIGN.md section 6)
  */
 #include "smc_oracle.h"
@@ -153,6 +156,8 @@ struct Model {
     std::vector<double> Mrate;       /* [E*P*P] backward migration rate p -> q per generation */
     std::vector<double> Mtot;        /* [E*P]   sum_q Mrate[e][p][q], summed q ascending */
     std::vector<int> jmap;           /* [E*P]   population after the fixed-time moves at the start of epoch e (-ej) */
+    std::vector<double> Cc, Cm;      /* [E*P]   integrals of inv2Np / Mtot from 0 to the epoch starts (the one-population Hc, per population) */
+    std::vector<double> Tjoin;       /* [E]     start of the next epoch after e whose jmap moves a population, +inf if none */
     std::vector<int> sample_pop;     /* [n] */
     /* variational-Bayes weight factors exp_digamma(c)/c per event (particle.cpp:266-272); empty = off */
     std::vector<double> vb_coal;     /* [E*P] */
@@ -541,7 +546,17 @@ struct Filter {
     /* The floating lineage starts at height h in population pf0 and moves up through the tree `t`
      * (ni internal nodes; root_id its top node, or the single leaf).  Above the root the root's own
      * lineage is the second active lineage.  One unit exponential is consumed across the intervals
-     * (sampleExpoLimit), the kind of event is drawn with one uniform. */
+     * (sampleExpoLimit), the kind of event is drawn with one uniform.
+     *
+     * D14 (arithmetic, not distribution).  The reference stops at every epoch boundary, node and event and
+     * subtracts (length x rate) from the budget (particle.cpp:230-300 with the TimeIntervalIterator of scrm).
+     * Between two changes of the configuration (next node, next migration event on the tree, next epoch with a
+     * fixed-time move) the lineages' populations and the number of partners are constant, so the hazard over
+     * that stretch is a difference of the cumulative intensities Cc / Cm tabulated at the epoch starts -- the
+     * same step D12 takes for one population with Hc.  The budget is compared with that difference once per
+     * stretch; in the stretch in which it runs out the epoch of the event is found by comparing the budget with the
+     * same difference taken to the epoch starts of the stretch.  The event records are still cut per epoch (one Ev
+     * per epoch of the stretch), as record_all_event makes them. */
     void mp_coalesce(int64_t slot, Particle* rec_p, const Tree& t, int ni, int root_id, double h, int pf0,
                      double x, int limit, Walk& W) {
         SlotRng& g = rng[slot];
@@ -555,81 +570,120 @@ struct Filter {
         int pf = pf0, pr = pop_base(t, root_id);
         W.npath = W.nrpath = 0;
         W.tfirst = -1.0;
+        auto ci = [&](int q, int ee, double tm) { return M.Cc[ee * P + q] + (tm - M.T[ee]) * M.inv2Np[ee * P + q]; };
+        auto cm = [&](int q, int ee, double tm) { return M.Cm[ee * P + q] + (tm - M.T[ee]) * M.Mtot[ee * P + q]; };
+        /* record_all_event for [a, b) of the walk, cut at the epoch boundaries; the event (if any) sits at b */
+        auto record = [&](bool root_active, int weight, double a, double b, int ea, int kind, int to) {
+            if (!(rec_p && record_events)) return;
+            for (int ee = ea; ee < M.E; ++ee) {
+                double lo = std::max(a, M.T[ee]), hi = std::min(b, M.epoch_end(ee));
+                const bool last = !(M.epoch_end(ee) <= b) || ee + 1 == M.E;
+                if ((M.recflags[ee] & REC_COALMIGR) && ee <= limit && (hi > lo || (last && kind != 0))) {
+                    if (hi < lo) hi = lo;
+                    Ev* ev = new_event(*rec_p, ee, 1, lo, hi, x, x, weight);
+                    ev->pop = (int8_t)pf;
+                    if (last && kind == 1) ev->event = 1;
+                    if (last && kind == 2) { ev->event = 2; ev->mig_to = (int8_t)to; }
+                    if (root_active) {
+                        /* second active node: no contemporaries above the root, migration opportunity only */
+                        Ev* ev2 = new_event(*rec_p, ee, 1, lo, hi, x, x, 0);
+                        ev2->pop = (int8_t)pr;
+                        if (last && kind == 3) { ev2->event = 2; ev2->mig_to = (int8_t)to; }
+                    }
+                }
+                if (last) break;
+            }
+        };
         for (;;) {
             const bool root_active = tt >= Hr;
             double tn_node = i < ni ? t.S[i] : HUGE_VAL;
             double tn_mig = j < t.nm ? t.Mt[j] : HUGE_VAL;
-            double tn_ep = M.epoch_end(e);
-            double tn = std::min(std::min(tn_node, tn_mig), tn_ep);
+            const double tj = M.Tjoin[e];
+            double tn = std::min(std::min(tn_node, tn_mig), tj);
             int dummy_r = 0, dummy_s = 0;
             int k = lineages_in_pop(t, ni, tt, pf, -1, &dummy_r, &dummy_s);
             int weight = k + ((root_active && pr == pf) ? 1 : 0);      /* particle.cpp:255-260, 277 */
-            double rc = (double)weight * M.inv2Np[e * P + pf];
-            double rmf = M.Mtot[e * P + pf];
-            double rmr = root_active ? M.Mtot[e * P + pr] : 0.0;
-            double lam = (rc + rmf) + rmr;
-            if (lam == 0.0 && !(tn < HUGE_VAL)) throw std::logic_error("No final coalescence event was sampled!");
-            double need = (tn - tt) * lam;
-            bool fire = !(g.ebuf > need);
-            double t1 = fire ? tt + g.ebuf / lam : tn;
-            int kind = 0, to = 0;          /* 1 coalescence, 2 floating lineage migrates, 3 root lineage migrates */
-            if (fire) {
-                double v = uni(slot) * lam;
-                if (v < rc || (rmf == 0.0 && rmr == 0.0)) kind = 1;
-                else {
-                    v -= rc;
-                    int from;
-                    if (v < rmf || rmr == 0.0) { kind = 2; from = pf; }
-                    else { kind = 3; from = pr; v -= rmf; }
-                    to = -1;
-                    for (int q = 0; q < P; ++q) {
-                        double m = M.Mrate[(e * P + from) * P + q];
-                        if (q == from || m == 0.0) continue;
-                        to = q;
-                        if (v < m) break;
-                        v -= m;
+            int en = e;
+            bool quiet = false;
+            if (tn < HUGE_VAL) {
+                while (en + 1 < M.E && M.T[en + 1] <= tn) ++en;
+                double need = (double)weight * (ci(pf, en, tn) - ci(pf, e, tt)) + (cm(pf, en, tn) - cm(pf, e, tt));
+                if (root_active) need = need + (cm(pr, en, tn) - cm(pr, e, tt));
+                if (g.ebuf > need) { g.ebuf -= need; quiet = true; }
+            }
+            if (!quiet) {
+                /* the epoch of the event: the hazard from tt to the start of epoch k is the same difference of cumulative
+                 * intensities as `need` (it ascends with k), so the event falls into the last epoch of the stretch whose
+                 * start the budget still reaches; one division places it there */
+                const double f0c = ci(pf, e, tt), f0m = cm(pf, e, tt), f0r = root_active ? cm(pr, e, tt) : 0.0;
+                const int elim = tn < HUGE_VAL ? en : M.E - 1;
+                int ee = e;
+                double gee = 0.0;
+                while (ee < elim) {
+                    double gk = (double)weight * (M.Cc[(ee + 1) * P + pf] - f0c) + (M.Cm[(ee + 1) * P + pf] - f0m);
+                    if (root_active) gk = gk + (M.Cm[(ee + 1) * P + pr] - f0r);
+                    if (!(g.ebuf > gk)) break;
+                    gee = gk;
+                    ++ee;
+                }
+                const double rc = (double)weight * M.inv2Np[ee * P + pf];
+                const double rmf = M.Mtot[ee * P + pf];
+                const double rmr = root_active ? M.Mtot[ee * P + pr] : 0.0;
+                const double lam = (rc + rmf) + rmr;
+                if (lam == 0.0) throw std::logic_error("No final coalescence event was sampled!");
+                double t1 = ee == e ? tt + g.ebuf / lam : M.T[ee] + (g.ebuf - gee) / lam;
+                {
+                    const double up = std::min(M.epoch_end(ee), tn);
+                    if (t1 > up) t1 = up;
+                }
+                {
+                    int kind = 0, to = 0;          /* 1 coalescence, 2 floating lineage migrates, 3 root lineage migrates */
+                    double v = uni(slot) * lam;
+                    if (v < rc || (rmf == 0.0 && rmr == 0.0)) kind = 1;
+                    else {
+                        v -= rc;
+                        int from;
+                        if (v < rmf || rmr == 0.0) { kind = 2; from = pf; }
+                        else { kind = 3; from = pr; v -= rmf; }
+                        to = -1;
+                        for (int q = 0; q < P; ++q) {
+                            double m = M.Mrate[(ee * P + from) * P + q];
+                            if (q == from || m == 0.0) continue;
+                            to = q;
+                            if (v < m) break;
+                            v -= m;
+                        }
                     }
+                    record(root_active, weight, tt, t1, e, kind, to);
+                    if (W.tfirst < 0.0) W.tfirst = t1;          /* particle.cpp:263-264 */
+                    g.ebuf = -smc_log(uni(slot));
+                    if (rec_p && !M.vb_coal.empty())            /* adjustWeights(exp_digamma(c)/c), particle.cpp:266-272 */
+                        upd_fac *= kind == 1 ? M.vb_coal[ee * P + pf] : M.vb_mig[(ee * P + (kind == 2 ? pf : pr)) * P + to];
+                    if (kind == 1) {
+                        W.tc = t1; W.pf = pf; W.pr = pr; W.weight = weight;
+                        return;
+                    }
+                    if (kind == 2) {
+                        if (W.npath >= MMAX) throw std::runtime_error("too many migration events on one local tree");
+                        W.pt[W.npath] = t1; W.pq[W.npath] = (int8_t)to; ++W.npath;
+                        pf = to;
+                    } else {
+                        if (W.nrpath >= MMAX) throw std::runtime_error("too many migration events on one local tree");
+                        W.rt[W.nrpath] = t1; W.rq[W.nrpath] = (int8_t)to; ++W.nrpath;
+                        pr = to;
+                    }
+                    tt = t1;
+                    e = ee;
+                    continue;
                 }
             }
-            if (rec_p && record_events && (M.recflags[e] & REC_COALMIGR) && e <= limit) {
-                Ev* ev = new_event(*rec_p, e, 1, tt, t1, x, x, weight);
-                ev->pop = (int8_t)pf;
-                if (kind == 1) ev->event = 1;
-                if (kind == 2) { ev->event = 2; ev->mig_to = (int8_t)to; }
-                if (root_active) {
-                    /* second active node: no contemporaries above the root, migration opportunity only */
-                    Ev* ev2 = new_event(*rec_p, e, 1, tt, t1, x, x, 0);
-                    ev2->pop = (int8_t)pr;
-                    if (kind == 3) { ev2->event = 2; ev2->mig_to = (int8_t)to; }
-                }
-            }
-            if (fire) {
-                if (W.tfirst < 0.0) W.tfirst = t1;          /* particle.cpp:263-264 */
-                g.ebuf = -smc_log(uni(slot));
-                if (rec_p && !M.vb_coal.empty())            /* adjustWeights(exp_digamma(c)/c), particle.cpp:266-272 */
-                    upd_fac *= kind == 1 ? M.vb_coal[e * P + pf] : M.vb_mig[(e * P + (kind == 2 ? pf : pr)) * P + to];
-                if (kind == 1) {
-                    W.tc = t1; W.pf = pf; W.pr = pr; W.weight = weight;
-                    return;
-                }
-                if (kind == 2) {
-                    if (W.npath >= MMAX) throw std::runtime_error("too many migration events on one local tree");
-                    W.pt[W.npath] = t1; W.pq[W.npath] = (int8_t)to; ++W.npath;
-                    pf = to;
-                } else {
-                    if (W.nrpath >= MMAX) throw std::runtime_error("too many migration events on one local tree");
-                    W.rt[W.nrpath] = t1; W.rq[W.nrpath] = (int8_t)to; ++W.nrpath;
-                    pr = to;
-                }
-                tt = t1;
-                continue;
-            }
-            g.ebuf -= need;
+            record(root_active, weight, tt, tn, e, 0, 0);
+            const bool at_join = !(tn < tj);
             tt = tn;
+            e = en;
             while (i < ni && t.S[i] <= tt) ++i;
             while (j < t.nm && t.Mt[j] <= tt) ++j;
-            if (tn_ep <= tn) {
-                ++e;
+            if (at_join) {
                 /* fixed-time moves at the start of epoch e */
                 int q = M.jmap[e * P + pf];
                 if (q != pf) {
@@ -1849,6 +1903,20 @@ static void fill_model(Model& M, const smco_model* m) {
             }
             M.jmap[e * P + a] = cur;
         }
+    M.Cc.assign(E * P, 0.0);
+    M.Cm.assign(E * P, 0.0);
+    for (int e = 0; e + 1 < E; ++e)
+        for (int a = 0; a < P; ++a) {
+            const double dt = M.T[e + 1] - M.T[e];
+            M.Cc[(e + 1) * P + a] = M.Cc[e * P + a] + dt * M.inv2Np[e * P + a];
+            M.Cm[(e + 1) * P + a] = M.Cm[e * P + a] + dt * M.Mtot[e * P + a];
+        }
+    M.Tjoin.assign(E, HUGE_VAL);
+    for (int e = E - 2; e >= 0; --e) {
+        bool moves = false;
+        for (int a = 0; a < P; ++a) moves |= M.jmap[(e + 1) * P + a] != a;
+        M.Tjoin[e] = moves ? M.T[e + 1] : M.Tjoin[e + 1];
+    }
     if (m->vb_coal_counts) {
         M.vb_coal.resize(E * P);
         for (int i = 0; i < E * P; ++i) M.vb_coal[i] = exp_digamma(m->vb_coal_counts[i]) / m->vb_coal_counts[i];

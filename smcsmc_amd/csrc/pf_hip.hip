@@ -340,10 +340,25 @@ __device__ __forceinline__ double in_vgpr(double x) { double y; asm("v_mov_b64 %
 __device__ __forceinline__ unsigned long long in_vgpr(unsigned long long x) { unsigned long long y; asm("v_mov_b64 %0, %1" : "=v"(y) : "s"(x)); return y; }
 
 #ifdef PF_STAMPS
+__device__ __forceinline__ void pf_acc_trip(unsigned long long* a) { a[5] += 1; }
+#else
+#define pf_acc_trip(a) do {} while (0)
+#endif
+#ifdef PF_STAMPS
 #define PF_STAMP(k) do { if (A.stamps && (threadIdx.x & 63) == 0 && s < A.stamp_rows)                                   \
-        A.stamps[((size_t)s * A.nc + (size_t)(((long long)blockIdx.x * PF_BS + threadIdx.x) >> 6)) * 16 + (k)] = wall_clock64(); } while (0)
+        A.stamps[((size_t)s * A.nc + (size_t)(((long long)blockIdx.x * PF_BS + threadIdx.x) >> 6)) * PF_STAMP_W + (k)] = wall_clock64(); } while (0)
+#define PF_TICK(var) unsigned long long var = wall_clock64()
+#define PF_ACC(slot, t0, t1) pf_acc[slot] += (t1) - (t0)
+#define PF_ACC_DECL unsigned long long pf_acc[6] = {0, 0, 0, 0, 0, 0}
+#define PF_ACC_STORE do { if (A.stamps && (threadIdx.x & 63) == 0 && s < A.stamp_rows)                                  \
+        for (int k_ = 0; k_ < 6; ++k_)                                                                                  \
+            A.stamps[((size_t)s * A.nc + (size_t)(((long long)blockIdx.x * PF_BS + threadIdx.x) >> 6)) * PF_STAMP_W + 9 + k_] = pf_acc[k_]; } while (0)
 #else
 #define PF_STAMP(k) do {} while (0)
+#define PF_TICK(var) do {} while (0)
+#define PF_ACC(slot, t0, t1) do {} while (0)
+#define PF_ACC_DECL do {} while (0)
+#define PF_ACC_STORE do {} while (0)
 #endif
 
 __device__ __forceinline__ int gridDim_particles(const KArgs& A) { return (int)((A.Np + PF_BS - 1) / PF_BS); }
@@ -818,7 +833,9 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
         else if (leaf_status == 1) B = cx.Ltree;
         else B = r_tracked_len(t, n, present_mask);
 
+        PF_ACC_DECL;
         while (updated_to < extend_to) {
+            PF_TICK(tk0);
             double new_to = extend_to < next_base ? extend_to : next_base;
             double f = fastexp(-v_mu * B * (new_to - updated_to));
             w_post *= f;
@@ -841,6 +858,8 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
                 next_base = r_sample_next_base<false>(cx, updated_to);
                 continue;
             }
+            PF_TICK(tk1);
+            PF_ACC(0, tk0, tk1);
             if (updated_to < extend_to) {
                 double* rec = rec_ptr(A, p, widx);
                 rec[0] = x_mark;
@@ -848,7 +867,11 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
 #pragma unroll
                 for (int r = 0; r < RTree<NM>::NI; ++r) if (r < n - 1) rec[5 + r] = t.S[r];
                 double h, tc;
+                PF_TICK(tk2);
+                PF_ACC(1, tk1, tk2);
                 r_genealogy_update<NM, BIASED>(cx, t, &h, &tc);
+                PF_TICK(tk3);
+                PF_ACC(2, tk2, tk3);
                 if (cx.vbc) { w_post *= cx.upd_fac; w_pilot *= cx.upd_fac; cx.upd_fac = 1.0; }
                 rec[2] = h;
                 rec[3] = tc;
@@ -856,6 +879,9 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
                 ++widx;
                 if (leaf_status == 0) B = r_tracked_len(t, n, present_mask);
                 if (leaf_status == 1) B = cx.Ltree;
+                PF_TICK(tk4);
+                PF_ACC(3, tk3, tk4);
+                pf_acc_trip(pf_acc);
                 if (BIASED) {
                     // particle.cpp:866-891: immediate vs delayed application of the importance weight
                     double iw = cx.last_iw, rbiw = cx.last_rbiw;
@@ -867,11 +893,15 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
                     double delay = A.app_delays[r_epoch_of(cx, delay_height)];
                     d_adjust_with_delay(ds, w_post, w_pilot, iw, delay, updated_to);
                 }
+                PF_TICK(tk5);
                 next_base = r_sample_next_base<true>(cx, updated_to);      // fourth uniform of the update
                 x_mark = updated_to;
                 mark_limit = limit;
+                PF_TICK(tk6);
+                PF_ACC(4, tk5, tk6);
             }
         }
+        PF_ACC_STORE;
 
         PF_STAMP(5);
         if (BIASED) {
@@ -1407,19 +1437,23 @@ __device__ __forceinline__ void records_contrib(AccT<P>& acc, const KArgs& A, co
                     if (W.T0 <= tc && tc < W.T1) acc.v[AC::CC] += w;
                 }
             } else {
-                // structured models: the coal/migr opportunities were integrated when the update was simulated
-                // (pieces of pf_mp.h; the record flags and the epoch limit were applied there)
+                // structured models: the walk of the update left pieces (pf_mp.h PLog) -- population, partners, [t0, t1),
+                // event at t1 -- that are clipped to this epoch here; record flags and the epoch limit as above
                 (void)n_eff;
-                if (inwin) {
+                if (inwin && (W.rf & REC_COALMIGR) && W.e <= lim_event) {
                     unsigned long long ref = (unsigned long long)__double_as_longlong(f3);
                     unsigned pstart = (unsigned)(ref & 0xffffffffu), np_ = (unsigned)(ref >> 32);
                     if (A.pidx[a] - pstart > A.pcap || np_ > A.pcap) { if (!A.ctrl->err) A.ctrl->err = ERR_LOG_OVERFLOW; np_ = 0; }
                     for (unsigned j = 0; j < np_; ++j) {
                         const double* q = A.plog + ((size_t)a * A.pcap + ((pstart + j) % A.pcap)) * 3;
                         long long tag = __double_as_longlong(q[0]);
-                        double co = q[1], mo = q[2];
-                        if ((int)(tag & 0xff) != W.e) continue;
-                        int pop = (int)((tag >> 8) & 0xff), kind = (int)((tag >> 16) & 0xff), to = (int)((tag >> 24) & 0xff);
+                        const double t0 = q[1], t1 = q[2];
+                        const int pop = (int)(tag & 0xff), kind = (int)((tag >> 8) & 0xff), to = (int)((tag >> 16) & 0xff);
+                        const double lo = t0 > W.T0 ? t0 : W.T0, hi = t1 < W.T1 ? t1 : W.T1;
+                        const double mo = hi > lo ? hi - lo : 0.0;
+                        const bool ev = kind != 0 && W.T0 <= t1 && t1 < W.T1;
+                        if (!(mo > 0.0) && !ev) continue;
+                        const double co = (double)((tag >> 24) & 0xff) * mo;
 #pragma unroll
                         for (int pp = 0; pp < P; ++pp)
                             if (pp == pop) {
@@ -1427,8 +1461,8 @@ __device__ __forceinline__ void records_contrib(AccT<P>& acc, const KArgs& A, co
                                 acc.v[AC::CW + pp] += w * w * co;
                                 acc.v[AC::MO + pp] += w * mo;
                                 acc.v[AC::MW + pp] += w * w * mo;
-                                if (kind & 1) acc.v[AC::CC + pp] += w;
-                                if (kind & 2) {
+                                if (ev && (kind & 1)) acc.v[AC::CC + pp] += w;
+                                if (ev && (kind & 2)) {
 #pragma unroll
                                     for (int qq = 0; qq < P; ++qq)
                                         if (qq == to) acc.v[AC::MC + pp * P + qq] += w;
@@ -2001,6 +2035,11 @@ __global__ __launch_bounds__(PF_BS) void k_decide(KArgs A, long long s, int mode
 // Launched with PF_LEDGER_MAXT threads per workgroup: the re-basing of a run list is bound by memory round trips per
 // tile, and with 1024 threads the longest list is one tile.  The decide, bookkeeping and run-list workgroups are
 // written for PF_BS threads; their other wavefronts leave at once.
+// Hardware-specific: the wavefronts that leave do so before the first barrier of the body, and on gfx9-class hardware
+// (gfx950 included) a wavefront that has ended no longer counts towards s_barrier, so the remaining four synchronise
+// among themselves; HIP itself leaves a barrier under divergent exit undefined.  Since round 2 this kernel is only
+// launched with PF_DEBUG_TWO_LAUNCH (the A/B form of the row pipeline); tests/test_gpu_headline.py
+// ::test_rings_wrap_many_times[...-8] pins the behaviour on the target.
 __global__ __launch_bounds__(PF_LEDGER_MAXT) void k_decide_ledger(KArgs A, long long s, int mode, Windows W, int nblocks, int ledger_nbt) {
     if ((int)blockIdx.x <= nblocks) {
         if (threadIdx.x < PF_BS) decide_body(A, s, mode, W, nblocks);
@@ -2623,7 +2662,9 @@ void pf_destroy(pf_handle* h);
 // single_mig_pop), prepared exactly as the oracle's fill_model does
 struct MpTables {
     std::vector<double> inv2Np, mrate, mtot;
-    std::vector<int> jmap, spop;
+    std::vector<double> cum_coal, cum_mig;     // [E*P] integrals of 1/2N_p and of the total emigration rate of p from 0 to the epoch start
+    std::vector<double> next_join;             // [E] start of the next epoch after e that moves a whole population (-ej), +inf if none
+    std::vector<int> jmap, spop, next_join_epoch;
 };
 static int build_mp_tables(const pf_model* m, MpTables& t) {
     const int E = m->n_epochs, P = m->n_pops, n = m->nsam;
@@ -2655,6 +2696,24 @@ static int build_mp_tables(const pf_model* m, MpTables& t) {
             }
             t.jmap[(size_t)e * P + a] = cur;
         }
+    // Tables of the structured walk (pf_mp.h mp_coalesce): the hazard of a lineage over a stretch that spans epochs is
+    // a difference of these; accumulated in this order, which the oracle restates.
+    t.cum_coal.assign((size_t)E * P, 0.0);
+    t.cum_mig.assign((size_t)E * P, 0.0);
+    for (int e = 0; e + 1 < E; ++e)
+        for (int a = 0; a < P; ++a) {
+            const double dt = m->change_times[e + 1] - m->change_times[e];
+            t.cum_coal[(size_t)(e + 1) * P + a] = t.cum_coal[(size_t)e * P + a] + dt * t.inv2Np[(size_t)e * P + a];
+            t.cum_mig[(size_t)(e + 1) * P + a] = t.cum_mig[(size_t)e * P + a] + dt * t.mtot[(size_t)e * P + a];
+        }
+    t.next_join.assign(E, INFINITY);
+    t.next_join_epoch.assign(E, E);
+    for (int e = E - 2; e >= 0; --e) {
+        bool moves = false;
+        for (int a = 0; a < P; ++a) moves |= t.jmap[(size_t)(e + 1) * P + a] != a;
+        t.next_join[e] = moves ? m->change_times[e + 1] : t.next_join[e + 1];
+        t.next_join_epoch[e] = moves ? e + 1 : t.next_join_epoch[e + 1];
+    }
     t.spop.assign(n, 0);
     if (m->sample_pops) t.spop.assign(m->sample_pops, m->sample_pops + n);
     for (int v : t.spop) if (v < 0 || v >= P) { g_err = "sample population out of range"; return -1; }
@@ -2662,7 +2721,15 @@ static int build_mp_tables(const pf_model* m, MpTables& t) {
 }
 
 static int upload_mp_tables(const MpTables& t, KArgs& A, std::vector<void*>& allocs) {
-    double *d1, *d2, *d3; int *i1, *i2;
+    double *d1, *d2, *d3, *d4, *d5, *d6; int *i1, *i2, *i3;
+    HIPCHK(hipMalloc(&i3, t.next_join_epoch.size() * 4)); allocs.push_back(i3);
+    HIPCHK(hipMemcpy(i3, t.next_join_epoch.data(), t.next_join_epoch.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&d4, t.cum_coal.size() * 8)); allocs.push_back(d4);
+    HIPCHK(hipMalloc(&d5, t.cum_mig.size() * 8)); allocs.push_back(d5);
+    HIPCHK(hipMalloc(&d6, t.next_join.size() * 8)); allocs.push_back(d6);
+    HIPCHK(hipMemcpy(d4, t.cum_coal.data(), t.cum_coal.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d5, t.cum_mig.data(), t.cum_mig.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d6, t.next_join.data(), t.next_join.size() * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&d1, t.inv2Np.size() * 8)); allocs.push_back(d1);
     HIPCHK(hipMalloc(&d2, t.mrate.size() * 8)); allocs.push_back(d2);
     HIPCHK(hipMalloc(&d3, t.mtot.size() * 8)); allocs.push_back(d3);
@@ -2674,6 +2741,7 @@ static int upload_mp_tables(const MpTables& t, KArgs& A, std::vector<void*>& all
     HIPCHK(hipMemcpy(i1, t.jmap.data(), t.jmap.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(i2, t.spop.data(), t.spop.size() * 4, hipMemcpyHostToDevice));
     A.inv2Np = d1; A.mig_rate = d2; A.mig_tot = d3; A.join_map = i1; A.sample_pop = i2;
+    A.cum_coal = d4; A.cum_mig = d5; A.next_join = d6; A.next_join_epoch = i3;
     return 0;
 }
 
@@ -3085,7 +3153,7 @@ static int launch_extend(pf_handle* h, long long s, int fuse = 0) {
         const size_t smem_reg = (size_t)(2 * PF_EPAD + h->E + 2 * PF_BIAS_MAX + 3) * 8;
         const bool biased = h->A.n_bias > 0 || h->A.g_K > 0;
         if (h->P > 1)
-            pf_mp_launch_extend(h->A, s, h->smem, h->stream);
+            pf_mp_launch_extend(h->A, s, h->smem, h->stream, h->force_lds);
         else if (h->n <= 4 && biased && !h->force_lds)
         {
             if (h->A.rec_trees) hipLaunchKernelGGL((k_extend_reg<4, true, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);
@@ -3493,7 +3561,7 @@ int pf_get_migrations(pf_handle* h, int32_t* n_events, double* times, int8_t* br
             bool ok = k < nm[p] && k < PF_MMAX;
             if (times) times[p * cap + k] = ok ? mt[(size_t)k * Np + p] : 0.0;
             if (branch) branch[p * cap + k] = ok ? mb[(size_t)k * Np + p] : 0;
-            if (newpop) newpop[p * cap + k] = ok ? mq[(size_t)k * Np + p] : 0;
+            if (newpop) newpop[p * cap + k] = ok ? (mq[(size_t)k * Np + p] & 3) : 0;      // the upper bits hold the event's epoch
         }
         if (node_pops) for (int r = 0; r < n - 1; ++r) node_pops[p * (n - 1) + r] = pn[(size_t)r * Np + p];
     }
@@ -3678,14 +3746,15 @@ int pf_debug_stamps(pf_handle* h, int64_t rows, uint64_t* out) {
     HIPCHK(hipSetDevice(h->device));
     if (rows > 0 && !out) {
         unsigned long long* buf = nullptr;
-        if (dalloc(h, &buf, (size_t)rows * h->A.nc * 16)) return -1;
+        if (dalloc(h, &buf, (size_t)rows * h->A.nc * PF_STAMP_W)) return -1;
+        HIPCHK(hipMemset(buf, 0, (size_t)rows * h->A.nc * PF_STAMP_W * 8));
         HIPCHK(hipStreamSynchronize(h->stream));
         h->A.stamps = buf; h->A.stamp_rows = rows;
         return 0;
     }
     if (!h->A.stamps) { g_err = "pf_debug_stamps: not enabled"; return -1; }
     if (pf_sync(h)) return -1;
-    HIPCHK(hipMemcpy(out, h->A.stamps, (size_t)std::min<long long>(rows, h->A.stamp_rows) * h->A.nc * 16 * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, h->A.stamps, (size_t)std::min<long long>(rows, h->A.stamp_rows) * h->A.nc * PF_STAMP_W * 8, hipMemcpyDeviceToHost));
     return 0;
 }
 

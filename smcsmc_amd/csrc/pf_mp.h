@@ -8,8 +8,8 @@
 //
 // Representation: the rank-sorted binary tree of pf_device.h is kept as it is; every coalescent node also
 // stores the population it happened in (Pn), and the migration events of the local tree live in one list
-// sorted by time: event m sits on the branch above node id Mb[m] and moves that lineage to population Mq[m]
-// at time Mt[m].  Likelihood, branch-length and recombination-opportunity code never see the events.
+// sorted by time: event m sits on the branch above node id Mb[m] and moves that lineage to population Mq[m] & 3
+// at time Mt[m]; the upper six bits of Mq[m] hold the epoch of the event (the walk needs it at every event it passes).  Likelihood, branch-length and recombination-opportunity code never see the events.
 // While a genealogy update is in flight, the events picked up by the floating lineage, by the root's own
 // lineage and the events of the cut branch's stub carry the temporary branch tags below.
 #pragma once
@@ -23,6 +23,23 @@
 
 namespace pf {
 
+// profiling builds (-DPF_STAMPS): time spent by a wavefront in the phases of the structured update, summed over the row
+#ifdef PF_STAMPS
+#define MP_TICK(v) const unsigned long long v = wall_clock64()
+// accumulated per wavefront (one per workgroup in pf_mp.hip): the first active lane adds, so the figure covers every trip
+// the wavefront makes, whichever lanes take part in it
+__shared__ unsigned long long g_mp_acc[PF_STAMP_W];
+__device__ __forceinline__ void mp_wave_acc(int k, unsigned long long v) {
+    if (threadIdx.x < 64 && (int)threadIdx.x == __ffsll((unsigned long long)__ballot(1)) - 1) g_mp_acc[k] += v;   // first wavefront only
+}
+#define MP_ACC(ml, k, a, b) mp_wave_acc(k, (b) - (a))
+#define MP_CYC(v) const unsigned long long v = clock64()
+#else
+#define MP_CYC(v) do {} while (0)
+#define MP_TICK(v) do {} while (0)
+#define MP_ACC(ml, k, a, b) do {} while (0)
+#endif
+
 struct MLane {
     int8_t* Pn;        // &sPn[tid]   population of coalescent node r at Pn[r*PF_BS]
     double* Mt;        // &sMt[tid]
@@ -34,6 +51,9 @@ struct MLane {
     const double* I2;  // [E*P]   1/(2 N_e,p)                 (LDS)
     const double* MR;  // [E*P*P] migration rates p -> q      (LDS)
     const double* MT;  // [E*P]   total emigration rate       (LDS)
+    const double* CI;  // [E*P]   cumulative coalescence intensity of population p at the epoch starts  (LDS)
+    const double* CM;  // [E*P]   cumulative emigration intensity of population p at the epoch starts   (LDS)
+    const double* TJ;  // [E]     start of the next epoch after e at which a fixed-time move (-ej) happens, +inf if none (LDS)
     const int* JM;     // [E*P]   fixed-time moves at the start of epoch e (LDS)
     const int* SP;     // [n]     sample populations          (LDS)
     const double* vbm; // [E*P*P] variational-Bayes factor of a migration event (global), or null
@@ -47,35 +67,38 @@ struct MLane {
 #define LBp(ml, id) ((ml).Bp[(id) * PF_BS])
 
 // coal/migr opportunity pieces of one genealogy update, written to the slot's piece ring (three words each):
-//   tag = epoch | pop << 8 | kind << 16 | to << 24   (kind bit0: coalescence at the end, bit1: migration to `to`)
-//   coal opportunity = sum over the merged intervals of weight * dt,  migration opportunity = sum of dt
+//   tag = pop | kind << 8 | to << 16 | weight << 24   (kind bit0: coalescence at the end, bit1: migration to `to`)
+//   t0, t1 = the stretch of the walk during which the lineage sat in `pop` with `weight` coalescence partners.
+// A piece may span several epochs; the count kernel clips it to the epoch it is counting (coalescence opportunity =
+// weight * overlap, migration opportunity = overlap, the event belongs to the epoch that holds t1) and applies the
+// record flags and the epoch limit of the row there.
 struct PLog {
     double* base;            // ring of this slot
     unsigned cap;
     unsigned idx;            // pieces ever written by this slot
     unsigned pos;            // idx % cap, kept incrementally
     bool on;
-    int fe, fp, re, rp;
-    double fco, fmo, rmo;
+    int fw, fp, rp;          // open piece of the floating lineage (weight, population) / of the root lineage (population)
+    double ft0, ft1, rt0, rt1;
     bool fopen, ropen;
 };
 
-__device__ __forceinline__ void plog_write(PLog& pl, int e, int pop, int kind, int to, double co, double mo) {
+__device__ __forceinline__ void plog_write(PLog& pl, int pop, int kind, int to, int weight, double t0, double t1) {
     double* q = pl.base + (size_t)pl.pos * 3;
-    long long tag = (long long)(e & 0xff) | ((long long)(pop & 0xff) << 8) | ((long long)(kind & 0xff) << 16) |
-                    ((long long)(to & 0xff) << 24);
+    long long tag = (long long)(pop & 0xff) | ((long long)(kind & 0xff) << 8) | ((long long)(to & 0xff) << 16) |
+                    ((long long)(weight & 0xff) << 24);
     q[0] = __longlong_as_double(tag);
-    q[1] = co;
-    q[2] = mo;
+    q[1] = t0;
+    q[2] = t1;
     ++pl.idx;
     if (++pl.pos == pl.cap) pl.pos = 0;
 }
 __device__ __forceinline__ void plog_flush_f(PLog& pl, int kind, int to) {
-    if (pl.fopen) plog_write(pl, pl.fe, pl.fp, kind, to, pl.fco, pl.fmo);
+    if (pl.fopen) plog_write(pl, pl.fp, kind, to, pl.fw, pl.ft0, pl.ft1);
     pl.fopen = false;
 }
 __device__ __forceinline__ void plog_flush_r(PLog& pl, int kind, int to) {
-    if (pl.ropen) plog_write(pl, pl.re, pl.rp, kind, to, 0.0, pl.rmo);
+    if (pl.ropen) plog_write(pl, pl.rp, kind, to, 0, pl.rt0, pl.rt1);
     pl.ropen = false;
 }
 
@@ -85,7 +108,7 @@ __device__ __forceinline__ int mp_pop_base(const Lane& ln, const MLane& ml, int 
 __device__ __forceinline__ int mp_pop_at(const Lane& ln, const MLane& ml, int id, double time) {
     int pop = mp_pop_base(ln, ml, id);
     for (int m = 0; m < ml.nm; ++m)
-        if (LMb(ml, m) == id && LMt(ml, m) <= time) pop = LMq(ml, m);
+        if (LMb(ml, m) == id && LMt(ml, m) <= time) pop = LMq(ml, m) & 3;
     return pop;
 }
 __device__ __forceinline__ int mp_lineages_in_pop(const Lane& ln, const MLane& ml, int ni, double time, int pop, int want,
@@ -103,7 +126,10 @@ __device__ __forceinline__ int mp_lineages_in_pop(const Lane& ln, const MLane& m
         }
     return cnt;
 }
-__device__ __forceinline__ void mp_ev_insert(MLane& ml, double time, int branch, int newpop) {
+// `newpop` arrives packed: population | epoch of the event << 2 (mp_ev_byte)
+__device__ __forceinline__ int mp_ev_byte(int pop, int epoch) { return pop | (epoch << 2); }
+template <class ML>
+__device__ __forceinline__ void mp_ev_insert(ML& ml, double time, int branch, int newpop) {
     if (ml.nm >= PF_MMAX) { ml.err = 1; return; }
     int m = ml.nm;
     while (m > 0 && LMt(ml, m - 1) > time) {
@@ -197,6 +223,7 @@ struct MWalk { double tc; int pf, pr, weight; double tfirst; };   // tfirst: fir
 template <bool LOG>
 __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int root_id, double h, int pf0, PLog& pl,
                                             int limit, MWalk& W) {
+    MP_TICK(tw0);
     const int P = ml.P;
     const int n = ln.n;
     const double Hr = node_h(ln, root_id);
@@ -219,7 +246,7 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
     while (i < ni && LS(ln, i) <= tt) ++i;
     while (j < ml.nm && LMt(ml, j) <= tt) {
         int b = LMb(ml, j);
-        if (b < PF_TAG_MIN) LBp(ml, b) = LMq(ml, j);
+        if (b < PF_TAG_MIN) LBp(ml, b) = (int8_t)(LMq(ml, j) & 3);
         ++j;
     }
     for (int r = i; r < ni; ++r)
@@ -236,7 +263,7 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
         else nS = PF_INF;
     };
     auto fetch_event = [&]() __attribute__((always_inline)) {
-        if (j < ml.nm) { eT = LMt(ml, j); eB = LMb(ml, j); eQ = LMq(ml, j); }
+        if (j < ml.nm) { eT = LMt(ml, j); eB = LMb(ml, j); eQ = LMq(ml, j) & 3; }
         else eT = PF_INF;
     };
     fetch_node();
@@ -261,24 +288,27 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
             fetch_event();
         }
     };
-    // record_all_event (particle.cpp:251-300) for the piece of the walk [tt, t1): kind 0 no event, 1 coalescence,
-    // 2 the floating lineage migrates to `to`, 3 the root lineage migrates to `to`
-    auto record = [&](bool root_active, int weight, double dt, int kind, int to) __attribute__((always_inline)) {
+    // record_all_event (particle.cpp:251-300) for the stretch [t0, t1) of the walk: kind 0 no event, 1 coalescence,
+    // 2 the floating lineage migrates to `to`, 3 the root lineage migrates to `to`.  Stretches of equal weight and
+    // population merge into one piece whatever epochs they span.
+    auto record = [&](bool root_active, int weight, double t0, double t1, int kind, int to) __attribute__((always_inline)) {
         if (!LOG) return;
-        if (!(pl.on && (ln.RF[e] & 2) && e <= limit)) return;
-        if (pl.fopen && (pl.fe != e || pl.fp != pf)) plog_flush_f(pl, 0, 0);
-        if (!pl.fopen) { pl.fopen = true; pl.fe = e; pl.fp = pf; pl.fco = 0.0; pl.fmo = 0.0; }
-        pl.fco += (double)weight * dt;
-        pl.fmo += dt;
+        if (!pl.on) return;
+        if (pl.fopen && (pl.fw != weight || pl.fp != pf)) plog_flush_f(pl, 0, 0);
+        if (!pl.fopen) { pl.fopen = true; pl.fw = weight; pl.fp = pf; pl.ft0 = t0; }
+        pl.ft1 = t1;
         if (kind == 1) plog_flush_f(pl, 1, 0);
         if (kind == 2) plog_flush_f(pl, 2, to);
         if (root_active) {
-            if (pl.ropen && (pl.re != e || pl.rp != pr)) plog_flush_r(pl, 0, 0);
-            if (!pl.ropen) { pl.ropen = true; pl.re = e; pl.rp = pr; pl.rmo = 0.0; }
-            pl.rmo += dt;
+            if (pl.ropen && pl.rp != pr) plog_flush_r(pl, 0, 0);
+            if (!pl.ropen) { pl.ropen = true; pl.rp = pr; pl.rt0 = t0; }
+            pl.rt1 = t1;
             if (kind == 3) plog_flush_r(pl, 2, to);
         }
     };
+    // cumulative intensities of population q at time t inside epoch ee (piecewise linear, tabulated at the epoch starts)
+    auto ci = [&](int q, int ee, double t) __attribute__((always_inline)) { return ml.CI[ee * P + q] + (t - ln.T[ee]) * ml.I2[ee * P + q]; };
+    auto cm = [&](int q, int ee, double t) __attribute__((always_inline)) { return ml.CM[ee * P + q] + (t - ln.T[ee]) * ml.MT[ee * P + q]; };
     // Events picked up by the two active lineages wait in registers until the walk is over (they are not lineages of
     // the stored tree, so nothing in the walk reads them); inserting into the LDS list inside the loop would make
     // the whole wavefront pay for every lane's migration.
@@ -307,11 +337,20 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
     // ahead, KP events' worth at a time, with the wavefront converged: Philox is counter-based, so numbers drawn
     // ahead and not used cost nothing but the arithmetic -- the draw counter only advances by what was consumed.
     // Inside the loop an event is then a division and a table lookup, and one loop serves the whole walk.
+    MP_TICK(tw1);
+    MP_ACC(ml, 2, tw0, tw1);
     constexpr int KP = 2;
     bool done = false;
+    (void)limit;                                          // the epoch limit of the recording is applied at count time
+    // One iteration per stretch between two changes of the configuration -- the next node of the stored tree, the next
+    // migration event on it, the next epoch with a fixed-time move -- NOT per epoch: with the lineages' populations and
+    // the number of partners fixed, the hazard of the two active lineages over [tt, tn) is a difference of the
+    // tabulated cumulative intensities, whatever epochs lie in between (the one-population walk does the same with
+    // its single table).  Only the stretch in which the unit-exponential budget runs out is walked
+    // epoch by epoch, to find the epoch of the event and its rates.
     for (int guard = 0; guard < 4096 && !done; ++guard) {
-        // an interval adds at most three events (one migration, two joins): the loop below only starts an
-        // interval with two free slots, so the list insertion never has to happen inside it
+        // a stretch adds at most three events (one migration, two joins): the loop below only starts a stretch with
+        // two free slots, so the list insertion never has to happen inside it
         if (nb > 1) PF_MP_FLUSH_BUFFER();
         const unsigned long long ctr0 = ln.ctr;
         double u_type[KP], eb_new[KP];
@@ -321,85 +360,114 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
             eb_new[k] = -dlog(philox_uniform(ln.seed, ln.slot, ln.stream, ctr0 + 2 * k + 1));
         }
         int used = 0;
-        // boundary times and rate-table entries are carried in registers and re-read only when their index moves
-        double tn_ep = epoch_end(ln, e);
-        double inv_f = ml.I2[e * P + pf], mt_f = ml.MT[e * P + pf], mt_r = ml.MT[e * P + pr];
         for (int g2 = 0; g2 < 100000; ++g2) {
             if (nb > 1) break;                            // make room in the event buffer first
+            MP_ACC(ml, 13, 0, 1);
             const bool root_active = tt >= Hr;
+            const double tj = ml.TJ[e];
             double tn = nS < eT ? nS : eT;
-            tn = tn < tn_ep ? tn : tn_ep;
+            tn = tn < tj ? tn : tj;
             const int k = count_of(pf);
             const int weight = k + ((root_active && pr == pf) ? 1 : 0);
-            const double rc = (double)weight * inv_f;
-            const double rmf = mt_f;
-            const double rmr = root_active ? mt_r : 0.0;
-            const double lam = (rc + rmf) + rmr;
-            if (lam == 0.0 && !(tn < PF_INF)) { ml.err = 3; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
-            const double need = (tn - tt) * lam;
-            if (!(ln.ebuf > need)) {
-                // ---- an event falls into this interval
+            int en = e;
+            bool quiet = false;                           // no event before tn
+            if (tn < PF_INF) {
+                while (en + 1 < ln.E && ln.T[en + 1] <= tn) ++en;
+                double need = (double)weight * (ci(pf, en, tn) - ci(pf, e, tt)) + (cm(pf, en, tn) - cm(pf, e, tt));
+                if (root_active) need = need + (cm(pr, en, tn) - cm(pr, e, tt));
+                if (ln.ebuf > need) { ln.ebuf -= need; quiet = true; }
+            }
+            if (!quiet) {
+                // ---- the budget runs out in this stretch: the epoch of the event is the number of epoch starts of the
+                // stretch the budget still reaches (the hazard up to an epoch start is the same difference of cumulative
+                // intensities as `need`, so it ascends with the epoch), then one division inside that epoch
                 if (used == KP) break;                    // out of pre-drawn numbers: draw more, then carry on
-                const double t1 = tt + ln.ebuf / lam;
-                if (W.tfirst < 0.0) W.tfirst = t1;
-                const double ut = used == 0 ? u_type[0] : u_type[1];
-                int kind, to = 0;
+                const double f0c = ci(pf, e, tt), f0m = cm(pf, e, tt), f0r = root_active ? cm(pr, e, tt) : 0.0;
+                const int elim = tn < PF_INF ? en : ln.E - 1;
+                int ee = e;
+                double gee = 0.0;
+                while (ee < elim) {
+                    double g = (double)weight * (ml.CI[(ee + 1) * P + pf] - f0c) + (ml.CM[(ee + 1) * P + pf] - f0m);
+                    if (root_active) g = g + (ml.CM[(ee + 1) * P + pr] - f0r);
+                    if (!(ln.ebuf > g)) break;
+                    gee = g;
+                    ++ee;
+                }
+                const double rc = (double)weight * ml.I2[ee * P + pf];
+                const double rmf = ml.MT[ee * P + pf];
+                const double rmr = root_active ? ml.MT[ee * P + pr] : 0.0;
+                const double lam = (rc + rmf) + rmr;
+                if (lam == 0.0) { ml.err = 3; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
+                double t1 = ee == e ? tt + ln.ebuf / lam : ln.T[ee] + (ln.ebuf - gee) / lam;
                 {
-                    double v = ut * lam;
-                    if (v < rc || (rmf == 0.0 && rmr == 0.0)) kind = 1;
-                    else {
-                        v -= rc;
-                        int from;
-                        if (v < rmf || rmr == 0.0) { kind = 2; from = pf; }
-                        else { kind = 3; from = pr; v -= rmf; }
-                        to = -1;
-                        for (int q = 0; q < P; ++q) {
-                            double mr = ml.MR[(e * P + from) * P + q];
-                            if (q == from || mr == 0.0) continue;
-                            to = q;
-                            if (v < mr) break;
-                            v -= mr;
+                    double up = epoch_end(ln, ee);
+                    up = up < tn ? up : tn;
+                    if (t1 > up) t1 = up;
+                }
+                {
+                    if (W.tfirst < 0.0) W.tfirst = t1;
+                    const double ut = used == 0 ? u_type[0] : u_type[1];
+                    int kind, to = 0;
+                    {
+                        double v = ut * lam;
+                        if (v < rc || (rmf == 0.0 && rmr == 0.0)) kind = 1;
+                        else {
+                            v -= rc;
+                            int from;
+                            if (v < rmf || rmr == 0.0) { kind = 2; from = pf; }
+                            else { kind = 3; from = pr; v -= rmf; }
+                            to = -1;
+                            for (int q = 0; q < P; ++q) {
+                                double mr = ml.MR[(ee * P + from) * P + q];
+                                if (q == from || mr == 0.0) continue;
+                                to = q;
+                                if (v < mr) break;
+                                v -= mr;
+                            }
                         }
                     }
+                    record(root_active, weight, tt, t1, kind, to);
+                    if (ln.vbc) ln.upd_fac *= kind == 1 ? ln.vbc[ee * P + pf] : ml.vbm[(ee * P + (kind == 2 ? pf : pr)) * P + to];
+                    ln.ebuf = used == 0 ? eb_new[0] : eb_new[1];
+                    ++used;
+                    if (kind == 1) {
+                        W.tc = t1; W.pf = pf; W.pr = pr; W.weight = weight;
+                        done = true;
+                        break;
+                    }
+                    PF_MP_BUF_PUSH(t1, kind == 2 ? PF_TAG_PATH : PF_TAG_RPATH, mp_ev_byte(to, ee));
+                    if (kind == 2) pf = to; else pr = to;
+                    tt = t1;
+                    e = ee;
+                    continue;
                 }
-                record(root_active, weight, t1 - tt, kind, to);
-                if (ln.vbc) ln.upd_fac *= kind == 1 ? ln.vbc[e * P + pf] : ml.vbm[(e * P + (kind == 2 ? pf : pr)) * P + to];
-                ln.ebuf = used == 0 ? eb_new[0] : eb_new[1];
-                ++used;
-                if (kind == 1) {
-                    W.tc = t1; W.pf = pf; W.pr = pr; W.weight = weight;
-                    done = true;
-                    break;
-                }
-                PF_MP_BUF_PUSH(t1, kind == 2 ? PF_TAG_PATH : PF_TAG_RPATH, to);
-                if (kind == 2) pf = to; else pr = to;
-                tt = t1;
-                inv_f = ml.I2[e * P + pf]; mt_f = ml.MT[e * P + pf]; mt_r = ml.MT[e * P + pr];
-                continue;
             }
-            record(root_active, weight, tn - tt, 0, 0);
-            ln.ebuf -= need;
-            const bool cross_ep = tn_ep <= tn;
+            // ---- the configuration changes at tn: node or event of the stored tree, or a fixed-time move
+            record(root_active, weight, tt, tn, 0, 0);
+            const bool at_join = !(tn < tj);
             tt = tn;
+            e = en;
             advance(tt);
-            if (cross_ep) {
-                ++e;
+            if (at_join) {
                 int q = ml.JM[e * P + pf];
-                if (q != pf) { PF_MP_BUF_PUSH(tt, PF_TAG_PATH, q); pf = q; }
+                if (q != pf) { PF_MP_BUF_PUSH(tt, PF_TAG_PATH, mp_ev_byte(q, e)); pf = q; }
                 if (tt >= Hr) {
                     int qr = ml.JM[e * P + pr];
-                    if (qr != pr) { PF_MP_BUF_PUSH(tt, PF_TAG_RPATH, qr); pr = qr; }
+                    if (qr != pr) { PF_MP_BUF_PUSH(tt, PF_TAG_RPATH, mp_ev_byte(qr, e)); pr = qr; }
                 }
-                tn_ep = epoch_end(ln, e);
-                inv_f = ml.I2[e * P + pf]; mt_f = ml.MT[e * P + pf]; mt_r = ml.MT[e * P + pr];
             }
             if (ml.err) { W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
         }
         ln.ctr = ctr0 + 2 * (unsigned long long)used;
+        MP_ACC(ml, 12, 0, 1);
     }
     if (!done) { ml.err = 3; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
+    MP_TICK(tw2);
+    MP_ACC(ml, 3, tw1, tw2);
     PF_MP_FLUSH_BUFFER();
     if (LOG) { plog_flush_f(pl, 0, 0); plog_flush_r(pl, 0, 0); }
+    MP_TICK(tw3);
+    MP_ACC(ml, 4, tw2, tw3);
 }
 #undef PF_MP_FLUSH_BUFFER
 #undef PF_MP_BUF_PUSH
@@ -451,10 +519,14 @@ template <bool LOG>
 __device__ __forceinline__ void mp_genealogy_rest(Lane& ln, MLane& ml, PLog& pl, int limit, int rp, int sb, double h,
                                                   double* tc_out, double* sp_out, bool* changed_out, double* tfirst_out = nullptr) {
     const int n = ln.n;
+    MP_TICK(tg0);
     int b_id = LC(ln, rp, sb), s_id = LC(ln, rp, 1 - sb);
     const int pf0 = mp_pop_at(ln, ml, b_id, h);
+    MP_TICK(tg1);
+    MP_ACC(ml, 1, tg0, tg1);
     MWalk W;
     mp_coalesce<LOG>(ln, ml, n - 1, n + n - 2, h, pf0, pl, limit, W);
+    MP_TICK(tg2);
     const double tc = W.tc;
     *tc_out = tc;
     if (tfirst_out) *tfirst_out = W.tfirst;
@@ -482,6 +554,8 @@ __device__ __forceinline__ void mp_genealogy_rest(Lane& ln, MLane& ml, PLog& pl,
     // the removal, hand the root path to the pruned root, relabel for the insertion and split the target branch,
     // settle the stub, hand the floating path to the cut branch, clear the branch above the root) would do to an
     // event depends on that event alone, so it is ONE pass with in-place compaction.
+    MP_TICK(tg3);
+    MP_ACC(ml, 5, tg2, tg3);
     const int pid = n + rp;
     const int b0 = b_id, s0 = s_id;                      // children of p: ids below pid, unchanged by the removal
     const bool into_stub = !(idx < nslots) && !(has_root && idx == nslots);
@@ -549,7 +623,11 @@ __device__ __forceinline__ void mp_genealogy_rest(Lane& ln, MLane& ml, PLog& pl,
     for (int r = ni; r > rn; --r) LPn(ml, r) = LPn(ml, r - 1);
     LPn(ml, rn) = (int8_t)pop_ins;
     insert_node(ln, ni, h_ins, b0, pr_ins, ps_ins, troot);
+    MP_TICK(tg4);
+    MP_ACC(ml, 6, tg3, tg4);
     ln.Ltree = tree_length(ln, n);
+    MP_TICK(tg5);
+    MP_ACC(ml, 7, tg4, tg5);
 }
 
 }  // namespace pf

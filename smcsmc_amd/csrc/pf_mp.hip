@@ -11,13 +11,14 @@
 #include "pf_types.h"
 #include "pf_lane.h"
 #include "pf_mp.h"
+#include "pf_mp_reg.h"
 #include "pf_mp_host.h"
 
 // ------------------------------------------------------------------ structured models (P > 1): LDS-tree kernels
 // Same structure as k_init / k_extend / k_calibrate with the migration-aware genealogy update of pf_mp.h.
-struct SmemMP { double* I2; double* MR; double* MT; double* Mt; int* JM; int* SP; int8_t* Pn; int8_t* Mb; int8_t* Mq; int8_t* Bp; };
+struct SmemMP { double* I2; double* MR; double* MT; double* CI; double* CM; double* TJ; double* Mt; int* JM; int* SP; int8_t* Pn; int8_t* Mb; int8_t* Mq; int8_t* Bp; };
 __host__ __device__ static size_t smem_mp_extra(int n, int E, int P) {
-    size_t dbl = (size_t)E * P * 2 + (size_t)E * P * P + (size_t)PF_MMAX * PF_BS;
+    size_t dbl = (size_t)E * P * 4 + (size_t)E + (size_t)E * P * P + (size_t)PF_MMAX * PF_BS;
     size_t ints = (size_t)E * P + (size_t)((n + 1) & ~1) + (size_t)((E * P) & 1);
     size_t bytes = (size_t)(n - 1) * PF_BS + (size_t)2 * PF_MMAX * PF_BS + (size_t)2 * n * PF_BS;
     return dbl * 8 + ints * 4 + bytes;
@@ -28,7 +29,10 @@ __device__ __forceinline__ SmemMP carve_mp(double* base, int n, int E, int P) {
     m.I2 = (double*)((char*)base + smem_bytes(n, E));
     m.MR = m.I2 + (size_t)E * P;
     m.MT = m.MR + (size_t)E * P * P;
-    m.Mt = m.MT + (size_t)E * P;
+    m.CI = m.MT + (size_t)E * P;
+    m.CM = m.CI + (size_t)E * P;
+    m.TJ = m.CM + (size_t)E * P;
+    m.Mt = m.TJ + (size_t)E;
     m.JM = (int*)(m.Mt + (size_t)PF_MMAX * PF_BS);
     m.SP = m.JM + (size_t)E * P + ((E * P) & 1);
     m.Pn = (int8_t*)(m.SP + ((n + 1) & ~1));
@@ -39,7 +43,8 @@ __device__ __forceinline__ SmemMP carve_mp(double* base, int n, int E, int P) {
 }
 __device__ __forceinline__ void load_model_mp(const KArgs& A, SmemMP& m) {
     const int EP = A.E * A.P;
-    for (int i = threadIdx.x; i < EP; i += blockDim.x) { m.I2[i] = A.inv2Np[i]; m.MT[i] = A.mig_tot[i]; m.JM[i] = A.join_map[i]; }
+    for (int i = threadIdx.x; i < EP; i += blockDim.x) { m.I2[i] = A.inv2Np[i]; m.MT[i] = A.mig_tot[i]; m.JM[i] = A.join_map[i]; m.CI[i] = A.cum_coal[i]; m.CM[i] = A.cum_mig[i]; }
+    for (int i = threadIdx.x; i < A.E; i += blockDim.x) m.TJ[i] = A.next_join[i];
     for (int i = threadIdx.x; i < EP * A.P; i += blockDim.x) m.MR[i] = A.mig_rate[i];
     for (int i = threadIdx.x; i < A.n; i += blockDim.x) m.SP[i] = A.sample_pop[i];
 }
@@ -47,7 +52,7 @@ __device__ __forceinline__ MLane make_mlane(const KArgs& A, SmemMP& m) {
     MLane ml;
     ml.Pn = m.Pn + threadIdx.x; ml.Mt = m.Mt + threadIdx.x; ml.Mb = m.Mb + threadIdx.x; ml.Mq = m.Mq + threadIdx.x; ml.Bp = m.Bp + threadIdx.x;
     ml.nm = 0; ml.P = A.P;
-    ml.I2 = m.I2; ml.MR = m.MR; ml.MT = m.MT; ml.JM = m.JM; ml.SP = m.SP; ml.vbm = A.vb_mig;
+    ml.I2 = m.I2; ml.MR = m.MR; ml.MT = m.MT; ml.CI = m.CI; ml.CM = m.CM; ml.TJ = m.TJ; ml.JM = m.JM; ml.SP = m.SP; ml.vbm = A.vb_mig;
     ml.err = 0;
     return ml;
 }
@@ -152,6 +157,12 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
     const bool active = p < A.Np;
     const int lane = threadIdx.x & 63;
     double w_post = 0.0, w_pilot = 0.0;
+    MP_TICK(tk_begin);
+#ifdef PF_STAMPS
+    if (threadIdx.x < PF_STAMP_W) g_mp_acc[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned long long* stamp_out = (A.stamps && s < A.stamp_rows) ? A.stamps + ((size_t)s * A.nc + (size_t)(p >> 6)) * PF_STAMP_W : nullptr;
+#endif
     const bool guided = BIASED && A.g_K > 0;
     const bool biased = BIASED && (A.n_bias > 0 || guided);          // a guide alone runs with one band of strength 1
     bool has_pending = false;
@@ -207,7 +218,11 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
         else if (leaf_status == 1) B = ln.Ltree;
         else B = tracked_len_lane(ln, data, tmp0);
 
+        MP_TICK(tk_loaded);
+        MP_ACC(ml, 0, tk_begin, tk_loaded);
         while (updated_to < extend_to) {
+            MP_ACC(ml, 14, 0, 1);
+            MP_TICK(tu0);
             double new_to = extend_to < next_base ? extend_to : next_base;
             double f = fastexp(-A.mu * B * (new_to - updated_to));
             w_post *= f;
@@ -245,6 +260,8 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
                 const unsigned desc = A.lmap_opp ? lane_desc_mask(ln, LC(ln, rp, sb), tmp0) : 0u;
                 unsigned p0 = pl.idx;
                 double tfirst = 0.0;
+                MP_TICK(tu1);
+                MP_ACC(ml, 8, tu0, tu1);
                 mp_genealogy_rest<true>(ln, ml, pl, limit, rp, sb, h, &tc, &sp_removed, &changed, &tfirst);
                 if (ln.vbc) { w_post *= ln.upd_fac; w_pilot *= ln.upd_fac; ln.upd_fac = 1.0; }
                 rec[2] = h;
@@ -252,6 +269,7 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
                 rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n, desc));
                 ++widx;
                 if (ml.err) break;
+                MP_TICK(tu2);
                 if (leaf_status == 0) B = tracked_len_lane(ln, data, tmp0);
                 if (leaf_status == 1) B = ln.Ltree;
                 if (biased) {
@@ -268,8 +286,11 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
                 next_base = sample_next_base_guided(ln, updated_to, A.g_K, A.g_pos, A.g_rho, ridx);
                 x_mark = updated_to;
                 mark_limit = limit;
+                MP_TICK(tu3);
+                MP_ACC(ml, 9, tu2, tu3);
             }
         }
+        MP_TICK(tk_loop);
         mp_report(A, ml);
         if (biased) {
             // apply the factors that fell due during this extension (particle.cpp:910-916)
@@ -329,6 +350,8 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
             w_post *= lik;
             w_pilot *= lik;
         }
+        MP_TICK(tk_lik);
+        MP_ACC(ml, 10, tk_loop, tk_lik);
 
         for (int r = 0; r < n - 1; ++r) {
             st.S[(size_t)r * A.Np + p] = LS(ln, r);
@@ -348,7 +371,14 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
         A.pidx[p] = pl.idx;
         for (int r = 0; r < n - 1; ++r) A.snap_S[A.sp][(size_t)r * A.Np + p] = LS(ln, r);
         A.snap_w[A.sp][p] = w_post; A.snap_xm[A.sp][p] = x_mark; A.snap_ml[A.sp][p] = mark_limit; A.snap_widx[A.sp][p] = widx;
+        MP_TICK(tk_stored);
+        MP_ACC(ml, 11, tk_lik, tk_stored);
+        MP_ACC(ml, 15, tk_begin, tk_stored);
     }
+#ifdef PF_STAMPS
+    __syncthreads();
+    if (stamp_out && threadIdx.x < PF_STAMP_W) stamp_out[threadIdx.x] = g_mp_acc[threadIdx.x];
+#endif
     double sp = wave_tree_sum(w_post);
     double sq = wave_tree_sum(w_pilot * w_pilot);
     double sc = wave_hs_scan(w_pilot, lane);
@@ -366,6 +396,353 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
     if (biased) {
         unsigned long long pend = __ballot(has_pending);
         if (lane == 0 && chunk < (A.Np + 63) / 64) A.chunk_dpend[chunk] = __popcll(pend);
+    }
+}
+
+// ------------------------------------------------------------------ structured models, register-resident tree (n <= 8)
+// The row kernel of the structured filter for small samples: the update of pf_mp_reg.h, state read from and written to
+// the same arrays as k_extend_mp (the two are interchangeable row by row; tests run both against the oracle).
+// LDS: the epoch tables of the model and, per lane, the migration events of its tree.
+#ifndef PF_MPR_LANES
+#define PF_MPR_LANES 32      // particles per wavefront of the register-tree row kernel (see k_extend_mpr)
+#endif
+struct SmemMPR { double* T; double* TJ; double* I2; double* MT; double* CI; double* CM; double* MR; double* Mt; int* JM; int* EJ; int8_t* Mb; int8_t* Mq; };
+__host__ __device__ static size_t smem_mpr_bytes(int E, int P) {
+    const size_t EP = (size_t)E * P;
+    return ((size_t)2 * PF_EPAD + 4 * EP + EP * P + (size_t)PF_MMAX * PF_BS) * 8 + (((EP + 1) & ~(size_t)1) + PF_EPAD) * 4 + (size_t)2 * PF_MMAX * PF_BS;
+}
+__device__ __forceinline__ SmemMPR carve_mpr(double* base, int E, int P) {
+    const size_t EP = (size_t)E * P;
+    SmemMPR m;
+    m.T = base; m.TJ = m.T + PF_EPAD; m.I2 = m.TJ + PF_EPAD; m.MT = m.I2 + EP; m.CI = m.MT + EP; m.CM = m.CI + EP;
+    m.MR = m.CM + EP; m.Mt = m.MR + EP * P;
+    m.JM = (int*)(m.Mt + (size_t)PF_MMAX * PF_BS);
+    m.EJ = m.JM + ((EP + 1) & ~(size_t)1);
+    m.Mb = (int8_t*)(m.EJ + PF_EPAD);
+    m.Mq = m.Mb + (size_t)PF_MMAX * PF_BS;
+    return m;
+}
+
+// LA = lanes of a wavefront that carry a particle.  A workgroup still owns 64 consecutive particles (the unit of the
+// canonical reductions), spread over 64 / LA wavefronts: a row lasts as long as its slowest wavefront, the lanes of a
+// wavefront wait for the one with the most recombinations and the longest walk, and with one workgroup per 64
+// particles most of the 1024 SIMDs have nothing to do -- half-filled wavefronts on twice as many SIMDs wait for the
+// maximum over 32 lanes instead of 64 and serialise fewer divergent paths.  The weights meet in LDS, and the first
+// wavefront does the reductions over the 64 particles exactly as the full wavefront did.
+template <int NM, bool BIASED, int LA>
+__global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long long s) {
+    constexpr int NI = RTree<NM>::NI;
+    extern __shared__ double smem[];
+    SmemMPR mm = carve_mpr(smem, A.E, A.P);
+    {
+        const int EP = A.E * A.P;
+        for (int i = threadIdx.x; i < PF_EPAD; i += blockDim.x) {
+            mm.T[i] = i < A.E ? A.T[i] : PF_INF;              // padded: the four-way search needs no bounds checks
+            mm.TJ[i] = i < A.E ? A.next_join[i] : PF_INF;
+            mm.EJ[i] = i < A.E ? A.next_join_epoch[i] : A.E;
+        }
+        for (int i = threadIdx.x; i < EP; i += blockDim.x) {
+            mm.I2[i] = A.inv2Np[i]; mm.MT[i] = A.mig_tot[i]; mm.CI[i] = A.cum_coal[i]; mm.CM[i] = A.cum_mig[i]; mm.JM[i] = A.join_map[i];
+        }
+        for (int i = threadIdx.x; i < EP * A.P; i += blockDim.x) mm.MR[i] = A.mig_rate[i];
+    }
+    __shared__ double sBH[PF_BIAS_MAX + 2], sBS[PF_BIAS_MAX + 1];      // focused sampling: band boundaries / strengths
+    __shared__ double sWpost[64], sWpilot[64];
+    __shared__ int sPend[64];
+    if (threadIdx.x < PF_BIAS_MAX + 2) {
+        sBH[threadIdx.x] = A.bias_H[threadIdx.x];
+        if (threadIdx.x < PF_BIAS_MAX + 1) sBS[threadIdx.x] = A.bias_S[threadIdx.x];
+    }
+    __syncthreads();
+    const Ctrl* c = A.ctrl;
+    const int n = A.n;
+    const int cur = __builtin_amdgcn_readfirstlane(c->cur);
+    const int lane = threadIdx.x & 63;
+    const int cslot = (int)(threadIdx.x >> 6) * LA + lane;             // place of this lane's particle in the workgroup's 64
+    const long long p = (long long)blockIdx.x * 64 + cslot;
+    const bool active = lane < LA && p < A.Np;
+    double w_post = 0.0, w_pilot = 0.0;
+    MP_TICK(tk_begin);
+#ifdef PF_STAMPS
+    if (threadIdx.x < PF_STAMP_W) g_mp_acc[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned long long* stamp_out = (A.stamps && s < A.stamp_rows) ? A.stamps + ((size_t)s * A.nc + (size_t)(p >> 6)) * PF_STAMP_W : nullptr;
+#endif
+    const bool guided = BIASED && A.g_K > 0;
+    const bool biased = BIASED && (A.n_bias > 0 || guided);          // a guide alone runs with one band of strength 1
+    bool has_pending = false;
+    if (active) {
+        const DState st = state_slot(A, cur);
+        RTree<NM> t;
+        MRLane ml;
+        ml.Mt = mm.Mt + cslot; ml.Mb = mm.Mb + cslot; ml.Mq = mm.Mq + cslot;
+        ml.P = A.P; ml.I2 = mm.I2; ml.MR = mm.MR; ml.MT = mm.MT; ml.CI = mm.CI; ml.CM = mm.CM; ml.TJ = mm.TJ; ml.JM = mm.JM; ml.EJ = mm.EJ;
+        ml.vbm = A.vb_mig; ml.err = 0; ml.pn = 0; ml.bp = 0; ml.sp = 0;
+        for (int i = 0; i < n; ++i) ml.sp |= (unsigned)A.sample_pop[i] << (2 * i);
+#pragma unroll
+        for (int r = 0; r < NI; ++r) {
+            t.S[r] = 0.0; t.C0[r] = 0; t.C1[r] = 0;
+            if (r < n - 1) {
+                t.S[r] = st.S[(size_t)r * A.Np + p];
+                t.C0[r] = st.C[(size_t)(2 * r) * A.Np + p];
+                t.C1[r] = st.C[(size_t)(2 * r + 1) * A.Np + p];
+                ml.pn |= (unsigned)st.Pn[(size_t)r * A.Np + p] << (2 * r);
+            }
+        }
+        ml.nm = st.nm[p];
+        for (int q = 0; q < ml.nm; ++q) {
+            LMt(ml, q) = st.Mt[(size_t)q * A.Np + p];
+            LMb(ml, q) = st.Mb[(size_t)q * A.Np + p];
+            LMq(ml, q) = st.Mq[(size_t)q * A.Np + p];
+        }
+        RCtx cx;
+        cx.T = mm.T; cx.I = nullptr; cx.H = nullptr; cx.E = A.E; cx.n = n; cx.L = A.L; cx.mu = A.mu; cx.rho = A.rho;
+        cx.seed = A.seed; cx.slot = (unsigned)p; cx.stream = 0; cx.u_nb = 0.0;
+        cx.nb = A.n_bias + 1; cx.bH = sBH; cx.bS = sBS; cx.last_iw = 1.0; cx.last_rbiw = 1.0;
+        cx.want_desc = false; cx.want_desc_new = false; cx.last_desc = 0; cx.last_desc_new = 0;
+        cx.vbc = A.vb_coal; cx.upd_fac = 1.0;
+        cx.gK = BIASED ? A.g_K : 0; cx.gpos = A.g_pos; cx.grho = A.g_rho; cx.gleaf = A.g_leaf;
+        cx.ridx = guided ? st.ridx[p] : 0; cx.g_rp = 0; cx.g_sb = 0;
+        DStore ds;
+        ds.pos = st.dpos + p; ds.fac = st.dfac + p; ds.delta = st.ddelta + p; ds.k = st.dk + p; ds.Np = A.Np;
+        ds.count = 0; ds.total = 1.0;
+        if (biased) { ds.count = st.dcount[p]; ds.total = st.total_delayed[p]; }
+        w_post = st.w_post[p];
+        w_pilot = st.w_pilot[p];
+        double next_base = st.next_base[p];
+        double x_mark = st.x_mark[p];
+        int mark_limit = st.mark_limit[p];
+        cx.Ltree = st.Ltree[p];
+        cx.ctr = A.rng_ctr[p];
+        cx.ebuf = A.ebuf[p];
+        unsigned widx = A.widx[p];
+        PLog pl;
+        pl.base = A.plog + (size_t)p * A.pcap * 3; pl.cap = A.pcap; pl.idx = A.pidx[p]; pl.pos = pl.idx % pl.cap; pl.on = true;
+        pl.fopen = false; pl.ropen = false;
+
+        const int8_t* data = A.seg_alleles + (size_t)s * n;
+        const double seg_end = A.seg_start[s] + A.seg_len[s];
+        const double extend_to = seg_end < A.L ? seg_end : A.L;
+        const int limit = A.seg_limit[s];
+        unsigned one_mask = 0, zero_mask = 0, present_mask = 0, two_mask = 0;
+        int missing = 0;
+        for (int i = 0; i < n; ++i) {
+            const int d = data[i];
+            missing += d == -1;
+            if (d == 1) one_mask |= 1u << i;
+            if (d == 0) zero_mask |= 1u << i;
+            if (d == 2) two_mask |= 1u << i;
+            if (d >= 0) present_mask |= 1u << i;
+        }
+        int leaf_status = 0;
+        if (missing == 0) leaf_status = 1;
+        if (missing == n) leaf_status = -1;
+
+        double updated_to = c->cur_pos;
+        double B;
+        if (leaf_status == -1) B = 0;
+        else if (leaf_status == 1) B = cx.Ltree;
+        else B = r_tracked_len(t, n, present_mask);
+
+        MP_TICK(tk_loaded);
+        MP_ACC(ml, 0, tk_begin, tk_loaded);
+        while (updated_to < extend_to) {
+            MP_ACC(ml, 14, 0, 1);
+            MP_TICK(tu0);
+            double new_to = extend_to < next_base ? extend_to : next_base;
+            double f = fastexp(-A.mu * B * (new_to - updated_to));
+            w_post *= f;
+            w_pilot *= f;
+            if (guided) {
+                // importance_weight_over_segment (particle.cpp:1138-1181)
+                const double dist = new_to - updated_to;
+                const double target_rate = dist * A.rho * cx.Ltree;
+                const double sampled_rate = dist * A.g_rho[cx.ridx] * cx.Ltree;
+                const double iws = fastexp(sampled_rate - target_rate);
+                w_post *= iws;
+                w_pilot *= iws;
+            }
+            updated_to = new_to;
+            if (guided && updated_to < extend_to && cx.ridx + 1 < A.g_K && updated_to == A.g_pos[cx.ridx + 1]) {
+                // reached a change of the guide rate: no genealogy change, new draw under the new rate
+                cx.ridx += 1;
+                next_base = r_sample_next_base<false>(cx, updated_to);
+                continue;
+            }
+            if (updated_to < extend_to) {
+                double* rec = rec_ptr(A, p, widx);
+                rec[0] = x_mark;
+                rec[1] = updated_to;
+#pragma unroll
+                for (int r = 0; r < NI; ++r) if (r < n - 1) rec[5 + r] = t.S[r];
+                int rp = 0, sb = 0, lin = 0;
+                double h, tc;
+                double iw = 1.0, rbiw = 1.0;
+                const double u_point = r_uni(cx);
+                if (guided) {
+                    r_sample_point_guided(cx, t, cx.nb > 1, u_point, &h);
+                    rp = cx.g_rp; sb = cx.g_sb; iw = cx.last_iw; rbiw = cx.last_rbiw;
+                } else {
+                    if (biased) { r_sample_point_biased(cx, t, u_point, &h, &lin); iw = cx.last_iw; rbiw = iw; }
+                    else r_sample_point_plain(cx, t, u_point, &h, &lin);
+                    r_lineages_at(t, n, n - 1, h, lin, &rp, &sb);
+                }
+                const unsigned desc = A.lmap_opp ? r_desc_mask(t, n, rp, sb) : 0u;
+                unsigned p0 = pl.idx;
+                double tfirst = 0.0;
+                MP_TICK(tu1);
+                MP_ACC(ml, 8, tu0, tu1);
+                rmp_genealogy_rest<NM, true>(cx, t, ml, pl, rp, sb, h, &tc, &tfirst);
+                if (cx.vbc) { w_post *= cx.upd_fac; w_pilot *= cx.upd_fac; cx.upd_fac = 1.0; }
+                rec[2] = h;
+                rec[3] = piece_ref(p0, pl.idx - p0);
+                rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n, desc));
+                ++widx;
+                if (ml.err) break;
+                MP_TICK(tu2);
+                if (leaf_status == 0) B = r_tracked_len(t, n, present_mask);
+                if (leaf_status == 1) B = cx.Ltree;
+                if (biased) {
+                    // particle.cpp:866-891: immediate vs delayed application of the importance weight
+                    const int nbands = A.n_bias + 1;
+                    const double delay_height = A.delay_type == 0 ? h : (A.delay_type == 2 ? tfirst : tc);
+                    int idx = 0;
+                    while (idx + 1 < nbands + 1 && sBH[idx + 1] < delay_height) ++idx;
+                    if (idx >= nbands) idx = nbands - 1;
+                    if (sBS[idx] == 1.0) { w_post *= rbiw; w_pilot *= rbiw; iw /= rbiw; }
+                    const double delay = A.app_delays[r_epoch_of(cx, delay_height)];
+                    d_adjust_with_delay(ds, w_post, w_pilot, iw, delay, updated_to);
+                }
+                next_base = r_sample_next_base<false>(cx, updated_to);
+                x_mark = updated_to;
+                mark_limit = limit;
+                MP_TICK(tu3);
+                MP_ACC(ml, 9, tu2, tu3);
+            }
+        }
+        MP_TICK(tk_loop);
+        if (ml.err == 1) A.ctrl->err = ERR_MIG_OVERFLOW;
+        if (ml.err == 2) A.ctrl->err = ERR_MP_INTERNAL;
+        if (ml.err == 3) A.ctrl->err = ERR_NO_COALESCENCE;
+        if (biased) {
+            // apply the factors that fell due during this extension (particle.cpp:910-916)
+            for (;;) {
+                if (ds.count == 0) break;
+                double pm = ds.pos[0];
+                for (int i = 1; i < ds.count; ++i) { double pi = ds.pos[(size_t)i * ds.Np]; if (pi < pm) pm = pi; }
+                if (!(pm < extend_to)) break;
+                d_apply_earliest(ds, w_pilot);
+            }
+            st.dcount[p] = ds.count;
+            st.total_delayed[p] = ds.total;
+            if (guided) st.ridx[p] = cx.ridx;
+            has_pending = ds.count > 0;
+        }
+
+        if (A.seg_state[s] == 0) {
+            // update_weight_at_site: marginalise over phasings of unphased hets (pc.cpp:138-224)
+            const bool dephase = A.flags & 2;
+            const bool anc = A.flags & 1;
+            unsigned het_pairs = 0;
+            int ncfg = 1;
+            for (int i = 0; i + 1 < n; i += 2) {
+                const bool d0_two = (two_mask >> i) & 1u;
+                const bool one0 = (one_mask >> i) & 1u, one1 = (one_mask >> (i + 1)) & 1u;
+                const bool zero0 = (zero_mask >> i) & 1u, zero1 = (zero_mask >> (i + 1)) & 1u;
+                const bool het = d0_two || (dephase && ((one0 && zero1) || (zero0 && one1)));
+                if (het) {
+                    ncfg *= 2;
+                    het_pairs |= 1u << i;
+                    one_mask &= ~(3u << i); zero_mask &= ~(3u << i);
+                    zero_mask |= 1u << i;
+                    one_mask |= 1u << (i + 1);
+                }
+            }
+            double norm = 1.0 / (double)ncfg;
+            double lik = 0;
+            for (;;) {
+                lik += r_site_lik(t, n, A.mu, one_mask, zero_mask, anc);
+                if (ncfg == 1) break;
+                bool more = false;
+                for (int i = 0; i + 1 < n; i += 2) {
+                    if (!((het_pairs >> i) & 1)) continue;
+                    if ((zero_mask >> i) & 1) {
+                        zero_mask &= ~(1u << i); one_mask |= 1u << i;
+                        one_mask &= ~(1u << (i + 1)); zero_mask |= 1u << (i + 1);
+                        more = true;
+                        break;
+                    }
+                    one_mask &= ~(1u << i); zero_mask |= 1u << i;
+                    zero_mask &= ~(1u << (i + 1)); one_mask |= 1u << (i + 1);
+                }
+                if (!more) break;
+            }
+            lik *= norm;
+            w_post *= lik;
+            w_pilot *= lik;
+        }
+        MP_TICK(tk_lik);
+        MP_ACC(ml, 10, tk_loop, tk_lik);
+
+#pragma unroll
+        for (int r = 0; r < NI; ++r)
+            if (r < n - 1) {
+                st.S[(size_t)r * A.Np + p] = t.S[r];
+                st.C[(size_t)(2 * r) * A.Np + p] = (int8_t)t.C0[r];
+                st.C[(size_t)(2 * r + 1) * A.Np + p] = (int8_t)t.C1[r];
+                st.Pn[(size_t)r * A.Np + p] = (int8_t)pk2_get(ml.pn, r);
+                A.snap_S[A.sp][(size_t)r * A.Np + p] = t.S[r];
+            }
+        st.nm[p] = ml.nm;
+        for (int q = 0; q < ml.nm; ++q) {
+            st.Mt[(size_t)q * A.Np + p] = LMt(ml, q);
+            st.Mb[(size_t)q * A.Np + p] = LMb(ml, q);
+            st.Mq[(size_t)q * A.Np + p] = LMq(ml, q);
+        }
+        st.w_post[p] = w_post;
+        st.w_pilot[p] = w_pilot;
+        st.next_base[p] = next_base;
+        st.x_mark[p] = x_mark;
+        st.mark_limit[p] = mark_limit;
+        st.Ltree[p] = cx.Ltree;
+        A.rng_ctr[p] = cx.ctr;
+        A.ebuf[p] = cx.ebuf;
+        A.widx[p] = widx;
+        A.pidx[p] = pl.idx;
+        A.snap_w[A.sp][p] = w_post; A.snap_xm[A.sp][p] = x_mark; A.snap_ml[A.sp][p] = mark_limit; A.snap_widx[A.sp][p] = widx;
+        MP_TICK(tk_stored);
+        MP_ACC(ml, 11, tk_lik, tk_stored);
+        MP_ACC(ml, 15, tk_begin, tk_stored);
+    }
+#ifdef PF_STAMPS
+    __syncthreads();
+    if (stamp_out && threadIdx.x < PF_STAMP_W) stamp_out[threadIdx.x] = g_mp_acc[threadIdx.x];
+#endif
+    if (lane < LA) { sWpost[cslot] = w_post; sWpilot[cslot] = w_pilot; sPend[cslot] = has_pending ? 1 : 0; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        // the canonical radix-64 reductions over the workgroup's particles, one per lane
+        const long long q = (long long)blockIdx.x * 64 + lane;
+        const bool live = q < A.Np;
+        const double wq_post = sWpost[lane], wq_pilot = sWpilot[lane];
+        double sp = wave_tree_sum(wq_post);
+        double sq = wave_tree_sum(wq_pilot * wq_pilot);
+        double sc = wave_hs_scan(wq_pilot, lane);
+        double scp = wave_hs_scan(wq_post, lane);
+        double scm = wave_max_scan_d(sc, lane);
+        const long long chunk = blockIdx.x;
+        if (live) { A.scan1[q] = sc; A.scanp2[A.sp][q] = scp; A.scan1m[q] = scm; }
+        if (lane == 63) {
+            A.chunk_post[chunk] = sp;
+            A.chunk_sq[chunk] = sq;
+            A.chunk_pil[chunk] = sc;
+            A.chunk_pp[chunk] = scp;
+            A.chunk_mx1[chunk] = scm;
+        }
+        if (biased) {
+            unsigned long long pend = __ballot(sPend[lane] != 0);
+            if (lane == 0) A.chunk_dpend[chunk] = __popcll(pend);
+        }
     }
 }
 
@@ -457,6 +834,12 @@ size_t pf_mp_smem_bytes(int n, int E, int P) { return smem_bytes_mp(n, E, P); }
 
 int pf_mp_prepare(size_t smem) {
     if (smem > 160 * 1024) return -1;
+    {
+        // the register-tree row kernels: their LDS does not depend on n (tables at their largest size here)
+        const int big = (int)smem_mpr_bytes(PF_EMAX, PF_PMAX);
+        if (hipFuncSetAttribute((const void*)k_extend_mpr<8, false, PF_MPR_LANES>, hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void*)k_extend_mpr<8, true, PF_MPR_LANES>, hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) return -1;
+    }
     if (smem > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)k_extend_mp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
         if (hipFuncSetAttribute((const void*)k_extend_mp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
@@ -470,7 +853,15 @@ static unsigned mp_blocks(long long n) { return (unsigned)((n + PF_BS - 1) / PF_
 void pf_mp_launch_init(const KArgs& A, double initial_position, size_t smem, hipStream_t st) {
     hipLaunchKernelGGL(k_init_mp, dim3(mp_blocks(A.Np)), dim3(PF_BS), smem, st, A, initial_position);
 }
-void pf_mp_launch_extend(const KArgs& A, long long s, size_t smem, hipStream_t st) {
+void pf_mp_launch_extend(const KArgs& A, long long s, size_t smem, hipStream_t st, bool lds_tree) {
+    if (!lds_tree && A.n <= 8) {
+        const size_t sm = smem_mpr_bytes(A.E, A.P);
+        if (A.n_bias > 0 || A.g_K > 0)
+            hipLaunchKernelGGL((k_extend_mpr<8, true, PF_MPR_LANES>), dim3(mp_blocks(A.Np)), dim3(64 * (64 / PF_MPR_LANES)), sm, st, A, s);
+        else
+            hipLaunchKernelGGL((k_extend_mpr<8, false, PF_MPR_LANES>), dim3(mp_blocks(A.Np)), dim3(64 * (64 / PF_MPR_LANES)), sm, st, A, s);
+        return;
+    }
     if (A.n_bias > 0 || A.g_K > 0)
         hipLaunchKernelGGL(k_extend_mp<true>, dim3(mp_blocks(A.Np)), dim3(PF_BS), smem, st, A, s);
     else

@@ -29,20 +29,29 @@ struct RTree {
         return __longlong_as_double(bits);
     }
     __device__ __forceinline__ void setS(int r, double x) {
+        const long long xb = __double_as_longlong(x);
 #pragma unroll
-        for (int k = 0; k < NI; ++k) S[k] = (r == k) ? x : S[k];
+        for (int k = 0; k < NI; ++k) {
+            const long long m = -(long long)(r == k);
+            S[k] = __longlong_as_double((__double_as_longlong(S[k]) & ~m) | (xb & m));
+        }
     }
     __device__ __forceinline__ int getC(int r, int s) const {
-        int v = s ? C1[0] : C0[0];
+        const int ms = -(int)(s != 0);
+        int v = 0;
 #pragma unroll
-        for (int k = 1; k < NI; ++k) v = (r == k) ? (s ? C1[k] : C0[k]) : v;
+        for (int k = 0; k < NI; ++k) {
+            const int m = -(int)(r == k);
+            v |= ((C0[k] & ~ms) | (C1[k] & ms)) & m;
+        }
         return v;
     }
     __device__ __forceinline__ void setC(int r, int s, int x) {
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
-            C0[k] = (r == k && s == 0) ? x : C0[k];
-            C1[k] = (r == k && s == 1) ? x : C1[k];
+            const int m0 = -(int)(r == k && s == 0), m1 = -(int)(r == k && s == 1);
+            C0[k] = (C0[k] & ~m0) | (x & m0);
+            C1[k] = (C1[k] & ~m1) | (x & m1);
         }
     }
 };

@@ -6,6 +6,7 @@
 #include <cstdint>
 
 #define PF_EMAX 64
+#define PF_STAMP_W 32        // profiling builds: words per wavefront and row in KArgs::stamps
 #define PF_MMAX_SLOT 96       // = PF_MMAX of pf_mp.h: migration events per local tree (stride of the per-event state arrays)
 #define PF_DCAP 32            // pending delayed factors per particle (the reference's heap is unbounded)
 #define PF_BIAS_MAX 8         // interior bias heights
@@ -100,6 +101,10 @@ struct KArgs {
     const double* mig_rate;        // [E*P*P]
     const double* mig_tot;         // [E*P]
     const int* join_map;           // [E*P]
+    const double* cum_coal;        // [E*P] cumulative coalescence intensity per population at the epoch starts
+    const double* cum_mig;         // [E*P] cumulative emigration intensity per population at the epoch starts
+    const double* next_join;       // [E]   start of the next epoch with a fixed-time population move
+    const int* next_join_epoch;    // [E]   that epoch (E if none)
     const int* sample_pop;         // [n]
     double* plog;                  // coal/migr opportunity pieces: plog[(p*pcap + k%pcap)*3 .. +3)
     unsigned pcap;
@@ -169,7 +174,7 @@ struct KArgs {
     int* rg_dpend; int* rg_blkcnt;
     unsigned* rg_widx;
     int nc;                        // wavefronts = (Np + 63) / 64
-    // profiling builds (-DPF_STAMPS): wall-clock stamps of the extend workgroups' phases, [rows][nc][16]; null otherwise
+    // profiling builds (-DPF_STAMPS): wall-clock stamps of the extend workgroups' phases, [rows][nc][PF_STAMP_W]; null otherwise
     unsigned long long* stamps;
     long long stamp_rows;
     // per-wavefront partials written by k_extend

@@ -114,12 +114,22 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "reference_bands"))
     ap.add_argument("--extra", default="", help="extra binary flags for every run (bisecting)")
+    ap.add_argument("--merge", default="", help="an earlier <out>.json: its rows for the configurations not run now are kept")
     args = ap.parse_args()
     cases = [c for c in load_cases() if not args.only or c["name"] in args.only.split(",")]
     tmpdir = tempfile.mkdtemp(prefix="refbands_")
     result = []
-    md = ["| configuration | target | reference band | at the reference's seed | mean over seeds | sd | inside band |",
+    if args.merge:
+        ran = {c["name"] for c in cases}
+        result = [r for r in json.load(open(args.merge)) if r["case"] not in ran]
+    header = ["| configuration | target | reference band | at the reference's seed | mean over seeds | sd | inside band |",
           "|---|---|---|---|---|---|---|"]
+
+    def md_row(r):
+        b, v = r["band"], r["values"]
+        return "| %s | %s | %.4g – %.4g | %.4g %s | %.4g | %.2g | %d / %d |" % (
+            r["case"], r["target"], b[0], b[1], v[0], "ok" if b[0] <= v[0] <= b[1] else "**out**", r["mean"], r["sd"], r["inside"], len(v))
+
     for c in cases:
         ref_seed = int(c["seed"][0])
         nseeds = args.seeds_big if c["sequence_length"] > 2e7 else args.seeds
@@ -135,10 +145,10 @@ def main():
             result.append(dict(case=c["name"], target=target_label(t), band=[t["min"], t["max"]], truth=t.get("truth"),
                                seeds=seeds, values=vals.tolist(), at_reference_seed=float(vals[0]),
                                mean=float(np.nanmean(vals)), sd=float(np.nanstd(vals)), inside=n_in))
-            md.append("| %s | %s | %.4g – %.4g | %.4g %s | %.4g | %.2g | %d / %d |" % (
-                c["name"], target_label(t), t["min"], t["max"], vals[0], "ok" if in_band(t, vals[0]) else "**out**",
-                np.nanmean(vals), np.nanstd(vals), n_in, len(vals)))
-        # results so far (a run that is cut short keeps what it has)
+        # results so far (a run that is cut short keeps what it has), in the order of the fixture
+        order = {c2["name"]: i for i, c2 in enumerate(load_cases())}
+        result.sort(key=lambda r: order.get(r["case"], 99))
+        md = header + [md_row(r) for r in result]
         os.makedirs(os.path.dirname(args.out), exist_ok=True)
         json.dump(result, open(args.out + ".json", "w"), indent=1)
         open(args.out + ".md", "w").write("\n".join(md) + "\n")

@@ -15,12 +15,12 @@ def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
-def _run_both(oracle, model, segs, Np, seed, ess=0.5):
+def _run_both(oracle, model, segs, Np, seed, ess=0.5, debug=0):
     from smcsmc_amd import ParticleFilter
     o = oracle.Oracle(model, Np, ess_fraction=ess, seed=seed, max_trace_events=64)
     o.init_prior(segs["start"][0])
     si = o.pack_segments(model, segs)
-    g = ParticleFilter(model, Np, ess_fraction=ess, seed=seed, max_trace_events=64)
+    g = ParticleFilter(model, Np, ess_fraction=ess, seed=seed, max_trace_events=64, debug=debug)
     g.init_prior(segs["start"][0])
     g.load_segments(segs)
     return o, si, g
@@ -62,12 +62,15 @@ def test_structured_prior_trees_bit_exact(oracle, hiplib):
     assert o.migrations()["n_events"].sum() > 0
 
 
-@pytest.mark.parametrize("n,E,P,Np,seed", [(4, 8, 2, 600, 2), (8, 8, 2, 256, 3), (6, 6, 3, 300, 4)])
-def test_structured_full_sweep_parity(oracle, hiplib, n, E, P, Np, seed):
+@pytest.mark.parametrize("lds_tree", [False, True])
+@pytest.mark.parametrize("n,E,P,Np,seed", [(4, 8, 2, 600, 2), (8, 8, 2, 256, 3), (6, 6, 3, 300, 4), (2, 5, 2, 200, 6), (7, 12, 4, 320, 7)])
+def test_structured_full_sweep_parity(oracle, hiplib, n, E, P, Np, seed, lds_tree):
+    """Both row kernels of the structured filter -- the register-resident tree (n <= 8, the default) and the LDS tree
+    (any n; forced here with PF_DEBUG_FORCE_LDS) -- against the oracle."""
     base = cases.make_model(n=n, E=E, L=1.0e5)
     segs = cases.make_segments(base, seed=seed, max_seg_len=5000)
     model = cases.make_structured(base, P=P, split_epoch=E - 3, mig=2.0)
-    o, si, g = _run_both(oracle, model, segs, Np, seed)
+    o, si, g = _run_both(oracle, model, segs, Np, seed, debug=1 if lds_tree else 0)
     o.run(si)
     g.run(); g.finish()
     to, tg = o.trace(), g.trace()
@@ -213,8 +216,9 @@ def test_structured_binary_end_to_end(hiplib, tmp_path):
     assert abs(da[(("LogL", -1, -1, -1, -1), "Count")] - ll_plain) < 0.02 * abs(ll_plain)
 
 
+@pytest.mark.parametrize("lds_tree", [False, True])
 @pytest.mark.parametrize("n,P,delay_type", [(4, 2, 0), (8, 2, 0), (6, 3, 1), (4, 2, 2)])
-def test_focused_sampling_with_structure_parity(oracle, hiplib, n, P, delay_type):
+def test_focused_sampling_with_structure_parity(oracle, hiplib, n, P, delay_type, lds_tree):
     """-bias_heights / -bias_strengths with several populations (the configuration of the reference's own two-population
     regression tests, test_two_pops.py:36-37): biased cut point on the LDS tree, delayed importance weights, resampling
     with pending factors -- trees, migration events, weights, ESS and resampling indices bit-identical to the oracle."""
@@ -224,7 +228,8 @@ def test_focused_sampling_with_structure_parity(oracle, hiplib, n, P, delay_type
     model = dict(model, bias_heights=[400.0], bias_strengths=[5.0, 1.0], application_delays=np.full(E, 3000.0), delay_type=delay_type)
     segs = cases.make_segments(cases.make_model(n=n, E=E, L=1.2e5), seed=90 + n, max_seg_len=5000)
     o = oracle.Oracle(model, 320, seed=8, max_trace_events=64); o.init_prior(segs["start"][0]); si = o.pack_segments(model, segs)
-    g = ParticleFilter(model, 320, seed=8, max_trace_events=64); g.init_prior(segs["start"][0]); g.load_segments(segs)
+    g = ParticleFilter(model, 320, seed=8, max_trace_events=64, debug=1 if lds_tree else 0)
+    g.init_prior(segs["start"][0]); g.load_segments(segs)
     o.run(si); g.run(); g.finish()
     to, tg = o.trace(), g.trace()
     assert (to["resampled"] == tg["resampled"]).all() and to["resampled"].sum() > 0
@@ -288,8 +293,9 @@ def test_auxiliary_particle_filter_with_structure_parity(oracle, hiplib, n, P, l
     assert not np.allclose(pg["w_post"], pg["w_pilot"])          # the look-ahead sits in the pilot weight only
 
 
+@pytest.mark.parametrize("lds_tree", [False, True])
 @pytest.mark.parametrize("n,P,bias", [(4, 2, False), (8, 2, True)])
-def test_recombination_guide_with_structure_parity(oracle, hiplib, n, P, bias):
+def test_recombination_guide_with_structure_parity(oracle, hiplib, n, P, bias, lds_tree):
     """-guide with several populations: position-dependent sampling rate, per-sample relative rates, importance weights
     over the stretch and per event (particle.cpp:942-1254), alone and together with the height bias."""
     from smcsmc_amd import ParticleFilter
@@ -304,7 +310,8 @@ def test_recombination_guide_with_structure_parity(oracle, hiplib, n, P, bias):
         model.update(bias_heights=[400.0], bias_strengths=[3.0, 1.0])
     segs = cases.make_segments(base, seed=60 + n, max_seg_len=5000)
     o = oracle.Oracle(model, 320, seed=6, max_trace_events=64); o.init_prior(segs["start"][0]); si = o.pack_segments(model, segs)
-    g = ParticleFilter(model, 320, seed=6, max_trace_events=64); g.init_prior(segs["start"][0]); g.load_segments(segs)
+    g = ParticleFilter(model, 320, seed=6, max_trace_events=64, debug=1 if lds_tree else 0)
+    g.init_prior(segs["start"][0]); g.load_segments(segs)
     o.run(si); g.run(); g.finish()
     to, tg = o.trace(), g.trace()
     assert (to["resampled"] == tg["resampled"]).all() and to["resampled"].sum() > 0
