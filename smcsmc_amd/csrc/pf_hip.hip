@@ -3153,7 +3153,7 @@ static int launch_extend(pf_handle* h, long long s, int fuse = 0) {
         const size_t smem_reg = (size_t)(2 * PF_EPAD + h->E + 2 * PF_BIAS_MAX + 3) * 8;
         const bool biased = h->A.n_bias > 0 || h->A.g_K > 0;
         if (h->P > 1)
-            pf_mp_launch_extend(h->A, s, h->smem, h->stream, h->force_lds);
+            pf_mp_launch_extend(h->A, s, h->smem, h->stream, h->force_lds, fuse);
         else if (h->n <= 4 && biased && !h->force_lds)
         {
             if (h->A.rec_trees) hipLaunchKernelGGL((k_extend_reg<4, true, true>), dim3(h->nblocks), dim3(PF_BS), smem_reg, h->stream, h->A, s, fuse);
@@ -3442,18 +3442,24 @@ int pf_run(pf_handle* h, int64_t s_begin, int64_t s_end) {
     HIPCHK(hipSetDevice(h->device));
     if (s_begin < 0 || s_end > h->n_segs) { g_err = "segment range out of bounds"; return -1; }
     if (extend_can_fuse(h)) return (h->pipe && !h->two_launch_rows) ? run_pipeline(h, s_begin, s_end) : run_single_stream(h, s_begin, s_end);
+    // structured models on the register-tree kernel: the next row's extend completes this row while it loads (two
+    // launches per row on the main stream instead of three); the last row of the call is completed by k_resample
+    const bool mp_fuse = h->P > 1 && pf_mp_can_fuse(h->A, h->force_lds) && h->A.apf == 0 && !h->no_fuse;
+    long long owed = -1;              // row decided but not completed yet
     for (long long s = s_begin; s < s_end; ++s) {
         h->step_windows = host_windows(h, seg_pos(h, s), false);
         h->A.sp = (int)(s & 1);
-        if (launch_extend(h, s, 0)) return -1;
+        if (launch_extend(h, s, owed >= 0 ? 1 : 0)) return -1;
         if (launch_decide(h, s, 0, h->step_windows)) return -1;
-        if (launch_resample(h, s)) return -1;
+        if (mp_fuse) owed = s;
+        else if (launch_resample(h, s)) return -1;
         if (launch_count(h, s, h->step_windows)) return -1;
         if (launch_ledger(h, s)) return -1;
         h->seg_done = s + 1;
         if (h->h_seg_start[s] + h->h_seg_len[s] >= h->h_L) break;   // smcsmc.cpp:353-356
         if ((s & 1023) == 1023) trim_spans(h);
     }
+    if (owed >= 0 && launch_resample(h, owed)) return -1;
     return 0;
 }
 

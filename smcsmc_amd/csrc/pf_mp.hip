@@ -430,7 +430,7 @@ __device__ __forceinline__ SmemMPR carve_mpr(double* base, int E, int P) {
 // maximum over 32 lanes instead of 64 and serialise fewer divergent paths.  The weights meet in LDS, and the first
 // wavefront does the reductions over the 64 particles exactly as the full wavefront did.
 template <int NM, bool BIASED, int LA>
-__global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long long s) {
+__global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long long s, int fuse) {
     constexpr int NI = RTree<NM>::NI;
     extern __shared__ double smem[];
     SmemMPR mm = carve_mpr(smem, A.E, A.P);
@@ -457,6 +457,11 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
     const Ctrl* c = A.ctrl;
     const int n = A.n;
     const int cur = __builtin_amdgcn_readfirstlane(c->cur);
+    // fuse: the previous row was decided (k_decide) but not completed -- this kernel does k_resample's part while it
+    // loads: normalisation, or the copy from the parent with the closing record of the old slot (pc.cpp:335-368)
+    const bool completing = fuse != 0;
+    const bool gather = completing && __builtin_amdgcn_readfirstlane(c->flag) != 0;
+    const int from_slot = gather ? (cur ^ 1) : cur;
     const int lane = threadIdx.x & 63;
     const int cslot = (int)(threadIdx.x >> 6) * LA + lane;             // place of this lane's particle in the workgroup's 64
     const long long p = (long long)blockIdx.x * 64 + cslot;
@@ -473,6 +478,9 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
     bool has_pending = false;
     if (active) {
         const DState st = state_slot(A, cur);
+        const DState from = state_slot(A, from_slot);
+        const long long a = gather ? (long long)A.parent[p] : p;
+        if (completing && p == 0) { Ctrl* cw = A.ctrl; cw->gen_prev = c->gen; cw->nres_prev = c->n_resample; }
         RTree<NM> t;
         MRLane ml;
         ml.Mt = mm.Mt + cslot; ml.Mb = mm.Mb + cslot; ml.Mq = mm.Mq + cslot;
@@ -483,17 +491,17 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
         for (int r = 0; r < NI; ++r) {
             t.S[r] = 0.0; t.C0[r] = 0; t.C1[r] = 0;
             if (r < n - 1) {
-                t.S[r] = st.S[(size_t)r * A.Np + p];
-                t.C0[r] = st.C[(size_t)(2 * r) * A.Np + p];
-                t.C1[r] = st.C[(size_t)(2 * r + 1) * A.Np + p];
-                ml.pn |= (unsigned)st.Pn[(size_t)r * A.Np + p] << (2 * r);
+                t.S[r] = from.S[(size_t)r * A.Np + a];
+                t.C0[r] = from.C[(size_t)(2 * r) * A.Np + a];
+                t.C1[r] = from.C[(size_t)(2 * r + 1) * A.Np + a];
+                ml.pn |= (unsigned)from.Pn[(size_t)r * A.Np + a] << (2 * r);
             }
         }
-        ml.nm = st.nm[p];
+        ml.nm = from.nm[a];
         for (int q = 0; q < ml.nm; ++q) {
-            LMt(ml, q) = st.Mt[(size_t)q * A.Np + p];
-            LMb(ml, q) = st.Mb[(size_t)q * A.Np + p];
-            LMq(ml, q) = st.Mq[(size_t)q * A.Np + p];
+            LMt(ml, q) = from.Mt[(size_t)q * A.Np + a];
+            LMb(ml, q) = from.Mb[(size_t)q * A.Np + a];
+            LMq(ml, q) = from.Mq[(size_t)q * A.Np + a];
         }
         RCtx cx;
         cx.T = mm.T; cx.I = nullptr; cx.H = nullptr; cx.E = A.E; cx.n = n; cx.L = A.L; cx.mu = A.mu; cx.rho = A.rho;
@@ -502,20 +510,62 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
         cx.want_desc = false; cx.want_desc_new = false; cx.last_desc = 0; cx.last_desc_new = 0;
         cx.vbc = A.vb_coal; cx.upd_fac = 1.0;
         cx.gK = BIASED ? A.g_K : 0; cx.gpos = A.g_pos; cx.grho = A.g_rho; cx.gleaf = A.g_leaf;
-        cx.ridx = guided ? st.ridx[p] : 0; cx.g_rp = 0; cx.g_sb = 0;
+        cx.ridx = guided ? from.ridx[a] : 0; cx.g_rp = 0; cx.g_sb = 0;
         DStore ds;
         ds.pos = st.dpos + p; ds.fac = st.dfac + p; ds.delta = st.ddelta + p; ds.k = st.dk + p; ds.Np = A.Np;
         ds.count = 0; ds.total = 1.0;
-        if (biased) { ds.count = st.dcount[p]; ds.total = st.total_delayed[p]; }
-        w_post = st.w_post[p];
-        w_pilot = st.w_pilot[p];
-        double next_base = st.next_base[p];
-        double x_mark = st.x_mark[p];
-        int mark_limit = st.mark_limit[p];
-        cx.Ltree = st.Ltree[p];
+        if (biased) {
+            ds.count = from.dcount[a]; ds.total = from.total_delayed[a];
+            if (gather)       // the copy constructor copies the pending factors (particle.cpp:122-123)
+                for (int k = 0; k < ds.count; ++k) {
+                    st.dpos[(size_t)k * A.Np + p] = from.dpos[(size_t)k * A.Np + a];
+                    st.dfac[(size_t)k * A.Np + p] = from.dfac[(size_t)k * A.Np + a];
+                    st.ddelta[(size_t)k * A.Np + p] = from.ddelta[(size_t)k * A.Np + a];
+                    st.dk[(size_t)k * A.Np + p] = from.dk[(size_t)k * A.Np + a];
+                }
+        }
+        w_post = from.w_post[a];
+        w_pilot = from.w_pilot[a];
+        double next_base = from.next_base[a];
+        double x_mark = from.x_mark[a];
+        int mark_limit = from.mark_limit[a];
+        cx.Ltree = from.Ltree[a];
         cx.ctr = A.rng_ctr[p];
         cx.ebuf = A.ebuf[p];
         unsigned widx = A.widx[p];
+        if (completing) {
+            const double inv = c->inv_T;
+            if (!gather) {
+                w_post *= inv;                             // normalize_probability, pc.cpp:435-437
+                w_pilot *= inv;
+            } else {
+                const int G = c->gen - 1;                  // the generation that ended with the previous row
+                const double pos = c->cur_pos;
+                const int* lo_tab = A.lo + (size_t)((G + A.Gcap) % A.Gcap) * (A.Np + 1);
+                // role of the old slot p: close its stretch if it has offspring
+                if (lo_tab[p + 1] > lo_tab[p]) {
+                    double* rec = rec_ptr(A, p, widx);
+                    rec[0] = from.x_mark[p];
+                    rec[1] = pos;
+                    rec[2] = 0.0; rec[3] = 0.0;
+                    rec[4] = __longlong_as_double((long long)make_meta(1, from.mark_limit[p], -1, n));
+                    for (int r = 0; r < n - 1; ++r) rec[5 + r] = from.S[(size_t)r * A.Np + p];
+                    ++widx;
+                }
+                A.gstart[(size_t)((G + 1) % A.Gcap) * A.Np + p] = widx;
+                // role of the new slot p: weights of the copy (pc.cpp:350-351), fresh position for all but the first
+                const int ev = (int)c->n_resample - 1;
+                if (ev < A.max_trace_events) A.ev_parents[(size_t)ev * A.Np + p] = (int)a;
+                const double wp = w_post * inv;
+                const double wq = w_pilot * inv;
+                const double sumn = c->S1 * inv;
+                const double adj = sumn / ((double)A.Np * wq);
+                w_post = wp * adj;
+                w_pilot = wq * adj;
+                x_mark = pos;
+                if (p != lo_tab[a] && pos < A.L) next_base = r_sample_next_base<false>(cx, pos);     // pc.cpp:357-368
+            }
+        }
         PLog pl;
         pl.base = A.plog + (size_t)p * A.pcap * 3; pl.cap = A.pcap; pl.idx = A.pidx[p]; pl.pos = pl.idx % pl.cap; pl.on = true;
         pl.fopen = false; pl.ropen = false;
@@ -853,13 +903,14 @@ static unsigned mp_blocks(long long n) { return (unsigned)((n + PF_BS - 1) / PF_
 void pf_mp_launch_init(const KArgs& A, double initial_position, size_t smem, hipStream_t st) {
     hipLaunchKernelGGL(k_init_mp, dim3(mp_blocks(A.Np)), dim3(PF_BS), smem, st, A, initial_position);
 }
-void pf_mp_launch_extend(const KArgs& A, long long s, size_t smem, hipStream_t st, bool lds_tree) {
+bool pf_mp_can_fuse(const KArgs& A, bool lds_tree) { return !lds_tree && A.n <= 8; }
+void pf_mp_launch_extend(const KArgs& A, long long s, size_t smem, hipStream_t st, bool lds_tree, int fuse) {
     if (!lds_tree && A.n <= 8) {
         const size_t sm = smem_mpr_bytes(A.E, A.P);
         if (A.n_bias > 0 || A.g_K > 0)
-            hipLaunchKernelGGL((k_extend_mpr<8, true, PF_MPR_LANES>), dim3(mp_blocks(A.Np)), dim3(64 * (64 / PF_MPR_LANES)), sm, st, A, s);
+            hipLaunchKernelGGL((k_extend_mpr<8, true, PF_MPR_LANES>), dim3(mp_blocks(A.Np)), dim3(64 * (64 / PF_MPR_LANES)), sm, st, A, s, fuse);
         else
-            hipLaunchKernelGGL((k_extend_mpr<8, false, PF_MPR_LANES>), dim3(mp_blocks(A.Np)), dim3(64 * (64 / PF_MPR_LANES)), sm, st, A, s);
+            hipLaunchKernelGGL((k_extend_mpr<8, false, PF_MPR_LANES>), dim3(mp_blocks(A.Np)), dim3(64 * (64 / PF_MPR_LANES)), sm, st, A, s, fuse);
         return;
     }
     if (A.n_bias > 0 || A.g_K > 0)

@@ -11,7 +11,9 @@ size_t pf_mp_smem_bytes(int n, int E, int P);
 int pf_mp_prepare(size_t smem);      // raises the dynamic-LDS limit of the kernels; -1 if the state does not fit
 void pf_mp_launch_init(const KArgs& A, double initial_position, size_t smem, hipStream_t st);
 // lds_tree: use the LDS-tree kernel whatever the sample size (n > 8 always does)
-void pf_mp_launch_extend(const KArgs& A, long long s, size_t smem, hipStream_t st, bool lds_tree);
+// fuse (register-tree kernel only, pf_mp_can_fuse): complete the previous row (k_resample's part) while loading
+void pf_mp_launch_extend(const KArgs& A, long long s, size_t smem, hipStream_t st, bool lds_tree, int fuse);
+bool pf_mp_can_fuse(const KArgs& A, bool lds_tree);
 void pf_mp_launch_calibrate(const KArgs& A, unsigned long long seed, long long rep0, long long nrep, int* out_epoch,
                             double* out_dist, int* out_err, size_t smem, hipStream_t st);
 void pf_mp_launch_tbl(const KArgs& A, unsigned long long seed, long long nrep, double* out_h, double* out_len, int* out_err,

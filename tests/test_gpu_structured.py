@@ -62,15 +62,16 @@ def test_structured_prior_trees_bit_exact(oracle, hiplib):
     assert o.migrations()["n_events"].sum() > 0
 
 
-@pytest.mark.parametrize("lds_tree", [False, True])
+@pytest.mark.parametrize("debug", [0, 2, 1], ids=["register-tree", "register-tree-unfused", "lds-tree"])
 @pytest.mark.parametrize("n,E,P,Np,seed", [(4, 8, 2, 600, 2), (8, 8, 2, 256, 3), (6, 6, 3, 300, 4), (2, 5, 2, 200, 6), (7, 12, 4, 320, 7)])
-def test_structured_full_sweep_parity(oracle, hiplib, n, E, P, Np, seed, lds_tree):
-    """Both row kernels of the structured filter -- the register-resident tree (n <= 8, the default) and the LDS tree
-    (any n; forced here with PF_DEBUG_FORCE_LDS) -- against the oracle."""
+def test_structured_full_sweep_parity(oracle, hiplib, n, E, P, Np, seed, debug):
+    """Both row kernels of the structured filter -- the register-resident tree (n <= 8, the default, completing the
+    previous row while it loads; with PF_DEBUG_NO_FUSE as three launches per row) and the LDS tree (any n; forced here
+    with PF_DEBUG_FORCE_LDS) -- against the oracle."""
     base = cases.make_model(n=n, E=E, L=1.0e5)
     segs = cases.make_segments(base, seed=seed, max_seg_len=5000)
     model = cases.make_structured(base, P=P, split_epoch=E - 3, mig=2.0)
-    o, si, g = _run_both(oracle, model, segs, Np, seed, debug=1 if lds_tree else 0)
+    o, si, g = _run_both(oracle, model, segs, Np, seed, debug=debug)
     o.run(si)
     g.run(); g.finish()
     to, tg = o.trace(), g.trace()
