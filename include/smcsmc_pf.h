@@ -75,7 +75,7 @@ typedef struct pf_params {
     uint64_t seed;               /* -seed */
     int32_t max_trace_events;    /* resampling events whose ancestor arrays are retained for inspection */
     int32_t flags;               /* bit0: record the 100-bp local recombination map (count.cpp:559-654);
-                                  * bit1: -arg, keep what pf_sample_tree_events needs (one population) */
+                                  * bit1: -arg, keep what pf_sample_tree_events needs */
     /* Capacities of the device-side rings that stand in for the reference's Arena of EvolutionaryEvents
      * (arena.cpp:56-111, unbounded there).  0 = default.  A ring that is too small for the lags in force is a
      * reported error (pf_sync returns -2, "event log ring overflow" / "generation ledger overflow"), never a
@@ -149,6 +149,13 @@ int pf_init_prior(pf_handle* h, double initial_position);
  * samples alone when it went back into its own branch).  Returns the number of events (fills at most max_events). */
 int64_t pf_sample_tree_events(pf_handle* h, int32_t* kind, double* pos, double* height, uint32_t* desc, int64_t max_events,
                               int64_t* particle_out);
+/* The same with the population columns of the file (pc.cpp:541-548): from_pop = population of the event (C and M lines,
+ * -1 for R), to_pop = destination of a migration (M lines, kind 2; -1 otherwise).  With several populations an update
+ * yields R, C and then the migrations of the two active lineages of the walk that led to the coalescence, latest first
+ * (particle.cpp:292-298; samples: those of the floating lineage, or everything else for the root's own lineage).
+ * Structured models need nsam <= 8 for -arg. */
+int64_t pf_sample_tree_events_pops(pf_handle* h, int32_t* kind, double* pos, double* height, uint32_t* desc, int32_t* from_pop,
+                                   int32_t* to_pop, int64_t max_events, int64_t* particle_out);
 
 /* after pf_load_segments: switches the auxiliary particle filter on (update_lookahead_likelihood, pc.cpp:227-240) */
 int pf_load_lookahead(pf_handle* h, const pf_lookahead* la);

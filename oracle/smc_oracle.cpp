@@ -243,9 +243,10 @@ struct Tree {
 /* a tree-modifying event of the pseudo-epoch of particle.cpp:240-249, 292-298, 379-389 (RECORD_TREE_EVENT): the
  * list is immutable and shared between a particle and its copies, as the reference's ref-counted event chains are */
 struct TreeEv {
-    int kind;                 /* 0 recombination (R), 1 coalescence (C) */
+    int kind;                 /* 0 recombination (R), 1 coalescence (C), 2 migration (M) */
     double x, t;
     uint32_t desc;
+    int from_pop, to_pop;     /* population of a C / M event, destination of an M event; -1 otherwise (pc.cpp:541-548) */
     std::shared_ptr<const TreeEv> parent;
 };
 
@@ -317,11 +318,16 @@ struct Filter {
     void apply_vb(Particle& p) { if (!M.vb_coal.empty()) { p.w_post *= upd_fac; p.w_pilot *= upd_fac; } upd_fac = 1.0; }
     double last_iw = 1.0, last_tc = 0.0, last_first_event = 0.0;
     bool record_trees = false;      /* -arg (pfparam.cpp:353-357) */
-    void push_tree_event(Particle& p, int kind, double x, double t, uint32_t desc) {
+    void push_tree_event(Particle& p, int kind, double x, double t, uint32_t desc, int from_pop = -1, int to_pop = -1) {
         auto ev = std::make_shared<TreeEv>();
         ev->kind = kind; ev->x = x; ev->t = t; ev->desc = desc; ev->parent = p.tree_head;
+        ev->from_pop = kind == 1 && from_pop < 0 ? 0 : from_pop;     /* one population: every coalescence is in population 0 */
+        ev->to_pop = to_pop;
         p.tree_head = ev;
     }
+    /* -arg with several populations: the samples whose lineage the two active lineages of the walk in progress are (what
+     * get_descendants(active_node(i)) returns in particle.cpp:292-298) */
+    uint32_t tree_fl_desc = 0, tree_rt_desc = 0;
     /* samples below node id of tree t */
     uint32_t desc_mask(const Tree& t, int id) const {
         if (id < M.n) return 1u << id;
@@ -655,6 +661,8 @@ struct Filter {
                         }
                     }
                     record(root_active, weight, tt, t1, e, kind, to);
+                    if (record_trees && rec_p && kind != 1)     /* the M line of printTrees (particle.cpp:292-298) */
+                        push_tree_event(*rec_p, 2, x, t1, kind == 2 ? tree_fl_desc : tree_rt_desc, kind == 2 ? pf : pr, to);
                     if (W.tfirst < 0.0) W.tfirst = t1;          /* particle.cpp:263-264 */
                     g.ebuf = -smc_log(uni(slot));
                     if (rec_p && !M.vb_coal.empty())            /* adjustWeights(exp_digamma(c)/c), particle.cpp:266-272 */
@@ -711,6 +719,7 @@ struct Filter {
         for (int i = 1; i < n; ++i) {
             int ni = i - 1;
             Walk W;
+            tree_fl_desc = 1u << i; tree_rt_desc = (1u << i) - 1u;
             mp_coalesce(slot, &p, t, ni, root, 0.0, M.sample_pop[i], 0.0, M.E - 1, W);
             apply_vb(p);
             double tc = W.tc;
@@ -725,8 +734,10 @@ struct Filter {
             int fl = i;
             if (idx < nslots) {
                 lineages_in_pop(t, ni, tc, W.pf, idx, &pr, &ps);
+                if (record_trees) push_tree_event(p, 1, 0.0, tc, (1u << i) | desc_mask(t, t.C[pr][ps]), W.pf);
                 mp_insert_node(t, ni, tc, &fl, pr, ps, root, W.pf);
             } else {
+                if (record_trees) push_tree_event(p, 1, 0.0, tc, (2u << i) - 1u, W.pf);
                 mp_insert_node(t, ni, tc, &fl, -1, 0, root, W.pf);
             }
             for (int m = 0; m < W.npath; ++m) ev_insert(t, W.pt[m], fl, W.pq[m]);
@@ -742,6 +753,8 @@ struct Filter {
         int b_id = t.C[rp][sb], s_id = t.C[rp][1 - sb];
         const int pf0 = pop_at(t, b_id, h);
         Walk W;
+        const uint32_t cut = record_trees ? desc_mask(t, b_id) : 0u;
+        tree_fl_desc = cut; tree_rt_desc = ((1u << n) - 1u) & ~cut;
         mp_coalesce(slot, &p, t, n - 1, n + n - 2, h, pf0, x, limit, W);
         const double tc = W.tc;
         last_tc = tc;
@@ -770,6 +783,19 @@ struct Filter {
         int idx = std::min((int)(u * (double)k), k - 1);
         last_sp = Sp;
         last_changed = !(has_stub && idx == k - 1);
+        if (record_trees) {
+            /* as in the one-population update: C with the samples below the node the lineage creates, then R */
+            uint32_t dn = cut;
+            if (idx < nslots) {
+                int qr = -1, qs = 0;
+                lineages_in_pop(t, ni, tc, W.pf, idx, &qr, &qs);
+                dn = cut | desc_mask(t, t.C[qr][qs]);
+            } else if (has_root && idx == nslots) {
+                dn = (1u << n) - 1u;
+            }
+            push_tree_event(p, 1, x, tc, dn, W.pf);
+            push_tree_event(p, 0, x, h, cut);
+        }
         if (idx < nslots) {
             lineages_in_pop(t, ni, tc, W.pf, idx, &pr, &ps);
             mp_insert_node(t, ni, tc, &b_id, pr, ps, troot, W.pf);
@@ -2131,7 +2157,6 @@ int smco_enable_local_recomb(void* h) { ((Filter*)h)->local_map = true; return 0
 /* -arg: call before smco_init_prior */
 int smco_enable_tree_recording(void* h) {
     Filter* f = (Filter*)h;
-    if (f->M.P > 1) { g_err = "tree recording is restated for one population"; return -1; }
     f->record_trees = true;
     return 0;
 }
@@ -2140,6 +2165,11 @@ int smco_enable_tree_recording(void* h) {
  * cumulative posterior weight passes U * total, U the next uniform of the resampler's stream; its events last first */
 int64_t smco_sample_tree_events(void* h, int32_t* kind, double* pos, double* height, uint32_t* desc, int64_t max_events,
                                 int64_t* particle_out) {
+    return smco_sample_tree_events_pops(h, kind, pos, height, desc, nullptr, nullptr, max_events, particle_out);
+}
+
+int64_t smco_sample_tree_events_pops(void* h, int32_t* kind, double* pos, double* height, uint32_t* desc, int32_t* from_pop,
+                                     int32_t* to_pop, int64_t max_events, int64_t* particle_out) {
     Filter* f = (Filter*)h;
     if (!f->record_trees) return -1;
     double total = 0.0;
@@ -2151,7 +2181,14 @@ int64_t smco_sample_tree_events(void* h, int32_t* kind, double* pos, double* hei
     if (particle_out) *particle_out = j;
     int64_t n = 0;
     for (const TreeEv* ev = f->parts[j].tree_head.get(); ev; ev = ev->parent.get()) {
-        if (n < max_events) { if (kind) kind[n] = ev->kind; if (pos) pos[n] = ev->x; if (height) height[n] = ev->t; if (desc) desc[n] = ev->desc; }
+        if (n < max_events) {
+            if (kind) kind[n] = ev->kind;
+            if (pos) pos[n] = ev->x;
+            if (height) height[n] = ev->t;
+            if (desc) desc[n] = ev->desc;
+            if (from_pop) from_pop[n] = ev->from_pop;
+            if (to_pop) to_pop[n] = ev->to_pop;
+        }
         ++n;
     }
     return n;

@@ -137,6 +137,8 @@ int smco_enable_local_recomb(void* h);
 int smco_enable_tree_recording(void* h);
 int64_t smco_sample_tree_events(void* h, int32_t* kind, double* pos, double* height, uint32_t* desc, int64_t max_events,
                                 int64_t* particle_out);
+int64_t smco_sample_tree_events_pops(void* h, int32_t* kind, double* pos, double* height, uint32_t* desc, int32_t* from_pop,
+                                     int32_t* to_pop, int64_t max_events, int64_t* particle_out);
 int smco_get_local_recomb(void* h, double* opp_diff, double* counts, int64_t nbins);
 /* structured models: migration events kept on each particle's local tree ([np*cap], sorted by time) and the
  * population of every coalescent node ([np*(nsam-1)]) */

@@ -246,12 +246,13 @@ static void pfARG_core(PfParam& P, const HostModel& M0, int device, const ChunkJ
     pp.max_trace_events = 0;
     pp.flags = 1;          // the local recombination map is always recorded (smcsmc.cpp:376-383)
     if (P.record_trees) {
-        if (NP > 1) throw Unsupported("-arg with more than one population");
+        if (NP > 1 && M.nsam > 8) throw Unsupported("-arg with more than one population and more than 8 samples");
         pp.flags |= 2;     // -arg (pfparam.cpp:353-357)
         // nothing may be overwritten while the history is needed: a slot appends about 0.6 records per row for its
         // recombinations and up to one per resampling, and there are at most as many generations as rows
         auto pow2_at_least = [](double v) { long long c = 16384; while ((double)c < v) c <<= 1; return c; };
-        const long long log_cap = pow2_at_least(1.4 * (double)start.size());
+        // (recombinations per row grow with the tree length: the figure above is for four samples)
+        const long long log_cap = pow2_at_least(1.4 * (double)start.size() * std::max(1.0, (M.nsam - 1) / 3.0));
         const long long gen_cap = pow2_at_least((double)start.size() + 2.0);
         const double gib = ((double)P.particles * (double)log_cap * (5.0 + M.nsam - 1) * 8.0 + (double)gen_cap * (double)P.particles * 20.0) / (1024.0 * 1024.0 * 1024.0);
         clog << " -arg: event log of " << log_cap << " records per particle, " << gen_cap << " generations (" << fixed << setprecision(1)
@@ -370,19 +371,20 @@ static void pfARG_core(PfParam& P, const HostModel& M0, int device, const ChunkJ
         // <prefix>.trees.gz (ParticleContainer::printTrees, pc.cpp:515-555) after the one-particle draw of smcsmc.cpp:395
         if (P.record_trees) {          // every E-step overwrites it, as the reference does
             int64_t particle = 0;
-            const int64_t nev = pf_sample_tree_events(h, nullptr, nullptr, nullptr, nullptr, 0, &particle);
+            const int64_t nev = pf_sample_tree_events_pops(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &particle);
             if (nev < 0) pf_check(-1);
-            std::vector<int32_t> kind((size_t)nev);
+            std::vector<int32_t> kind((size_t)nev), from((size_t)nev), to((size_t)nev);
             std::vector<double> xs((size_t)nev), ts((size_t)nev);
             std::vector<uint32_t> ds((size_t)nev);
-            if (pf_sample_tree_events(h, kind.data(), xs.data(), ts.data(), ds.data(), nev, &particle) < 0) pf_check(-1);
+            if (pf_sample_tree_events_pops(h, kind.data(), xs.data(), ts.data(), ds.data(), from.data(), to.data(), nev, &particle) < 0)
+                pf_check(-1);
             std::string text;
             text.reserve((size_t)nev * 48);
             char buf[96];
             for (int64_t i = 0; i < nev; ++i) {
                 // out << eventcode << x + start_position - 1 << t << from_pop << to_pop, fixed, one decimal
-                int len = snprintf(buf, sizeof buf, "%c\t%.1f\t%.1f\t%d\t-1\t", kind[i] == 0 ? 'R' : 'C', xs[i] + P.start_position - 1, ts[i],
-                                   kind[i] == 0 ? -1 : 0);
+                int len = snprintf(buf, sizeof buf, "%c\t%.1f\t%.1f\t%d\t%d\t", kind[i] == 0 ? 'R' : (kind[i] == 1 ? 'C' : 'M'),
+                                   xs[i] + P.start_position - 1, ts[i], from[i], to[i]);
                 text.append(buf, (size_t)len);
                 // print_descendants (descendants.hpp:51-65)
                 const uint32_t m = ds[i];

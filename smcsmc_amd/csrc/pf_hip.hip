@@ -1451,7 +1451,7 @@ __device__ __forceinline__ void records_contrib(AccT<P>& acc, const KArgs& A, co
                         const int pop = (int)(tag & 0xff), kind = (int)((tag >> 8) & 0xff), to = (int)((tag >> 16) & 0xff);
                         const double lo = t0 > W.T0 ? t0 : W.T0, hi = t1 < W.T1 ? t1 : W.T1;
                         const double mo = hi > lo ? hi - lo : 0.0;
-                        const bool ev = kind != 0 && W.T0 <= t1 && t1 < W.T1;
+                        const bool ev = (kind & 3) != 0 && W.T0 <= t1 && t1 < W.T1;
                         if (!(mo > 0.0) && !ev) continue;
                         const double co = (double)((tag >> 24) & 0xff) * mo;
 #pragma unroll
@@ -2784,7 +2784,10 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     h->max_trace_events = std::max(0, p->max_trace_events);
     if (p->flags & 2) {
         // -arg: the parent table of every resampling is kept (it is the ancestry the tree dump walks back through)
-        if (P > 1) { delete h; return fail("pf_create: tree recording (-arg) is implemented for one population"); }
+        if (P > 1 && (n > 8 || (p->debug & PF_DEBUG_FORCE_LDS))) {
+            delete h;
+            return fail("pf_create: tree recording (-arg) with several populations needs nsam <= 8 (register-tree kernel)");
+        }
         if (gen_cap > 0x7fffffffLL / 2) gen_cap = 0x7fffffffLL / 2;
         h->max_trace_events = (int)gen_cap;
     }
@@ -3662,8 +3665,25 @@ __global__ void k_gather_records(KArgs A, int ngen, const int* slot, const unsig
     }
 }
 
+// pieces of the records gathered by k_gather_records (structured models): entry i copies np[i] pieces of slot[i] from pstart[i]
+__global__ void k_gather_pieces(KArgs A, int nrec, const int* slot, const unsigned* pstart, const unsigned* np, const long long* off,
+                                double* out) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= nrec) return;
+    double* o = out + (size_t)off[i] * 3;
+    for (unsigned j = 0; j < np[i]; ++j) {
+        const double* q = A.plog + ((size_t)slot[i] * A.pcap + ((pstart[i] + j) % A.pcap)) * 3;
+        *o++ = q[0]; *o++ = q[1]; *o++ = q[2];
+    }
+}
+
 int64_t pf_sample_tree_events(pf_handle* h, int32_t* kind, double* pos, double* height, uint32_t* desc, int64_t max_events,
                               int64_t* particle_out) {
+    return pf_sample_tree_events_pops(h, kind, pos, height, desc, nullptr, nullptr, max_events, particle_out);
+}
+
+int64_t pf_sample_tree_events_pops(pf_handle* h, int32_t* kind, double* pos, double* height, uint32_t* desc, int32_t* from_pop,
+                                   int32_t* to_pop, int64_t max_events, int64_t* particle_out) {
     if (!h->A.rec_trees) { g_err = "pf_sample_tree_events: the handle was not created with tree recording (pf_params.flags bit 1)"; return -1; }
     if (pf_sync(h)) return -1;
     Ctrl c;
@@ -3700,23 +3720,78 @@ int64_t pf_sample_tree_events(pf_handle* h, int32_t* kind, double* pos, double* 
     HIPCHK(hipStreamSynchronize(h->stream));
     std::vector<double> rec((size_t)nrec * RS);
     if (nrec) HIPCHK(hipMemcpy(rec.data(), drec, rec.size() * 8, hipMemcpyDeviceToHost));
+    // structured models: the migrations and the coalescence of an update are in its pieces (pf_mp.h PLog)
+    std::vector<double> pieces;
+    std::vector<long long> poff((size_t)nrec + 1, 0);
+    if (h->P > 1 && nrec) {
+        std::vector<int> gslot(G + 1);
+        HIPCHK(hipMemcpy(gslot.data(), dslot, (size_t)(G + 1) * 4, hipMemcpyDeviceToHost));
+        std::vector<int> rslot((size_t)nrec);
+        std::vector<unsigned> rstart((size_t)nrec), rnp((size_t)nrec);
+        for (int g = 0; g <= G; ++g)
+            for (long long r = off[g]; r < off[g] + (long long)(k1[g] - k0[g]); ++r) rslot[(size_t)r] = gslot[g];
+        for (long long r = 0; r < nrec; ++r) {
+            const double* q = &rec[(size_t)r * RS];
+            unsigned long long meta, ref;
+            memcpy(&meta, &q[4], 8);
+            memcpy(&ref, &q[3], 8);
+            const int type = (int)(meta & 0xff);
+            const bool has = type == 0 || type == 2;
+            rstart[(size_t)r] = has ? (unsigned)(ref & 0xffffffffu) : 0u;
+            rnp[(size_t)r] = has ? (unsigned)(ref >> 32) : 0u;
+            poff[(size_t)r + 1] = poff[(size_t)r] + rnp[(size_t)r];
+        }
+        const long long npieces = poff[(size_t)nrec];
+        int* d_s; unsigned *d_p0, *d_np; long long* d_off; double* d_out;
+        HIPCHK(hipMalloc(&d_s, (size_t)nrec * 4)); HIPCHK(hipMalloc(&d_p0, (size_t)nrec * 4)); HIPCHK(hipMalloc(&d_np, (size_t)nrec * 4));
+        HIPCHK(hipMalloc(&d_off, (size_t)nrec * 8)); HIPCHK(hipMalloc(&d_out, std::max<size_t>(1, (size_t)npieces * 3) * 8));
+        HIPCHK(hipMemcpy(d_s, rslot.data(), (size_t)nrec * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_p0, rstart.data(), (size_t)nrec * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_np, rnp.data(), (size_t)nrec * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_off, poff.data(), (size_t)nrec * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_gather_pieces, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, h->stream, h->A, (int)nrec, d_s, d_p0, d_np, d_off, d_out);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        pieces.resize((size_t)npieces * 3);
+        if (npieces) HIPCHK(hipMemcpy(pieces.data(), d_out, pieces.size() * 8, hipMemcpyDeviceToHost));
+        hipFree(d_s); hipFree(d_p0); hipFree(d_np); hipFree(d_off); hipFree(d_out);
+    }
     hipFree(dslot); hipFree(dk0); hipFree(dk1); hipFree(doff); hipFree(drec);
-    // last position first; within an update the R line precedes the C line (pc.cpp:527-551)
+    // last position first; within an update the R line precedes the C line, which precedes the M lines of the walk that
+    // led to it, latest first (the reference prepends every event to one list and prints from its head, pc.cpp:527-551)
     int64_t nout = 0;
-    auto emit = [&](int kd, double x, double t, unsigned d) {
-        if (nout < max_events) { if (kind) kind[nout] = kd; if (pos) pos[nout] = x; if (height) height[nout] = t; if (desc) desc[nout] = d; }
+    auto emit = [&](int kd, double x, double t, unsigned d, int from, int to) {
+        if (nout < max_events) {
+            if (kind) kind[nout] = kd;
+            if (pos) pos[nout] = x;
+            if (height) height[nout] = t;
+            if (desc) desc[nout] = d;
+            if (from_pop) from_pop[nout] = from;
+            if (to_pop) to_pop[nout] = to;
+        }
         ++nout;
     };
+    const unsigned full = (1u << h->n) - 1u;
     for (long long r = nrec - 1; r >= 0; --r) {
         const double* q = &rec[(size_t)r * RS];
         unsigned long long meta;
         memcpy(&meta, &q[4], 8);
         const int type = (int)(meta & 0xff);
-        if (type == 0) {
-            emit(0, q[1], q[2], (unsigned)((meta >> 32) & 0xffff));
-            emit(1, q[1], q[3], (unsigned)((meta >> 48) & 0xffff));
-        } else if (type == 2) {
-            emit(1, q[1], q[3], (unsigned)((meta >> 48) & 0xffff));
+        if (type != 0 && type != 2) continue;
+        const unsigned cut = (unsigned)((meta >> 32) & 0xffff), below = (unsigned)((meta >> 48) & 0xffff);
+        if (type == 0) emit(0, q[1], q[2], cut, -1, -1);
+        if (h->P == 1) { emit(1, q[1], q[3], below, 0, -1); continue; }
+        // the floating lineage is the cut branch (an update) or leaf i on its way into the partial tree (initial tree:
+        // n_eff = i); the other active lineage is the root's own, above everything that is not the floating lineage
+        const int leaf = (int)((meta >> 24) & 0xff);
+        const unsigned fl = type == 0 ? cut : (1u << leaf);
+        const unsigned rt = type == 0 ? (full & ~cut) : ((1u << leaf) - 1u);
+        for (long long j = poff[(size_t)r + 1] - 1; j >= poff[(size_t)r]; --j) {
+            long long tag;
+            memcpy(&tag, &pieces[(size_t)j * 3], 8);
+            const int pop = (int)(tag & 0xff), kd = (int)((tag >> 8) & 0xff), to = (int)((tag >> 16) & 0xff);
+            const double t1 = pieces[(size_t)j * 3 + 2];
+            if (kd & 1) emit(1, q[1], t1, below, pop, -1);
+            if (kd & 2) emit(2, q[1], t1, (kd & 4) ? rt : fl, pop, to);
         }
     }
     return nout;

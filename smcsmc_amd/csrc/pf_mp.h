@@ -67,7 +67,8 @@ struct MLane {
 #define LBp(ml, id) ((ml).Bp[(id) * PF_BS])
 
 // coal/migr opportunity pieces of one genealogy update, written to the slot's piece ring (three words each):
-//   tag = pop | kind << 8 | to << 16 | weight << 24   (kind bit0: coalescence at the end, bit1: migration to `to`)
+//   tag = pop | kind << 8 | to << 16 | weight << 24   (kind bit0: coalescence at the end, bit1: migration to `to`,
+//                                                       bit2: piece of the root's own lineage, not of the floating one)
 //   t0, t1 = the stretch of the walk during which the lineage sat in `pop` with `weight` coalescence partners.
 // A piece may span several epochs; the count kernel clips it to the epoch it is counting (coalescence opportunity =
 // weight * overlap, migration opportunity = overlap, the event belongs to the epoch that holds t1) and applies the
@@ -98,7 +99,7 @@ __device__ __forceinline__ void plog_flush_f(PLog& pl, int kind, int to) {
     pl.fopen = false;
 }
 __device__ __forceinline__ void plog_flush_r(PLog& pl, int kind, int to) {
-    if (pl.ropen) plog_write(pl, pl.rp, kind, to, 0, pl.rt0, pl.rt1);
+    if (pl.ropen) plog_write(pl, pl.rp, kind | 4, to, 0, pl.rt0, pl.rt1);
     pl.ropen = false;
 }
 
@@ -477,9 +478,10 @@ __device__ __forceinline__ void mp_retag(MLane& ml, int from, int to) {
         if (LMb(ml, m) == from) LMb(ml, m) = (int8_t)to;
 }
 
-// Forest::buildInitialTree(true) for a structured model.  `emit(i, pstart, npieces, tc)` logs the record of leaf i.
+// Forest::buildInitialTree(true) for a structured model.  `emit(i, pstart, npieces, tc, below)` logs the record of leaf i;
+// `below` = the samples under the node leaf i creates (computed when `tmp`, n-1 doubles of per-lane LDS scratch, is given).
 template <bool LOG, class Emit>
-__device__ __forceinline__ void mp_build_initial_tree(Lane& ln, MLane& ml, PLog& pl, Emit emit) {
+__device__ __forceinline__ void mp_build_initial_tree(Lane& ln, MLane& ml, PLog& pl, Emit emit, double* tmp = nullptr) {
     const int n = ln.n;
     ml.nm = 0;
     int root = 0;
@@ -489,7 +491,7 @@ __device__ __forceinline__ void mp_build_initial_tree(Lane& ln, MLane& ml, PLog&
         unsigned p0 = LOG ? pl.idx : 0u;
         mp_coalesce<LOG>(ln, ml, ni, root, 0.0, ml.SP[i], pl, ln.E - 1, W);
         if (ml.err) return;
-        emit(i, p0, LOG ? pl.idx - p0 : 0u, W.tc);
+        const unsigned np_ = LOG ? pl.idx - p0 : 0u;
         double tc = W.tc;
         mp_retag(ml, PF_TAG_RPATH, root);
         // candidates: the lineages of the partial tree in the coalescence population (their populations at tc are
@@ -504,8 +506,10 @@ __device__ __forceinline__ void mp_build_initial_tree(Lane& ln, MLane& ml, PLog&
         int fl = i;
         if (idx < nslots) {
             mp_slots_at(ln, ml, ni, -1, tc, W.pf, 0, 0, idx, &pr, &ps);
+            emit(i, p0, np_, tc, tmp ? (1u << i) | lane_desc_mask(ln, LC(ln, pr, ps), tmp) : 0u);
             mp_insert_node(ln, ml, ni, tc, &fl, pr, ps, root, W.pf);
         } else {
+            emit(i, p0, np_, tc, (2u << i) - 1u);
             mp_insert_node(ln, ml, ni, tc, &fl, -1, 0, root, W.pf);
         }
         mp_retag(ml, PF_TAG_PATH, fl);

@@ -102,16 +102,16 @@ __global__ __launch_bounds__(PF_BS) void k_init_mp(KArgs A, double initial_posit
     pl.base = A.plog + (size_t)p * A.pcap * 3; pl.cap = A.pcap; pl.idx = 0; pl.pos = 0; pl.on = true; pl.fopen = false; pl.ropen = false;
     // every coalescence of the initial tree is logged as a type-2 record at position 0 (particle.cpp:251-300)
     double w0 = 1.0 / (double)A.Np;
-    mp_build_initial_tree<true>(ln, ml, pl, [&](int i, unsigned p0, unsigned np_, double tc) {
+    mp_build_initial_tree<true>(ln, ml, pl, [&](int i, unsigned p0, unsigned np_, double tc, unsigned below) {
         if (ln.vbc) { w0 *= ln.upd_fac; ln.upd_fac = 1.0; }
         double* rec = rec_ptr(A, p, widx);
         rec[0] = 0.0; rec[1] = 0.0; rec[2] = 0.0;
         rec[3] = piece_ref(p0, np_);
-        rec[4] = __longlong_as_double((long long)make_meta(2, A.E - 1, A.E - 1, i));
+        rec[4] = __longlong_as_double((long long)make_meta(2, A.E - 1, A.E - 1, i, 0, below));
         for (int r = 0; r < n - 1; ++r) rec[5 + r] = 0.0;
         (void)tc;
         ++widx;
-    });
+    }, A.rec_trees ? m.t0 + threadIdx.x : nullptr);
     mp_report(A, ml);
     double nb = sample_next_base_guided(ln, 0.0, A.g_K, A.g_pos, A.g_rho, 0);
     const DState st = A.st0;
@@ -429,7 +429,9 @@ __device__ __forceinline__ SmemMPR carve_mpr(double* base, int E, int P) {
 // particles most of the 1024 SIMDs have nothing to do -- half-filled wavefronts on twice as many SIMDs wait for the
 // maximum over 32 lanes instead of 64 and serialise fewer divergent paths.  The weights meet in LDS, and the first
 // wavefront does the reductions over the 64 particles exactly as the full wavefront did.
-template <int NM, bool BIASED, int LA>
+// TREES (-arg): every record carries the samples below the cut branch and below the node the update creates, and
+// neither the record ring nor the piece ring may wrap.
+template <int NM, bool BIASED, int LA, bool TREES>
 __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long long s, int fuse) {
     constexpr int NI = RTree<NM>::NI;
     extern __shared__ double smem[];
@@ -637,16 +639,17 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
                     else r_sample_point_plain(cx, t, u_point, &h, &lin);
                     r_lineages_at(t, n, n - 1, h, lin, &rp, &sb);
                 }
-                const unsigned desc = A.lmap_opp ? r_desc_mask(t, n, rp, sb) : 0u;
+                const unsigned desc = (TREES || A.lmap_opp) ? r_desc_mask(t, n, rp, sb) : 0u;
+                unsigned desc_new = 0;
                 unsigned p0 = pl.idx;
                 double tfirst = 0.0;
                 MP_TICK(tu1);
                 MP_ACC(ml, 8, tu0, tu1);
-                rmp_genealogy_rest<NM, true>(cx, t, ml, pl, rp, sb, h, &tc, &tfirst);
+                rmp_genealogy_rest<NM, true, TREES>(cx, t, ml, pl, rp, sb, h, &tc, &tfirst, desc, &desc_new);
                 if (cx.vbc) { w_post *= cx.upd_fac; w_pilot *= cx.upd_fac; cx.upd_fac = 1.0; }
                 rec[2] = h;
                 rec[3] = piece_ref(p0, pl.idx - p0);
-                rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n, desc));
+                rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n, desc, desc_new));
                 ++widx;
                 if (ml.err) break;
                 MP_TICK(tu2);
@@ -759,6 +762,7 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
         A.ebuf[p] = cx.ebuf;
         A.widx[p] = widx;
         A.pidx[p] = pl.idx;
+        if (TREES && (widx >= A.cap || pl.idx >= A.pcap)) A.ctrl->err = ERR_LOG_OVERFLOW;       // -arg keeps every record and piece
         A.snap_w[A.sp][p] = w_post; A.snap_xm[A.sp][p] = x_mark; A.snap_ml[A.sp][p] = mark_limit; A.snap_widx[A.sp][p] = widx;
         MP_TICK(tk_stored);
         MP_ACC(ml, 11, tk_lik, tk_stored);
@@ -814,7 +818,7 @@ __global__ __launch_bounds__(PF_BS) void k_calibrate_mp(KArgs A, unsigned long l
     ln.ebuf = -dlog(uni(ln));
     PLog nolog;
     nolog.on = false;
-    mp_build_initial_tree<false>(ln, ml, nolog, [&](int, unsigned, unsigned, double) {});
+    mp_build_initial_tree<false>(ln, ml, nolog, [&](int, unsigned, unsigned, double, unsigned) {});
     double* orig = m.t0 + threadIdx.x;
     int alive = n - 1;
     for (int j = 0; j < n - 1; ++j) {
@@ -868,7 +872,7 @@ __global__ __launch_bounds__(PF_BS) void k_tbl_mp(KArgs A, unsigned long long se
     ln.ebuf = -dlog(uni(ln));
     PLog nolog;
     nolog.on = false;
-    mp_build_initial_tree<false>(ln, ml, nolog, [&](int, unsigned, unsigned, double) {});
+    mp_build_initial_tree<false>(ln, ml, nolog, [&](int, unsigned, unsigned, double, unsigned) {});
     out_len[r] = ln.Ltree;
     for (int i = 0; i < n; ++i) {
         int pr = -1;
@@ -887,8 +891,10 @@ int pf_mp_prepare(size_t smem) {
     {
         // the register-tree row kernels: their LDS does not depend on n (tables at their largest size here)
         const int big = (int)smem_mpr_bytes(PF_EMAX, PF_PMAX);
-        if (hipFuncSetAttribute((const void*)k_extend_mpr<8, false, PF_MPR_LANES>, hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) return -1;
-        if (hipFuncSetAttribute((const void*)k_extend_mpr<8, true, PF_MPR_LANES>, hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void*)k_extend_mpr<8, false, PF_MPR_LANES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void*)k_extend_mpr<8, true, PF_MPR_LANES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void*)k_extend_mpr<8, false, PF_MPR_LANES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void*)k_extend_mpr<8, true, PF_MPR_LANES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) return -1;
     }
     if (smem > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)k_extend_mp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
@@ -907,10 +913,12 @@ bool pf_mp_can_fuse(const KArgs& A, bool lds_tree) { return !lds_tree && A.n <= 
 void pf_mp_launch_extend(const KArgs& A, long long s, size_t smem, hipStream_t st, bool lds_tree, int fuse) {
     if (!lds_tree && A.n <= 8) {
         const size_t sm = smem_mpr_bytes(A.E, A.P);
-        if (A.n_bias > 0 || A.g_K > 0)
-            hipLaunchKernelGGL((k_extend_mpr<8, true, PF_MPR_LANES>), dim3(mp_blocks(A.Np)), dim3(64 * (64 / PF_MPR_LANES)), sm, st, A, s, fuse);
-        else
-            hipLaunchKernelGGL((k_extend_mpr<8, false, PF_MPR_LANES>), dim3(mp_blocks(A.Np)), dim3(64 * (64 / PF_MPR_LANES)), sm, st, A, s, fuse);
+        const dim3 grid(mp_blocks(A.Np)), blk(64 * (64 / PF_MPR_LANES));
+        const bool biased = A.n_bias > 0 || A.g_K > 0;
+        if (biased && A.rec_trees) hipLaunchKernelGGL((k_extend_mpr<8, true, PF_MPR_LANES, true>), grid, blk, sm, st, A, s, fuse);
+        else if (biased) hipLaunchKernelGGL((k_extend_mpr<8, true, PF_MPR_LANES, false>), grid, blk, sm, st, A, s, fuse);
+        else if (A.rec_trees) hipLaunchKernelGGL((k_extend_mpr<8, false, PF_MPR_LANES, true>), grid, blk, sm, st, A, s, fuse);
+        else hipLaunchKernelGGL((k_extend_mpr<8, false, PF_MPR_LANES, false>), grid, blk, sm, st, A, s, fuse);
         return;
     }
     if (A.n_bias > 0 || A.g_K > 0)

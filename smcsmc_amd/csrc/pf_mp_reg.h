@@ -104,7 +104,7 @@ __device__ __forceinline__ void r_sample_point_plain(RCtx& cx, const RTree<NM>& 
 // of rank rp; populations from bp as the walk left them.  S ascends, so "node id is at or below tc" is a rank test.
 template <int NM>
 __device__ __forceinline__ int rmp_slots_at(const RTree<NM>& t, const MRLane& ml, int n, int rp, double tc, int pop, int s_id, double Sp,
-                                            int want, int* pr, int* ps) {
+                                            int want, int* pr, int* ps, int* eff_out = nullptr) {
     constexpr int NI = RTree<NM>::NI;
     const int ni = n - 1;
     const int pid = n + rp;
@@ -128,7 +128,7 @@ __device__ __forceinline__ int rmp_slots_at(const RTree<NM>& t, const MRLane& ml
                     crossing = id < n || id - n < R;
                 }
                 if (crossing && pk2_get(ml.bp, eff) == pop) {
-                    if (cnt == want) { *pr = r - (r > rp ? 1 : 0); *ps = s; }
+                    if (cnt == want) { *pr = r - (r > rp ? 1 : 0); *ps = s; if (eff_out) *eff_out = eff; }
                     ++cnt;
                 }
             }
@@ -402,11 +402,28 @@ __device__ __forceinline__ void rmp_coalesce(RCtx& cx, const RTree<NM>& t, MRLan
 #undef PF_MPR_BUF_PUSH
 
 // mp_genealogy_rest of pf_mp.h: the update after the recombination point (slot (rp, sb), height h) has been sampled
-template <int NM, bool LOG>
+// TREES (-arg): *desc_new receives the samples below the node the update creates -- the cut samples `cut` plus those
+// below the lineage it lands on, all of them above the root, its own only when it falls back into its branch
+template <int NM, bool LOG, bool TREES = false>
 __device__ __forceinline__ void rmp_genealogy_rest(RCtx& cx, RTree<NM>& t, MRLane& ml, PLog& pl, int rp, int sb, double h,
-                                                   double* tc_out, double* tfirst_out) {
+                                                   double* tc_out, double* tfirst_out, unsigned cut = 0, unsigned* desc_new = nullptr) {
     constexpr int NI = RTree<NM>::NI;
     const int n = cx.n;
+    unsigned below[NI];
+    if (TREES) {
+#pragma unroll
+        for (int r = 0; r < NI; ++r) {
+            below[r] = 0;
+            if (r < n - 1) {
+                const int c0 = t.C0[r], c1 = t.C1[r];
+                unsigned m0 = c0 < n ? (1u << c0) : 0u, m1 = c1 < n ? (1u << c1) : 0u;
+#pragma unroll
+                for (int k = 0; k < NI; ++k)
+                    if (k < r) { m0 = (c0 - n == k) ? below[k] : m0; m1 = (c1 - n == k) ? below[k] : m1; }
+                below[r] = m0 | m1;
+            }
+        }
+    }
     int b_id = t.getC(rp, sb), s_id = t.getC(rp, 1 - sb);
     MWalk W;
     rmp_coalesce<NM, LOG>(cx, t, ml, b_id, h, pl, W);
@@ -428,7 +445,20 @@ __device__ __forceinline__ void rmp_genealogy_rest(RCtx& cx, RTree<NM>& t, MRLan
     if (k != W.weight || k < 1) { ml.err = 2; return; }
     const double u = r_uni(cx);
     const int idx = min((int)(u * (double)k), k - 1);
-    if (idx < nslots) rmp_slots_at(t, ml, n, rp, tc, W.pf, s_id, Sp, idx, &pr, &ps);
+    int eff = 0;
+    if (idx < nslots) rmp_slots_at(t, ml, n, rp, tc, W.pf, s_id, Sp, idx, &pr, &ps, &eff);
+    if (TREES) {
+        unsigned dn = cut;
+        if (idx < nslots) {
+            unsigned tm = eff < n ? (1u << eff) : 0u;
+#pragma unroll
+            for (int k = 0; k < NI; ++k) tm = (eff - n == k) ? below[k] : tm;
+            dn = cut | tm;
+        } else if (has_root && idx == nslots) {
+            dn = (1u << n) - 1u;
+        }
+        *desc_new = dn;
+    }
     MP_TICK(tg3);
     MP_ACC(ml, 5, tg2, tg3);
     // ---- the edit (see mp_genealogy_rest: tree by one removal and one insertion, event list in one pass)

@@ -97,15 +97,15 @@ def descendants_text(mask):
     return "".join("1" if (mask >> i) & 1 else "0" for i in range(top))
 
 
-def trees_text(kind, pos, height, desc, start_position=1.0):
-    """The lines of `<prefix>.trees.gz` (ParticleContainer::printTrees, pc.cpp:515-555): event code, position
-    (x + start_position - 1), height, from and to population, descendants; fixed notation with one decimal."""
+def trees_text(kind, pos, height, desc, start_position=1.0, from_pop=None, to_pop=None):
+    """The lines of `<prefix>.trees.gz` (ParticleContainer::printTrees, pc.cpp:515-555): event code (R, C, M), position
+    (x + start_position - 1), height, from and to population, descendants; fixed notation with one decimal.  Without the
+    population columns every coalescence is in population 0."""
     out = []
-    for k, x, t, d in zip(kind, pos, height, desc):
-        if k == 0:
-            out.append("R\t%.1f\t%.1f\t-1\t-1\t%s\n" % (x + start_position - 1, t, descendants_text(d)))
-        else:
-            out.append("C\t%.1f\t%.1f\t0\t-1\t%s\n" % (x + start_position - 1, t, descendants_text(d)))
+    for i, (k, x, t, d) in enumerate(zip(kind, pos, height, desc)):
+        fr = -1 if k == 0 else (0 if from_pop is None else int(from_pop[i]))
+        to = -1 if to_pop is None else int(to_pop[i])
+        out.append("%s\t%.1f\t%.1f\t%d\t%d\t%s\n" % ("RCM"[int(k)], x + start_position - 1, t, fr, to, descendants_text(d)))
     return "".join(out)
 
 

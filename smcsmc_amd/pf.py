@@ -94,7 +94,7 @@ EXPORTS = [
     "pf_terminal_branch_quantiles",
     "pf_update_segment", "pf_count", "pf_resample", "pf_run", "pf_finish", "pf_sync",
     "pf_num_segments_done", "pf_logl", "pf_get_counts", "pf_get_trace", "pf_get_resample_events",
-    "pf_get_particles", "pf_get_migrations", "pf_get_local_recomb", "pf_sample_tree_events", "pf_get_kernel_time", "pf_set_timing", "pf_get_stats", "pf_debug_stamps", "pf_simulate_sites",
+    "pf_get_particles", "pf_get_migrations", "pf_get_local_recomb", "pf_sample_tree_events", "pf_sample_tree_events_pops", "pf_get_kernel_time", "pf_set_timing", "pf_get_stats", "pf_debug_stamps", "pf_simulate_sites",
     "pf_median_survival", "pf_test_math", "pf_test_div", "pf_test_uniform", "pf_test_reduce", "pf_test_systematic",
 ]
 
@@ -127,6 +127,8 @@ def load_library(path=None):
     L.pf_sync.argtypes = [vp]
     L.pf_sample_tree_events.restype = C.c_int64
     L.pf_sample_tree_events.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.POINTER(C.c_int64)]
+    L.pf_sample_tree_events_pops.restype = C.c_int64
+    L.pf_sample_tree_events_pops.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.pf_num_segments_done.restype = C.c_int64
     L.pf_num_segments_done.argtypes = [vp]
     L.pf_logl.restype = C.c_double
@@ -370,15 +372,20 @@ class ParticleFilter:
         self._chk(self.L.pf_get_local_recomb(self.h, opp.ctypes.data, cnt.ctypes.data, nb))
         return {"opp_diff": opp, "counts": cnt}
 
-    def sample_tree_events(self):
+    def sample_tree_events(self, pops=False):
         """-arg: the particle of the final one-particle draw and the tree-modifying events of its history, last position
-        first: (particle, kind[K] (0 R, 1 C), pos[K], height[K], descendants[K] as sample bit masks)."""
+        first: (particle, kind[K] (0 R, 1 C, 2 M), pos[K], height[K], descendants[K] as sample bit masks); with pops=True
+        also (from_pop[K], to_pop[K]), the population columns of the .trees.gz lines."""
         part = C.c_int64()
-        n = self.L.pf_sample_tree_events(self.h, None, None, None, None, 0, C.byref(part))
+        n = self.L.pf_sample_tree_events_pops(self.h, None, None, None, None, None, None, 0, C.byref(part))
         if n < 0:
             raise PfError(_err(self.L))
         kind = np.zeros(n, np.int32); pos = np.zeros(n); hgt = np.zeros(n); desc = np.zeros(n, np.uint32)
-        self.L.pf_sample_tree_events(self.h, kind.ctypes.data, pos.ctypes.data, hgt.ctypes.data, desc.ctypes.data, n, C.byref(part))
+        fr = np.zeros(n, np.int32); to = np.zeros(n, np.int32)
+        self.L.pf_sample_tree_events_pops(self.h, kind.ctypes.data, pos.ctypes.data, hgt.ctypes.data, desc.ctypes.data,
+                                          fr.ctypes.data, to.ctypes.data, n, C.byref(part))
+        if pops:
+            return int(part.value), kind, pos, hgt, desc, fr, to
         return int(part.value), kind, pos, hgt, desc
 
     def migrations(self, cap=96):

@@ -77,6 +77,8 @@ def lib():
         L.smco_enable_tree_recording.argtypes = [C.c_void_p]
         L.smco_sample_tree_events.restype = C.c_int64
         L.smco_sample_tree_events.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.smco_sample_tree_events_pops.restype = C.c_int64
+        L.smco_sample_tree_events_pops.argtypes = [C.c_void_p] * 7 + [C.c_int64, C.POINTER(C.c_int64)]
         L.smco_get_local_recomb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.smco_logl.restype = C.c_double
         L.smco_logl.argtypes = [C.c_void_p]
@@ -228,13 +230,17 @@ class Oracle:
         """-arg: before init_prior"""
         self._chk(self.L.smco_enable_tree_recording(self.h))
 
-    def sample_tree_events(self):
+    def sample_tree_events(self, pops=False):
         part = C.c_int64()
-        n = self.L.smco_sample_tree_events(self.h, None, None, None, None, 0, C.byref(part))
+        n = self.L.smco_sample_tree_events_pops(self.h, None, None, None, None, None, None, 0, C.byref(part))
         if n < 0:
             raise RuntimeError("tree recording is off")
         kind = np.zeros(n, np.int32); pos = np.zeros(n); hgt = np.zeros(n); desc = np.zeros(n, np.uint32)
-        self.L.smco_sample_tree_events(self.h, kind.ctypes.data, pos.ctypes.data, hgt.ctypes.data, desc.ctypes.data, n, C.byref(part))
+        fr = np.zeros(n, np.int32); to = np.zeros(n, np.int32)
+        self.L.smco_sample_tree_events_pops(self.h, kind.ctypes.data, pos.ctypes.data, hgt.ctypes.data, desc.ctypes.data,
+                                            fr.ctypes.data, to.ctypes.data, n, C.byref(part))
+        if pops:
+            return int(part.value), kind, pos, hgt, desc, fr, to
         return int(part.value), kind, pos, hgt, desc
 
     def update_segment(self, seg_inp, s):

@@ -215,6 +215,17 @@ def test_structured_binary_end_to_end(hiplib, tmp_path):
     da = outfile.parse_outfile(str(tmp_path / "apf.out"))
     ll_plain = data[(("LogL", -1, -1, -1, -1), "Count")]
     assert abs(da[(("LogL", -1, -1, -1, -1), "Count")] - ll_plain) < 0.02 * abs(ll_plain)
+    # -arg on the structured model: R, C and M lines with their populations (pc.cpp:515-555)
+    import gzip
+    r = subprocess.run([binary] + core + common + ["-Np", "200", "-seed", "6", "-lag", "50000", "-arg", "-o", str(tmp_path / "arg")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = [ln.split("\t") for ln in gzip.open(tmp_path / "arg.trees.gz", "rt").read().splitlines()]
+    assert all(len(f) == 6 and f[0] in ("R", "C", "M") for f in lines)
+    ms = [f for f in lines if f[0] == "M"]
+    assert ms and all(f[3] in ("0", "1") and f[4] in ("0", "1") and f[3] != f[4] for f in ms)
+    assert all(f[3] in ("0", "1") and f[4] == "-1" for f in lines if f[0] == "C") and all(f[3] == "-1" for f in lines if f[0] == "R")
+    assert lines[-1][0] in ("C", "M") and float(lines[-1][1]) == 0.0                   # the first tree
 
 
 @pytest.mark.parametrize("lds_tree", [False, True])
@@ -328,3 +339,48 @@ def test_recombination_guide_with_structure_parity(oracle, hiplib, n, P, bias, l
     co, cg = o.counts(), g.counts()
     for k in ("coal_count", "coal_opp", "rec_count", "rec_opp", "mig_count", "mig_opp"):
         np.testing.assert_allclose(cg[k], co[k], rtol=1e-9, atol=1e-9 * np.abs(co[k]).max(), err_msg=k)
+
+
+@pytest.mark.parametrize("n,P,Np,bias", [(4, 2, 300, False), (8, 2, 160, False), (6, 3, 200, True)])
+def test_tree_dump_with_structure(oracle, hiplib, n, P, Np, bias):
+    """-arg with several populations (pc.cpp:515-555, particle.cpp:292-298): the R, C and M lines of the drawn particle's
+    history -- positions, heights, populations and descendants -- equal the oracle's linked list event for event; every
+    update reads R, C, then the migrations of the walk latest first, and each migration leaves the population the
+    next one (earlier in the file order: later in time) starts from."""
+    from smcsmc_amd import ParticleFilter, outfile
+    E = 8
+    base = cases.make_model(n=n, E=E, L=1.2e5)
+    segs = cases.make_segments(base, seed=40 + n, max_seg_len=5000)
+    model = cases.make_structured(base, P=P, split_epoch=E - 3, mig=2.0)
+    if bias:
+        model = dict(model, bias_heights=[400.0], bias_strengths=[4.0, 1.0], application_delays=np.full(E, 3000.0))
+    g = ParticleFilter(model, Np, seed=5, max_trace_events=0, record_trees=True, log_cap=8192, gen_cap=4096)
+    g.init_prior(segs["start"][0]); g.load_segments(segs); g.run(); g.finish()
+    assert g.trace()["resampled"].sum() > 3
+    part, kind, pos, hgt, desc, fr, to = g.sample_tree_events(pops=True)
+    o = oracle.Oracle(model, Np, seed=5, max_trace_events=0)
+    o.enable_tree_recording()
+    o.init_prior(segs["start"][0]); o.run(o.pack_segments(model, segs))
+    opart, okind, opos, ohgt, odesc, ofr, oto = o.sample_tree_events(pops=True)
+    assert opart == part and len(okind) == len(kind)
+    assert (okind == kind).all() and (odesc == desc).all() and (ofr == fr).all() and (oto == to).all()
+    assert (_bits(opos) == _bits(pos)).all() and (_bits(ohgt) == _bits(hgt)).all()
+    assert (kind == 2).sum() > 0, "the case must exercise migrations"
+    assert (np.diff(pos) <= 0).all()
+    full = (1 << n) - 1
+    i = 0
+    while i < len(kind):
+        if kind[i] == 0:                       # an update: R, C, M...
+            cut = int(desc[i]); x = pos[i]; i += 1
+            assert kind[i] == 1 and pos[i] == x and hgt[i] >= hgt[i - 1] and (int(desc[i]) & cut) == cut
+        else:                                  # a leaf of the first tree: C, M...
+            assert kind[i] == 1 and pos[i] == 0.0
+            cut = None
+        tc = hgt[i]; i += 1
+        while i < len(kind) and kind[i] == 2:
+            assert hgt[i] <= tc and fr[i] != to[i] and 0 <= to[i] < P
+            if cut is not None:
+                assert int(desc[i]) in (cut, full & ~cut)
+            i += 1
+    text = outfile.trees_text(kind, pos, hgt, desc, start_position=1.0, from_pop=fr, to_pop=to)
+    assert any(ln.startswith("M\t") for ln in text.splitlines()) and len(text.splitlines()) == len(kind)
