@@ -11,7 +11,11 @@
  * resampling indices or log-likelihood.  The oracle is pinned
  * (a) structurally, function by function against the cited reference lines,
  * (b) by the reference's .seg fixtures / FormatDouble contract for the boundary, and
- * (c) distributionally (coalescent prior expectations, known simulation truth).
+ * (c) distributionally (coalescent prior expectations, known simulation truth), and
+ * (d) by the acceptance bands the reference's own regression tests hold (tests/golden/reference_bands.json,
+ *     transcribed from test/old/newtests by tests/golden/make_reference_bands.py): the no-data classes are
+ *     asserted on this oracle in tests/test_oracle_cpu.py, all of them through the GPU path in
+ *     tests/test_gpu_reference_bands.py; DESIGN.md section 6 has the pass/fail table.
  *
  * The struct layouts below are deliberately identical to include/smcsmc_pf.h so the
  * parity tests can feed both sides the same buffers.

@@ -151,8 +151,11 @@ __device__ __forceinline__ double philox_uniform(unsigned long long seed, unsign
     unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a high and a low half (integer multiplies are
+        // the slow instructions of this loop)
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0;
+        unsigned hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
         unsigned n0 = hi1 ^ c1 ^ k0;
         unsigned n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
@@ -173,8 +176,11 @@ __device__ __forceinline__ void philox_pair(unsigned long long seed, unsigned sl
     unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a high and a low half (integer multiplies are
+        // the slow instructions of this loop)
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0;
+        unsigned hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
         unsigned n0 = hi1 ^ c1 ^ k0;
         unsigned n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;

@@ -3,8 +3,10 @@ coalescent prior expectations and a distributional acceptance run on reference d
 
 The reference's own tests hold no golden vectors for weights / indices / log-likelihood
 ("parity unpinned"), so the oracle is pinned by what *can* be pinned:
-published known answers (Philox), analytic expectations of the model it simulates, and the
-reference's committed real-scrm data with the known simulation truth."""
+published known answers (Philox), analytic expectations of the model it simulates, the
+reference's committed real-scrm data with the known simulation truth, and the acceptance bands of
+the reference's own no-data regression classes (tests/golden/reference_bands.json; the other
+classes need Np = 1000 over 10 Mb and run on the GPU, tests/test_gpu_reference_bands.py)."""
 import numpy as np
 import pytest
 
@@ -348,3 +350,55 @@ def test_focused_sampling_with_structure_is_unbiased(oracle):
     rates = c["coal_count"][2:4] / c["coal_opp"][2:4] * 2e4
     assert np.abs(rates - 1).max() < 0.06
     assert abs(o.logl()) < 0.5
+
+
+@pytest.mark.parametrize("name", ["TestConstPopSize_MissingData", "TestConstPopSize_FourEpochs_MissingData"])
+def test_oracle_meets_the_reference_no_data_bands(oracle, built_binary, name):
+    """The oracle against numbers the reference itself holds: the two no-data regression classes
+    (test/old/newtests/test_const_pop_size.py:150-170 and its four-epoch sibling; bands and flags in
+    tests/golden/reference_bands.json).  All genotypes are missing, the filter samples the prior at Np = 100, and the bands
+    are +-1 % around the truth -- they isolate the coalescent engine (reconstructed) from weighting and
+    resampling.  As in tests/test_gpu_reference_bands.py::test_engine_reproduces_the_no_data_bands the recording limit far
+    from data (smcsmc.cpp:266-275; the bands predate it) is lifted: mean over eight seeds inside every band, and at least
+    six of the eight runs inside each."""
+    import json
+    import os
+    import subprocess
+    import reference_bands as rb
+    from smcsmc_amd import segments as segmod
+    c = [x for x in rb.load_cases() if x["name"] == name][0]
+    argv = list(c["binary_argv"])
+    seg = os.path.join(rb.GOLD, "seg", c["data"])
+    argv[argv.index("@SEG@")] = seg
+    out = subprocess.run([rb.BIN] + argv + ["-dumpmodel"], capture_output=True, text=True)
+    m = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    E = len(m["change_times"])
+    bh = [float(argv[argv.index("-bias_heights") + 1])]
+    bs = [float(v) for v in argv[argv.index("-bias_strengths") + 1:argv.index("-bias_strengths") + 3]]
+    lf = float(argv[argv.index("-calibrate_lag") + 1])
+    model = dict(change_times=np.array(m["change_times"], float), pop_sizes=np.array(m["pop_sizes"], float)[:, 0], nsam=m["nsam"],
+                 loci_length=float(m["loci_length"]), mutation_rate=m["mutation_rate"], recombination_rate=m["recombination_rate"])
+    model["lags"] = np.ones(E)
+    med, _ = oracle.median_survival(model, seed=1, min_events=200, max_trees=1000000)
+    model.update(lags=med * lf, bias_heights=bh, bias_strengths=bs, application_delays=med * 0.5, delay_type=0)
+    S = segmod.Segments(seg, m["nsam"], m["loci_length"], max_segment_length=int(2.0 / (m["recombination_rate"] * 4 * m["N0"])))
+    segs = S.pack(model["lags"])
+    segs["max_record_epoch"][:] = E - 1
+    N = model["pop_sizes"]
+    est = []
+    for seed in range(1, 9):
+        o = oracle.Oracle(model, c["np"], seed=seed, max_trace_events=0)
+        o.init_prior(segs["start"][0])
+        o.run(o.pack_segments(model, segs))
+        cn = o.counts()
+        ne = (cn["coal_opp"] + 1.0) / (2 * (cn["coal_count"] + 1.0 / (2 * N)))          # with the prior pseudo-counts of the .out rows
+        rec = (cn["rec_count"].sum() + E * model["recombination_rate"]) / (cn["rec_opp"].sum() + E)
+        est.append(list(ne) + [rec])
+        o.close()
+    est = np.array(est)
+    for t in c["targets"]:
+        col = t["epoch"] if t["type"] == "Coal" else E
+        vals = est[:, col]
+        assert t["min"] <= vals.mean() <= t["max"], (rb.target_label(t), vals.mean(), t["min"], t["max"])
+        if t["type"] != "Coal" or t["epoch"] > 0:
+            assert ((vals >= t["min"]) & (vals <= t["max"])).sum() >= 6, (rb.target_label(t), vals)
