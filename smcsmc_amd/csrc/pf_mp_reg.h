@@ -74,8 +74,9 @@ template <int NM>
 __device__ __forceinline__ void r_sample_point_plain(RCtx& cx, const RTree<NM>& t, double u_point, double* h_out, int* lin_out) {
     const int n = cx.n;
     double r = u_point * cx.Ltree;
-    double prev = 0.0, h = 0.0;
-    int lin = 0;
+    double prev = 0.0;
+    double sel_r = 0.0, sel_d = 1.0, sel_prev = 0.0, sel_sr = 0.0;
+    int sel_k = 1;
     bool done = false;
 #pragma unroll
     for (int ri = 0; ri < RTree<NM>::NI; ++ri) {
@@ -85,10 +86,7 @@ __device__ __forceinline__ void r_sample_point_plain(RCtx& cx, const RTree<NM>& 
             double d = sr - prev;
             double seg = (double)k * d;
             if (r < seg || ri == n - 2) {
-                double q = r / d;
-                lin = min((int)q, k - 1);
-                h = prev + (q - (double)lin) * d;
-                if (!(h < sr)) h = prev;
+                sel_r = r; sel_d = d; sel_prev = prev; sel_sr = sr; sel_k = k;
                 done = true;
             } else {
                 r -= seg;
@@ -96,6 +94,10 @@ __device__ __forceinline__ void r_sample_point_plain(RCtx& cx, const RTree<NM>& 
             }
         }
     }
+    const double q = sel_r / sel_d;
+    const int lin = min((int)q, sel_k - 1);
+    double h = sel_prev + (q - (double)lin) * sel_d;
+    if (!(h < sel_sr)) h = sel_prev;
     *h_out = h;
     *lin_out = lin;
 }

@@ -498,8 +498,11 @@ __device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, doubl
         r_sample_point_biased(cx, t, u_point, &h, &lin);
         cx.last_rbiw = cx.last_iw;
     } else {
+        // the slice is found first, the one division follows (inside the unrolled scan every rank would carry its own)
         double r = u_point * cx.Ltree;
         double prev = 0.0;
+        double sel_r = 0.0, sel_d = 1.0, sel_prev = 0.0, sel_sr = 0.0;
+        int sel_k = 1;
         bool done = false;
 #pragma unroll
         for (int ri = 0; ri < RTree<NM>::NI; ++ri) {
@@ -509,16 +512,19 @@ __device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, doubl
                 double d = sr - prev;
                 double seg = (double)k * d;
                 if (r < seg || ri == n - 2) {
-                    double q = r / d;
-                    lin = min((int)q, k - 1);
-                    h = prev + (q - (double)lin) * d;
-                    if (!(h < sr)) h = prev;
+                    sel_r = r; sel_d = d; sel_prev = prev; sel_sr = sr; sel_k = k;
                     done = true;
                 } else {
                     r -= seg;
                     prev = sr;
                 }
             }
+        }
+        {
+            double q = sel_r / sel_d;
+            lin = min((int)q, sel_k - 1);
+            h = sel_prev + (q - (double)lin) * sel_d;
+            if (!(h < sel_sr)) h = sel_prev;
         }
     }
     int rp = 0, sb = 0;
