@@ -1440,7 +1440,10 @@ __device__ __forceinline__ void records_contrib(AccT<P>& acc, const KArgs& A, co
                 // structured models: the walk of the update left pieces (pf_mp.h PLog) -- population, partners, [t0, t1),
                 // event at t1 -- that are clipped to this epoch here; record flags and the epoch limit as above
                 (void)n_eff;
-                if (inwin && (W.rf & REC_COALMIGR) && W.e <= lim_event) {
+                // without a tree dump the record says which epochs its pieces touch (piece_span, pf_mp.h)
+                const unsigned span = (unsigned)((meta >> 48) & 0xffff);
+                const bool elsewhere = !A.rec_trees && (span & 0x1000u) && (W.e < (int)(span & 63u) || W.e > (int)((span >> 6) & 63u));
+                if (inwin && (W.rf & REC_COALMIGR) && W.e <= lim_event && !elsewhere) {
                     unsigned long long ref = (unsigned long long)__double_as_longlong(f3);
                     unsigned pstart = (unsigned)(ref & 0xffffffffu), np_ = (unsigned)(ref >> 32);
                     if (A.pidx[a] - pstart > A.pcap || np_ > A.pcap) { if (!A.ctrl->err) A.ctrl->err = ERR_LOG_OVERFLOW; np_ = 0; }

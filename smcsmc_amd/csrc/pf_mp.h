@@ -216,7 +216,10 @@ __device__ __forceinline__ int mp_slots_at(const Lane& ln, const MLane& ml, int 
     return cnt;
 }
 
-struct MWalk { double tc; int pf, pr, weight; double tfirst; };   // tfirst: first sampled event of the walk (migration or coalescence)
+struct MWalk { double tc; int pf, pr, weight; double tfirst; int e0, e1; };   // tfirst: first sampled event of the walk (migration or coalescence); e0, e1: epochs of its start and of its coalescence
+// what a record says about where its pieces lie (bits 48-63 of the meta word when no tree dump is recorded): epochs
+// outside [e0, e1] need not look at them
+__device__ __forceinline__ unsigned piece_span(int e0, int e1) { return (unsigned)e0 | ((unsigned)e1 << 6) | 0x1000u; }
 
 // The floating lineage starts at height h in population pf0 and moves up through the stored tree (ni internal
 // nodes, root_id its top node or the single leaf); above the root the root's own lineage is the second active
@@ -233,6 +236,7 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
     int i = 0, j = 0;
     int pf = pf0, pr = mp_pop_base(ln, ml, root_id);
     W.tfirst = -1.0;
+    W.e0 = e; W.e1 = ln.E - 1;
     if (LOG) { pl.fopen = false; pl.ropen = false; }
     // Lineages of the stored tree per population, kept up to date while the walk moves up (the restatement
     // recounts them in every interval; the numbers are the same).  Bp[id] = current population of the lineage
@@ -433,6 +437,7 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
                     ++used;
                     if (kind == 1) {
                         W.tc = t1; W.pf = pf; W.pr = pr; W.weight = weight;
+                        W.e1 = (ee + 1 < ln.E && !(t1 < ln.T[ee + 1])) ? ee + 1 : ee;       // an event placed at the end of its epoch counts in the next
                         done = true;
                         break;
                     }
@@ -479,7 +484,8 @@ __device__ __forceinline__ void mp_retag(MLane& ml, int from, int to) {
 }
 
 // Forest::buildInitialTree(true) for a structured model.  `emit(i, pstart, npieces, tc, below)` logs the record of leaf i;
-// `below` = the samples under the node leaf i creates (computed when `tmp`, n-1 doubles of per-lane LDS scratch, is given).
+// `below` = the samples under the node leaf i creates (computed when `tmp`, n-1 doubles of per-lane LDS scratch, is given;
+// otherwise the epoch span of the walk's pieces, piece_span).
 template <bool LOG, class Emit>
 __device__ __forceinline__ void mp_build_initial_tree(Lane& ln, MLane& ml, PLog& pl, Emit emit, double* tmp = nullptr) {
     const int n = ln.n;
@@ -506,10 +512,10 @@ __device__ __forceinline__ void mp_build_initial_tree(Lane& ln, MLane& ml, PLog&
         int fl = i;
         if (idx < nslots) {
             mp_slots_at(ln, ml, ni, -1, tc, W.pf, 0, 0, idx, &pr, &ps);
-            emit(i, p0, np_, tc, tmp ? (1u << i) | lane_desc_mask(ln, LC(ln, pr, ps), tmp) : 0u);
+            emit(i, p0, np_, tc, tmp ? (1u << i) | lane_desc_mask(ln, LC(ln, pr, ps), tmp) : piece_span(W.e0, W.e1));
             mp_insert_node(ln, ml, ni, tc, &fl, pr, ps, root, W.pf);
         } else {
-            emit(i, p0, np_, tc, (2u << i) - 1u);
+            emit(i, p0, np_, tc, tmp ? (2u << i) - 1u : piece_span(W.e0, W.e1));
             mp_insert_node(ln, ml, ni, tc, &fl, -1, 0, root, W.pf);
         }
         mp_retag(ml, PF_TAG_PATH, fl);
@@ -521,7 +527,8 @@ __device__ __forceinline__ void mp_build_initial_tree(Lane& ln, MLane& ml, PLog&
 // the part of a genealogy update after the recombination point (slot (rp,sb), height h) has been sampled
 template <bool LOG>
 __device__ __forceinline__ void mp_genealogy_rest(Lane& ln, MLane& ml, PLog& pl, int limit, int rp, int sb, double h,
-                                                  double* tc_out, double* sp_out, bool* changed_out, double* tfirst_out = nullptr) {
+                                                  double* tc_out, double* sp_out, bool* changed_out, double* tfirst_out = nullptr,
+                                                  unsigned* span_out = nullptr) {
     const int n = ln.n;
     MP_TICK(tg0);
     int b_id = LC(ln, rp, sb), s_id = LC(ln, rp, 1 - sb);
@@ -534,6 +541,7 @@ __device__ __forceinline__ void mp_genealogy_rest(Lane& ln, MLane& ml, PLog& pl,
     const double tc = W.tc;
     *tc_out = tc;
     if (tfirst_out) *tfirst_out = W.tfirst;
+    if (span_out) *span_out = piece_span(W.e0, W.e1);
     const double Sp = LS(ln, rp);
     *sp_out = Sp;
     *changed_out = true;

@@ -262,11 +262,12 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
                 double tfirst = 0.0;
                 MP_TICK(tu1);
                 MP_ACC(ml, 8, tu0, tu1);
-                mp_genealogy_rest<true>(ln, ml, pl, limit, rp, sb, h, &tc, &sp_removed, &changed, &tfirst);
+                unsigned span = 0;
+                mp_genealogy_rest<true>(ln, ml, pl, limit, rp, sb, h, &tc, &sp_removed, &changed, &tfirst, &span);
                 if (ln.vbc) { w_post *= ln.upd_fac; w_pilot *= ln.upd_fac; ln.upd_fac = 1.0; }
                 rec[2] = h;
                 rec[3] = piece_ref(p0, pl.idx - p0);
-                rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n, desc));
+                rec[4] = __longlong_as_double((long long)make_meta(0, mark_limit, limit, n, desc, span));
                 ++widx;
                 if (ml.err) break;
                 MP_TICK(tu2);

@@ -173,6 +173,7 @@ __device__ __forceinline__ void rmp_coalesce(RCtx& cx, const RTree<NM>& t, MRLan
 #pragma unroll
     for (int k = 0; k < NI; ++k) i += (k < ni && t.S[k] <= tt) ? 1 : 0;
     W.tfirst = -1.0;
+    W.e0 = e; W.e1 = cx.E - 1;
     if (LOG) { pl.fopen = false; pl.ropen = false; }
     // Every stretch of the walk ends at a node, at an event of the tree or at a fixed-time move, and needs the epoch of
     // its end: the nodes' epochs are searched here, all at once (independent chains of LDS reads cost one search's
@@ -360,6 +361,7 @@ __device__ __forceinline__ void rmp_coalesce(RCtx& cx, const RTree<NM>& t, MRLan
                     MP_ACC(ml, 19, cy2, cy3);
                     if (kind == 1) {
                         W.tc = t1; W.pf = pf; W.pr = pr; W.weight = weight;
+                        W.e1 = (ee + 1 < cx.E && !(t1 < cx.T[ee + 1])) ? ee + 1 : ee;
                         done = true;
                         break;
                     }
@@ -449,6 +451,7 @@ __device__ __forceinline__ void rmp_genealogy_rest(RCtx& cx, RTree<NM>& t, MRLan
     const int idx = min((int)(u * (double)k), k - 1);
     int eff = 0;
     if (idx < nslots) rmp_slots_at(t, ml, n, rp, tc, W.pf, s_id, Sp, idx, &pr, &ps, &eff);
+    if (!TREES && desc_new) *desc_new = piece_span(W.e0, W.e1);
     if (TREES) {
         unsigned dn = cut;
         if (idx < nslots) {
