@@ -201,7 +201,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--np", type=int, default=10000)
+    ap.add_argument("--np", "--particles", dest="np", type=int, default=10000,
+                    help="particles per chunk (--particles: the spelling to use behind torch.distributed.run, whose own parser trips over --np)")
     ap.add_argument("--nsam", type=int, default=4)
     ap.add_argument("--length", type=float, default=1e8)
     ap.add_argument("--epochs", type=int, default=32)
@@ -221,6 +222,9 @@ def main():
     ap.add_argument("--uncalibrated-lags", action="store_true",
                     help="the reference's uncalibrated lags 4/(rho*top_t) instead of the calibrated default of the binary")
     ap.add_argument("--debug", type=int, default=0, help="pf_params.debug bits (include/smcsmc_pf.h): 4 no counting, 8 two launches per row")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank rehearsal on a single-GPU box: every rank uses device 0 and the collectives go through gloo "
+                         "on host tensors (RCCL refuses two ranks on one device); the numbers it prints are not a scaling result")
     ap.add_argument("--chunks-per-gpu", type=int, default=1,
                     help="independent chunks filtered concurrently on each GPU (one host thread + stream each); "
                          "1 = the headline single-chunk configuration")
@@ -231,10 +235,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    cdev = "cuda"                       # where the tensors of the collectives live
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+            cdev = "cpu"
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from smcsmc_amd import ParticleFilter
     from smcsmc_amd import build as pfbuild
     from smcsmc_amd import pf as pfmod
@@ -243,7 +252,7 @@ def main():
 
     import threading
     C = max(1, args.chunks_per_gpu)
-    dev = local_rank if world > 1 else 0
+    dev = local_rank if (world > 1 and not args.rehearse_on_one_gpu) else 0
     args.device = dev
     chunks = []
     for k in range(C):
@@ -294,16 +303,16 @@ def main():
     n_seg0 = len(segs["start"])
 
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt_max = float(tmax.item())
-        segs_all = torch.tensor([float(n_segments)], dtype=torch.float64, device="cuda")
+        segs_all = torch.tensor([float(n_segments)], dtype=torch.float64, device=cdev)
         dist.all_reduce(segs_all, op=dist.ReduceOp.SUM)
         total_segments = float(segs_all.item())
         # CountModel "all-reduce": all-gather + sum in rank order (bit-identical for any arrival order)
         packed = np.concatenate([np.ravel(counts[k]) for k in sorted(counts) if isinstance(counts[k], np.ndarray)]
                                 + [[counts["delayed_opp"], counts["resample_count"], logl]])
-        mine = torch.tensor(packed, dtype=torch.float64, device="cuda")
+        mine = torch.tensor(packed, dtype=torch.float64, device=cdev)
         gathered = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
         reduced = gathered[0].clone()

@@ -52,3 +52,30 @@ def test_chunked_em_iterations(hiplib, tmp_path):
     assert iters == [0, 1]
     ll = [float(ln.split()[8]) for ln in text.splitlines()[1:] if ln.split()[4] == "LogL"]
     assert len(ll) == 2 and all(np.isfinite(ll))
+
+
+def test_bench_two_ranks_rehearsal(hiplib):
+    """bench.py's multi-rank flow (one process per rank under torch.distributed.run, barrier + MAX of the times, ordered
+    sum of the gathered statistics, one JSON line from rank 0) on this one-GPU box: both ranks on device 0, collectives
+    through gloo (--rehearse-on-one-gpu; RCCL itself is exercised by bin/smcsmc -chunks above).  The aggregate must count
+    the segments of both ranks."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "1", "--warmup", "0", "--length", "2e6", "--particles", "1000", "--no-cpu"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, cwd=root, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    j1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu"] + common,
+                         capture_output=True, text=True, cwd=root, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    lines = [ln for ln in two.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    j2 = json.loads(lines[0])
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "weak" and j2["metric"] == j1["metric"]
+    seg1 = j1["config"]["segments_per_chunk"]
+    assert j2["value"] * j2["ms_per_step"] * 1e-3 > 1.5 * seg1            # both ranks' segments are in the aggregate
+    assert np.isfinite(j2["config"]["log_likelihood_sum"]) and j2["config"]["log_likelihood_sum"] < j1["config"]["log_likelihood_sum"]
