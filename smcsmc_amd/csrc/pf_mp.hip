@@ -514,6 +514,7 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
         cx.vbc = A.vb_coal; cx.upd_fac = 1.0;
         cx.gK = BIASED ? A.g_K : 0; cx.gpos = A.g_pos; cx.grho = A.g_rho; cx.gleaf = A.g_leaf;
         cx.ridx = guided ? from.ridx[a] : 0; cx.g_rp = 0; cx.g_sb = 0;
+        ml.nep = rmp_node_epochs(cx, t);
         DStore ds;
         ds.pos = st.dpos + p; ds.fac = st.dfac + p; ds.delta = st.ddelta + p; ds.k = st.dk + p; ds.Np = A.Np;
         ds.count = 0; ds.total = 1.0;

@@ -23,6 +23,7 @@ struct MRLane {
     int nm;
     int P;
     unsigned pn, bp, sp;
+    unsigned long long nep;   // epoch of the coalescent node of rank r, six bits each (kept with the tree: no search per walk)
     const double* I2;  // [E*P]   1/(2 N_e,p)                 (LDS)
     const double* MR;  // [E*P*P] migration rates p -> q      (LDS)
     const double* MT;  // [E*P]   total emigration rate       (LDS)
@@ -45,6 +46,30 @@ __device__ __forceinline__ unsigned pk2_remove(unsigned v, int i) {
 __device__ __forceinline__ unsigned pk2_insert(unsigned v, int i, int x) {
     const unsigned low = v & ((1u << (2 * i)) - 1u);
     return low | ((unsigned)x << (2 * i)) | ((v >> (2 * i)) << (2 * i + 2));
+}
+// the same with six bits per entry (node epochs)
+__device__ __forceinline__ int pk6_get(unsigned long long v, int i) { return (int)((v >> (6 * i)) & 63ull); }
+__device__ __forceinline__ unsigned long long pk6_remove(unsigned long long v, int i) {
+    const unsigned long long low = v & ((1ull << (6 * i)) - 1ull);
+    return low | ((v >> (6 * i + 6)) << (6 * i));
+}
+__device__ __forceinline__ unsigned long long pk6_insert(unsigned long long v, int i, int x) {
+    const unsigned long long low = v & ((1ull << (6 * i)) - 1ull);
+    return low | ((unsigned long long)x << (6 * i)) | ((v >> (6 * i)) << (6 * i + 6));
+}
+// epochs of all node heights of a tree: one batch of four-way searches (independent chains of LDS reads)
+template <int NM>
+__device__ __forceinline__ unsigned long long rmp_node_epochs(const RCtx& cx, const RTree<NM>& t) {
+    constexpr int NI = RTree<NM>::NI;
+    double tv[NI];
+    int ev[NI];
+#pragma unroll
+    for (int r = 0; r < NI; ++r) tv[r] = t.S[r];
+    r_search4_batch<NI>(cx.T, tv, ev);
+    unsigned long long nep = 0;
+#pragma unroll
+    for (int r = 0; r < NI; ++r) nep |= (unsigned long long)ev[r] << (6 * r);
+    return nep;
 }
 
 // samples below the branch above child sb of rank rp (get_descendants, descendants.hpp:22-33): masks bottom-up
@@ -176,18 +201,8 @@ __device__ __forceinline__ void rmp_coalesce(RCtx& cx, const RTree<NM>& t, MRLan
     W.e0 = e; W.e1 = cx.E - 1;
     if (LOG) { pl.fopen = false; pl.ropen = false; }
     // Every stretch of the walk ends at a node, at an event of the tree or at a fixed-time move, and needs the epoch of
-    // its end: the nodes' epochs are searched here, all at once (independent chains of LDS reads cost one search's
-    // latency), events carry theirs, and the moves' come from a table.  Six bits per rank.
-    unsigned long long nep = 0;
-    {
-        double tv[NI];
-        int ev[NI];
-#pragma unroll
-        for (int r = 0; r < NI; ++r) tv[r] = t.S[r];
-        r_search4_batch<NI>(cx.T, tv, ev);
-#pragma unroll
-        for (int r = 0; r < NI; ++r) nep |= (unsigned long long)ev[r] << (6 * r);
-    }
+    // its end: the nodes' epochs travel with the tree (ml.nep), events carry theirs, the moves' come from a table.
+    const unsigned long long nep = ml.nep;
     // population of the lineage above every node id: the samples', the nodes' own, then the events up to the cut
     unsigned bp = ml.sp | (ml.pn << (2 * n));
     double nS = PF_INF, eT = PF_INF;
@@ -259,6 +274,10 @@ __device__ __forceinline__ void rmp_coalesce(RCtx& cx, const RTree<NM>& t, MRLan
     MP_ACC(ml, 2, tw0, tw1);
     constexpr int KP = 2;
     bool done = false;
+    // cumulative intensities at the start of the stretch: what the end of the last stretch computed, unless a lineage
+    // changed population or the root's lineage has just become active
+    double f0c = 0.0, f0m = 0.0, f0r = 0.0;
+    bool f_fresh = false, f_root = false;
     for (int guard = 0; guard < 4096 && !done; ++guard) {
         MP_CYC(cy_o0);
         if (nb > 1) PF_MPR_FLUSH_BUFFER();
@@ -284,10 +303,16 @@ __device__ __forceinline__ void rmp_coalesce(RCtx& cx, const RTree<NM>& t, MRLan
             const int weight = k + ((root_active && pr == pf) ? 1 : 0);
             int en = e;
             bool quiet = false;
+            if (!f_fresh || f_root != root_active) {
+                f0c = ci(pf, e, tt); f0m = cm(pf, e, tt); f0r = root_active ? cm(pr, e, tt) : 0.0;
+                f_fresh = true; f_root = root_active;
+            }
+            double f1c = 0.0, f1m = 0.0, f1r = 0.0;
             if (tn < PF_INF) {
                 en = !(nS > tn) ? nE : (!(eT > tn) ? eE : ml.EJ[e]);
-                double need = (double)weight * (ci(pf, en, tn) - ci(pf, e, tt)) + (cm(pf, en, tn) - cm(pf, e, tt));
-                if (root_active) need = need + (cm(pr, en, tn) - cm(pr, e, tt));
+                f1c = ci(pf, en, tn); f1m = cm(pf, en, tn);
+                double need = (double)weight * (f1c - f0c) + (f1m - f0m);
+                if (root_active) { f1r = cm(pr, en, tn); need = need + (f1r - f0r); }
                 if (cx.ebuf > need) { cx.ebuf -= need; quiet = true; }
             }
             MP_CYC(cy1);
@@ -296,7 +321,6 @@ __device__ __forceinline__ void rmp_coalesce(RCtx& cx, const RTree<NM>& t, MRLan
                 // the epoch of the event: the number of epoch starts of the stretch the budget still reaches (see
                 // mp_coalesce), counted four at a time with their reads in flight together
                 if (used == KP) break;
-                const double f0c = ci(pf, e, tt), f0m = cm(pf, e, tt), f0r = root_active ? cm(pr, e, tt) : 0.0;
                 const int elim = tn < PF_INF ? en : cx.E - 1;
                 int ee = e;
                 double gee = 0.0;
@@ -369,6 +393,7 @@ __device__ __forceinline__ void rmp_coalesce(RCtx& cx, const RTree<NM>& t, MRLan
                     if (kind == 2) pf = to; else pr = to;
                     tt = t1;
                     e = ee;
+                    f_fresh = false;
                     continue;
                 }
             }
@@ -377,15 +402,16 @@ __device__ __forceinline__ void rmp_coalesce(RCtx& cx, const RTree<NM>& t, MRLan
             const bool at_join = !(tn < tj);
             tt = tn;
             e = en;
+            f0c = f1c; f0m = f1m; f0r = f1r;              // ci(pf, en, tn) is ci(pf, e, tt) of the next stretch
             advance(tt);
             MP_CYC(cy5);
             MP_ACC(ml, 20, cy4, cy5);
             if (at_join) {
                 int q = ml.JM[e * P + pf];
-                if (q != pf) { PF_MPR_BUF_PUSH(tt, PF_TAG_PATH, mp_ev_byte(q, e)); pf = q; }
+                if (q != pf) { PF_MPR_BUF_PUSH(tt, PF_TAG_PATH, mp_ev_byte(q, e)); pf = q; f_fresh = false; }
                 if (tt >= Hr) {
                     int qr = ml.JM[e * P + pr];
-                    if (qr != pr) { PF_MPR_BUF_PUSH(tt, PF_TAG_RPATH, mp_ev_byte(qr, e)); pr = qr; }
+                    if (qr != pr) { PF_MPR_BUF_PUSH(tt, PF_TAG_RPATH, mp_ev_byte(qr, e)); pr = qr; f_fresh = false; }
                 }
             }
             if (ml.err) { ml.bp = bp; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
@@ -471,6 +497,8 @@ __device__ __forceinline__ void rmp_genealogy_rest(RCtx& cx, RTree<NM>& t, MRLan
     const int b0 = b_id, s0 = s_id;
     const bool into_stub = !(idx < nslots) && !(has_root && idx == nslots);
     ml.pn = pk2_remove(ml.pn, rp);
+    const int p_epoch = pk6_get(ml.nep, rp);
+    ml.nep = pk6_remove(ml.nep, rp);
     r_remove_rank(t, n, n - 1, rp, s_id, &b_id, &s_id);
     const int ni = n - 2;
     const int troot = p_was_root ? s0 : n + (ni - 1);
@@ -536,6 +564,7 @@ __device__ __forceinline__ void rmp_genealogy_rest(RCtx& cx, RTree<NM>& t, MRLan
         ml.nm = o;
     }
     ml.pn = pk2_insert(ml.pn, rn, pop_ins);
+    ml.nep = pk6_insert(ml.nep, rn, into_stub ? p_epoch : W.e1);
     r_insert_node(t, n, ni, h_ins, b0, pr_ins, ps_ins, troot);
     MP_TICK(tg4);
     MP_ACC(ml, 6, tg3, tg4);
