@@ -84,7 +84,10 @@ typedef struct pf_params {
     int64_t gen_cap;             /* resampling generations kept by the ancestor ledger (default 8192; -arg 131072) */
     int64_t piece_cap;           /* structured models: coal/migr opportunity pieces per slot (default 4*log_cap) */
     int32_t debug;               /* testing switches: PF_DEBUG_* below */
-    int32_t reserved;
+    int32_t mig_cap;             /* structured models: migration events kept per local tree (the reference's node list is
+                                  * unbounded); 0 = 96.  The lists live in LDS next to the epoch tables: about 230 fit with
+                                  * 32 epochs and two populations, pf_create says when a value does not.  One too many on
+                                  * any tree is a reported error ("too many migration events on one local tree"). */
 } pf_params;
 #define PF_DEBUG_FORCE_LDS 1     /* run the LDS-tree kernels whatever nsam is */
 #define PF_DEBUG_NO_FUSE   2     /* complete every row with the stand-alone k_resample (two-stream pipeline) */

@@ -55,7 +55,8 @@ namespace smco {
 static thread_local std::string g_err;
 
 enum { NMAX = 16 };
-enum { MMAX = 96 };   /* migration events kept per local tree (multi-population models) */
+enum { MMAX = 256 };  /* storage for migration events per local tree (multi-population models); the limit in force is
+                       * Filter::mig_cap (smco_params.mig_cap, default 96, as pf_params.mig_cap of the device path) */
 enum { DCAP = 32 };   /* capacity of the per-particle delayed-factor store (the reference's heap is unbounded) */
 enum { REC_RECOMB = 1, REC_COALMIGR = 2 };
 
@@ -318,6 +319,7 @@ struct Filter {
     void apply_vb(Particle& p) { if (!M.vb_coal.empty()) { p.w_post *= upd_fac; p.w_pilot *= upd_fac; } upd_fac = 1.0; }
     double last_iw = 1.0, last_tc = 0.0, last_first_event = 0.0;
     bool record_trees = false;      /* -arg (pfparam.cpp:353-357) */
+    int mig_cap = 96;               /* migration events a local tree may hold (capacity of the device path) */
     void push_tree_event(Particle& p, int kind, double x, double t, uint32_t desc, int from_pop = -1, int to_pop = -1) {
         auto ev = std::make_shared<TreeEv>();
         ev->kind = kind; ev->x = x; ev->t = t; ev->desc = desc; ev->parent = p.tree_head;
@@ -486,7 +488,7 @@ struct Filter {
         return cnt;
     }
     void ev_insert(Tree& t, double time, int branch, int newpop) const {
-        if (t.nm >= MMAX) throw std::runtime_error("too many migration events on one local tree");
+        if (t.nm >= mig_cap) throw std::runtime_error("too many migration events on one local tree");
         int m = t.nm;
         while (m > 0 && t.Mt[m - 1] > time) {
             t.Mt[m] = t.Mt[m - 1]; t.Mb[m] = t.Mb[m - 1]; t.Mq[m] = t.Mq[m - 1];
@@ -1960,6 +1962,8 @@ void* smco_create(const smco_model* m, const smco_params* p) {
         Filter* f = new Filter();
         Model& M = f->M;
         fill_model(M, m);
+        if (p->mig_cap > MMAX) throw std::runtime_error("oracle: mig_cap above the storage of the restatement");
+        if (p->mig_cap > 0) f->mig_cap = p->mig_cap;
         M.recflags.assign(m->record_flags, m->record_flags + M.E);
         M.lags.assign(m->lags, m->lags + M.E);
         if (m->n_bias_heights > 0) {

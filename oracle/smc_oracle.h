@@ -68,7 +68,8 @@ typedef struct smco_params {
     double ess_fraction;         /* -ESS (pfparam.cpp:323) */
     uint64_t seed;
     int32_t max_trace_events;    /* number of resampling events whose ancestor arrays are kept */
-    int32_t reserved;
+    int32_t mig_cap;             /* migration events a local tree may hold before the run stops (0 = 96; at most 256):
+                                  * the capacity of the device path, pf_params.mig_cap */
 } smco_params;
 
 typedef struct smco_segments {

@@ -2787,7 +2787,9 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     const int P = m->n_pops;
     h->E = E; h->n = n; h->Np = Np; h->P = P;
     h->nblocks = (int)((Np + PF_BS - 1) / PF_BS);
-    h->smem = P > 1 ? pf_mp_smem_bytes(n, E, P) : smem_bytes(n, E);
+    const int mcap = p->mig_cap > 0 ? p->mig_cap : PF_MMAX;
+    if (mcap > 4096) { delete h; return fail("pf_create: mig_cap out of range"); }
+    h->smem = P > 1 ? pf_mp_smem_bytes(n, E, P, mcap) : smem_bytes(n, E);
     h->max_trace_events = std::max(0, p->max_trace_events);
     if (p->flags & 2) {
         // -arg: the parent table of every resampling is kept (it is the ancestry the tree dump walks back through)
@@ -2810,6 +2812,7 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     A.E = E; A.n = n; A.flags = m->flags;
     A.L = m->loci_length; A.mu = m->mutation_rate; A.rho = m->recombination_rate;
     A.Np = Np;
+    A.mcap = mcap;
     A.ess_threshold = (double)Np * p->ess_fraction;
     A.seed = p->seed;
     int rc = 0;
@@ -2878,9 +2881,9 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
         if (P > 1) {
             rc |= dalloc(h, &st.Pn, K * (size_t)(n - 1) * Np);
             rc |= dalloc(h, &st.nm, K * Np);
-            rc |= dalloc(h, &st.Mt, K * (size_t)PF_MMAX * Np);
-            rc |= dalloc(h, &st.Mb, K * (size_t)PF_MMAX * Np);
-            rc |= dalloc(h, &st.Mq, K * (size_t)PF_MMAX * Np);
+            rc |= dalloc(h, &st.Mt, K * (size_t)A.mcap * Np);
+            rc |= dalloc(h, &st.Mb, K * (size_t)A.mcap * Np);
+            rc |= dalloc(h, &st.Mq, K * (size_t)A.mcap * Np);
         }
         if (m->n_rate_segments > 0) rc |= dalloc(h, &st.ridx, K * Np);
         if (m->n_bias_heights > 0 || m->n_rate_segments > 0) {
@@ -2971,9 +2974,14 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
         hipFuncSetAttribute((const void*)k_extend, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem);
         hipFuncSetAttribute((const void*)k_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem);
     }
-    if (h->smem > 160 * 1024 || (P > 1 && pf_mp_prepare(h->smem))) {
+    // structured models: the LDS-tree kernels serve the prior tree and calibration for every n, the row kernel is the
+    // register-tree one for n <= 8
+    const bool lds_rows = P > 1 && (n > 8 || h->force_lds);
+    if (h->smem > 160 * 1024 || (P > 1 && pf_mp_prepare(h->smem, A.mcap)) ||
+        (P > 1 && !lds_rows && pf_mp_reg_smem_bytes(E, P, A.mcap) > 160 * 1024)) {
         pf_destroy(h);
-        return fail("pf_create: the local-tree state does not fit the LDS of one workgroup");
+        return fail(P > 1 ? "pf_create: the local-tree state (tree, epoch tables and pf_params.mig_cap migration events per lane) does not fit the LDS of one workgroup"
+                          : "pf_create: the local-tree state does not fit the LDS of one workgroup");
     }
     return h;
 }
@@ -3565,8 +3573,9 @@ int pf_get_migrations(pf_handle* h, int32_t* n_events, double* times, int8_t* br
     const int n = h->n;
     std::vector<int> nm(Np);
     HIPCHK(hipMemcpy(nm.data(), st.nm, Np * 4, hipMemcpyDeviceToHost));
-    std::vector<double> mt((size_t)PF_MMAX * Np);
-    std::vector<int8_t> mb((size_t)PF_MMAX * Np), mq((size_t)PF_MMAX * Np), pn((size_t)(n - 1) * Np);
+    const int mcap = h->A.mcap;
+    std::vector<double> mt((size_t)mcap * Np);
+    std::vector<int8_t> mb((size_t)mcap * Np), mq((size_t)mcap * Np), pn((size_t)(n - 1) * Np);
     HIPCHK(hipMemcpy(mt.data(), st.Mt, mt.size() * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(mb.data(), st.Mb, mb.size(), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(mq.data(), st.Mq, mq.size(), hipMemcpyDeviceToHost));
@@ -3574,7 +3583,7 @@ int pf_get_migrations(pf_handle* h, int32_t* n_events, double* times, int8_t* br
     for (long long p = 0; p < Np; ++p) {
         if (n_events) n_events[p] = nm[p];
         for (int k = 0; k < cap; ++k) {
-            bool ok = k < nm[p] && k < PF_MMAX;
+            bool ok = k < nm[p] && k < mcap;
             if (times) times[p * cap + k] = ok ? mt[(size_t)k * Np + p] : 0.0;
             if (branch) branch[p * cap + k] = ok ? mb[(size_t)k * Np + p] : 0;
             if (newpop) newpop[p * cap + k] = ok ? (mq[(size_t)k * Np + p] & 3) : 0;      // the upper bits hold the event's epoch
@@ -4023,7 +4032,7 @@ int pf_terminal_branch_quantiles(const pf_model* m, uint64_t seed, int64_t n_tre
     const int E = m->n_epochs, n = m->nsam, P = m->n_pops;
     KArgs A;
     memset(&A, 0, sizeof(A));
-    A.E = E; A.n = n; A.P = P; A.L = m->loci_length; A.mu = m->mutation_rate; A.rho = m->recombination_rate;
+    A.E = E; A.n = n; A.P = P; A.L = m->loci_length; A.mu = m->mutation_rate; A.rho = m->recombination_rate; A.mcap = PF_MMAX;
     double *dT, *dI, *dh, *dl; int *dRF, *derr;
     std::vector<void*> mp_allocs;
     HIPCHK(hipMalloc(&dT, E * 8)); HIPCHK(hipMalloc(&dI, E * 8)); HIPCHK(hipMalloc(&dRF, E * 4)); HIPCHK(hipMalloc(&derr, 4));
@@ -4046,8 +4055,8 @@ int pf_terminal_branch_quantiles(const pf_model* m, uint64_t seed, int64_t n_tre
     if (P > 1) {
         MpTables tb;
         if (build_mp_tables(m, tb) || upload_mp_tables(tb, A, mp_allocs)) return -1;
-        const size_t smem = pf_mp_smem_bytes(n, E, P);
-        if (pf_mp_prepare(smem)) { g_err = "pf_terminal_branch_quantiles: the local-tree state does not fit the LDS"; return -1; }
+        const size_t smem = pf_mp_smem_bytes(n, E, P, PF_MMAX);
+        if (pf_mp_prepare(smem, PF_MMAX)) { g_err = "pf_terminal_branch_quantiles: the local-tree state does not fit the LDS"; return -1; }
         pf_mp_launch_tbl(A, (unsigned long long)seed, (long long)n_trees, dh, dl, derr, smem, 0);
     } else {
         const size_t smem = smem_bytes(n, E);
@@ -4094,7 +4103,7 @@ int pf_median_survival(const pf_model* m, uint64_t seed, int32_t min_events, int
     const int E = m->n_epochs, n = m->nsam, P = m->n_pops;
     KArgs A;
     memset(&A, 0, sizeof(A));
-    A.E = E; A.n = n; A.P = P; A.L = m->loci_length; A.mu = m->mutation_rate; A.rho = m->recombination_rate;
+    A.E = E; A.n = n; A.P = P; A.L = m->loci_length; A.mu = m->mutation_rate; A.rho = m->recombination_rate; A.mcap = PF_MMAX;
     double *dT, *dI; int *dRF, *dep, *derr; double* ddist;
     std::vector<void*> mp_allocs;
     HIPCHK(hipMalloc(&dT, E * 8)); HIPCHK(hipMalloc(&dI, E * 8)); HIPCHK(hipMalloc(&dRF, E * 4)); HIPCHK(hipMalloc(&derr, 4));
@@ -4126,8 +4135,8 @@ int pf_median_survival(const pf_model* m, uint64_t seed, int32_t min_events, int
     std::vector<int> hep(PF_CAL_GROUP * per_batch);
     std::vector<double> hdist(PF_CAL_GROUP * per_batch);
     long long trees = 0;
-    const size_t smem = P > 1 ? pf_mp_smem_bytes(n, E, P) : smem_bytes(n, E);
-    if (P > 1 && pf_mp_prepare(smem)) { g_err = "pf_median_survival: the local-tree state does not fit the LDS"; return -1; }
+    const size_t smem = P > 1 ? pf_mp_smem_bytes(n, E, P, PF_MMAX) : smem_bytes(n, E);
+    if (P > 1 && pf_mp_prepare(smem, PF_MMAX)) { g_err = "pf_median_survival: the local-tree state does not fit the LDS"; return -1; }
     const size_t smem_cal = smem + (size_t)(2 * PF_EPAD + E) * 8;          // + the padded epoch tables of the register path
     if (P == 1 && smem_cal > 64 * 1024) {
         hipFuncSetAttribute((const void*)k_calibrate<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_cal);

@@ -47,6 +47,7 @@ struct MLane {
     int8_t* Mq;        // &sMq[tid]
     int8_t* Bp;        // &sBp[tid]   scratch of the walk: current population of the lineage above every node id
     int nm;
+    int mcap;          // capacity of the event list (KArgs::mcap)
     int P;
     const double* I2;  // [E*P]   1/(2 N_e,p)                 (LDS)
     const double* MR;  // [E*P*P] migration rates p -> q      (LDS)
@@ -131,7 +132,7 @@ __device__ __forceinline__ int mp_lineages_in_pop(const Lane& ln, const MLane& m
 __device__ __forceinline__ int mp_ev_byte(int pop, int epoch) { return pop | (epoch << 2); }
 template <class ML>
 __device__ __forceinline__ void mp_ev_insert(ML& ml, double time, int branch, int newpop) {
-    if (ml.nm >= PF_MMAX) { ml.err = 1; return; }
+    if (ml.nm >= ml.mcap) { ml.err = 1; return; }
     int m = ml.nm;
     while (m > 0 && LMt(ml, m - 1) > time) {
         LMt(ml, m) = LMt(ml, m - 1); LMb(ml, m) = LMb(ml, m - 1); LMq(ml, m) = LMq(ml, m - 1);

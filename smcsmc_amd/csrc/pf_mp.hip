@@ -17,14 +17,14 @@
 // ------------------------------------------------------------------ structured models (P > 1): LDS-tree kernels
 // Same structure as k_init / k_extend / k_calibrate with the migration-aware genealogy update of pf_mp.h.
 struct SmemMP { double* I2; double* MR; double* MT; double* CI; double* CM; double* TJ; double* Mt; int* JM; int* SP; int8_t* Pn; int8_t* Mb; int8_t* Mq; int8_t* Bp; };
-__host__ __device__ static size_t smem_mp_extra(int n, int E, int P) {
-    size_t dbl = (size_t)E * P * 4 + (size_t)E + (size_t)E * P * P + (size_t)PF_MMAX * PF_BS;
+__host__ __device__ static size_t smem_mp_extra(int n, int E, int P, int mcap) {
+    size_t dbl = (size_t)E * P * 4 + (size_t)E + (size_t)E * P * P + (size_t)mcap * PF_BS;
     size_t ints = (size_t)E * P + (size_t)((n + 1) & ~1) + (size_t)((E * P) & 1);
-    size_t bytes = (size_t)(n - 1) * PF_BS + (size_t)2 * PF_MMAX * PF_BS + (size_t)2 * n * PF_BS;
+    size_t bytes = (size_t)(n - 1) * PF_BS + (size_t)2 * mcap * PF_BS + (size_t)2 * n * PF_BS;
     return dbl * 8 + ints * 4 + bytes;
 }
-static size_t smem_bytes_mp(int n, int E, int P) { return smem_bytes(n, E) + smem_mp_extra(n, E, P); }
-__device__ __forceinline__ SmemMP carve_mp(double* base, int n, int E, int P) {
+static size_t smem_bytes_mp(int n, int E, int P, int mcap) { return smem_bytes(n, E) + smem_mp_extra(n, E, P, mcap); }
+__device__ __forceinline__ SmemMP carve_mp(double* base, int n, int E, int P, int mcap) {
     SmemMP m;
     m.I2 = (double*)((char*)base + smem_bytes(n, E));
     m.MR = m.I2 + (size_t)E * P;
@@ -33,12 +33,12 @@ __device__ __forceinline__ SmemMP carve_mp(double* base, int n, int E, int P) {
     m.CM = m.CI + (size_t)E * P;
     m.TJ = m.CM + (size_t)E * P;
     m.Mt = m.TJ + (size_t)E;
-    m.JM = (int*)(m.Mt + (size_t)PF_MMAX * PF_BS);
+    m.JM = (int*)(m.Mt + (size_t)mcap * PF_BS);
     m.SP = m.JM + (size_t)E * P + ((E * P) & 1);
     m.Pn = (int8_t*)(m.SP + ((n + 1) & ~1));
     m.Mb = m.Pn + (size_t)(n - 1) * PF_BS;
-    m.Mq = m.Mb + (size_t)PF_MMAX * PF_BS;
-    m.Bp = m.Mq + (size_t)PF_MMAX * PF_BS;
+    m.Mq = m.Mb + (size_t)mcap * PF_BS;
+    m.Bp = m.Mq + (size_t)mcap * PF_BS;
     return m;
 }
 __device__ __forceinline__ void load_model_mp(const KArgs& A, SmemMP& m) {
@@ -51,7 +51,7 @@ __device__ __forceinline__ void load_model_mp(const KArgs& A, SmemMP& m) {
 __device__ __forceinline__ MLane make_mlane(const KArgs& A, SmemMP& m) {
     MLane ml;
     ml.Pn = m.Pn + threadIdx.x; ml.Mt = m.Mt + threadIdx.x; ml.Mb = m.Mb + threadIdx.x; ml.Mq = m.Mq + threadIdx.x; ml.Bp = m.Bp + threadIdx.x;
-    ml.nm = 0; ml.P = A.P;
+    ml.nm = 0; ml.P = A.P; ml.mcap = A.mcap;
     ml.I2 = m.I2; ml.MR = m.MR; ml.MT = m.MT; ml.CI = m.CI; ml.CM = m.CM; ml.TJ = m.TJ; ml.JM = m.JM; ml.SP = m.SP; ml.vbm = A.vb_mig;
     ml.err = 0;
     return ml;
@@ -78,7 +78,7 @@ __device__ __forceinline__ void store_mp_state(const KArgs& A, const DState& st,
 __global__ __launch_bounds__(PF_BS) void k_init_mp(KArgs A, double initial_position) {
     extern __shared__ double smem[];
     Smem m = carve(smem, A.n, A.E);
-    SmemMP mm = carve_mp(smem, A.n, A.E, A.P);
+    SmemMP mm = carve_mp(smem, A.n, A.E, A.P, A.mcap);
     load_model(A, m);
     load_model_mp(A, mm);
     __syncthreads();
@@ -141,7 +141,7 @@ template <bool BIASED>
 __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
     extern __shared__ double smem[];
     Smem m = carve(smem, A.n, A.E);
-    SmemMP mm = carve_mp(smem, A.n, A.E, A.P);
+    SmemMP mm = carve_mp(smem, A.n, A.E, A.P, A.mcap);
     load_model(A, m);
     load_model_mp(A, mm);
     __shared__ double sBH[PF_BIAS_MAX + 2], sBS[PF_BIAS_MAX + 1];      // focused sampling: band boundaries / strengths
@@ -408,19 +408,19 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
 #define PF_MPR_LANES 32      // particles per wavefront of the register-tree row kernel (see k_extend_mpr)
 #endif
 struct SmemMPR { double* T; double* TJ; double* I2; double* MT; double* CI; double* CM; double* MR; double* Mt; int* JM; int* EJ; int8_t* Mb; int8_t* Mq; };
-__host__ __device__ static size_t smem_mpr_bytes(int E, int P) {
+__host__ __device__ static size_t smem_mpr_bytes(int E, int P, int mcap) {
     const size_t EP = (size_t)E * P;
-    return ((size_t)2 * PF_EPAD + 4 * EP + EP * P + (size_t)PF_MMAX * PF_BS) * 8 + (((EP + 1) & ~(size_t)1) + PF_EPAD) * 4 + (size_t)2 * PF_MMAX * PF_BS;
+    return ((size_t)2 * PF_EPAD + 4 * EP + EP * P + (size_t)mcap * PF_BS) * 8 + (((EP + 1) & ~(size_t)1) + PF_EPAD) * 4 + (size_t)2 * mcap * PF_BS;
 }
-__device__ __forceinline__ SmemMPR carve_mpr(double* base, int E, int P) {
+__device__ __forceinline__ SmemMPR carve_mpr(double* base, int E, int P, int mcap) {
     const size_t EP = (size_t)E * P;
     SmemMPR m;
     m.T = base; m.TJ = m.T + PF_EPAD; m.I2 = m.TJ + PF_EPAD; m.MT = m.I2 + EP; m.CI = m.MT + EP; m.CM = m.CI + EP;
     m.MR = m.CM + EP; m.Mt = m.MR + EP * P;
-    m.JM = (int*)(m.Mt + (size_t)PF_MMAX * PF_BS);
+    m.JM = (int*)(m.Mt + (size_t)mcap * PF_BS);
     m.EJ = m.JM + ((EP + 1) & ~(size_t)1);
     m.Mb = (int8_t*)(m.EJ + PF_EPAD);
-    m.Mq = m.Mb + (size_t)PF_MMAX * PF_BS;
+    m.Mq = m.Mb + (size_t)mcap * PF_BS;
     return m;
 }
 
@@ -436,7 +436,7 @@ template <int NM, bool BIASED, int LA, bool TREES>
 __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long long s, int fuse) {
     constexpr int NI = RTree<NM>::NI;
     extern __shared__ double smem[];
-    SmemMPR mm = carve_mpr(smem, A.E, A.P);
+    SmemMPR mm = carve_mpr(smem, A.E, A.P, A.mcap);
     {
         const int EP = A.E * A.P;
         for (int i = threadIdx.x; i < PF_EPAD; i += blockDim.x) {
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
         RTree<NM> t;
         MRLane ml;
         ml.Mt = mm.Mt + cslot; ml.Mb = mm.Mb + cslot; ml.Mq = mm.Mq + cslot;
-        ml.P = A.P; ml.I2 = mm.I2; ml.MR = mm.MR; ml.MT = mm.MT; ml.CI = mm.CI; ml.CM = mm.CM; ml.TJ = mm.TJ; ml.JM = mm.JM; ml.EJ = mm.EJ;
+        ml.P = A.P; ml.mcap = A.mcap; ml.I2 = mm.I2; ml.MR = mm.MR; ml.MT = mm.MT; ml.CI = mm.CI; ml.CM = mm.CM; ml.TJ = mm.TJ; ml.JM = mm.JM; ml.EJ = mm.EJ;
         ml.vbm = A.vb_mig; ml.err = 0; ml.pn = 0; ml.bp = 0; ml.sp = 0;
         for (int i = 0; i < n; ++i) ml.sp |= (unsigned)A.sample_pop[i] << (2 * i);
 #pragma unroll
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(PF_BS) void k_calibrate_mp(KArgs A, unsigned long l
                                                         int* out_epoch, double* out_dist, int* out_err) {
     extern __shared__ double smem[];
     Smem m = carve(smem, A.n, A.E);
-    SmemMP mm = carve_mp(smem, A.n, A.E, A.P);
+    SmemMP mm = carve_mp(smem, A.n, A.E, A.P, A.mcap);
     load_model(A, m);
     load_model_mp(A, mm);
     __syncthreads();
@@ -860,7 +860,7 @@ __global__ __launch_bounds__(PF_BS) void k_tbl_mp(KArgs A, unsigned long long se
                                                   double* out_len /* [nrep] */, int* out_err) {
     extern __shared__ double smem[];
     Smem m = carve(smem, A.n, A.E);
-    SmemMP mm = carve_mp(smem, A.n, A.E, A.P);
+    SmemMP mm = carve_mp(smem, A.n, A.E, A.P, A.mcap);
     load_model(A, m);
     load_model_mp(A, mm);
     __syncthreads();
@@ -886,13 +886,14 @@ __global__ __launch_bounds__(PF_BS) void k_tbl_mp(KArgs A, unsigned long long se
 }
 
 // ------------------------------------------------------------------ launchers (called from pf_hip.hip)
-size_t pf_mp_smem_bytes(int n, int E, int P) { return smem_bytes_mp(n, E, P); }
+size_t pf_mp_smem_bytes(int n, int E, int P, int mcap) { return smem_bytes_mp(n, E, P, mcap); }
 
-int pf_mp_prepare(size_t smem) {
+int pf_mp_prepare(size_t smem, int mcap) {
     if (smem > 160 * 1024) return -1;
     {
         // the register-tree row kernels: their LDS does not depend on n (tables at their largest size here)
-        const int big = (int)smem_mpr_bytes(PF_EMAX, PF_PMAX);
+        const size_t big_sz = smem_mpr_bytes(PF_EMAX, PF_PMAX, mcap);
+        const int big = (int)(big_sz < 160 * 1024 ? big_sz : 160 * 1024);
         if (hipFuncSetAttribute((const void*)k_extend_mpr<8, false, PF_MPR_LANES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) return -1;
         if (hipFuncSetAttribute((const void*)k_extend_mpr<8, true, PF_MPR_LANES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) return -1;
         if (hipFuncSetAttribute((const void*)k_extend_mpr<8, false, PF_MPR_LANES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) return -1;
@@ -912,9 +913,10 @@ void pf_mp_launch_init(const KArgs& A, double initial_position, size_t smem, hip
     hipLaunchKernelGGL(k_init_mp, dim3(mp_blocks(A.Np)), dim3(PF_BS), smem, st, A, initial_position);
 }
 bool pf_mp_can_fuse(const KArgs& A, bool lds_tree) { return !lds_tree && A.n <= 8; }
+size_t pf_mp_reg_smem_bytes(int E, int P, int mcap) { return smem_mpr_bytes(E, P, mcap); }
 void pf_mp_launch_extend(const KArgs& A, long long s, size_t smem, hipStream_t st, bool lds_tree, int fuse) {
     if (!lds_tree && A.n <= 8) {
-        const size_t sm = smem_mpr_bytes(A.E, A.P);
+        const size_t sm = smem_mpr_bytes(A.E, A.P, A.mcap);
         const dim3 grid(mp_blocks(A.Np)), blk(64 * (64 / PF_MPR_LANES));
         const bool biased = A.n_bias > 0 || A.g_K > 0;
         if (biased && A.rec_trees) hipLaunchKernelGGL((k_extend_mpr<8, true, PF_MPR_LANES, true>), grid, blk, sm, st, A, s, fuse);

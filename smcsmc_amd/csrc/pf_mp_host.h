@@ -7,8 +7,9 @@
 #define PF_PMAX 4             // populations supported by the HIP path
 #define PF_MMAX 96            // migration events kept per local tree
 
-size_t pf_mp_smem_bytes(int n, int E, int P);
-int pf_mp_prepare(size_t smem);      // raises the dynamic-LDS limit of the kernels; -1 if the state does not fit
+size_t pf_mp_smem_bytes(int n, int E, int P, int mcap);       // LDS-tree kernels
+size_t pf_mp_reg_smem_bytes(int E, int P, int mcap);          // register-tree row kernel
+int pf_mp_prepare(size_t smem, int mcap);      // raises the dynamic-LDS limit of the kernels; -1 if the state does not fit
 void pf_mp_launch_init(const KArgs& A, double initial_position, size_t smem, hipStream_t st);
 // lds_tree: use the LDS-tree kernel whatever the sample size (n > 8 always does)
 // fuse (register-tree kernel only, pf_mp_can_fuse): complete the previous row (k_resample's part) while loading

@@ -21,6 +21,7 @@ struct MRLane {
     int8_t* Mb;        // &sMb[tid]   ... branch (node id below it, or a PF_TAG_* while an update is in flight)
     int8_t* Mq;        // &sMq[tid]   ... population the lineage moves to
     int nm;
+    int mcap;          // capacity of the event list (KArgs::mcap)
     int P;
     unsigned pn, bp, sp;
     unsigned long long nep;   // epoch of the coalescent node of rank r, six bits each (kept with the tree: no search per walk)

@@ -7,7 +7,6 @@
 
 #define PF_EMAX 64
 #define PF_STAMP_W 32        // profiling builds: words per wavefront and row in KArgs::stamps
-#define PF_MMAX_SLOT 96       // = PF_MMAX of pf_mp.h: migration events per local tree (stride of the per-event state arrays)
 #define PF_DCAP 32            // pending delayed factors per particle (the reference's heap is unbounded)
 #define PF_BIAS_MAX 8         // interior bias heights
 #define PF_DECIDE_TAB 16384   // offspring / parent tables fit LDS (16-bit entries) up to this many particles
@@ -37,9 +36,9 @@ struct DState {
     // structured models (pf_mp.h); allocated only when P > 1
     int8_t* Pn;              // [(n-1)][Np] population of every coalescent node
     int* nm;                 // [Np] migration events on the local tree
-    double* Mt;              // [PF_MMAX][Np]
-    int8_t* Mb;              // [PF_MMAX][Np]
-    int8_t* Mq;              // [PF_MMAX][Np]
+    double* Mt;              // [mcap][Np]
+    int8_t* Mb;              // [mcap][Np]
+    int8_t* Mq;              // [mcap][Np]
 };
 
 struct Ctrl {
@@ -105,6 +104,7 @@ struct KArgs {
     const double* cum_mig;         // [E*P] cumulative emigration intensity per population at the epoch starts
     const double* next_join;       // [E]   start of the next epoch with a fixed-time population move
     const int* next_join_epoch;    // [E]   that epoch (E if none)
+    int mcap;                      // migration events kept per local tree (pf_params.mig_cap, default PF_MMAX)
     const int* sample_pop;         // [n]
     double* plog;                  // coal/migr opportunity pieces: plog[(p*pcap + k%pcap)*3 .. +3)
     unsigned pcap;
@@ -229,7 +229,7 @@ __host__ __device__ inline DState state_slot(const KArgs& A, int k) {
     d.dpos += K * PF_DCAP * Np; d.dfac += K * PF_DCAP * Np; d.ddelta += K * PF_DCAP * Np; d.dk += K * PF_DCAP * Np;
     d.ridx += K * Np; d.lookahead += K * Np;
     d.Pn += K * n1 * Np; d.nm += K * Np;
-    d.Mt += K * PF_MMAX_SLOT * Np; d.Mb += K * PF_MMAX_SLOT * Np; d.Mq += K * PF_MMAX_SLOT * Np;
+    d.Mt += K * (size_t)A.mcap * Np; d.Mb += K * (size_t)A.mcap * Np; d.Mq += K * (size_t)A.mcap * Np;
     return d;
 }
 

@@ -49,7 +49,7 @@ class _Params(C.Structure):
     _fields_ = [("np", C.c_int64), ("ess_fraction", C.c_double), ("seed", C.c_uint64),
                 ("max_trace_events", C.c_int32), ("flags", C.c_int32),
                 ("log_cap", C.c_int64), ("gen_cap", C.c_int64), ("piece_cap", C.c_int64),
-                ("debug", C.c_int32), ("reserved", C.c_int32)]
+                ("debug", C.c_int32), ("mig_cap", C.c_int32)]
 
 
 DEBUG_FORCE_LDS, DEBUG_NO_FUSE, DEBUG_NO_COUNT, DEBUG_TWO_LAUNCH = 1, 2, 4, 8
@@ -249,7 +249,7 @@ KERNEL_CLASSES = ("extend", "decide", "count", "resample")
 
 class ParticleFilter:
     def __init__(self, model, np_particles, ess_fraction=0.5, seed=1, max_trace_events=64, device=0, local_recomb=False,
-                 record_trees=False, log_cap=0, gen_cap=0, piece_cap=0, debug=0):
+                 record_trees=False, log_cap=0, gen_cap=0, piece_cap=0, debug=0, mig_cap=0):
         self.L = load_library()
         m = model
         self._ct = np.ascontiguousarray(m["change_times"], dtype=np.float64)
@@ -269,7 +269,8 @@ class ParticleFilter:
         self.loci_length = float(m["loci_length"])
         self._params = _Params(self.Np, float(ess_fraction), int(seed), self.max_trace_events,
                                (1 if local_recomb else 0) | (2 if record_trees else 0),
-                               int(log_cap), int(gen_cap), int(piece_cap), int(debug), 0)
+                               int(log_cap), int(gen_cap), int(piece_cap), int(debug), int(mig_cap))
+        self.mig_cap = int(mig_cap) if mig_cap else 96
         self.h = self.L.pf_create(C.byref(self._model), C.byref(self._params), int(device))
         if not self.h:
             raise PfError(_err(self.L))
@@ -388,9 +389,10 @@ class ParticleFilter:
             return int(part.value), kind, pos, hgt, desc, fr, to
         return int(part.value), kind, pos, hgt, desc
 
-    def migrations(self, cap=96):
+    def migrations(self, cap=None):
         """Migration events on every particle's local tree and the population of every coalescent node."""
         n = self.nsam
+        cap = self.mig_cap if cap is None else cap
         nm = np.zeros(self.Np, np.int32); t = np.zeros((self.Np, cap)); b = np.zeros((self.Np, cap), np.int8)
         q = np.zeros((self.Np, cap), np.int8); npop = np.zeros((self.Np, n - 1), np.int8)
         self._chk(self.L.pf_get_migrations(self.h, nm.ctypes.data, t.ctypes.data, b.ctypes.data, q.ctypes.data,

@@ -34,7 +34,7 @@ class Model(C.Structure):
 
 class Params(C.Structure):
     _fields_ = [("np", C.c_int64), ("ess_fraction", C.c_double), ("seed", C.c_uint64),
-                ("max_trace_events", C.c_int32), ("reserved", C.c_int32)]
+                ("max_trace_events", C.c_int32), ("mig_cap", C.c_int32)]
 
 
 class Segments(C.Structure):
@@ -188,11 +188,12 @@ class PackedInputs:
 
 
 class Oracle:
-    def __init__(self, model, np_particles, ess_fraction=0.5, seed=1, max_trace_events=64):
+    def __init__(self, model, np_particles, ess_fraction=0.5, seed=1, max_trace_events=64, mig_cap=0):
         self.L = lib()
         self.inp = PackedInputs(model, None)
         self.Np = int(np_particles)
-        self.params = Params(self.Np, float(ess_fraction), int(seed), int(max_trace_events), 0)
+        self.params = Params(self.Np, float(ess_fraction), int(seed), int(max_trace_events), int(mig_cap))
+        self.mig_cap = int(mig_cap) if mig_cap else 96
         self.h = self.L.smco_create(C.byref(self.inp.model), C.byref(self.params))
         if not self.h:
             raise RuntimeError(self.L.smco_last_error().decode())
@@ -289,8 +290,9 @@ class Oracle:
         self._chk(self.L.smco_get_local_recomb(self.h, opp.ctypes.data, cnt.ctypes.data, nb))
         return {"opp_diff": opp, "counts": cnt}
 
-    def migrations(self, cap=96):
+    def migrations(self, cap=None):
         n = self.inp.nsam
+        cap = self.mig_cap if cap is None else cap
         nm = np.zeros(self.Np, np.int32); t = np.zeros((self.Np, cap)); b = np.zeros((self.Np, cap), np.int8)
         q = np.zeros((self.Np, cap), np.int8); npop = np.zeros((self.Np, n - 1), np.int8)
         self.L.smco_get_migrations(self.h, nm.ctypes.data, t.ctypes.data, b.ctypes.data, q.ctypes.data,
