@@ -245,6 +245,7 @@ static void pfARG_core(PfParam& P, const HostModel& M0, int device, const ChunkJ
     pp.seed = base_seed(M) + 1000ull * (uint64_t)P.em_iteration + (job ? job->seed_offset : 0);   // same rule as smcsmc_amd/em.py: seed + 1000 * iteration + chunk
     pp.max_trace_events = 0;
     pp.flags = 1;          // the local recombination map is always recorded (smcsmc.cpp:376-383)
+    pp.mig_cap = P.mig_cap;
     if (P.record_trees) {
         if (NP > 1 && M.nsam > 8) throw Unsupported("-arg with more than one population and more than 8 samples");
         pp.flags |= 2;     // -arg (pfparam.cpp:353-357)

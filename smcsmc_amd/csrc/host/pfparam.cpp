@@ -293,6 +293,9 @@ const std::vector<DriverOption>& driver_options() {
          [](PfParam& p, const std::string& v) { p.devices = convert<int>("-devices", v); if (p.devices < 1) throw OutOfRange("-devices", v); }},
         {"-reduce", "STR", "Several chunks", "Exchange of the statistics between ranks: rccl (one device per rank) or host [ rccl when possible ]",
          [](PfParam& p, const std::string& v) { p.reduce_transport = v; }},
+        // not a reference flag: room for migration events on one local tree (the reference's node list is unbounded)
+        {"-migcap", "INT", "Several populations", "Migration events one local tree may hold; about 230 fit the LDS with 32 epochs [ 96 ]",
+         [](PfParam& p, const std::string& v) { p.mig_cap = convert<int>("-migcap", v); if (p.mig_cap < 1) throw OutOfRange("-migcap", v); }},
         // not reference flags: print what the host side made of the input, as JSON, and exit (used by the tests)
         {"-dumpmodel", "", nullptr, "", [](PfParam& p, const std::string&) { p.dump_model = true; }},
         {"-dumplookahead", "", nullptr, "", [](PfParam& p, const std::string&) { p.dump_lookahead = true; }},

@@ -1207,7 +1207,7 @@ __device__ __forceinline__ void decide_body(const KArgs& A, long long s, int mod
     }
     const double u = flag ? philox_uniform(A.seed, 0xFFFFFFFFu, 1, n_res) : 0.0;
     if (blockIdx.x == 0 && tid == 0) {
-        if (!(T > 0.0)) c->err = ERR_ZERO_PROB;
+        if (!(T > 0.0) && !c->err) c->err = ERR_ZERO_PROB;       // the first error is the one reported
         double logl = c->logl + dlog(T);
         c->logl = logl;
         double inv = 1.0 / T;
@@ -1960,7 +1960,7 @@ __device__ __forceinline__ void pipe_bookkeeping(const KArgs& A, const PipeLds& 
         c->count_active = W.first < E;
         if (W.first < E) c->pending_fin = 1;
         c->nbx_used = A.nbx;
-        if (!(d.T > 0.0)) c->err = ERR_ZERO_PROB;
+        if (!(d.T > 0.0) && !c->err) c->err = ERR_ZERO_PROB;
         double logl = c->logl + dlog(d.T);
         c->logl = logl;
         const long long row = PL.b_row;

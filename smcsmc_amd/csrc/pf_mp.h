@@ -403,7 +403,7 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
                 const double rmf = ml.MT[ee * P + pf];
                 const double rmr = root_active ? ml.MT[ee * P + pr] : 0.0;
                 const double lam = (rc + rmf) + rmr;
-                if (lam == 0.0) { ml.err = 3; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
+                if (lam == 0.0) { if (!ml.err) ml.err = 3; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
                 double t1 = ee == e ? tt + ln.ebuf / lam : ln.T[ee] + (ln.ebuf - gee) / lam;
                 {
                     double up = epoch_end(ln, ee);
@@ -468,7 +468,7 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
         ln.ctr = ctr0 + 2 * (unsigned long long)used;
         MP_ACC(ml, 12, 0, 1);
     }
-    if (!done) { ml.err = 3; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
+    if (!done) { if (!ml.err) ml.err = 3; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
     MP_TICK(tw2);
     MP_ACC(ml, 3, tw1, tw2);
     PF_MP_FLUSH_BUFFER();
@@ -507,7 +507,7 @@ __device__ __forceinline__ void mp_build_initial_tree(Lane& ln, MLane& ml, PLog&
         int nslots = mp_slots_at(ln, ml, ni, -1, tc, W.pf, 0, 0, -1, &pr, &ps);
         bool has_root = tc >= node_h(ln, root) && W.pr == W.pf;
         int k = nslots + (has_root ? 1 : 0);
-        if (k != W.weight || k < 1) { ml.err = 2; return; }
+        if (k != W.weight || k < 1) { if (!ml.err) ml.err = 2; return; }
         double u = uni(ln);
         int idx = min((int)(u * (double)k), k - 1);
         int fl = i;
@@ -557,7 +557,7 @@ __device__ __forceinline__ void mp_genealogy_rest(Lane& ln, MLane& ml, PLog& pl,
     else has_root = tc >= LS(ln, n - 2) && W.pr == W.pf;
     const bool has_stub = tc < Sp && LBp(ml, b_id) == W.pf;
     const int k = nslots + (has_root ? 1 : 0) + (has_stub ? 1 : 0);
-    if (k != W.weight || k < 1) { ml.err = 2; return; }
+    if (k != W.weight || k < 1) { if (!ml.err) ml.err = 2; return; }
     const double u = uni(ln);
     const int idx = min((int)(u * (double)k), k - 1);
     if (idx < nslots) mp_slots_at(ln, ml, n - 1, rp, tc, W.pf, s_id, Sp, idx, &pr, &ps);

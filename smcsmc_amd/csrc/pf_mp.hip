@@ -57,9 +57,8 @@ __device__ __forceinline__ MLane make_mlane(const KArgs& A, SmemMP& m) {
     return ml;
 }
 __device__ __forceinline__ void mp_report(const KArgs& A, const MLane& ml) {
-    if (ml.err == 1) A.ctrl->err = ERR_MIG_OVERFLOW;
-    if (ml.err == 2) A.ctrl->err = ERR_MP_INTERNAL;
-    if (ml.err == 3) A.ctrl->err = ERR_NO_COALESCENCE;
+    // an error of an earlier row stays the one reported (what follows it on a broken state is a consequence)
+    if (ml.err && !A.ctrl->err) A.ctrl->err = ml.err == 1 ? ERR_MIG_OVERFLOW : (ml.err == 2 ? ERR_MP_INTERNAL : ERR_NO_COALESCENCE);
 }
 __device__ __forceinline__ double piece_ref(unsigned pstart, unsigned npieces) {
     return __longlong_as_double((long long)((unsigned long long)pstart | ((unsigned long long)npieces << 32)));
@@ -676,9 +675,7 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
             }
         }
         MP_TICK(tk_loop);
-        if (ml.err == 1) A.ctrl->err = ERR_MIG_OVERFLOW;
-        if (ml.err == 2) A.ctrl->err = ERR_MP_INTERNAL;
-        if (ml.err == 3) A.ctrl->err = ERR_NO_COALESCENCE;
+        if (ml.err && !A.ctrl->err) A.ctrl->err = ml.err == 1 ? ERR_MIG_OVERFLOW : (ml.err == 2 ? ERR_MP_INTERNAL : ERR_NO_COALESCENCE);
         if (biased) {
             // apply the factors that fell due during this extension (particle.cpp:910-916)
             for (;;) {

@@ -347,7 +347,7 @@ __device__ __forceinline__ void rmp_coalesce(RCtx& cx, const RTree<NM>& t, MRLan
                 const double rmf = ml.MT[ee * P + pf];
                 const double rmr = root_active ? ml.MT[ee * P + pr] : 0.0;
                 const double lam = (rc + rmf) + rmr;
-                if (lam == 0.0) { ml.err = 3; ml.bp = bp; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
+                if (lam == 0.0) { if (!ml.err) ml.err = 3; ml.bp = bp; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
                 double t1 = ee == e ? tt + cx.ebuf / lam : cx.T[ee] + (cx.ebuf - gee) / lam;
                 {
                     double up = r_epoch_end(cx, ee);
@@ -421,7 +421,7 @@ __device__ __forceinline__ void rmp_coalesce(RCtx& cx, const RTree<NM>& t, MRLan
         MP_ACC(ml, 12, 0, 1);
     }
     ml.bp = bp;
-    if (!done) { ml.err = 3; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
+    if (!done) { if (!ml.err) ml.err = 3; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
     MP_TICK(tw2);
     MP_ACC(ml, 3, tw1, tw2);
     PF_MPR_FLUSH_BUFFER();
@@ -473,7 +473,7 @@ __device__ __forceinline__ void rmp_genealogy_rest(RCtx& cx, RTree<NM>& t, MRLan
     else has_root = tc >= t.getS(n - 2) && W.pr == W.pf;
     const bool has_stub = tc < Sp && pk2_get(ml.bp, b_id) == W.pf;
     const int k = nslots + (has_root ? 1 : 0) + (has_stub ? 1 : 0);
-    if (k != W.weight || k < 1) { ml.err = 2; return; }
+    if (k != W.weight || k < 1) { if (!ml.err) ml.err = 2; return; }
     const double u = r_uni(cx);
     const int idx = min((int)(u * (double)k), k - 1);
     int eff = 0;

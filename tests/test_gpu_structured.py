@@ -388,13 +388,13 @@ def test_tree_dump_with_structure(oracle, hiplib, n, P, Np, bias):
 
 def test_migration_event_capacity_is_a_parameter(oracle, hiplib):
     """pf_params.mig_cap: a model with fast migration and no join puts more than the default 96 migration events on a
-    local tree.  With the default the run stops with a reported error (on the device and in the oracle alike); with room
-    for 200 it runs through and matches the oracle, event lists included."""
+    local tree at some point of the sweep.  With the default the run stops with a reported error (on the device and in the
+    oracle alike); with room for 160 it runs through and matches the oracle, event lists included."""
     from smcsmc_amd import ParticleFilter, PfError
     E, n = 5, 6
     base = cases.make_model(n=n, E=E, L=6e4)
     segs = cases.make_segments(base, seed=77, max_seg_len=5000)
-    model = cases.make_structured(base, P=2, split_epoch=E, mig=16.0)
+    model = cases.make_structured(base, P=2, split_epoch=E, mig=5.0)
     with pytest.raises(RuntimeError, match="too many migration events"):
         o = oracle.Oracle(model, 200, seed=3, max_trace_events=8)
         o.init_prior(segs["start"][0]); o.run(o.pack_segments(model, segs))
@@ -402,13 +402,12 @@ def test_migration_event_capacity_is_a_parameter(oracle, hiplib):
         g = ParticleFilter(model, 200, seed=3, max_trace_events=8)
         g.init_prior(segs["start"][0]); g.load_segments(segs); g.run(); g.finish()
     for debug in (0, 1):
-        o = oracle.Oracle(model, 200, seed=3, max_trace_events=8, mig_cap=200)
+        o = oracle.Oracle(model, 200, seed=3, max_trace_events=8, mig_cap=160)
         o.init_prior(segs["start"][0]); o.run(o.pack_segments(model, segs))
-        g = ParticleFilter(model, 200, seed=3, max_trace_events=8, mig_cap=200, debug=debug)
+        g = ParticleFilter(model, 200, seed=3, max_trace_events=8, mig_cap=160, debug=debug)
         g.init_prior(segs["start"][0]); g.load_segments(segs); g.run(); g.finish()
         assert (_bits(o.trace()["logl"]) == _bits(g.trace()["logl"])).all()
         _assert_state_equal(o, g)
-        assert o.migrations()["n_events"].max() > 96
         _assert_counts_close(o.counts(), g.counts())
     with pytest.raises(PfError, match="does not fit the LDS"):
         ParticleFilter(model, 200, seed=3, mig_cap=600)
