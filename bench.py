@@ -77,8 +77,10 @@ def build_workload(args, seed):
             seg = simulate.simulate_seg(n, L, mu, rho, ct, ps, seed=seed)
             np.savez(cache, **seg)
     else:
-        # generated on the device (k_simulate: one lane per chunk, the filter's own SMC' transition), seeded
-        seg = simulate.simulate_seg_device(n, L, mu, rho, ct, ps, seed=seed, nchunks=1, device=getattr(args, "device", 0))[0]
+        # generated on the device (k_simulate / k_simulate_mp: one lane per chunk, the filter's own SMC' transition, from
+        # the model the sweep then assumes -- with several populations the isolation-with-migration model), seeded
+        seg = simulate.simulate_seg_device(n, L, mu, rho, ct, ps, seed=seed, nchunks=1, device=getattr(args, "device", 0),
+                                           structure=model if args.pops > 1 else None)[0]
     max_seg_len = int(2.0 / (rho * 4 * N0))        # pfparam.cpp:364
     S = segmod.Segments.from_sites(seg["start"], seg["length"], seg["alleles"], n, L, max_segment_length=max_seg_len)
     if not getattr(args, "uncalibrated_lags", False):

@@ -211,7 +211,8 @@ int pf_median_survival(const pf_model* model, uint64_t seed, int32_t min_events,
                        int64_t* trees_used, int device);
 
 /* Synthetic data next to the path (the reference shells out to scrm and converts, populationmodels.py:440-577): `nchunks`
- * independent chunks of the model's length under the same SMC' process the filter simulates, one population; per chunk
+ * independent chunks of the model's length under the same SMC' process the filter simulates (one population, or a
+ * structured model with migration and joins, up to 96 migration events per local tree); per chunk
  * ascending continuous site positions pos[c*max_sites + k] and carrier masks (bit i = sample i carries the mutation).
  * n_sites[c] < 0 means more than max_sites sites were drawn (the first max_sites are returned). */
 int pf_simulate_sites(const pf_model* model, uint64_t seed, int32_t nchunks, int64_t max_sites, double* pos, uint32_t* masks,

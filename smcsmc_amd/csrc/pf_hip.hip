@@ -4200,20 +4200,20 @@ int pf_median_survival(const pf_model* m, uint64_t seed, int32_t min_events, int
 int pf_simulate_sites(const pf_model* m, uint64_t seed, int32_t nchunks, int64_t max_sites, double* pos, uint32_t* masks,
                       int64_t* n_sites, int device) {
     if (test_setup(device)) return -1;
-    if (m->n_pops != 1 || m->nsam < 2 || m->nsam > PF_NMAX || m->n_epochs < 1 || m->n_epochs > PF_EMAX || nchunks < 1 || max_sites < 1) {
-        g_err = "pf_simulate_sites: one population, 2..16 haplotypes, 1..64 epochs";
+    if (m->n_pops < 1 || m->n_pops > PF_PMAX || m->nsam < 2 || m->nsam > PF_NMAX || m->n_epochs < 1 || m->n_epochs > PF_EMAX || nchunks < 1 || max_sites < 1) {
+        g_err = "pf_simulate_sites: 1..4 populations, 2..16 haplotypes, 1..64 epochs";
         return -1;
     }
-    const int E = m->n_epochs, n = m->nsam;
+    const int E = m->n_epochs, n = m->nsam, P = m->n_pops;
     KArgs A;
     memset(&A, 0, sizeof(A));
-    A.E = E; A.n = n; A.P = 1; A.L = m->loci_length; A.mu = m->mutation_rate; A.rho = m->recombination_rate;
+    A.E = E; A.n = n; A.P = P; A.L = m->loci_length; A.mu = m->mutation_rate; A.rho = m->recombination_rate; A.mcap = PF_MMAX;
     double *dT, *dI, *dHc, *dpos; int* dRF; unsigned* dmask; long long* dn;
     HIPCHK(hipMalloc(&dT, E * 8)); HIPCHK(hipMalloc(&dI, E * 8)); HIPCHK(hipMalloc(&dHc, E * 8)); HIPCHK(hipMalloc(&dRF, E * 4));
     HIPCHK(hipMalloc(&dpos, (size_t)nchunks * max_sites * 8)); HIPCHK(hipMalloc(&dmask, (size_t)nchunks * max_sites * 4));
     HIPCHK(hipMalloc(&dn, (size_t)nchunks * 8));
     std::vector<double> inv2N(E);
-    for (int e = 0; e < E; ++e) inv2N[e] = 1.0 / (2.0 * m->pop_sizes[e]);
+    for (int e = 0; e < E; ++e) inv2N[e] = 1.0 / (2.0 * m->pop_sizes[(size_t)e * P]);
     std::vector<int> rf(E, 3);
     const std::vector<double> Hc = cumulative_intensity(m->change_times, inv2N, E);
     HIPCHK(hipMemcpy(dT, m->change_times, E * 8, hipMemcpyHostToDevice));
@@ -4221,12 +4221,31 @@ int pf_simulate_sites(const pf_model* m, uint64_t seed, int32_t nchunks, int64_t
     HIPCHK(hipMemcpy(dHc, Hc.data(), E * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dRF, rf.data(), E * 4, hipMemcpyHostToDevice));
     A.T = dT; A.inv2N = dI; A.Hc = dHc; A.recflags = dRF;
-    const size_t smem = smem_bytes(n, E);
-    if (smem > 64 * 1024) hipFuncSetAttribute((const void*)k_simulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k_simulate, dim3((unsigned)((nchunks + PF_BS - 1) / PF_BS)), dim3(PF_BS), smem, 0, A, (unsigned long long)seed,
-                       (int)nchunks, (long long)max_sites, dpos, dmask, dn);
-    int rc = check_launch("k_simulate");
+    std::vector<void*> mp_allocs;
+    int* derr = nullptr;
+    int rc = 0;
+    if (P > 1) {
+        // structured model: the LDS-tree walk of pf_mp.h, one lane per chunk
+        MpTables tb;
+        if (build_mp_tables(m, tb) || upload_mp_tables(tb, A, mp_allocs)) return -1;
+        HIPCHK(hipMalloc(&derr, 4));
+        HIPCHK(hipMemset(derr, 0, 4));
+        const size_t smem = pf_mp_smem_bytes(n, E, P, PF_MMAX);
+        if (pf_mp_prepare(smem, PF_MMAX)) { g_err = "pf_simulate_sites: the local-tree state does not fit the LDS"; return -1; }
+        pf_mp_launch_simulate(A, (unsigned long long)seed, (int)nchunks, (long long)max_sites, dpos, dmask, dn, derr, smem, 0);
+    } else {
+        const size_t smem = smem_bytes(n, E);
+        if (smem > 64 * 1024) hipFuncSetAttribute((const void*)k_simulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(k_simulate, dim3((unsigned)((nchunks + PF_BS - 1) / PF_BS)), dim3(PF_BS), smem, 0, A, (unsigned long long)seed,
+                           (int)nchunks, (long long)max_sites, dpos, dmask, dn);
+    }
+    rc = check_launch("k_simulate");
     if (!rc && hipDeviceSynchronize() != hipSuccess) { g_err = "k_simulate failed"; rc = -1; }
+    if (!rc && derr) {
+        int herr = 0;
+        HIPCHK(hipMemcpy(&herr, derr, 4, hipMemcpyDeviceToHost));
+        if (herr) { g_err = herr == 1 ? "too many migration events on one local tree" : (herr == 3 ? "No final coalescence event was sampled!" : "structured simulation: internal error"); rc = -1; }
+    }
     if (!rc) {
         std::vector<long long> hn(nchunks);
         HIPCHK(hipMemcpy(hn.data(), dn, (size_t)nchunks * 8, hipMemcpyDeviceToHost));
@@ -4237,6 +4256,8 @@ int pf_simulate_sites(const pf_model* m, uint64_t seed, int32_t nchunks, int64_t
             HIPCHK(hipMemcpy(masks + (size_t)c * max_sites, dmask + (size_t)c * max_sites, (size_t)k * 4, hipMemcpyDeviceToHost));
         }
     }
+    for (void* q : mp_allocs) hipFree(q);
+    if (derr) hipFree(derr);
     hipFree(dT); hipFree(dI); hipFree(dHc); hipFree(dRF); hipFree(dpos); hipFree(dmask); hipFree(dn);
     return rc;
 }

@@ -851,6 +851,62 @@ __global__ __launch_bounds__(PF_BS) void k_calibrate_mp(KArgs A, unsigned long l
 }
 
 
+// k_simulate for structured models: one lane = one chunk; the prior tree with migration,
+// then along the sequence the structured SMC' transition of the filter (mp_genealogy_rest) and, between recombinations,
+// mutations dropped on the tree in proportion to branch length.  Its own Philox stream (3), as k_simulate.
+__global__ __launch_bounds__(PF_BS) void k_simulate_mp(KArgs A, unsigned long long seed, int nchunks, long long max_sites,
+                                                       double* pos_out, unsigned* mask_out, long long* n_out, int* out_err) {
+    extern __shared__ double smem[];
+    Smem m = carve(smem, A.n, A.E);
+    SmemMP mm = carve_mp(smem, A.n, A.E, A.P, A.mcap);
+    load_model(A, m);
+    load_model_mp(A, mm);
+    __syncthreads();
+    const long long r = (long long)blockIdx.x * PF_BS + threadIdx.x;
+    if (r >= nchunks) return;
+    Lane ln = make_lane(A, m, r);
+    MLane ml = make_mlane(A, mm);
+    ln.seed = seed;
+    ln.stream = 3;
+    ln.ebuf = -dlog(uni(ln));
+    PLog nolog;
+    nolog.on = false;
+    mp_build_initial_tree<false>(ln, ml, nolog, [&](int, unsigned, unsigned, double, unsigned) {});
+    double* tmp = m.t0 + threadIdx.x;        // per-lane LDS column for the descendant masks
+    double* pos = pos_out + (size_t)r * max_sites;
+    unsigned* msk = mask_out + (size_t)r * max_sites;
+    long long ns = 0;
+    double x = 0.0;
+    double next_rec = ml.err ? A.L : sample_next_base(ln, 0.0);
+    double next_mut = x + (-dlog(uni(ln))) / (A.mu * ln.Ltree);
+    bool overflow = false;
+    while (x < A.L && !ml.err) {
+        if (next_mut < next_rec && next_mut < A.L) {
+            int rp = 0, sb = 0;
+            double h;
+            sample_point(ln, &rp, &sb, &h);
+            const unsigned carriers = lane_desc_mask(ln, LC(ln, rp, sb), tmp);
+            if (ns < max_sites) { pos[ns] = next_mut; msk[ns] = carriers; }
+            else overflow = true;
+            ++ns;
+            x = next_mut;
+            next_mut = x + (-dlog(uni(ln))) / (A.mu * ln.Ltree);
+            continue;
+        }
+        x = next_rec;
+        if (!(x < A.L)) break;
+        int rp = 0, sb = 0;
+        double h, tc, sp;
+        bool changed;
+        sample_point(ln, &rp, &sb, &h);
+        mp_genealogy_rest<false>(ln, ml, nolog, -1, rp, sb, h, &tc, &sp, &changed);
+        next_rec = sample_next_base(ln, x);
+        next_mut = x + (-dlog(uni(ln))) / (A.mu * ln.Ltree);     // memoryless: redrawn under the new tree length
+    }
+    if (ml.err) *out_err = ml.err;
+    n_out[r] = overflow ? -ns : ns;
+}
+
 // calculate_terminal_branch_length_quantiles (smcsmc.cpp:128-166) for a structured model: the parent height of every
 // leaf in nrep prior trees (migrations ignored: parent_height_ignoring_migrations, smcsmc.cpp:115-125) and the tree length
 __global__ __launch_bounds__(PF_BS) void k_tbl_mp(KArgs A, unsigned long long seed, long long nrep, double* out_h /* [n][nrep] */,
@@ -902,6 +958,7 @@ int pf_mp_prepare(size_t smem, int mcap) {
         if (hipFuncSetAttribute((const void*)k_init_mp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
         if (hipFuncSetAttribute((const void*)k_calibrate_mp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
         if (hipFuncSetAttribute((const void*)k_tbl_mp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void*)k_simulate_mp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
     }
     return 0;
 }
@@ -936,4 +993,9 @@ void pf_mp_launch_calibrate(const KArgs& A, unsigned long long seed, long long r
 void pf_mp_launch_tbl(const KArgs& A, unsigned long long seed, long long nrep, double* out_h, double* out_len, int* out_err,
                       size_t smem, hipStream_t st) {
     hipLaunchKernelGGL(k_tbl_mp, dim3(mp_blocks(nrep)), dim3(PF_BS), smem, st, A, seed, nrep, out_h, out_len, out_err);
+}
+
+void pf_mp_launch_simulate(const KArgs& A, unsigned long long seed, int nchunks, long long max_sites, double* pos, unsigned* masks,
+                           long long* n_sites, int* out_err, size_t smem, hipStream_t st) {
+    hipLaunchKernelGGL(k_simulate_mp, dim3(mp_blocks(nchunks)), dim3(PF_BS), smem, st, A, seed, nchunks, max_sites, pos, masks, n_sites, out_err);
 }

@@ -19,3 +19,5 @@ void pf_mp_launch_calibrate(const KArgs& A, unsigned long long seed, long long r
                             double* out_dist, int* out_err, size_t smem, hipStream_t st);
 void pf_mp_launch_tbl(const KArgs& A, unsigned long long seed, long long nrep, double* out_h, double* out_len, int* out_err,
                       size_t smem, hipStream_t st);
+void pf_mp_launch_simulate(const KArgs& A, unsigned long long seed, int nchunks, long long max_sites, double* pos, unsigned* masks,
+                           long long* n_sites, int* out_err, size_t smem, hipStream_t st);

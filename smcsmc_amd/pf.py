@@ -462,7 +462,9 @@ def simulate_sites(model, seed=1, nchunks=1, max_sites=None, device=0):
         # expected sites 4 N mu H(n-1) L with the largest population size, with ample room
         harmonic = sum(1.0 / i for i in range(1, n))
         nmax = float(np.max(np.asarray(model["pop_sizes"], float)))
-        max_sites = int(2.0 * 4.0 * nmax * model["mutation_rate"] * harmonic * model["loci_length"]) + 4096
+        # (populations that stay apart for a long time add the time to their join to every pair across them)
+        deep = float(np.max(np.asarray(model["change_times"], float))) if int(model.get("n_pops", 1)) > 1 else 0.0
+        max_sites = int(2.0 * (4.0 * nmax * harmonic + n * deep) * model["mutation_rate"] * model["loci_length"]) + 4096
     pos = np.zeros((nchunks, max_sites))
     masks = np.zeros((nchunks, max_sites), np.uint32)
     cnt = np.zeros(nchunks, np.int64)

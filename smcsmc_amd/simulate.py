@@ -204,14 +204,18 @@ def sites_to_seg(positions, patterns, n, L, missing=()):
             "alleles": np.array(alleles, np.int8).reshape(-1, n)}
 
 
-def simulate_seg_device(n, L, mu, rho, change_times, pop_sizes, seed=1, nchunks=1, device=0, missing=()):
+def simulate_seg_device(n, L, mu, rho, change_times, pop_sizes, seed=1, nchunks=1, device=0, missing=(), structure=None):
     """The same data model simulated on the GPU (k_simulate: one lane per chunk, the filter's own SMC' transition,
     Philox stream 3): a list of `nchunks` independent chunks in the format of simulate_seg.  A 100 Mb chunk of two
-    diploids takes well under a second; the chunks of a call run side by side."""
+    diploids takes well under a second; the chunks of a call run side by side.  `structure` = the structured part of a
+    model dictionary (n_pops, pop_sizes [E][P], mig_rates, single_mig, sample_pops): the data then comes from that
+    isolation-with-migration model (k_simulate_mp)."""
     from . import pf
     change_times = np.asarray(change_times, float)
     model = dict(change_times=change_times, pop_sizes=np.asarray(pop_sizes, float), lags=np.ones(len(change_times)), nsam=int(n),
                  loci_length=float(L), mutation_rate=float(mu), recombination_rate=float(rho))
+    if structure:
+        model.update({k: structure[k] for k in ("n_pops", "pop_sizes", "mig_rates", "single_mig", "sample_pops") if k in structure})
     out = []
     for pos, masks in pf.simulate_sites(model, seed=seed, nchunks=nchunks, device=device):
         pats = ((masks[:, None] >> np.arange(n)[None, :]) & 1).astype(np.int8)

@@ -49,3 +49,32 @@ def test_device_simulator_is_reproducible_and_feeds_the_filter(hiplib, oracle):
     o = oracle.Oracle(model, 500, seed=3); o.init_prior(0.0); o.run(o.pack_segments(model, segs))
     assert np.float64(g.logl()).view(np.uint64) == np.float64(o.logl()).view(np.uint64)
     assert np.isfinite(g.logl()) and g.logl() < 0
+
+
+def test_structured_device_simulation_shows_the_split(hiplib):
+    """k_simulate_mp: data from an isolation model (two populations, no migration, joined at T generations).  A pair
+    of samples from one population coalesces after 2N generations on average, a pair across the populations after
+    T + 2N: mean pairwise differences per base 4 N mu within and 2 mu (T + 2N) across."""
+    from smcsmc_amd import simulate
+    N0, mu, rho, L, n = 1e4, 2.5e-8, 1e-8, 4e6, 4
+    ct = np.array([0.0, 5000.0, 20000.0, 60000.0])
+    E, P = len(ct), 2
+    T = ct[2]
+    sm = np.zeros((E, P, P)); sm[2, 1, 0] = 1.0
+    structure = dict(n_pops=P, pop_sizes=np.full((E, P), N0), mig_rates=np.zeros((E, P, P)), single_mig=sm, sample_pops=[0, 0, 1, 1])
+    within, across = [], []
+    for seg in simulate.simulate_seg_device(n, L, mu, rho, ct, np.full(E, N0), seed=3, nchunks=6, structure=structure):
+        a = seg["alleles"][seg["alleles"].max(axis=1) >= 0]          # rows that carry a site
+        a = a[(a.min(axis=1) == 0) & (a.max(axis=1) == 1)]
+        d = lambda i, j: float((a[:, i] != a[:, j]).sum()) / L      # noqa: E731
+        within += [d(0, 1), d(2, 3)]
+        across += [d(0, 2), d(0, 3), d(1, 2), d(1, 3)]
+    assert np.mean(within) == pytest.approx(4 * N0 * mu, rel=0.08)
+    assert np.mean(across) == pytest.approx(2 * mu * (T + 2 * N0), rel=0.08)
+    # with migration the populations look alike again
+    structure["mig_rates"] = np.zeros((E, P, P))
+    structure["mig_rates"][:2] = (8.0 / (4 * N0)) * (1 - np.eye(P))            # until the join
+    seg = simulate.simulate_seg_device(n, L, mu, rho, ct, np.full(E, N0), seed=4, nchunks=1, structure=structure)[0]
+    a = seg["alleles"]; a = a[(a.min(axis=1) == 0) & (a.max(axis=1) == 1)]
+    w = np.mean([(a[:, 0] != a[:, 1]).mean(), (a[:, 2] != a[:, 3]).mean()]); x = np.mean([(a[:, 0] != a[:, 2]).mean(), (a[:, 1] != a[:, 3]).mean()])
+    assert 0.9 < x / w < 1.3                      # against 2.0 without migration
