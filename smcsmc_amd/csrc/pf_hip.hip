@@ -13,6 +13,7 @@
 //
 // No CUDA compatibility layer, no CPU fallback: this file is HIP for gfx950 only.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -3210,11 +3211,14 @@ static int launch_decide(pf_handle* h, long long s, int mode, const Windows& W) 
     if (h->ev_cnt) hipStreamWaitEvent(h->stream, h->ev_cnt, 0);
     {
         Timed tm(h, 1, t);
-        hipLaunchKernelGGL(k_decide, dim3(h->nblocks + 1), dim3(PF_BS), 0, h->stream, h->A, s, mode, W, h->nblocks);
-    }
-    if (!h->no_count) {
-        h->ev_dec = next_sync_event(h);
-        hipEventRecord(h->ev_dec, h->stream);
+        if (!h->no_count) {
+            // the event the counting stream waits on is the kernel's own completion signal (no marker packet between
+            // this kernel and the next row's extend)
+            h->ev_dec = next_sync_event(h);
+            hipExtLaunchKernelGGL(k_decide, dim3(h->nblocks + 1), dim3(PF_BS), 0, h->stream, nullptr, h->ev_dec, 0, h->A, s, mode, W, h->nblocks);
+        } else {
+            hipLaunchKernelGGL(k_decide, dim3(h->nblocks + 1), dim3(PF_BS), 0, h->stream, h->A, s, mode, W, h->nblocks);
+        }
     }
     return check_launch("k_decide");
 }
