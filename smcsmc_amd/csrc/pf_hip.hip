@@ -1569,8 +1569,6 @@ __device__ __forceinline__ void count_body(const KArgs& A, const CountSrc& Q, in
     const int lane = threadIdx.x & 63;
     const long long gtid = (long long)bx * PF_BS + threadIdx.x;
     const long long nthreads = (long long)nbxg * PF_BS;
-    const int my_wave = (int)(gtid >> 6);
-    const int total_waves = (int)(nthreads >> 6);
     AC acc;
 #pragma unroll
     for (int k = 0; k < AC::NC; ++k) acc.v[k] = 0.0;

@@ -243,7 +243,6 @@ __device__ __forceinline__ double r_coalesce_up(RCtx& cx, const RTree<NM>& t, in
     for (int r = 0; r < NI; ++r) tv[r] = t.S[r];     // unused ranks hold 0: a harmless search, no branch
     tv[NI] = h;
     r_search4_batch<NI + 1>(cx.T, tv, ev);
-    const int e = ev[NI];
     double Hn[NI];
     {
         double hh[NI + 1], tt[NI + 1], ii[NI + 1];
