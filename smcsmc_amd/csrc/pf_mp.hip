@@ -403,8 +403,16 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
 // The row kernel of the structured filter for small samples: the update of pf_mp_reg.h, state read from and written to
 // the same arrays as k_extend_mp (the two are interchangeable row by row; tests run both against the oracle).
 // LDS: the epoch tables of the model and, per lane, the migration events of its tree.
-#ifndef PF_MPR_LANES
-#define PF_MPR_LANES 32      // particles per wavefront of the register-tree row kernel (see k_extend_mpr)
+// particles per wavefront of the register-tree row kernel (see k_extend_mpr): the fewer, the less a wavefront serialises
+// the divergent paths of its lanes -- as long as all workgroups of a launch are resident at once.  Without focused sampling
+// the kernel needs 223 VGPRs, two wavefronts share a SIMD, and four quarter-filled wavefronts per workgroup fit (C5 shape:
+// 7.64e3 segments/s against 7.38e3 with two half-filled and 7.30e3 with one full wavefront, alternating runs on one box);
+// the focused-sampling instantiation needs more than 256 registers (one wavefront per SIMD) and stays at two.
+#ifndef PF_MPR_LANES_PLAIN
+#define PF_MPR_LANES_PLAIN 16
+#endif
+#ifndef PF_MPR_LANES_BIASED
+#define PF_MPR_LANES_BIASED 32
 #endif
 struct SmemMPR { double* T; double* TJ; double* I2; double* MT; double* CI; double* CM; double* MR; double* Mt; int* JM; int* EJ; int8_t* Mb; int8_t* Mq; };
 __host__ __device__ static size_t smem_mpr_bytes(int E, int P, int mcap) {
@@ -947,10 +955,10 @@ int pf_mp_prepare(size_t smem, int mcap) {
         // the register-tree row kernels: their LDS does not depend on n (tables at their largest size here)
         const size_t big_sz = smem_mpr_bytes(PF_EMAX, PF_PMAX, mcap);
         const int big = (int)(big_sz < 160 * 1024 ? big_sz : 160 * 1024);
-        if (hipFuncSetAttribute((const void*)k_extend_mpr<8, false, PF_MPR_LANES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) return -1;
-        if (hipFuncSetAttribute((const void*)k_extend_mpr<8, true, PF_MPR_LANES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) return -1;
-        if (hipFuncSetAttribute((const void*)k_extend_mpr<8, false, PF_MPR_LANES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) return -1;
-        if (hipFuncSetAttribute((const void*)k_extend_mpr<8, true, PF_MPR_LANES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void*)k_extend_mpr<8, false, PF_MPR_LANES_PLAIN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void*)k_extend_mpr<8, true, PF_MPR_LANES_BIASED, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void*)k_extend_mpr<8, false, PF_MPR_LANES_PLAIN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void*)k_extend_mpr<8, true, PF_MPR_LANES_BIASED, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess) return -1;
     }
     if (smem > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)k_extend_mp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
@@ -971,12 +979,12 @@ size_t pf_mp_reg_smem_bytes(int E, int P, int mcap) { return smem_mpr_bytes(E, P
 void pf_mp_launch_extend(const KArgs& A, long long s, size_t smem, hipStream_t st, bool lds_tree, int fuse) {
     if (!lds_tree && A.n <= 8) {
         const size_t sm = smem_mpr_bytes(A.E, A.P, A.mcap);
-        const dim3 grid(mp_blocks(A.Np)), blk(64 * (64 / PF_MPR_LANES));
         const bool biased = A.n_bias > 0 || A.g_K > 0;
-        if (biased && A.rec_trees) hipLaunchKernelGGL((k_extend_mpr<8, true, PF_MPR_LANES, true>), grid, blk, sm, st, A, s, fuse);
-        else if (biased) hipLaunchKernelGGL((k_extend_mpr<8, true, PF_MPR_LANES, false>), grid, blk, sm, st, A, s, fuse);
-        else if (A.rec_trees) hipLaunchKernelGGL((k_extend_mpr<8, false, PF_MPR_LANES, true>), grid, blk, sm, st, A, s, fuse);
-        else hipLaunchKernelGGL((k_extend_mpr<8, false, PF_MPR_LANES, false>), grid, blk, sm, st, A, s, fuse);
+        const dim3 grid(mp_blocks(A.Np)), blk(64 * (64 / (biased ? PF_MPR_LANES_BIASED : PF_MPR_LANES_PLAIN)));
+        if (biased && A.rec_trees) hipLaunchKernelGGL((k_extend_mpr<8, true, PF_MPR_LANES_BIASED, true>), grid, blk, sm, st, A, s, fuse);
+        else if (biased) hipLaunchKernelGGL((k_extend_mpr<8, true, PF_MPR_LANES_BIASED, false>), grid, blk, sm, st, A, s, fuse);
+        else if (A.rec_trees) hipLaunchKernelGGL((k_extend_mpr<8, false, PF_MPR_LANES_PLAIN, true>), grid, blk, sm, st, A, s, fuse);
+        else hipLaunchKernelGGL((k_extend_mpr<8, false, PF_MPR_LANES_PLAIN, false>), grid, blk, sm, st, A, s, fuse);
         return;
     }
     if (A.n_bias > 0 || A.g_K > 0)
