@@ -273,140 +273,62 @@ __device__ __forceinline__ void rmp_coalesce(RCtx& cx, const RTree<NM>& t, MRLan
     int nb = 0;
     MP_TICK(tw1);
     MP_ACC(ml, 2, tw0, tw1);
-    constexpr int KP = 2;
     bool done = false;
     // cumulative intensities at the start of the stretch: what the end of the last stretch computed, unless a lineage
     // changed population or the root's lineage has just become active
     double f0c = 0.0, f0m = 0.0, f0r = 0.0;
     bool f_fresh = false, f_root = false;
+    // One trip of the outer loop per EVENT of the walk (a migration, or the coalescence that ends it), in two phases that
+    // every lane of the wavefront goes through together:
+    //   1. stretches without an event -- a short loop (boundary, hazard, compare, advance) that a lane leaves when its
+    //      budget runs out in the stretch at hand; the lanes wait for the one with the most stretches to pass;
+    //   2. the event -- its epoch, one division, the kind, the record -- once, with the wavefront converged.
+    // The same arithmetic in the same order as one loop over stretches with the event code inside; but there a wavefront
+    // whose lanes are in different places pays for the event code in nearly every iteration (it was two fifths of the
+    // iteration), here once per event.  The event's two random numbers are drawn at the top, converged as well.
     for (int guard = 0; guard < 4096 && !done; ++guard) {
         MP_CYC(cy_o0);
         if (nb > 1) PF_MPR_FLUSH_BUFFER();
-        const unsigned long long ctr0 = cx.ctr;
-        double u_type[KP], eb_new[KP];
-#pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            u_type[k] = philox_uniform(cx.seed, cx.slot, cx.stream, ctr0 + 2 * k);
-            eb_new[k] = -dlog(philox_uniform(cx.seed, cx.slot, cx.stream, ctr0 + 2 * k + 1));
-        }
-        int used = 0;
+        const double u_type = philox_uniform(cx.seed, cx.slot, cx.stream, cx.ctr);
+        const double eb_new = -dlog(philox_uniform(cx.seed, cx.slot, cx.stream, cx.ctr + 1));
         MP_CYC(cy_o1);
         MP_ACC(ml, 16, cy_o0, cy_o1);
+        bool root_active = false;
+        double tn = PF_INF;
+        int weight = 0, en = e;
+        // ---- phase 1
         for (int g2 = 0; g2 < 100000; ++g2) {
-            if (nb > 1) break;
             MP_ACC(ml, 13, 0, 1);
             MP_CYC(cy0);
-            const bool root_active = tt >= Hr;
+            if (nb > 1) PF_MPR_FLUSH_BUFFER();            // joins may have queued events (rare)
+            root_active = tt >= Hr;
             const double tj = ml.TJ[e];
-            double tn = nS < eT ? nS : eT;
+            tn = nS < eT ? nS : eT;
             tn = tn < tj ? tn : tj;
             const int k = (int)((cnt >> (8 * pf)) & 0xffu);
-            const int weight = k + ((root_active && pr == pf) ? 1 : 0);
-            int en = e;
-            bool quiet = false;
+            weight = k + ((root_active && pr == pf) ? 1 : 0);
+            en = e;
             if (!f_fresh || f_root != root_active) {
                 f0c = ci(pf, e, tt); f0m = cm(pf, e, tt); f0r = root_active ? cm(pr, e, tt) : 0.0;
                 f_fresh = true; f_root = root_active;
             }
-            double f1c = 0.0, f1m = 0.0, f1r = 0.0;
-            if (tn < PF_INF) {
-                en = !(nS > tn) ? nE : (!(eT > tn) ? eE : ml.EJ[e]);
-                f1c = ci(pf, en, tn); f1m = cm(pf, en, tn);
-                double need = (double)weight * (f1c - f0c) + (f1m - f0m);
-                if (root_active) { f1r = cm(pr, en, tn); need = need + (f1r - f0r); }
-                if (cx.ebuf > need) { cx.ebuf -= need; quiet = true; }
-            }
+            if (!(tn < PF_INF)) break;                    // nothing above but the event
+            en = !(nS > tn) ? nE : (!(eT > tn) ? eE : ml.EJ[e]);
+            const double f1c = ci(pf, en, tn), f1m = cm(pf, en, tn);
+            double f1r = 0.0;
+            double need = (double)weight * (f1c - f0c) + (f1m - f0m);
+            if (root_active) { f1r = cm(pr, en, tn); need = need + (f1r - f0r); }
             MP_CYC(cy1);
             MP_ACC(ml, 17, cy0, cy1);
-            if (!quiet) {
-                // the epoch of the event: the number of epoch starts of the stretch the budget still reaches (see
-                // mp_coalesce), counted four at a time with their reads in flight together
-                if (used == KP) break;
-                const int elim = tn < PF_INF ? en : cx.E - 1;
-                int ee = e;
-                double gee = 0.0;
-                while (ee < elim) {
-                    double g[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int kk = ee + 1 + q < cx.E ? ee + 1 + q : cx.E - 1;       // past the stretch: read, never used
-                        g[q] = (double)weight * (ml.CI[kk * P + pf] - f0c) + (ml.CM[kk * P + pf] - f0m);
-                        if (root_active) g[q] = g[q] + (ml.CM[kk * P + pr] - f0r);
-                    }
-                    int adv = 0;
-                    bool open = true;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        open = open && ee + 1 + q <= elim && cx.ebuf > g[q];
-                        if (open) { gee = g[q]; ++adv; }
-                    }
-                    ee += adv;
-                    if (adv < 4) break;
-                }
-                const double rc = (double)weight * ml.I2[ee * P + pf];
-                const double rmf = ml.MT[ee * P + pf];
-                const double rmr = root_active ? ml.MT[ee * P + pr] : 0.0;
-                const double lam = (rc + rmf) + rmr;
-                if (lam == 0.0) { if (!ml.err) ml.err = 3; ml.bp = bp; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
-                double t1 = ee == e ? tt + cx.ebuf / lam : cx.T[ee] + (cx.ebuf - gee) / lam;
-                {
-                    double up = r_epoch_end(cx, ee);
-                    up = up < tn ? up : tn;
-                    if (t1 > up) t1 = up;
-                }
-                MP_CYC(cy2);
-                MP_ACC(ml, 18, cy1, cy2);
-                {
-                    if (W.tfirst < 0.0) W.tfirst = t1;
-                    const double ut = used == 0 ? u_type[0] : u_type[1];
-                    int kind, to = 0;
-                    {
-                        double v = ut * lam;
-                        if (v < rc || (rmf == 0.0 && rmr == 0.0)) kind = 1;
-                        else {
-                            v -= rc;
-                            int from;
-                            if (v < rmf || rmr == 0.0) { kind = 2; from = pf; }
-                            else { kind = 3; from = pr; v -= rmf; }
-                            to = -1;
-                            for (int q = 0; q < P; ++q) {
-                                double mr = ml.MR[(ee * P + from) * P + q];
-                                if (q == from || mr == 0.0) continue;
-                                to = q;
-                                if (v < mr) break;
-                                v -= mr;
-                            }
-                        }
-                    }
-                    record(root_active, weight, tt, t1, kind, to);
-                    if (cx.vbc) cx.upd_fac *= kind == 1 ? cx.vbc[ee * P + pf] : ml.vbm[(ee * P + (kind == 2 ? pf : pr)) * P + to];
-                    cx.ebuf = used == 0 ? eb_new[0] : eb_new[1];
-                    ++used;
-                    MP_CYC(cy3);
-                    MP_ACC(ml, 19, cy2, cy3);
-                    if (kind == 1) {
-                        W.tc = t1; W.pf = pf; W.pr = pr; W.weight = weight;
-                        W.e1 = (ee + 1 < cx.E && !(t1 < cx.T[ee + 1])) ? ee + 1 : ee;
-                        done = true;
-                        break;
-                    }
-                    PF_MPR_BUF_PUSH(t1, kind == 2 ? PF_TAG_PATH : PF_TAG_RPATH, mp_ev_byte(to, ee));
-                    if (kind == 2) pf = to; else pr = to;
-                    tt = t1;
-                    e = ee;
-                    f_fresh = false;
-                    continue;
-                }
-            }
-            MP_CYC(cy4);
+            if (!(cx.ebuf > need)) break;                 // the event falls into this stretch
+            cx.ebuf -= need;
+            // the configuration changes at tn: node or event of the stored tree, or a fixed-time move
             record(root_active, weight, tt, tn, 0, 0);
             const bool at_join = !(tn < tj);
             tt = tn;
             e = en;
             f0c = f1c; f0m = f1m; f0r = f1r;              // ci(pf, en, tn) is ci(pf, e, tt) of the next stretch
             advance(tt);
-            MP_CYC(cy5);
-            MP_ACC(ml, 20, cy4, cy5);
             if (at_join) {
                 int q = ml.JM[e * P + pf];
                 if (q != pf) { PF_MPR_BUF_PUSH(tt, PF_TAG_PATH, mp_ev_byte(q, e)); pf = q; f_fresh = false; }
@@ -415,9 +337,86 @@ __device__ __forceinline__ void rmp_coalesce(RCtx& cx, const RTree<NM>& t, MRLan
                     if (qr != pr) { PF_MPR_BUF_PUSH(tt, PF_TAG_RPATH, mp_ev_byte(qr, e)); pr = qr; f_fresh = false; }
                 }
             }
-            if (ml.err) { ml.bp = bp; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
+            MP_CYC(cy5);
+            MP_ACC(ml, 20, cy1, cy5);
+            if (ml.err) break;
         }
-        cx.ctr = ctr0 + 2 * (unsigned long long)used;
+        if (ml.err) { ml.bp = bp; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
+        // ---- phase 2: the event, in the stretch [tt, tn)
+        MP_CYC(cy2a);
+        {
+            // its epoch: the number of epoch starts of the stretch the budget still reaches (see mp_coalesce), counted
+            // four at a time with their reads in flight together
+            const int elim = tn < PF_INF ? en : cx.E - 1;
+            int ee = e;
+            double gee = 0.0;
+            while (ee < elim) {
+                double g[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int kk = ee + 1 + q < cx.E ? ee + 1 + q : cx.E - 1;       // past the stretch: read, never used
+                    g[q] = (double)weight * (ml.CI[kk * P + pf] - f0c) + (ml.CM[kk * P + pf] - f0m);
+                    if (root_active) g[q] = g[q] + (ml.CM[kk * P + pr] - f0r);
+                }
+                int adv = 0;
+                bool open = true;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    open = open && ee + 1 + q <= elim && cx.ebuf > g[q];
+                    if (open) { gee = g[q]; ++adv; }
+                }
+                ee += adv;
+                if (adv < 4) break;
+            }
+            const double rc = (double)weight * ml.I2[ee * P + pf];
+            const double rmf = ml.MT[ee * P + pf];
+            const double rmr = root_active ? ml.MT[ee * P + pr] : 0.0;
+            const double lam = (rc + rmf) + rmr;
+            if (lam == 0.0) { if (!ml.err) ml.err = 3; ml.bp = bp; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
+            double t1 = ee == e ? tt + cx.ebuf / lam : cx.T[ee] + (cx.ebuf - gee) / lam;
+            {
+                double up = r_epoch_end(cx, ee);
+                up = up < tn ? up : tn;
+                if (t1 > up) t1 = up;
+            }
+            if (W.tfirst < 0.0) W.tfirst = t1;
+            int kind, to = 0;
+            {
+                double v = u_type * lam;
+                if (v < rc || (rmf == 0.0 && rmr == 0.0)) kind = 1;
+                else {
+                    v -= rc;
+                    int from;
+                    if (v < rmf || rmr == 0.0) { kind = 2; from = pf; }
+                    else { kind = 3; from = pr; v -= rmf; }
+                    to = -1;
+                    for (int q = 0; q < P; ++q) {
+                        double mr = ml.MR[(ee * P + from) * P + q];
+                        if (q == from || mr == 0.0) continue;
+                        to = q;
+                        if (v < mr) break;
+                        v -= mr;
+                    }
+                }
+            }
+            record(root_active, weight, tt, t1, kind, to);
+            if (cx.vbc) cx.upd_fac *= kind == 1 ? cx.vbc[ee * P + pf] : ml.vbm[(ee * P + (kind == 2 ? pf : pr)) * P + to];
+            cx.ebuf = eb_new;
+            cx.ctr += 2;
+            if (kind == 1) {
+                W.tc = t1; W.pf = pf; W.pr = pr; W.weight = weight;
+                W.e1 = (ee + 1 < cx.E && !(t1 < cx.T[ee + 1])) ? ee + 1 : ee;
+                done = true;
+            } else {
+                PF_MPR_BUF_PUSH(t1, kind == 2 ? PF_TAG_PATH : PF_TAG_RPATH, mp_ev_byte(to, ee));
+                if (kind == 2) pf = to; else pr = to;
+                tt = t1;
+                e = ee;
+                f_fresh = false;
+            }
+        }
+        MP_CYC(cy3);
+        MP_ACC(ml, 18, cy2a, cy3);
         MP_ACC(ml, 12, 0, 1);
     }
     ml.bp = bp;
