@@ -508,10 +508,21 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
             }
         }
         ml.nm = from.nm[a];
-        for (int q = 0; q < ml.nm; ++q) {
-            LMt(ml, q) = from.Mt[(size_t)q * A.Np + a];
-            LMb(ml, q) = from.Mb[(size_t)q * A.Np + a];
-            LMq(ml, q) = from.Mq[(size_t)q * A.Np + a];
+        // eight events at a time, their loads issued before the first LDS store: a load-then-store loop pays one memory
+        // round trip per event (about a microsecond each, and a tree carries ten)
+        for (int q0 = 0; q0 < ml.nm; q0 += 8) {
+            double tv[8];
+            int8_t bv[8], qv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int q = q0 + j < ml.nm ? q0 + j : ml.nm - 1;
+                tv[j] = from.Mt[(size_t)q * A.Np + a];
+                bv[j] = from.Mb[(size_t)q * A.Np + a];
+                qv[j] = from.Mq[(size_t)q * A.Np + a];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (q0 + j < ml.nm) { LMt(ml, q0 + j) = tv[j]; LMb(ml, q0 + j) = bv[j]; LMq(ml, q0 + j) = qv[j]; }
         }
         RCtx cx;
         cx.T = mm.T; cx.I = nullptr; cx.H = nullptr; cx.E = A.E; cx.n = n; cx.L = A.L; cx.mu = A.mu; cx.rho = A.rho;
