@@ -339,117 +339,42 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
         else { bt3 = (T_); bg3 = (TAG_); bq3 = (Q_); }                                                          \
         ++nb;                                                                                                   \
     } while (0)
-    // The random numbers an event needs (one uniform for its kind, one log for the next waiting time) are drawn
-    // ahead, KP events' worth at a time, with the wavefront converged: Philox is counter-based, so numbers drawn
-    // ahead and not used cost nothing but the arithmetic -- the draw counter only advances by what was consumed.
-    // Inside the loop an event is then a division and a table lookup, and one loop serves the whole walk.
     MP_TICK(tw1);
     MP_ACC(ml, 2, tw0, tw1);
-    constexpr int KP = 2;
     bool done = false;
     (void)limit;                                          // the epoch limit of the recording is applied at count time
-    // One iteration per stretch between two changes of the configuration -- the next node of the stored tree, the next
-    // migration event on it, the next epoch with a fixed-time move -- NOT per epoch: with the lineages' populations and
-    // the number of partners fixed, the hazard of the two active lineages over [tt, tn) is a difference of the
-    // tabulated cumulative intensities, whatever epochs lie in between (the one-population walk does the same with
-    // its single table).  Only the stretch in which the unit-exponential budget runs out is walked
-    // epoch by epoch, to find the epoch of the event and its rates.
+    // A stretch lies between two changes of the configuration -- the next node of the stored tree, the next migration
+    // event on it, the next epoch with a fixed-time move -- NOT between epoch boundaries: with the lineages' populations
+    // and the number of partners fixed, the hazard of the two active lineages over [tt, tn) is a difference of the
+    // tabulated cumulative intensities, whatever epochs lie in between (the one-population walk does the same with its
+    // single table).
+    // One trip of the outer loop per EVENT of the walk, in two phases the lanes of a wavefront go through together (see
+    // rmp_coalesce in pf_mp_reg.h, the same loop on the register tree): the stretches without an event, then the event.
     for (int guard = 0; guard < 4096 && !done; ++guard) {
-        // a stretch adds at most three events (one migration, two joins): the loop below only starts a stretch with
-        // two free slots, so the list insertion never has to happen inside it
         if (nb > 1) PF_MP_FLUSH_BUFFER();
-        const unsigned long long ctr0 = ln.ctr;
-        double u_type[KP], eb_new[KP];
-#pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            u_type[k] = philox_uniform(ln.seed, ln.slot, ln.stream, ctr0 + 2 * k);
-            eb_new[k] = -dlog(philox_uniform(ln.seed, ln.slot, ln.stream, ctr0 + 2 * k + 1));
-        }
-        int used = 0;
+        const double u_type = philox_uniform(ln.seed, ln.slot, ln.stream, ln.ctr);
+        const double eb_new = -dlog(philox_uniform(ln.seed, ln.slot, ln.stream, ln.ctr + 1));
+        bool root_active = false;
+        double tn = PF_INF;
+        int weight = 0, en = e;
+        // ---- phase 1: stretches the budget outlasts
         for (int g2 = 0; g2 < 100000; ++g2) {
-            if (nb > 1) break;                            // make room in the event buffer first
             MP_ACC(ml, 13, 0, 1);
-            const bool root_active = tt >= Hr;
+            if (nb > 1) PF_MP_FLUSH_BUFFER();             // joins may have queued events (rare)
+            root_active = tt >= Hr;
             const double tj = ml.TJ[e];
-            double tn = nS < eT ? nS : eT;
+            tn = nS < eT ? nS : eT;
             tn = tn < tj ? tn : tj;
             const int k = count_of(pf);
-            const int weight = k + ((root_active && pr == pf) ? 1 : 0);
-            int en = e;
-            bool quiet = false;                           // no event before tn
-            if (tn < PF_INF) {
-                while (en + 1 < ln.E && ln.T[en + 1] <= tn) ++en;
-                double need = (double)weight * (ci(pf, en, tn) - ci(pf, e, tt)) + (cm(pf, en, tn) - cm(pf, e, tt));
-                if (root_active) need = need + (cm(pr, en, tn) - cm(pr, e, tt));
-                if (ln.ebuf > need) { ln.ebuf -= need; quiet = true; }
-            }
-            if (!quiet) {
-                // ---- the budget runs out in this stretch: the epoch of the event is the number of epoch starts of the
-                // stretch the budget still reaches (the hazard up to an epoch start is the same difference of cumulative
-                // intensities as `need`, so it ascends with the epoch), then one division inside that epoch
-                if (used == KP) break;                    // out of pre-drawn numbers: draw more, then carry on
-                const double f0c = ci(pf, e, tt), f0m = cm(pf, e, tt), f0r = root_active ? cm(pr, e, tt) : 0.0;
-                const int elim = tn < PF_INF ? en : ln.E - 1;
-                int ee = e;
-                double gee = 0.0;
-                while (ee < elim) {
-                    double g = (double)weight * (ml.CI[(ee + 1) * P + pf] - f0c) + (ml.CM[(ee + 1) * P + pf] - f0m);
-                    if (root_active) g = g + (ml.CM[(ee + 1) * P + pr] - f0r);
-                    if (!(ln.ebuf > g)) break;
-                    gee = g;
-                    ++ee;
-                }
-                const double rc = (double)weight * ml.I2[ee * P + pf];
-                const double rmf = ml.MT[ee * P + pf];
-                const double rmr = root_active ? ml.MT[ee * P + pr] : 0.0;
-                const double lam = (rc + rmf) + rmr;
-                if (lam == 0.0) { if (!ml.err) ml.err = 3; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
-                double t1 = ee == e ? tt + ln.ebuf / lam : ln.T[ee] + (ln.ebuf - gee) / lam;
-                {
-                    double up = epoch_end(ln, ee);
-                    up = up < tn ? up : tn;
-                    if (t1 > up) t1 = up;
-                }
-                {
-                    if (W.tfirst < 0.0) W.tfirst = t1;
-                    const double ut = used == 0 ? u_type[0] : u_type[1];
-                    int kind, to = 0;
-                    {
-                        double v = ut * lam;
-                        if (v < rc || (rmf == 0.0 && rmr == 0.0)) kind = 1;
-                        else {
-                            v -= rc;
-                            int from;
-                            if (v < rmf || rmr == 0.0) { kind = 2; from = pf; }
-                            else { kind = 3; from = pr; v -= rmf; }
-                            to = -1;
-                            for (int q = 0; q < P; ++q) {
-                                double mr = ml.MR[(ee * P + from) * P + q];
-                                if (q == from || mr == 0.0) continue;
-                                to = q;
-                                if (v < mr) break;
-                                v -= mr;
-                            }
-                        }
-                    }
-                    record(root_active, weight, tt, t1, kind, to);
-                    if (ln.vbc) ln.upd_fac *= kind == 1 ? ln.vbc[ee * P + pf] : ml.vbm[(ee * P + (kind == 2 ? pf : pr)) * P + to];
-                    ln.ebuf = used == 0 ? eb_new[0] : eb_new[1];
-                    ++used;
-                    if (kind == 1) {
-                        W.tc = t1; W.pf = pf; W.pr = pr; W.weight = weight;
-                        W.e1 = (ee + 1 < ln.E && !(t1 < ln.T[ee + 1])) ? ee + 1 : ee;       // an event placed at the end of its epoch counts in the next
-                        done = true;
-                        break;
-                    }
-                    PF_MP_BUF_PUSH(t1, kind == 2 ? PF_TAG_PATH : PF_TAG_RPATH, mp_ev_byte(to, ee));
-                    if (kind == 2) pf = to; else pr = to;
-                    tt = t1;
-                    e = ee;
-                    continue;
-                }
-            }
-            // ---- the configuration changes at tn: node or event of the stored tree, or a fixed-time move
+            weight = k + ((root_active && pr == pf) ? 1 : 0);
+            en = e;
+            if (!(tn < PF_INF)) break;                    // nothing above but the event
+            while (en + 1 < ln.E && ln.T[en + 1] <= tn) ++en;
+            double need = (double)weight * (ci(pf, en, tn) - ci(pf, e, tt)) + (cm(pf, en, tn) - cm(pf, e, tt));
+            if (root_active) need = need + (cm(pr, en, tn) - cm(pr, e, tt));
+            if (!(ln.ebuf > need)) break;                 // the event falls into this stretch
+            ln.ebuf -= need;
+            // the configuration changes at tn: node or event of the stored tree, or a fixed-time move
             record(root_active, weight, tt, tn, 0, 0);
             const bool at_join = !(tn < tj);
             tt = tn;
@@ -463,9 +388,70 @@ __device__ __forceinline__ void mp_coalesce(Lane& ln, MLane& ml, int ni, int roo
                     if (qr != pr) { PF_MP_BUF_PUSH(tt, PF_TAG_RPATH, mp_ev_byte(qr, e)); pr = qr; }
                 }
             }
-            if (ml.err) { W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
+            if (ml.err) break;
         }
-        ln.ctr = ctr0 + 2 * (unsigned long long)used;
+        if (ml.err) { W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
+        // ---- phase 2: the event, in the stretch [tt, tn): its epoch is the number of epoch starts of the stretch the
+        // budget still reaches (the hazard up to an epoch start is the same difference of cumulative intensities as
+        // `need`, so it ascends with the epoch), then one division inside that epoch
+        {
+            const double f0c = ci(pf, e, tt), f0m = cm(pf, e, tt), f0r = root_active ? cm(pr, e, tt) : 0.0;
+            const int elim = tn < PF_INF ? en : ln.E - 1;
+            int ee = e;
+            double gee = 0.0;
+            while (ee < elim) {
+                double g = (double)weight * (ml.CI[(ee + 1) * P + pf] - f0c) + (ml.CM[(ee + 1) * P + pf] - f0m);
+                if (root_active) g = g + (ml.CM[(ee + 1) * P + pr] - f0r);
+                if (!(ln.ebuf > g)) break;
+                gee = g;
+                ++ee;
+            }
+            const double rc = (double)weight * ml.I2[ee * P + pf];
+            const double rmf = ml.MT[ee * P + pf];
+            const double rmr = root_active ? ml.MT[ee * P + pr] : 0.0;
+            const double lam = (rc + rmf) + rmr;
+            if (lam == 0.0) { if (!ml.err) ml.err = 3; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
+            double t1 = ee == e ? tt + ln.ebuf / lam : ln.T[ee] + (ln.ebuf - gee) / lam;
+            {
+                double up = epoch_end(ln, ee);
+                up = up < tn ? up : tn;
+                if (t1 > up) t1 = up;
+            }
+            if (W.tfirst < 0.0) W.tfirst = t1;
+            int kind, to = 0;
+            {
+                double v = u_type * lam;
+                if (v < rc || (rmf == 0.0 && rmr == 0.0)) kind = 1;
+                else {
+                    v -= rc;
+                    int from;
+                    if (v < rmf || rmr == 0.0) { kind = 2; from = pf; }
+                    else { kind = 3; from = pr; v -= rmf; }
+                    to = -1;
+                    for (int q = 0; q < P; ++q) {
+                        double mr = ml.MR[(ee * P + from) * P + q];
+                        if (q == from || mr == 0.0) continue;
+                        to = q;
+                        if (v < mr) break;
+                        v -= mr;
+                    }
+                }
+            }
+            record(root_active, weight, tt, t1, kind, to);
+            if (ln.vbc) ln.upd_fac *= kind == 1 ? ln.vbc[ee * P + pf] : ml.vbm[(ee * P + (kind == 2 ? pf : pr)) * P + to];
+            ln.ebuf = eb_new;
+            ln.ctr += 2;
+            if (kind == 1) {
+                W.tc = t1; W.pf = pf; W.pr = pr; W.weight = weight;
+                W.e1 = (ee + 1 < ln.E && !(t1 < ln.T[ee + 1])) ? ee + 1 : ee;       // an event placed at the end of its epoch counts in the next
+                done = true;
+            } else {
+                PF_MP_BUF_PUSH(t1, kind == 2 ? PF_TAG_PATH : PF_TAG_RPATH, mp_ev_byte(to, ee));
+                if (kind == 2) pf = to; else pr = to;
+                tt = t1;
+                e = ee;
+            }
+        }
         MP_ACC(ml, 12, 0, 1);
     }
     if (!done) { if (!ml.err) ml.err = 3; W.tc = tt; W.pf = pf; W.pr = pr; W.weight = 0; return; }
