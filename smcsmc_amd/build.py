@@ -43,6 +43,16 @@ def build_lib(force=False):
     return LIB
 
 
+def build_stamps_lib(force=False):
+    """The profiling build of the library (-DPF_STAMPS: wall-clock stamps per wavefront, row and phase of the extend
+    workgroups, read back through pf_debug_stamps).  Used by profiles/stamps.py and profiles/stamps_mp.py only."""
+    out = os.path.join(CSRC, "libsmcsmc_pf_stamps.so")
+    units = [os.path.join(CSRC, "pf_hip.hip"), os.path.join(CSRC, "pf_mp.hip")]
+    if force or _stale(out, units + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]):
+        subprocess.check_call([_hipcc()] + HIPCC_FLAGS + ["-DPF_STAMPS", "-shared", "-o", out] + units)
+    return out
+
+
 def build_all(force=False):
     lib = build_lib(force)
     host = os.path.join(CSRC, "host")

@@ -219,6 +219,7 @@ static void pfARG_core(PfParam& P, const HostModel& M0, int device, const ChunkJ
     std::vector<int8_t> state, alleles;
     std::vector<int32_t> mre;
     P.segments->pack(lags, start, length, state, alleles, mre);
+    if (P.record_all) std::fill(mre.begin(), mre.end(), E - 1);
     pf_segments sg = {(int64_t)start.size(), start.data(), length.data(), state.data(), alleles.data(), mre.data()};
 
     // auxiliary particle filter: look-ahead per row + terminal branch length quantiles (smcsmc.cpp:288, 128-166)

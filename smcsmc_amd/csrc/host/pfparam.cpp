@@ -296,6 +296,11 @@ const std::vector<DriverOption>& driver_options() {
         // not a reference flag: room for migration events on one local tree (the reference's node list is unbounded)
         {"-migcap", "INT", "Several populations", "Migration events one local tree may hold; about 230 fit the LDS with 32 epochs [ 96 ]",
          [](PfParam& p, const std::string& v) { p.mig_cap = convert<int>("-migcap", v); if (p.mig_cap < 1) throw OutOfRange("-migcap", v); }},
+        // not a reference flag: keep recording events however far the next informative site is.  The surveyed reference stops
+        // recording epoch e beyond half a lag from data (max_epoch_to_update, smcsmc.cpp:266-275), which on an all-missing
+        // file leaves almost nothing to count; its no-data regression bands predate that rule
+        {"-record_all", "", "Inference tuning", "Record events in every epoch at every row (no limit far from data)",
+         [](PfParam& p, const std::string&) { p.record_all = true; }},
         // not reference flags: print what the host side made of the input, as JSON, and exit (used by the tests)
         {"-dumpmodel", "", nullptr, "", [](PfParam& p, const std::string&) { p.dump_model = true; }},
         {"-dumplookahead", "", nullptr, "", [](PfParam& p, const std::string&) { p.dump_lookahead = true; }},

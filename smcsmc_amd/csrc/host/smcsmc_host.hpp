@@ -205,6 +205,7 @@ class PfParam {
     std::string out_prefix = "smcsmc", seg_path, guide_path, pattern;
     std::vector<EpochRange> exclude_recomb, exclude_coalmigr;
     int chunks = 1, ranks = 0, devices = 0;          // several chunks in one process (main.cpp: run_chunks)
+    bool record_all = false;                         // -record_all: no recording limit far from data
     int mig_cap = 0;                                 // -migcap: pf_params.mig_cap (0 = the library's default)
     std::string reduce_transport;                    // "rccl" / "host" / "" = choose
     double segment_cap() const;                      // rows longer than this many bases are cut (pfparam.cpp:364)

@@ -36,6 +36,19 @@ CLASSES = [
     ("test_const_pop_size", "TestConstPopSize_FourEpochs_FalseStart", "test_const_pop_size.py:232-246"),
     ("test_const_pop_size", "TestConstPopSize_Migration", "test_const_pop_size.py:249-318"),
     ("test_two_pops", "TestTwoPopsSplitUniDirMigr", "test_two_pops.py:51-119"),
+    # the remaining classes with committed data: the no-data focused-sampling checks (the reference's direct test of
+    # biased tree-point sampling with delayed importance weights, with min-ESS targets) ...
+    ("test_bias_nodata", "TestBias_00_NoBias", "test_bias_nodata.py:15-49"),
+    ("test_bias_nodata", "TestBias_01_Bias2", "test_bias_nodata.py:53-63"),
+    ("test_bias_nodata", "TestBias_02_Bias5", "test_bias_nodata.py:67-78"),
+    ("test_bias_nodata", "TestBias_0_Migr_NoBias", "test_bias_nodata.py:81-122"),
+    ("test_bias_nodata", "TestBias_1_Migr_Bias2", "test_bias_nodata.py:126-136"),
+    # ... and the other two-population split scenarios (30 Mb, 5 E-steps each)
+    ("test_two_pops", "TestTwoPopsSplitUniDirMigrInRecentEpoch", "test_two_pops.py:234-301"),
+    ("test_two_pops", "TestTwoPopsSplitUniDirMigrInMidEpoch", "test_two_pops.py:303-371"),
+    ("test_two_pops", "TestTwoPopsSplitUniDirMigr_bs3", "test_two_pops.py:376-424"),
+    ("test_two_pops", "TestTwoPopsSplitUniDirMigrInRecentEpoch_bs3", "test_two_pops.py:429-477"),
+    ("test_two_pops", "TestTwoPopsSplitUniDirMigrInMidEpoch_bs3", "test_two_pops.py:481-529"),
 ]
 
 
@@ -48,7 +61,7 @@ def load_modules():
     ctx.execute = importlib.import_module("smcsmc.execute")
     sys.modules["context"] = ctx
     sys.path.insert(0, NEWTESTS)
-    return {m: importlib.import_module(m) for m in ("test_const_pop_size", "test_two_pops")}
+    return {m: importlib.import_module(m) for m in ("test_const_pop_size", "test_two_pops", "test_bias_nodata")}
 
 
 def binary_argv(cmd):
