@@ -51,7 +51,9 @@ typedef struct pf_model {
     /* focused sampling + delayed importance weights (particle.cpp:866-891, 1020-1126; particle.hpp:59-101, 185-209);
      * n_bias_heights == 0 switches it off */
     int32_t n_bias_heights;      /* k interior band boundaries (-bias_heights, generations) */
-    int32_t delay_type;          /* PfParam::ResampleDelayType: 0 recombination, 1 coalescence, 2 coal/migr */
+    int32_t delay_type;          /* PfParam::ResampleDelayType: 0 recombination, 1 coalescence, 2 coal/migr; + 4 (not a reference
+                                  * option): importance factors of events above the focused band are delayed like the others
+                                  * instead of applied at once (particle.cpp:878-885 left out) */
     const double* bias_heights;  /* [k] */
     const double* bias_strengths;/* [k+1] */
     const double* application_delays; /* [E] Model::application_delays (smcsmc.cpp:306-307) */

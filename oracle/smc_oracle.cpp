@@ -1469,11 +1469,15 @@ struct Filter {
                     double iw = last_iw;
                     double rbiw = last_rbiw;                       /* without a guide both weights coincide */
                     /* RESAMPLE_DELAY_RECOMB: the cut height; _COAL: first_coal_height_; _COALMIGR: first_event_height_ */
-                    double delay_height = M.delay_type == 0 ? h : (M.delay_type == 2 ? last_first_event : last_tc);
+                    const int dtype = M.delay_type & 3;
+                    double delay_height = dtype == 0 ? h : (dtype == 2 ? last_first_event : last_tc);
                     int idx = 0;
                     while (idx + 1 < (int)M.bias_H.size() && M.bias_H[idx + 1] < delay_height) ++idx;
                     if (idx >= (int)M.bias_S.size()) idx = (int)M.bias_S.size() - 1;
-                    if (M.bias_S[idx] == 1.0) {
+                    /* delay_type bit 2 (an experiment switch of the oracle, not a reference option): every factor goes
+                     * through the delayed store, as on the branch the two-population bands were calibrated on
+                     * ("2b3a_wo_apply_immediately_hack", test_two_pops.py:50) */
+                    if (M.bias_S[idx] == 1.0 && !(M.delay_type & 4)) {
                         p.w_post *= rbiw; p.w_pilot *= rbiw;
                         iw /= rbiw;
                     }

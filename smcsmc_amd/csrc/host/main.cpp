@@ -192,7 +192,7 @@ static void pfARG_core(PfParam& P, const HostModel& M0, int device, const ChunkJ
             app_delays[e] = med[e] * P.delay;                                 // Model::lags_to_application_delays
             if (P.delay > 0) clog << " Application delay for epoch " << e << " set to " << app_delays[e] << endl;
         }
-        pm.delay_type = P.delay_type;
+        pm.delay_type = P.delay_type | (P.delay_all ? 4 : 0);
         pm.application_delays = app_delays.data();
     }
     if (guided) {          // PfParam::setModelRates (pfparam.cpp:383-388)
@@ -204,7 +204,7 @@ static void pfARG_core(PfParam& P, const HostModel& M0, int device, const ChunkJ
     }
     if (biased) {
         pm.n_bias_heights = (int32_t)M.bias_heights.size();
-        pm.delay_type = P.delay_type;
+        pm.delay_type = P.delay_type | (P.delay_all ? 4 : 0);
         pm.bias_heights = M.bias_heights.data();
         pm.bias_strengths = M.bias_strengths.data();
         pm.application_delays = app_delays.data();

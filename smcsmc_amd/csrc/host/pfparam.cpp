@@ -270,6 +270,11 @@ const std::vector<DriverOption>& driver_options() {
          [](PfParam& p, const std::string&) { p.delay_type = 1; }},
         {"-delay_migr", "", "Inference tuning", "Delay by the first coalescence or migration height",
          [](PfParam& p, const std::string&) { p.delay_type = 2; }},
+        // not a reference flag: the block that applies the importance factor of an event above the focused band at once
+        // (particle.cpp:878-885) is left out, as on the branch the reference's two-population bands were calibrated on
+        // ("2b3a_wo_apply_immediately_hack", test_two_pops.py:50)
+        {"-delay_all", "", "Inference tuning", "Delay every importance factor of focused sampling, also above the focused band",
+         [](PfParam& p, const std::string&) { p.delay_all = true; }},
         {"-tmax", "FLT", "Inference tuning", "Maximum tree height, in unit of 4N0 [ 2 ]",
          [](PfParam& p, const std::string& v) { p.tmax = convert<double>("-tmax", v); }},
         {"-p", "STR", "Inference tuning", "Pattern of time segments, e.g. 1*3+15*4+1",

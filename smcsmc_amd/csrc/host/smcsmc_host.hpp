@@ -205,6 +205,7 @@ class PfParam {
     std::string out_prefix = "smcsmc", seg_path, guide_path, pattern;
     std::vector<EpochRange> exclude_recomb, exclude_coalmigr;
     int chunks = 1, ranks = 0, devices = 0;          // several chunks in one process (main.cpp: run_chunks)
+    bool delay_all = false;                          // -delay_all: pf_model.delay_type bit 2
     bool record_all = false;                         // -record_all: no recording limit far from data
     int mig_cap = 0;                                 // -migcap: pf_params.mig_cap (0 = the library's default)
     std::string reduce_transport;                    // "rccl" / "host" / "" = choose

@@ -221,11 +221,11 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
                 if (biased) {
                     // particle.cpp:866-891: immediate vs delayed application of the importance weight
                     const int nbands = A.n_bias + 1;
-                    const double delay_height = A.delay_type == 0 ? h : tc;
+                    const double delay_height = (A.delay_type & 3) == 0 ? h : tc;
                     int idx = 0;
                     while (idx + 1 < nbands + 1 && sBH[idx + 1] < delay_height) ++idx;
                     if (idx >= nbands) idx = nbands - 1;
-                    if (sBS[idx] == 1.0) { w_post *= rbiw; w_pilot *= rbiw; iw /= rbiw; }
+                    if (sBS[idx] == 1.0 && !(A.delay_type & 4)) { w_post *= rbiw; w_pilot *= rbiw; iw /= rbiw; }   // bit 2: every factor delayed (pf_model.delay_type)
                     const double delay = A.app_delays[epoch_of(ln, delay_height)];
                     d_adjust_with_delay(ds, w_post, w_pilot, iw, delay, updated_to);
                 }
@@ -886,11 +886,11 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
                 if (BIASED) {
                     // particle.cpp:866-891: immediate vs delayed application of the importance weight
                     double iw = cx.last_iw, rbiw = cx.last_rbiw;
-                    double delay_height = A.delay_type == 0 ? h : tc;
+                    double delay_height = (A.delay_type & 3) == 0 ? h : tc;
                     int idx = 0;
                     while (idx + 1 < cx.nb + 1 && sBH[idx + 1] < delay_height) ++idx;
                     if (idx >= cx.nb) idx = cx.nb - 1;
-                    if (sBS[idx] == 1.0) { w_post *= rbiw; w_pilot *= rbiw; iw /= rbiw; }
+                    if (sBS[idx] == 1.0 && !(A.delay_type & 4)) { w_post *= rbiw; w_pilot *= rbiw; iw /= rbiw; }   // bit 2: every factor delayed (pf_model.delay_type)
                     double delay = A.app_delays[r_epoch_of(cx, delay_height)];
                     d_adjust_with_delay(ds, w_post, w_pilot, iw, delay, updated_to);
                 }

@@ -275,11 +275,11 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
                 if (biased) {
                     // particle.cpp:866-891: immediate vs delayed application of the importance weight
                     const int nbands = A.n_bias + 1;
-                    const double delay_height = A.delay_type == 0 ? h : (A.delay_type == 2 ? tfirst : tc);
+                    const double delay_height = (A.delay_type & 3) == 0 ? h : ((A.delay_type & 3) == 2 ? tfirst : tc);
                     int idx = 0;
                     while (idx + 1 < nbands + 1 && sBH[idx + 1] < delay_height) ++idx;
                     if (idx >= nbands) idx = nbands - 1;
-                    if (sBS[idx] == 1.0) { w_post *= rbiw; w_pilot *= rbiw; iw /= rbiw; }
+                    if (sBS[idx] == 1.0 && !(A.delay_type & 4)) { w_post *= rbiw; w_pilot *= rbiw; iw /= rbiw; }   // bit 2: every factor delayed (pf_model.delay_type)
                     const double delay = A.app_delays[epoch_of(ln, delay_height)];
                     d_adjust_with_delay(ds, w_post, w_pilot, iw, delay, updated_to);
                 }
@@ -678,11 +678,11 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
                 if (biased) {
                     // particle.cpp:866-891: immediate vs delayed application of the importance weight
                     const int nbands = A.n_bias + 1;
-                    const double delay_height = A.delay_type == 0 ? h : (A.delay_type == 2 ? tfirst : tc);
+                    const double delay_height = (A.delay_type & 3) == 0 ? h : ((A.delay_type & 3) == 2 ? tfirst : tc);
                     int idx = 0;
                     while (idx + 1 < nbands + 1 && sBH[idx + 1] < delay_height) ++idx;
                     if (idx >= nbands) idx = nbands - 1;
-                    if (sBS[idx] == 1.0) { w_post *= rbiw; w_pilot *= rbiw; iw /= rbiw; }
+                    if (sBS[idx] == 1.0 && !(A.delay_type & 4)) { w_post *= rbiw; w_pilot *= rbiw; iw /= rbiw; }   // bit 2: every factor delayed (pf_model.delay_type)
                     const double delay = A.app_delays[r_epoch_of(cx, delay_height)];
                     d_adjust_with_delay(ds, w_post, w_pilot, iw, delay, updated_to);
                 }

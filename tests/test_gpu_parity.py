@@ -266,7 +266,7 @@ def test_binary_end_to_end_matches_library_and_front_end_contract(oracle, hiplib
     assert d[(("Delay", -1, -1, -1, -1), "Count")] > 0
 
 
-@pytest.mark.parametrize("n,delay_type", [(4, 0), (2, 1), (6, 0), (12, 0), (10, 1)])
+@pytest.mark.parametrize("n,delay_type", [(4, 0), (2, 1), (6, 0), (12, 0), (10, 1), (4, 4), (12, 5)])   # + 4: every factor delayed
 def test_focused_sampling_and_delayed_importance_weights(oracle, hiplib, n, delay_type):
     """-bias_heights / -bias_strengths with delayed application of the importance weights
     (particle.cpp:866-891, 1020-1126; particle.hpp:59-101, 185-209): the configuration of the reference's own

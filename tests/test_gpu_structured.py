@@ -229,7 +229,7 @@ def test_structured_binary_end_to_end(hiplib, tmp_path):
 
 
 @pytest.mark.parametrize("lds_tree", [False, True])
-@pytest.mark.parametrize("n,P,delay_type", [(4, 2, 0), (8, 2, 0), (6, 3, 1), (4, 2, 2)])
+@pytest.mark.parametrize("n,P,delay_type", [(4, 2, 0), (8, 2, 0), (6, 3, 1), (4, 2, 2), (8, 2, 4)])
 def test_focused_sampling_with_structure_parity(oracle, hiplib, n, P, delay_type, lds_tree):
     """-bias_heights / -bias_strengths with several populations (the configuration of the reference's own two-population
     regression tests, test_two_pops.py:36-37): biased cut point on the LDS tree, delayed importance weights, resampling
