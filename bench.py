@@ -223,13 +223,16 @@ def main():
                     help="synthetic data from the numpy simulator (round-1 inputs) instead of the device-side simulator")
     ap.add_argument("--uncalibrated-lags", action="store_true",
                     help="the reference's uncalibrated lags 4/(rho*top_t) instead of the calibrated default of the binary")
-    ap.add_argument("--debug", type=int, default=0, help="pf_params.debug bits (include/smcsmc_pf.h): 4 no counting, 8 two launches per row")
+    ap.add_argument("--debug", type=int, default=0, help="pf_params.debug bits (include/smcsmc_pf.h): 4 no counting, 8 two launches per row, 16 k_pipe instead of k_sweep")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a single-GPU box: every rank uses device 0 and the collectives go through gloo "
                          "on host tensors (RCCL refuses two ranks on one device); the numbers it prints are not a scaling result")
     ap.add_argument("--chunks-per-gpu", type=int, default=1,
-                    help="independent chunks filtered concurrently on each GPU (one host thread + stream each); "
+                    help="independent chunks filtered concurrently on each GPU, all in one launch per row (pf_run_many); "
                          "1 = the headline single-chunk configuration")
+    ap.add_argument("--count-wgs", type=int, default=0, help="pf_params.count_wgs: count workgroups per epoch in the row pipeline (0 = default)")
+    ap.add_argument("--chunk-threads", action="store_true",
+                    help="with --chunks-per-gpu: one host thread and stream per chunk (rounds 1 and 2) instead of pf_run_many")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -260,7 +263,7 @@ def main():
     for k in range(C):
         model, segs = build_workload(args, seed=args.seed + rank * C + k)     # independent chunks
         f = ParticleFilter(model, args.np, ess_fraction=0.5, seed=args.seed + 1000 * (rank * C + k), max_trace_events=0,
-                           device=dev, local_recomb=not args.no_local_recomb, debug=args.debug)
+                           device=dev, local_recomb=not args.no_local_recomb, debug=args.debug, count_wgs=args.count_wgs)
         f.load_segments(segs)
         chunks.append((f, segs))
     pf, segs = chunks[0]
@@ -271,9 +274,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    many = C > 1 and not args.chunk_threads and args.pops == 1 and args.nsam <= 8 and not (args.debug & (8 | 16))
+
     def sweep_all():
         if C == 1:
             run_sweep(pf, segs)
+            return
+        if many:
+            for f, sg in chunks:
+                f.init_prior(float(sg["start"][0]))
+            ParticleFilter.run_many([f for f, _ in chunks])
+            for f, _ in chunks:
+                f.finish()
             return
         th = [threading.Thread(target=run_sweep, args=(f, sg)) for f, sg in chunks]
         for t in th:
@@ -356,8 +368,8 @@ def main():
                        "populations": args.pops, "local_recombination_map": not args.no_local_recomb,
                        "segments_per_chunk": n_segments, "nsam": args.nsam, "np": args.np,
                        "sequence_length": args.length, "epochs": args.epochs,
-                       "parallelism": "%d chunk(s) per gpu x %d gpu(s)" % (C, world), "log_likelihood_sum": logl_sum},
-            "roofline": {"bound": "hbm", "kernel": "k_pipe (one launch per row: extend workgroups; bookkeeping, ledger and counts ride along)" if args.pops == 1 and args.nsam <= 8 and not (args.debug & 8) else ("k_row" if args.pops == 1 and args.nsam <= 8 else ("k_extend_mpr (register tree, completes the previous row while loading)" if args.nsam <= 8 and not (args.debug & 3) else "k_extend_mp") if args.pops > 1 else "k_extend"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "parallelism": "%d chunk(s) per gpu%s x %d gpu(s)" % (C, (", one launch per row for all of them" if many else ", one host thread and stream each") if C > 1 else "", world), "log_likelihood_sum": logl_sum},
+            "roofline": {"bound": "hbm", "kernel": ("k_pipe" if args.debug & 16 else "k_sweep") + " (one launch per row: extend workgroups; bookkeeping, ledger and counts ride along)" if args.pops == 1 and args.nsam <= 8 and not (args.debug & 8) else ("k_row" if args.pops == 1 and args.nsam <= 8 else ("k_extend_mpr (register tree, completes the previous row while loading)" if args.nsam <= 8 and not (args.debug & 3) else "k_extend_mp") if args.pops > 1 else "k_extend"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_us": avg_ext_us,
                          "kernel_ms_estimate": {k: v[0] for k, v in kt.items()},

@@ -15,6 +15,8 @@
  *   pf_resample          ParticleContainer::resample (particleContainer.cpp:247-311)
  *   pf_run               the do-while of pfARG_core (smcsmc.cpp:324-360) over a segment range,
  *                        enqueued without host round trips
+ *   pf_run_many          the same loop for the chunks the front-end starts side by side, one process each
+ *                        (smcsmc/model.py:1094-1098): one launch per row covers all of them
  *   pf_finish            final normalize_probability + lag-free flush (smcsmc.cpp:371-373)
  *   pf_get_counts        CountModel totals consumed by log_counts (count.cpp:66-158)
  *   pf_logl              ParticleContainer::ln_normalization_factor (particleContainer.hpp)
@@ -90,11 +92,16 @@ typedef struct pf_params {
                                   * unbounded); 0 = 96.  The lists live in LDS next to the epoch tables: about 230 fit with
                                   * 32 epochs and two populations, pf_create says when a value does not.  One too many on
                                   * any tree is a reported error ("too many migration events on one local tree"). */
+    int32_t count_wgs;           /* row pipeline: workgroups per epoch that share the lagged counting of a row (0 = 8; at
+                                  * most one per 256 particles).  The sums are grouped by workgroup, so the value is part
+                                  * of what makes two runs bit-identical. */
+    int32_t reserved3;
 } pf_params;
 #define PF_DEBUG_FORCE_LDS 1     /* run the LDS-tree kernels whatever nsam is */
 #define PF_DEBUG_NO_FUSE   2     /* complete every row with the stand-alone k_resample (two-stream pipeline) */
 #define PF_DEBUG_NO_COUNT  4     /* profiling: skip the lagged counting and the ledger upkeep */
 #define PF_DEBUG_TWO_LAUNCH 8    /* rows as two launches (extend + decide) instead of the single-launch pipeline */
+#define PF_DEBUG_K_PIPE   16     /* rows through k_pipe (argument block passed by value, windows from the host) instead of k_sweep */
 
 typedef struct pf_segments {
     int64_t n;
@@ -175,6 +182,11 @@ int pf_count(pf_handle* h, int64_t s, int end_data);
 int pf_resample(pf_handle* h, int64_t s);
 /* the hot loop over segments [s_begin, s_end): update -> count -> resample per segment */
 int pf_run(pf_handle* h, int64_t s_begin, int64_t s_end);
+/* the same loop for several chunks at once: rows [s_begin, s_end) of n_handles independent filters (one per chromosome
+ * chunk; same device, particle count, haplotypes, epochs and options) step in lockstep through one kernel launch per row
+ * whose grid covers all of them.  The reference starts one process per chunk, all at once (smcsmc/model.py:1094-1098);
+ * every chunk's results are bit-identical to its own pf_run.  A chunk that runs out of rows simply stops. */
+int pf_run_many(pf_handle* const* handles, int32_t n_handles, int64_t s_begin, int64_t s_end);
 int pf_finish(pf_handle* h);
 int pf_sync(pf_handle* h);
 

@@ -3,6 +3,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -119,8 +120,6 @@ static uint64_t base_seed(const HostModel& M) {
     return M.seed_set ? M.seed : from_clock;
 }
 
-static void report_counts(PfParam& P, const HostModel& M0, const std::vector<double>& packed, double chunks);
-
 // what the chunks of one E-step share: the lag calibration depends on the model only (done once per iteration), and
 // every chunk hands its raw sufficient statistics back instead of writing the rows itself
 struct ChunkJob {
@@ -130,8 +129,20 @@ struct ChunkJob {
     uint64_t seed_offset = 0;                          // + chunk index, the rule of smcsmc_amd/em.py
 };
 
-// pfARG_core (smcsmc.cpp:278-401): one E-step over the chunk
-static void pfARG_core(PfParam& P, const HostModel& M0, int device, const ChunkJob* job = nullptr) {
+// One chunk's filter between its creation and the collection of its results: pfARG_core (smcsmc.cpp:278-401) in three
+// steps -- open_filter (everything up to the initial particles), the rows (pf_run, or pf_run_many for several chunks in
+// lockstep on one device), close_filter (final flush, outputs, statistics).
+struct ChunkFilter {
+    PfParam* P = nullptr;
+    pf_handle* h = nullptr;
+    int E = 0, NP = 1;
+    int64_t rows = 0;
+    std::vector<double> start, length;       // row table as loaded (progress report, .resample)
+    ~ChunkFilter() { if (h) pf_destroy(h); }
+};
+
+static void open_filter(ChunkFilter& F, PfParam& P, const HostModel& M0, int device, const ChunkJob* job) {
+    F.P = &P;
     HostModel& M = P.model;
     const int E = (int)M.change_times.size();
     const int NP = M.npop;
@@ -264,32 +275,60 @@ static void pfARG_core(PfParam& P, const HostModel& M0, int device, const ChunkJ
     }
     pf_handle* h = pf_create(&pm, &pp, device);
     if (!h) throw std::runtime_error(pf_last_error());
-    try {
-        pf_check(pf_load_segments(h, &sg));
-        if (P.apf_level > 0) {
-            pf_lookahead pl;
-            memset(&pl, 0, sizeof(pl));
-            pl.level = P.apf_level; pl.max_doubletons = la.max_doubletons; pl.n_quantiles = 7; pl.n = sg.n;
-            pl.first_singleton_distance = la.first_singleton_distance.data();
-            pl.relative_mutation_rate = la.relative_mutation_rate.data();
-            pl.is_singleton_unphased = la.is_singleton_unphased.data();
-            pl.n_doubletons = la.n_doubletons.data();
-            pl.doubleton_idx = la.doubleton_idx.data(); pl.doubleton_dist = la.doubleton_dist.data();
-            pl.first_split_distance = la.first_split_distance.data();
-            pl.split_alleles = la.split_alleles.data(); pl.split_count = la.split_count.data();
-            pl.quantiles = tbl_quantiles; pl.tbl_lengths = tbl_lengths.data(); pl.mean_total_branch_length = mean_tbl;
-            pf_check(pf_load_lookahead(h, &pl));
+    F.h = h; F.E = E; F.NP = NP;
+    pf_check(pf_load_segments(h, &sg));
+    if (P.apf_level > 0) {
+        pf_lookahead pl;
+        memset(&pl, 0, sizeof(pl));
+        pl.level = P.apf_level; pl.max_doubletons = la.max_doubletons; pl.n_quantiles = 7; pl.n = sg.n;
+        pl.first_singleton_distance = la.first_singleton_distance.data();
+        pl.relative_mutation_rate = la.relative_mutation_rate.data();
+        pl.is_singleton_unphased = la.is_singleton_unphased.data();
+        pl.n_doubletons = la.n_doubletons.data();
+        pl.doubleton_idx = la.doubleton_idx.data(); pl.doubleton_dist = la.doubleton_dist.data();
+        pl.first_split_distance = la.first_split_distance.data();
+        pl.split_alleles = la.split_alleles.data(); pl.split_count = la.split_count.data();
+        pl.quantiles = tbl_quantiles; pl.tbl_lengths = tbl_lengths.data(); pl.mean_total_branch_length = mean_tbl;
+        pf_check(pf_load_lookahead(h, &pl));
+    }
+    pf_check(pf_init_prior(h, start.empty() ? 0.0 : start[0]));
+    F.rows = sg.n;
+    F.start.swap(start); F.length.swap(length);
+}
+
+// the do-while of pfARG_core (smcsmc.cpp:324-360) for the filters of `group` (one, or several chunks of one device in
+// lockstep: one launch per row covers all of them, pf_run_many)
+static void run_filters(std::vector<ChunkFilter*>& group, bool progress) {
+    int64_t S = 0;
+    for (ChunkFilter* F : group) S = std::max(S, F->rows);
+    std::vector<pf_handle*> hs;
+    for (ChunkFilter* F : group) hs.push_back(F->h);
+    const ChunkFilter& F0 = *group[0];
+    const double L0 = F0.P->model.loci_length;
+    const int64_t step = 1000;
+    for (int64_t s0 = 0; s0 < S; s0 += step) {
+        const int64_t s1 = std::min(S, s0 + step);
+        if (hs.size() == 1) pf_check(pf_run(hs[0], s0, std::min(s1, F0.rows)));
+        else pf_check(pf_run_many(hs.data(), (int32_t)hs.size(), s0, s1));
+        if (progress) {
+            const int64_t r = std::min(s1, F0.rows);
+            const double end = r > 0 ? F0.start[r - 1] + F0.length[r - 1] : 0.0;
+            cout << "\r Particle filtering " << setw(4) << int((end * 100) / L0) << "% completed." << flush;
+            if (hs.size() == 1 && end >= L0) break;
         }
-        pf_check(pf_init_prior(h, start.empty() ? 0.0 : start[0]));
-        const int64_t S = sg.n;
-        const int64_t step = 1000;
-        for (int64_t s0 = 0; s0 < S; s0 += step) {
-            int64_t s1 = std::min(S, s0 + step);
-            pf_check(pf_run(h, s0, s1));
-            double end = start[s1 - 1] + length[s1 - 1];
-            cout << "\r Particle filtering " << setw(4) << int((end * 100) / M.loci_length) << "% completed." << flush;
-            if (end >= M.loci_length) break;
-        }
+    }
+}
+
+static void report_counts(PfParam& P, const HostModel& M0, const std::vector<double>& packed, double chunks);
+
+static void close_filter(ChunkFilter& F, const HostModel& M0, const ChunkJob* job) {
+    PfParam& P = *F.P;
+    HostModel& M = P.model;
+    pf_handle* h = F.h;
+    const int E = F.E, NP = F.NP;
+    const std::vector<double>& start = F.start;
+    const std::vector<double>& length = F.length;
+    {
         pf_check(pf_finish(h));
         cout << "\r Particle filtering step 100% completed." << endl;
         int64_t done = pf_num_segments_done(h);
@@ -300,7 +339,6 @@ static void pfARG_core(PfParam& P, const HostModel& M0, int device, const ChunkJ
         clog << " Inference step completed." << endl;
         if (job && job->packed_out) {        // a chunk of a multi-chunk E-step: the statistics go to the reduction
             *job->packed_out = packed;
-            pf_destroy(h);
             return;
         }
         if (P.write_resample) {
@@ -399,11 +437,16 @@ static void pfARG_core(PfParam& P, const HostModel& M0, int device, const ChunkJ
             if (gz) { gzwrite(gz, text.data(), (unsigned)text.size()); gzclose(gz); }
         }
         report_counts(P, M0, packed, 1.0);
-    } catch (...) {
-        pf_destroy(h);
-        throw;
     }
-    pf_destroy(h);
+}
+
+// pfARG_core (smcsmc.cpp:278-401): one E-step over one chunk
+static void pfARG_core(PfParam& P, const HostModel& M0, int device, const ChunkJob* job = nullptr) {
+    ChunkFilter F;
+    open_filter(F, P, M0, device, job);
+    std::vector<ChunkFilter*> one{&F};
+    run_filters(one, true);
+    close_filter(F, M0, job);
 }
 
 // log_counts + reset_model_parameters (count.cpp:44-158, 267-352) on the statistics of one E-step summed over `chunks`
@@ -490,51 +533,99 @@ static void report_counts(PfParam& P, const HostModel& M0, const std::vector<dou
 // ---- several chunks in one process -------------------------------------------------------------------------------
 // The data-parallel layer of the reference is one OS process per chromosome chunk and a sum of the chunks' .out files in
 // Python (smcsmc/model.py:563-662, 1050-1100, 1176-1184).  Here: K chunks of the window are dealt to R host threads
-// ("ranks", rank r takes chunks r, r + R, ...), rank r drives device r mod G; every rank filters its chunks from a fresh
-// prior (chunks are independent, smcsmc.cpp:296), then ONE all-gather of the packed statistics (mgpu.cpp: RCCL over xGMI
-// when every rank has its own device) and a sum in chunk order on every rank -- bit-identical for any R and G.
-static void run_chunks(PfParam& P, const HostModel& M0) {
-    const int K = P.chunks;
-    int G = P.devices > 0 ? P.devices : visible_devices();
-    if (G < 1) throw std::runtime_error("no HIP device available (there is no CPU fallback)");
-    if (G > visible_devices()) throw std::runtime_error("-devices exceeds the devices visible to this process");
-    int R = P.ranks > 0 ? P.ranks : std::min(G, K);
-    if (R > K) R = K;
-    std::string transport = P.reduce_transport.empty() ? (R <= G ? "rccl" : "host") : P.reduce_transport;
-    std::vector<int> device_of_rank(R);
-    for (int r = 0; r < R; ++r) device_of_rank[r] = r % G;
+// ("ranks", rank r takes chunks r, r + R, ...), rank r drives device r mod G.  A rank filters ITS chunks side by side:
+// all of them from a fresh prior (chunks are independent, smcsmc.cpp:296) through one kernel launch per row whose grid
+// covers them (pf_run_many) when the single-launch row pipeline applies, one after the other otherwise.  Then ONE
+// all-gather of the packed statistics (mgpu.cpp: RCCL over xGMI when every rank has its own device) and a sum in chunk
+// order on every rank -- bit-identical for any R and G.
+struct ChunkPlan {                      // what stays the same over the EM iterations of a run
+    int K = 0, R = 0, G = 0, slots = 0;
+    size_t LEN = 0;
+    std::vector<int> device_of_rank;
+    std::vector<long long> first;                       // first[c] .. first[c + 1]: the bases of chunk c
+    std::vector<std::unique_ptr<Segment>> tables;       // the chunks' row tables, read and cut once (row cap of the initial model, pfparam.cpp:364)
+    std::unique_ptr<CountAllGather> exchange;
+};
+
+static void plan_chunks(ChunkPlan& C, PfParam& P) {
+    if (P.record_trees) throw Unsupported("-arg together with -chunks / -ranks (the tree dump is that of one filter)");
+    if (P.write_resample) throw Unsupported("-record_ess together with -chunks / -ranks (one .resample file per filter)");
+    C.K = P.chunks;
+    C.G = P.devices > 0 ? P.devices : visible_devices();
+    if (C.G < 1) throw std::runtime_error("no HIP device available (there is no CPU fallback)");
+    if (C.G > visible_devices()) throw std::runtime_error("-devices exceeds the devices visible to this process");
+    C.R = P.ranks > 0 ? P.ranks : std::min(C.G, C.K);
+    if (C.R > C.K) C.R = C.K;
+    const std::string transport = P.reduce_transport.empty() ? (C.R <= C.G ? "rccl" : "host") : P.reduce_transport;
+    C.device_of_rank.resize(C.R);
+    for (int r = 0; r < C.R; ++r) C.device_of_rank[r] = r % C.G;
     const int E = (int)P.model.change_times.size();
-    const size_t LEN = (size_t)PF_COUNTS_LEN2(E, P.model.npop);
-    const int slots = (K + R - 1) / R;                          // chunks per rank (the last ranks may hold one fewer)
-    CountAllGather exchange(R, device_of_rank, (size_t)slots * LEN, transport);
-    clog << " " << K << " chunks on " << R << " rank(s), " << G << " device(s); statistics exchanged by " << exchange.transport() << endl;
-    // the window [startpos, startpos + L) in K pieces
+    C.LEN = (size_t)PF_COUNTS_LEN2(E, P.model.npop);
+    C.slots = (C.K + C.R - 1) / C.R;                    // chunks per rank (the last ranks may hold one fewer)
+    C.exchange.reset(new CountAllGather(C.R, C.device_of_rank, (size_t)C.slots * C.LEN, transport));
     const double L = P.model.loci_length;
-    std::vector<long long> first(K + 1);
-    for (int c = 0; c <= K; ++c) first[c] = (long long)P.start_position + (long long)std::floor(L * c / K);
+    C.first.resize(C.K + 1);
+    for (int c = 0; c <= C.K; ++c) C.first[c] = (long long)P.start_position + (long long)std::floor(L * c / C.K);
+    const double cap = P.segment_cap();                 // from the initial recombination rate, once
+    for (int c = 0; c < C.K; ++c)
+        C.tables.emplace_back(new Segment(P.seg_path, P.nsam, (double)(C.first[c + 1] - C.first[c]), P.nodata_theta, C.first[c], cap));
+}
+
+static void run_chunks(ChunkPlan& C, PfParam& P, const HostModel& M0) {
+    const int K = C.K, R = C.R, slots = C.slots;
+    const size_t LEN = C.LEN;
+    clog << " " << K << " chunks on " << R << " rank(s), " << C.G << " device(s); statistics exchanged by " << C.exchange->transport() << endl;
     std::vector<std::vector<double>> mine(R, std::vector<double>((size_t)slots * LEN, 0.0));
     std::vector<std::vector<double>> all(R, std::vector<double>((size_t)R * slots * LEN, 0.0));
     std::vector<std::string> failure(R);
+    // the chunks of a rank go through one launch per row when the row pipeline applies to them (include/smcsmc_pf.h, pf_run_many)
+    const bool lockstep = P.model.npop == 1 && P.model.nsam <= 8 && P.apf_level == 0;
     auto rank_main = [&](int r) {
+        bool entered = false;
         try {
+            std::vector<int> my_chunks;
+            for (int c = r; c < K; c += R) my_chunks.push_back(c);
+            std::vector<PfParam> params(my_chunks.size(), P);          // same flags and model, each its own piece of the data
+            std::vector<ChunkFilter> filters(my_chunks.size());
+            std::vector<ChunkJob> jobs(my_chunks.size());
+            std::vector<std::vector<double>> packed(my_chunks.size());
             std::vector<double> survival;
-            for (int c = r, slot = 0; c < K; c += R, ++slot) {
-                PfParam Pc = P;                                 // same flags and model, its own piece of the data
-                Pc.model.loci_length = (double)(first[c + 1] - first[c]);
-                Pc.start_position = (double)first[c];
-                Segment table(P.seg_path, P.nsam, Pc.model.loci_length, P.nodata_theta, first[c], P.segment_cap());
-                Pc.segments = &table;
-                std::vector<double> packed;
-                ChunkJob job;
-                job.survival = &survival; job.survival_out = &survival; job.packed_out = &packed; job.seed_offset = (uint64_t)c;
-                pfARG_core(Pc, M0, device_of_rank[r], &job);
-                std::copy(packed.begin(), packed.end(), mine[r].begin() + (size_t)slot * LEN);
+            for (size_t k = 0; k < my_chunks.size(); ++k) {
+                const int c = my_chunks[k];
+                params[k].model.loci_length = (double)(C.first[c + 1] - C.first[c]);
+                params[k].start_position = (double)C.first[c];
+                params[k].segments = C.tables[c].get();
+                jobs[k].survival = &survival; jobs[k].survival_out = &survival; jobs[k].packed_out = &packed[k]; jobs[k].seed_offset = (uint64_t)c;
             }
-            exchange.all_gather(r, mine[r].data(), all[r].data());
+            if (lockstep && my_chunks.size() > 1) {
+                std::vector<ChunkFilter*> group;
+                for (size_t k = 0; k < my_chunks.size(); ++k) {
+                    open_filter(filters[k], params[k], M0, C.device_of_rank[r], &jobs[k]);
+                    group.push_back(&filters[k]);
+                }
+                run_filters(group, r == 0);
+                for (size_t k = 0; k < my_chunks.size(); ++k) close_filter(filters[k], M0, &jobs[k]);
+            } else {
+                for (size_t k = 0; k < my_chunks.size(); ++k) {
+                    ChunkFilter F;
+                    open_filter(F, params[k], M0, C.device_of_rank[r], &jobs[k]);
+                    std::vector<ChunkFilter*> one{&F};
+                    run_filters(one, r == 0);
+                    close_filter(F, M0, &jobs[k]);
+                }
+            }
+            for (size_t k = 0; k < my_chunks.size(); ++k) std::copy(packed[k].begin(), packed[k].end(), mine[r].begin() + k * LEN);
+            entered = true;
+            C.exchange->all_gather(r, mine[r].data(), all[r].data());
         } catch (const std::exception& e) {
             failure[r] = e.what();
-            // the other ranks still wait at the exchange: contribute zeros so that they can leave and report
-            try { exchange.all_gather(r, mine[r].data(), all[r].data()); } catch (...) {}
+        } catch (...) {
+            failure[r] = "unknown failure";
+        }
+        if (!failure[r].empty() && !entered) {
+            // the other ranks wait at the exchange: contribute zeros so that they can leave and report.  (A rank that
+            // failed inside the exchange has already taken part in it: calling it again would leave an unmatched collective.)
+            try { C.exchange->all_gather(r, mine[r].data(), all[r].data()); } catch (...) {}
         }
     };
     std::vector<std::thread> pool;
@@ -565,11 +656,13 @@ int main(int argc, char* argv[]) {
         if (P.dump_segments) { dump_segments_json(P); return EXIT_SUCCESS; }
         P.write_out_header();
         const HostModel initial_model = P.model;        // what CountModel is constructed from (smcsmc.cpp:77)
+        ChunkPlan chunk_plan;
+        if (P.chunks > 1 || P.ranks > 1) plan_chunks(chunk_plan, P);
         for (int i = 0; i <= P.em_iterations; i++) {
             clog << "EM step " << i << endl;
             int device = 0;
             if (const char* d = getenv("SMCSMC_DEVICE")) device = atoi(d);      // which device a single-chunk run uses
-            if (P.chunks > 1 || P.ranks > 1) run_chunks(P, initial_model);
+            if (P.chunks > 1 || P.ranks > 1) run_chunks(chunk_plan, P, initial_model);
             else pfARG_core(P, initial_model, device);
             // the model the next E-step runs under (Model::addPopulationSize / addMigrationRate / setRecombinationRate)
             P.model.pop_sizes = P.next_sizes; P.model.mig_rates = P.next_mig; P.model.recombination_rate = P.next_rho;

@@ -494,7 +494,7 @@ void PfParam::finalize() {
     exclude(exclude_recomb, RECORD_RECOMB);
     exclude(exclude_coalmigr, RECORD_COALMIGR);
     int max_seg_len = (int)segment_cap();
-    if (!dump_model)
+    if (!dump_model && !(chunks > 1 || ranks > 1))      // several chunks: main.cpp reads one table per chunk instead
         segments = new Segment(seg_path, nsam, model.loci_length, nodata_theta,
                               (long long)start_position, max_seg_len);
 }

@@ -362,13 +362,22 @@ __device__ __forceinline__ void pf_acc_trip(unsigned long long* a) { a[5] += 1; 
 #define PF_ACC_STORE do {} while (0)
 #endif
 
-__device__ __forceinline__ int gridDim_particles(const KArgs& A) { return (int)((A.Np + PF_BS - 1) / PF_BS); }
+template <class KA>
+__device__ __forceinline__ int gridDim_particles(const KA& A) { return (int)((A.Np + PF_BS - 1) / PF_BS); }
+
+// A fresh, opaque handle on the same argument block in the constant address space: loads through it cannot be merged with
+// earlier ones nor hoisted above this point, so what a phase of a long kernel needs from the block is loaded in that phase
+// instead of being held in (and spilled from) scalar registers across the phases before it.  The by-value form of the
+// block (kernels that take KArgs as an argument) is returned as it is.
+__device__ __forceinline__ KArgsC& pf_reopen(KArgsC& A) { KArgsC* q = &A; asm volatile("" : "+s"(q)); return *q; }
+__device__ __forceinline__ const KArgs& pf_reopen(const KArgs& A) { return A; }
 
 // ---- decision on a finished row, made redundantly by every workgroup that needs it (single-launch pipeline) --------
 // normalize_probability (pc.cpp:420-438) and the ESS test of resample (pc.cpp:247-283) from the per-wavefront partials
 // the row's extend workgroups left in ring slot `slot`: the level-2 / level-3 part of the canonical radix-64 reduction,
 // operation for operation what k_decide does, so T, S1, ESS, the flag and the uniform are bit-identical everywhere.
 #define PF_PIPE_STAGE 16        // wavefronts of pilot scans staged per workgroup for the parent search
+#define PF_PIPE_COUNT_WGS 8     // default count workgroups per epoch of the row pipeline (pf_params.count_wgs)
 struct RowDecision { double T, S1, S2, ess, inv, u; int flag; };
 struct PipeLds {                // carved from the dynamic LDS of k_pipe behind the epoch tables
     double* l2s;                // [ncpad] level-2 inclusive scan of the per-wavefront pilot totals
@@ -406,7 +415,8 @@ __device__ __forceinline__ double pipe_chunk_offset(const PipeLds& q, int ch) {
 // the partials a thread needs first, requested before anything else so that their memory round trip overlaps the
 // particle's own loads (what the previous launch wrote comes from another XCD's L2: about a microsecond)
 struct RowPre { double vp = 0.0, vs = 0.0, vl = 0.0, last1 = 0.0; bool have = false; };
-__device__ __forceinline__ RowPre row_preload(const KArgs& A, int slot) {
+template <class KA>
+__device__ __forceinline__ RowPre row_preload(const KA& A, int slot) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nc = A.nc, ch = wave * 64 + lane;
     RowPre r;
@@ -419,8 +429,8 @@ __device__ __forceinline__ RowPre row_preload(const KArgs& A, int slot) {
     r.last1 = A.ctrl->last1[slot];
     return r;
 }
-template <bool WANT_TABLE>
-__device__ __forceinline__ RowDecision decide_row(const KArgs& A, const PipeLds& q, int slot, long long n_res, RowPre pre = RowPre()) {
+template <bool WANT_TABLE, class KA>
+__device__ __forceinline__ RowDecision decide_row(const KA& A, const PipeLds& q, int slot, long long n_res, RowPre pre = RowPre()) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = PF_BS / 64;
     const int nc = A.nc;
     const int ng = (nc + 63) / 64;
@@ -512,8 +522,8 @@ struct PipeRow {
 // derives the offspring offsets of its own particles and finds the parent of each of its slots by a two-level search
 // over the pilot prefix sums -- no offspring / parent table from an earlier kernel is read --, reads the previous row
 // from one slot of the state ring and writes this row into the next, and leaves the offspring table for the ledger.
-template <int NM, bool BIASED, bool EXACT = false, bool TREES = false, bool PIPE = false>
-__device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int fuse, PipeRow PR = PipeRow()) {
+template <int NM, bool BIASED, bool EXACT = false, bool TREES = false, bool PIPE = false, class KA>
+__device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fuse, PipeRow PR = PipeRow()) {
     extern __shared__ double smem[];
     double* sT = smem;                            // epoch starts and ...
     double* sH = smem + PF_EPAD;                  // ... cumulative coalescence intensity there, both padded with +inf (r_search4)
@@ -905,6 +915,10 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
         PF_ACC_STORE;
 
         PF_STAMP(5);
+        // a fresh handle on the argument block (pf_reopen): what the rest of the row needs from it -- the pointers of the output
+        // slot, the scan rings -- is loaded from here on and does not sit in scalar registers across the update loop
+        const KA& A1 = pf_reopen(A);
+        const DState st1 = state_slot(A1, cur);
         if (BIASED) {
             // apply the factors that fell due during this extension (particle.cpp:910-916)
             for (;;) {
@@ -914,14 +928,14 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
                 if (!(pm < extend_to)) break;
                 d_apply_earliest(ds, w_pilot);
             }
-            st.dcount[p] = ds.count;
-            st.total_delayed[p] = ds.total;
-            if (cx.gK > 0) st.ridx[p] = cx.ridx;
+            st1.dcount[p] = ds.count;
+            st1.total_delayed[p] = ds.total;
+            if (cx.gK > 0) st1.ridx[p] = cx.ridx;
             has_pending = ds.count > 0;
         }
-        if (do_extend && A.seg_state[s] == 0) {
-            const bool dephase = A.flags & 2;
-            const bool anc = A.flags & 1;
+        if (do_extend && A1.seg_state[s] == 0) {
+            const bool dephase = A1.flags & 2;
+            const bool anc = A1.flags & 1;
             unsigned het_pairs = 0;
             int ncfg = 1;
             for (int i = 0; i + 1 < n; i += 2) {
@@ -965,32 +979,33 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
 #pragma unroll
         for (int r = 0; r < RTree<NM>::NI; ++r)
             if (r < n - 1) {
-                st.S[(size_t)r * A.Np + p] = t.S[r];
-                st.C[(size_t)(2 * r) * A.Np + p] = (int8_t)t.C0[r];
-                st.C[(size_t)(2 * r + 1) * A.Np + p] = (int8_t)t.C1[r];
+                st1.S[(size_t)r * A1.Np + p] = t.S[r];
+                st1.C[(size_t)(2 * r) * A1.Np + p] = (int8_t)t.C0[r];
+                st1.C[(size_t)(2 * r + 1) * A1.Np + p] = (int8_t)t.C1[r];
             }
-        st.w_post[p] = w_post;
-        st.w_pilot[p] = w_pilot;
-        st.next_base[p] = next_base;
-        st.x_mark[p] = x_mark;
-        st.mark_limit[p] = mark_limit;
-        st.Ltree[p] = cx.Ltree;
-        A.rng_ctr[p] = cx.ctr;
-        A.ebuf[p] = cx.ebuf;
+        st1.w_post[p] = w_post;
+        st1.w_pilot[p] = w_pilot;
+        st1.next_base[p] = next_base;
+        st1.x_mark[p] = x_mark;
+        st1.mark_limit[p] = mark_limit;
+        st1.Ltree[p] = cx.Ltree;
+        A1.rng_ctr[p] = cx.ctr;
+        A1.ebuf[p] = cx.ebuf;
         if constexpr (PIPE) {
-            A.rg_widx[(size_t)cur * A.Np + p] = widx;
-            if (!do_extend) A.widx[p] = widx;              // the state goes back to the general kernels
+            A1.rg_widx[(size_t)cur * A1.Np + p] = widx;
+            if (!do_extend) A1.widx[p] = widx;              // the state goes back to the general kernels
         } else {
-            A.widx[p] = widx;
+            A1.widx[p] = widx;
         }
-        if (TREES && widx >= A.cap) A.ctrl->err = ERR_LOG_OVERFLOW;       // -arg keeps every record
+        if (TREES && widx >= A1.cap) A1.ctrl->err = ERR_LOG_OVERFLOW;       // -arg keeps every record
         if constexpr (!PIPE) {
 #pragma unroll
-            for (int r = 0; r < RTree<NM>::NI; ++r) if (r < n - 1) A.snap_S[A.sp][(size_t)r * A.Np + p] = t.S[r];
-            A.snap_w[A.sp][p] = w_post; A.snap_xm[A.sp][p] = x_mark; A.snap_ml[A.sp][p] = mark_limit; A.snap_widx[A.sp][p] = widx;
+            for (int r = 0; r < RTree<NM>::NI; ++r) if (r < n - 1) A1.snap_S[A1.sp][(size_t)r * A1.Np + p] = t.S[r];
+            A1.snap_w[A1.sp][p] = w_post; A1.snap_xm[A1.sp][p] = x_mark; A1.snap_ml[A1.sp][p] = mark_limit; A1.snap_widx[A1.sp][p] = widx;
         }
     }
     PF_STAMP(7);
+    const KA& A2 = pf_reopen(A);
     double sp = wave_tree_sum(w_post);
     double sq = wave_tree_sum(w_pilot * w_pilot);
     double sc = wave_hs_scan(w_pilot, lane);
@@ -999,35 +1014,35 @@ __device__ __forceinline__ void extend_reg_body(const KArgs& A, long long s, int
     long long chunk = p >> 6;
     PF_STAMP(8);
     if constexpr (PIPE) {
-        const size_t ro = (size_t)cur * A.Np, co = (size_t)cur * A.nc;
-        if (active) { A.rg_scan1[ro + p] = sc; A.rg_scanp[ro + p] = scp; A.rg_scan1m[ro + p] = scm; }
-        if (p == A.Np - 1) A.ctrl->last1[cur] = sc;
-        if (lane == 63 && chunk < A.nc) {
-            A.rg_cpost[co + chunk] = sp;
-            A.rg_csq[co + chunk] = sq;
-            A.rg_cpil[co + chunk] = sc;
-            A.rg_cpp[co + chunk] = scp;
-            A.rg_cmx1[co + chunk] = scm;
+        const size_t ro = (size_t)cur * A2.Np, co = (size_t)cur * A2.nc;
+        if (active) { A2.rg_scan1[ro + p] = sc; A2.rg_scanp[ro + p] = scp; A2.rg_scan1m[ro + p] = scm; }
+        if (p == A2.Np - 1) A2.ctrl->last1[cur] = sc;
+        if (lane == 63 && chunk < A2.nc) {
+            A2.rg_cpost[co + chunk] = sp;
+            A2.rg_csq[co + chunk] = sq;
+            A2.rg_cpil[co + chunk] = sc;
+            A2.rg_cpp[co + chunk] = scp;
+            A2.rg_cmx1[co + chunk] = scm;
         }
         if (BIASED) {
             unsigned long long pend = __ballot(has_pending);
-            if (lane == 0 && chunk < A.nc) {
-                A.rg_dpend[co + chunk] = __popcll(pend);
-                if (!PR.extend) A.chunk_dpend[chunk] = __popcll(pend);     // the state goes back to the general kernels
+            if (lane == 0 && chunk < A2.nc) {
+                A2.rg_dpend[co + chunk] = __popcll(pend);
+                if (!PR.extend) A2.chunk_dpend[chunk] = __popcll(pend);     // the state goes back to the general kernels
             }
         }
     } else {
-        if (active) { A.scan1[p] = sc; A.scanp2[A.sp][p] = scp; A.scan1m[p] = scm; }
-        if (lane == 63 && chunk < (A.Np + 63) / 64) {
-            A.chunk_post[chunk] = sp;
-            A.chunk_sq[chunk] = sq;
-            A.chunk_pil[chunk] = sc;
-            A.chunk_pp[chunk] = scp;
-            A.chunk_mx1[chunk] = scm;
+        if (active) { A2.scan1[p] = sc; A2.scanp2[A2.sp][p] = scp; A2.scan1m[p] = scm; }
+        if (lane == 63 && chunk < (A2.Np + 63) / 64) {
+            A2.chunk_post[chunk] = sp;
+            A2.chunk_sq[chunk] = sq;
+            A2.chunk_pil[chunk] = sc;
+            A2.chunk_pp[chunk] = scp;
+            A2.chunk_mx1[chunk] = scm;
         }
         if (BIASED) {
             unsigned long long pend = __ballot(has_pending);
-            if (lane == 0 && chunk < (A.Np + 63) / 64) A.chunk_dpend[chunk] = __popcll(pend);
+            if (lane == 0 && chunk < (A2.Np + 63) / 64) A2.chunk_dpend[chunk] = __popcll(pend);
         }
     }
 }
@@ -1045,7 +1060,8 @@ __global__ __launch_bounds__(PF_BS) void k_extend_reg(KArgs A, long long s, int 
 #define PF_FIN_TILE_B 64       // k_count workgroup partials staged per pass
 #define PF_FIN_PAIRS 64        // (epoch, statistic) pairs staged per pass
 
-__device__ void finalize_counts(const KArgs& A, Ctrl* c, int tid, int nthreads, double* stage /* PF_FIN_PAIRS*PF_FIN_TILE_B */) {
+template <class KA>
+__device__ void finalize_counts(const KA& A, Ctrl* c, int tid, int nthreads, double* stage /* PF_FIN_PAIRS*PF_FIN_TILE_B */) {
     const int E = A.E;
     const int nb = A.nbx;
     const int NC = A.ncol;
@@ -1087,7 +1103,8 @@ __device__ void finalize_counts(const KArgs& A, Ctrl* c, int tid, int nthreads, 
 
 // generation bookkeeping for the windows of the coming count step: g_lo[e] / g_hi[e] = generations
 // that hold the window ends (both monotone along the sweep: amortised O(1) per step)
-__device__ void window_generations(const KArgs& A, Ctrl* c, const Windows& W, int tid) {
+template <class KA>
+__device__ void window_generations(const KA& A, Ctrl* c, const Windows& W, int tid) {
     const int E = A.E;
     const int G = c->gen_prev;
     if (tid < E) {
@@ -1135,7 +1152,8 @@ __device__ void window_generations(const KArgs& A, Ctrl* c, const Windows& W, in
 //     the parent table entries of their offspring and its survivor count: no inter-workgroup wait;
 //   * the bookkeeping workgroup advances the window
 //     generations (off the critical path).
-__device__ __forceinline__ void decide_body(const KArgs& A, long long s, int mode, const Windows& W, int nblocks) {
+template <class KA>
+__device__ __forceinline__ void decide_body(const KA& A, long long s, int mode, const Windows& W, int nblocks) {
     __shared__ double l2s[4096];          // level-2 inclusive scan of the per-wavefront pilot totals / finalize staging
     __shared__ double l2_post[64], l2_sq[64], l2_tot[64], l2_totp[64];
     __shared__ int wred[PF_BS / 64];
@@ -1392,8 +1410,8 @@ __device__ __forceinline__ void lmap_event(const LMap& L, int n, double event_ba
     atomicAdd(&L.gcnt[(size_t)(n + 1) * L.nbins + idx], weight * dlog(h + 1.0));
 }
 
-template <int NI, int P>
-__device__ __forceinline__ void stretch_contrib(AccT<P>& acc, const KArgs& A, const Win& W, const LMap& L, double w, double x0,
+template <int NI, int P, class KA>
+__device__ __forceinline__ void stretch_contrib(AccT<P>& acc, const KA& A, const Win& W, const LMap& L, double w, double x0,
                                                 double x1, const double (&S)[NI], int lim_start) {
     if (!(W.rf & REC_RECOMB) || W.e > lim_start) return;
     double xs = ovl(x0, x1, W.a_e, W.b_e);
@@ -1407,8 +1425,8 @@ __device__ __forceinline__ void stretch_contrib(AccT<P>& acc, const KArgs& A, co
 
 // All fields of a record are fetched in one round of independent loads before anything is tested:
 // the kernel is bound by dependent-load latency, not by bytes.
-template <int NI, int P>
-__device__ __forceinline__ void records_contrib(AccT<P>& acc, const KArgs& A, const Win& W, const LMap& L, double w, long long a,
+template <int NI, int P, class KA>
+__device__ __forceinline__ void records_contrib(AccT<P>& acc, const KA& A, const Win& W, const LMap& L, double w, long long a,
                                                 unsigned k0, unsigned k1) {
     using AC = AccT<P>;
     const int n = A.n;
@@ -1497,12 +1515,14 @@ struct CountSrc {
     RunLists lists;
     double inv; int G, g_lo, g_hi;                // normalisation of the row, its generation, generations of the epoch's window
 };
-__device__ __forceinline__ RunLists run_lists(const KArgs& A, int ver) {
+template <class KA>
+__device__ __forceinline__ RunLists run_lists(const KA& A, int ver) {
     RunLists r;
     r.st = ver ? A.run_st2 : A.run_st; r.anc = ver ? A.run_anc2 : A.run_anc; r.nruns = ver ? A.nruns2 : A.nruns;
     return r;
 }
-__device__ __forceinline__ CountSrc count_src_parity(const KArgs& A, int sp, int e) {
+template <class KA>
+__device__ __forceinline__ CountSrc count_src_parity(const KA& A, int sp, int e) {
     const Ctrl* c = A.ctrl;
     CountSrc q;
     q.w = A.snap_w[sp]; q.S = A.snap_S[sp]; q.xm = A.snap_xm[sp]; q.ml = A.snap_ml[sp]; q.widx = A.snap_widx[sp];
@@ -1517,8 +1537,8 @@ __device__ __forceinline__ CountSrc count_src_parity(const KArgs& A, int sp, int
 #define PF_CNT_TILE 2048      // generations whose run counts are staged in LDS at a time
 #define PF_CNT_WIDE 128       // run lists longer than this are strided over by the whole grid column
 
-template <int NI, int P>
-__device__ __forceinline__ void count_run(AccT<P>& acc, const KArgs& A, const CountSrc& Q, const Win& W, const LMap& L, int g, long long i,
+template <int NI, int P, class KA>
+__device__ __forceinline__ void count_run(AccT<P>& acc, const KA& A, const CountSrc& Q, const Win& W, const LMap& L, int g, long long i,
                                           int nr, const int* rst, const int* ran, double inv) {
     const long long Np = A.Np;
     int q0 = rst[i];
@@ -1542,8 +1562,8 @@ __device__ __forceinline__ void count_run(AccT<P>& acc, const KArgs& A, const Co
 
 // The body of k_count for the workgroup (bx, by) of a column of nbxg workgroups; `sp` = parity of the step whose
 // weights and snapshot it reads.  Called from k_count and from the count workgroups of k_row.
-template <int NM, int P, bool EXACT = false>
-__device__ __forceinline__ void count_body(const KArgs& A, const CountSrc& Q, int e, double win_a, double win_b, int bx, int nbxg) {
+template <int NM, int P, bool EXACT = false, class KA>
+__device__ __forceinline__ void count_body(const KA& A, const CountSrc& Q, int e, double win_a, double win_b, int bx, int nbxg) {
     constexpr int NI = NM - 1;
     using AC = AccT<P>;
     __shared__ AC red[PF_BS / 64];
@@ -1706,7 +1726,8 @@ __global__ void k_count_fin(KArgs A) {
 #define PF_LEDGER_MAXT 1024   // largest workgroup the ledger code is launched with
 #define PF_LEDGER_NEW 64      // the newest generations (long run lists) are re-based by a whole workgroup each
 
-__device__ __forceinline__ void ledger_update(const KArgs& A, int lb, int nlb, int G, int g_ret, RunLists src, RunLists dst) {
+template <class KA>
+__device__ __forceinline__ void ledger_update(const KA& A, int lb, int nlb, int G, int g_ret, RunLists src, RunLists dst) {
     __shared__ int scnt[PF_LEDGER_PER * (PF_LEDGER_MAXT / 64)], sexc[PF_LEDGER_PER * (PF_LEDGER_MAXT / 64)];
     __shared__ int stot;
     const long long Np = A.Np;
@@ -1830,7 +1851,8 @@ __device__ __forceinline__ void ledger_update(const KArgs& A, int lb, int nlb, i
 // body of k_ledger for workgroup bx of nbt; `sp` = parity of the step whose resampling it follows up
 // run list of the generation Gx that ends with a resampling: its survivors, in slot order (start = lo[a], ancestor = a).
 // Position = survivors in earlier workgroups (blkcnt, counted where the offspring table was made) + rank inside this one.
-__device__ __forceinline__ void ledger_new_list(const KArgs& A, RunLists dst, const int* blkcnt, int nblocks, int bx, int Gx) {
+template <class KA>
+__device__ __forceinline__ void ledger_new_list(const KA& A, RunLists dst, const int* blkcnt, int nblocks, int bx, int Gx) {
     const long long Np = A.Np;
     const long long i = (long long)bx * PF_BS + threadIdx.x;
     __shared__ int wsum[PF_BS / 64];
@@ -1858,7 +1880,8 @@ __device__ __forceinline__ void ledger_new_list(const KArgs& A, RunLists dst, co
     }
 }
 
-__device__ __forceinline__ void ledger_body(const KArgs& A, int sp, int nblocks, int bx, int nbt) {
+template <class KA>
+__device__ __forceinline__ void ledger_body(const KA& A, int sp, int nblocks, int bx, int nbt) {
     const Ctrl* c = A.ctrl;
     if (!c->step[sp].flag) return;
     const int Gx = c->step[sp].G;
@@ -1900,8 +1923,8 @@ __global__ void k_pipe_seed(KArgs A, int slot) {
     r.inv_T = 1.0; r.T = 1.0; r.S1 = 0.0; r.u = 0.0; r.pos = c->cur_pos;
 }
 
-template <bool BIASED>
-__device__ __forceinline__ void pipe_bookkeeping(const KArgs& A, const PipeLds& q, const PipeLaunch& PL, const Windows& W) {
+template <bool BIASED, class KA>
+__device__ __forceinline__ void pipe_bookkeeping(const KA& A, const PipeLds& q, const PipeLaunch& PL, const Windows& W) {
     Ctrl* c = A.ctrl;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = PF_BS / 64;
     const int E = A.E, nc = A.nc, ng = (nc + 63) / 64;
@@ -1983,8 +2006,8 @@ __device__ __forceinline__ void pipe_bookkeeping(const KArgs& A, const PipeLds& 
     }
 }
 
-template <int NM, bool BIASED, bool EXACT, bool TREES>
-__global__ __launch_bounds__(PF_BS) void k_pipe(KArgs A, long long s, PipeLaunch PL, Windows Wb) {
+template <int NM, bool BIASED, bool EXACT, bool TREES, class KA>
+__device__ __forceinline__ void pipe_roles(const KA& A, long long s, const PipeLaunch& PL, const Windows& Wb) {
     const int bx = (int)blockIdx.x;
     const int nb = PL.nb;
     if (bx < nb) {
@@ -2022,6 +2045,116 @@ __global__ __launch_bounds__(PF_BS) void k_pipe(KArgs A, long long s, PipeLaunch
     Q.lists = run_lists(A, r.lver);
     Q.inv = r.inv_T; Q.G = r.gen; Q.g_lo = r.g_lo[e]; Q.g_hi = r.g_hi[e];
     count_body<NM, 1, EXACT>(A, Q, e, r.wa[e], r.wb[e], idx % PL.ncw, PL.ncw);
+}
+
+template <int NM, bool BIASED, bool EXACT, bool TREES>
+__global__ __launch_bounds__(PF_BS) void k_pipe(KArgs A, long long s, PipeLaunch PL, Windows Wb) {
+    pipe_roles<NM, BIASED, EXACT, TREES>(A, s, PL, Wb);
+}
+
+// ------------------------------------------------------------------ k_sweep: several chunks per launch
+// The same four roles as k_pipe, for C independent chunks at once: blockIdx.y is the chunk, each with its own argument
+// block in device memory (SweepChunk::A, read through the constant address space: every field is a scalar load where it
+// is used, nothing of the block is a kernel argument any more), its own Ctrl, rings and event log.  All chunks step in
+// lockstep: launch t handles row s = s_begin + t of every chunk that still has one (then its two flush steps).  What
+// k_pipe is told per launch by the host is derived here: the plan of the step (sweep_plan = the `launch` lambda of
+// run_pipeline) from (s, s_begin, s_last), and the count windows of row s - 1 by the bookkeeping workgroup from the
+// chunk's own window state (sweep_windows = host_windows, operation for operation), so the host only supplies t.
+// One chunk per GPU uses a sixth of the SIMDs; the reference's data parallelism is one process per chunk, all at once
+// (smcsmc/model.py:1094-1098), which is what a grid over chunks is here.
+struct SweepChunk {
+    KArgs A;
+    long long s_begin;             // first row of this call
+    long long s_last;              // last row extended by this call; steps s_last + 1 and s_last + 2 flush
+    double counted_to[PF_EMAX];    // window state (CountModel::counted_to) at the start of the call
+    int no_count;
+    int nL_full;                   // ledger workgroups per step
+    int ncw;                       // count workgroups per epoch
+    int pad;
+};
+typedef const __attribute__((address_space(4))) SweepChunk SweepChunkC;
+
+template <class KA>
+__device__ __forceinline__ double sweep_seg_pos(const KA& A, long long s) {       // seg_pos() of the host
+    const double e = A.seg_start[s] + A.seg_len[s];
+    return e < A.L ? e : A.L;
+}
+
+// what run_pipeline's `launch` lambda computes on the host, from the step's row alone
+__device__ __forceinline__ bool sweep_plan(SweepChunkC& ch, long long s, int nb, PipeLaunch& PL) {
+    const long long s_begin = ch.s_begin, s_last = ch.s_last;
+    if (s_last < s_begin || s > s_last + 2) return false;
+    const bool extend = s <= s_last, flush1 = s == s_last + 1;
+    const bool have_b = extend ? (s > s_begin) : flush1;
+    const bool have_lc = extend ? (s > s_begin + 1) : (flush1 ? (s_last - 1 >= s_begin) : true);
+    PL.nb = nb;
+    PL.row.extend = extend ? 1 : 0;
+    PL.row.complete = ((extend && s > s_begin) || flush1) ? 1 : 0;
+    PL.row.slot_prev = PL.row.complete ? (int)((s - 1) & 3) : -1;
+    PL.row.slot_out = (int)(s & 3);
+    PL.row.pos_prev = s > s_begin ? sweep_seg_pos(ch.A, s - 1) : 0.0;
+    PL.b_slot = have_b ? (int)((s - 1) & 3) : -1;
+    PL.b_row = s - 1;
+    PL.b_pos = have_b ? sweep_seg_pos(ch.A, s - 1) : 0.0;
+    PL.b_set_cur = flush1 ? (int)((s_last + 1) & 3) : -1;
+    PL.lc_slot = (have_lc && !ch.no_count) ? (int)((s - 2) & 3) : -1;
+    PL.live_slot = (int)((s - 1) & 3);
+    PL.nL = PL.lc_slot >= 0 ? ch.nL_full : 0;
+    PL.ncw = ch.ncw;
+    return true;
+}
+
+// extract_and_update_count's window rule (count.cpp:363-385) for the row that ends at `pos`: host_windows() on the device,
+// the same operations in the same order on the same doubles; the window state lives in Ctrl::counted_to.  Called by all
+// threads of the bookkeeping workgroup; W is in LDS.
+template <class KA>
+__device__ __forceinline__ void sweep_windows(const KA& A, Ctrl* c, double pos, Windows& W) {
+    const int e = threadIdx.x, E = A.E;
+    if (e < 64) {
+        const bool in = e < E;
+        const double lagging = in ? A.lags[e] : 0.0;
+        const double x_end = pos - lagging;
+        const double ct = in ? c->counted_to[e] : 0.0;
+        const bool small = (x_end - ct) < lagging * 0.1;
+        const unsigned long long moved = __ballot(in && !small);
+        const int first = moved ? (int)__builtin_ctzll(moved) : E;
+        if (in) {
+            const double b = (small && first > e) ? ct : x_end;
+            W.a[e] = ct; W.b[e] = b;
+            c->counted_to[e] = b;
+        }
+        if (e == 0) { W.first = first; W.end_data = 0; }
+    }
+    __syncthreads();
+}
+
+template <int NM, bool BIASED, bool EXACT, bool TREES>
+__global__ __launch_bounds__(PF_BS) void k_sweep(const SweepChunk* tab_g, long long t, int nb) {
+    SweepChunkC* tab = (SweepChunkC*)tab_g;
+    SweepChunkC& ch = tab[blockIdx.y];
+    KArgsC& A = ch.A;
+    const long long s = ch.s_begin + t;
+    __shared__ Windows W;           // written and read by the bookkeeping workgroup only
+    PipeLaunch PL;
+    if (!sweep_plan(ch, s, nb, PL)) return;
+    if ((int)blockIdx.x == nb && PL.b_slot >= 0) sweep_windows(A, A.ctrl, PL.b_pos, W);
+    pipe_roles<NM, BIASED, EXACT, TREES>(A, s, PL, W);
+}
+
+// first step of a call: the seed of k_pipe_seed, and the chunk's window state
+__global__ void k_sweep_seed(const SweepChunk* tab_g) {
+    SweepChunkC* tab = (SweepChunkC*)tab_g;
+    SweepChunkC& ch = tab[blockIdx.x];
+    KArgsC& A = ch.A;
+    if (ch.s_last < ch.s_begin) return;              // nothing to do for this chunk in this call
+    Ctrl* c = A.ctrl;
+    const int slot = (int)((ch.s_begin + 3) & 3);
+    if (threadIdx.x == 0) {
+        Ctrl::RowInfo& r = c->ri[slot];
+        r.n_res = c->n_resample; r.gen = c->gen; r.flag = 0; r.lver = c->lver; r.g_retain = c->g_retain; r.first = A.E;
+        r.inv_T = 1.0; r.T = 1.0; r.S1 = 0.0; r.u = 0.0; r.pos = c->cur_pos;
+    }
+    if ((int)threadIdx.x < A.E) c->counted_to[threadIdx.x] = ch.counted_to[threadIdx.x];
 }
 
 __global__ __launch_bounds__(PF_BS) void k_ledger(KArgs A, int nblocks) {
@@ -2623,6 +2756,11 @@ struct pf_handle {
     bool two_launch_rows = false; // PF_DEBUG_TWO_LAUNCH: the round-1 row pipeline (k_row + k_decide_ledger) instead of k_pipe
     bool pipe = false;            // the single-launch pipeline applies (one population, n <= 8; rings allocated)
     size_t smem_pipe = 0;
+    int ncw = 0;                  // count workgroups per epoch in the row pipeline (pf_params.count_wgs)
+    bool use_k_pipe = false;      // PF_DEBUG_K_PIPE: rows through k_pipe (argument block by value, one chunk per launch) instead of k_sweep
+    SweepChunk* d_sweep = nullptr; // device table of the chunks this handle leads through k_sweep
+    int d_sweep_cap = 0;
+    std::vector<SweepChunk> h_sweep;
     // timing
     int timing_period = 0;
     struct Span { hipEvent_t a, b; int k; };
@@ -2801,6 +2939,7 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     h->no_fuse = (p->debug & PF_DEBUG_NO_FUSE) != 0;
     h->no_count = (p->debug & PF_DEBUG_NO_COUNT) != 0;
     h->two_launch_rows = (p->debug & PF_DEBUG_TWO_LAUNCH) != 0;
+    h->use_k_pipe = (p->debug & PF_DEBUG_K_PIPE) != 0;
     h->h_lags.assign(m->lags, m->lags + E);
     h->h_counted_to.assign(E, 0.0);
     h->h_L = m->loci_length;
@@ -2960,6 +3099,9 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     // accumulators of the count workgroups per epoch (measured: four times as many count workgroups per epoch in the row
     // pipeline made a row 15 % slower -- the launch then holds 5 000 workgroups of 30 KB LDS each, four rounds of the chip)
     A.nbx = h->nblocks;
+    // the row pipeline spreads an epoch's count tasks (the ancestor runs of the generations in its window: a few hundred to
+    // a few thousand per row) over this many workgroups; the stand-alone k_count uses one per particle workgroup
+    h->ncw = p->count_wgs > 0 ? std::min<int>(p->count_wgs, h->nblocks) : std::min(h->nblocks, PF_PIPE_COUNT_WGS);
     rc |= dalloc(h, &A.totals, (size_t)A.ncol * E);
     rc |= dalloc(h, &A.partial, (size_t)E * A.nbx * A.ncol);
     A.max_trace_events = h->max_trace_events;
@@ -3005,6 +3147,7 @@ void pf_destroy(pf_handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->cstream) hipStreamSynchronize(h->cstream);
     for (void* p : h->allocs) hipFree(p);
+    if (h->d_sweep) hipFree(h->d_sweep);
     for (auto e : h->sync_ev) if (e) hipEventDestroy(e);
     if (h->cstream) hipStreamDestroy(h->cstream);
     for (auto& sp : h->spans) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
@@ -3426,7 +3569,7 @@ static int run_pipeline(pf_handle* h, long long s_begin, long long s_end) {
         PL.lc_slot = (have_lc && !h->no_count) ? (int)((s - 2) & 3) : -1;
         PL.live_slot = (int)((s - 1) & 3);
         PL.nL = PL.lc_slot >= 0 ? nL_full : 0;
-        PL.ncw = h->A.nbx;
+        PL.ncw = h->ncw;
         const int ncount_wg = (PL.lc_slot >= 0 && W2.first < E) ? PL.ncw * (E - W2.first) : 0;
         if (ncount_wg > 0) h->fin_pending = true;
         const bool t = extend && timing_on(h, s);
@@ -3456,10 +3599,126 @@ static int run_pipeline(pf_handle* h, long long s_begin, long long s_end) {
     return 0;
 }
 
+// Rows [s_begin, s_end) of several chunks (handles on one device, same shape) in lockstep, one k_sweep launch per step on
+// the leader's stream.  Every chunk is bit-identical to its own pf_run (tests/test_gpu_sweep.py): a chunk never reads
+// another chunk's memory, and the launch geometry a chunk sees is the one k_pipe gives it.
+template <int NM, bool BIASED>
+static void launch_sweep(pf_handle* h, const dim3& grid, long long t) {
+    const dim3 blk(PF_BS);
+    const size_t lds = h->smem_pipe;
+    if (h->A.rec_trees) hipLaunchKernelGGL((k_sweep<NM, BIASED, false, true>), grid, blk, lds, h->stream, h->d_sweep, t, h->nblocks);
+    else if (h->n == NM) hipLaunchKernelGGL((k_sweep<NM, BIASED, true, false>), grid, blk, lds, h->stream, h->d_sweep, t, h->nblocks);
+    else hipLaunchKernelGGL((k_sweep<NM, BIASED, false, false>), grid, blk, lds, h->stream, h->d_sweep, t, h->nblocks);
+}
+
+static bool sweep_compatible(const pf_handle* a, const pf_handle* b) {
+    const bool ba = a->A.n_bias > 0 || a->A.g_K > 0, bb = b->A.n_bias > 0 || b->A.g_K > 0;
+    return a->device == b->device && a->Np == b->Np && a->n == b->n && a->E == b->E && a->P == b->P && ba == bb &&
+           a->A.rec_trees == b->A.rec_trees && a->ncw == b->ncw && a->smem_pipe == b->smem_pipe && a->no_count == b->no_count;
+}
+
+static int run_sweep(pf_handle* const* hs, int nh, long long s_begin, long long s_end) {
+    pf_handle* h = hs[0];
+    if (s_begin >= s_end) return 0;
+    const int nb = h->nblocks, E = h->E;
+    const bool biased = h->A.n_bias > 0 || h->A.g_K > 0;
+    const int nL_full = nb + std::max(16, std::min(PF_LEDGER_BLOCKS, 192));
+    // the other handles' streams (anything they still have in flight) come first, then the table
+    for (int k = 0; k < nh; ++k) {
+        pf_handle* g = hs[k];
+        if (g->ev_cnt) { hipStreamWaitEvent(h->stream, g->ev_cnt, 0); g->ev_cnt = nullptr; }
+        if (k > 0) {
+            hipEvent_t ev = next_sync_event(g);
+            hipEventRecord(ev, g->stream);
+            hipStreamWaitEvent(h->stream, ev, 0);
+        }
+    }
+    if (h->d_sweep_cap < nh) {
+        if (h->d_sweep) { HIPCHK(hipStreamSynchronize(h->stream)); HIPCHK(hipFree(h->d_sweep)); }
+        HIPCHK(hipMalloc((void**)&h->d_sweep, sizeof(SweepChunk) * (size_t)nh));
+        h->d_sweep_cap = nh;
+    }
+    // the table of the previous call may still be read by its launches: a fresh host copy per call, uploaded in stream order
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->h_sweep.assign((size_t)nh, SweepChunk());
+    long long steps = 0;
+    for (int k = 0; k < nh; ++k) {
+        pf_handle* g = hs[k];
+        SweepChunk& ch = h->h_sweep[k];
+        memset(&ch, 0, sizeof(ch));
+        ch.A = g->A;
+        ch.s_begin = s_begin;
+        long long e = std::min<long long>(s_end, g->n_segs), last = s_begin - 1;
+        for (long long s = s_begin; s < e; ++s) { last = s; if (g->h_seg_start[s] + g->h_seg_len[s] >= g->h_L) break; }   // smcsmc.cpp:353-356
+        ch.s_last = last;
+        for (int q = 0; q < E; ++q) ch.counted_to[q] = g->h_counted_to[q];
+        ch.no_count = g->no_count ? 1 : 0;
+        ch.nL_full = nL_full;
+        ch.ncw = g->ncw;
+        if (last >= s_begin) steps = std::max(steps, last - s_begin + 3);
+    }
+    if (steps == 0) return 0;
+    HIPCHK(hipMemcpyAsync(h->d_sweep, h->h_sweep.data(), sizeof(SweepChunk) * (size_t)nh, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_sweep_seed, dim3(nh), dim3(64), 0, h->stream, h->d_sweep);
+    const dim3 grid((unsigned)(nb + 1 + nL_full + h->ncw * E), (unsigned)nh);
+    for (long long t = 0; t < steps; ++t) {
+        const bool tm_on = timing_on(h, s_begin + t);
+        {
+            Timed tm(h, 0, tm_on);
+            if (h->n <= 4 && biased) launch_sweep<4, true>(h, grid, t);
+            else if (h->n <= 4) launch_sweep<4, false>(h, grid, t);
+            else if (biased) launch_sweep<8, true>(h, grid, t);
+            else launch_sweep<8, false>(h, grid, t);
+        }
+        if (check_launch("k_sweep")) return -1;
+        if ((t & 1023) == 1023) trim_spans(h);
+    }
+    h->k_launches[0] -= 2;                                      // flush steps are not rows
+    // the host's copy of the window state and the bookkeeping flags of every chunk follow the rows it has done
+    for (int k = 0; k < nh; ++k) {
+        pf_handle* g = hs[k];
+        const long long last = h->h_sweep[k].s_last;
+        for (long long s = s_begin; s <= last; ++s) {
+            g->step_windows = host_windows(g, seg_pos(g, s), false);
+            if (g->step_windows.first < E && !g->no_count) g->fin_pending = true;
+        }
+        if (last >= s_begin) g->seg_done = last + 1;
+        if (k > 0) {                                            // the chunk's own stream continues after the sweep
+            hipEvent_t ev = next_sync_event(h);
+            hipEventRecord(ev, h->stream);
+            hipStreamWaitEvent(g->stream, ev, 0);
+        }
+    }
+    return 0;
+}
+
+int pf_run_many(pf_handle* const* handles, int32_t n_handles, int64_t s_begin, int64_t s_end) {
+    if (n_handles < 1 || !handles || !handles[0]) { g_err = "pf_run_many: no handles"; return -1; }
+    pf_handle* h = handles[0];
+    HIPCHK(hipSetDevice(h->device));
+    for (int k = 0; k < n_handles; ++k) {
+        pf_handle* g = handles[k];
+        if (!g) { g_err = "pf_run_many: null handle"; return -1; }
+        if (s_begin < 0) { g_err = "segment range out of bounds"; return -1; }        // a chunk with fewer rows sits the call out
+        if (!(extend_can_fuse(g) && g->pipe && !g->two_launch_rows)) {
+            g_err = "pf_run_many: the chunks must run on the single-launch row pipeline (one population, at most 8 haplotypes, no look-ahead)";
+            return -1;
+        }
+        if (!sweep_compatible(h, g)) { g_err = "pf_run_many: the chunks must share device, particle count, haplotypes, epochs and options"; return -1; }
+        for (int j = 0; j < k; ++j) if (handles[j] == g) { g_err = "pf_run_many: a handle appears twice"; return -1; }
+    }
+    return run_sweep(handles, n_handles, s_begin, s_end);
+}
+
 int pf_run(pf_handle* h, int64_t s_begin, int64_t s_end) {
     HIPCHK(hipSetDevice(h->device));
     if (s_begin < 0 || s_end > h->n_segs) { g_err = "segment range out of bounds"; return -1; }
-    if (extend_can_fuse(h)) return (h->pipe && !h->two_launch_rows) ? run_pipeline(h, s_begin, s_end) : run_single_stream(h, s_begin, s_end);
+    if (extend_can_fuse(h)) {
+        if (!h->pipe || h->two_launch_rows) return run_single_stream(h, s_begin, s_end);
+        if (h->use_k_pipe) return run_pipeline(h, s_begin, s_end);
+        pf_handle* one[1] = {h};
+        return run_sweep(one, 1, s_begin, s_end);
+    }
     // structured models on the register-tree kernel: the next row's extend completes this row while it loads (two
     // launches per row on the main stream instead of three); the last row of the call is completed by k_resample
     const bool mp_fuse = h->P > 1 && pf_mp_can_fuse(h->A, h->force_lds) && h->A.apf == 0 && !h->no_fuse;

@@ -220,8 +220,15 @@ struct KArgs {
 };
 
 // copy k of the particle state (see KArgs::st0); fields that are not allocated stay unusable, as in st0
-__host__ __device__ inline DState state_slot(const KArgs& A, int k) {
-    DState d = A.st0;
+template <class KA>
+__host__ __device__ inline DState state_slot(const KA& A, int k) {
+    // member by member: A may live in the constant address space (KArgsC), from which a struct cannot be copy-constructed
+    DState d;
+    d.S = A.st0.S; d.C = A.st0.C; d.w_post = A.st0.w_post; d.w_pilot = A.st0.w_pilot; d.next_base = A.st0.next_base;
+    d.x_mark = A.st0.x_mark; d.Ltree = A.st0.Ltree; d.mark_limit = A.st0.mark_limit;
+    d.total_delayed = A.st0.total_delayed; d.dcount = A.st0.dcount; d.dpos = A.st0.dpos; d.dfac = A.st0.dfac;
+    d.ddelta = A.st0.ddelta; d.dk = A.st0.dk; d.ridx = A.st0.ridx; d.lookahead = A.st0.lookahead;
+    d.Pn = A.st0.Pn; d.nm = A.st0.nm; d.Mt = A.st0.Mt; d.Mb = A.st0.Mb; d.Mq = A.st0.Mq;
     const size_t K = (size_t)k, Np = (size_t)A.Np, n1 = (size_t)(A.n - 1);
     d.S += K * n1 * Np; d.C += K * 2 * n1 * Np;
     d.w_post += K * Np; d.w_pilot += K * Np; d.next_base += K * Np; d.x_mark += K * Np; d.Ltree += K * Np; d.mark_limit += K * Np;
@@ -232,6 +239,11 @@ __host__ __device__ inline DState state_slot(const KArgs& A, int k) {
     d.Mt += K * (size_t)A.mcap * Np; d.Mb += K * (size_t)A.mcap * Np; d.Mq += K * (size_t)A.mcap * Np;
     return d;
 }
+
+// The argument block as the kernels of the multi-chunk sweep see it: one KArgs per chunk in device memory, read through
+// the constant address space so that every field is a scalar load issued where it is used (a kernel gets a plain
+// pointer and casts it).  Device functions take the block as `const KA&` and work on either form.
+typedef const __attribute__((address_space(4))) KArgs KArgsC;
 
 // Count windows of one step (count.cpp:363-385).  The rule depends only on segment positions and lags,
 // so the host evaluates it (host_first_epoch) and hands the result to the kernels by value.
@@ -256,7 +268,8 @@ __device__ __forceinline__ unsigned long long make_meta(int type, int lim_start,
            ((unsigned long long)(desc & 0xffff) << 32) | ((unsigned long long)(desc_new & 0xffff) << 48);
 }
 
-__device__ __forceinline__ double* rec_ptr(const KArgs& A, long long p, unsigned k) {
+template <class KA>
+__device__ __forceinline__ double* rec_ptr(const KA& A, long long p, unsigned k) {
     return A.log + ((size_t)p * A.cap + (k % A.cap)) * A.RS;
 }
 

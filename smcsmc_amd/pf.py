@@ -49,7 +49,7 @@ class _Params(C.Structure):
     _fields_ = [("np", C.c_int64), ("ess_fraction", C.c_double), ("seed", C.c_uint64),
                 ("max_trace_events", C.c_int32), ("flags", C.c_int32),
                 ("log_cap", C.c_int64), ("gen_cap", C.c_int64), ("piece_cap", C.c_int64),
-                ("debug", C.c_int32), ("mig_cap", C.c_int32)]
+                ("debug", C.c_int32), ("mig_cap", C.c_int32), ("count_wgs", C.c_int32), ("reserved3", C.c_int32)]
 
 
 DEBUG_FORCE_LDS, DEBUG_NO_FUSE, DEBUG_NO_COUNT, DEBUG_TWO_LAUNCH = 1, 2, 4, 8
@@ -92,7 +92,7 @@ class PackedLookahead:
 EXPORTS = [
     "pf_last_error", "pf_device_count", "pf_create", "pf_destroy", "pf_init_prior", "pf_load_segments", "pf_load_lookahead",
     "pf_terminal_branch_quantiles",
-    "pf_update_segment", "pf_count", "pf_resample", "pf_run", "pf_finish", "pf_sync",
+    "pf_update_segment", "pf_count", "pf_resample", "pf_run", "pf_run_many", "pf_finish", "pf_sync",
     "pf_num_segments_done", "pf_logl", "pf_get_counts", "pf_get_trace", "pf_get_resample_events",
     "pf_get_particles", "pf_get_migrations", "pf_get_local_recomb", "pf_sample_tree_events", "pf_sample_tree_events_pops", "pf_get_kernel_time", "pf_set_timing", "pf_get_stats", "pf_debug_stamps", "pf_simulate_sites",
     "pf_median_survival", "pf_test_math", "pf_test_div", "pf_test_uniform", "pf_test_reduce", "pf_test_systematic",
@@ -123,6 +123,7 @@ def load_library(path=None):
     L.pf_count.argtypes = [vp, C.c_int64, C.c_int]
     L.pf_resample.argtypes = [vp, C.c_int64]
     L.pf_run.argtypes = [vp, C.c_int64, C.c_int64]
+    L.pf_run_many.argtypes = [vp, C.c_int32, C.c_int64, C.c_int64]
     L.pf_finish.argtypes = [vp]
     L.pf_sync.argtypes = [vp]
     L.pf_sample_tree_events.restype = C.c_int64
@@ -249,7 +250,7 @@ KERNEL_CLASSES = ("extend", "decide", "count", "resample")
 
 class ParticleFilter:
     def __init__(self, model, np_particles, ess_fraction=0.5, seed=1, max_trace_events=64, device=0, local_recomb=False,
-                 record_trees=False, log_cap=0, gen_cap=0, piece_cap=0, debug=0, mig_cap=0):
+                 record_trees=False, log_cap=0, gen_cap=0, piece_cap=0, debug=0, mig_cap=0, count_wgs=0):
         self.L = load_library()
         m = model
         self._ct = np.ascontiguousarray(m["change_times"], dtype=np.float64)
@@ -269,7 +270,7 @@ class ParticleFilter:
         self.loci_length = float(m["loci_length"])
         self._params = _Params(self.Np, float(ess_fraction), int(seed), self.max_trace_events,
                                (1 if local_recomb else 0) | (2 if record_trees else 0),
-                               int(log_cap), int(gen_cap), int(piece_cap), int(debug), int(mig_cap))
+                               int(log_cap), int(gen_cap), int(piece_cap), int(debug), int(mig_cap), int(count_wgs), 0)
         self.mig_cap = int(mig_cap) if mig_cap else 96
         self.h = self.L.pf_create(C.byref(self._model), C.byref(self._params), int(device))
         if not self.h:
@@ -317,6 +318,15 @@ class ParticleFilter:
 
     def run(self, s_begin=0, s_end=None):
         self._chk(self.L.pf_run(self.h, int(s_begin), int(self.n_segs if s_end is None else s_end)))
+
+    @staticmethod
+    def run_many(filters, s_begin=0, s_end=None):
+        """Rows [s_begin, s_end) of several chunks (filters on one device, same shape) in lockstep: one launch per row
+        covers all of them (pf_run_many).  A chunk with fewer rows stops at its end."""
+        if s_end is None:
+            s_end = max(f.n_segs for f in filters)
+        hs = (C.c_void_p * len(filters))(*[f.h for f in filters])
+        filters[0]._chk(filters[0].L.pf_run_many(hs, len(filters), int(s_begin), int(s_end)))
 
     def update_segment(self, s):
         self._chk(self.L.pf_update_segment(self.h, int(s)))

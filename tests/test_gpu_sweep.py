@@ -1,0 +1,113 @@
+"""The multi-chunk row pipeline (k_sweep, pf_run_many): the argument block read from device memory, the count windows and
+the plan of every step worked out on the device, several chunks per launch.  Every chunk must be bit-identical to its
+own single-chunk run through k_pipe (argument block by value, windows from the host) and to the oracle."""
+import numpy as np
+import pytest
+
+import cases
+from smcsmc_amd import ParticleFilter
+
+pytestmark = pytest.mark.gpu
+K_PIPE = 16          # PF_DEBUG_K_PIPE
+
+
+def _bits(x):
+    return np.asarray(x, np.float64).view(np.uint64)
+
+
+def _run_alone(model, segs, Np, seed, debug, step=None, **kw):
+    f = ParticleFilter(model, Np, seed=seed, debug=debug, **kw)
+    f.init_prior(0.0); f.load_segments(segs)
+    if step is None:
+        f.run()
+    else:
+        n = len(segs["start"])
+        for s0 in range(0, n, step):
+            f.run(s0, min(n, s0 + step))
+    f.finish()
+    return f
+
+
+def _same(a, b):
+    assert _bits(a.logl()) == _bits(b.logl())
+    ta, tb = a.trace(), b.trace()
+    for k in ("T", "ess", "logl"):
+        assert (_bits(ta[k]) == _bits(tb[k])).all(), k
+    assert (ta["resampled"] == tb["resampled"]).all()
+    sa, pa = a.resample_events(); sb, pb = b.resample_events()
+    assert (sa == sb).all() and (pa == pb).all()
+    ca, cb = a.counts(), b.counts()
+    for k in ca:
+        assert (_bits(ca[k]) == _bits(cb[k])).all(), k
+    wa, wb = a.particles(), b.particles()
+    for k in wa:
+        assert (np.asarray(wa[k]).view(np.uint8) == np.asarray(wb[k]).view(np.uint8)).all(), k
+
+
+@pytest.mark.parametrize("n,Np,biased", [(4, 1000, False), (2, 300, False), (8, 700, False), (4, 640, True), (6, 513, True)])
+def test_sweep_equals_k_pipe_and_oracle(oracle, hiplib, n, Np, biased):
+    import oracle_lib
+    model = cases.make_model(n=n, E=10, L=1.5e5)
+    if biased:
+        model.update(bias_heights=[400.0], bias_strengths=[3.0, 1.0], delay_type=0, application_delays=np.full(10, 3000.0))
+    segs = cases.make_segments(model, seed=11, max_seg_len=4000)
+    a = _run_alone(model, segs, Np, 5, 0, local_recomb=True)               # k_sweep, one chunk
+    b = _run_alone(model, segs, Np, 5, K_PIPE, local_recomb=True)          # k_pipe
+    _same(a, b)
+    la, lb = a.local_recomb(), b.local_recomb()
+    for k in la:                                                            # atomics: same terms, any order
+        np.testing.assert_allclose(la[k], lb[k], rtol=1e-9, atol=1e-9 * max(1e-300, float(np.abs(lb[k]).max())))
+    o = oracle_lib.Oracle(model, Np, seed=5)
+    o.init_prior(0.0); o.run(o.pack_segments(model, segs))
+    assert _bits(a.logl()) == _bits(o.logl())
+    sg, pg = a.resample_events(); so, po = o.resample_events()
+    assert (sg == so).all() and (pg == po).all()
+    co, cg = o.counts(), a.counts()
+    for k in ("coal_count", "coal_opp", "rec_count", "rec_opp"):
+        np.testing.assert_allclose(cg[k], co[k], rtol=1e-9, atol=1e-300)
+
+
+def test_sweep_in_pieces_equals_one_call(hiplib):
+    """pf_run over [0, S) in calls of 37 rows (two flush steps and a fresh window seed each) = one call."""
+    model = cases.make_model(n=4, E=8, L=1.2e5)
+    segs = cases.make_segments(model, seed=3, max_seg_len=3000)
+    a = _run_alone(model, segs, 900, 2, 0)
+    b = _run_alone(model, segs, 900, 2, 0, step=37)
+    _same(a, b)
+
+
+def test_chunks_in_one_launch_equal_their_own_runs(hiplib):
+    """Five chunks with different data, lengths and seeds through pf_run_many: each equals its pf_run, bit for bit."""
+    model = cases.make_model(n=4, E=12, L=2e5)
+    chunks = []
+    for k in range(5):
+        m = dict(model, loci_length=float(model["loci_length"] * (0.5 + 0.125 * k)))
+        segs = cases.make_segments(m, seed=20 + k, max_seg_len=5000)
+        chunks.append((m, segs))
+    alone = [_run_alone(m, sg, 1024, 7 + k, K_PIPE) for k, (m, sg) in enumerate(chunks)]
+    many = []
+    for k, (m, sg) in enumerate(chunks):
+        f = ParticleFilter(m, 1024, seed=7 + k)
+        f.init_prior(0.0); f.load_segments(sg)
+        many.append(f)
+    nmax = max(f.n_segs for f in many)
+    assert len({f.n_segs for f in many}) > 1                # the chunks do not end together
+    for s0 in range(0, nmax, 300):                          # several calls: chunks that are done sit the later ones out
+        ParticleFilter.run_many(many, s0, min(nmax, s0 + 300))
+    for f in many:
+        f.finish()
+    for f, g in zip(many, alone):
+        assert f.segments_done() == g.segments_done()
+        _same(f, g)
+
+
+def test_run_many_rejects_chunks_of_different_shape(hiplib):
+    from smcsmc_amd import PfError
+    m1 = cases.make_model(n=4, E=8, L=5e4)
+    s1 = cases.make_segments(m1, seed=1, max_seg_len=3000)
+    a = ParticleFilter(m1, 512, seed=1); a.init_prior(0.0); a.load_segments(s1)
+    b = ParticleFilter(m1, 256, seed=1); b.init_prior(0.0); b.load_segments(s1)
+    with pytest.raises(PfError, match="must share"):
+        ParticleFilter.run_many([a, b])
+    with pytest.raises(PfError, match="twice"):
+        ParticleFilter.run_many([a, a])
