@@ -92,8 +92,8 @@ typedef struct pf_params {
                                   * unbounded); 0 = 96.  The lists live in LDS next to the epoch tables: about 230 fit with
                                   * 32 epochs and two populations, pf_create says when a value does not.  One too many on
                                   * any tree is a reported error ("too many migration events on one local tree"). */
-    int32_t count_wgs;           /* row pipeline: workgroups per epoch that share the lagged counting of a row (0 = 8; at
-                                  * most one per 256 particles).  The sums are grouped by workgroup, so the value is part
+    int32_t count_wgs;           /* row pipeline: workgroups per epoch that share the lagged counting of a row (0 = one
+                                  * per 256 particles, which is also the most).  The sums are grouped by workgroup, so the value is part
                                   * of what makes two runs bit-identical. */
     int32_t reserved3;
 } pf_params;

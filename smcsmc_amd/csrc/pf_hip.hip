@@ -377,7 +377,6 @@ __device__ __forceinline__ const KArgs& pf_reopen(const KArgs& A) { return A; }
 // the row's extend workgroups left in ring slot `slot`: the level-2 / level-3 part of the canonical radix-64 reduction,
 // operation for operation what k_decide does, so T, S1, ESS, the flag and the uniform are bit-identical everywhere.
 #define PF_PIPE_STAGE 16        // wavefronts of pilot scans staged per workgroup for the parent search
-#define PF_PIPE_COUNT_WGS 8     // default count workgroups per epoch of the row pipeline (pf_params.count_wgs)
 struct RowDecision { double T, S1, S2, ess, inv, u; int flag; };
 struct PipeLds {                // carved from the dynamic LDS of k_pipe behind the epoch tables
     double* l2s;                // [ncpad] level-2 inclusive scan of the per-wavefront pilot totals
@@ -3099,9 +3098,10 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     // accumulators of the count workgroups per epoch (measured: four times as many count workgroups per epoch in the row
     // pipeline made a row 15 % slower -- the launch then holds 5 000 workgroups of 30 KB LDS each, four rounds of the chip)
     A.nbx = h->nblocks;
-    // the row pipeline spreads an epoch's count tasks (the ancestor runs of the generations in its window: a few hundred to
-    // a few thousand per row) over this many workgroups; the stand-alone k_count uses one per particle workgroup
-    h->ncw = p->count_wgs > 0 ? std::min<int>(p->count_wgs, h->nblocks) : std::min(h->nblocks, PF_PIPE_COUNT_WGS);
+    // the row pipeline spreads an epoch's count tasks (the ancestor runs of the generations in its window: for the old epochs,
+    // whose lag is a few rows, nearly one per particle) over this many workgroups; fewer is slower (C3 shape, one chunk: 40
+    // workgroups 32.9 us per row, 16: 38.7, 8: 53.7, 4: 91.4, 2: 168 -- profiles/round3/count_wgs.md)
+    h->ncw = p->count_wgs > 0 ? std::min<int>(p->count_wgs, h->nblocks) : h->nblocks;
     rc |= dalloc(h, &A.totals, (size_t)A.ncol * E);
     rc |= dalloc(h, &A.partial, (size_t)E * A.nbx * A.ncol);
     A.max_trace_events = h->max_trace_events;

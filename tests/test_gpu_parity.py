@@ -694,6 +694,8 @@ def test_binary_writes_the_tree_dump(hiplib, tmp_path):
     text = gzip.open(tmp_path / "arg.trees.gz", "rt").read()
     lines = text.splitlines()
     assert len(lines) > 10 and all(ln.split("\t")[0] in ("R", "C") and len(ln.split("\t")) == 6 for ln in lines)
+    import trees_format
+    trees_format.check_lines(lines, nsam=2, npop=1)           # the grammar of the reference's own example file
     assert lines[-1].split("\t")[0] == "C" and lines[-1].split("\t")[5] == "11"       # the first tree: sample 2 joins sample 1
     m = json.loads(subprocess.run([binary] + core + ["-nsam", "2", "-tmax", "4", "-dumpmodel"], capture_output=True, text=True).stdout)
     E = len(m["change_times"])

@@ -220,7 +220,10 @@ def test_structured_binary_end_to_end(hiplib, tmp_path):
     r = subprocess.run([binary] + core + common + ["-Np", "200", "-seed", "6", "-lag", "50000", "-arg", "-o", str(tmp_path / "arg")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    lines = [ln.split("\t") for ln in gzip.open(tmp_path / "arg.trees.gz", "rt").read().splitlines()]
+    raw_lines = gzip.open(tmp_path / "arg.trees.gz", "rt").read().splitlines()
+    import trees_format
+    trees_format.check_lines(raw_lines, nsam=8, npop=2)   # the grammar of the reference's own example file (R, C and M lines)
+    lines = [ln.split("\t") for ln in raw_lines]
     assert all(len(f) == 6 and f[0] in ("R", "C", "M") for f in lines)
     ms = [f for f in lines if f[0] == "M"]
     assert ms and all(f[3] in ("0", "1") and f[4] in ("0", "1") and f[3] != f[4] for f in ms)
