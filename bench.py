@@ -323,9 +323,11 @@ def main():
         segs_all = torch.tensor([float(n_segments)], dtype=torch.float64, device=cdev)
         dist.all_reduce(segs_all, op=dist.ReduceOp.SUM)
         total_segments = float(segs_all.item())
-        # CountModel "all-reduce": all-gather + sum in rank order (bit-identical for any arrival order)
-        packed = np.concatenate([np.ravel(counts[k]) for k in sorted(counts) if isinstance(counts[k], np.ndarray)]
-                                + [[counts["delayed_opp"], counts["resample_count"], logl]])
+        # CountModel "all-reduce": all-gather + sum in rank order (bit-identical for any arrival order), in the packed layout
+        # of the library (reduce.pack_counts = PF_COUNTS_LEN2: what bin/smcsmc exchanges and the gloo tests cover)
+        from smcsmc_amd import reduce as pfreduce
+        counts["logl"] = logl
+        packed = pfreduce.pack_counts(counts)
         mine = torch.tensor(packed, dtype=torch.float64, device=cdev)
         gathered = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
@@ -353,7 +355,8 @@ def main():
         # rocprofv3 passes (counters cannot be read from inside this process) and kept under profiles/
         traffic = None
         import glob
-        for pmc_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round2", "*_pmc_k_*.json"))):
+        for pmc_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round2", "*_pmc_k_*.json"))) + \
+                sorted(glob.glob(os.path.join(ROOT, "profiles", "round3", "*_pmc_k_*.json"))):      # the newest matching file wins
             pmc = json.load(open(pmc_path))
             if pmc.get("shape") == {"nsam": args.nsam, "np": args.np, "epochs": args.epochs, "pops": args.pops}:
                 traffic = pmc["traffic_bytes_per_launch"]

@@ -101,6 +101,7 @@ typedef struct pf_params {
 #define PF_DEBUG_NO_FUSE   2     /* complete every row with the stand-alone k_resample (two-stream pipeline) */
 #define PF_DEBUG_NO_COUNT  4     /* profiling: skip the lagged counting and the ledger upkeep */
 #define PF_DEBUG_TWO_LAUNCH 8    /* rows as two launches (extend + decide) instead of the single-launch pipeline */
+#define PF_DEBUG_NO_SPEC_STAGE 32 /* row pipeline: stage the pilot scans for the parent search only once the range is known (A/B) */
 #define PF_DEBUG_K_PIPE   16     /* rows through k_pipe (argument block passed by value, windows from the host) instead of k_sweep */
 
 typedef struct pf_segments {

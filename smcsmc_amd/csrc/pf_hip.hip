@@ -545,12 +545,29 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
     unsigned o_widx = 0;
     unsigned long long o_ctr = 0;
     long long o_nres = 0; int o_bflag = 0, o_bgen = 0;
+    double spec_sm[PF_PIPE_STAGE * 64 / PF_BS];
+    int spec_lo = 0;
     if constexpr (PIPE) {
         const int fs = __builtin_amdgcn_readfirstlane(PR.slot_prev >= 0 ? PR.slot_prev : c->cur);
         if (PR.complete) {
             pre = row_preload(A, fs);
             const Ctrl::RowInfo& before = c->ri[(fs + 3) & 3];     // the row before it, published by the previous launch
             o_nres = before.n_res; o_bflag = before.flag; o_bgen = before.gen;
+            // The parent search of a resampling row stages the pilot scans of the wavefronts its parents sit in.  Offspring
+            // stay close to their parents' slots (the offsets drift like a random walk of a few hundred slots), so the scans
+            // of this workgroup's own wavefronts and six on either side are requested now, with everything else the prologue
+            // reads, instead of in a round trip of their own once the search knows the range; a range outside this window
+            // is staged the old way.
+            spec_lo = (int)blockIdx.x * (PF_BS / 64) - (PF_PIPE_STAGE - PF_BS / 64) / 2;
+            if (spec_lo > A.nc - PF_PIPE_STAGE) spec_lo = A.nc - PF_PIPE_STAGE;
+            if (spec_lo < 0) spec_lo = 0;
+            if (A.flags & 256) spec_lo = -0x40000000;              // PF_DEBUG_NO_SPEC_STAGE (A/B): never covers the range
+            const double* sm0 = A.rg_scan1m + (size_t)fs * A.Np;
+#pragma unroll
+            for (int k = 0; k < PF_PIPE_STAGE * 64 / PF_BS; ++k) {
+                const long long src = (long long)spec_lo * 64 + k * PF_BS + threadIdx.x;
+                spec_sm[k] = (src >= 0 && src < A.Np) ? sm0[src] : PF_INF;
+            }
         }
         if (active) {
             const DState own = state_slot(A, fs);
@@ -598,6 +615,8 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
             G_end = o_bgen + o_bflag;
             ev = (int)n_res;
             PF_STAMP(1);
+#pragma unroll
+            for (int k = 0; k < PF_PIPE_STAGE * 64 / PF_BS; ++k) q.stage[k * PF_BS + threadIdx.x] = spec_sm[k];    // visible after decide_row's barriers
             RowDecision d = decide_row<true>(A, q, row_slot, n_res, pre);
             PF_STAMP(2);
             inv = d.inv; S1v = d.S1;
@@ -654,9 +673,15 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
                 int nst = cmax - cmin + 1;
                 if (nst > PF_PIPE_STAGE) nst = PF_PIPE_STAGE;
                 if (nst < 0) nst = 0;
-                for (int idx = threadIdx.x; idx < nst * 64; idx += PF_BS) {
-                    long long src = (long long)cmin * 64 + idx;
-                    q.stage[idx] = src < A.Np ? sm[src] : PF_INF;
+                int stage_lo = cmin;
+                if (cmin >= spec_lo && cmax < spec_lo + PF_PIPE_STAGE) {
+                    stage_lo = spec_lo; nst = PF_PIPE_STAGE;       // the scans requested with the prologue cover the range
+                } else {
+                    __syncthreads();                               // everybody has read the range before the buffer is refilled
+                    for (int idx = threadIdx.x; idx < nst * 64; idx += PF_BS) {
+                        long long src = (long long)cmin * 64 + idx;
+                        q.stage[idx] = src < A.Np ? sm[src] : PF_INF;
+                    }
                 }
                 __syncthreads();
                 if (threadIdx.x == 0) {
@@ -667,10 +692,10 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
                 if (active) {
                     const double coff_p = pipe_chunk_offset(q, pch);
                     const double pm_p = q.pmx[pch];
-                    const bool staged = pch - cmin < nst;
+                    const bool staged = pch >= stage_lo && pch - stage_lo < nst;
                     auto val_at = [&](int l) -> double {           // largest prefix sum up to particle pch*64 + l
                         long long idx = (long long)pch * 64 + l;
-                        double smv = staged ? q.stage[(pch - cmin) * 64 + l] : (idx < A.Np ? sm[idx] : PF_INF);
+                        double smv = staged ? q.stage[(pch - stage_lo) * 64 + l] : (idx < A.Np ? sm[idx] : PF_INF);
                         double w = coff_p + smv;
                         return pm_p > w ? pm_p : w;
                     };
@@ -1535,6 +1560,7 @@ __device__ __forceinline__ CountSrc count_src_parity(const KA& A, int sp, int e)
 
 #define PF_CNT_TILE 2048      // generations whose run counts are staged in LDS at a time
 #define PF_CNT_WIDE 128       // run lists longer than this are strided over by the whole grid column
+#define PF_CNT_BATCH 2        // count tasks whose first two rounds of loads a thread has in flight together
 
 template <int NI, int P, class KA>
 __device__ __forceinline__ void count_run(AccT<P>& acc, const KA& A, const CountSrc& Q, const Win& W, const LMap& L, int g, long long i,
@@ -1633,35 +1659,97 @@ __device__ __forceinline__ void count_body(const KA& A, const CountSrc& Q, int e
         if (threadIdx.x == PF_BS - 1) s_off[ntile] = run;      // total (idx == ntile is only reached when ntile == TILE)
         __syncthreads();
         const long long T = s_off[ntile];
-        for (long long t = gtid; t < T; t += nthreads) {
-            // generation of task t: last idx with s_off[idx] <= t
-            int lo_i = 0, hi_i = ntile;
-            while (hi_i - lo_i > 1) {
-                int mid = (lo_i + hi_i) >> 1;
-                if ((long long)s_off[mid] <= t) lo_i = mid; else hi_i = mid;
-            }
-            const int g = tile_hi - lo_i;
-            const long long i = t - s_off[lo_i];
-            if (g == G) {
-                // live particle: its own weight, its open stretch, the records it wrote this generation
-                const long long a = i;
-                double w = Q.w[a] * inv;
-                double S[NI];
+        // PF_CNT_BATCH tasks per thread and trip: a task is three dependent rounds of loads (run list -> posterior scan and
+        // record range -> records) and little arithmetic, and the count workgroups hide latency badly (three per CU), so
+        // the first two rounds of four tasks are in flight together.  The contributions are still added in task order
+        // (t, t + nthreads, ...): the sums do not change.
+        for (long long tb = gtid; tb < T; tb += (long long)PF_CNT_BATCH * nthreads) {
+            int tg[PF_CNT_BATCH], tnr[PF_CNT_BATCH];
+            long long ti[PF_CNT_BATCH];
+            bool tval[PF_CNT_BATCH], tlive[PF_CNT_BATCH];
 #pragma unroll
-                for (int r = 0; r < NI; ++r) S[r] = r < n - 1 ? Q.S[(size_t)r * Np + a] : 0.0;
-                double xm = Q.xm[a];
-                int ml = Q.ml[a];
-                unsigned k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
-                unsigned k1 = Q.widx[a];
-                if (w == 0.0) continue;
-                stretch_contrib<NI, P>(acc, A, W, L, w, xm, PF_INF, S, ml);
-                if (k1 - k0 > A.cap) { if (!A.ctrl->err) A.ctrl->err = ERR_LOG_OVERFLOW; continue; }
-                records_contrib<NI, P>(acc, A, W, L, w, a, k0, k1);
-            } else {
-                const int nr = s_off[lo_i + 1] - s_off[lo_i];
-                const int* rst = Q.lists.st + (size_t)(g % A.Gcap) * Np;
-                const int* ran = Q.lists.anc + (size_t)(g % A.Gcap) * Np;
-                count_run<NI, P>(acc, A, Q, W, L, g, i, nr, rst, ran, inv);
+            for (int u = 0; u < PF_CNT_BATCH; ++u) {
+                const long long t = tb + (long long)u * nthreads;
+                tval[u] = t < T;
+                // generation of task t: last idx with s_off[idx] <= t
+                int lo_i = 0, hi_i = ntile;
+                while (tval[u] && hi_i - lo_i > 1) {
+                    int mid = (lo_i + hi_i) >> 1;
+                    if ((long long)s_off[mid] <= t) lo_i = mid; else hi_i = mid;
+                }
+                tg[u] = tile_hi - lo_i;
+                ti[u] = t - s_off[lo_i];
+                tnr[u] = s_off[lo_i + 1] - s_off[lo_i];
+                tlive[u] = tval[u] && tg[u] == G;
+            }
+            // round 1: the run (slots [q0, q1) of the row descend from slot a of generation g)
+            int q0[PF_CNT_BATCH], q1[PF_CNT_BATCH];
+            long long aa[PF_CNT_BATCH];
+#pragma unroll
+            for (int u = 0; u < PF_CNT_BATCH; ++u) {
+                q0[u] = 0; q1[u] = 0; aa[u] = -1;
+                if (tval[u] && !tlive[u]) {
+                    const int* rst = Q.lists.st + (size_t)(tg[u] % A.Gcap) * Np;
+                    const int* ran = Q.lists.anc + (size_t)(tg[u] % A.Gcap) * Np;
+                    q0[u] = rst[ti[u]];
+                    q1[u] = ti[u] + 1 < tnr[u] ? rst[ti[u] + 1] : (int)Np;
+                    aa[u] = ran[ti[u]];
+                }
+            }
+            // round 2: posterior mass of the run's slots (difference of the inclusive posterior scan) and the ancestor's records
+            // of that generation.  A ledger ring that has overflowed (reported by the bookkeeping, ERR_GEN_OVERFLOW) aliases
+            // generations: whatever is read then must stay inside the arrays until the host sees the error.
+            bool tok[PF_CNT_BATCH];
+            double mhi[PF_CNT_BATCH], mlo[PF_CNT_BATCH];
+            unsigned rk0[PF_CNT_BATCH], rk1[PF_CNT_BATCH], rwl[PF_CNT_BATCH];
+#pragma unroll
+            for (int u = 0; u < PF_CNT_BATCH; ++u) {
+                tok[u] = tval[u] && !tlive[u] && !(q1[u] <= q0[u] || q1[u] > (int)Np || q0[u] < 0 || aa[u] < 0 || aa[u] >= Np);
+                mhi[u] = 0.0; mlo[u] = 0.0; rk0[u] = 0; rk1[u] = 0; rwl[u] = 0;
+                if (tok[u]) {
+                    mhi[u] = Q.offp[(q1[u] - 1) >> 6] + Q.scanp[q1[u] - 1];
+                    mlo[u] = q0[u] > 0 ? Q.offp[(q0[u] - 1) >> 6] + Q.scanp[q0[u] - 1] : 0.0;
+                    rk0[u] = A.gstart[(size_t)(tg[u] % A.Gcap) * Np + aa[u]];
+                    rk1[u] = A.gstart[(size_t)((tg[u] + 1) % A.Gcap) * Np + aa[u]];
+                    rwl[u] = Q.widx_live[aa[u]];
+                }
+            }
+            // round 3, task by task.  One copy of the record loop for the four tasks: the task's values are picked with selects
+            // (the arrays live in registers and cannot be indexed at run time).
+#pragma unroll 1
+            for (int u = 0; u < PF_CNT_BATCH; ++u) {
+                bool live_u = false, ok_u = false;
+                int g_u = 0;
+                long long i_u = 0, a_u = 0;
+                double hi_u = 0.0, lo_u = 0.0;
+                unsigned k0_u = 0, k1_u = 0, wl_u = 0;
+#pragma unroll
+                for (int v = 0; v < PF_CNT_BATCH; ++v)
+                    if (v == u) {
+                        live_u = tlive[v]; ok_u = tok[v]; g_u = tg[v]; i_u = ti[v]; a_u = aa[v];
+                        hi_u = mhi[v]; lo_u = mlo[v]; k0_u = rk0[v]; k1_u = rk1[v]; wl_u = rwl[v];
+                    }
+                if (live_u) {
+                    // live particle: its own weight, its open stretch, the records it wrote this generation
+                    const long long a = i_u;
+                    double w = Q.w[a] * inv;
+                    double S[NI];
+#pragma unroll
+                    for (int r = 0; r < NI; ++r) S[r] = r < n - 1 ? Q.S[(size_t)r * Np + a] : 0.0;
+                    double xm = Q.xm[a];
+                    int ml = Q.ml[a];
+                    unsigned k0 = A.gstart[(size_t)(g_u % A.Gcap) * Np + a];
+                    unsigned k1 = Q.widx[a];
+                    if (w == 0.0) continue;
+                    stretch_contrib<NI, P>(acc, A, W, L, w, xm, PF_INF, S, ml);
+                    if (k1 - k0 > A.cap) { if (!A.ctrl->err) A.ctrl->err = ERR_LOG_OVERFLOW; continue; }
+                    records_contrib<NI, P>(acc, A, W, L, w, a, k0, k1);
+                } else if (ok_u) {
+                    const double w = (hi_u - lo_u) * inv;
+                    if (!(w > 0.0)) continue;
+                    if (wl_u - k0_u > A.cap || k1_u - k0_u > A.cap) { if (!A.ctrl->err) A.ctrl->err = ERR_LOG_OVERFLOW; continue; }
+                    records_contrib<NI, P>(acc, A, W, L, w, a_u, k0_u, k1_u);
+                }
             }
         }
     }
@@ -2756,6 +2844,7 @@ struct pf_handle {
     bool pipe = false;            // the single-launch pipeline applies (one population, n <= 8; rings allocated)
     size_t smem_pipe = 0;
     int ncw = 0;                  // count workgroups per epoch in the row pipeline (pf_params.count_wgs)
+    bool no_spec_stage = false;   // PF_DEBUG_NO_SPEC_STAGE
     bool use_k_pipe = false;      // PF_DEBUG_K_PIPE: rows through k_pipe (argument block by value, one chunk per launch) instead of k_sweep
     SweepChunk* d_sweep = nullptr; // device table of the chunks this handle leads through k_sweep
     int d_sweep_cap = 0;
@@ -2939,12 +3028,13 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     h->no_count = (p->debug & PF_DEBUG_NO_COUNT) != 0;
     h->two_launch_rows = (p->debug & PF_DEBUG_TWO_LAUNCH) != 0;
     h->use_k_pipe = (p->debug & PF_DEBUG_K_PIPE) != 0;
+    h->no_spec_stage = (p->debug & PF_DEBUG_NO_SPEC_STAGE) != 0;
     h->h_lags.assign(m->lags, m->lags + E);
     h->h_counted_to.assign(E, 0.0);
     h->h_L = m->loci_length;
     KArgs& A = h->A;
     memset(&A, 0, sizeof(A));
-    A.E = E; A.n = n; A.flags = m->flags;
+    A.E = E; A.n = n; A.flags = m->flags | (h->no_spec_stage ? 256 : 0);
     A.L = m->loci_length; A.mu = m->mutation_rate; A.rho = m->recombination_rate;
     A.Np = Np;
     A.mcap = mcap;
@@ -3660,9 +3750,17 @@ static int run_sweep(pf_handle* const* hs, int nh, long long s_begin, long long 
     if (steps == 0) return 0;
     HIPCHK(hipMemcpyAsync(h->d_sweep, h->h_sweep.data(), sizeof(SweepChunk) * (size_t)nh, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_sweep_seed, dim3(nh), dim3(64), 0, h->stream, h->d_sweep);
-    const dim3 grid((unsigned)(nb + 1 + nL_full + h->ncw * E), (unsigned)nh);
+    // the count workgroups of a step belong to row s - 2, whose windows the host knows as well as the device does: the grid
+    // ends with the last epoch column any chunk needs (epochs before a chunk's first moving one are not launched at all)
+    std::vector<Windows> W1((size_t)nh), W2((size_t)nh);
+    for (int k = 0; k < nh; ++k) { W1[k] = no_windows(hs[k]); W2[k] = W1[k]; }
     for (long long t = 0; t < steps; ++t) {
-        const bool tm_on = timing_on(h, s_begin + t);
+        const long long s = s_begin + t;
+        int columns = 0;
+        for (int k = 0; k < nh; ++k)
+            if (s >= s_begin + 2 && s - 2 <= h->h_sweep[k].s_last && !hs[k]->no_count) columns = std::max(columns, E - W2[k].first);
+        const dim3 grid((unsigned)(nb + 1 + nL_full + h->ncw * columns), (unsigned)nh);
+        const bool tm_on = timing_on(h, s);
         {
             Timed tm(h, 0, tm_on);
             if (h->n <= 4 && biased) launch_sweep<4, true>(h, grid, t);
@@ -3672,16 +3770,22 @@ static int run_sweep(pf_handle* const* hs, int nh, long long s_begin, long long 
         }
         if (check_launch("k_sweep")) return -1;
         if ((t & 1023) == 1023) trim_spans(h);
+        for (int k = 0; k < nh; ++k) {
+            pf_handle* g = hs[k];
+            W2[k] = W1[k];
+            if (s <= h->h_sweep[k].s_last) {
+                W1[k] = host_windows(g, seg_pos(g, s), false);
+                g->step_windows = W1[k];
+                if (W1[k].first < E && !g->no_count) g->fin_pending = true;
+            } else {
+                W1[k] = no_windows(g);
+            }
+        }
     }
     h->k_launches[0] -= 2;                                      // flush steps are not rows
-    // the host's copy of the window state and the bookkeeping flags of every chunk follow the rows it has done
     for (int k = 0; k < nh; ++k) {
         pf_handle* g = hs[k];
         const long long last = h->h_sweep[k].s_last;
-        for (long long s = s_begin; s <= last; ++s) {
-            g->step_windows = host_windows(g, seg_pos(g, s), false);
-            if (g->step_windows.first < E && !g->no_count) g->fin_pending = true;
-        }
         if (last >= s_begin) g->seg_done = last + 1;
         if (k > 0) {                                            // the chunk's own stream continues after the sweep
             hipEvent_t ev = next_sync_event(h);

@@ -86,6 +86,21 @@ def test_c3_shape_at_its_own_particle_count(oracle, hiplib):
     assert co["rec_count"].sum() > 0
 
 
+def test_c3_on_the_configuration_bench_py_times(oracle, hiplib):
+    """The same check on exactly what bench.py runs by default: its build_workload() -- data drawn on the device (k_simulate),
+    the calibrated lags of the binary's default (-calibrate_lag 2) -- at Np = 10 000; a 160 kb chunk of it."""
+    import argparse
+    import bench
+    args = argparse.Namespace(nsam=4, length=1.6e5, epochs=32, pops=1, np=10000, device=0, host_data=False, uncalibrated_lags=False)
+    model, segs = bench.build_workload(args, seed=1)
+    uncal = _bench_model(4, 32, 1.6e5)["lags"]
+    assert not np.allclose(model["lags"], uncal)               # calibrated, not the round-1 defaults
+    assert len(segs["start"]) >= 200
+    to, co, g = _compare_sweep(oracle, model, segs, 10000, seed=1, local_recomb=True)
+    assert to["resampled"].sum() >= 40
+    assert co["rec_count"].sum() > 0
+
+
 def test_c5_shape_at_its_own_particle_count(oracle, hiplib):
     """BASELINE.json configs[4]: 4 diploids from two populations (isolation with migration), Np = 20 000, E = 32 -- the
     first 40 kb (about 100 rows)."""
