@@ -223,7 +223,7 @@ def main():
                     help="synthetic data from the numpy simulator (round-1 inputs) instead of the device-side simulator")
     ap.add_argument("--uncalibrated-lags", action="store_true",
                     help="the reference's uncalibrated lags 4/(rho*top_t) instead of the calibrated default of the binary")
-    ap.add_argument("--debug", type=int, default=0, help="pf_params.debug bits (include/smcsmc_pf.h): 4 no counting, 8 two launches per row, 16 k_pipe instead of k_sweep")
+    ap.add_argument("--debug", type=int, default=0, help="pf_params.debug bits (include/smcsmc_pf.h): 4 no counting, 8 two launches per row, 16 the round-2 row paths, 32 no speculative staging, 64 extend role and the other roles as two launches")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a single-GPU box: every rank uses device 0 and the collectives go through gloo "
                          "on host tensors (RCCL refuses two ranks on one device); the numbers it prints are not a scaling result")

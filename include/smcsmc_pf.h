@@ -101,8 +101,11 @@ typedef struct pf_params {
 #define PF_DEBUG_NO_FUSE   2     /* complete every row with the stand-alone k_resample (two-stream pipeline) */
 #define PF_DEBUG_NO_COUNT  4     /* profiling: skip the lagged counting and the ledger upkeep */
 #define PF_DEBUG_TWO_LAUNCH 8    /* rows as two launches (extend + decide) instead of the single-launch pipeline */
+#define PF_DEBUG_SPLIT_ROLES 64  /* one population: the extend role and the bookkeeping / ledger / count roles of a step as two launches on
+                                  * two streams, as the structured models run them (A/B against the single launch) */
 #define PF_DEBUG_NO_SPEC_STAGE 32 /* row pipeline: stage the pilot scans for the parent search only once the range is known (A/B) */
-#define PF_DEBUG_K_PIPE   16     /* rows through k_pipe (argument block passed by value, windows from the host) instead of k_sweep */
+#define PF_DEBUG_K_PIPE   16     /* the round-2 row paths: k_pipe (argument block passed by value, windows from the host) instead of k_sweep;
+                                  * structured models: k_extend_mpr + k_decide with the counts on a second stream instead of the row pipeline */
 
 typedef struct pf_segments {
     int64_t n;

@@ -6,11 +6,11 @@ from smcsmc_amd import pf, build as _build
 pf.LIB_PATH = _build.build_stamps_lib()          # the -DPF_STAMPS build of the library (smcsmc_amd/build.py)
 import bench
 ap = argparse.ArgumentParser(); ap.add_argument("--rows", type=int, default=3000); ap.add_argument("--epochs", type=int, default=32)
-ap.add_argument("--np", type=int, default=20000)
+ap.add_argument("--np", type=int, default=20000); ap.add_argument("--debug", type=int, default=0)
 a = ap.parse_args()
 args = argparse.Namespace(nsam=8, length=3e6, epochs=a.epochs, pops=2)
 model, segs = bench.build_workload(args, seed=1)
-f = pf.ParticleFilter(model, a.np, seed=1, max_trace_events=0, local_recomb=True)
+f = pf.ParticleFilter(model, a.np, seed=1, max_trace_events=0, local_recomb=True, debug=a.debug)
 f.load_segments(segs)
 L = f.L
 L.pf_debug_stamps.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]; L.pf_debug_stamps.restype = C.c_int

@@ -29,6 +29,7 @@
 #include "pf_lane.h"
 #include "pf_tree_reg.h"
 #include "pf_mp_host.h"
+#include "pf_pipe.h"
 
 using namespace pf;
 
@@ -365,149 +366,6 @@ __device__ __forceinline__ void pf_acc_trip(unsigned long long* a) { a[5] += 1; 
 template <class KA>
 __device__ __forceinline__ int gridDim_particles(const KA& A) { return (int)((A.Np + PF_BS - 1) / PF_BS); }
 
-// A fresh, opaque handle on the same argument block in the constant address space: loads through it cannot be merged with
-// earlier ones nor hoisted above this point, so what a phase of a long kernel needs from the block is loaded in that phase
-// instead of being held in (and spilled from) scalar registers across the phases before it.  The by-value form of the
-// block (kernels that take KArgs as an argument) is returned as it is.
-__device__ __forceinline__ KArgsC& pf_reopen(KArgsC& A) { KArgsC* q = &A; asm volatile("" : "+s"(q)); return *q; }
-__device__ __forceinline__ const KArgs& pf_reopen(const KArgs& A) { return A; }
-
-// ---- decision on a finished row, made redundantly by every workgroup that needs it (single-launch pipeline) --------
-// normalize_probability (pc.cpp:420-438) and the ESS test of resample (pc.cpp:247-283) from the per-wavefront partials
-// the row's extend workgroups left in ring slot `slot`: the level-2 / level-3 part of the canonical radix-64 reduction,
-// operation for operation what k_decide does, so T, S1, ESS, the flag and the uniform are bit-identical everywhere.
-#define PF_PIPE_STAGE 16        // wavefronts of pilot scans staged per workgroup for the parent search
-struct RowDecision { double T, S1, S2, ess, inv, u; int flag; };
-struct PipeLds {                // carved from the dynamic LDS of k_pipe behind the epoch tables
-    double* l2s;                // [ncpad] level-2 inclusive scan of the per-wavefront pilot totals
-    double* pmx;                // [ncpad + 1] pmx[ch] = largest pilot prefix sum before wavefront ch (pmx[ch + 1]: up to its end)
-    double* l2_post; double* l2_sq; double* l2_tot;   // [64] each
-    double* wredd;              // [PF_BS / 64]
-    double* stage;              // [PF_PIPE_STAGE * 64]
-    int* slo;                   // [PF_BS]
-    int* wint;                  // [3 * PF_BS / 64]
-};
-__host__ __device__ inline size_t pipe_lds_doubles(int nc) {
-    const size_t ncpad = ((size_t)nc + 63) / 64 * 64;
-    return ncpad + (ncpad + 1) + 3 * 64 + PF_BS / 64 + (size_t)PF_PIPE_STAGE * 64 + (PF_BS + 3 * (PF_BS / 64) + 1) / 2 + 2;
-}
-__device__ __forceinline__ PipeLds pipe_carve(double* base, int nc) {
-    const size_t ncpad = ((size_t)nc + 63) / 64 * 64;
-    PipeLds q;
-    q.l2s = base; base += ncpad;
-    q.pmx = base; base += ncpad + 1;
-    q.l2_post = base; base += 64; q.l2_sq = base; base += 64; q.l2_tot = base; base += 64;
-    q.wredd = base; base += PF_BS / 64;
-    q.stage = base; base += (size_t)PF_PIPE_STAGE * 64;
-    q.slo = (int*)base; q.wint = q.slo + PF_BS;
-    return q;
-}
-__device__ __forceinline__ double pipe_chunk_offset(const PipeLds& q, int ch) {
-    double run = 0.0;
-    const int gq = ch / 64;
-    for (int g = 0; g < gq; ++g) run = run + q.l2_tot[g];
-    double off = (ch % 64 == 0) ? 0.0 : q.l2s[ch - 1];
-    return run + off;
-}
-// every thread of the workgroup calls this (it contains barriers); WANT_TABLE: also the prefix maxima the offspring
-// table / parent search need (only computed when the row resamples)
-// the partials a thread needs first, requested before anything else so that their memory round trip overlaps the
-// particle's own loads (what the previous launch wrote comes from another XCD's L2: about a microsecond)
-struct RowPre { double vp = 0.0, vs = 0.0, vl = 0.0, last1 = 0.0; bool have = false; };
-template <class KA>
-__device__ __forceinline__ RowPre row_preload(const KA& A, int slot) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nc = A.nc, ch = wave * 64 + lane;
-    RowPre r;
-    r.have = true;
-    if (ch < nc) {
-        r.vp = A.rg_cpost[(size_t)slot * nc + ch];
-        r.vs = A.rg_csq[(size_t)slot * nc + ch];
-        r.vl = A.rg_cpil[(size_t)slot * nc + ch];
-    }
-    r.last1 = A.ctrl->last1[slot];
-    return r;
-}
-template <bool WANT_TABLE, class KA>
-__device__ __forceinline__ RowDecision decide_row(const KA& A, const PipeLds& q, int slot, long long n_res, RowPre pre = RowPre()) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = PF_BS / 64;
-    const int nc = A.nc;
-    const int ng = (nc + 63) / 64;
-    const double* cpost = A.rg_cpost + (size_t)slot * nc;
-    const double* csq = A.rg_csq + (size_t)slot * nc;
-    const double* cpil = A.rg_cpil + (size_t)slot * nc;
-    const double* cmx1 = A.rg_cmx1 + (size_t)slot * nc;
-    const double last_scan1 = pre.have ? pre.last1 : A.ctrl->last1[slot];
-    for (int g = wave; g < ng; g += nwaves) {
-        int ch = g * 64 + lane;
-        const bool first = pre.have && g == wave;
-        double vp = first ? pre.vp : (ch < nc ? cpost[ch] : 0.0);
-        double vs = first ? pre.vs : (ch < nc ? csq[ch] : 0.0);
-        double vl = first ? pre.vl : (ch < nc ? cpil[ch] : 0.0);
-        double rp = wave_tree_sum(vp);
-        double rs = wave_tree_sum(vs);
-        double sc = wave_hs_scan(vl, lane);
-        if (ch < nc) q.l2s[ch] = sc;
-        if (lane == 63) { q.l2_post[g] = rp; q.l2_sq[g] = rs; q.l2_tot[g] = sc; }
-    }
-    __syncthreads();
-    RowDecision d;
-    {
-        double vp = lane < ng ? q.l2_post[lane] : 0.0;
-        double vs = lane < ng ? q.l2_sq[lane] : 0.0;
-        d.T = wave_tree_sum(vp);
-        d.S2 = wave_tree_sum(vs);
-    }
-    d.S1 = pipe_chunk_offset(q, nc - 1) + last_scan1;   // inclusive scan at the last particle (= oracle incl[N-1])
-    d.ess = (d.S1 * d.S1) / d.S2;
-    d.flag = (d.ess < A.ess_threshold - 1e-6) ? 1 : 0;
-    d.inv = 1.0 / d.T;
-    d.u = d.flag ? philox_uniform(A.seed, 0xFFFFFFFFu, 1, (unsigned long long)n_res) : 0.0;
-    if (WANT_TABLE && d.flag) {
-        // pmx[ch] = max over wavefronts c' < ch of (chunk_off[c'] + mx1[c']): the running maximum that makes the offspring
-        // table monotone is taken on the prefix sums (lo_raw is monotone in its argument), as in k_decide
-        const int perc = (nc + PF_BS - 1) / PF_BS;
-        const int c0 = tid * perc, c1 = c0 + perc < nc ? c0 + perc : nc;
-        double run = 0.0;
-        for (int ch = c0; ch < c1; ++ch) { double vch = pipe_chunk_offset(q, ch) + cmx1[ch]; run = vch > run ? vch : run; }
-        double scd = wave_max_scan_d(run, lane);
-        if (lane == 63) q.wredd[wave] = scd;
-        __syncthreads();
-        double pre = 0.0;
-        for (int w = 0; w < wave; ++w) pre = q.wredd[w] > pre ? q.wredd[w] : pre;
-        double before = __shfl_up(scd, 1, 64);
-        if (lane > 0) pre = before > pre ? before : pre;
-        run = pre;
-        for (int ch = c0; ch < c1; ++ch) {
-            q.pmx[ch] = run;
-            double vch = pipe_chunk_offset(q, ch) + cmx1[ch];
-            run = vch > run ? vch : run;
-        }
-        if (c1 == nc && c0 < c1) q.pmx[nc] = run;
-        __syncthreads();
-    }
-    return d;
-}
-// final offspring offset from the (running-maximum) pilot prefix sum v: #{ j in [0,N) : (j+u) * S1 < N * v }  (pc.cpp:491
-// scaled by N*S1: no division), guess plus exact predicate correction -- the arithmetic of k_decide's lo_at
-__device__ __forceinline__ int pipe_lo_from(double v, double dn, long long Np, double S1, double invS1, double u) {
-    double rhs = dn * v;
-    double guess = floor(rhs * invS1 - u);
-    long long g = guess < 0 ? 0 : (guess > dn ? Np : (long long)guess);
-    while (g > 0 && !((((double)(g - 1)) + u) * S1 < rhs)) --g;
-    while (g < Np && ((((double)g) + u) * S1 < rhs)) ++g;
-    return (int)g;
-}
-
-// what the single-launch pipeline tells the extend workgroups about their row
-struct PipeRow {
-    int complete;          // the previous row has to be completed on load (0 for the first row of a pf_run call)
-    int extend;            // 0: completion only (flush at the end of a pf_run call)
-    int slot_prev;         // state ring slot to read (the general double-buffer index when !complete)
-    int slot_out;          // slot to write
-    double pos_prev;       // end of the previous row
-};
-
 // ------------------------------------------------------------------ k_extend_reg
 // Same computation as k_extend with the local tree held in registers (pf_tree_reg.h); used for
 // n <= 8.  LDS only carries the two epoch tables.
@@ -551,8 +409,9 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
         const int fs = __builtin_amdgcn_readfirstlane(PR.slot_prev >= 0 ? PR.slot_prev : c->cur);
         if (PR.complete) {
             pre = row_preload(A, fs);
-            const Ctrl::RowInfo& before = c->ri[(fs + 3) & 3];     // the row before it, published by the previous launch
-            o_nres = before.n_res; o_bflag = before.flag; o_bgen = before.gen;
+            // the row before it: what the extend role of the previous launch noted about it (the same numbers the bookkeeping
+            // role publishes in Ctrl::ri, without depending on the launch that carries that role)
+            o_nres = c->xr[(fs + 3) & 3].n_res; o_bflag = c->xr[(fs + 3) & 3].flag; o_bgen = c->xr[(fs + 3) & 3].gen;
             // The parent search of a resampling row stages the pilot scans of the wavefronts its parents sit in.  Offspring
             // stay close to their parents' slots (the offsets drift like a random walk of a few hundred slots), so the scans
             // of this workgroup's own wavefronts and six on either side are requested now, with everything else the prologue
@@ -621,6 +480,10 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
             PF_STAMP(2);
             inv = d.inv; S1v = d.S1;
             gather = d.flag != 0;
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                Ctrl* cw = A.ctrl;
+                cw->xr[row_slot].n_res = n_res; cw->xr[row_slot].gen = G_end; cw->xr[row_slot].flag = d.flag;
+            }
             if (gather) {
                 const double dn = (double)A.Np;
                 const double invS1 = 1.0 / d.S1;
@@ -687,7 +550,7 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
                 if (threadIdx.x == 0) {
                     int tot = 0;
                     for (int w = 0; w < PF_BS / 64; ++w) tot += q.wint[2 * (PF_BS / 64) + w];
-                    A.rg_blkcnt[(size_t)row_slot * gridDim_particles(A) + blockIdx.x] = tot;
+                    A.rg_blkcnt[(size_t)row_slot * gridDim_particles(A) * A.blk_gran + blockIdx.x] = tot;
                 }
                 if (active) {
                     const double coff_p = pipe_chunk_offset(q, pch);
@@ -1939,7 +1802,7 @@ __device__ __forceinline__ void ledger_update(const KA& A, int lb, int nlb, int 
 // run list of the generation Gx that ends with a resampling: its survivors, in slot order (start = lo[a], ancestor = a).
 // Position = survivors in earlier workgroups (blkcnt, counted where the offspring table was made) + rank inside this one.
 template <class KA>
-__device__ __forceinline__ void ledger_new_list(const KA& A, RunLists dst, const int* blkcnt, int nblocks, int bx, int Gx) {
+__device__ __forceinline__ void ledger_new_list(const KA& A, RunLists dst, const int* blkcnt, int nblocks, int bx, int Gx, int gran = 1) {
     const long long Np = A.Np;
     const long long i = (long long)bx * PF_BS + threadIdx.x;
     __shared__ int wsum[PF_BS / 64];
@@ -1951,7 +1814,12 @@ __device__ __forceinline__ void ledger_new_list(const KA& A, RunLists dst, const
     unsigned long long bal = __ballot(surv);
     if (lane == 0) wsum[wave] = __popcll(bal);
     __shared__ int sblk[1024];
-    for (int b = threadIdx.x; b < nblocks; b += PF_BS) sblk[b] = blkcnt[b];
+    // survivors per block of 256 particles; the structured extend workgroups own 64 particles each and leave four entries per block
+    for (int b = threadIdx.x; b < nblocks; b += PF_BS) {
+        int v = 0;
+        for (int j = 0; j < gran; ++j) v += blkcnt[b * gran + j];
+        sblk[b] = v;
+    }
     __syncthreads();
     int base = 0;
     for (int b = 0; b < bx; ++b) base += sblk[b];
@@ -1990,24 +1858,12 @@ __device__ __forceinline__ void ledger_body(const KA& A, int sp, int nblocks, in
 //   C(s-2)  the lagged counts of row s-2 from the lists in force for that row and its slot of the state ring.
 // What a role reads was written by an earlier launch (stream order) or is private to it; nothing waits inside the
 // launch.  The decide kernel and its two dependent kernel boundaries per row are gone from the critical path.
-struct PipeLaunch {
-    PipeRow row;
-    int nb;                // extend workgroups
-    int b_slot;            // ring slot of the row whose bookkeeping is due (-1: none)
-    long long b_row;       // its row index (traces)
-    double b_pos;          // its end position
-    int b_set_cur;         // >= 0: the general kernels take over after this launch, with this state slot
-    int lc_slot;           // ring slot of the row whose ledger upkeep and counts are due (-1: none)
-    int live_slot;         // newest complete slot of the per-slot record counters (ring-overwrite check)
-    int nL;                // ledger workgroups
-    int ncw;               // count workgroups per epoch
-};
-
 __global__ void k_pipe_seed(KArgs A, int slot) {
     Ctrl* c = A.ctrl;
     Ctrl::RowInfo& r = c->ri[slot];
     r.n_res = c->n_resample; r.gen = c->gen; r.flag = 0; r.lver = c->lver; r.g_retain = c->g_retain; r.first = A.E;
     r.inv_T = 1.0; r.T = 1.0; r.S1 = 0.0; r.u = 0.0; r.pos = c->cur_pos;
+    c->xr[slot].n_res = c->n_resample; c->xr[slot].gen = c->gen; c->xr[slot].flag = 0;
 }
 
 template <bool BIASED, class KA>
@@ -2093,12 +1949,12 @@ __device__ __forceinline__ void pipe_bookkeeping(const KA& A, const PipeLds& q, 
     }
 }
 
-template <int NM, bool BIASED, bool EXACT, bool TREES, class KA>
+template <int NM, bool BIASED, bool EXACT, bool TREES, int P = 1, class KA>
 __device__ __forceinline__ void pipe_roles(const KA& A, long long s, const PipeLaunch& PL, const Windows& Wb) {
     const int bx = (int)blockIdx.x;
     const int nb = PL.nb;
     if (bx < nb) {
-        if (PL.row.extend || PL.row.complete) extend_reg_body<NM, BIASED, EXACT, TREES, true>(A, s, 0, PL.row);
+        if constexpr (P == 1) { if (PL.row.extend || PL.row.complete) extend_reg_body<NM, BIASED, EXACT, TREES, true>(A, s, 0, PL.row); }
         return;
     }
     if (bx == nb) {
@@ -2115,8 +1971,9 @@ __device__ __forceinline__ void pipe_roles(const KA& A, long long s, const PipeL
     if (lb < PL.nL) {
         if (!r.flag) return;
         const RunLists src = run_lists(A, r.lver), dst = run_lists(A, r.lver ^ 1);
-        if (lb < nb) ledger_new_list(A, dst, A.rg_blkcnt + (size_t)PL.lc_slot * gridDim_particles(A), nb, lb, r.gen);
-        else ledger_update(A, lb - nb, PL.nL - nb, r.gen, r.g_retain, src, dst);
+        const int nblk = PL.nblk;              // particle blocks of 256 (the extend workgroups of the one-population kernels)
+        if (lb < nblk) ledger_new_list(A, dst, A.rg_blkcnt + (size_t)PL.lc_slot * nblk * A.blk_gran, nblk, lb, r.gen, A.blk_gran);
+        else ledger_update(A, lb - nblk, PL.nL - nblk, r.gen, r.g_retain, src, dst);
         return;
     }
     const int idx = lb - PL.nL;
@@ -2131,7 +1988,7 @@ __device__ __forceinline__ void pipe_roles(const KA& A, long long s, const PipeL
     Q.offp = A.rg_coffp + (size_t)PL.lc_slot * A.nc;
     Q.lists = run_lists(A, r.lver);
     Q.inv = r.inv_T; Q.G = r.gen; Q.g_lo = r.g_lo[e]; Q.g_hi = r.g_hi[e];
-    count_body<NM, 1, EXACT>(A, Q, e, r.wa[e], r.wb[e], idx % PL.ncw, PL.ncw);
+    count_body<NM, P, EXACT>(A, Q, e, r.wa[e], r.wb[e], idx % PL.ncw, PL.ncw);
 }
 
 template <int NM, bool BIASED, bool EXACT, bool TREES>
@@ -2149,48 +2006,6 @@ __global__ __launch_bounds__(PF_BS) void k_pipe(KArgs A, long long s, PipeLaunch
 // chunk's own window state (sweep_windows = host_windows, operation for operation), so the host only supplies t.
 // One chunk per GPU uses a sixth of the SIMDs; the reference's data parallelism is one process per chunk, all at once
 // (smcsmc/model.py:1094-1098), which is what a grid over chunks is here.
-struct SweepChunk {
-    KArgs A;
-    long long s_begin;             // first row of this call
-    long long s_last;              // last row extended by this call; steps s_last + 1 and s_last + 2 flush
-    double counted_to[PF_EMAX];    // window state (CountModel::counted_to) at the start of the call
-    int no_count;
-    int nL_full;                   // ledger workgroups per step
-    int ncw;                       // count workgroups per epoch
-    int pad;
-};
-typedef const __attribute__((address_space(4))) SweepChunk SweepChunkC;
-
-template <class KA>
-__device__ __forceinline__ double sweep_seg_pos(const KA& A, long long s) {       // seg_pos() of the host
-    const double e = A.seg_start[s] + A.seg_len[s];
-    return e < A.L ? e : A.L;
-}
-
-// what run_pipeline's `launch` lambda computes on the host, from the step's row alone
-__device__ __forceinline__ bool sweep_plan(SweepChunkC& ch, long long s, int nb, PipeLaunch& PL) {
-    const long long s_begin = ch.s_begin, s_last = ch.s_last;
-    if (s_last < s_begin || s > s_last + 2) return false;
-    const bool extend = s <= s_last, flush1 = s == s_last + 1;
-    const bool have_b = extend ? (s > s_begin) : flush1;
-    const bool have_lc = extend ? (s > s_begin + 1) : (flush1 ? (s_last - 1 >= s_begin) : true);
-    PL.nb = nb;
-    PL.row.extend = extend ? 1 : 0;
-    PL.row.complete = ((extend && s > s_begin) || flush1) ? 1 : 0;
-    PL.row.slot_prev = PL.row.complete ? (int)((s - 1) & 3) : -1;
-    PL.row.slot_out = (int)(s & 3);
-    PL.row.pos_prev = s > s_begin ? sweep_seg_pos(ch.A, s - 1) : 0.0;
-    PL.b_slot = have_b ? (int)((s - 1) & 3) : -1;
-    PL.b_row = s - 1;
-    PL.b_pos = have_b ? sweep_seg_pos(ch.A, s - 1) : 0.0;
-    PL.b_set_cur = flush1 ? (int)((s_last + 1) & 3) : -1;
-    PL.lc_slot = (have_lc && !ch.no_count) ? (int)((s - 2) & 3) : -1;
-    PL.live_slot = (int)((s - 1) & 3);
-    PL.nL = PL.lc_slot >= 0 ? ch.nL_full : 0;
-    PL.ncw = ch.ncw;
-    return true;
-}
-
 // extract_and_update_count's window rule (count.cpp:363-385) for the row that ends at `pos`: host_windows() on the device,
 // the same operations in the same order on the same doubles; the window state lives in Ctrl::counted_to.  Called by all
 // threads of the bookkeeping workgroup; W is in LDS.
@@ -2228,6 +2043,23 @@ __global__ __launch_bounds__(PF_BS) void k_sweep(const SweepChunk* tab_g, long l
     pipe_roles<NM, BIASED, EXACT, TREES>(A, s, PL, W);
 }
 
+// The bookkeeping, ledger and count roles of a step as a launch of their own: what the structured models run on the counting
+// stream beside their extend launch (k_sweep_xmp, pf_mp.hip).  The extend workgroups of those models carry their trees'
+// migration events in LDS (61 KB per 64 particles at the default capacity); in one launch every count workgroup would be
+// given the same allocation and one would fit a CU.
+template <int NM, int P, bool BIASED>
+__global__ __launch_bounds__(PF_BS) void k_sweep_blc(const SweepChunk* tab_g, long long t) {
+    SweepChunkC* tab = (SweepChunkC*)tab_g;
+    SweepChunkC& ch = tab[blockIdx.y];
+    KArgsC& A = ch.A;
+    const long long s = ch.s_begin + t;
+    __shared__ Windows W;
+    PipeLaunch PL;
+    if (!sweep_plan(ch, s, 0, PL)) return;
+    if ((int)blockIdx.x == 0 && PL.b_slot >= 0) sweep_windows(A, A.ctrl, PL.b_pos, W);
+    pipe_roles<NM, BIASED, false, false, P>(A, s, PL, W);
+}
+
 // first step of a call: the seed of k_pipe_seed, and the chunk's window state
 __global__ void k_sweep_seed(const SweepChunk* tab_g) {
     SweepChunkC* tab = (SweepChunkC*)tab_g;
@@ -2240,6 +2072,7 @@ __global__ void k_sweep_seed(const SweepChunk* tab_g) {
         Ctrl::RowInfo& r = c->ri[slot];
         r.n_res = c->n_resample; r.gen = c->gen; r.flag = 0; r.lver = c->lver; r.g_retain = c->g_retain; r.first = A.E;
         r.inv_T = 1.0; r.T = 1.0; r.S1 = 0.0; r.u = 0.0; r.pos = c->cur_pos;
+        c->xr[slot].n_res = c->n_resample; c->xr[slot].gen = c->gen; c->xr[slot].flag = 0;
     }
     if ((int)threadIdx.x < A.E) c->counted_to[threadIdx.x] = ch.counted_to[threadIdx.x];
 }
@@ -2844,6 +2677,10 @@ struct pf_handle {
     bool pipe = false;            // the single-launch pipeline applies (one population, n <= 8; rings allocated)
     size_t smem_pipe = 0;
     int ncw = 0;                  // count workgroups per epoch in the row pipeline (pf_params.count_wgs)
+    bool split_roles = false;     // PF_DEBUG_SPLIT_ROLES: one population too runs the extend role and the other roles as two launches on two streams
+    bool pipe_mp = false;         // structured models on the row pipeline: extend launches on the filter stream, the other roles on the counting stream
+    size_t smem_sweep_x = 0;
+    std::vector<hipEvent_t> ev_x, ev_blc;   // completion of the last 16 extend / bookkeeping-ledger-count launches
     bool no_spec_stage = false;   // PF_DEBUG_NO_SPEC_STAGE
     bool use_k_pipe = false;      // PF_DEBUG_K_PIPE: rows through k_pipe (argument block by value, one chunk per launch) instead of k_sweep
     SweepChunk* d_sweep = nullptr; // device table of the chunks this handle leads through k_sweep
@@ -3029,6 +2866,7 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     h->two_launch_rows = (p->debug & PF_DEBUG_TWO_LAUNCH) != 0;
     h->use_k_pipe = (p->debug & PF_DEBUG_K_PIPE) != 0;
     h->no_spec_stage = (p->debug & PF_DEBUG_NO_SPEC_STAGE) != 0;
+    h->split_roles = (p->debug & PF_DEBUG_SPLIT_ROLES) != 0;
     h->h_lags.assign(m->lags, m->lags + E);
     h->h_counted_to.assign(E, 0.0);
     h->h_L = m->loci_length;
@@ -3091,8 +2929,11 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
         A.app_delays = dad;
     }
     h->pipe = P == 1 && n <= 8 && Np <= 131072;      // beyond that the decision tables outgrow the default dynamic LDS
+    // structured models with the tree in registers: the same pipeline, the extend role as its own launch (run_sweep_mp)
+    h->pipe_mp = P > 1 && n <= 8 && Np <= 131072 && !(p->flags & 2) && !(p->debug & (PF_DEBUG_FORCE_LDS | PF_DEBUG_NO_FUSE | PF_DEBUG_K_PIPE));
+    A.blk_gran = h->pipe_mp ? 4 : 1;
     {
-        const size_t K = h->pipe ? 4 : 2;               // copies of the particle state (KArgs::st0)
+        const size_t K = (h->pipe || h->pipe_mp) ? 4 : 2;               // copies of the particle state (KArgs::st0)
         A.nslots = (int)K;
         DState& st = A.st0;
         rc |= dalloc(h, &st.S, K * (size_t)(n - 1) * Np);
@@ -3164,7 +3005,7 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     rc |= dalloc(h, &A.nruns, A.Gcap);
     const size_t nc = (size_t)((Np + 63) / 64);
     A.nc = (int)nc;
-    if (h->pipe) {
+    if (h->pipe || h->pipe_mp) {
         rc |= dalloc(h, &A.run_st2, (size_t)A.Gcap * Np);
         rc |= dalloc(h, &A.run_anc2, (size_t)A.Gcap * Np);
         rc |= dalloc(h, &A.nruns2, A.Gcap);
@@ -3172,7 +3013,7 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
         rc |= dalloc(h, &A.rg_scanp, 4 * (size_t)Np); rc |= dalloc(h, &A.rg_widx, 4 * (size_t)Np);
         rc |= dalloc(h, &A.rg_cpost, 4 * nc); rc |= dalloc(h, &A.rg_csq, 4 * nc); rc |= dalloc(h, &A.rg_cpil, 4 * nc);
         rc |= dalloc(h, &A.rg_cpp, 4 * nc); rc |= dalloc(h, &A.rg_cmx1, 4 * nc); rc |= dalloc(h, &A.rg_coffp, 4 * nc);
-        rc |= dalloc(h, &A.rg_dpend, 4 * nc); rc |= dalloc(h, &A.rg_blkcnt, 4 * (size_t)h->nblocks);
+        rc |= dalloc(h, &A.rg_dpend, 4 * nc); rc |= dalloc(h, &A.rg_blkcnt, 4 * (size_t)h->nblocks * 4);
         h->smem_pipe = ((size_t)(2 * PF_EPAD + E + 2 * PF_BIAS_MAX + 3) + pipe_lds_doubles((int)nc)) * 8;
     }
     rc |= dalloc(h, &A.chunk_post, nc); rc |= dalloc(h, &A.chunk_sq, nc); rc |= dalloc(h, &A.chunk_pil, nc);
@@ -3212,6 +3053,10 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
         return fail(P > 1 ? "pf_create: the local-tree state (tree, epoch tables and pf_params.mig_cap migration events per lane) does not fit the LDS of one workgroup"
                           : "pf_create: the local-tree state does not fit the LDS of one workgroup");
     }
+    if (h->pipe_mp) {
+        h->smem_sweep_x = pf_mp_sweep_smem_bytes(E, P, A.mcap, A.nc);
+        if (pf_mp_sweep_prepare(h->smem_sweep_x)) h->pipe_mp = false;        // the event lists and the decision tables do not fit together: the two-stream path
+    }
     return h;
 }
 
@@ -3239,6 +3084,8 @@ void pf_destroy(pf_handle* h) {
     for (void* p : h->allocs) hipFree(p);
     if (h->d_sweep) hipFree(h->d_sweep);
     for (auto e : h->sync_ev) if (e) hipEventDestroy(e);
+    for (auto e : h->ev_x) if (e) hipEventDestroy(e);
+    for (auto e : h->ev_blc) if (e) hipEventDestroy(e);
     if (h->cstream) hipStreamDestroy(h->cstream);
     for (auto& sp : h->spans) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
     for (auto e : h->ev_pool) hipEventDestroy(e);
@@ -3645,7 +3492,7 @@ static int run_pipeline(pf_handle* h, long long s_begin, long long s_end) {
     auto launch = [&](long long s, bool extend, bool have_b, bool have_lc, int set_cur) -> int {
         PipeLaunch PL;
         memset(&PL, 0, sizeof(PL));
-        PL.nb = nb;
+        PL.nb = nb; PL.nblk = nb;
         PL.row.extend = extend ? 1 : 0;
         PL.row.complete = (s > s_begin && s - 1 <= last && (extend || have_b)) ? 1 : 0;
         if (!extend && !have_b) PL.row.complete = 0;
@@ -3707,6 +3554,45 @@ static bool sweep_compatible(const pf_handle* a, const pf_handle* b) {
            a->A.rec_trees == b->A.rec_trees && a->ncw == b->ncw && a->smem_pipe == b->smem_pipe && a->no_count == b->no_count;
 }
 
+// the per-chunk table of a k_sweep call in the leader's device buffer; returns the number of steps (0: nothing to do)
+static long long sweep_table(pf_handle* const* hs, int nh, long long s_begin, long long s_end, int nL_full, bool* failed) {
+    pf_handle* h = hs[0];
+    const int E = h->E;
+    *failed = true;
+    if (h->d_sweep_cap < nh) {
+        if (h->d_sweep) { if (hipStreamSynchronize(h->stream) != hipSuccess || hipFree(h->d_sweep) != hipSuccess) return 0; }
+        if (hipMalloc((void**)&h->d_sweep, sizeof(SweepChunk) * (size_t)nh) != hipSuccess) { g_err = "hipMalloc of the chunk table failed"; return 0; }
+        h->d_sweep_cap = nh;
+    }
+    // the table of the previous call may still be read by its launches: a fresh host copy per call, uploaded in stream order
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { g_err = "hipStreamSynchronize failed"; return 0; }
+    h->h_sweep.assign((size_t)nh, SweepChunk());
+    long long steps = 0;
+    for (int k = 0; k < nh; ++k) {
+        pf_handle* g = hs[k];
+        SweepChunk& ch = h->h_sweep[k];
+        memset(&ch, 0, sizeof(ch));
+        ch.A = g->A;
+        ch.s_begin = s_begin;
+        long long e = std::min<long long>(s_end, g->n_segs), last = s_begin - 1;
+        for (long long s = s_begin; s < e; ++s) { last = s; if (g->h_seg_start[s] + g->h_seg_len[s] >= g->h_L) break; }   // smcsmc.cpp:353-356
+        ch.s_last = last;
+        for (int q = 0; q < E; ++q) ch.counted_to[q] = g->h_counted_to[q];
+        ch.no_count = g->no_count ? 1 : 0;
+        ch.nL_full = nL_full;
+        ch.ncw = g->ncw;
+        ch.nblk = g->nblocks;
+        if (last >= s_begin) steps = std::max(steps, last - s_begin + 3);
+    }
+    *failed = false;
+    if (steps == 0) return 0;
+    if (hipMemcpyAsync(h->d_sweep, h->h_sweep.data(), sizeof(SweepChunk) * (size_t)nh, hipMemcpyHostToDevice, h->stream) != hipSuccess) {
+        g_err = "upload of the chunk table failed"; *failed = true; return 0;
+    }
+    hipLaunchKernelGGL(k_sweep_seed, dim3(nh), dim3(64), 0, h->stream, h->d_sweep);
+    return steps;
+}
+
 static int run_sweep(pf_handle* const* hs, int nh, long long s_begin, long long s_end) {
     pf_handle* h = hs[0];
     if (s_begin >= s_end) return 0;
@@ -3723,33 +3609,10 @@ static int run_sweep(pf_handle* const* hs, int nh, long long s_begin, long long 
             hipStreamWaitEvent(h->stream, ev, 0);
         }
     }
-    if (h->d_sweep_cap < nh) {
-        if (h->d_sweep) { HIPCHK(hipStreamSynchronize(h->stream)); HIPCHK(hipFree(h->d_sweep)); }
-        HIPCHK(hipMalloc((void**)&h->d_sweep, sizeof(SweepChunk) * (size_t)nh));
-        h->d_sweep_cap = nh;
-    }
-    // the table of the previous call may still be read by its launches: a fresh host copy per call, uploaded in stream order
-    HIPCHK(hipStreamSynchronize(h->stream));
-    h->h_sweep.assign((size_t)nh, SweepChunk());
-    long long steps = 0;
-    for (int k = 0; k < nh; ++k) {
-        pf_handle* g = hs[k];
-        SweepChunk& ch = h->h_sweep[k];
-        memset(&ch, 0, sizeof(ch));
-        ch.A = g->A;
-        ch.s_begin = s_begin;
-        long long e = std::min<long long>(s_end, g->n_segs), last = s_begin - 1;
-        for (long long s = s_begin; s < e; ++s) { last = s; if (g->h_seg_start[s] + g->h_seg_len[s] >= g->h_L) break; }   // smcsmc.cpp:353-356
-        ch.s_last = last;
-        for (int q = 0; q < E; ++q) ch.counted_to[q] = g->h_counted_to[q];
-        ch.no_count = g->no_count ? 1 : 0;
-        ch.nL_full = nL_full;
-        ch.ncw = g->ncw;
-        if (last >= s_begin) steps = std::max(steps, last - s_begin + 3);
-    }
+    bool failed = false;
+    const long long steps = sweep_table(hs, nh, s_begin, s_end, nL_full, &failed);
+    if (failed) return -1;
     if (steps == 0) return 0;
-    HIPCHK(hipMemcpyAsync(h->d_sweep, h->h_sweep.data(), sizeof(SweepChunk) * (size_t)nh, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_sweep_seed, dim3(nh), dim3(64), 0, h->stream, h->d_sweep);
     // the count workgroups of a step belong to row s - 2, whose windows the host knows as well as the device does: the grid
     // ends with the last epoch column any chunk needs (epochs before a chunk's first moving one are not launched at all)
     std::vector<Windows> W1((size_t)nh), W2((size_t)nh);
@@ -3796,6 +3659,78 @@ static int run_sweep(pf_handle* const* hs, int nh, long long s_begin, long long 
     return 0;
 }
 
+// Structured models (register-tree kernel) on the row pipeline.  Per step two launches: the extend role (k_sweep_xmp, with the
+// decision on the previous row in its prologue) on the filter stream, the bookkeeping / ledger / count roles (k_sweep_blc) on
+// the counting stream -- separate launches because the extend workgroups' LDS (their trees' migration events) would be
+// allocated to every count workgroup too.  Step t's second launch needs the extend launch of step t - 1 (partials, offspring
+// table, records), the extend launch of step t must not overwrite ring slot t & 3 before the counts of step t - 2 are done:
+// one wait each way per step, on the kernels' own completion signals; the extend role does not read anything the other
+// launch writes (it keeps its own note of n_resample / generation, Ctrl::xr).  k_decide, its boundary and the wait of the
+// next row on the previous row's ledger upkeep are gone from the critical stream.
+static int run_sweep_mp(pf_handle* h, long long s_begin, long long s_end) {
+    if (s_begin >= s_end) return 0;
+    const int nb = h->nblocks, E = h->E;
+    const bool biased = h->A.n_bias > 0 || h->A.g_K > 0;
+    const int nL_full = nb + std::max(16, std::min(PF_LEDGER_BLOCKS, 192));
+    if (h->ev_cnt) { hipStreamWaitEvent(h->stream, h->ev_cnt, 0); h->ev_cnt = nullptr; }
+    if (h->ev_x.empty()) {
+        h->ev_x.resize(16); h->ev_blc.resize(16);
+        for (auto& e : h->ev_x) if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) { g_err = "hipEventCreate failed"; return -1; }
+        for (auto& e : h->ev_blc) if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) { g_err = "hipEventCreate failed"; return -1; }
+    }
+    pf_handle* one[1] = {h};
+    bool failed = false;
+    const long long steps = sweep_table(one, 1, s_begin, s_end, nL_full, &failed);
+    if (failed) return -1;
+    if (steps == 0) return 0;
+    // the counting stream starts behind the table and the seed
+    hipEvent_t seeded = next_sync_event(h);
+    hipEventRecord(seeded, h->stream);
+    Windows W1 = no_windows(h), W2 = W1;
+    const long long last = h->h_sweep[0].s_last;
+    for (long long t = 0; t < steps; ++t) {
+        const long long s = s_begin + t;
+        if (t >= 2) hipStreamWaitEvent(h->stream, h->ev_blc[(size_t)((t - 2) & 15)], 0);
+        {
+            Timed tm(h, 0, timing_on(h, s));
+            if (h->P > 1) pf_mp_launch_sweep_x(h->A, h->d_sweep, t, h->smem_sweep_x, h->stream, h->ev_x[(size_t)(t & 15)]);
+            else {
+                // one population (PF_DEBUG_SPLIT_ROLES): k_sweep with a grid of the extend workgroups only
+                const dim3 gx((unsigned)nb, 1u), bx(PF_BS);
+                hipEvent_t xdone = h->ev_x[(size_t)(t & 15)];
+#define PF_LAUNCH_X(NMV, BV, EV) hipExtLaunchKernelGGL((k_sweep<NMV, BV, EV, false>), gx, bx, h->smem_pipe, h->stream, nullptr, xdone, 0, h->d_sweep, t, nb)
+                if (h->n <= 4) { if (biased) { if (h->n == 4) PF_LAUNCH_X(4, true, true); else PF_LAUNCH_X(4, true, false); } else { if (h->n == 4) PF_LAUNCH_X(4, false, true); else PF_LAUNCH_X(4, false, false); } }
+                else { if (biased) { if (h->n == 8) PF_LAUNCH_X(8, true, true); else PF_LAUNCH_X(8, true, false); } else { if (h->n == 8) PF_LAUNCH_X(8, false, true); else PF_LAUNCH_X(8, false, false); } }
+#undef PF_LAUNCH_X
+            }
+        }
+        if (check_launch("k_sweep (extend role)")) return -1;
+        hipStreamWaitEvent(h->cstream, t >= 1 ? h->ev_x[(size_t)((t - 1) & 15)] : seeded, 0);
+        const int columns = (s >= s_begin + 2 && s - 2 <= last && !h->no_count) ? E - W2.first : 0;
+        const dim3 grid((unsigned)(1 + nL_full + h->ncw * columns), 1u), blk(PF_BS);
+        hipEvent_t done = h->ev_blc[(size_t)(t & 15)];
+#define PF_LAUNCH_BLC(NMV, PV, BV) hipExtLaunchKernelGGL((k_sweep_blc<NMV, PV, BV>), grid, blk, h->smem_pipe, h->cstream, nullptr, done, 0, h->d_sweep, t)
+        if (h->P == 1) { if (h->n <= 4) { if (biased) PF_LAUNCH_BLC(4, 1, true); else PF_LAUNCH_BLC(4, 1, false); } else { if (biased) PF_LAUNCH_BLC(8, 1, true); else PF_LAUNCH_BLC(8, 1, false); } }
+        else if (h->P == 2) { if (biased) PF_LAUNCH_BLC(8, 2, true); else PF_LAUNCH_BLC(8, 2, false); }
+        else { if (biased) PF_LAUNCH_BLC(8, PF_PMAX, true); else PF_LAUNCH_BLC(8, PF_PMAX, false); }
+#undef PF_LAUNCH_BLC
+        if (check_launch("k_sweep_blc")) return -1;
+        if ((t & 1023) == 1023) trim_spans(h);
+        W2 = W1;
+        if (s <= last) {
+            W1 = host_windows(h, seg_pos(h, s), false);
+            h->step_windows = W1;
+            if (W1.first < E && !h->no_count) h->fin_pending = true;
+        } else {
+            W1 = no_windows(h);
+        }
+    }
+    h->k_launches[0] -= 2;                                      // flush steps are not rows
+    h->ev_cnt = h->ev_blc[(size_t)((steps - 1) & 15)];       // what follows on the filter stream waits for the last counts
+    if (last >= s_begin) h->seg_done = last + 1;
+    return 0;
+}
+
 int pf_run_many(pf_handle* const* handles, int32_t n_handles, int64_t s_begin, int64_t s_end) {
     if (n_handles < 1 || !handles || !handles[0]) { g_err = "pf_run_many: no handles"; return -1; }
     pf_handle* h = handles[0];
@@ -3820,9 +3755,11 @@ int pf_run(pf_handle* h, int64_t s_begin, int64_t s_end) {
     if (extend_can_fuse(h)) {
         if (!h->pipe || h->two_launch_rows) return run_single_stream(h, s_begin, s_end);
         if (h->use_k_pipe) return run_pipeline(h, s_begin, s_end);
+        if (h->split_roles && !h->A.rec_trees) return run_sweep_mp(h, s_begin, s_end);
         pf_handle* one[1] = {h};
         return run_sweep(one, 1, s_begin, s_end);
     }
+    if (h->pipe_mp && h->A.apf == 0 && !h->force_lds && !h->no_fuse) return run_sweep_mp(h, s_begin, s_end);
     // structured models on the register-tree kernel: the next row's extend completes this row while it loads (two
     // launches per row on the main stream instead of three); the last row of the call is completed by k_resample
     const bool mp_fuse = h->P > 1 && pf_mp_can_fuse(h->A, h->force_lds) && h->A.apf == 0 && !h->no_fuse;

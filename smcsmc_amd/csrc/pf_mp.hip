@@ -6,6 +6,7 @@
 // wavefront per workgroup spreads them over more compute units.
 #define PF_BS 64
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "pf_device.h"
 #include "pf_types.h"
@@ -13,6 +14,7 @@
 #include "pf_mp.h"
 #include "pf_mp_reg.h"
 #include "pf_mp_host.h"
+#include "pf_pipe.h"
 
 // ------------------------------------------------------------------ structured models (P > 1): LDS-tree kernels
 // Same structure as k_init / k_extend / k_calibrate with the migration-aware genealogy update of pf_mp.h.
@@ -439,9 +441,15 @@ __device__ __forceinline__ SmemMPR carve_mpr(double* base, int E, int P, int mca
 // wavefront does the reductions over the 64 particles exactly as the full wavefront did.
 // TREES (-arg): every record carries the samples below the cut branch and below the node the update creates, and
 // neither the record ring nor the piece ring may wrap.
-template <int NM, bool BIASED, int LA, bool TREES>
-__global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long long s, int fuse) {
+// PIPE: the extend role of the row pipeline for structured models (k_sweep_xmp): the workgroup takes the decision on the
+// previous row itself (decide_row), its first wavefront works out the offspring offsets and finds the parents of the
+// workgroup's 64 slots by search (the code of extend_reg_body's prologue, one particle per lane of that wavefront), the
+// previous row is read from one slot of the state ring and this row written to the next -- nothing from k_decide is read.
+template <int NM, bool BIASED, int LA, bool TREES, bool PIPE, class KA>
+__device__ __forceinline__ void extend_mpr_body(const KA& A, long long s, int fuse, PipeRow PR = PipeRow()) {
     constexpr int NI = RTree<NM>::NI;
+    constexpr int BS = 64 * (64 / LA);
+    MP_TICK(tk_begin);                      // profiling builds: "load state" counts from here (tables, completion of the previous row)
     extern __shared__ double smem[];
     SmemMPR mm = carve_mpr(smem, A.E, A.P, A.mcap);
     {
@@ -466,18 +474,139 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
     __syncthreads();
     const Ctrl* c = A.ctrl;
     const int n = A.n;
-    const int cur = __builtin_amdgcn_readfirstlane(c->cur);
-    // fuse: the previous row was decided (k_decide) but not completed -- this kernel does k_resample's part while it
-    // loads: normalisation, or the copy from the parent with the closing record of the old slot (pc.cpp:335-368)
-    const bool completing = fuse != 0;
-    const bool gather = completing && __builtin_amdgcn_readfirstlane(c->flag) != 0;
-    const int from_slot = gather ? (cur ^ 1) : cur;
     const int lane = threadIdx.x & 63;
     const int cslot = (int)(threadIdx.x >> 6) * LA + lane;             // place of this lane's particle in the workgroup's 64
     const long long p = (long long)blockIdx.x * 64 + cslot;
     const bool active = lane < LA && p < A.Np;
+    // fuse: the previous row was decided (k_decide) but not completed -- this kernel does k_resample's part while it
+    // loads: normalisation, or the copy from the parent with the closing record of the old slot (pc.cpp:335-368)
+    int cur, from_slot;
+    bool completing, gather;
+    double inv_prev = 1.0, S1_prev = 0.0, pos_prev = 0.0;
+    int G_end = 0, ev_idx = 0;
+    long long a_par = p;
+    int lo_p = 0, lo_p1 = 0;
+    bool first_copy = true;
+    if constexpr (PIPE) {
+        __shared__ long long sPar[64];
+        __shared__ int sLoP[64], sLoP1[64], sFirst[64], sRange[2];
+        // the decision's tables live where the migration events of the lanes go afterwards (they are loaded once the previous row
+        // is completed): with an area of their own the workgroup would need 85 KB and a CU would hold one instead of two
+        const bool shared_area = pipe_lds_doubles(A.nc) <= (size_t)A.mcap * PF_BS;          // else behind everything (a small mig_cap)
+        PipeLds q = pipe_carve(shared_area ? mm.Mt : (double*)((char*)smem + smem_mpr_bytes(A.E, A.P, A.mcap)), A.nc);
+        const int fs = __builtin_amdgcn_readfirstlane(PR.slot_prev >= 0 ? PR.slot_prev : c->cur);
+        cur = PR.slot_out; from_slot = fs;
+        completing = PR.complete != 0;
+        gather = false;
+        pos_prev = PR.pos_prev;
+        if (completing) {
+            const int row_slot = fs;
+            RowPre pre = row_preload(A, row_slot);
+            // the row before it: what the extend role of the previous launch noted (the bookkeeping role runs on another
+            // stream here and is not waited for)
+            const long long n_res = c->xr[(fs + 3) & 3].n_res + c->xr[(fs + 3) & 3].flag;
+            G_end = c->xr[(fs + 3) & 3].gen + c->xr[(fs + 3) & 3].flag;
+            ev_idx = (int)n_res;
+            RowDecision d = decide_row<true, BS>(A, q, row_slot, n_res, pre);
+            inv_prev = d.inv; S1_prev = d.S1;
+            gather = d.flag != 0;
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                Ctrl* cw = A.ctrl;
+                cw->xr[row_slot].n_res = n_res; cw->xr[row_slot].gen = G_end; cw->xr[row_slot].flag = d.flag;
+            }
+            if (gather) {
+                const double dn = (double)A.Np;
+                const double invS1 = 1.0 / d.S1;
+                const double* sm = A.rg_scan1m + (size_t)row_slot * A.Np;
+                const long long qp = (long long)blockIdx.x * 64 + lane;          // first wavefront: one of the workgroup's slots per lane
+                const bool qa = threadIdx.x < 64 && qp < A.Np;
+                const int ch_own = (int)blockIdx.x;
+                const double lhs = ((double)qp + d.u) * d.S1;
+                int pch = 0, lo_next = 0;
+                if (threadIdx.x < 64) {
+                    if (qa) {
+                        const double w = pipe_chunk_offset(q, ch_own) + sm[qp];
+                        const double v_own = q.pmx[ch_own] > w ? q.pmx[ch_own] : w;      // largest pilot prefix sum up to slot qp
+                        lo_next = qp + 1 < A.Np ? pipe_lo_from(v_own, dn, A.Np, d.S1, invS1, d.u) : (int)A.Np;
+                        int lo_c = 0, hi_c = A.nc - 1;
+                        while (lo_c < hi_c) {
+                            int mid = (lo_c + hi_c) >> 1;
+                            if (lhs < dn * q.pmx[mid + 1]) hi_c = mid; else lo_c = mid + 1;
+                        }
+                        pch = lo_c;
+                    }
+                    int cmin = qa ? pch : 0x7fffffff, cmax = qa ? pch : -1;
+#pragma unroll
+                    for (int m = 1; m < 64; m <<= 1) {
+                        int o1 = __shfl_xor(cmin, m, 64), o2 = __shfl_xor(cmax, m, 64);
+                        cmin = o1 < cmin ? o1 : cmin; cmax = o2 > cmax ? o2 : cmax;
+                    }
+                    if (lane == 0) { sRange[0] = cmin; sRange[1] = cmax; }
+                }
+                __syncthreads();
+                const int cmin = sRange[0], cmax = sRange[1];
+                int nst = cmax - cmin + 1;
+                if (nst > PF_PIPE_STAGE) nst = PF_PIPE_STAGE;
+                if (nst < 0) nst = 0;
+                for (int idx = threadIdx.x; idx < nst * 64; idx += BS) {
+                    const long long src = (long long)cmin * 64 + idx;
+                    q.stage[idx] = src < A.Np ? sm[src] : PF_INF;
+                }
+                __syncthreads();
+                if (threadIdx.x < 64) {
+                    int lp = __shfl_up(lo_next, 1, 64);
+                    if (lane == 0) lp = qp > 0 ? pipe_lo_from(q.pmx[ch_own], dn, A.Np, d.S1, invS1, d.u) : 0;
+                    const unsigned long long bal = __ballot(qa && lo_next > lp);
+                    if (lane == 0) A.rg_blkcnt[(size_t)row_slot * ((A.Np + 255) / 256) * A.blk_gran + blockIdx.x] = __popcll(bal);
+                    if (qa) {
+                        const double coff_p = pipe_chunk_offset(q, pch);
+                        const double pm_p = q.pmx[pch];
+                        const bool staged = pch - cmin < nst;
+                        auto val_at = [&](int l) -> double {           // largest prefix sum up to particle pch*64 + l
+                            long long idx = (long long)pch * 64 + l;
+                            double smv = staged ? q.stage[(pch - cmin) * 64 + l] : (idx < A.Np ? sm[idx] : PF_INF);
+                            double w = coff_p + smv;
+                            return pm_p > w ? pm_p : w;
+                        };
+                        int lo_l = 0, hi_l = 63;
+                        while (lo_l < hi_l) {
+                            int mid = (lo_l + hi_l) >> 1;
+                            if (lhs < dn * val_at(mid)) hi_l = mid; else lo_l = mid + 1;
+                        }
+                        long long a = (long long)pch * 64 + lo_l;
+                        if (a > A.Np - 1) a = A.Np - 1;
+                        bool fc;
+                        const int la = (int)(a & 63);
+                        if (qp == 0 || a == 0) fc = (qp == 0);
+                        else {
+                            double vprev = la > 0 ? val_at(la - 1) : pm_p;      // largest prefix sum up to a - 1
+                            if (a != (long long)pch * 64 + lo_l) {             // clamped: recompute on the true chunk of a - 1
+                                long long am = a - 1;
+                                int chm = (int)(am >> 6);
+                                double w = pipe_chunk_offset(q, chm) + sm[am];
+                                vprev = q.pmx[chm] > w ? q.pmx[chm] : w;
+                            }
+                            fc = ((((double)(qp - 1)) + d.u) * d.S1 < dn * vprev);
+                        }
+                        sPar[lane] = a; sFirst[lane] = fc ? 1 : 0; sLoP[lane] = lp; sLoP1[lane] = lo_next;
+                        // the offspring table of the generation that ends here, for the ledger and -arg
+                        int* lo_tab = A.lo + (size_t)(G_end % A.Gcap) * (A.Np + 1);
+                        lo_tab[qp] = lp;
+                        if (qp == A.Np - 1) lo_tab[A.Np] = (int)A.Np;
+                    }
+                }
+                __syncthreads();
+                if (active) { a_par = sPar[cslot]; first_copy = sFirst[cslot] != 0; lo_p = sLoP[cslot]; lo_p1 = sLoP1[cslot]; }
+            }
+        }
+        __syncthreads();          // the tables are dead from here on: the lanes' event lists take their place
+    } else {
+        cur = __builtin_amdgcn_readfirstlane(c->cur);
+        completing = fuse != 0;
+        gather = completing && __builtin_amdgcn_readfirstlane(c->flag) != 0;
+        from_slot = gather ? (cur ^ 1) : cur;
+    }
     double w_post = 0.0, w_pilot = 0.0;
-    MP_TICK(tk_begin);
 #ifdef PF_STAMPS
     if (threadIdx.x < PF_STAMP_W) g_mp_acc[threadIdx.x] = 0;
     __syncthreads();
@@ -489,8 +618,8 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
     if (active) {
         const DState st = state_slot(A, cur);
         const DState from = state_slot(A, from_slot);
-        const long long a = gather ? (long long)A.parent[p] : p;
-        if (completing && p == 0) { Ctrl* cw = A.ctrl; cw->gen_prev = c->gen; cw->nres_prev = c->n_resample; }
+        const long long a = PIPE ? (gather ? a_par : p) : (gather ? (long long)A.parent[p] : p);
+        if (!PIPE && completing && p == 0) { Ctrl* cw = A.ctrl; cw->gen_prev = c->gen; cw->nres_prev = c->n_resample; }
         RTree<NM> t;
         MRLane ml;
         ml.Mt = mm.Mt + cslot; ml.Mb = mm.Mb + cslot; ml.Mq = mm.Mq + cslot;
@@ -538,7 +667,7 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
         ds.count = 0; ds.total = 1.0;
         if (biased) {
             ds.count = from.dcount[a]; ds.total = from.total_delayed[a];
-            if (gather)       // the copy constructor copies the pending factors (particle.cpp:122-123)
+            if (gather || PIPE)   // the copy constructor copies the pending factors (particle.cpp:122-123); the ring moves them every row
                 for (int k = 0; k < ds.count; ++k) {
                     st.dpos[(size_t)k * A.Np + p] = from.dpos[(size_t)k * A.Np + a];
                     st.dfac[(size_t)k * A.Np + p] = from.dfac[(size_t)k * A.Np + a];
@@ -554,18 +683,18 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
         cx.Ltree = from.Ltree[a];
         cx.ctr = A.rng_ctr[p];
         cx.ebuf = A.ebuf[p];
-        unsigned widx = A.widx[p];
+        unsigned widx = (PIPE && completing) ? A.rg_widx[(size_t)from_slot * A.Np + p] : A.widx[p];
         if (completing) {
-            const double inv = c->inv_T;
+            const double inv = PIPE ? inv_prev : c->inv_T;
             if (!gather) {
                 w_post *= inv;                             // normalize_probability, pc.cpp:435-437
                 w_pilot *= inv;
             } else {
-                const int G = c->gen - 1;                  // the generation that ended with the previous row
-                const double pos = c->cur_pos;
+                const int G = PIPE ? G_end : c->gen - 1;   // the generation that ended with the previous row
+                const double pos = PIPE ? pos_prev : c->cur_pos;
                 const int* lo_tab = A.lo + (size_t)((G + A.Gcap) % A.Gcap) * (A.Np + 1);
                 // role of the old slot p: close its stretch if it has offspring
-                if (lo_tab[p + 1] > lo_tab[p]) {
+                if (PIPE ? (lo_p1 > lo_p) : (lo_tab[p + 1] > lo_tab[p])) {
                     double* rec = rec_ptr(A, p, widx);
                     rec[0] = from.x_mark[p];
                     rec[1] = pos;
@@ -576,29 +705,30 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
                 }
                 A.gstart[(size_t)((G + 1) % A.Gcap) * A.Np + p] = widx;
                 // role of the new slot p: weights of the copy (pc.cpp:350-351), fresh position for all but the first
-                const int ev = (int)c->n_resample - 1;
+                const int ev = PIPE ? ev_idx : (int)c->n_resample - 1;
                 if (ev < A.max_trace_events) A.ev_parents[(size_t)ev * A.Np + p] = (int)a;
                 const double wp = w_post * inv;
                 const double wq = w_pilot * inv;
-                const double sumn = c->S1 * inv;
+                const double sumn = (PIPE ? S1_prev : c->S1) * inv;
                 const double adj = sumn / ((double)A.Np * wq);
                 w_post = wp * adj;
                 w_pilot = wq * adj;
                 x_mark = pos;
-                if (p != lo_tab[a] && pos < A.L) next_base = r_sample_next_base<false>(cx, pos);     // pc.cpp:357-368
+                if ((PIPE ? !first_copy : (p != lo_tab[a])) && pos < A.L) next_base = r_sample_next_base<false>(cx, pos);     // pc.cpp:357-368
             }
         }
         PLog pl;
         pl.base = A.plog + (size_t)p * A.pcap * 3; pl.cap = A.pcap; pl.idx = A.pidx[p]; pl.pos = pl.idx % pl.cap; pl.on = true;
         pl.fopen = false; pl.ropen = false;
 
+        const bool do_extend = !PIPE || PR.extend != 0;        // the flush step of a call only completes the last row
         const int8_t* data = A.seg_alleles + (size_t)s * n;
-        const double seg_end = A.seg_start[s] + A.seg_len[s];
+        const double seg_end = do_extend ? A.seg_start[s] + A.seg_len[s] : 0.0;
         const double extend_to = seg_end < A.L ? seg_end : A.L;
-        const int limit = A.seg_limit[s];
+        const int limit = do_extend ? A.seg_limit[s] : 0;
         unsigned one_mask = 0, zero_mask = 0, present_mask = 0, two_mask = 0;
         int missing = 0;
-        for (int i = 0; i < n; ++i) {
+        for (int i = 0; i < n && do_extend; ++i) {
             const int d = data[i];
             missing += d == -1;
             if (d == 1) one_mask |= 1u << i;
@@ -610,7 +740,8 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
         if (missing == 0) leaf_status = 1;
         if (missing == n) leaf_status = -1;
 
-        double updated_to = c->cur_pos;
+        double updated_to = (PIPE && completing) ? pos_prev : c->cur_pos;
+        if (!do_extend) updated_to = extend_to;
         double B;
         if (leaf_status == -1) B = 0;
         else if (leaf_status == 1) B = cx.Ltree;
@@ -698,7 +829,7 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
         if (biased) {
             // apply the factors that fell due during this extension (particle.cpp:910-916)
             for (;;) {
-                if (ds.count == 0) break;
+                if (ds.count == 0 || !do_extend) break;
                 double pm = ds.pos[0];
                 for (int i = 1; i < ds.count; ++i) { double pi = ds.pos[(size_t)i * ds.Np]; if (pi < pm) pm = pi; }
                 if (!(pm < extend_to)) break;
@@ -710,7 +841,7 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
             has_pending = ds.count > 0;
         }
 
-        if (A.seg_state[s] == 0) {
+        if (do_extend && A.seg_state[s] == 0) {
             // update_weight_at_site: marginalise over phasings of unphased hets (pc.cpp:138-224)
             const bool dephase = A.flags & 2;
             const bool anc = A.flags & 1;
@@ -762,7 +893,7 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
                 st.C[(size_t)(2 * r) * A.Np + p] = (int8_t)t.C0[r];
                 st.C[(size_t)(2 * r + 1) * A.Np + p] = (int8_t)t.C1[r];
                 st.Pn[(size_t)r * A.Np + p] = (int8_t)pk2_get(ml.pn, r);
-                A.snap_S[A.sp][(size_t)r * A.Np + p] = t.S[r];
+                if constexpr (!PIPE) A.snap_S[A.sp][(size_t)r * A.Np + p] = t.S[r];
             }
         st.nm[p] = ml.nm;
         for (int q = 0; q < ml.nm; ++q) {
@@ -778,10 +909,15 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
         st.Ltree[p] = cx.Ltree;
         A.rng_ctr[p] = cx.ctr;
         A.ebuf[p] = cx.ebuf;
-        A.widx[p] = widx;
+        if constexpr (PIPE) {
+            A.rg_widx[(size_t)cur * A.Np + p] = widx;
+            if (!do_extend) A.widx[p] = widx;              // the state goes back to the general kernels
+        } else {
+            A.widx[p] = widx;
+        }
         A.pidx[p] = pl.idx;
         if (TREES && (widx >= A.cap || pl.idx >= A.pcap)) A.ctrl->err = ERR_LOG_OVERFLOW;       // -arg keeps every record and piece
-        A.snap_w[A.sp][p] = w_post; A.snap_xm[A.sp][p] = x_mark; A.snap_ml[A.sp][p] = mark_limit; A.snap_widx[A.sp][p] = widx;
+        if constexpr (!PIPE) { A.snap_w[A.sp][p] = w_post; A.snap_xm[A.sp][p] = x_mark; A.snap_ml[A.sp][p] = mark_limit; A.snap_widx[A.sp][p] = widx; }
         MP_TICK(tk_stored);
         MP_ACC(ml, 11, tk_lik, tk_stored);
         MP_ACC(ml, 15, tk_begin, tk_stored);
@@ -803,6 +939,20 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
         double scp = wave_hs_scan(wq_post, lane);
         double scm = wave_max_scan_d(sc, lane);
         const long long chunk = blockIdx.x;
+        if constexpr (PIPE) {
+            const size_t ro = (size_t)cur * A.Np, co = (size_t)cur * A.nc;
+            if (live) { A.rg_scan1[ro + q] = sc; A.rg_scanp[ro + q] = scp; A.rg_scan1m[ro + q] = scm; }
+            if (q == A.Np - 1) A.ctrl->last1[cur] = sc;
+            if (lane == 63) {
+                A.rg_cpost[co + chunk] = sp; A.rg_csq[co + chunk] = sq; A.rg_cpil[co + chunk] = sc;
+                A.rg_cpp[co + chunk] = scp; A.rg_cmx1[co + chunk] = scm;
+            }
+            unsigned long long pend = __ballot(sPend[lane] != 0);
+            if (lane == 0) {
+                A.rg_dpend[co + chunk] = __popcll(pend);
+                if (!PR.extend) A.chunk_dpend[chunk] = __popcll(pend);
+            }
+        } else {
         if (live) { A.scan1[q] = sc; A.scanp2[A.sp][q] = scp; A.scan1m[q] = scm; }
         if (lane == 63) {
             A.chunk_post[chunk] = sp;
@@ -815,7 +965,26 @@ __global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long lon
             unsigned long long pend = __ballot(sPend[lane] != 0);
             if (lane == 0) A.chunk_dpend[chunk] = __popcll(pend);
         }
+        }
     }
+}
+
+template <int NM, bool BIASED, int LA, bool TREES>
+__global__ __launch_bounds__(64 * (64 / LA)) void k_extend_mpr(KArgs A, long long s, int fuse) {
+    extend_mpr_body<NM, BIASED, LA, TREES, false>(A, s, fuse);
+}
+
+// the extend role of the row pipeline for structured models: step t of the chunk table (pf_pipe.h; one chunk per launch
+// for now), the bookkeeping / ledger / count roles of the step run as their own launch on the counting stream (pf_hip.hip)
+template <int NM, bool BIASED, int LA, bool TREES>
+__global__ __launch_bounds__(64 * (64 / LA)) void k_sweep_xmp(const SweepChunk* tab_g, long long t) {
+    SweepChunkC* tab = (SweepChunkC*)tab_g;
+    SweepChunkC& ch = tab[blockIdx.y];
+    KArgsC& A = ch.A;
+    const long long s = ch.s_begin + t;
+    PipeLaunch PL;
+    if (!sweep_plan(ch, s, 0, PL)) return;
+    if (PL.row.extend || PL.row.complete) extend_mpr_body<NM, BIASED, LA, TREES, true>(A, s, 0, PL.row);
 }
 
 __global__ __launch_bounds__(PF_BS) void k_calibrate_mp(KArgs A, unsigned long long seed, long long rep0, long long nrep,
@@ -982,6 +1151,25 @@ int pf_mp_prepare(size_t smem, int mcap) {
     return 0;
 }
 static unsigned mp_blocks(long long n) { return (unsigned)((n + PF_BS - 1) / PF_BS); }
+
+// the extend role of the row pipeline (k_sweep_xmp): LDS = the register-tree kernel's plus the decision's carve-out
+size_t pf_mp_sweep_smem_bytes(int E, int P, int mcap, int nc) {
+    // the decision's tables (pf_pipe.h) share the LDS of the lanes' migration events: whichever is larger
+    const size_t events = (size_t)mcap * PF_BS * 8, tables = pipe_lds_doubles(nc) * 8;
+    return smem_mpr_bytes(E, P, mcap) + (tables > events ? tables : 0);
+}
+int pf_mp_sweep_prepare(size_t smem) {
+    if (smem > 160 * 1024) return -1;
+    if (hipFuncSetAttribute((const void*)k_sweep_xmp<8, false, PF_MPR_LANES_PLAIN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)k_sweep_xmp<8, true, PF_MPR_LANES_BIASED, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return -1;
+    return 0;
+}
+void pf_mp_launch_sweep_x(const KArgs& A, const SweepChunk* tab, long long t, size_t smem, hipStream_t st, hipEvent_t done) {
+    const bool biased = A.n_bias > 0 || A.g_K > 0;
+    const dim3 grid(mp_blocks(A.Np)), blk(64 * (64 / (biased ? PF_MPR_LANES_BIASED : PF_MPR_LANES_PLAIN)));
+    if (biased) hipExtLaunchKernelGGL((k_sweep_xmp<8, true, PF_MPR_LANES_BIASED, false>), grid, blk, smem, st, nullptr, done, 0, tab, t);
+    else hipExtLaunchKernelGGL((k_sweep_xmp<8, false, PF_MPR_LANES_PLAIN, false>), grid, blk, smem, st, nullptr, done, 0, tab, t);
+}
 void pf_mp_launch_init(const KArgs& A, double initial_position, size_t smem, hipStream_t st) {
     hipLaunchKernelGGL(k_init_mp, dim3(mp_blocks(A.Np)), dim3(PF_BS), smem, st, A, initial_position);
 }

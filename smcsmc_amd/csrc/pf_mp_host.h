@@ -15,6 +15,11 @@ void pf_mp_launch_init(const KArgs& A, double initial_position, size_t smem, hip
 // fuse (register-tree kernel only, pf_mp_can_fuse): complete the previous row (k_resample's part) while loading
 void pf_mp_launch_extend(const KArgs& A, long long s, size_t smem, hipStream_t st, bool lds_tree, int fuse);
 bool pf_mp_can_fuse(const KArgs& A, bool lds_tree);
+// the extend role of the row pipeline for structured models (k_sweep_xmp, one launch per step; `done` is recorded when it ends)
+struct SweepChunk;
+size_t pf_mp_sweep_smem_bytes(int E, int P, int mcap, int nc);
+int pf_mp_sweep_prepare(size_t smem);
+void pf_mp_launch_sweep_x(const KArgs& A, const SweepChunk* tab, long long t, size_t smem, hipStream_t st, hipEvent_t done);
 void pf_mp_launch_calibrate(const KArgs& A, unsigned long long seed, long long rep0, long long nrep, int* out_epoch,
                             double* out_dist, int* out_err, size_t smem, hipStream_t st);
 void pf_mp_launch_tbl(const KArgs& A, unsigned long long seed, long long nrep, double* out_h, double* out_len, int* out_err,

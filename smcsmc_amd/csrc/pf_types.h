@@ -81,6 +81,9 @@ struct Ctrl {
         double wa[PF_EMAX], wb[PF_EMAX];   // count windows of the row (count.cpp:363-385)
         int g_lo[PF_EMAX], g_hi[PF_EMAX];
     } ri[4];
+    // what the extend role itself notes about the row it completes (slot r & 3): the structured models' extend launches run
+    // on their own stream and do not wait for the bookkeeping role, which derives the same numbers on the counting stream
+    struct ExtendNote { long long n_res; int gen; int flag; } xr[4];
     double last1[4];       // pilot scan value at the last particle of the row in ring slot k (= oracle incl[N-1] minus chunk offset)
 };
 
@@ -172,6 +175,7 @@ struct KArgs {
     double* rg_scan1; double* rg_scan1m; double* rg_scanp;
     double* rg_cpost; double* rg_csq; double* rg_cpil; double* rg_cpp; double* rg_cmx1; double* rg_coffp;
     int* rg_dpend; int* rg_blkcnt;
+    int blk_gran;                  // entries of rg_blkcnt per block of 256 particles: 1, or 4 when the extend workgroups own 64 particles
     unsigned* rg_widx;
     int nc;                        // wavefronts = (Np + 63) / 64
     // profiling builds (-DPF_STAMPS): wall-clock stamps of the extend workgroups' phases, [rows][nc][PF_STAMP_W]; null otherwise

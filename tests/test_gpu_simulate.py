@@ -78,3 +78,50 @@ def test_structured_device_simulation_shows_the_split(hiplib):
     a = seg["alleles"]; a = a[(a.min(axis=1) == 0) & (a.max(axis=1) == 1)]
     w = np.mean([(a[:, 0] != a[:, 1]).mean(), (a[:, 2] != a[:, 3]).mean()]); x = np.mean([(a[:, 0] != a[:, 2]).mean(), (a[:, 1] != a[:, 3]).mean()])
     assert 0.9 < x / w < 1.3                      # against 2.0 without migration
+
+
+def test_device_simulator_against_the_independent_numpy_simulator(hiplib):
+    """k_simulate shares the filter's own transition code; smcsmc_amd.simulate.simulate_seg is an independent numpy
+    implementation of the same SMC' process with mutations.  200 chunks of 50 kb from each under a model with a sixfold
+    size change: two-sample Kolmogorov-Smirnov tests on the segregating sites per chunk, on the mean pairwise difference per
+    chunk and on two linkage statistics (incompatible neighbouring sites: four-gamete test at lag 1 and at lag 10)."""
+    from scipy import stats
+    from smcsmc_amd import simulate
+    n, L, N0, mu, rho = 4, 5.0e4, 1e4, 2.5e-8, 1e-8
+    ct = np.array([0.0, 2000.0, 20000.0, 60000.0])
+    ps = np.array([1.0, 0.3, 2.0, 1.0]) * N0
+    R = 200
+    dev = simulate.simulate_seg_device(n, L, mu, rho, ct, ps, seed=77, nchunks=R)
+    host = [simulate.simulate_seg(n, L, mu, rho, ct, ps, seed=1000 + r) for r in range(R)]
+
+    def four_gamete_failures(a, lag):
+        if len(a) <= lag:
+            return 0.0
+        x, y = a[:-lag], a[lag:]
+        bad = 0
+        for i in range(len(x)):
+            bad += len({(int(p), int(q)) for p, q in zip(x[i], y[i])}) == 4
+        return bad / len(x)
+
+    def stats_of(chunks):
+        S, pi, g1, g10 = [], [], [], []
+        for c in chunks:
+            a = c["alleles"][:-1]
+            a = a[(a.min(axis=1) >= 0)]
+            S.append(len(a))
+            d = 0.0
+            for i in range(n):
+                for j in range(i + 1, n):
+                    d += (a[:, i] != a[:, j]).sum()
+            pi.append(d / (n * (n - 1) / 2) / L)
+            g1.append(four_gamete_failures(a, 1)); g10.append(four_gamete_failures(a, 10))
+        return [np.array(v, float) for v in (S, pi, g1, g10)]
+
+    sd, sh = stats_of(dev), stats_of(host)
+    for name, x, y in zip(("segregating sites", "pairwise difference", "four-gamete lag 1", "four-gamete lag 10"), sd, sh):
+        p = stats.ks_2samp(x, y).pvalue
+        assert p > 1e-3, (name, p, x.mean(), y.mean())
+    # and the two agree on the means within their standard errors (3.5 sigma)
+    for x, y in zip(sd[:2], sh[:2]):
+        se = np.sqrt(x.var() / R + y.var() / R)
+        assert abs(x.mean() - y.mean()) < 3.5 * se, (x.mean(), y.mean(), se)

@@ -111,3 +111,24 @@ def test_run_many_rejects_chunks_of_different_shape(hiplib):
         ParticleFilter.run_many([a, b])
     with pytest.raises(PfError, match="twice"):
         ParticleFilter.run_many([a, a])
+
+
+@pytest.mark.parametrize("n,P,Np,biased", [(8, 2, 640, False), (4, 2, 1000, False), (6, 3, 500, False), (4, 2, 512, True)])
+def test_structured_rows_on_the_pipeline_equal_the_two_stream_path(hiplib, n, P, Np, biased):
+    """Structured models (register-tree kernel): the row pipeline (extend launches with the decision in their prologue on
+    the filter stream, bookkeeping / ledger / counts as their own launches on the counting stream) against the round-2
+    path (k_extend_mpr + k_decide, PF_DEBUG_K_PIPE) -- trees, weights, migration events, resampling indices bit for bit,
+    the lagged counts too (same workgroups, same order); in one call and in calls of 23 rows."""
+    base = cases.make_model(n=n, E=8, L=1.2e5)
+    segs = cases.make_segments(base, seed=31 + n, max_seg_len=4000)
+    model = cases.make_structured(base, P=P, split_epoch=5, mig=1.5)
+    if biased:
+        model = dict(model, bias_heights=[400.0], bias_strengths=[4.0, 1.0], application_delays=np.full(8, 2500.0), delay_type=0)
+    a = _run_alone(model, segs, Np, 9, 0, local_recomb=True)
+    b = _run_alone(model, segs, Np, 9, K_PIPE, local_recomb=True)
+    c = _run_alone(model, segs, Np, 9, 0, step=23, local_recomb=True)
+    for x in (b, c):
+        _same(a, x)
+        ma, mx = a.migrations(), x.migrations()
+        for k in ma:
+            assert (np.asarray(ma[k]) == np.asarray(mx[k])).all(), k
