@@ -411,7 +411,7 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
             pre = row_preload(A, fs);
             // the row before it: what the extend role of the previous launch noted about it (the same numbers the bookkeeping
             // role publishes in Ctrl::ri, without depending on the launch that carries that role)
-            o_nres = c->xr[(fs + 3) & 3].n_res; o_bflag = c->xr[(fs + 3) & 3].flag; o_bgen = c->xr[(fs + 3) & 3].gen;
+            o_nres = c->xr[(fs + PF_RING - 1) & (PF_RING - 1)].n_res; o_bflag = c->xr[(fs + PF_RING - 1) & (PF_RING - 1)].flag; o_bgen = c->xr[(fs + PF_RING - 1) & (PF_RING - 1)].gen;
             // The parent search of a resampling row stages the pilot scans of the wavefronts its parents sit in.  Offspring
             // stay close to their parents' slots (the offsets drift like a random walk of a few hundred slots), so the scans
             // of this workgroup's own wavefronts and six on either side are requested now, with everything else the prologue
@@ -1853,7 +1853,7 @@ __device__ __forceinline__ void ledger_body(const KA& A, int sp, int nblocks, in
 //   X(s)    workgroups [0, nb): extend the particles over row s.  On load they complete row s-1 themselves: decision
 //           (decide_row), offspring offsets, parent search, gather or normalisation -- nothing from k_decide is read;
 //   B(s-1)  one workgroup: the bookkeeping of row s-1 (log-likelihood, traces, generations of the count windows,
-//           posterior-scan offsets), published in Ctrl::ri[(s-1) & 3];
+//           posterior-scan offsets), published in Ctrl::ri[(s-1) & (PF_RING-1)];
 //   L(s-2)  ledger upkeep after the resampling of row s-2: reads the run lists in force, writes the other copy;
 //   C(s-2)  the lagged counts of row s-2 from the lists in force for that row and its slot of the state ring.
 // What a role reads was written by an earlier launch (stream order) or is private to it; nothing waits inside the
@@ -2067,7 +2067,7 @@ __global__ void k_sweep_seed(const SweepChunk* tab_g) {
     KArgsC& A = ch.A;
     if (ch.s_last < ch.s_begin) return;              // nothing to do for this chunk in this call
     Ctrl* c = A.ctrl;
-    const int slot = (int)((ch.s_begin + 3) & 3);
+    const int slot = (int)((ch.s_begin + PF_RING - 1) & (PF_RING - 1));
     if (threadIdx.x == 0) {
         Ctrl::RowInfo& r = c->ri[slot];
         r.n_res = c->n_resample; r.gen = c->gen; r.flag = 0; r.lver = c->lver; r.g_retain = c->g_retain; r.first = A.E;
@@ -2933,7 +2933,7 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     h->pipe_mp = P > 1 && n <= 8 && Np <= 131072 && !(p->flags & 2) && !(p->debug & (PF_DEBUG_FORCE_LDS | PF_DEBUG_NO_FUSE | PF_DEBUG_K_PIPE));
     A.blk_gran = h->pipe_mp ? 4 : 1;
     {
-        const size_t K = (h->pipe || h->pipe_mp) ? 4 : 2;               // copies of the particle state (KArgs::st0)
+        const size_t K = (h->pipe || h->pipe_mp) ? PF_RING : 2;               // copies of the particle state (KArgs::st0)
         A.nslots = (int)K;
         DState& st = A.st0;
         rc |= dalloc(h, &st.S, K * (size_t)(n - 1) * Np);
@@ -3009,11 +3009,11 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
         rc |= dalloc(h, &A.run_st2, (size_t)A.Gcap * Np);
         rc |= dalloc(h, &A.run_anc2, (size_t)A.Gcap * Np);
         rc |= dalloc(h, &A.nruns2, A.Gcap);
-        rc |= dalloc(h, &A.rg_scan1, 4 * (size_t)Np); rc |= dalloc(h, &A.rg_scan1m, 4 * (size_t)Np);
-        rc |= dalloc(h, &A.rg_scanp, 4 * (size_t)Np); rc |= dalloc(h, &A.rg_widx, 4 * (size_t)Np);
-        rc |= dalloc(h, &A.rg_cpost, 4 * nc); rc |= dalloc(h, &A.rg_csq, 4 * nc); rc |= dalloc(h, &A.rg_cpil, 4 * nc);
-        rc |= dalloc(h, &A.rg_cpp, 4 * nc); rc |= dalloc(h, &A.rg_cmx1, 4 * nc); rc |= dalloc(h, &A.rg_coffp, 4 * nc);
-        rc |= dalloc(h, &A.rg_dpend, 4 * nc); rc |= dalloc(h, &A.rg_blkcnt, 4 * (size_t)h->nblocks * 4);
+        rc |= dalloc(h, &A.rg_scan1, PF_RING * (size_t)Np); rc |= dalloc(h, &A.rg_scan1m, PF_RING * (size_t)Np);
+        rc |= dalloc(h, &A.rg_scanp, PF_RING * (size_t)Np); rc |= dalloc(h, &A.rg_widx, PF_RING * (size_t)Np);
+        rc |= dalloc(h, &A.rg_cpost, PF_RING * nc); rc |= dalloc(h, &A.rg_csq, PF_RING * nc); rc |= dalloc(h, &A.rg_cpil, PF_RING * nc);
+        rc |= dalloc(h, &A.rg_cpp, PF_RING * nc); rc |= dalloc(h, &A.rg_cmx1, PF_RING * nc); rc |= dalloc(h, &A.rg_coffp, PF_RING * nc);
+        rc |= dalloc(h, &A.rg_dpend, PF_RING * nc); rc |= dalloc(h, &A.rg_blkcnt, PF_RING * (size_t)h->nblocks * 4);
         h->smem_pipe = ((size_t)(2 * PF_EPAD + E + 2 * PF_BIAS_MAX + 3) + pipe_lds_doubles((int)nc)) * 8;
     }
     rc |= dalloc(h, &A.chunk_post, nc); rc |= dalloc(h, &A.chunk_sq, nc); rc |= dalloc(h, &A.chunk_pil, nc);
@@ -3478,7 +3478,7 @@ static int run_pipeline(pf_handle* h, long long s_begin, long long s_end) {
     const int nb = h->nblocks, E = h->E;
     // whatever the two-stream kernels of an earlier call left on the counting stream must be done first
     if (h->ev_cnt) { hipStreamWaitEvent(h->stream, h->ev_cnt, 0); h->ev_cnt = nullptr; }
-    hipLaunchKernelGGL(k_pipe_seed, dim3(1), dim3(1), 0, h->stream, h->A, (int)((s_begin + 3) & 3));
+    hipLaunchKernelGGL(k_pipe_seed, dim3(1), dim3(1), 0, h->stream, h->A, (int)((s_begin + PF_RING - 1) & (PF_RING - 1)));
     Windows W1 = no_windows(h), W2 = no_windows(h);      // windows of rows s-1 and s-2
     long long last = s_begin - 1;                        // last row extended so far
     const int nL_full = nb + std::max(16, std::min(PF_LEDGER_BLOCKS, 192));
@@ -3496,15 +3496,15 @@ static int run_pipeline(pf_handle* h, long long s_begin, long long s_end) {
         PL.row.extend = extend ? 1 : 0;
         PL.row.complete = (s > s_begin && s - 1 <= last && (extend || have_b)) ? 1 : 0;
         if (!extend && !have_b) PL.row.complete = 0;
-        PL.row.slot_prev = PL.row.complete ? (int)((s - 1) & 3) : -1;
-        PL.row.slot_out = (int)(s & 3);
+        PL.row.slot_prev = PL.row.complete ? (int)((s - 1) & (PF_RING - 1)) : -1;
+        PL.row.slot_out = (int)(s & (PF_RING - 1));
         PL.row.pos_prev = s > s_begin ? seg_pos(h, s - 1) : 0.0;
-        PL.b_slot = have_b ? (int)((s - 1) & 3) : -1;
+        PL.b_slot = have_b ? (int)((s - 1) & (PF_RING - 1)) : -1;
         PL.b_row = s - 1;
         PL.b_pos = have_b ? seg_pos(h, s - 1) : 0.0;
         PL.b_set_cur = set_cur;
-        PL.lc_slot = (have_lc && !h->no_count) ? (int)((s - 2) & 3) : -1;
-        PL.live_slot = (int)((s - 1) & 3);
+        PL.lc_slot = (have_lc && !h->no_count) ? (int)((s - 2) & (PF_RING - 1)) : -1;
+        PL.live_slot = (int)((s - 1) & (PF_RING - 1));
         PL.nL = PL.lc_slot >= 0 ? nL_full : 0;
         PL.ncw = h->ncw;
         const int ncount_wg = (PL.lc_slot >= 0 && W2.first < E) ? PL.ncw * (E - W2.first) : 0;
@@ -3530,7 +3530,7 @@ static int run_pipeline(pf_handle* h, long long s_begin, long long s_end) {
     }
     // flush 1: complete row `last` into the next ring slot (the general kernels continue from there), its bookkeeping,
     // ledger + counts of the row before it; flush 2: ledger + counts of row `last`
-    if (launch(last + 1, false, true, last - 1 >= s_begin, (int)((last + 1) & 3))) return -1;
+    if (launch(last + 1, false, true, last - 1 >= s_begin, (int)((last + 1) & (PF_RING - 1)))) return -1;
     W2 = W1;
     if (launch(last + 2, false, false, true, -1)) return -1;
     return 0;
@@ -3663,7 +3663,7 @@ static int run_sweep(pf_handle* const* hs, int nh, long long s_begin, long long 
 // decision on the previous row in its prologue) on the filter stream, the bookkeeping / ledger / count roles (k_sweep_blc) on
 // the counting stream -- separate launches because the extend workgroups' LDS (their trees' migration events) would be
 // allocated to every count workgroup too.  Step t's second launch needs the extend launch of step t - 1 (partials, offspring
-// table, records), the extend launch of step t must not overwrite ring slot t & 3 before the counts of step t - 2 are done:
+// table, records), the extend launch of step t must not overwrite ring slot t & (PF_RING - 1) before the counts of step t - 2 are done:
 // one wait each way per step, on the kernels' own completion signals; the extend role does not read anything the other
 // launch writes (it keeps its own note of n_resample / generation, Ctrl::xr).  k_decide, its boundary and the wait of the
 // next row on the previous row's ledger upkeep are gone from the critical stream.
@@ -3690,7 +3690,11 @@ static int run_sweep_mp(pf_handle* h, long long s_begin, long long s_end) {
     const long long last = h->h_sweep[0].s_last;
     for (long long t = 0; t < steps; ++t) {
         const long long s = s_begin + t;
-        if (t >= 2) hipStreamWaitEvent(h->stream, h->ev_blc[(size_t)((t - 2) & 15)], 0);
+        // ring slot reuse: the extend launch of step t overwrites the slot of row t - PF_RING, which the counts read in step
+        // t - PF_RING + 2.  One wait every eight steps, for the second launch of seven steps ago, covers the eight steps that
+        // follow (t + 7 - 14 <= t - 7); between two waits the extend launches are dispatched back to back.
+        static_assert(PF_RING == 16, "the wait schedule below is written for sixteen ring slots");
+        if (t >= 8 && (t & 7) == 0) hipStreamWaitEvent(h->stream, h->ev_blc[(size_t)((t - 7) & 15)], 0);
         {
             Timed tm(h, 0, timing_on(h, s));
             if (h->P > 1) pf_mp_launch_sweep_x(h->A, h->d_sweep, t, h->smem_sweep_x, h->stream, h->ev_x[(size_t)(t & 15)]);

@@ -504,8 +504,8 @@ __device__ __forceinline__ void extend_mpr_body(const KA& A, long long s, int fu
             RowPre pre = row_preload(A, row_slot);
             // the row before it: what the extend role of the previous launch noted (the bookkeeping role runs on another
             // stream here and is not waited for)
-            const long long n_res = c->xr[(fs + 3) & 3].n_res + c->xr[(fs + 3) & 3].flag;
-            G_end = c->xr[(fs + 3) & 3].gen + c->xr[(fs + 3) & 3].flag;
+            const long long n_res = c->xr[(fs + PF_RING - 1) & (PF_RING - 1)].n_res + c->xr[(fs + PF_RING - 1) & (PF_RING - 1)].flag;
+            G_end = c->xr[(fs + PF_RING - 1) & (PF_RING - 1)].gen + c->xr[(fs + PF_RING - 1) & (PF_RING - 1)].flag;
             ev_idx = (int)n_res;
             RowDecision d = decide_row<true, BS>(A, q, row_slot, n_res, pre);
             inv_prev = d.inv; S1_prev = d.S1;

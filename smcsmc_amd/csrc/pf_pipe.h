@@ -195,15 +195,15 @@ __device__ __forceinline__ bool sweep_plan(SweepChunkC& ch, long long s, int nb,
     PL.nb = nb; PL.nblk = ch.nblk;
     PL.row.extend = extend ? 1 : 0;
     PL.row.complete = ((extend && s > s_begin) || flush1) ? 1 : 0;
-    PL.row.slot_prev = PL.row.complete ? (int)((s - 1) & 3) : -1;
-    PL.row.slot_out = (int)(s & 3);
+    PL.row.slot_prev = PL.row.complete ? (int)((s - 1) & (PF_RING - 1)) : -1;
+    PL.row.slot_out = (int)(s & (PF_RING - 1));
     PL.row.pos_prev = s > s_begin ? sweep_seg_pos(ch.A, s - 1) : 0.0;
-    PL.b_slot = have_b ? (int)((s - 1) & 3) : -1;
+    PL.b_slot = have_b ? (int)((s - 1) & (PF_RING - 1)) : -1;
     PL.b_row = s - 1;
     PL.b_pos = have_b ? sweep_seg_pos(ch.A, s - 1) : 0.0;
-    PL.b_set_cur = flush1 ? (int)((s_last + 1) & 3) : -1;
-    PL.lc_slot = (have_lc && !ch.no_count) ? (int)((s - 2) & 3) : -1;
-    PL.live_slot = (int)((s - 1) & 3);
+    PL.b_set_cur = flush1 ? (int)((s_last + 1) & (PF_RING - 1)) : -1;
+    PL.lc_slot = (have_lc && !ch.no_count) ? (int)((s - 2) & (PF_RING - 1)) : -1;
+    PL.live_slot = (int)((s - 1) & (PF_RING - 1));
     PL.nL = PL.lc_slot >= 0 ? ch.nL_full : 0;
     PL.ncw = ch.ncw;
     return true;

@@ -10,6 +10,9 @@
 #define PF_DCAP 32            // pending delayed factors per particle (the reference's heap is unbounded)
 #define PF_BIAS_MAX 8         // interior bias heights
 #define PF_DECIDE_TAB 16384   // offspring / parent tables fit LDS (16-bit entries) up to this many particles
+#define PF_RING 16             // slots of the row pipeline's rings (state, scans, partials, per-row control data): row s lives in slot s & 15.
+                               // Four would do for one launch per row (the counts of row s - 2 ride in launch s); sixteen let the extend
+                               // launches of the two-launch form run up to eight steps between two waits for the counting stream
 #define PF_LEDGER_BLOCKS 192   // extra workgroups of k_resample that maintain the ancestor ledger
 #define REC_RECOMB 1
 #define REC_COALMIGR 2
@@ -68,7 +71,7 @@ struct Ctrl {
     int nbx_used;
     int lver;              // which of the two copies of the run lists is in force (the single-launch pipeline writes the
                            // re-based lists into the other copy; every other kernel updates them in place)
-    // Single-launch row pipeline (k_pipe): everything a later launch needs to know about row r, in slot r & 3.
+    // Single-launch row pipeline (k_pipe): everything a later launch needs to know about row r, in slot r & (PF_RING - 1).
     // Written by the bookkeeping workgroup of launch r + 1, read by launches r + 2 and r + 3.
     struct RowInfo {
         double T, inv_T, S1, u, pos;
@@ -80,11 +83,11 @@ struct Ctrl {
         int pad;
         double wa[PF_EMAX], wb[PF_EMAX];   // count windows of the row (count.cpp:363-385)
         int g_lo[PF_EMAX], g_hi[PF_EMAX];
-    } ri[4];
-    // what the extend role itself notes about the row it completes (slot r & 3): the structured models' extend launches run
+    } ri[PF_RING];
+    // what the extend role itself notes about the row it completes (slot r & (PF_RING - 1)): the structured models' extend launches run
     // on their own stream and do not wait for the bookkeeping role, which derives the same numbers on the counting stream
-    struct ExtendNote { long long n_res; int gen; int flag; } xr[4];
-    double last1[4];       // pilot scan value at the last particle of the row in ring slot k (= oracle incl[N-1] minus chunk offset)
+    struct ExtendNote { long long n_res; int gen; int flag; } xr[PF_RING];
+    double last1[PF_RING];       // pilot scan value at the last particle of the row in ring slot k (= oracle incl[N-1] minus chunk offset)
 };
 
 struct KArgs {
@@ -143,7 +146,7 @@ struct KArgs {
     double delayed_count_unused;
     // state: every array of DState holds `nslots` copies back to back and st0 points at copy 0 (state_slot() below gives
     // copy k).  Copies 0 and 1 are the double buffer of the general kernels; the single-launch pipeline uses four as a
-    // ring indexed by row & 3 (a row's raw weights, tree and stretch stay readable for the counts two launches later).
+    // ring indexed by row & (PF_RING - 1) (a row's raw weights, tree and stretch stay readable for the counts two launches later).
     // Pointer arithmetic instead of an array of structs: a kernel argument indexed at run time would be copied to the
     // stack.
     DState st0;
@@ -170,8 +173,8 @@ struct KArgs {
     int* run_st2;                  // second copy of the three (Ctrl::lver), allocated for the single-launch pipeline
     int* run_anc2;
     int* nruns2;
-    // rings of the single-launch pipeline, slot = row & 3: per-particle scans [4][Np], per-wavefront partials [4][nc],
-    // survivors per workgroup [4][nblocks], records appended per slot [4][Np]
+    // rings of the single-launch pipeline, slot = row & (PF_RING - 1): per-particle scans [PF_RING][Np], per-wavefront partials [PF_RING][nc],
+    // survivors per workgroup [PF_RING][nblocks], records appended per slot [PF_RING][Np]
     double* rg_scan1; double* rg_scan1m; double* rg_scanp;
     double* rg_cpost; double* rg_csq; double* rg_cpil; double* rg_cpp; double* rg_cmx1; double* rg_coffp;
     int* rg_dpend; int* rg_blkcnt;
