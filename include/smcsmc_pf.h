@@ -107,6 +107,9 @@ typedef struct pf_params {
 #define PF_DEBUG_K_PIPE   16     /* the round-2 row paths: k_pipe (argument block passed by value, windows from the host) instead of k_sweep;
                                   * structured models: k_extend_mpr + k_decide with the counts on a second stream instead of the row pipeline */
 
+#define PF_DEBUG_NO_DRAW_TABLE 128 /* k_sweep: every genealogy update computes its own random numbers instead of reading the ones made
+                                  * ahead by the draw role (A/B; the numbers are the same) */
+
 typedef struct pf_segments {
     int64_t n;
     const double* start;             /* [n] relative to -startpos (segdata.cpp:200-209) */

@@ -35,7 +35,7 @@ def _stale(target, sources):
 def build_lib(force=False):
     units = [os.path.join(CSRC, "pf_hip.hip"), os.path.join(CSRC, "pf_mp.hip")]
     deps = [os.path.join(CSRC, f) for f in ("pf_device.h", "pf_types.h", "pf_lane.h", "pf_tree_reg.h", "pf_mp.h",
-                                            "pf_mp_host.h")]
+                                            "pf_mp_host.h", "pf_mp_reg.h", "pf_pipe.h")]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "smcsmc_pf.h"))
     if force or _stale(LIB, units + deps):
         cmd = [_hipcc()] + HIPCC_FLAGS + ["-shared", "-o", LIB] + units

@@ -402,6 +402,7 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
     int o_ml = 0;
     unsigned o_widx = 0;
     unsigned long long o_ctr = 0;
+    unsigned o_tab_end = 0;
     long long o_nres = 0; int o_bflag = 0, o_bgen = 0;
     double spec_sm[PF_PIPE_STAGE * 64 / PF_BS];
     int spec_lo = 0;
@@ -443,6 +444,7 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
             o_ml = own.mark_limit[p]; o_Ltree = own.Ltree[p];
             o_widx = PR.complete ? A.rg_widx[(size_t)fs * A.Np + p] : A.widx[p];
             o_ctr = A.rng_ctr[p]; o_ebuf = A.ebuf[p];
+            if (PR.draws) o_tab_end = (unsigned)A.dt_filled[(size_t)((PR.draws - 1) ^ 1) * A.Np + p];
             if (PR.complete) o_sm = A.rg_scan1m[(size_t)fs * A.Np + p];
         }
     }
@@ -638,6 +640,13 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
         cx.vbc = A.vb_coal; cx.upd_fac = 1.0;
         cx.gK = BIASED ? A.g_K : 0; cx.gpos = A.g_pos; cx.grho = A.g_rho; cx.gleaf = A.g_leaf; cx.last_rbiw = 1.0;
         cx.ridx = cx.gK > 0 ? from.ridx[a] : 0; cx.g_rp = 0; cx.g_sb = 0;
+        if constexpr (PIPE) {
+            cx.tab = nullptr; cx.tab_end = 0; cx.pf_ok = false; cx.pf_ctr = 0; cx.draws_log = false;
+            if (PR.draws) {
+                cx.tab = (const double2*)A.dt_tab + (size_t)p * PF_DRAW_RING;
+                cx.tab_end = o_tab_end;
+            }
+        }
         DStore ds;
         if (BIASED) {
             ds.pos = st.dpos + p; ds.fac = st.dfac + p; ds.delta = st.ddelta + p; ds.k = st.dk + p; ds.Np = A.Np;
@@ -663,7 +672,7 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
         } else {
             w_post = o_wpost; w_pilot = o_wpilot; next_base = o_next; x_mark = o_xmark; mark_limit = o_ml; cx.Ltree = o_Ltree;
         }
-        if constexpr (PIPE) { cx.ctr = o_ctr; cx.ebuf = o_ebuf; widx = o_widx; }
+        if constexpr (PIPE) { cx.ctr = o_ctr; cx.ebuf = o_ebuf; widx = o_widx; r_draws_prefetch(cx); }
         else { cx.ctr = A.rng_ctr[p]; cx.ebuf = A.ebuf[p]; widx = A.widx[p]; }
         if (completing) {
             if (!PIPE && p == 0) { Ctrl* cw = A.ctrl; cw->gen_prev = c->gen; cw->nres_prev = c->n_resample; }
@@ -699,7 +708,10 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
                 w_post = wp * adj;
                 w_pilot = wq * adj;
                 x_mark = pos;
-                if (!first_copy && pos < v_L) next_base = r_sample_next_base<false>(cx, pos);     // pc.cpp:357-368
+                if (!first_copy && pos < v_L) {
+                    next_base = r_sample_next_base<false>(cx, pos);     // pc.cpp:357-368
+                    if constexpr (PIPE) r_draws_prefetch(cx);           // the counter moved: the request of the prologue is stale
+                }
             }
         }
 
@@ -754,6 +766,7 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
                 // (particle.cpp:822-826); the open stretch continues
                 cx.ridx += 1;
                 next_base = r_sample_next_base<false>(cx, updated_to);
+                if constexpr (PIPE) r_draws_prefetch(cx);
                 continue;
             }
             PF_TICK(tk1);
@@ -767,7 +780,7 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
                 double h, tc;
                 PF_TICK(tk2);
                 PF_ACC(1, tk1, tk2);
-                r_genealogy_update<NM, BIASED>(cx, t, &h, &tc);
+                r_genealogy_update<NM, BIASED, PIPE>(cx, t, &h, &tc);
                 PF_TICK(tk3);
                 PF_ACC(2, tk2, tk3);
                 if (cx.vbc) { w_post *= cx.upd_fac; w_pilot *= cx.upd_fac; cx.upd_fac = 1.0; }
@@ -792,7 +805,7 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
                     d_adjust_with_delay(ds, w_post, w_pilot, iw, delay, updated_to);
                 }
                 PF_TICK(tk5);
-                next_base = r_sample_next_base<true>(cx, updated_to);      // fourth uniform of the update
+                next_base = r_sample_next_base<true, PIPE>(cx, updated_to);      // fourth uniform of the update
                 x_mark = updated_to;
                 mark_limit = limit;
                 PF_TICK(tk6);
@@ -879,6 +892,7 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
         A1.rng_ctr[p] = cx.ctr;
         A1.ebuf[p] = cx.ebuf;
         if constexpr (PIPE) {
+            if (PR.draws) A1.dt_ctr[(size_t)(PR.draws - 1) * A1.Np + p] = cx.ctr;      // where the next row's draws start
             A1.rg_widx[(size_t)cur * A1.Np + p] = widx;
             if (!do_extend) A1.widx[p] = widx;              // the state goes back to the general kernels
         } else {
@@ -1949,6 +1963,35 @@ __device__ __forceinline__ void pipe_bookkeeping(const KA& A, const PipeLds& q, 
     }
 }
 
+// The draw table (one-population rows of k_sweep).  The random numbers of a slot are a function of (seed, slot, draw index)
+// alone -- the stream belongs to the slot, not to the particle that sits in it -- so the numbers the slot's next genealogy
+// updates will ask for can be made before they are asked for, by workgroups that are off the critical path: a third of
+// an update's instructions are its two Philox blocks and the logarithms of two of the four uniforms.  Step s brings the
+// table of every slot up to PF_DRAW_RING blocks past the counter the slot had at the start of row s (written by the extend
+// role of step s - 1); the extend role of step s + 1 reads it.  What the extend role of step s reads at the same time lies
+// below the old mark, what is written here at or above it, and the ring holds PF_DRAW_RING blocks: no entry is read and
+// written in one launch.  A slot that outruns its table (more than sixteen updates in a row) computes its own numbers, and
+// the table skips ahead.
+template <class KA>
+__device__ __forceinline__ void draw_role(const KA& A, int tb, int nT, int par) {
+    const long long Np = A.Np;
+    const unsigned long long* c_in = A.dt_ctr + (size_t)(par ^ 1) * Np;
+    const unsigned long long* f_in = A.dt_filled + (size_t)(par ^ 1) * Np;
+    unsigned long long* f_out = A.dt_filled + (size_t)par * Np;
+    const unsigned long long seed = A.seed;
+    for (long long p = (long long)tb * PF_BS + threadIdx.x; p < Np; p += (long long)nT * PF_BS) {
+        const unsigned long long c0 = c_in[p], f_old = f_in[p];
+        const unsigned long long to = c0 + PF_DRAW_RING;
+        double2* tab = (double2*)A.dt_tab + (size_t)p * PF_DRAW_RING;
+        for (unsigned long long cc = f_old > c0 ? f_old : c0; cc < to; ++cc) {
+            double u0, u1;
+            philox_pair(seed, (unsigned)p, 0u, cc, u0, u1);
+            tab[(unsigned)cc & (PF_DRAW_RING - 1)] = make_double2(u0, -dlog(u1));
+        }
+        f_out[p] = to;
+    }
+}
+
 template <int NM, bool BIASED, bool EXACT, bool TREES, int P = 1, class KA>
 __device__ __forceinline__ void pipe_roles(const KA& A, long long s, const PipeLaunch& PL, const Windows& Wb) {
     const int bx = (int)blockIdx.x;
@@ -1964,10 +2007,14 @@ __device__ __forceinline__ void pipe_roles(const KA& A, long long s, const PipeL
         pipe_bookkeeping<BIASED>(A, q, PL, Wb);
         return;
     }
+    if (bx - (nb + 1) < PL.nT) {
+        if constexpr (P == 1) draw_role(A, bx - (nb + 1), PL.nT, PL.row.draws - 1);
+        return;
+    }
     if (PL.lc_slot < 0) return;
     const Ctrl* c = A.ctrl;
     const Ctrl::RowInfo& r = c->ri[PL.lc_slot];
-    const int lb = bx - (nb + 1);
+    const int lb = bx - (nb + 1) - PL.nT;
     if (lb < PL.nL) {
         if (!r.flag) return;
         const RunLists src = run_lists(A, r.lver), dst = run_lists(A, r.lver ^ 1);
@@ -2075,6 +2122,14 @@ __global__ void k_sweep_seed(const SweepChunk* tab_g) {
         c->xr[slot].n_res = c->n_resample; c->xr[slot].gen = c->gen; c->xr[slot].flag = 0;
     }
     if ((int)threadIdx.x < A.E) c->counted_to[threadIdx.x] = ch.counted_to[threadIdx.x];
+    if (ch.nT > 0) {
+        // the draw table starts every call empty, from the counters the slots have now
+        const size_t par = (size_t)((ch.s_begin + 1) & 1);          // parity of row s_begin - 1
+        for (long long p = threadIdx.x; p < A.Np; p += blockDim.x) {
+            A.dt_ctr[par * A.Np + p] = A.rng_ctr[p];
+            A.dt_filled[par * A.Np + p] = 0;
+        }
+    }
 }
 
 __global__ __launch_bounds__(PF_BS) void k_ledger(KArgs A, int nblocks) {
@@ -2982,6 +3037,13 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
         A.g_K = K; A.g_pos = gp; A.g_rho = gr; A.g_leaf = gl;
     }
     rc |= dalloc(h, &A.rng_ctr, Np);
+    A.dt_tab = nullptr; A.dt_filled = nullptr; A.dt_ctr = nullptr;
+    if (h->pipe && !h->use_k_pipe && !h->split_roles && !(p->debug & PF_DEBUG_NO_DRAW_TABLE)) {
+        // draw table of k_sweep (draw_role): 512 bytes per slot
+        rc |= dalloc(h, &A.dt_tab, (size_t)2 * PF_DRAW_RING * Np);
+        rc |= dalloc(h, &A.dt_filled, (size_t)2 * Np);
+        rc |= dalloc(h, &A.dt_ctr, (size_t)2 * Np);
+    }
     rc |= dalloc(h, &A.ebuf, Np);
     rc |= dalloc(h, &A.widx, Np);
     A.cap = (unsigned)log_cap;
@@ -3507,6 +3569,7 @@ static int run_pipeline(pf_handle* h, long long s_begin, long long s_end) {
         PL.live_slot = (int)((s - 1) & (PF_RING - 1));
         PL.nL = PL.lc_slot >= 0 ? nL_full : 0;
         PL.ncw = h->ncw;
+        PL.nT = 0; PL.row.draws = 0;               // k_pipe keeps no draw table
         const int ncount_wg = (PL.lc_slot >= 0 && W2.first < E) ? PL.ncw * (E - W2.first) : 0;
         if (ncount_wg > 0) h->fin_pending = true;
         const bool t = extend && timing_on(h, s);
@@ -3551,7 +3614,8 @@ static void launch_sweep(pf_handle* h, const dim3& grid, long long t) {
 static bool sweep_compatible(const pf_handle* a, const pf_handle* b) {
     const bool ba = a->A.n_bias > 0 || a->A.g_K > 0, bb = b->A.n_bias > 0 || b->A.g_K > 0;
     return a->device == b->device && a->Np == b->Np && a->n == b->n && a->E == b->E && a->P == b->P && ba == bb &&
-           a->A.rec_trees == b->A.rec_trees && a->ncw == b->ncw && a->smem_pipe == b->smem_pipe && a->no_count == b->no_count;
+           a->A.rec_trees == b->A.rec_trees && a->ncw == b->ncw && a->smem_pipe == b->smem_pipe && a->no_count == b->no_count &&
+           (a->A.dt_tab != nullptr) == (b->A.dt_tab != nullptr);
 }
 
 // the per-chunk table of a k_sweep call in the leader's device buffer; returns the number of steps (0: nothing to do)
@@ -3582,6 +3646,7 @@ static long long sweep_table(pf_handle* const* hs, int nh, long long s_begin, lo
         ch.nL_full = nL_full;
         ch.ncw = g->ncw;
         ch.nblk = g->nblocks;
+        ch.nT = g->A.dt_tab ? g->nblocks : 0;
         if (last >= s_begin) steps = std::max(steps, last - s_begin + 3);
     }
     *failed = false;
@@ -3589,7 +3654,7 @@ static long long sweep_table(pf_handle* const* hs, int nh, long long s_begin, lo
     if (hipMemcpyAsync(h->d_sweep, h->h_sweep.data(), sizeof(SweepChunk) * (size_t)nh, hipMemcpyHostToDevice, h->stream) != hipSuccess) {
         g_err = "upload of the chunk table failed"; *failed = true; return 0;
     }
-    hipLaunchKernelGGL(k_sweep_seed, dim3(nh), dim3(64), 0, h->stream, h->d_sweep);
+    hipLaunchKernelGGL(k_sweep_seed, dim3(nh), dim3(PF_BS), 0, h->stream, h->d_sweep);
     return steps;
 }
 
@@ -3622,7 +3687,7 @@ static int run_sweep(pf_handle* const* hs, int nh, long long s_begin, long long 
         int columns = 0;
         for (int k = 0; k < nh; ++k)
             if (s >= s_begin + 2 && s - 2 <= h->h_sweep[k].s_last && !hs[k]->no_count) columns = std::max(columns, E - W2[k].first);
-        const dim3 grid((unsigned)(nb + 1 + nL_full + h->ncw * columns), (unsigned)nh);
+        const dim3 grid((unsigned)(nb + 1 + h->h_sweep[0].nT + nL_full + h->ncw * columns), (unsigned)nh);
         const bool tm_on = timing_on(h, s);
         {
             Timed tm(h, 0, tm_on);

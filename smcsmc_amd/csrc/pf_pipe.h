@@ -149,6 +149,7 @@ struct PipeRow {
     int slot_prev;         // state ring slot to read (the general double-buffer index when !complete)
     int slot_out;          // slot to write
     double pos_prev;       // end of the previous row
+    int draws;             // the draw table is kept up by this launch sequence (k_sweep): 1 + parity of the row, 0: no table
 };
 
 
@@ -164,6 +165,7 @@ struct PipeLaunch {
     int live_slot;         // newest complete slot of the per-slot record counters (ring-overwrite check)
     int nL;                // ledger workgroups
     int ncw;               // count workgroups per epoch
+    int nT;                // workgroups that keep up the draw table (k_sweep only)
 };
 
 
@@ -176,6 +178,7 @@ struct SweepChunk {
     int nL_full;                   // ledger workgroups per step
     int ncw;                       // count workgroups per epoch
     int nblk;                      // particle blocks of 256
+    int nT;                        // draw-table workgroups per step (0: no table)
 };
 typedef const __attribute__((address_space(4))) SweepChunk SweepChunkC;
 
@@ -198,6 +201,8 @@ __device__ __forceinline__ bool sweep_plan(SweepChunkC& ch, long long s, int nb,
     PL.row.slot_prev = PL.row.complete ? (int)((s - 1) & (PF_RING - 1)) : -1;
     PL.row.slot_out = (int)(s & (PF_RING - 1));
     PL.row.pos_prev = s > s_begin ? sweep_seg_pos(ch.A, s - 1) : 0.0;
+    PL.row.draws = ch.nT > 0 ? 1 + (int)(s & 1) : 0;
+    PL.nT = extend ? ch.nT : 0;
     PL.b_slot = have_b ? (int)((s - 1) & (PF_RING - 1)) : -1;
     PL.b_row = s - 1;
     PL.b_pos = have_b ? sweep_seg_pos(ch.A, s - 1) : 0.0;

@@ -87,7 +87,31 @@ struct RCtx {
     unsigned last_desc_new;   // samples below the node created by the last update (only computed when want_desc)
     bool want_desc;
     bool want_desc_new;   // -arg only
+    // draw table of the row pipeline (draw_role, pf_hip.hip): the blocks of this slot's stream below `tab_end` are in `tab`
+    // (entry c % PF_DRAW_RING = first uniform of block c and minus the logarithm of its second one).  The four numbers of
+    // the next update are requested one update ahead (r_draws_prefetch) and wait here.
+    const double2* tab;       // null: no table
+    unsigned tab_end;         // low word of the first block index that is not in the table
+    unsigned pf_ctr;          // low word of the block index the prefetched numbers belong to
+    bool pf_ok;
+    bool draws_log;           // the second and fourth number of the update in progress are already -log(uniform)
+    double pf_u0, pf_e1, pf_u2, pf_e3;
 };
+
+#define PF_DRAW_RING 32        // blocks per slot kept in the draw table (sixteen genealogy updates)
+
+// request the table entries of the update that starts at block cx.ctr (a round trip to the L2 or beyond: issued an update
+// ahead, or in the prologue of the row); without an entry for both blocks the update computes its own
+__device__ __forceinline__ void r_draws_prefetch(RCtx& cx) {
+    cx.pf_ok = false;
+    if (cx.tab != nullptr && (int)(cx.tab_end - (unsigned)cx.ctr) >= 2) {
+        const double2 a = cx.tab[(unsigned)cx.ctr & (PF_DRAW_RING - 1)];
+        const double2 b = cx.tab[((unsigned)cx.ctr + 1u) & (PF_DRAW_RING - 1)];
+        cx.pf_u0 = a.x; cx.pf_e1 = a.y; cx.pf_u2 = b.x; cx.pf_e3 = b.y;
+        cx.pf_ctr = (unsigned)cx.ctr;
+        cx.pf_ok = true;
+    }
+}
 
 __device__ __forceinline__ double r_uni(RCtx& cx) { return philox_uniform(cx.seed, cx.slot, cx.stream, cx.ctr++); }
 // Largest e with tab[e] <= t, for an ascending table of PF_EPAD = 64 doubles in LDS, padded with +inf behind its E
@@ -228,7 +252,7 @@ __device__ __forceinline__ void r_insert_node(RTree<NM>& t, int n, int ni, doubl
     t.setC(rn, 1, target);
 }
 
-template <int NM>
+template <int NM, bool TAB = false>
 __device__ __forceinline__ double r_coalesce_up(RCtx& cx, const RTree<NM>& t, int ns, int nl, double h, double u_refresh) {
     // Cumulative-intensity form of the walk (see coalesce_up in pf_device.h: same arithmetic, operation for
     // operation): one comparison per node passed instead of one per epoch passed, then the inverse of the piecewise
@@ -271,12 +295,12 @@ __device__ __forceinline__ double r_coalesce_up(RCtx& cx, const RTree<NM>& t, in
     double t1 = cx.T[es] + (C - cx.H[es]) / cx.I[es];
     if (t1 < lower) t1 = lower;
     if (t1 > sn) t1 = sn;
-    cx.ebuf = -dlog(u_refresh);
+    cx.ebuf = (TAB && cx.draws_log) ? u_refresh : -dlog(u_refresh);
     if (cx.vbc) cx.upd_fac *= cx.vbc[es];
     return t1;
 }
 
-template <bool SPARE>
+template <bool SPARE, bool TAB = false>
 __device__ __forceinline__ double r_sample_next_base(RCtx& cx, double x) {
     // with a guide: the rate of the particle's current segment, the draw limited to the segment (particle.cpp:1203-1232)
     double rho_here = cx.rho, seg_end = cx.L;
@@ -292,7 +316,8 @@ __device__ __forceinline__ double r_sample_next_base(RCtx& cx, double x) {
         return seg_end;
     }
     double nb = x + cx.ebuf / rate;
-    cx.ebuf = -dlog(SPARE ? cx.u_nb : r_uni(cx));
+    if (SPARE && TAB && cx.draws_log) cx.ebuf = cx.u_nb;
+    else cx.ebuf = -dlog(SPARE ? cx.u_nb : r_uni(cx));
     if (nb == x) {
         nb = __longlong_as_double(__double_as_longlong(x) + 1);
         if (x == 0.0) nb = 4.9406564584124654e-324;
@@ -478,7 +503,7 @@ __device__ __forceinline__ void r_sample_point_guided(RCtx& cx, const RTree<NM>&
 }
 
 // One SMC' genealogy update; mirrors genealogy_update() in pf_hip.hip / Filter::genealogy_update in the oracle.
-template <int NM, bool BIASED>
+template <int NM, bool BIASED, bool TAB = false>
 __device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, double* h_out, double* tc_out,
                                                    double* sp_out = nullptr, bool* changed_out = nullptr) {
     const int n = cx.n;
@@ -486,10 +511,21 @@ __device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, doubl
     int lin = 0;
     bool guided_pt = false;
     // the update's four uniforms: two Philox blocks, drawn together (philox_pair)
+    // TAB: from the draw table when the numbers of exactly this update were requested in time (then the second and the fourth
+    // arrive as logarithms), and the request for the next update goes out at once
     double u_point, u_refresh, u_attach;
-    philox_pair(cx.seed, cx.slot, cx.stream, cx.ctr, u_point, u_refresh);
-    philox_pair(cx.seed, cx.slot, cx.stream, cx.ctr + 1, u_attach, cx.u_nb);
+    bool from_tab = false;
+    if constexpr (TAB) {
+        from_tab = cx.pf_ok && cx.pf_ctr == (unsigned)cx.ctr;
+        cx.draws_log = from_tab;
+        u_point = cx.pf_u0; u_refresh = cx.pf_e1; u_attach = cx.pf_u2; cx.u_nb = cx.pf_e3;
+    }
+    if (!from_tab) {
+        philox_pair(cx.seed, cx.slot, cx.stream, cx.ctr, u_point, u_refresh);
+        philox_pair(cx.seed, cx.slot, cx.stream, cx.ctr + 1, u_attach, cx.u_nb);
+    }
     cx.ctr += 2;
+    if constexpr (TAB) r_draws_prefetch(cx);
     if (BIASED && cx.gK > 0 && cx.stream == 0) {
         r_sample_point_guided(cx, t, cx.nb > 1, u_point, &h);
         guided_pt = true;
@@ -554,7 +590,7 @@ __device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, doubl
             for (int r = 0; r < RTree<NM>::NI; ++r) tmask[r] = below[r];
         }
     }
-    double tc = r_coalesce_up(cx, t, n - 1, n, h, u_refresh);
+    double tc = r_coalesce_up<NM, TAB>(cx, t, n - 1, n, h, u_refresh);
     *tc_out = tc;
     double Sp = t.getS(rp);
     int b_id = t.getC(rp, sb), s_id = t.getC(rp, 1 - sb);

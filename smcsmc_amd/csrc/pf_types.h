@@ -152,6 +152,9 @@ struct KArgs {
     DState st0;
     int nslots;
     unsigned long long* rng_ctr;   // slot-owned
+    // draw table of the row pipeline (draw_role): [Np][PF_DRAW_RING] entries of two doubles, the first block index that is not in
+    // it and the counter at the start of a row, both [2][Np] by row parity (one launch writes what the next one reads)
+    double* dt_tab; unsigned long long* dt_filled; unsigned long long* dt_ctr;
     double* ebuf;                  // slot-owned
     unsigned* widx;                // slot-owned: records ever appended by this slot
     // event log: rec[(p*cap + k%cap)*RS .. +RS)

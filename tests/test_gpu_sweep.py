@@ -67,6 +67,35 @@ def test_sweep_equals_k_pipe_and_oracle(oracle, hiplib, n, Np, biased):
         np.testing.assert_allclose(cg[k], co[k], rtol=1e-9, atol=1e-300)
 
 
+NO_DRAW_TABLE = 128  # PF_DEBUG_NO_DRAW_TABLE
+
+
+@pytest.mark.parametrize("n,biased,mu,rho,step", [(4, False, 2.5e-8, 1e-8, None), (4, False, 2.5e-9, 4e-8, None), (8, False, 2.5e-9, 2e-8, 23),
+                                                 (4, True, 2.5e-8, 1e-8, 31), (6, True, 4e-9, 3e-8, None)])
+def test_draw_table_changes_nothing(oracle, hiplib, n, biased, mu, rho, step):
+    """The random numbers made ahead by the draw role of k_sweep are the ones an update would compute itself: with and
+    without the table, trees, weights, resampling and counts are the same bits, and equal the oracle's.  The sparse-data
+    cases make a dozen or more recombinations per row and particle, so slots outrun their sixteen updates' worth of table,
+    fall back to their own numbers and let the table skip ahead; `step` cuts the sweep into calls (the table restarts)."""
+    import oracle_lib
+    model = cases.make_model(n=n, E=8, L=4e5, mu=mu, rho=rho)
+    if biased:
+        model.update(bias_heights=[400.0], bias_strengths=[3.0, 1.0], delay_type=0, application_delays=np.full(8, 3000.0))
+    segs = cases.make_segments(model, seed=4, max_seg_len=30000)
+    a = _run_alone(model, segs, 600, 3, 0, step=step)
+    b = _run_alone(model, segs, 600, 3, NO_DRAW_TABLE)
+    _same(a, b)
+    if rho > 1e-8:
+        per_row = float(np.sum(a.counts()["rec_count"])) / len(segs["start"])
+        assert per_row > 5.0, per_row                      # with 600 particles the table (sixteen updates per row) is outrun in most rows
+    o = oracle_lib.Oracle(model, 600, seed=3)
+    o.init_prior(0.0); o.run(o.pack_segments(model, segs))
+    assert _bits(a.logl()) == _bits(o.logl())
+    co, cg = o.counts(), a.counts()
+    for k in ("coal_count", "coal_opp", "rec_count", "rec_opp"):
+        np.testing.assert_allclose(cg[k], co[k], rtol=1e-9, atol=1e-300)
+
+
 def test_sweep_in_pieces_equals_one_call(hiplib):
     """pf_run over [0, S) in calls of 37 rows (two flush steps and a fresh window seed each) = one call."""
     model = cases.make_model(n=4, E=8, L=1.2e5)
