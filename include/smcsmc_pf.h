@@ -110,6 +110,8 @@ typedef struct pf_params {
 #define PF_DEBUG_NO_DRAW_TABLE 128 /* k_sweep: every genealogy update computes its own random numbers instead of reading the ones made
                                   * ahead by the draw role (A/B; the numbers are the same) */
 
+#define PF_DEBUG_NO_SEARCH_LUT 256 /* k_sweep: the epoch searches of an update by the four-way search instead of the bucket tables (A/B) */
+
 typedef struct pf_segments {
     int64_t n;
     const double* start;             /* [n] relative to -startpos (segdata.cpp:200-209) */

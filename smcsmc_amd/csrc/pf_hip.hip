@@ -457,6 +457,11 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
         sBH[threadIdx.x] = A.bias_H[threadIdx.x];
         if (threadIdx.x < PF_BIAS_MAX + 1) sBS[threadIdx.x] = A.bias_S[threadIdx.x];
     }
+    __shared__ unsigned s_lut[PIPE ? 2 * PF_LUT_N / 4 : 1];
+    const bool use_lut = PIPE && A.lut != nullptr;
+    if constexpr (PIPE) {
+        if (use_lut && threadIdx.x < 2 * PF_LUT_N / 4) s_lut[threadIdx.x] = ((const unsigned*)A.lut)[threadIdx.x];
+    }
     // ---- what completing the previous row needs ----
     int cur = 0, from_slot = 0;
     bool completing = false, gather = false;
@@ -641,6 +646,9 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
         cx.gK = BIASED ? A.g_K : 0; cx.gpos = A.g_pos; cx.grho = A.g_rho; cx.gleaf = A.g_leaf; cx.last_rbiw = 1.0;
         cx.ridx = cx.gK > 0 ? from.ridx[a] : 0; cx.g_rp = 0; cx.g_sb = 0;
         if constexpr (PIPE) {
+            cx.lutT = use_lut ? (const unsigned char*)s_lut : nullptr;
+            cx.lutH = use_lut ? (const unsigned char*)s_lut + PF_LUT_N : nullptr;
+            cx.kbT = A.lut_kbT; cx.kbH = A.lut_kbH;
             cx.tab = nullptr; cx.tab_end = 0; cx.pf_ok = false; cx.pf_ctr = 0; cx.draws_log = false;
             if (PR.draws) {
                 cx.tab = (const double2*)A.dt_tab + (size_t)p * PF_DRAW_RING;
@@ -2762,6 +2770,37 @@ static int dalloc(pf_handle* h, T** p, size_t count) {
     return 0;
 }
 
+// Bucket table of r_search_lut for an ascending table tab[0..E) with tab[0] = 0: lut[j] = the largest e with tab[e] <= the
+// lower edge of bucket j, bucket j = the doubles whose upper sixteen bits are kbase + j (bucket 0 also takes everything
+// below, the last bucket everything above).  Returns false when the table spans more buckets than PF_LUT_N, when a bucket
+// holds more than two entries (the two probes of the device would not finish the search) or when the probes could leave
+// the padded table.
+static bool lut_build(const double* tab, int E, unsigned char* lut, int* kbase) {
+    auto key = [](double v) { uint64_t b; memcpy(&b, &v, 8); return (int)(b >> 48); };
+    auto edge = [](int k) { uint64_t b = (uint64_t)k << 48; double v; memcpy(&v, &b, 8); return v; };
+    if (E + 2 > PF_EPAD) return false;
+    for (int e = 0; e < E; ++e) if (!(tab[e] >= 0.0) || !std::isfinite(tab[e]) || (e > 0 && tab[e] < tab[e - 1])) return false;
+    if (E == 1 || !(tab[E - 1] > 0.0)) { memset(lut, 0, PF_LUT_N); *kbase = 0x3ff0; return E == 1; }
+    int first = 1;
+    while (first < E && tab[first] == 0.0) ++first;              // entries equal to tab[0] (an epoch of zero intensity at the start)
+    const int kb = key(tab[first]) - 1;
+    if (kb < 1 || key(tab[E - 1]) > kb + PF_LUT_N - 2) return false;
+    *kbase = kb;
+    for (int j = 0; j < PF_LUT_N; ++j) {
+        const double lo = j == 0 ? 0.0 : edge(kb + j);
+        int e = 0;
+        while (e + 1 < E && tab[e + 1] <= lo) ++e;
+        lut[j] = (unsigned char)e;
+        if (j + 1 < PF_LUT_N) {
+            const double hi = edge(kb + j + 1);
+            int inside = 0;
+            for (int q = e + 1; q < E && tab[q] < hi; ++q) ++inside;
+            if (inside > 2) return false;
+        } else if (e != E - 1) return false;
+    }
+    return true;
+}
+
 // cumulative coalescence intensity at the epoch starts, in exactly this order of operations on both sides of the
 // parity tests: Hc[0] = 0, Hc[e+1] = Hc[e] + (T[e+1] - T[e]) * inv2N[e]
 static std::vector<double> cumulative_intensity(const double* T, const std::vector<double>& inv2N, int E) {
@@ -2970,6 +3009,15 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     hipMemcpyAsync(dRF, m->record_flags, E * 4, hipMemcpyHostToDevice, h->stream);
     hipStreamSynchronize(h->stream);
     A.T = dT; A.inv2N = dI; A.Hc = dHc; A.lags = dlag; A.recflags = dRF;
+    A.lut = nullptr; A.lut_kbT = 0; A.lut_kbH = 0;
+    if (!(p->debug & PF_DEBUG_NO_SEARCH_LUT)) {
+        unsigned char lut[2 * PF_LUT_N];
+        if (lut_build(m->change_times, E, lut, &A.lut_kbT) && lut_build(Hc.data(), E, lut + PF_LUT_N, &A.lut_kbH)) {
+            unsigned char* dl;
+            rc |= dalloc(h, &dl, 2 * PF_LUT_N);
+            if (!rc) { hipMemcpy(dl, lut, sizeof(lut), hipMemcpyHostToDevice); A.lut = dl; }
+        }
+    }
     A.n_bias = m->n_bias_heights;
     A.delay_type = m->delay_type;
     for (int k = 0; k < PF_BIAS_MAX + 2; ++k) A.bias_H[k] = HUGE_VAL;

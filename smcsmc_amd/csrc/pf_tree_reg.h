@@ -96,6 +96,9 @@ struct RCtx {
     bool pf_ok;
     bool draws_log;           // the second and fourth number of the update in progress are already -log(uniform)
     double pf_u0, pf_e1, pf_u2, pf_e3;
+    // bucket tables of the two searches of an update (r_search_lut): 256 bytes each in LDS, or null
+    const unsigned char* lutT; const unsigned char* lutH;
+    int kbT, kbH;
 };
 
 #define PF_DRAW_RING 32        // blocks per slot kept in the draw table (sixteen genealogy updates)
@@ -147,6 +150,33 @@ __device__ __forceinline__ void r_search4_batch(const double* tab, const double 
         for (int k = 0; k < N; ++k)
             lo[k] += stride * ((v1[k] <= tv[k] ? 1 : 0) + (v2[k] <= tv[k] ? 1 : 0) + (v3[k] <= tv[k] ? 1 : 0));
     }
+}
+// The same answer from a bucket table: the upper sixteen bits of a non-negative double (exponent and four bits of the
+// mantissa: sixteen buckets per octave) grow with the number, so `lut[key - kbase]` = the answer at the bucket's lower edge is
+// a lower bound, and the host only supplies the table when no bucket holds more than two table entries (lut_build, pf_hip.hip):
+// two probes finish the search.  One byte and two doubles from LDS in two round trips and a dozen instructions, where the
+// four-way search takes nine doubles in three round trips and thirty instructions.
+#define PF_LUT_N 256
+__device__ __forceinline__ int r_search_lut(const double* tab, const unsigned char* lut, int kbase, double t) {
+    int key = (int)(((unsigned)__double2hiint(t) >> 16) & 0x7fffu) - kbase;
+    key = key < 0 ? 0 : (key > PF_LUT_N - 1 ? PF_LUT_N - 1 : key);
+    const int e = lut[key];
+    const double v1 = tab[e + 1], v2 = tab[e + 2];
+    return e + (v1 <= t ? 1 : 0) + (v2 <= t ? 1 : 0);
+}
+template <int N>
+__device__ __forceinline__ void r_search_lut_batch(const double* tab, const unsigned char* lut, int kbase, const double (&tv)[N], int (&lo)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        int key = (int)(((unsigned)__double2hiint(tv[k]) >> 16) & 0x7fffu) - kbase;
+        key = key < 0 ? 0 : (key > PF_LUT_N - 1 ? PF_LUT_N - 1 : key);
+        lo[k] = lut[key];
+    }
+    double v1[N], v2[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) { v1[k] = tab[lo[k] + 1]; v2[k] = tab[lo[k] + 2]; }
+#pragma unroll
+    for (int k = 0; k < N; ++k) lo[k] += (v1[k] <= tv[k] ? 1 : 0) + (v2[k] <= tv[k] ? 1 : 0);
 }
 // epoch containing time t: the largest e with T[e] <= t (T[0] = 0)
 __device__ __forceinline__ int r_epoch_of(const RCtx& cx, double t) { return r_search4(cx.T, t); }
@@ -266,7 +296,8 @@ __device__ __forceinline__ double r_coalesce_up(RCtx& cx, const RTree<NM>& t, in
 #pragma unroll
     for (int r = 0; r < NI; ++r) tv[r] = t.S[r];     // unused ranks hold 0: a harmless search, no branch
     tv[NI] = h;
-    r_search4_batch<NI + 1>(cx.T, tv, ev);
+    if (TAB && cx.lutT) r_search_lut_batch<NI + 1>(cx.T, cx.lutT, cx.kbT, tv, ev);
+    else r_search4_batch<NI + 1>(cx.T, tv, ev);
     double Hn[NI];
     {
         double hh[NI + 1], tt[NI + 1], ii[NI + 1];
@@ -291,7 +322,7 @@ __device__ __forceinline__ double r_coalesce_up(RCtx& cx, const RTree<NM>& t, in
         }
     }
     const double C = Hc + cx.ebuf / kd;
-    const int es = r_search4(cx.H, C);
+    const int es = (TAB && cx.lutH) ? r_search_lut(cx.H, cx.lutH, cx.kbH, C) : r_search4(cx.H, C);
     double t1 = cx.T[es] + (C - cx.H[es]) / cx.I[es];
     if (t1 < lower) t1 = lower;
     if (t1 > sn) t1 = sn;

@@ -155,6 +155,9 @@ struct KArgs {
     // draw table of the row pipeline (draw_role): [Np][PF_DRAW_RING] entries of two doubles, the first block index that is not in
     // it and the counter at the start of a row, both [2][Np] by row parity (one launch writes what the next one reads)
     double* dt_tab; unsigned long long* dt_filled; unsigned long long* dt_ctr;
+    // bucket tables of the epoch search and of the inverse of the cumulative intensity (r_search_lut): 2 x 256 bytes, the
+    // key of bucket 0 of either; null when a table does not qualify (then the four-way search runs)
+    const unsigned char* lut; int lut_kbT, lut_kbH;
     double* ebuf;                  // slot-owned
     unsigned* widx;                // slot-owned: records ever appended by this slot
     // event log: rec[(p*cap + k%cap)*RS .. +RS)
