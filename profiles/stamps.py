@@ -39,6 +39,18 @@ for sel, nm in ((np.ones(len(end), bool), "all rows"), (flag[4:rows-1] == 1, "ro
     crit = cr[np.arange(len(idx)), idx, :]
     print("   critical wave phase durations:", " ".join("%.2f" % v for v in np.diff(crit, axis=1).mean(axis=0)), " start offset %.2f" % crit[:, 0].mean())
 
+# the parent search of the rows that follow a resampling row, step by step (stamps 16-20 between "decide_row done" and "prologue done")
+sub = out[5:, :, 16:21].astype(np.int64) * 10.0 / 1000.0
+selr = (flag[4:rows-1] == 1)[:len(end)]
+if selr.any() and sub[selr].max() > 0:
+    base = st[selr][:, :, 2]
+    seq = [base] + [sub[selr][:, :, k] for k in range(5)] + [st[selr][:, :, 3]]
+    nm = ["own offset (pipe_lo_from)", "search over wavefronts", "barrier, range, survivors", "staging decided, barrier", "search inside the wavefront", "first copy?, offspring table, barrier"]
+    print("parent search, rows after a resampling row (mean over wavefronts of the step's duration):")
+    for k in range(6):
+        d = seq[k + 1] - seq[k]
+        print("   %-40s %6.2f us" % (nm[k], d.mean()))
+
 acc = out[5:, :, 9:15].astype(np.int64)
 trips = acc[:, :, 5].astype(float)
 print("update trips per wave and row: mean %.2f, max over waves (mean over rows) %.2f" % (trips.mean(), trips.max(axis=1).mean()))

@@ -506,6 +506,7 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
                     lo_next = p + 1 < A.Np ? pipe_lo_from(v_own, dn, A.Np, d.S1, invS1, d.u) : (int)A.Np;
                     q.slo[threadIdx.x] = lo_next;
                 }
+                PF_STAMP(16);
                 // ---- parent of slot p: the first particle a with (p+u) * S1 < N * (largest prefix sum up to a) ----
                 const double lhs = ((double)p + d.u) * d.S1;
                 int pch = 0;
@@ -517,6 +518,7 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
                     }
                     pch = lo_c;
                 }
+                PF_STAMP(17);
                 int cmin = active ? pch : 0x7fffffff, cmax = active ? pch : -1;
 #pragma unroll
                 for (int m = 1; m < 64; m <<= 1) {
@@ -540,6 +542,7 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
                     unsigned long long bal = __ballot(active && lo_p1 > lo_p);
                     if (lane == 0) q.wint[2 * (PF_BS / 64) + wave] = __popcll(bal);
                 }
+                PF_STAMP(18);
                 int nst = cmax - cmin + 1;
                 if (nst > PF_PIPE_STAGE) nst = PF_PIPE_STAGE;
                 if (nst < 0) nst = 0;
@@ -554,6 +557,7 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
                     }
                 }
                 __syncthreads();
+                PF_STAMP(19);
                 if (threadIdx.x == 0) {
                     int tot = 0;
                     for (int w = 0; w < PF_BS / 64; ++w) tot += q.wint[2 * (PF_BS / 64) + w];
@@ -575,6 +579,7 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
                         if (lhs < dn * val_at(mid)) hi_l = mid; else lo_l = mid + 1;
                     }
                     a = (long long)pch * 64 + lo_l;
+                    PF_STAMP(20);
                     if (a > A.Np - 1) a = A.Np - 1;
                     // slot p is the first copy of a (it keeps a's next recombination position) iff it equals a's offset
                     const int la = (int)(a & 63);

@@ -56,7 +56,7 @@ __device__ __forceinline__ double pipe_chunk_offset(const PipeLds& q, int ch) {
 // table / parent search need (only computed when the row resamples)
 // the partials a thread needs first, requested before anything else so that their memory round trip overlaps the
 // particle's own loads (what the previous launch wrote comes from another XCD's L2: about a microsecond)
-struct RowPre { double vp = 0.0, vs = 0.0, vl = 0.0, last1 = 0.0; bool have = false; };
+struct RowPre { double vp = 0.0, vs = 0.0, vl = 0.0, vm = 0.0, last1 = 0.0; bool have = false; };
 template <class KA>
 __device__ __forceinline__ RowPre row_preload(const KA& A, int slot) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -67,6 +67,7 @@ __device__ __forceinline__ RowPre row_preload(const KA& A, int slot) {
         r.vp = A.rg_cpost[(size_t)slot * nc + ch];
         r.vs = A.rg_csq[(size_t)slot * nc + ch];
         r.vl = A.rg_cpil[(size_t)slot * nc + ch];
+        r.vm = A.rg_cmx1[(size_t)slot * nc + ch];       // only a resampling row uses it (the prefix maxima), but then a round trip earlier
     }
     r.last1 = A.ctrl->last1[slot];
     return r;
@@ -112,7 +113,10 @@ __device__ __forceinline__ RowDecision decide_row(const KA& A, const PipeLds& q,
         const int perc = (nc + BS - 1) / BS;
         const int c0 = tid * perc, c1 = c0 + perc < nc ? c0 + perc : nc;
         double run = 0.0;
-        for (int ch = c0; ch < c1; ++ch) { double vch = pipe_chunk_offset(q, ch) + cmx1[ch]; run = vch > run ? vch : run; }
+        // one wavefront per thread (nc <= BS): thread tid's entry is the one row_preload asked for
+        const bool pre_mx = pre.have && perc == 1;
+        const double pre_vm = pre.vm;
+        for (int ch = c0; ch < c1; ++ch) { double vch = pipe_chunk_offset(q, ch) + (pre_mx ? pre_vm : cmx1[ch]); run = vch > run ? vch : run; }
         double scd = wave_max_scan_d(run, lane);
         if (lane == 63) q.wredd[wave] = scd;
         __syncthreads();
@@ -123,7 +127,7 @@ __device__ __forceinline__ RowDecision decide_row(const KA& A, const PipeLds& q,
         run = pre;
         for (int ch = c0; ch < c1; ++ch) {
             q.pmx[ch] = run;
-            double vch = pipe_chunk_offset(q, ch) + cmx1[ch];
+            double vch = pipe_chunk_offset(q, ch) + (pre_mx ? pre_vm : cmx1[ch]);
             run = vch > run ? vch : run;
         }
         if (c1 == nc && c0 < c1) q.pmx[nc] = run;
