@@ -51,6 +51,21 @@ if selr.any() and sub[selr].max() > 0:
         d = seq[k + 1] - seq[k]
         print("   %-40s %6.2f us" % (nm[k], d.mean()))
 
+# What a wavefront does between "state ready" and "scans done" needs nothing from other wavefronts.  Were two rows run back to
+# back per wavefront (the second one speculating that the first does not resample), a pair would take as long as the
+# wavefront with the largest SUM, not the sum of the two largest:
+d = rel[:, :, 8] - rel[:, :, 4]
+m = (len(d) // 2) * 2
+pair = (d[0:m:2] + d[1:m:2]).max(axis=1)
+single = d[0:m:2].max(axis=1) + d[1:m:2].max(axis=1)
+pre = rel[:, :, 4].max(axis=1)
+print("own work of a row (state ready -> scans done), slowest wavefront: %.2f us; two rows back to back, slowest wavefront: %.2f us per pair"
+      " (two single rows: %.2f us); before it (launch start -> state ready, slowest wavefront): %.2f us" % (d.max(axis=1).mean(), pair.mean(), single.mean(), pre.mean()))
+for k in (3, 4):
+    mk = (len(d) // k) * k
+    grp = sum(d[i:mk:k] for i in range(k)).max(axis=1)
+    print("   %d rows back to back: %.2f us per group" % (k, grp.mean()))
+
 acc = out[5:, :, 9:15].astype(np.int64)
 trips = acc[:, :, 5].astype(float)
 print("update trips per wave and row: mean %.2f, max over waves (mean over rows) %.2f" % (trips.mean(), trips.max(axis=1).mean()))
