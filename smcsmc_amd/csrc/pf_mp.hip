@@ -861,9 +861,11 @@ __device__ __forceinline__ void extend_mpr_body(const KA& A, long long s, int fu
                 }
             }
             double norm = 1.0 / (double)ncfg;
+            RBranchP<NM> bprob;
+            r_site_branch_probs(t, n, A.mu, bprob);     // once per row: the phasing configurations share them
             double lik = 0;
             for (;;) {
-                lik += r_site_lik(t, n, A.mu, one_mask, zero_mask, anc);
+                lik += r_site_lik_from(t, n, bprob, one_mask, zero_mask, anc);
                 if (ncfg == 1) break;
                 bool more = false;
                 for (int i = 0; i + 1 < n; i += 2) {

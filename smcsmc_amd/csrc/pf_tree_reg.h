@@ -759,4 +759,75 @@ __device__ __forceinline__ double r_site_lik(const RTree<NM>& t, int n, double m
     return res0 * p0 + res1 * p1;
 }
 
+// The same likelihood in two steps.  (1) The no-mutation probabilities of the 2 (n - 1) branches: they depend on the tree
+// alone, not on each other and not on the data, and each is a chain of some fifty dependent f64 instructions (fastexp: two
+// divisions), so they are computed side by side -- written as one straight-line block that the wavefront takes when
+// every argument of every lane is in fastexp's rational range (the scheduler then interleaves the chains; inside
+// fastexp's own branch each chain would run alone), lane by lane through fastexp otherwise: the same operations on the
+// same numbers either way.  (2) The pruning pass per phasing configuration (r_site_lik_from), which reuses them.
+template <int NM>
+struct RBranchP { double pl[RTree<NM>::NI], pr[RTree<NM>::NI]; };
+template <int NM>
+__device__ __forceinline__ void r_site_branch_probs(const RTree<NM>& t, int n, double mu, RBranchP<NM>& bp) {
+    constexpr int NI = RTree<NM>::NI;
+    double x[2 * NI];
+    bool small = true;
+#pragma unroll
+    for (int r = 0; r < NI; ++r) {
+        x[2 * r] = 0.0; x[2 * r + 1] = 0.0;
+        if (r < n - 1) {
+            const int c0 = t.C0[r], c1 = t.C1[r];
+            const double sr = t.S[r];
+            double h0 = 0.0, h1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < NI; ++k) if (k < r) { h0 = (c0 - n == k) ? t.S[k] : h0; h1 = (c1 - n == k) ? t.S[k] : h1; }
+            const double tl = sr - h0, trr = sr - h1;
+            x[2 * r] = -tl * mu; x[2 * r + 1] = -trr * mu;
+            small = small && (x[2 * r] * x[2 * r] < 0.516167859) && (x[2 * r + 1] * x[2 * r + 1] < 0.516167859);
+        }
+    }
+    double e[2 * NI];
+    if (__all(small)) {
+#pragma unroll
+        for (int i = 0; i < 2 * NI; ++i) { const double xx = x[i] * x[i]; e[i] = 1 + 2 * x[i] / (2 - x[i] + xx / (6 + xx * 0.1)); }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2 * NI; ++i) e[i] = fastexp(x[i]);
+    }
+#pragma unroll
+    for (int r = 0; r < NI; ++r) { bp.pl[r] = e[2 * r]; bp.pr[r] = e[2 * r + 1]; }
+}
+template <int NM>
+__device__ __forceinline__ double r_site_lik_from(const RTree<NM>& t, int n, const RBranchP<NM>& bp, unsigned one_mask, unsigned zero_mask, bool anc) {
+    double m0[RTree<NM>::NI], m1[RTree<NM>::NI];
+    double res0 = 0.0, res1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < RTree<NM>::NI; ++r) {
+        m0[r] = 0.0; m1[r] = 0.0;
+        if (r < n - 1) {
+            const int c0 = t.C0[r], c1 = t.C1[r];
+            double a0, a1, b0, b1;
+            if (c0 < n) { a0 = (one_mask >> c0) & 1u ? 0.0 : 1.0; a1 = (zero_mask >> c0) & 1u ? 0.0 : 1.0; }
+            else {
+                a0 = m0[0]; a1 = m1[0];
+#pragma unroll
+                for (int k = 1; k < RTree<NM>::NI; ++k) if (k < r && c0 - n == k) { a0 = m0[k]; a1 = m1[k]; }
+            }
+            if (c1 < n) { b0 = (one_mask >> c1) & 1u ? 0.0 : 1.0; b1 = (zero_mask >> c1) & 1u ? 0.0 : 1.0; }
+            else {
+                b0 = m0[0]; b1 = m1[0];
+#pragma unroll
+                for (int k = 1; k < RTree<NM>::NI; ++k) if (k < r && c1 - n == k) { b0 = m0[k]; b1 = m1[k]; }
+            }
+            const double pl = bp.pl[r], pr = bp.pr[r];
+            double v0 = (a0 * pl + a1 * (1 - pl)) * (b0 * pr + b1 * (1 - pr));
+            double v1 = (a1 * pl + a0 * (1 - pl)) * (b1 * pr + b0 * (1 - pr));
+            m0[r] = v0; m1[r] = v1;
+            if (r == n - 2) { res0 = v0; res1 = v1; }
+        }
+    }
+    double p0 = anc ? 1.0 : 0.5, p1 = anc ? 0.0 : 0.5;
+    return res0 * p0 + res1 * p1;
+}
+
 }  // namespace pf
