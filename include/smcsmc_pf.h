@@ -112,6 +112,8 @@ typedef struct pf_params {
 
 #define PF_DEBUG_NO_SEARCH_LUT 256 /* k_sweep: the epoch searches of an update by the four-way search instead of the bucket tables (A/B) */
 
+#define PF_DEBUG_COUNT_YOUNG_FIRST 512 /* row pipeline: count workgroups in ascending epoch order, as before round 3 (A/B) */
+
 typedef struct pf_segments {
     int64_t n;
     const double* start;             /* [n] relative to -startpos (segdata.cpp:200-209) */

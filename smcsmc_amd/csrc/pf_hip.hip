@@ -2039,8 +2039,11 @@ __device__ __forceinline__ void pipe_roles(const KA& A, long long s, const PipeL
         return;
     }
     const int idx = lb - PL.nL;
-    const int e = r.first + idx / PL.ncw;
-    if (e >= A.E) return;
+    // the columns of the oldest epochs first: their lags are the shortest, their windows sit right behind the front where
+    // nearly every particle is still its own ancestor, and their workgroups are the long ones -- dispatched last they were
+    // what a launch ended with
+    const int e = (A.flags & 512) ? r.first + idx / PL.ncw : A.E - 1 - idx / PL.ncw;
+    if (e >= A.E || e < r.first) return;
     const DState st = state_slot(A, PL.lc_slot);
     CountSrc Q;
     Q.w = st.w_post; Q.S = st.S; Q.xm = st.x_mark; Q.ml = st.mark_limit;
@@ -2973,7 +2976,7 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     h->h_L = m->loci_length;
     KArgs& A = h->A;
     memset(&A, 0, sizeof(A));
-    A.E = E; A.n = n; A.flags = m->flags | (h->no_spec_stage ? 256 : 0);
+    A.E = E; A.n = n; A.flags = m->flags | (h->no_spec_stage ? 256 : 0) | ((p->debug & PF_DEBUG_COUNT_YOUNG_FIRST) ? 512 : 0);
     A.L = m->loci_length; A.mu = m->mutation_rate; A.rho = m->recombination_rate;
     A.Np = Np;
     A.mcap = mcap;
