@@ -114,6 +114,8 @@ typedef struct pf_params {
 
 #define PF_DEBUG_COUNT_YOUNG_FIRST 512 /* row pipeline: count workgroups in ascending epoch order, as before round 3 (A/B) */
 
+#define PF_DEBUG_CU_MASK 1024     /* with PF_DEBUG_SPLIT_ROLES: the two streams on disjoint sets of compute units (experiment) */
+
 typedef struct pf_segments {
     int64_t n;
     const double* start;             /* [n] relative to -startpos (segdata.cpp:200-209) */

@@ -2016,7 +2016,7 @@ __device__ __forceinline__ void pipe_roles(const KA& A, long long s, const PipeL
         return;
     }
     if (bx == nb) {
-        if (PL.b_slot < 0) return;
+        if (PL.b_slot < 0 || PL.nL < -1) return;           // nL = -2: the extend launch of a split step
         extern __shared__ double smem[];
         PipeLds q = pipe_carve(smem + (2 * PF_EPAD + A.E + 2 * PF_BIAS_MAX + 3), A.nc);
         pipe_bookkeeping<BIASED>(A, q, PL, Wb);
@@ -2026,7 +2026,7 @@ __device__ __forceinline__ void pipe_roles(const KA& A, long long s, const PipeL
         if constexpr (P == 1) draw_role(A, bx - (nb + 1), PL.nT, PL.row.draws - 1);
         return;
     }
-    if (PL.lc_slot < 0) return;
+    if (PL.lc_slot < 0 || PL.nL < -1) return;
     const Ctrl* c = A.ctrl;
     const Ctrl::RowInfo& r = c->ri[PL.lc_slot];
     const int lb = bx - (nb + 1) - PL.nT;
@@ -2104,7 +2104,8 @@ __global__ __launch_bounds__(PF_BS) void k_sweep(const SweepChunk* tab_g, long l
     __shared__ Windows W;           // written and read by the bookkeeping workgroup only
     PipeLaunch PL;
     if (!sweep_plan(ch, s, nb, PL)) return;
-    if ((int)blockIdx.x == nb && PL.b_slot >= 0) sweep_windows(A, A.ctrl, PL.b_pos, W);
+    if (ch.split) PL.nL = -2;                              // extend and draw roles only: the other roles are k_sweep_blc's
+    else if ((int)blockIdx.x == nb && PL.b_slot >= 0) sweep_windows(A, A.ctrl, PL.b_pos, W);
     pipe_roles<NM, BIASED, EXACT, TREES>(A, s, PL, W);
 }
 
@@ -2121,6 +2122,7 @@ __global__ __launch_bounds__(PF_BS) void k_sweep_blc(const SweepChunk* tab_g, lo
     __shared__ Windows W;
     PipeLaunch PL;
     if (!sweep_plan(ch, s, 0, PL)) return;
+    PL.nT = 0;                                             // the draw role rides with the extend launch
     if ((int)blockIdx.x == 0 && PL.b_slot >= 0) sweep_windows(A, A.ctrl, PL.b_pos, W);
     pipe_roles<NM, BIASED, false, false, P>(A, s, PL, W);
 }
@@ -2942,8 +2944,21 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     if (hipSetDevice(device) != hipSuccess) { delete h; return fail("hipSetDevice failed"); }
     // (no stream priorities: a high-priority filter stream per handle gains nothing for one chunk and costs 30 % of the
     // throughput when several chunks share the device -- priority streams share fewer hardware queues)
+    if ((p->debug & PF_DEBUG_SPLIT_ROLES) && (p->debug & PF_DEBUG_CU_MASK) && m->n_pops == 1) {
+        // the extend launches on compute units of their own: the count workgroups of the other stream, which wait on memory
+        // most of the time but share issue slots, LDS and the vector memory path with whatever sits beside them, stay off them
+        int ncu = 0;
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+        const int words = (ncu + 31) / 32;
+        const int nx = std::min(ncu / 2, (int)((p->np + PF_BS - 1) / PF_BS) * 2 + 8);       // extend + draw workgroups
+        std::vector<uint32_t> mx((size_t)words, 0u), mc((size_t)words, 0u);
+        for (int i = 0; i < ncu; ++i) (i < nx ? mx : mc)[(size_t)(i >> 5)] |= 1u << (i & 31);
+        if (hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)words, mx.data()) != hipSuccess ||
+            hipExtStreamCreateWithCUMask(&h->cstream, (uint32_t)words, mc.data()) != hipSuccess) { delete h; return fail("hipExtStreamCreateWithCUMask failed"); }
+    } else {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail("hipStreamCreate failed"); }
     if (hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail("hipStreamCreate failed"); }
+    }
     h->sync_ev.resize(512);
     for (auto& e : h->sync_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) { delete h; return fail("hipEventCreate failed"); }
     const int E = m->n_epochs, n = m->nsam;
@@ -3096,7 +3111,7 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     }
     rc |= dalloc(h, &A.rng_ctr, Np);
     A.dt_tab = nullptr; A.dt_filled = nullptr; A.dt_ctr = nullptr;
-    if (h->pipe && !h->use_k_pipe && !h->split_roles && !(p->debug & PF_DEBUG_NO_DRAW_TABLE)) {
+    if (h->pipe && !h->use_k_pipe && !(p->debug & PF_DEBUG_NO_DRAW_TABLE)) {
         // draw table of k_sweep (draw_role): 512 bytes per slot
         rc |= dalloc(h, &A.dt_tab, (size_t)2 * PF_DRAW_RING * Np);
         rc |= dalloc(h, &A.dt_filled, (size_t)2 * Np);
@@ -3704,7 +3719,8 @@ static long long sweep_table(pf_handle* const* hs, int nh, long long s_begin, lo
         ch.nL_full = nL_full;
         ch.ncw = g->ncw;
         ch.nblk = g->nblocks;
-        ch.nT = g->A.dt_tab ? g->nblocks : 0;
+        ch.nT = (g->A.dt_tab && g->P == 1) ? g->nblocks : 0;
+        ch.split = (g->P == 1 && g->split_roles && !g->A.rec_trees) ? 1 : 0;
         if (last >= s_begin) steps = std::max(steps, last - s_begin + 3);
     }
     *failed = false;
@@ -3823,7 +3839,7 @@ static int run_sweep_mp(pf_handle* h, long long s_begin, long long s_end) {
             if (h->P > 1) pf_mp_launch_sweep_x(h->A, h->d_sweep, t, h->smem_sweep_x, h->stream, h->ev_x[(size_t)(t & 15)]);
             else {
                 // one population (PF_DEBUG_SPLIT_ROLES): k_sweep with a grid of the extend workgroups only
-                const dim3 gx((unsigned)nb, 1u), bx(PF_BS);
+                const dim3 gx((unsigned)(nb + (h->h_sweep[0].nT > 0 ? 1 + h->h_sweep[0].nT : 0)), 1u), bx(PF_BS);
                 hipEvent_t xdone = h->ev_x[(size_t)(t & 15)];
 #define PF_LAUNCH_X(NMV, BV, EV) hipExtLaunchKernelGGL((k_sweep<NMV, BV, EV, false>), gx, bx, h->smem_pipe, h->stream, nullptr, xdone, 0, h->d_sweep, t, nb)
                 if (h->n <= 4) { if (biased) { if (h->n == 4) PF_LAUNCH_X(4, true, true); else PF_LAUNCH_X(4, true, false); } else { if (h->n == 4) PF_LAUNCH_X(4, false, true); else PF_LAUNCH_X(4, false, false); } }

@@ -183,6 +183,7 @@ struct SweepChunk {
     int ncw;                       // count workgroups per epoch
     int nblk;                      // particle blocks of 256
     int nT;                        // draw-table workgroups per step (0: no table)
+    int split;                     // the extend role (with the draw role) and the other roles are separate launches (PF_DEBUG_SPLIT_ROLES)
 };
 typedef const __attribute__((address_space(4))) SweepChunk SweepChunkC;
 
