@@ -13,6 +13,7 @@
 //
 // No CUDA compatibility layer, no CPU fallback: this file is HIP for gfx950 only.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -1284,6 +1285,7 @@ struct Win { int e, rf; double T0, T1, a_e, b_e; bool end_seq; };
 #define PF_LBINS 2048
 struct LMap {
     double* lds;          // [PF_LBINS] bins of this workgroup, bin 0 = interval b0
+    int nlds;             // bins in use: the window of the step spans few of them (the rest of a step's additions, if any, go to memory)
     long long b0;
     double* gopp;         // global differential opportunity (null: map not recorded)
     double* gcnt;         // global counts [(n+2)][nbins]
@@ -1292,7 +1294,7 @@ struct LMap {
 __device__ __forceinline__ void lmap_add(const LMap& L, long long idx, double v) {
     if (idx < 0 || idx >= L.nbins) return;
     long long k = idx - L.b0;
-    if (k >= 0 && k < PF_LBINS) atomicAdd(&L.lds[k], v);
+    if (k >= 0 && k < L.nlds) atomicAdd(&L.lds[k], v);
     else atomicAdd(&L.gopp[idx], v);
 }
 // constant opportunity density over [x_lo, x_hi): the differential encoding of count.cpp:578-588
@@ -1498,11 +1500,13 @@ __device__ __forceinline__ void count_body(const KA& A, const CountSrc& Q, int e
     __shared__ double s_lbins[PF_LBINS];
     LMap L;
     L.lds = s_lbins; L.b0 = (long long)(W.a_e / 100.0); L.gopp = A.lmap_opp; L.gcnt = A.lmap_cnt; L.nbins = A.lmap_bins;
-    if (L.gopp) {
-        for (int k = threadIdx.x; k < PF_LBINS; k += PF_BS) s_lbins[k] = 0.0;
-        __syncthreads();
+    {
+        const long long span = (long long)(W.b_e / 100.0) - L.b0 + 4;
+        L.nlds = span < 1 ? 1 : (span > PF_LBINS ? PF_LBINS : (int)span);
     }
+    bool bins_ready = false;
     const int g_lo = Q.g_lo, g_hi = Q.g_hi;
+    if (g_hi < g_lo) return;                                  // an empty window: nothing to add to this workgroup's accumulators
     const int lane = threadIdx.x & 63;
     const long long gtid = (long long)bx * PF_BS + threadIdx.x;
     const long long nthreads = (long long)nbxg * PF_BS;
@@ -1555,6 +1559,15 @@ __device__ __forceinline__ void count_body(const KA& A, const CountSrc& Q, int e
         // record range -> records) and little arithmetic, and the count workgroups hide latency badly (three per CU), so
         // the first two rounds of four tasks are in flight together.  The contributions are still added in task order
         // (t, t + nthreads, ...): the sums do not change.
+        // A column is launched with as many workgroups as its busiest epochs need; the window of a younger epoch sits far behind
+        // the front, where few ancestors are left: most of its workgroups have no task at all and leave here, before the bins,
+        // the barriers and the reduction (adding zero to their accumulators is leaving them alone).
+        if (tile_hi == g_hi && tile_lo == g_lo && (long long)bx * PF_BS >= T) return;
+        if (L.gopp && !bins_ready) {
+            for (int k = threadIdx.x; k < L.nlds; k += PF_BS) s_lbins[k] = 0.0;
+            __syncthreads();
+            bins_ready = true;
+        }
         for (long long tb = gtid; tb < T; tb += (long long)PF_CNT_BATCH * nthreads) {
             int tg[PF_CNT_BATCH], tnr[PF_CNT_BATCH];
             long long ti[PF_CNT_BATCH];
@@ -1646,9 +1659,9 @@ __device__ __forceinline__ void count_body(const KA& A, const CountSrc& Q, int e
         }
     }
     // deterministic workgroup reduction: butterfly per wavefront, then wavefronts in order
-    if (L.gopp) {
+    if (L.gopp && bins_ready) {
         __syncthreads();
-        for (int k = threadIdx.x; k < PF_LBINS; k += PF_BS) {
+        for (int k = threadIdx.x; k < L.nlds; k += PF_BS) {
             double v = s_lbins[k];
             long long idx = L.b0 + k;
             if (v != 0.0 && idx < L.nbins) atomicAdd(&L.gopp[idx], v);
@@ -1925,7 +1938,10 @@ __device__ __forceinline__ void pipe_bookkeeping(const KA& A, const PipeLds& q, 
     Ctrl::RowInfo& r = c->ri[slot];
     // generations that hold the ends of the row's count windows (both monotone along the sweep)
     // (the windows are a kernel argument: indexed with a uniform epoch so that they are read with scalar loads)
-    for (int e = 0; e < E; ++e) {
+    // k_sweep / k_sweep_blc keep the windows in LDS: thread e takes epoch e (each of the two searches is a chain of dependent
+    // loads; one epoch after the other, as the by-value form below has to, they were 20 us of a launch)
+    constexpr bool W_IN_LDS = !std::is_same<KA, KArgs>::value;
+    for (int e = W_IN_LDS ? (tid < E ? tid : E) : 0; e < E; e = W_IN_LDS ? E : e + 1) {
         const double wa = W.a[e], wb = W.b[e];
         if (tid != e) continue;
         int g = c->g_lo[e];
