@@ -41,3 +41,9 @@ for k in range(16, 21):
     col = cyc[:, :, k]
     c = col[np.arange(len(crit)), crit]
     print("   %-34s mean %9.0f   critical wave %9.0f  cycles (s_memtime)" % (cn[k - 16], col.mean(), c.mean()))
+
+pn = ["  load: tables in LDS, barrier", "  load: decision on the previous row", "  load: parent search (resampling rows)", "  load: tree, event lists", "  load: rest (weights, completion, row data)"]
+for k in range(21, 26):
+    col = us[:, :, k]
+    c = col[np.arange(len(crit)), crit]
+    print("   %-42s mean %7.2f   critical wave %7.2f us" % (pn[k - 21], col.mean(), c.mean()))

@@ -4667,10 +4667,13 @@ int pf_simulate_sites(const pf_model* m, uint64_t seed, int32_t nchunks, int64_t
     KArgs A;
     memset(&A, 0, sizeof(A));
     A.E = E; A.n = n; A.P = P; A.L = m->loci_length; A.mu = m->mutation_rate; A.rho = m->recombination_rate; A.mcap = PF_MMAX;
+    // every exit path frees what was allocated so far
+    struct Bufs { std::vector<void*> v; ~Bufs() { for (void* q : v) hipFree(q); } } bufs;
+    auto dmalloc = [&](auto** q, size_t bytes) { void* r = nullptr; hipError_t e = hipMalloc(&r, bytes); if (e == hipSuccess) bufs.v.push_back(r); *q = (std::remove_reference_t<decltype(**q)>*)r; return e; };
     double *dT, *dI, *dHc, *dpos; int* dRF; unsigned* dmask; long long* dn;
-    HIPCHK(hipMalloc(&dT, E * 8)); HIPCHK(hipMalloc(&dI, E * 8)); HIPCHK(hipMalloc(&dHc, E * 8)); HIPCHK(hipMalloc(&dRF, E * 4));
-    HIPCHK(hipMalloc(&dpos, (size_t)nchunks * max_sites * 8)); HIPCHK(hipMalloc(&dmask, (size_t)nchunks * max_sites * 4));
-    HIPCHK(hipMalloc(&dn, (size_t)nchunks * 8));
+    HIPCHK(dmalloc(&dT, E * 8)); HIPCHK(dmalloc(&dI, E * 8)); HIPCHK(dmalloc(&dHc, E * 8)); HIPCHK(dmalloc(&dRF, E * 4));
+    HIPCHK(dmalloc(&dpos, (size_t)nchunks * max_sites * 8)); HIPCHK(dmalloc(&dmask, (size_t)nchunks * max_sites * 4));
+    HIPCHK(dmalloc(&dn, (size_t)nchunks * 8));
     std::vector<double> inv2N(E);
     for (int e = 0; e < E; ++e) inv2N[e] = 1.0 / (2.0 * m->pop_sizes[(size_t)e * P]);
     std::vector<int> rf(E, 3);
@@ -4686,8 +4689,10 @@ int pf_simulate_sites(const pf_model* m, uint64_t seed, int32_t nchunks, int64_t
     if (P > 1) {
         // structured model: the LDS-tree walk of pf_mp.h, one lane per chunk
         MpTables tb;
-        if (build_mp_tables(m, tb) || upload_mp_tables(tb, A, mp_allocs)) return -1;
-        HIPCHK(hipMalloc(&derr, 4));
+        const int up = build_mp_tables(m, tb) || upload_mp_tables(tb, A, mp_allocs);
+        for (void* q : mp_allocs) bufs.v.push_back(q);
+        if (up) return -1;
+        HIPCHK(dmalloc(&derr, 4));
         HIPCHK(hipMemset(derr, 0, 4));
         const size_t smem = pf_mp_smem_bytes(n, E, P, PF_MMAX);
         if (pf_mp_prepare(smem, PF_MMAX)) { g_err = "pf_simulate_sites: the local-tree state does not fit the LDS"; return -1; }
@@ -4715,8 +4720,5 @@ int pf_simulate_sites(const pf_model* m, uint64_t seed, int32_t nchunks, int64_t
             HIPCHK(hipMemcpy(masks + (size_t)c * max_sites, dmask + (size_t)c * max_sites, (size_t)k * 4, hipMemcpyDeviceToHost));
         }
     }
-    for (void* q : mp_allocs) hipFree(q);
-    if (derr) hipFree(derr);
-    hipFree(dT); hipFree(dI); hipFree(dHc); hipFree(dRF); hipFree(dpos); hipFree(dmask); hipFree(dn);
     return rc;
 }

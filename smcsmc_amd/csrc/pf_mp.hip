@@ -471,8 +471,38 @@ __device__ __forceinline__ void extend_mpr_body(const KA& A, long long s, int fu
         sBH[threadIdx.x] = A.bias_H[threadIdx.x];
         if (threadIdx.x < PF_BIAS_MAX + 1) sBS[threadIdx.x] = A.bias_S[threadIdx.x];
     }
-    __syncthreads();
     const Ctrl* c = A.ctrl;
+    // PIPE: what the decision on the previous row reads is requested before the barrier below waits for the tables, so that
+    // the two round trips to memory overlap
+    RowPre pre_row;
+    long long pre_nres = 0; int pre_gen = 0;
+    // ... and so is what the parent search of a resampling row reads: the pilot scan of the workgroup's own slot and of the
+    // wavefronts around it (offspring stay close to their parents' slots; a range outside is staged the old way)
+    double pre_sm = 0.0, spec_sm[PF_PIPE_STAGE * 64 / BS];
+    int spec_lo = 0;
+    if constexpr (PIPE) {
+        if (PR.complete != 0) {
+            const int fs0 = __builtin_amdgcn_readfirstlane(PR.slot_prev >= 0 ? PR.slot_prev : c->cur);
+            pre_row = row_preload<BS>(A, fs0);
+            const double* sm0 = A.rg_scan1m + (size_t)fs0 * A.Np;
+            spec_lo = (int)blockIdx.x - (PF_PIPE_STAGE - 1) / 2;
+            if (spec_lo > A.nc - PF_PIPE_STAGE) spec_lo = A.nc - PF_PIPE_STAGE;
+            if (spec_lo < 0) spec_lo = 0;
+#pragma unroll
+            for (int k = 0; k < PF_PIPE_STAGE * 64 / BS; ++k) {
+                const long long src = (long long)spec_lo * 64 + k * BS + threadIdx.x;
+                spec_sm[k] = src < A.Np ? sm0[src] : PF_INF;
+            }
+            {
+                const long long qp0 = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+                if (threadIdx.x < 64 && qp0 < A.Np) pre_sm = sm0[qp0];
+            }
+            pre_nres = c->xr[(fs0 + PF_RING - 1) & (PF_RING - 1)].n_res + c->xr[(fs0 + PF_RING - 1) & (PF_RING - 1)].flag;
+            pre_gen = c->xr[(fs0 + PF_RING - 1) & (PF_RING - 1)].gen + c->xr[(fs0 + PF_RING - 1) & (PF_RING - 1)].flag;
+        }
+    }
+    __syncthreads();
+    MP_TICK(tk_tables);
     const int n = A.n;
     const int lane = threadIdx.x & 63;
     const int cslot = (int)(threadIdx.x >> 6) * LA + lane;             // place of this lane's particle in the workgroup's 64
@@ -487,6 +517,7 @@ __device__ __forceinline__ void extend_mpr_body(const KA& A, long long s, int fu
     long long a_par = p;
     int lo_p = 0, lo_p1 = 0;
     bool first_copy = true;
+    unsigned long long tk_decided = 0;
     if constexpr (PIPE) {
         __shared__ long long sPar[64];
         __shared__ int sLoP[64], sLoP1[64], sFirst[64], sRange[2];
@@ -501,13 +532,14 @@ __device__ __forceinline__ void extend_mpr_body(const KA& A, long long s, int fu
         pos_prev = PR.pos_prev;
         if (completing) {
             const int row_slot = fs;
-            RowPre pre = row_preload(A, row_slot);
+            const RowPre pre = pre_row;
             // the row before it: what the extend role of the previous launch noted (the bookkeeping role runs on another
             // stream here and is not waited for)
-            const long long n_res = c->xr[(fs + PF_RING - 1) & (PF_RING - 1)].n_res + c->xr[(fs + PF_RING - 1) & (PF_RING - 1)].flag;
-            G_end = c->xr[(fs + PF_RING - 1) & (PF_RING - 1)].gen + c->xr[(fs + PF_RING - 1) & (PF_RING - 1)].flag;
+            const long long n_res = pre_nres;
+            G_end = pre_gen;
             ev_idx = (int)n_res;
             RowDecision d = decide_row<true, BS>(A, q, row_slot, n_res, pre);
+            tk_decided = wall_clock64();
             inv_prev = d.inv; S1_prev = d.S1;
             gather = d.flag != 0;
             if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -525,7 +557,7 @@ __device__ __forceinline__ void extend_mpr_body(const KA& A, long long s, int fu
                 int pch = 0, lo_next = 0;
                 if (threadIdx.x < 64) {
                     if (qa) {
-                        const double w = pipe_chunk_offset(q, ch_own) + sm[qp];
+                        const double w = pipe_chunk_offset(q, ch_own) + pre_sm;
                         const double v_own = q.pmx[ch_own] > w ? q.pmx[ch_own] : w;      // largest pilot prefix sum up to slot qp
                         lo_next = qp + 1 < A.Np ? pipe_lo_from(v_own, dn, A.Np, d.S1, invS1, d.u) : (int)A.Np;
                         int lo_c = 0, hi_c = A.nc - 1;
@@ -544,13 +576,20 @@ __device__ __forceinline__ void extend_mpr_body(const KA& A, long long s, int fu
                     if (lane == 0) { sRange[0] = cmin; sRange[1] = cmax; }
                 }
                 __syncthreads();
-                const int cmin = sRange[0], cmax = sRange[1];
+                int cmin = sRange[0];
+                const int cmax = sRange[1];
                 int nst = cmax - cmin + 1;
                 if (nst > PF_PIPE_STAGE) nst = PF_PIPE_STAGE;
                 if (nst < 0) nst = 0;
-                for (int idx = threadIdx.x; idx < nst * 64; idx += BS) {
-                    const long long src = (long long)cmin * 64 + idx;
-                    q.stage[idx] = src < A.Np ? sm[src] : PF_INF;
+                if (cmin >= spec_lo && cmax < spec_lo + PF_PIPE_STAGE) {
+                    cmin = spec_lo; nst = PF_PIPE_STAGE;           // the scans requested with the prologue cover the range
+#pragma unroll
+                    for (int k = 0; k < PF_PIPE_STAGE * 64 / BS; ++k) q.stage[k * BS + threadIdx.x] = spec_sm[k];
+                } else {
+                    for (int idx = threadIdx.x; idx < nst * 64; idx += BS) {
+                        const long long src = (long long)cmin * 64 + idx;
+                        q.stage[idx] = src < A.Np ? sm[src] : PF_INF;
+                    }
                 }
                 __syncthreads();
                 if (threadIdx.x < 64) {
@@ -607,6 +646,7 @@ __device__ __forceinline__ void extend_mpr_body(const KA& A, long long s, int fu
         from_slot = gather ? (cur ^ 1) : cur;
     }
     double w_post = 0.0, w_pilot = 0.0;
+    MP_TICK(tk_searched);
 #ifdef PF_STAMPS
     if (threadIdx.x < PF_STAMP_W) g_mp_acc[threadIdx.x] = 0;
     __syncthreads();
@@ -636,10 +676,33 @@ __device__ __forceinline__ void extend_mpr_body(const KA& A, long long s, int fu
                 ml.pn |= (unsigned)from.Pn[(size_t)r * A.Np + a] << (2 * r);
             }
         }
-        ml.nm = from.nm[a];
-        // eight events at a time, their loads issued before the first LDS store: a load-then-store loop pays one memory
-        // round trip per event (about a microsecond each, and a tree carries ten)
-        for (int q0 = 0; q0 < ml.nm; q0 += 8) {
+        // Everything of the particle that does not depend on anything else is requested in ONE round: the tree above, the
+        // number of migration events, the first eight events whatever that number is (the arrays hold mcap >= 8 entries; what
+        // lies beyond the count is ignored), and the scalars of the state.  Loads placed behind the LDS stores of the event
+        // lists cannot be moved above them by the compiler: each group was a memory round trip of its own.
+        const int nm_ld = from.nm[a];
+        constexpr int FB = 12;                       // events of the first round (a tree carries ten on average)
+        double tv0[FB];
+        int8_t bv0[FB], qv0[FB];
+#pragma unroll
+        for (int j = 0; j < FB; ++j) {
+            const int q = j < A.mcap ? j : A.mcap - 1;
+            tv0[j] = from.Mt[(size_t)q * A.Np + a];
+            bv0[j] = from.Mb[(size_t)q * A.Np + a];
+            qv0[j] = from.Mq[(size_t)q * A.Np + a];
+        }
+        const double ld_wpost = from.w_post[a], ld_wpilot = from.w_pilot[a], ld_next = from.next_base[a], ld_xmark = from.x_mark[a];
+        const int ld_ml = from.mark_limit[a];
+        const double ld_Ltree = from.Ltree[a], ld_ebuf = A.ebuf[p];
+        const unsigned long long ld_ctr = A.rng_ctr[p];
+        const unsigned ld_widx = (PIPE && completing) ? A.rg_widx[(size_t)from_slot * A.Np + p] : A.widx[p];
+        const unsigned ld_pidx = A.pidx[p];
+        ml.nm = nm_ld;
+#pragma unroll
+        for (int j = 0; j < FB; ++j)
+            if (j < ml.nm) { LMt(ml, j) = tv0[j]; LMb(ml, j) = bv0[j]; LMq(ml, j) = qv0[j]; }
+        // the rest eight at a time, their loads issued before the first LDS store
+        for (int q0 = FB; q0 < ml.nm; q0 += 8) {
             double tv[8];
             int8_t bv[8], qv[8];
 #pragma unroll
@@ -653,6 +716,7 @@ __device__ __forceinline__ void extend_mpr_body(const KA& A, long long s, int fu
             for (int j = 0; j < 8; ++j)
                 if (q0 + j < ml.nm) { LMt(ml, q0 + j) = tv[j]; LMb(ml, q0 + j) = bv[j]; LMq(ml, q0 + j) = qv[j]; }
         }
+        MP_TICK(tk_lists);
         RCtx cx;
         cx.T = mm.T; cx.I = nullptr; cx.H = nullptr; cx.E = A.E; cx.n = n; cx.L = A.L; cx.mu = A.mu; cx.rho = A.rho;
         cx.seed = A.seed; cx.slot = (unsigned)p; cx.stream = 0; cx.u_nb = 0.0;
@@ -675,15 +739,15 @@ __device__ __forceinline__ void extend_mpr_body(const KA& A, long long s, int fu
                     st.dk[(size_t)k * A.Np + p] = from.dk[(size_t)k * A.Np + a];
                 }
         }
-        w_post = from.w_post[a];
-        w_pilot = from.w_pilot[a];
-        double next_base = from.next_base[a];
-        double x_mark = from.x_mark[a];
-        int mark_limit = from.mark_limit[a];
-        cx.Ltree = from.Ltree[a];
-        cx.ctr = A.rng_ctr[p];
-        cx.ebuf = A.ebuf[p];
-        unsigned widx = (PIPE && completing) ? A.rg_widx[(size_t)from_slot * A.Np + p] : A.widx[p];
+        w_post = ld_wpost;
+        w_pilot = ld_wpilot;
+        double next_base = ld_next;
+        double x_mark = ld_xmark;
+        int mark_limit = ld_ml;
+        cx.Ltree = ld_Ltree;
+        cx.ctr = ld_ctr;
+        cx.ebuf = ld_ebuf;
+        unsigned widx = ld_widx;
         if (completing) {
             const double inv = PIPE ? inv_prev : c->inv_T;
             if (!gather) {
@@ -718,7 +782,7 @@ __device__ __forceinline__ void extend_mpr_body(const KA& A, long long s, int fu
             }
         }
         PLog pl;
-        pl.base = A.plog + (size_t)p * A.pcap * 3; pl.cap = A.pcap; pl.idx = A.pidx[p]; pl.pos = pl.idx % pl.cap; pl.on = true;
+        pl.base = A.plog + (size_t)p * A.pcap * 3; pl.cap = A.pcap; pl.idx = ld_pidx; pl.pos = pl.idx % pl.cap; pl.on = true;
         pl.fopen = false; pl.ropen = false;
 
         const bool do_extend = !PIPE || PR.extend != 0;        // the flush step of a call only completes the last row
@@ -749,6 +813,10 @@ __device__ __forceinline__ void extend_mpr_body(const KA& A, long long s, int fu
 
         MP_TICK(tk_loaded);
         MP_ACC(ml, 0, tk_begin, tk_loaded);
+        MP_ACC(ml, 21, tk_begin, tk_tables);
+        if (PIPE && tk_decided) { MP_ACC(ml, 22, tk_tables, tk_decided); MP_ACC(ml, 23, tk_decided, tk_searched); }
+        MP_ACC(ml, 24, tk_searched, tk_lists);
+        MP_ACC(ml, 25, tk_lists, tk_loaded);
         while (updated_to < extend_to) {
             MP_ACC(ml, 14, 0, 1);
             MP_TICK(tu0);

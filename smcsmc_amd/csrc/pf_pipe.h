@@ -56,18 +56,31 @@ __device__ __forceinline__ double pipe_chunk_offset(const PipeLds& q, int ch) {
 // table / parent search need (only computed when the row resamples)
 // the partials a thread needs first, requested before anything else so that their memory round trip overlaps the
 // particle's own loads (what the previous launch wrote comes from another XCD's L2: about a microsecond)
-struct RowPre { double vp = 0.0, vs = 0.0, vl = 0.0, vm = 0.0, last1 = 0.0; bool have = false; };
-template <class KA>
+// (the second set: a workgroup of BS threads reduces up to 2 BS wavefront partials -- the structured models' 64-particle
+// workgroups at Np = 20 000 have 313 for 256 threads -- and the second pass of a thread would otherwise start with a
+// round trip of its own; vm / vm2 are the two consecutive entries a thread of the prefix-maxima pass owns then)
+struct RowPre { double vp = 0.0, vs = 0.0, vl = 0.0, vm = 0.0, last1 = 0.0, vp2 = 0.0, vs2 = 0.0, vl2 = 0.0, vm2 = 0.0; bool have = false; };
+template <int BS = PF_PIPE_BS, class KA>
 __device__ __forceinline__ RowPre row_preload(const KA& A, int slot) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nc = A.nc, ch = wave * 64 + lane;
+    const int nc = A.nc, ch = threadIdx.x;
+    const int perc = (nc + BS - 1) / BS;
     RowPre r;
     r.have = true;
     if (ch < nc) {
         r.vp = A.rg_cpost[(size_t)slot * nc + ch];
         r.vs = A.rg_csq[(size_t)slot * nc + ch];
         r.vl = A.rg_cpil[(size_t)slot * nc + ch];
-        r.vm = A.rg_cmx1[(size_t)slot * nc + ch];       // only a resampling row uses it (the prefix maxima), but then a round trip earlier
+    }
+    if (ch + BS < nc) {
+        r.vp2 = A.rg_cpost[(size_t)slot * nc + ch + BS];
+        r.vs2 = A.rg_csq[(size_t)slot * nc + ch + BS];
+        r.vl2 = A.rg_cpil[(size_t)slot * nc + ch + BS];
+    }
+    // only a resampling row uses them (the prefix maxima), but then a round trip earlier
+    if (perc == 1) { if (ch < nc) r.vm = A.rg_cmx1[(size_t)slot * nc + ch]; }
+    else if (perc == 2) {
+        if (2 * ch < nc) r.vm = A.rg_cmx1[(size_t)slot * nc + 2 * ch];
+        if (2 * ch + 1 < nc) r.vm2 = A.rg_cmx1[(size_t)slot * nc + 2 * ch + 1];
     }
     r.last1 = A.ctrl->last1[slot];
     return r;
@@ -84,10 +97,10 @@ __device__ __forceinline__ RowDecision decide_row(const KA& A, const PipeLds& q,
     const double last_scan1 = pre.have ? pre.last1 : A.ctrl->last1[slot];
     for (int g = wave; g < ng; g += nwaves) {
         int ch = g * 64 + lane;
-        const bool first = pre.have && g == wave;
-        double vp = first ? pre.vp : (ch < nc ? cpost[ch] : 0.0);
-        double vs = first ? pre.vs : (ch < nc ? csq[ch] : 0.0);
-        double vl = first ? pre.vl : (ch < nc ? cpil[ch] : 0.0);
+        const bool first = pre.have && g == wave, second = pre.have && g == wave + nwaves;
+        double vp = first ? pre.vp : (second ? pre.vp2 : (ch < nc ? cpost[ch] : 0.0));
+        double vs = first ? pre.vs : (second ? pre.vs2 : (ch < nc ? csq[ch] : 0.0));
+        double vl = first ? pre.vl : (second ? pre.vl2 : (ch < nc ? cpil[ch] : 0.0));
         double rp = wave_tree_sum(vp);
         double rs = wave_tree_sum(vs);
         double sc = wave_hs_scan(vl, lane);
@@ -114,9 +127,9 @@ __device__ __forceinline__ RowDecision decide_row(const KA& A, const PipeLds& q,
         const int c0 = tid * perc, c1 = c0 + perc < nc ? c0 + perc : nc;
         double run = 0.0;
         // one wavefront per thread (nc <= BS): thread tid's entry is the one row_preload asked for
-        const bool pre_mx = pre.have && perc == 1;
-        const double pre_vm = pre.vm;
-        for (int ch = c0; ch < c1; ++ch) { double vch = pipe_chunk_offset(q, ch) + (pre_mx ? pre_vm : cmx1[ch]); run = vch > run ? vch : run; }
+        const bool pre_mx = pre.have && perc <= 2;
+        const double pre_vm = pre.vm, pre_vm2 = pre.vm2;
+        for (int ch = c0; ch < c1; ++ch) { double vch = pipe_chunk_offset(q, ch) + (pre_mx ? (ch == c0 ? pre_vm : pre_vm2) : cmx1[ch]); run = vch > run ? vch : run; }
         double scd = wave_max_scan_d(run, lane);
         if (lane == 63) q.wredd[wave] = scd;
         __syncthreads();
@@ -127,7 +140,7 @@ __device__ __forceinline__ RowDecision decide_row(const KA& A, const PipeLds& q,
         run = pre;
         for (int ch = c0; ch < c1; ++ch) {
             q.pmx[ch] = run;
-            double vch = pipe_chunk_offset(q, ch) + (pre_mx ? pre_vm : cmx1[ch]);
+            double vch = pipe_chunk_offset(q, ch) + (pre_mx ? (ch == c0 ? pre_vm : pre_vm2) : cmx1[ch]);
             run = vch > run ? vch : run;
         }
         if (c1 == nc && c0 < c1) q.pmx[nc] = run;
