@@ -227,6 +227,10 @@ int pf_set_timing(pf_handle* h, int enable);
 /* profiling builds of the library (-DPF_STAMPS) only: out == NULL enables wall-clock stamps (100 MHz ticks) of the phases of
  * the extend workgroups for the first `rows` rows; out != NULL copies them back as [rows][wavefronts][16] */
 int pf_debug_stamps(pf_handle* h, int64_t rows, uint64_t* out);
+/* testing (host only, no device needed): the bucket table the row kernels search an ascending table with (r_search_lut: key =
+ * upper sixteen bits of the double minus *kbase, clamped to 0..255; answer = lut[key] plus one for each of the next two entries
+ * that is <= t).  Returns 1 and fills lut[256] / *kbase when the table qualifies, 0 when the kernels keep the four-way search. */
+int pf_test_search_lut(const double* tab, int32_t n, uint8_t* lut, int32_t* kbase);
 /* bookkeeping for the roofline: records appended to the event log, bytes of particle state */
 int pf_get_stats(pf_handle* h, int64_t* n_records, int64_t* state_bytes_per_particle, int64_t* n_resamples);
 

@@ -4298,6 +4298,13 @@ int pf_set_timing(pf_handle* h, int period) {
 
 // profiling builds (-DPF_STAMPS): wall-clock stamps (100 MHz) of the phases of the extend workgroups, one set per row and
 // wavefront; a regular build records nothing
+int pf_test_search_lut(const double* tab, int32_t n, uint8_t* lut, int32_t* kbase) {
+    int kb = 0;
+    if (n < 1 || n > PF_EMAX || !lut_build(tab, n, lut, &kb)) return 0;
+    *kbase = kb;
+    return 1;
+}
+
 int pf_debug_stamps(pf_handle* h, int64_t rows, uint64_t* out) {
     HIPCHK(hipSetDevice(h->device));
     if (rows > 0 && !out) {

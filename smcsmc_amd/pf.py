@@ -94,7 +94,7 @@ EXPORTS = [
     "pf_terminal_branch_quantiles",
     "pf_update_segment", "pf_count", "pf_resample", "pf_run", "pf_run_many", "pf_finish", "pf_sync",
     "pf_num_segments_done", "pf_logl", "pf_get_counts", "pf_get_trace", "pf_get_resample_events",
-    "pf_get_particles", "pf_get_migrations", "pf_get_local_recomb", "pf_sample_tree_events", "pf_sample_tree_events_pops", "pf_get_kernel_time", "pf_set_timing", "pf_get_stats", "pf_debug_stamps", "pf_simulate_sites",
+    "pf_get_particles", "pf_get_migrations", "pf_get_local_recomb", "pf_sample_tree_events", "pf_sample_tree_events_pops", "pf_get_kernel_time", "pf_set_timing", "pf_get_stats", "pf_debug_stamps", "pf_test_search_lut", "pf_simulate_sites",
     "pf_median_survival", "pf_test_math", "pf_test_div", "pf_test_uniform", "pf_test_reduce", "pf_test_systematic",
 ]
 
