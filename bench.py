@@ -231,7 +231,7 @@ def main():
                     help="independent chunks filtered concurrently on each GPU, all in one launch per row (pf_run_many); "
                          "1 = the headline single-chunk configuration")
     ap.add_argument("--count-wgs", type=int, default=0, help="pf_params.count_wgs: count workgroups per epoch in the row pipeline (0 = default: one per "
-                    "particle block; 24 with six or more chunks per GPU in one launch, where the chip holds a third of the count workgroups at a time)")
+                    "particle block; 24 with six or more chunks per GPU, where the chip holds a fraction of the count workgroups at a time)")
     ap.add_argument("--chunk-threads", action="store_true",
                     help="with --chunks-per-gpu: one host thread and stream per chunk (rounds 1 and 2) instead of pf_run_many")
     args = ap.parse_args()
@@ -265,7 +265,7 @@ def main():
         model, segs = build_workload(args, seed=args.seed + rank * C + k)     # independent chunks
         f = ParticleFilter(model, args.np, ess_fraction=0.5, seed=args.seed + 1000 * (rank * C + k), max_trace_events=0,
                            device=dev, local_recomb=not args.no_local_recomb, debug=args.debug,
-                           count_wgs=args.count_wgs or (24 if (args.chunks_per_gpu >= 6 and not args.chunk_threads) else 0))
+                           count_wgs=args.count_wgs or (24 if args.chunks_per_gpu >= 6 else 0))
         f.load_segments(segs)
         chunks.append((f, segs))
     pf, segs = chunks[0]
@@ -373,7 +373,7 @@ def main():
                        "populations": args.pops, "local_recombination_map": not args.no_local_recomb,
                        "segments_per_chunk": n_segments, "nsam": args.nsam, "np": args.np,
                        "sequence_length": args.length, "epochs": args.epochs,
-                       "count_workgroups_per_epoch": args.count_wgs or (24 if (args.chunks_per_gpu >= 6 and not args.chunk_threads) else "one per particle block"),
+                       "count_workgroups_per_epoch": args.count_wgs or (24 if args.chunks_per_gpu >= 6 else "one per particle block"),
                        "parallelism": "%d chunk(s) per gpu%s x %d gpu(s)" % (C, (", one launch per row for all of them" if many else ", one host thread and stream each") if C > 1 else "", world), "log_likelihood_sum": logl_sum},
             "roofline": {"bound": "hbm", "kernel": ("k_pipe" if args.debug & 16 else "k_sweep") + " (one launch per row: extend workgroups; bookkeeping, ledger and counts ride along)" if args.pops == 1 and args.nsam <= 8 and not (args.debug & 8) else ("k_row" if args.pops == 1 and args.nsam <= 8 else (("k_sweep_xmp (extend role of the row pipeline; bookkeeping, ledger and counts as k_sweep_blc on a second stream)" if not (args.debug & 16) else "k_extend_mpr (register tree, completes the previous row while loading)") if args.nsam <= 8 and not (args.debug & 3) else "k_extend_mp") if args.pops > 1 else "k_extend"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
