@@ -598,7 +598,9 @@ __device__ __forceinline__ void r_genealogy_update(RCtx& cx, RTree<NM>& t, doubl
     else r_lineages_at(t, n, n - 1, h, lin, &rp, &sb);
     *h_out = h;
     unsigned tmask[RTree<NM>::NI + NM];          // -arg only: samples below every node id of the tree before the cut
-    if (cx.want_desc) {
+    if (TAB || cx.want_desc) {
+        // (on the rows of k_sweep always: a dozen selects that the scheduler can place beside the search that follows, where
+        //  a branch on the flag made them a block of their own in the chain; the local map is on by default)
         // get_descendants (descendants.hpp:22-33) of the cut branch on the tree before it changes: masks bottom-up
         unsigned below[RTree<NM>::NI];
         unsigned cut = 0;
