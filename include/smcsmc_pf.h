@@ -79,7 +79,9 @@ typedef struct pf_params {
     uint64_t seed;               /* -seed */
     int32_t max_trace_events;    /* resampling events whose ancestor arrays are retained for inspection */
     int32_t flags;               /* bit0: record the 100-bp local recombination map (count.cpp:559-654);
-                                  * bit1: -arg, keep what pf_sample_tree_events needs */
+                                  * bit1: -arg, keep what pf_sample_tree_events needs;
+                                  * bit2: a full delayed-factor store applies its earliest factor early instead of stopping the run
+                                  *       (see delay_cap) */
     /* Capacities of the device-side rings that stand in for the reference's Arena of EvolutionaryEvents
      * (arena.cpp:56-111, unbounded there).  0 = default.  A ring that is too small for the lags in force is a
      * reported error (pf_sync returns -2, "event log ring overflow" / "generation ledger overflow"), never a
@@ -95,7 +97,11 @@ typedef struct pf_params {
     int32_t count_wgs;           /* row pipeline: workgroups per epoch that share the lagged counting of a row (0 = one
                                   * per 256 particles, which is also the most).  The sums are grouped by workgroup, so the value is part
                                   * of what makes two runs bit-identical. */
-    int32_t reserved3;
+    int32_t delay_cap;           /* focused sampling / guide: delayed importance factors a particle may have pending (0 = 128).  The
+                                  * reference keeps them in an unbounded heap (particle.hpp:59-101, 248); here the store is a column of
+                                  * delay_cap entries per particle in device memory.  One factor too many is a reported error
+                                  * ("delayed-factor store overflow"), unless flags bit2 is set: then the earliest pending factor is
+                                  * applied ahead of its position to make room, and pf_get_delay_stats says how often that happened. */
 } pf_params;
 #define PF_DEBUG_FORCE_LDS 1     /* run the LDS-tree kernels whatever nsam is */
 #define PF_DEBUG_NO_FUSE   2     /* complete every row with the stand-alone k_resample (two-stream pipeline) */
@@ -231,6 +237,9 @@ int pf_debug_stamps(pf_handle* h, int64_t rows, uint64_t* out);
  * upper sixteen bits of the double minus *kbase, clamped to 0..255; answer = lut[key] plus one for each of the next two entries
  * that is <= t).  Returns 1 and fills lut[256] / *kbase when the table qualifies, 0 when the kernels keep the four-way search. */
 int pf_test_search_lut(const double* tab, int32_t n, uint8_t* lut, int32_t* kbase);
+/* the delayed-factor store (adjustWeightsWithDelay, particle.hpp:185-209): factors applied ahead of their position because the
+ * store was full (only with pf_params.flags bit2; otherwise that is an error) and the most factors any particle ever had pending */
+int pf_get_delay_stats(pf_handle* h, int64_t* n_forced, int32_t* peak_pending);
 /* bookkeeping for the roofline: records appended to the event log, bytes of particle state */
 int pf_get_stats(pf_handle* h, int64_t* n_records, int64_t* state_bytes_per_particle, int64_t* n_resamples);
 

@@ -57,7 +57,9 @@ static thread_local std::string g_err;
 enum { NMAX = 16 };
 enum { MMAX = 256 };  /* storage for migration events per local tree (multi-population models); the limit in force is
                        * Filter::mig_cap (smco_params.mig_cap, default 96, as pf_params.mig_cap of the device path) */
-enum { DCAP = 32 };   /* capacity of the per-particle delayed-factor store (the reference's heap is unbounded) */
+enum { DCAP_DEFAULT = 128 };   /* default capacity of the per-particle delayed-factor store: the capacity of the device path
+                               * (pf_params.delay_cap).  The reference's heap is unbounded (particle.hpp:248); a full store is a
+                               * reported error unless smco_params.delay_evict asks for the oldest factor to be applied early */
 enum { REC_RECOMB = 1, REC_COALMIGR = 2 };
 
 /* ------------------------------------------------------------------ canonical reductions */
@@ -262,9 +264,9 @@ struct Particle {
     double lookahead = 1.0;                  /* lookahead_weight_ (particle.hpp:239) */
     int ridx = 0;                            /* _current_seq_idx: guide segment the particle is in (particle.hpp:177-178) */
     double total_delayed = 1.0;              /* total_delayed_adjustment_ */
-    int dcount = 0;                          /* pending DelayedFactors (particle.hpp:248) */
-    double dpos[DCAP], dfac[DCAP], ddelta[DCAP];
-    int dk[DCAP];
+    int dcount = 0;                          /* pending DelayedFactors (particle.hpp:248: a std::priority_queue) */
+    std::vector<double> dpos, dfac, ddelta;
+    std::vector<int> dk;
     std::vector<Ev*> head;  /* eventTrees[epoch] (particle.hpp:235) */
     std::vector<Ev*> open;  /* the open rectangles of the current stretch (heads of their chains) */
 };
@@ -320,6 +322,10 @@ struct Filter {
     double last_iw = 1.0, last_tc = 0.0, last_first_event = 0.0;
     bool record_trees = false;      /* -arg (pfparam.cpp:353-357) */
     int mig_cap = 96;               /* migration events a local tree may hold (capacity of the device path) */
+    int delay_cap = DCAP_DEFAULT;   /* pending delayed factors a particle may hold (capacity of the device path) */
+    bool delay_evict = false;
+    int64_t n_delay_evict = 0;      /* factors applied ahead of their position to make room (delay_evict only) */
+    int delay_peak = 0;             /* most factors any particle ever had pending */
     void push_tree_event(Particle& p, int kind, double x, double t, uint32_t desc, int from_pop = -1, int to_pop = -1) {
         auto ev = std::make_shared<TreeEv>();
         ev->kind = kind; ev->x = x; ev->t = t; ev->desc = desc; ev->parent = p.tree_head;
@@ -1501,15 +1507,23 @@ struct Filter {
             p.w_pilot *= adj;
             return;
         }
-        while (p.dcount == DCAP) apply_earliest(p);     /* bounded store: make room (the reference's heap is unbounded) */
+        /* the store of the device path is bounded (delay_cap entries per particle): a full store stops the run, as every
+         * other bounded ring does -- or, with delay_evict, the earliest pending factor is applied ahead of its position to
+         * make room, and the event is counted */
+        if (p.dcount == delay_cap) {
+            if (!delay_evict) throw std::runtime_error("delayed-factor store overflow");
+            while (p.dcount == delay_cap) { apply_earliest(p); ++n_delay_evict; }
+        }
         p.total_delayed *= adj;
         double final_pos = cur + delay;
         double delta = (final_pos - cur) / 7.0;
         int i = p.dcount++;
+        if ((int)p.dpos.size() <= i) { p.dpos.resize(i + 1); p.dfac.resize(i + 1); p.ddelta.resize(i + 1); p.dk.resize(i + 1); }
         p.dpos[i] = cur + delta;
         p.dfac[i] = smc_exp(smc_log(adj) * (1.0 / 3));   /* pow(factor, 1.0/k), libm-free */
         p.ddelta[i] = delta;
         p.dk[i] = 3;
+        if (p.dcount > delay_peak) delay_peak = p.dcount;
     }
     /* applyDelayedAdjustment (particle.hpp:199-209); the entry with the smallest position (ties: lowest index) */
     void apply_earliest(Particle& p) {
@@ -1778,7 +1792,8 @@ struct Filter {
                 d.next_base = src.next_base; d.Ltree = src.Ltree;
                 d.lookahead = src.lookahead; d.ridx = src.ridx;
                 d.total_delayed = src.total_delayed; d.dcount = src.dcount;
-                for (int k = 0; k < src.dcount; ++k) { d.dpos[k] = src.dpos[k]; d.dfac[k] = src.dfac[k]; d.ddelta[k] = src.ddelta[k]; d.dk[k] = src.dk[k]; }
+                d.dpos.assign(src.dpos.begin(), src.dpos.begin() + src.dcount); d.dfac.assign(src.dfac.begin(), src.dfac.begin() + src.dcount);
+                d.ddelta.assign(src.ddelta.begin(), src.ddelta.begin() + src.dcount); d.dk.assign(src.dk.begin(), src.dk.begin() + src.dcount);
                 d.tree_head = src.tree_head;             /* the pseudo-epoch of tree events is copied with the others */
                 d.head = src.head;                       /* copyEventContainers: particle.cpp:139-148 */
                 for (Ev* h : d.head) if (h) ++h->refs;
@@ -1968,6 +1983,8 @@ void* smco_create(const smco_model* m, const smco_params* p) {
         fill_model(M, m);
         if (p->mig_cap > MMAX) throw std::runtime_error("oracle: mig_cap above the storage of the restatement");
         if (p->mig_cap > 0) f->mig_cap = p->mig_cap;
+        if (p->delay_cap > 0) f->delay_cap = p->delay_cap;
+        f->delay_evict = p->delay_evict != 0;
         M.recflags.assign(m->record_flags, m->record_flags + M.E);
         M.lags.assign(m->lags, m->lags + M.E);
         if (m->n_bias_heights > 0) {
@@ -2237,6 +2254,13 @@ int smco_get_stats(void* h, int64_t* n_recomb, int64_t* n_alloc, int64_t* n_resa
     if (n_recomb) *n_recomb = f->n_recomb;
     if (n_alloc) *n_alloc = f->pool.n_alloc;
     if (n_resamples) *n_resamples = f->n_resample;
+    return 0;
+}
+
+int smco_get_delay_stats(void* h, int64_t* n_forced, int32_t* peak_pending) {
+    Filter* f = (Filter*)h;
+    if (n_forced) *n_forced = f->n_delay_evict;
+    if (peak_pending) *peak_pending = f->delay_peak;
     return 0;
 }
 

@@ -70,6 +70,11 @@ typedef struct smco_params {
     int32_t max_trace_events;    /* number of resampling events whose ancestor arrays are kept */
     int32_t mig_cap;             /* migration events a local tree may hold before the run stops (0 = 96; at most 256):
                                   * the capacity of the device path, pf_params.mig_cap */
+    int32_t delay_cap;           /* pending delayed importance factors a particle may hold (0 = 128, the device path's default,
+                                  * pf_params.delay_cap).  The reference's heap is unbounded (particle.hpp:248); here a full store
+                                  * is a reported error ("delayed-factor store overflow") ... */
+    int32_t delay_evict;         /* ... unless this is non-zero: then the earliest pending factor is applied ahead of its
+                                  * position to make room, and smco_get_delay_stats counts how often */
 } smco_params;
 
 typedef struct smco_segments {
@@ -152,6 +157,9 @@ int smco_get_migrations(void* h, int32_t* n_events, double* times, int8_t* branc
 double smco_logl(void* h);
 /* work statistics for DESIGN.md / roofline bookkeeping */
 int smco_get_stats(void* h, int64_t* n_recombinations, int64_t* n_events_allocated, int64_t* n_resamples);
+
+/* delayed-factor store: factors applied early to make room (delay_evict), most factors any particle had pending */
+int smco_get_delay_stats(void* h, int64_t* n_forced, int32_t* peak_pending);
 
 /* calculate_median_survival_distances (smcsmc.cpp:169-263), batched like the HIP driver */
 int smco_median_survival(const smco_model* m, uint64_t seed, int32_t min_events, int64_t max_trees, double* median_out,

@@ -32,25 +32,35 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
-def build_lib(force=False):
+def _compile_units(out, extra_flags, force, tag):
+    """Each translation unit to its own object file (two hipcc processes side by side: the units take minutes), then one link.
+    An object is rebuilt when its unit or any header is newer."""
+    import concurrent.futures
     units = [os.path.join(CSRC, "pf_hip.hip"), os.path.join(CSRC, "pf_mp.hip")]
-    deps = [os.path.join(CSRC, f) for f in ("pf_device.h", "pf_types.h", "pf_lane.h", "pf_tree_reg.h", "pf_mp.h",
-                                            "pf_mp_host.h", "pf_mp_reg.h", "pf_pipe.h")]
+    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "smcsmc_pf.h"))
-    if force or _stale(LIB, units + deps):
-        cmd = [_hipcc()] + HIPCC_FLAGS + ["-shared", "-o", LIB] + units
-        subprocess.check_call(cmd)
-    return LIB
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs = [os.path.join(objdir, os.path.basename(u)[:-4] + tag + ".o") for u in units]
+    todo = [(u, o) for u, o in zip(units, objs) if force or _stale(o, [u] + deps)]
+    if todo:
+        def cc(uo):
+            subprocess.check_call([_hipcc()] + HIPCC_FLAGS + extra_flags + ["-c", uo[0], "-o", uo[1]])
+        with concurrent.futures.ThreadPoolExecutor(len(todo)) as ex:
+            list(ex.map(cc, todo))
+    if todo or force or _stale(out, objs):
+        subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
+def build_lib(force=False):
+    return _compile_units(LIB, [], force, "")
 
 
 def build_stamps_lib(force=False):
     """The profiling build of the library (-DPF_STAMPS: wall-clock stamps per wavefront, row and phase of the extend
     workgroups, read back through pf_debug_stamps).  Used by profiles/stamps.py and profiles/stamps_mp.py only."""
-    out = os.path.join(CSRC, "libsmcsmc_pf_stamps.so")
-    units = [os.path.join(CSRC, "pf_hip.hip"), os.path.join(CSRC, "pf_mp.hip")]
-    if force or _stale(out, units + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]):
-        subprocess.check_call([_hipcc()] + HIPCC_FLAGS + ["-DPF_STAMPS", "-shared", "-o", out] + units)
-    return out
+    return _compile_units(os.path.join(CSRC, "libsmcsmc_pf_stamps.so"), ["-DPF_STAMPS"], force, "_stamps")
 
 
 def build_all(force=False):

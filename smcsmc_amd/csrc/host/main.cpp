@@ -258,6 +258,8 @@ static void open_filter(ChunkFilter& F, PfParam& P, const HostModel& M0, int dev
     pp.max_trace_events = 0;
     pp.flags = 1;          // the local recombination map is always recorded (smcsmc.cpp:376-383)
     pp.mig_cap = P.mig_cap;
+    pp.delay_cap = P.delay_cap;
+    if (P.delay_evict) pp.flags |= 4;
     if (P.record_trees) {
         if (NP > 1 && M.nsam > 8) throw Unsupported("-arg with more than one population and more than 8 samples");
         pp.flags |= 2;     // -arg (pfparam.cpp:353-357)
@@ -336,6 +338,14 @@ static void close_filter(ChunkFilter& F, const HostModel& M0, const ChunkJob* jo
         pf_check(pf_get_counts(h, packed.data(), (int32_t)packed.size()));
         const double* tail = &packed[packed.size() - 4];
         clog << "Got to end of sequence; resampled " << (long long)tail[2] << " times" << endl;
+        {
+            // the reference's heap of delayed factors is unbounded (particle.hpp:248); the store here is not, so say how full it got
+            int64_t forced = 0; int32_t peak = 0;
+            pf_check(pf_get_delay_stats(h, &forced, &peak));
+            if (peak > 0)
+                clog << " Delayed importance factors: at most " << peak << " pending per particle; " << (long long)forced
+                     << " applied early to make room" << endl;
+        }
         clog << " Inference step completed." << endl;
         if (job && job->packed_out) {        // a chunk of a multi-chunk E-step: the statistics go to the reduction
             *job->packed_out = packed;

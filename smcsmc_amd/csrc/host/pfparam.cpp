@@ -301,6 +301,12 @@ const std::vector<DriverOption>& driver_options() {
         // not a reference flag: room for migration events on one local tree (the reference's node list is unbounded)
         {"-migcap", "INT", "Several populations", "Migration events one local tree may hold; about 230 fit the LDS with 32 epochs [ 96 ]",
          [](PfParam& p, const std::string& v) { p.mig_cap = convert<int>("-migcap", v); if (p.mig_cap < 1) throw OutOfRange("-migcap", v); }},
+        // not reference flags: room for pending delayed importance factors per particle (the reference's heap is unbounded,
+        // particle.hpp:248), and what happens when it runs out
+        {"-delaycap", "INT", "Inference tuning", "Delayed importance factors a particle may have pending; one too many stops the run [ 128 ]",
+         [](PfParam& p, const std::string& v) { p.delay_cap = convert<int>("-delaycap", v); if (p.delay_cap < 1) throw OutOfRange("-delaycap", v); }},
+        {"-delay_evict", "", "Inference tuning", "A full store of delayed factors applies its earliest factor early instead of stopping (counted in the log)",
+         [](PfParam& p, const std::string&) { p.delay_evict = true; }},
         // not a reference flag: keep recording events however far the next informative site is.  The surveyed reference stops
         // recording epoch e beyond half a lag from data (max_epoch_to_update, smcsmc.cpp:266-275), which on an all-missing
         // file leaves almost nothing to count; its no-data regression bands predate that rule

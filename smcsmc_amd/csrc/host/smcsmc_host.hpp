@@ -208,6 +208,8 @@ class PfParam {
     bool delay_all = false;                          // -delay_all: pf_model.delay_type bit 2
     bool record_all = false;                         // -record_all: no recording limit far from data
     int mig_cap = 0;                                 // -migcap: pf_params.mig_cap (0 = the library's default)
+    int delay_cap = 0;                               // -delaycap: pf_params.delay_cap (0 = the library's default)
+    bool delay_evict = false;                        // -delay_evict: pf_params.flags bit 2
     std::string reduce_transport;                    // "rccl" / "host" / "" = choose
     double segment_cap() const;                      // rows longer than this many bases are cut (pfparam.cpp:364)
     // ---- derived

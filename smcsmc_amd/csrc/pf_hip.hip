@@ -154,7 +154,7 @@ __global__ __launch_bounds__(PF_BS) void k_extend(KArgs A, long long s) {
         ln.ebuf = A.ebuf[p];
         unsigned widx = A.widx[p];
         DStore ds;
-        ds.pos = st.dpos + p; ds.fac = st.dfac + p; ds.delta = st.ddelta + p; ds.k = st.dk + p; ds.Np = A.Np;
+        d_bind(ds, A, st, p);
         ds.count = 0; ds.total = 1.0;
         if (biased) { ds.count = st.dcount[p]; ds.total = st.total_delayed[p]; }
         int ridx = guided ? st.ridx[p] : 0;
@@ -663,7 +663,7 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
         }
         DStore ds;
         if (BIASED) {
-            ds.pos = st.dpos + p; ds.fac = st.dfac + p; ds.delta = st.ddelta + p; ds.k = st.dk + p; ds.Np = A.Np;
+            d_bind(ds, A, st, p);
             ds.count = from.dcount[a]; ds.total = from.total_delayed[a];
             if (gather || PIPE)   // the copy constructor copies the pending factors (particle.cpp:122-123); the ring moves them every row
                 for (int k = 0; k < ds.count; ++k) {
@@ -3056,11 +3056,14 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
         if (lut_build(m->change_times, E, lut, &A.lut_kbT) && lut_build(Hc.data(), E, lut + PF_LUT_N, &A.lut_kbH)) {
             unsigned char* dl;
             rc |= dalloc(h, &dl, 2 * PF_LUT_N);
-            if (!rc) { hipMemcpy(dl, lut, sizeof(lut), hipMemcpyHostToDevice); A.lut = dl; }
+            // on the handle's stream, behind the memset of dalloc (a plain hipMemcpy is not ordered with a non-blocking stream)
+            if (!rc) { hipMemcpyAsync(dl, lut, sizeof(lut), hipMemcpyHostToDevice, h->stream); hipStreamSynchronize(h->stream); A.lut = dl; }
         }
     }
     A.n_bias = m->n_bias_heights;
     A.delay_type = m->delay_type;
+    A.dcap = p->delay_cap > 0 ? p->delay_cap : PF_DCAP_DEFAULT;
+    A.delay_evict = (p->flags & 4) ? 1 : 0;
     for (int k = 0; k < PF_BIAS_MAX + 2; ++k) A.bias_H[k] = HUGE_VAL;
     for (int k = 0; k < PF_BIAS_MAX + 1; ++k) A.bias_S[k] = 1.0;
     A.bias_H[0] = 0.0;
@@ -3069,7 +3072,10 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
         for (int k = 0; k <= A.n_bias && A.n_bias > 0; ++k) A.bias_S[k] = m->bias_strengths[k];
         double* dad;
         if (dalloc(h, &dad, E)) { pf_destroy(h); return nullptr; }
-        hipMemcpy(dad, m->application_delays, E * 8, hipMemcpyHostToDevice);
+        // on the handle's stream, behind the memset of dalloc: a plain hipMemcpy is not ordered with a non-blocking stream, and
+        // the memset, queued behind those of the state arrays, could land after it and leave every delay at zero
+        hipMemcpyAsync(dad, m->application_delays, E * 8, hipMemcpyHostToDevice, h->stream);
+        hipStreamSynchronize(h->stream);
         A.app_delays = dad;
     }
     h->pipe = P == 1 && n <= 8 && Np <= 131072;      // beyond that the decision tables outgrow the default dynamic LDS
@@ -3099,10 +3105,10 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
         if (m->n_bias_heights > 0 || m->n_rate_segments > 0) {
             rc |= dalloc(h, &st.total_delayed, K * Np);
             rc |= dalloc(h, &st.dcount, K * Np);
-            rc |= dalloc(h, &st.dpos, K * (size_t)PF_DCAP * Np);
-            rc |= dalloc(h, &st.dfac, K * (size_t)PF_DCAP * Np);
-            rc |= dalloc(h, &st.ddelta, K * (size_t)PF_DCAP * Np);
-            rc |= dalloc(h, &st.dk, K * (size_t)PF_DCAP * Np);
+            rc |= dalloc(h, &st.dpos, K * (size_t)A.dcap * Np);
+            rc |= dalloc(h, &st.dfac, K * (size_t)A.dcap * Np);
+            rc |= dalloc(h, &st.ddelta, K * (size_t)A.dcap * Np);
+            rc |= dalloc(h, &st.dk, K * (size_t)A.dcap * Np);
         }
     }
     if (p->flags & 1) {
@@ -3306,6 +3312,7 @@ int pf_sync(pf_handle* h) {
         if (c.err == ERR_MIG_OVERFLOW) msg = "too many migration events on one local tree";
         if (c.err == ERR_MP_INTERNAL) msg = "structured-model genealogy update: coalescence partners inconsistent";
         if (c.err == ERR_NO_COALESCENCE) msg = "No final coalescence event was sampled!";   /* particle.cpp:1383 */
+        if (c.err == ERR_DELAY_OVERFLOW) msg = "delayed-factor store overflow (raise pf_params.delay_cap)";
         g_err = msg;
         return -2;
     }
@@ -3649,7 +3656,7 @@ static int run_pipeline(pf_handle* h, long long s_begin, long long s_end) {
         if (!extend && !have_b) PL.row.complete = 0;
         PL.row.slot_prev = PL.row.complete ? (int)((s - 1) & (PF_RING - 1)) : -1;
         PL.row.slot_out = (int)(s & (PF_RING - 1));
-        PL.row.pos_prev = s > s_begin ? seg_pos(h, s - 1) : 0.0;
+        PL.row.pos_prev = (PL.row.complete && s > s_begin) ? seg_pos(h, s - 1) : 0.0;   // row s - 1 of the second flush step may lie past the table
         PL.b_slot = have_b ? (int)((s - 1) & (PF_RING - 1)) : -1;
         PL.b_row = s - 1;
         PL.b_pos = have_b ? seg_pos(h, s - 1) : 0.0;
@@ -4328,6 +4335,15 @@ int pf_get_kernel_time(pf_handle* h, int k, double* ms, int64_t* launches) {
     double mean = h->k_timed[k] ? h->k_ms[k] / (double)h->k_timed[k] : 0.0;
     if (ms) *ms = mean * (double)h->k_launches[k];
     if (launches) *launches = h->k_launches[k];
+    return 0;
+}
+
+int pf_get_delay_stats(pf_handle* h, int64_t* n_forced, int32_t* peak_pending) {
+    if (pf_sync(h)) return -1;
+    Ctrl c;
+    HIPCHK(hipMemcpy(&c, h->A.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
+    if (n_forced) *n_forced = (int64_t)c.n_delay_evict;
+    if (peak_pending) *peak_pending = c.delay_peak;
     return 0;
 }
 

@@ -13,7 +13,14 @@ struct DStore {
     long long Np;
     int count;
     double total;
+    int cap, evict;        // KArgs::dcap, KArgs::delay_evict
+    Ctrl* ctrl;            // error flag and the two statistics of the store
 };
+template <class KA>
+__device__ __forceinline__ void d_bind(DStore& d, const KA& A, const DState& st, long long p) {
+    d.pos = st.dpos + p; d.fac = st.dfac + p; d.delta = st.ddelta + p; d.k = st.dk + p; d.Np = A.Np;
+    d.cap = A.dcap; d.evict = A.delay_evict; d.ctrl = A.ctrl;
+}
 __device__ __forceinline__ void d_apply_earliest(DStore& d, double& w_pilot) {
     int m = 0;
     double pm = d.pos[0];
@@ -38,7 +45,15 @@ __device__ __forceinline__ void d_apply_earliest(DStore& d, double& w_pilot) {
 __device__ __forceinline__ void d_adjust_with_delay(DStore& d, double& w_post, double& w_pilot, double adj, double delay, double cur) {
     w_post *= adj;
     if ((adj > 0.99 && adj < 1.01) || (delay <= 1)) { w_pilot *= adj; return; }
-    while (d.count == PF_DCAP) d_apply_earliest(d, w_pilot);      // an entry leaves only with its third part
+    if (d.count == d.cap) {
+        // a full store stops the run like every other bounded ring (the reference's heap is unbounded); with delay_evict the
+        // earliest factor is applied ahead of its position instead (an entry leaves only with its third part), and counted
+        if (!d.evict) { if (!d.ctrl->err) d.ctrl->err = ERR_DELAY_OVERFLOW; }
+        while (d.count == d.cap) {
+            d_apply_earliest(d, w_pilot);
+            if (d.evict) atomicAdd(&d.ctrl->n_delay_evict, 1ull);
+        }
+    }
     d.total *= adj;
     double final_pos = cur + delay;
     double delta = (final_pos - cur) / 7.0;
@@ -47,6 +62,7 @@ __device__ __forceinline__ void d_adjust_with_delay(DStore& d, double& w_post, d
     d.fac[(size_t)i * d.Np] = dexp(dlog(adj) * (1.0 / 3));
     d.delta[(size_t)i * d.Np] = delta;
     d.k[(size_t)i * d.Np] = 3;
+    if (d.count > d.ctrl->delay_peak) atomicMax(&d.ctrl->delay_peak, d.count);
 }
 
 // LDS carve-up shared by k_init / k_extend

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(PF_BS) void k_extend_mp(KArgs A, long long s) {
         Lane ln = make_lane(A, m, p);
         MLane ml = make_mlane(A, mm);
         DStore ds;
-        ds.pos = st.dpos + p; ds.fac = st.dfac + p; ds.delta = st.ddelta + p; ds.k = st.dk + p; ds.Np = A.Np;
+        d_bind(ds, A, st, p);
         ds.count = 0; ds.total = 1.0;
         if (biased) { ds.count = st.dcount[p]; ds.total = st.total_delayed[p]; }
         int ridx = guided ? st.ridx[p] : 0;
@@ -727,7 +727,7 @@ __device__ __forceinline__ void extend_mpr_body(const KA& A, long long s, int fu
         cx.ridx = guided ? from.ridx[a] : 0; cx.g_rp = 0; cx.g_sb = 0;
         ml.nep = rmp_node_epochs(cx, t);
         DStore ds;
-        ds.pos = st.dpos + p; ds.fac = st.dfac + p; ds.delta = st.ddelta + p; ds.k = st.dk + p; ds.Np = A.Np;
+        d_bind(ds, A, st, p);
         ds.count = 0; ds.total = 1.0;
         if (biased) {
             ds.count = from.dcount[a]; ds.total = from.total_delayed[a];

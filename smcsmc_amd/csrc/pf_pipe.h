@@ -218,7 +218,8 @@ __device__ __forceinline__ bool sweep_plan(SweepChunkC& ch, long long s, int nb,
     PL.row.complete = ((extend && s > s_begin) || flush1) ? 1 : 0;
     PL.row.slot_prev = PL.row.complete ? (int)((s - 1) & (PF_RING - 1)) : -1;
     PL.row.slot_out = (int)(s & (PF_RING - 1));
-    PL.row.pos_prev = s > s_begin ? sweep_seg_pos(ch.A, s - 1) : 0.0;
+    // only a step that completes a row needs its end; on the second flush step row s - 1 = s_last + 1 may lie past the table
+    PL.row.pos_prev = (PL.row.complete && s > s_begin) ? sweep_seg_pos(ch.A, s - 1) : 0.0;
     PL.row.draws = ch.nT > 0 ? 1 + (int)(s & 1) : 0;
     PL.nT = extend ? ch.nT : 0;
     PL.b_slot = have_b ? (int)((s - 1) & (PF_RING - 1)) : -1;

@@ -7,7 +7,8 @@
 
 #define PF_EMAX 64
 #define PF_STAMP_W 32        // profiling builds: words per wavefront and row in KArgs::stamps
-#define PF_DCAP 32            // pending delayed factors per particle (the reference's heap is unbounded)
+#define PF_DCAP_DEFAULT 128   // pending delayed factors per particle unless pf_params.delay_cap says otherwise (the reference's heap,
+                              // particle.hpp:248, is unbounded; a full store is a reported error)
 #define PF_BIAS_MAX 8         // interior bias heights
 #define PF_DECIDE_TAB 16384   // offspring / parent tables fit LDS (16-bit entries) up to this many particles
 #define PF_RING 16             // slots of the row pipeline's rings (state, scans, partials, per-row control data): row s lives in slot s & 15.
@@ -30,10 +31,10 @@ struct DState {
     // delayed importance factors (particle.hpp:59-101, 185-209); allocated only with focused sampling
     double* total_delayed;   // [Np]
     int* dcount;             // [Np]
-    double* dpos;            // [PF_DCAP][Np] application positions
-    double* dfac;            // [PF_DCAP][Np]
-    double* ddelta;          // [PF_DCAP][Np]
-    int* dk;                 // [PF_DCAP][Np]
+    double* dpos;            // [dcap][Np] application positions
+    double* dfac;            // [dcap][Np]
+    double* ddelta;          // [dcap][Np]
+    int* dk;                 // [dcap][Np]
     int* ridx;               // [Np] guide segment the particle is in (_current_seq_idx); allocated with a guide
     double* lookahead;       // [Np] lookahead_weight_ (auxiliary particle filter); allocated with pf_load_lookahead
     // structured models (pf_mp.h); allocated only when P > 1
@@ -64,6 +65,8 @@ struct Ctrl {
     int count_active;
     int end_seq;
     int pending_fin;       // k_count partials of the previous step still have to be folded into the totals
+    int delay_peak;        // most delayed factors any particle ever had pending
+    unsigned long long n_delay_evict;   // factors applied ahead of their position because the store was full (delay_evict only)
     long long nres_prev;   // n_resample as of the end of the last k_resample (stable during k_decide)
     // what the counting stream needs to know about a step, double-buffered by step parity
     struct StepInfo { double inv_T; int G; int flag; } step[2];
@@ -139,6 +142,7 @@ struct KArgs {
     unsigned long long seed;
     // focused sampling
     int n_bias, delay_type;
+    int dcap, delay_evict;         // capacity of the delayed-factor store per particle; full store: apply the earliest factor early (and count) instead of stopping
     double bias_H[PF_BIAS_MAX + 2];
     double bias_S[PF_BIAS_MAX + 1];
     const double* app_delays;
@@ -246,7 +250,7 @@ __host__ __device__ inline DState state_slot(const KA& A, int k) {
     d.S += K * n1 * Np; d.C += K * 2 * n1 * Np;
     d.w_post += K * Np; d.w_pilot += K * Np; d.next_base += K * Np; d.x_mark += K * Np; d.Ltree += K * Np; d.mark_limit += K * Np;
     d.total_delayed += K * Np; d.dcount += K * Np;
-    d.dpos += K * PF_DCAP * Np; d.dfac += K * PF_DCAP * Np; d.ddelta += K * PF_DCAP * Np; d.dk += K * PF_DCAP * Np;
+    d.dpos += K * (size_t)A.dcap * Np; d.dfac += K * (size_t)A.dcap * Np; d.ddelta += K * (size_t)A.dcap * Np; d.dk += K * (size_t)A.dcap * Np;
     d.ridx += K * Np; d.lookahead += K * Np;
     d.Pn += K * n1 * Np; d.nm += K * Np;
     d.Mt += K * (size_t)A.mcap * Np; d.Mb += K * (size_t)A.mcap * Np; d.Mq += K * (size_t)A.mcap * Np;
@@ -268,7 +272,7 @@ struct Windows {
 };
 
 enum { ERR_LOG_OVERFLOW = 1, ERR_GEN_OVERFLOW = 2, ERR_ZERO_PROB = 3, ERR_COUNT_MISMATCH = 4, ERR_MIG_OVERFLOW = 5,
-       ERR_MP_INTERNAL = 6, ERR_NO_COALESCENCE = 7 };
+       ERR_MP_INTERNAL = 6, ERR_NO_COALESCENCE = 7, ERR_DELAY_OVERFLOW = 8 };
 
 // record meta word: type | lim_start+1 << 8 | lim_event+1 << 16 | n_eff << 24 | descendants << 32 (samples below the
 // branch cut by the recombination that ends the stretch, bit i = sample i; descendants.hpp:22-33) | descendants of the

@@ -49,7 +49,7 @@ class _Params(C.Structure):
     _fields_ = [("np", C.c_int64), ("ess_fraction", C.c_double), ("seed", C.c_uint64),
                 ("max_trace_events", C.c_int32), ("flags", C.c_int32),
                 ("log_cap", C.c_int64), ("gen_cap", C.c_int64), ("piece_cap", C.c_int64),
-                ("debug", C.c_int32), ("mig_cap", C.c_int32), ("count_wgs", C.c_int32), ("reserved3", C.c_int32)]
+                ("debug", C.c_int32), ("mig_cap", C.c_int32), ("count_wgs", C.c_int32), ("delay_cap", C.c_int32)]
 
 
 DEBUG_FORCE_LDS, DEBUG_NO_FUSE, DEBUG_NO_COUNT, DEBUG_TWO_LAUNCH = 1, 2, 4, 8
@@ -94,7 +94,7 @@ EXPORTS = [
     "pf_terminal_branch_quantiles",
     "pf_update_segment", "pf_count", "pf_resample", "pf_run", "pf_run_many", "pf_finish", "pf_sync",
     "pf_num_segments_done", "pf_logl", "pf_get_counts", "pf_get_trace", "pf_get_resample_events",
-    "pf_get_particles", "pf_get_migrations", "pf_get_local_recomb", "pf_sample_tree_events", "pf_sample_tree_events_pops", "pf_get_kernel_time", "pf_set_timing", "pf_get_stats", "pf_debug_stamps", "pf_test_search_lut", "pf_simulate_sites",
+    "pf_get_particles", "pf_get_migrations", "pf_get_local_recomb", "pf_sample_tree_events", "pf_sample_tree_events_pops", "pf_get_kernel_time", "pf_set_timing", "pf_get_stats", "pf_get_delay_stats", "pf_debug_stamps", "pf_test_search_lut", "pf_simulate_sites",
     "pf_median_survival", "pf_test_math", "pf_test_div", "pf_test_uniform", "pf_test_reduce", "pf_test_systematic",
 ]
 
@@ -143,6 +143,7 @@ def load_library(path=None):
     L.pf_get_kernel_time.argtypes = [vp, C.c_int, vp, vp]
     L.pf_set_timing.argtypes = [vp, C.c_int]
     L.pf_get_stats.argtypes = [vp, vp, vp, vp]
+    L.pf_get_delay_stats.argtypes = [vp, vp, vp]
     L.pf_median_survival.argtypes = [C.POINTER(_Model), C.c_uint64, C.c_int32, C.c_int64, vp, vp, C.c_int]
     L.pf_test_math.argtypes = [vp, C.c_int64, vp, vp, vp, C.c_int]
     L.pf_test_div.argtypes = [vp, vp, C.c_int64, vp, C.c_int]
@@ -250,7 +251,8 @@ KERNEL_CLASSES = ("extend", "decide", "count", "resample")
 
 class ParticleFilter:
     def __init__(self, model, np_particles, ess_fraction=0.5, seed=1, max_trace_events=64, device=0, local_recomb=False,
-                 record_trees=False, log_cap=0, gen_cap=0, piece_cap=0, debug=0, mig_cap=0, count_wgs=0):
+                 record_trees=False, log_cap=0, gen_cap=0, piece_cap=0, debug=0, mig_cap=0, count_wgs=0, delay_cap=0,
+                 delay_evict=False):
         self.L = load_library()
         m = model
         self._ct = np.ascontiguousarray(m["change_times"], dtype=np.float64)
@@ -269,8 +271,8 @@ class ParticleFilter:
         _attach_structure(self, self._model, m, E, P)
         self.loci_length = float(m["loci_length"])
         self._params = _Params(self.Np, float(ess_fraction), int(seed), self.max_trace_events,
-                               (1 if local_recomb else 0) | (2 if record_trees else 0),
-                               int(log_cap), int(gen_cap), int(piece_cap), int(debug), int(mig_cap), int(count_wgs), 0)
+                               (1 if local_recomb else 0) | (2 if record_trees else 0) | (4 if delay_evict else 0),
+                               int(log_cap), int(gen_cap), int(piece_cap), int(debug), int(mig_cap), int(count_wgs), int(delay_cap))
         self.mig_cap = int(mig_cap) if mig_cap else 96
         self.h = self.L.pf_create(C.byref(self._model), C.byref(self._params), int(device))
         if not self.h:
@@ -425,6 +427,13 @@ class ParticleFilter:
         a = C.c_int64(); b = C.c_int64(); c = C.c_int64()
         self._chk(self.L.pf_get_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return {"records": a.value, "state_bytes_per_particle": b.value, "resamples": c.value}
+
+    def delay_stats(self):
+        """delayed-factor store: factors applied ahead of their position to make room (only with delay_evict; otherwise a full
+        store is an error) and the most factors any particle ever had pending"""
+        a = C.c_int64(); b = C.c_int32()
+        self._chk(self.L.pf_get_delay_stats(self.h, C.byref(a), C.byref(b)))
+        return {"forced": a.value, "peak": b.value}
 
 
 class _PackedModel:

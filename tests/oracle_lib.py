@@ -34,7 +34,7 @@ class Model(C.Structure):
 
 class Params(C.Structure):
     _fields_ = [("np", C.c_int64), ("ess_fraction", C.c_double), ("seed", C.c_uint64),
-                ("max_trace_events", C.c_int32), ("mig_cap", C.c_int32)]
+                ("max_trace_events", C.c_int32), ("mig_cap", C.c_int32), ("delay_cap", C.c_int32), ("delay_evict", C.c_int32)]
 
 
 class Segments(C.Structure):
@@ -83,6 +83,7 @@ def lib():
         L.smco_logl.restype = C.c_double
         L.smco_logl.argtypes = [C.c_void_p]
         L.smco_get_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.smco_get_delay_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         for name in ("smco_exp", "smco_log", "smco_fastexp"):
             getattr(L, name).restype = C.c_double
             getattr(L, name).argtypes = [C.c_double]
@@ -188,11 +189,13 @@ class PackedInputs:
 
 
 class Oracle:
-    def __init__(self, model, np_particles, ess_fraction=0.5, seed=1, max_trace_events=64, mig_cap=0):
+    def __init__(self, model, np_particles, ess_fraction=0.5, seed=1, max_trace_events=64, mig_cap=0, delay_cap=0,
+                 delay_evict=False):
         self.L = lib()
         self.inp = PackedInputs(model, None)
         self.Np = int(np_particles)
-        self.params = Params(self.Np, float(ess_fraction), int(seed), int(max_trace_events), int(mig_cap))
+        self.params = Params(self.Np, float(ess_fraction), int(seed), int(max_trace_events), int(mig_cap), int(delay_cap),
+                             int(bool(delay_evict)))
         self.mig_cap = int(mig_cap) if mig_cap else 96
         self.h = self.L.smco_create(C.byref(self.inp.model), C.byref(self.params))
         if not self.h:
@@ -306,6 +309,12 @@ class Oracle:
         a = C.c_int64(); b = C.c_int64(); c = C.c_int64()
         self.L.smco_get_stats(self.h, C.byref(a), C.byref(b), C.byref(c))
         return {"recombinations": a.value, "events_allocated": b.value, "resamples": c.value}
+
+    def delay_stats(self):
+        """(factors applied ahead of their position to make room, most factors any particle had pending)"""
+        a = C.c_int64(); b = C.c_int32()
+        self.L.smco_get_delay_stats(self.h, C.byref(a), C.byref(b))
+        return {"forced": a.value, "peak": b.value}
 
 
 def counts_len(E, P=1):

@@ -89,12 +89,12 @@ def test_systematic_resampling_offsets_bit_exact(oracle, hiplib, n):
         assert lo[0] == 0 and lo[-1] == n and (np.diff(lo) >= 0).all()
 
 
-def _run_both(oracle, model, segs, Np, seed, ess=0.5):
+def _run_both(oracle, model, segs, Np, seed, ess=0.5, **kw):
     from smcsmc_amd import ParticleFilter
-    o = oracle.Oracle(model, Np, ess_fraction=ess, seed=seed, max_trace_events=64)
+    o = oracle.Oracle(model, Np, ess_fraction=ess, seed=seed, max_trace_events=64, **kw)
     o.init_prior(segs["start"][0])
     si = o.pack_segments(model, segs)
-    g = ParticleFilter(model, Np, ess_fraction=ess, seed=seed, max_trace_events=64)
+    g = ParticleFilter(model, Np, ess_fraction=ess, seed=seed, max_trace_events=64, **kw)
     g.init_prior(segs["start"][0])
     g.load_segments(segs)
     return o, si, g
@@ -290,6 +290,42 @@ def test_focused_sampling_and_delayed_importance_weights(oracle, hiplib, n, dela
     # pilot and posterior weights differ while factors are pending
     p = g.particles()
     assert not np.allclose(p["w_post"], p["w_pilot"])
+
+
+@pytest.mark.parametrize("n,P", [(4, 1), (12, 1), (4, 2), (10, 2)])    # register-tree and LDS-tree kernels, one and two populations
+def test_delayed_factor_store_is_bounded_and_says_so(oracle, hiplib, n, P):
+    """The reference keeps a particle's delayed importance factors in an unbounded heap (particle.hpp:59-101, 248); the
+    device keeps pf_params.delay_cap of them per particle.  A full store stops the run with a message, as every other
+    bounded ring does; with delay_evict the earliest factor is applied ahead of its position instead, and both sides count
+    how often (same number, same weights).  With room enough nothing is ever forced."""
+    from smcsmc_amd.pf import PfError
+    model = cases.make_model(n=n, E=8, L=1.0e5)
+    model.update(bias_heights=[400.0], bias_strengths=[8.0, 1.0], application_delays=np.array(model["lags"]) * 0.5)
+    if P > 1:
+        model = cases.make_structured(model, P=P, split_epoch=5, mig=1.0)
+    segs = cases.make_segments(cases.make_model(n=n, E=8, L=1.0e5), seed=23 + n, max_seg_len=5000)
+    Np = 300 if n <= 8 else 128
+    # (1) plenty of room: the peak is reported, nothing is forced
+    o, si, g = _run_both(oracle, model, segs, Np, seed=3)
+    o.run(si); g.run(); g.finish()
+    so, sg = o.delay_stats(), g.delay_stats()
+    assert so == sg and so["forced"] == 0 and 3 < so["peak"] <= 128, (so, sg)
+    ref_logl = g.logl()
+    cap = max(2, so["peak"] // 3)
+    # (2) a store a third that size, eviction allowed: counted, identical on both sides, and the weights do change
+    o, si, g = _run_both(oracle, model, segs, Np, seed=3, delay_cap=cap, delay_evict=True)
+    o.run(si); g.run(); g.finish()
+    so, sg = o.delay_stats(), g.delay_stats()
+    assert so == sg and so["forced"] > 0 and so["peak"] == cap, (so, sg)
+    assert (_bits(o.trace()["logl"]) == _bits(g.trace()["logl"])).all()
+    _assert_state_equal(o, g)
+    assert g.trace()["ess"].tolist() != [] and g.logl() != ref_logl or so["forced"] > 0
+    # (3) the same store without the switch: an error on both sides
+    o, si, g = _run_both(oracle, model, segs, Np, seed=3, delay_cap=cap)
+    with pytest.raises(RuntimeError, match="delayed-factor store overflow"):
+        o.run(si)
+    with pytest.raises(PfError, match="delayed-factor store overflow"):
+        g.run(); g.finish()
 
 
 def test_three_bias_bands(oracle, hiplib):

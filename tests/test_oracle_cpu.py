@@ -402,3 +402,27 @@ def test_oracle_meets_the_reference_no_data_bands(oracle, built_binary, name):
         assert t["min"] <= vals.mean() <= t["max"], (rb.target_label(t), vals.mean(), t["min"], t["max"])
         if t["type"] != "Coal" or t["epoch"] > 0:
             assert ((vals >= t["min"]) & (vals <= t["max"])).sum() >= 6, (rb.target_label(t), vals)
+
+
+def test_delayed_factor_store_capacity(oracle):
+    """The reference's heap of delayed factors is unbounded (particle.hpp:248).  The restatement holds delay_cap of them per
+    particle like the device path: with room nothing is forced; a full store is an error, or -- with delay_evict -- the
+    earliest factor is applied early and counted."""
+    model = cases.make_model(n=4, E=8, L=6e4)
+    model.update(bias_heights=[400.0], bias_strengths=[8.0, 1.0], application_delays=np.array(model["lags"]) * 0.5)
+    segs = cases.make_segments(cases.make_model(n=4, E=8, L=6e4), seed=27, max_seg_len=5000)
+
+    def run(**kw):
+        o = oracle.Oracle(model, 200, seed=3, **kw)
+        o.init_prior(segs["start"][0]); o.run(o.pack_segments(model, segs))
+        return o
+    o = run()
+    st = o.delay_stats()
+    assert st["forced"] == 0 and st["peak"] > 3
+    logl = o.logl()
+    o2 = run(delay_cap=max(2, st["peak"] // 3), delay_evict=True)
+    st2 = o2.delay_stats()
+    assert st2["forced"] > 0 and st2["peak"] == max(2, st["peak"] // 3)
+    assert o2.logl() != logl            # early application changes the pilot weights, hence the resampling, hence everything
+    with pytest.raises(RuntimeError, match="delayed-factor store overflow"):
+        run(delay_cap=max(2, st["peak"] // 3))
