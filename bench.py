@@ -265,7 +265,7 @@ def main():
         model, segs = build_workload(args, seed=args.seed + rank * C + k)     # independent chunks
         f = ParticleFilter(model, args.np, ess_fraction=0.5, seed=args.seed + 1000 * (rank * C + k), max_trace_events=0,
                            device=dev, local_recomb=not args.no_local_recomb, debug=args.debug,
-                           count_wgs=args.count_wgs or (24 if args.chunks_per_gpu >= 6 else 0))
+                           count_wgs=args.count_wgs or (24 if (args.chunks_per_gpu >= 6 and not (args.debug & 2048)) else 0))
         f.load_segments(segs)
         chunks.append((f, segs))
     pf, segs = chunks[0]
@@ -352,16 +352,30 @@ def main():
         # algorithmic bytes of one k_extend launch: every particle's state read and written once,
         # plus the event records appended
         alg_bytes = args.np * 2 * state_bytes + rec_per_seg * rec_bytes
-        achieved = alg_bytes / (avg_ext_us * 1e-6) / 1e9 if avg_ext_us > 0 else 0.0
-        # HBM traffic of the same kernel from the PMC counters: collected by profiles/collect_round1.sh in separate
-        # rocprofv3 passes (counters cannot be read from inside this process) and kept under profiles/
-        traffic = None
+        # Duration of one launch of the row kernel.  HIP events bracket every `--timing-period`-th launch (avg_ext_us: an estimate
+        # from a sample, minus the cost of an empty span); the driver's clock sees rows, not launches, so the figure the roofline
+        # fraction is computed from is the wall-clock time per row of chunk 0's sweep -- ms_per_step / rows, launch gaps included,
+        # an upper bound of the kernel's duration that agrees with rocprofv3's per-kernel average (profiles/round4) -- whenever one
+        # launch per row is what runs (one chunk per GPU); with several chunks in flight the sampled event figure stands.
+        us_per_row_wall = 1e6 * (dt_max / args.steps) / max(1, n_seg0)
+        one_launch_per_row = C == 1 and args.nsam <= 8 and not (args.debug & (8 | 3))
+        dur_us = us_per_row_wall if (one_launch_per_row and args.pops == 1) else avg_ext_us
+        achieved = alg_bytes / (dur_us * 1e-6) / 1e9 if dur_us > 0 else 0.0
+        # HBM traffic of the same kernel from the PMC counters: collected by profiles/collect_round*.sh in separate
+        # rocprofv3 passes (counters cannot be read from inside this process) and kept under profiles/; a file counts only when
+        # it is of this shape AND of the kernel this run's rows go through
+        if args.pops == 1:
+            kern_key = "k_pipe" if args.debug & 16 else ("k_row" if args.debug & 8 else "k_sweep")
+        else:
+            kern_key = "k_sweep_xmp" if (args.nsam <= 8 and not (args.debug & (16 | 3))) else ("k_extend_mpr" if args.nsam <= 8 and not (args.debug & 3) else "k_extend_mp")
+        traffic, traffic_src = None, None
         import glob
-        for pmc_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round2", "*_pmc_k_*.json"))) + \
-                sorted(glob.glob(os.path.join(ROOT, "profiles", "round3", "*_pmc_k_*.json"))):      # the newest matching file wins
-            pmc = json.load(open(pmc_path))
-            if pmc.get("shape") == {"nsam": args.nsam, "np": args.np, "epochs": args.epochs, "pops": args.pops}:
-                traffic = pmc["traffic_bytes_per_launch"]
+        for rnd in ("round2", "round3", "round4"):                       # the newest matching file wins
+            for pmc_path in sorted(glob.glob(os.path.join(ROOT, "profiles", rnd, "*_pmc_k_*.json"))):
+                pmc = json.load(open(pmc_path))
+                if pmc.get("shape") == {"nsam": args.nsam, "np": args.np, "epochs": args.epochs, "pops": args.pops} and kern_key + "<" in pmc.get("kernel", "").replace("4<", "<"):
+                    traffic = pmc["traffic_bytes_per_launch"]
+                    traffic_src = dict(file=os.path.relpath(pmc_path, ROOT), kernel=pmc.get("kernel"), counter_run=pmc.get("counter_run", pmc.get("note", ""))[:300])
         out = {
             "metric": "genome segments/sec per EM iteration (%s)" % workload_label(args),
             "value": value, "unit": "segments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -373,11 +387,19 @@ def main():
                        "populations": args.pops, "local_recombination_map": not args.no_local_recomb,
                        "segments_per_chunk": n_segments, "nsam": args.nsam, "np": args.np,
                        "sequence_length": args.length, "epochs": args.epochs,
-                       "count_workgroups_per_epoch": args.count_wgs or (24 if args.chunks_per_gpu >= 6 else "one per particle block"),
+                       "count_workgroups_per_epoch": args.count_wgs or (24 if (args.chunks_per_gpu >= 6 and not (args.debug & 2048)) else "one per particle block"),
                        "parallelism": "%d chunk(s) per gpu%s x %d gpu(s)" % (C, (", one launch per row for all of them" if many else ", one host thread and stream each") if C > 1 else "", world), "log_likelihood_sum": logl_sum},
             "roofline": {"bound": "hbm", "kernel": ("k_pipe" if args.debug & 16 else "k_sweep") + " (one launch per row: extend workgroups; bookkeeping, ledger and counts ride along)" if args.pops == 1 and args.nsam <= 8 and not (args.debug & 8) else ("k_row" if args.pops == 1 and args.nsam <= 8 else (("k_sweep_xmp (extend role of the row pipeline; bookkeeping, ledger and counts as k_sweep_blc on a second stream)" if not (args.debug & 16) else "k_extend_mpr (register tree, completes the previous row while loading)") if args.nsam <= 8 and not (args.debug & 3) else "k_extend_mp") if args.pops > 1 else "k_extend"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "alg_bytes_per_launch": alg_bytes, "avg_launch_us": avg_ext_us,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "alg_bytes_per_launch": alg_bytes,
+                         "alg_bytes_model": "2 x %d B of state per particle (read and written once per row) x Np + %.2f records of %d B appended per row (DESIGN.md section 2)" % (state_bytes, rec_per_seg, rec_bytes),
+                         "launch_us": dur_us,
+                         "launch_us_basis": ("wall clock per row (ms_per_step / rows of the chunk): every launch, gaps included" if dur_us == us_per_row_wall
+                                             else "HIP events on every %d-th launch" % args.timing_period),
+                         "avg_launch_us": avg_ext_us, "us_per_row_wall": us_per_row_wall,
+                         # SURVEY.md section 8(d) prices a row at 11 MB with its model of the state (256 B per particle) and of the records
+                         # (32-byte payloads, one per tree slice and epoch): against that figure the fraction would be
+                         "frac_against_survey_model_bytes": (11.0e6 / (dur_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (args.nsam == 4 and args.np == 10000 and args.pops == 1 and dur_us > 0) else None,
                          "kernel_ms_estimate": {k: v[0] for k, v in kt.items()},
                          "kernel_launches": {k: v[1] for k, v in kt.items()}},
         }

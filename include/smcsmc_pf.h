@@ -96,7 +96,7 @@ typedef struct pf_params {
                                   * any tree is a reported error ("too many migration events on one local tree"). */
     int32_t count_wgs;           /* row pipeline: workgroups per epoch that share the lagged counting of a row (0 = one
                                   * per 256 particles, which is also the most).  The sums are grouped by workgroup, so the value is part
-                                  * of what makes two runs bit-identical. */
+                                  * of what makes two runs bit-identical.  (With PF_DEBUG_COUNT_UNITS: workgroups per step.) */
     int32_t delay_cap;           /* focused sampling / guide: delayed importance factors a particle may have pending (0 = 128).  The
                                   * reference keeps them in an unbounded heap (particle.hpp:59-101, 248); here the store is a column of
                                   * delay_cap entries per particle in device memory.  One factor too many is a reported error
@@ -119,6 +119,11 @@ typedef struct pf_params {
 #define PF_DEBUG_NO_SEARCH_LUT 256 /* k_sweep: the epoch searches of an update by the four-way search instead of the bucket tables (A/B) */
 
 #define PF_DEBUG_COUNT_YOUNG_FIRST 512 /* row pipeline: count workgroups in ascending epoch order, as before round 3 (A/B) */
+
+#define PF_DEBUG_COUNT_UNITS 2048 /* with PF_DEBUG_SPLIT_ROLES, one population: the lagged counts dealt out by generation (256 tasks of one
+                                  * generation for up to four of the epochs whose windows meet it; count_units_body) instead of one
+                                  * column of workgroups per epoch -- an experiment of round 4, measured slower;
+                                  * the sums are grouped differently and agree to rounding */
 
 #define PF_DEBUG_CU_MASK 1024     /* with PF_DEBUG_SPLIT_ROLES: the two streams on disjoint sets of compute units (experiment) */
 
@@ -206,6 +211,10 @@ int pf_run(pf_handle* h, int64_t s_begin, int64_t s_end);
  * whose grid covers all of them.  The reference starts one process per chunk, all at once (smcsmc/model.py:1094-1098);
  * every chunk's results are bit-identical to its own pf_run.  A chunk that runs out of rows simply stops. */
 int pf_run_many(pf_handle* const* handles, int32_t n_handles, int64_t s_begin, int64_t s_end);
+/* 1 when pf_run_many would take these handles, 0 when the caller has to run them one after the other with pf_run (the row
+ * pipeline does not apply to one of them -- several populations, more than 8 haplotypes, look-ahead, more than 131 072
+ * particles -- or they differ in shape) */
+int pf_can_run_many(pf_handle* const* handles, int32_t n_handles);
 int pf_finish(pf_handle* h);
 int pf_sync(pf_handle* h);
 
@@ -237,6 +246,11 @@ int pf_debug_stamps(pf_handle* h, int64_t rows, uint64_t* out);
  * upper sixteen bits of the double minus *kbase, clamped to 0..255; answer = lut[key] plus one for each of the next two entries
  * that is <= t).  Returns 1 and fills lut[256] / *kbase when the table qualifies, 0 when the kernels keep the four-way search. */
 int pf_test_search_lut(const double* tab, int32_t n, uint8_t* lut, int32_t* kbase);
+/* measurement probe (smcsmc_amd/csrc/pf_probe.hip; not part of the filter): the hand-off of a row between `nw` wavefronts, as `rows`
+ * launches back to back (mode 0: a kernel boundary per row, what the row pipeline pays) or inside one resident grid (mode 1:
+ * release stores, an arrival counter per row, polling, coherent loads), with spin_ticks x 10 ns of stand-in work per wavefront
+ * and row and the same reduction of all wavefronts' five partials either way.  Microseconds per row in *us_per_row. */
+int pf_probe_handoff(int32_t mode, int32_t rows, int32_t nw, int64_t spin_ticks, double* us_per_row, double* checksum, int32_t device);
 /* the delayed-factor store (adjustWeightsWithDelay, particle.hpp:185-209): factors applied ahead of their position because the
  * store was full (only with pf_params.flags bit2; otherwise that is an error) and the most factors any particle ever had pending */
 int pf_get_delay_stats(pf_handle* h, int64_t* n_forced, int32_t* peak_pending);

@@ -36,7 +36,7 @@ def _compile_units(out, extra_flags, force, tag):
     """Each translation unit to its own object file (two hipcc processes side by side: the units take minutes), then one link.
     An object is rebuilt when its unit or any header is newer."""
     import concurrent.futures
-    units = [os.path.join(CSRC, "pf_hip.hip"), os.path.join(CSRC, "pf_mp.hip")]
+    units = [os.path.join(CSRC, "pf_hip.hip"), os.path.join(CSRC, "pf_mp.hip"), os.path.join(CSRC, "pf_probe.hip")]
     deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "smcsmc_pf.h"))
     objdir = os.path.join(CSRC, "build")

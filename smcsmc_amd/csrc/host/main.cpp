@@ -141,6 +141,10 @@ struct ChunkFilter {
     ~ChunkFilter() { if (h) pf_destroy(h); }
 };
 
+static void release_filter(ChunkFilter& F) {
+    if (F.h) { pf_destroy(F.h); F.h = nullptr; }
+}
+
 static void open_filter(ChunkFilter& F, PfParam& P, const HostModel& M0, int device, const ChunkJob* job) {
     F.P = &P;
     HostModel& M = P.model;
@@ -347,11 +351,11 @@ static void close_filter(ChunkFilter& F, const HostModel& M0, const ChunkJob* jo
                      << " applied early to make room" << endl;
         }
         clog << " Inference step completed." << endl;
-        if (job && job->packed_out) {        // a chunk of a multi-chunk E-step: the statistics go to the reduction
-            *job->packed_out = packed;
-            return;
-        }
-        if (P.write_resample) {
+        // a chunk of a multi-chunk E-step: the statistics go to the reduction; its local recombination map is written like any
+        // chunk process's (<prefix>.chunkN.recomb.gz: the reference writes one per chunk process, smcsmc.cpp:376-383)
+        const bool chunk_job = job && job->packed_out;
+        if (chunk_job) *job->packed_out = packed;
+        if (!chunk_job && P.write_resample) {
             std::vector<double> ess(done);
             std::vector<int32_t> flag(done);
             pf_check(pf_get_trace(h, nullptr, ess.data(), flag.data(), nullptr, done));
@@ -418,6 +422,7 @@ static void close_filter(ChunkFilter& F, const HostModel& M0, const ChunkJob* jo
                 fclose(fz);
             }
         }
+        if (chunk_job) return;
         // <prefix>.trees.gz (ParticleContainer::printTrees, pc.cpp:515-555) after the one-particle draw of smcsmc.cpp:395
         if (P.record_trees) {          // every E-step overwrites it, as the reference does
             int64_t particle = 0;
@@ -605,24 +610,42 @@ static void run_chunks(ChunkPlan& C, PfParam& P, const HostModel& M0) {
                 params[k].model.loci_length = (double)(C.first[c + 1] - C.first[c]);
                 params[k].start_position = (double)C.first[c];
                 params[k].segments = C.tables[c].get();
+                // the chunk's own local recombination map, as a chunk process of the front-end would leave it
+                // (<out>/emiterI/chunkC.recomb.gz there; model.py:1057-1092)
+                params[k].recomb_map_path = P.recomb_map_path.substr(0, P.recomb_map_path.size() - std::string(".recomb.gz").size()) +
+                                            ".chunk" + std::to_string(c) + ".recomb.gz";
+                if (P.em_iteration == 0) remove(params[k].recomb_map_path.c_str());
                 jobs[k].survival = &survival; jobs[k].survival_out = &survival; jobs[k].packed_out = &packed[k]; jobs[k].seed_offset = (uint64_t)c;
             }
-            if (lockstep && my_chunks.size() > 1) {
+            // Side by side in groups: as many of the rank's chunks as the device has memory for are opened together (every
+            // filter holds its own rings: the event log alone is Np x 16 384 records by default) and go through one launch per
+            // row when the library says the group can (pf_can_run_many: the row pipeline applies to all of them -- one
+            // population, at most 8 haplotypes, no look-ahead, Np <= 131 072 -- and they share their shape); otherwise, and
+            // whenever a group comes down to one chunk, one after the other.
+            size_t k0 = 0;
+            while (k0 < my_chunks.size()) {
                 std::vector<ChunkFilter*> group;
-                for (size_t k = 0; k < my_chunks.size(); ++k) {
-                    open_filter(filters[k], params[k], M0, C.device_of_rank[r], &jobs[k]);
-                    group.push_back(&filters[k]);
+                size_t k1 = k0;
+                while (k1 < my_chunks.size() && (k1 == k0 || lockstep)) {
+                    try {
+                        open_filter(filters[k1], params[k1], M0, C.device_of_rank[r], &jobs[k1]);
+                    } catch (const std::exception& e) {
+                        if (k1 == k0 || std::string(e.what()).find("memory") == std::string::npos) throw;
+                        clog << " rank " << r << ": " << (k1 - k0) << " chunks fill the device; the rest follow" << endl;
+                        break;                               // no room for another filter beside the open ones: run those first
+                    }
+                    group.push_back(&filters[k1]);
+                    ++k1;
                 }
-                run_filters(group, r == 0);
-                for (size_t k = 0; k < my_chunks.size(); ++k) close_filter(filters[k], M0, &jobs[k]);
-            } else {
-                for (size_t k = 0; k < my_chunks.size(); ++k) {
-                    ChunkFilter F;
-                    open_filter(F, params[k], M0, C.device_of_rank[r], &jobs[k]);
-                    std::vector<ChunkFilter*> one{&F};
-                    run_filters(one, r == 0);
-                    close_filter(F, M0, &jobs[k]);
+                std::vector<pf_handle*> hs;
+                for (ChunkFilter* F : group) hs.push_back(F->h);
+                if (group.size() > 1 && pf_can_run_many(hs.data(), (int32_t)hs.size())) {
+                    run_filters(group, r == 0);
+                } else {
+                    for (ChunkFilter* F : group) { std::vector<ChunkFilter*> one{F}; run_filters(one, r == 0); }
                 }
+                for (size_t k = k0; k < k1; ++k) { close_filter(filters[k], M0, &jobs[k]); release_filter(filters[k]); }
+                k0 = k1;
             }
             for (size_t k = 0; k < my_chunks.size(); ++k) std::copy(packed[k].begin(), packed[k].end(), mine[r].begin() + k * LEN);
             entered = true;

@@ -200,6 +200,26 @@ __device__ __forceinline__ double wave_tree_sum(double v) {
     for (int m = 1; m < 64; m <<= 1) v = v + __shfl_xor(v, m, 64);
     return v;
 }
+// Sum over the wavefront without LDS traffic: row shifts and row broadcasts of the data-parallel primitives (four steps inside the
+// rows of sixteen lanes, two across them), total read from lane 63.  A different association from wave_tree_sum's butterfly --
+// for sums whose grouping is not part of the canonical arithmetic (the lagged counts) -- and the same one in every run.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double wave_dpp_add(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int slo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    const int shi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(shi, slo);
+}
+__device__ __forceinline__ double wave_total_dpp(double v) {
+    v = wave_dpp_add<0x111, 0xf>(v);      // row_shr:1
+    v = wave_dpp_add<0x112, 0xf>(v);      // row_shr:2
+    v = wave_dpp_add<0x114, 0xf>(v);      // row_shr:4
+    v = wave_dpp_add<0x118, 0xf>(v);      // row_shr:8   -> lane 15 of every row holds the row's sum
+    v = wave_dpp_add<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v = wave_dpp_add<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
 // Hillis-Steele inclusive scan across the wavefront (matches oracle hs64).
 __device__ __forceinline__ double wave_hs_scan(double v, int lane) {
 #pragma unroll

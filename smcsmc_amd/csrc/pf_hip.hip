@@ -911,6 +911,12 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
             if (PR.draws) A1.dt_ctr[(size_t)(PR.draws - 1) * A1.Np + p] = cx.ctr;      // where the next row's draws start
             A1.rg_widx[(size_t)cur * A1.Np + p] = widx;
             if (!do_extend) A1.widx[p] = widx;              // the state goes back to the general kernels
+            if (PR.ahead) {
+                // running ahead of the counts: what they check of the ring (records appended as of the row they count) cannot see
+                // this row's writes, so the writer checks them itself against the oldest generation any pending count can ask for
+                const unsigned kold = A1.gstart[(size_t)(A1.ctrl->g_safe % A1.Gcap) * A1.Np + p];
+                if (widx - kold > A1.cap && !A1.ctrl->err) A1.ctrl->err = ERR_LOG_OVERFLOW;
+            }
         } else {
             A1.widx[p] = widx;
         }
@@ -1282,7 +1288,7 @@ struct Win { int e, rf; double T0, T1, a_e, b_e; bool end_seq; };
 
 // local recombination map (record_local_recomb_events, count.cpp:559-613): per workgroup the differential
 // opportunity of its window is collected in LDS bins and flushed with one global atomic per touched bin
-#define PF_LBINS 2048
+#define PF_LBINS 1024
 struct LMap {
     double* lds;          // [PF_LBINS] bins of this workgroup, bin 0 = interval b0
     int nlds;             // bins in use: the window of the step spans few of them (the rest of a step's additions, if any, go to memory)
@@ -1335,10 +1341,87 @@ __device__ __forceinline__ void stretch_contrib(AccT<P>& acc, const KA& A, const
     double xs = ovl(x0, x1, W.a_e, W.b_e);
     if (!(xs > 0.0)) return;
     double len = slice_len<NI>(S, A.n - 1, A.n, W.T0, W.T1, 0.0, PF_INF, false);
+    // a tree that does not reach the epoch has no opportunity there: nothing to add to the sums (adding zero leaves them as
+    // they are) and nothing to the map -- most (record, epoch) pairs of the old epochs, whose windows hold the most records
+    if (!(len > 0.0)) return;
     double opp = len * xs;
     acc.v[AccT<P>::RO] += w * opp;
     acc.v[AccT<P>::RW] += w * w * opp;
     if (L.gopp) lmap_opportunity(L, x0 > W.a_e ? x0 : W.a_e, x1 < W.b_e ? x1 : W.b_e, w, opp);
+}
+
+// What one record adds to the sums of one epoch window (update_all_counts_single_evolevent, count.cpp:495-555): f0..f4 are the
+// record's head [x0, x1, h, t_c | piece reference, meta], S the heights of the tree in force over [x0, x1].
+template <int NI, int P, class KA>
+__device__ __forceinline__ void record_contrib_one(AccT<P>& acc, const KA& A, const Win& W, const LMap& L, double w, long long a,
+                                                   double f0, double f1, double f2, double f3, double f4, const double (&S)[NI]) {
+    using AC = AccT<P>;
+    const int n = A.n;
+    double x0 = f0, x1 = f1;
+    if (x1 < W.a_e) return;        // consumed by earlier windows
+    unsigned long long meta = (unsigned long long)__double_as_longlong(f4);
+    int type = (int)(meta & 0xff);
+    int lim_start = (int)((meta >> 8) & 0xff) - 1;
+    int lim_event = (int)((meta >> 16) & 0xff) - 1;
+    int n_eff = (int)((meta >> 24) & 0xff);
+    if (type <= 1) stretch_contrib<NI, P>(acc, A, W, L, w, x0, x1, S, lim_start);
+    if (type == 0 || type == 2) {
+        double h = f2;
+        bool inwin = (W.a_e <= x1) && (x1 < W.b_e);
+        if constexpr (P == 1) {
+            double tc = f3;
+            if (inwin && (W.rf & REC_COALMIGR) && W.e <= lim_event && tc >= W.T0 && h < W.T1) {      // (the floating lineage's path [h, t_c] meets the epoch)
+                double opp = slice_len<NI>(S, n_eff - 1, n_eff, W.T0, W.T1, h, tc, true);
+                acc.v[AC::CO] += w * opp;
+                acc.v[AC::CW] += w * w * opp;
+                if (W.T0 <= tc && tc < W.T1) acc.v[AC::CC] += w;
+            }
+        } else {
+            // structured models: the walk of the update left pieces (pf_mp.h PLog) -- population, partners, [t0, t1),
+            // event at t1 -- that are clipped to this epoch here; record flags and the epoch limit as above
+            (void)n_eff;
+            // without a tree dump the record says which epochs its pieces touch (piece_span, pf_mp.h)
+            const unsigned span = (unsigned)((meta >> 48) & 0xffff);
+            const bool elsewhere = !A.rec_trees && (span & 0x1000u) && (W.e < (int)(span & 63u) || W.e > (int)((span >> 6) & 63u));
+            if (inwin && (W.rf & REC_COALMIGR) && W.e <= lim_event && !elsewhere) {
+                unsigned long long ref = (unsigned long long)__double_as_longlong(f3);
+                unsigned pstart = (unsigned)(ref & 0xffffffffu), np_ = (unsigned)(ref >> 32);
+                if (A.pidx[a] - pstart > A.pcap || np_ > A.pcap) { if (!A.ctrl->err) A.ctrl->err = ERR_LOG_OVERFLOW; np_ = 0; }
+                for (unsigned j = 0; j < np_; ++j) {
+                    const double* q = A.plog + ((size_t)a * A.pcap + ((pstart + j) % A.pcap)) * 3;
+                    long long tag = __double_as_longlong(q[0]);
+                    const double t0 = q[1], t1 = q[2];
+                    const int pop = (int)(tag & 0xff), kind = (int)((tag >> 8) & 0xff), to = (int)((tag >> 16) & 0xff);
+                    const double lo = t0 > W.T0 ? t0 : W.T0, hi = t1 < W.T1 ? t1 : W.T1;
+                    const double mo = hi > lo ? hi - lo : 0.0;
+                    const bool ev = (kind & 3) != 0 && W.T0 <= t1 && t1 < W.T1;
+                    if (!(mo > 0.0) && !ev) continue;
+                    const double co = (double)((tag >> 24) & 0xff) * mo;
+#pragma unroll
+                    for (int pp = 0; pp < P; ++pp)
+                        if (pp == pop) {
+                            acc.v[AC::CO + pp] += w * co;
+                            acc.v[AC::CW + pp] += w * w * co;
+                            acc.v[AC::MO + pp] += w * mo;
+                            acc.v[AC::MW + pp] += w * w * mo;
+                            if (ev && (kind & 1)) acc.v[AC::CC + pp] += w;
+                            if (ev && (kind & 2)) {
+#pragma unroll
+                                for (int qq = 0; qq < P; ++qq)
+                                    if (qq == to) acc.v[AC::MC + pp * P + qq] += w;
+                            }
+                        }
+                }
+            }
+        }
+        if (type == 0) {
+            bool inwin_r = (W.a_e <= x1) && ((x1 < W.b_e) || W.end_seq);
+            if (inwin_r && (W.rf & REC_RECOMB) && W.e <= lim_event && W.T0 <= h && h < W.T1) {
+                acc.v[AC::RC] += w;
+                if (L.gopp) lmap_event(L, n, x1, h, (unsigned)((meta >> 32) & 0xffff), w);
+            }
+        }
+    }
 }
 
 // All fields of a record are fetched in one round of independent loads before anything is tested:
@@ -1346,7 +1429,6 @@ __device__ __forceinline__ void stretch_contrib(AccT<P>& acc, const KA& A, const
 template <int NI, int P, class KA>
 __device__ __forceinline__ void records_contrib(AccT<P>& acc, const KA& A, const Win& W, const LMap& L, double w, long long a,
                                                 unsigned k0, unsigned k1) {
-    using AC = AccT<P>;
     const int n = A.n;
     for (unsigned k = k0; k != k1; ++k) {
         const double* rec = rec_ptr(A, a, k);
@@ -1354,71 +1436,7 @@ __device__ __forceinline__ void records_contrib(AccT<P>& acc, const KA& A, const
         double S[NI];
 #pragma unroll
         for (int r = 0; r < NI; ++r) S[r] = r < n - 1 ? rec[5 + r] : 0.0;
-        double x0 = f0, x1 = f1;
-        if (x1 < W.a_e) continue;      // consumed by earlier windows
-        unsigned long long meta = (unsigned long long)__double_as_longlong(f4);
-        int type = (int)(meta & 0xff);
-        int lim_start = (int)((meta >> 8) & 0xff) - 1;
-        int lim_event = (int)((meta >> 16) & 0xff) - 1;
-        int n_eff = (int)((meta >> 24) & 0xff);
-        if (type <= 1) stretch_contrib<NI, P>(acc, A, W, L, w, x0, x1, S, lim_start);
-        if (type == 0 || type == 2) {
-            double h = f2;
-            bool inwin = (W.a_e <= x1) && (x1 < W.b_e);
-            if constexpr (P == 1) {
-                double tc = f3;
-                if (inwin && (W.rf & REC_COALMIGR) && W.e <= lim_event) {
-                    double opp = slice_len<NI>(S, n_eff - 1, n_eff, W.T0, W.T1, h, tc, true);
-                    acc.v[AC::CO] += w * opp;
-                    acc.v[AC::CW] += w * w * opp;
-                    if (W.T0 <= tc && tc < W.T1) acc.v[AC::CC] += w;
-                }
-            } else {
-                // structured models: the walk of the update left pieces (pf_mp.h PLog) -- population, partners, [t0, t1),
-                // event at t1 -- that are clipped to this epoch here; record flags and the epoch limit as above
-                (void)n_eff;
-                // without a tree dump the record says which epochs its pieces touch (piece_span, pf_mp.h)
-                const unsigned span = (unsigned)((meta >> 48) & 0xffff);
-                const bool elsewhere = !A.rec_trees && (span & 0x1000u) && (W.e < (int)(span & 63u) || W.e > (int)((span >> 6) & 63u));
-                if (inwin && (W.rf & REC_COALMIGR) && W.e <= lim_event && !elsewhere) {
-                    unsigned long long ref = (unsigned long long)__double_as_longlong(f3);
-                    unsigned pstart = (unsigned)(ref & 0xffffffffu), np_ = (unsigned)(ref >> 32);
-                    if (A.pidx[a] - pstart > A.pcap || np_ > A.pcap) { if (!A.ctrl->err) A.ctrl->err = ERR_LOG_OVERFLOW; np_ = 0; }
-                    for (unsigned j = 0; j < np_; ++j) {
-                        const double* q = A.plog + ((size_t)a * A.pcap + ((pstart + j) % A.pcap)) * 3;
-                        long long tag = __double_as_longlong(q[0]);
-                        const double t0 = q[1], t1 = q[2];
-                        const int pop = (int)(tag & 0xff), kind = (int)((tag >> 8) & 0xff), to = (int)((tag >> 16) & 0xff);
-                        const double lo = t0 > W.T0 ? t0 : W.T0, hi = t1 < W.T1 ? t1 : W.T1;
-                        const double mo = hi > lo ? hi - lo : 0.0;
-                        const bool ev = (kind & 3) != 0 && W.T0 <= t1 && t1 < W.T1;
-                        if (!(mo > 0.0) && !ev) continue;
-                        const double co = (double)((tag >> 24) & 0xff) * mo;
-#pragma unroll
-                        for (int pp = 0; pp < P; ++pp)
-                            if (pp == pop) {
-                                acc.v[AC::CO + pp] += w * co;
-                                acc.v[AC::CW + pp] += w * w * co;
-                                acc.v[AC::MO + pp] += w * mo;
-                                acc.v[AC::MW + pp] += w * w * mo;
-                                if (ev && (kind & 1)) acc.v[AC::CC + pp] += w;
-                                if (ev && (kind & 2)) {
-#pragma unroll
-                                    for (int qq = 0; qq < P; ++qq)
-                                        if (qq == to) acc.v[AC::MC + pp * P + qq] += w;
-                                }
-                            }
-                    }
-                }
-            }
-            if (type == 0) {
-                bool inwin_r = (W.a_e <= x1) && ((x1 < W.b_e) || W.end_seq);
-                if (inwin_r && (W.rf & REC_RECOMB) && W.e <= lim_event && W.T0 <= h && h < W.T1) {
-                    acc.v[AC::RC] += w;
-                    if (L.gopp) lmap_event(L, n, x1, h, (unsigned)((meta >> 32) & 0xffff), w);
-                }
-            }
-        }
+        record_contrib_one<NI, P>(acc, A, W, L, w, a, f0, f1, f2, f3, f4, S);
     }
 }
 
@@ -1450,6 +1468,19 @@ __device__ __forceinline__ CountSrc count_src_parity(const KA& A, int sp, int e)
     q.inv = c->step[sp].inv_T; q.G = c->step[sp].G;
     q.g_lo = e < A.E ? c->g_lo[e] : 0; q.g_hi = e < A.E ? c->g_hi[e] : 0;
     return q;
+}
+
+// LDS bins of the local recombination map: one array for whichever count body the workgroup runs
+__device__ __forceinline__ double* count_bins() {
+    __shared__ double bins[PF_LBINS];
+    return bins;
+}
+
+// LDS of the count roles: a workgroup runs one of the two bodies
+#define PF_COUNT_LDS_BYTES 14336
+__device__ __forceinline__ char* count_lds() {
+    __shared__ __attribute__((aligned(16))) char buf[PF_COUNT_LDS_BYTES];
+    return buf;
 }
 
 #define PF_CNT_TILE 2048      // generations whose run counts are staged in LDS at a time
@@ -1485,9 +1516,12 @@ template <int NM, int P, bool EXACT = false, class KA>
 __device__ __forceinline__ void count_body(const KA& A, const CountSrc& Q, int e, double win_a, double win_b, int bx, int nbxg) {
     constexpr int NI = NM - 1;
     using AC = AccT<P>;
-    __shared__ AC red[PF_BS / 64];
-    __shared__ int s_off[PF_CNT_TILE + 1];
-    __shared__ int s_wsum[PF_BS / 64];
+    // LDS from the count roles' common buffer (count_units_body is the other tenant)
+    static_assert(sizeof(AC) * (PF_BS / 64) + sizeof(int) * (PF_CNT_TILE + 1 + PF_BS / 64) + 16 <= PF_COUNT_LDS_BYTES, "count_body's LDS");
+    char* const cl = count_lds();
+    AC* const red = (AC*)cl;
+    int* const s_off = (int*)(cl + ((sizeof(AC) * (PF_BS / 64) + 15) & ~(size_t)15));
+    int* const s_wsum = s_off + PF_CNT_TILE + 1;
     const long long Np = A.Np;
     const int n = EXACT ? NM : A.n;
     const int G = Q.G;                                  // the generation the weights belong to
@@ -1497,7 +1531,7 @@ __device__ __forceinline__ void count_body(const KA& A, const CountSrc& Q, int e
     W.T0 = A.T[e]; W.T1 = e + 1 < A.E ? A.T[e + 1] : PF_INF;
     W.a_e = win_a; W.b_e = win_b;
     W.end_seq = (A.L == W.b_e);
-    __shared__ double s_lbins[PF_LBINS];
+    double* const s_lbins = count_bins();
     LMap L;
     L.lds = s_lbins; L.b0 = (long long)(W.a_e / 100.0); L.gopp = A.lmap_opp; L.gcnt = A.lmap_cnt; L.nbins = A.lmap_bins;
     {
@@ -1563,6 +1597,7 @@ __device__ __forceinline__ void count_body(const KA& A, const CountSrc& Q, int e
         // the front, where few ancestors are left: most of its workgroups have no task at all and leave here, before the bins,
         // the barriers and the reduction (adding zero to their accumulators is leaving them alone).
         if (tile_hi == g_hi && tile_lo == g_lo && (long long)bx * PF_BS >= T) return;
+        if (A.flags & (1 << 20)) return;          // probe: what the workgroups cost before their first task
         if (L.gopp && !bins_ready) {
             for (int k = threadIdx.x; k < L.nlds; k += PF_BS) s_lbins[k] = 0.0;
             __syncthreads();
@@ -1619,6 +1654,7 @@ __device__ __forceinline__ void count_body(const KA& A, const CountSrc& Q, int e
                     rwl[u] = Q.widx_live[aa[u]];
                 }
             }
+            if (A.flags & (1 << 21)) continue;        // probe: rounds 1 and 2 only
             // round 3, task by task.  One copy of the record loop for the four tasks: the task's values are picked with selects
             // (the arrays live in registers and cannot be indexed at run time).
 #pragma unroll 1
@@ -1676,6 +1712,271 @@ __device__ __forceinline__ void count_body(const KA& A, const CountSrc& Q, int e
         double t = red[0].v[k];
         for (int w = 1; w < PF_BS / 64; ++w) t += red[w].v[k];
         A.partial[((size_t)e * A.nbx + bx) * AC::NC + k] += t;      // this workgroup's own accumulator (folded by k_count_fin)
+    }
+}
+
+// ------------------------------------------------------------------ counting by generation (round 4)
+// count_body gives every epoch a column of workgroups that walks the (generation, ancestor run) pairs of the epoch's window: a
+// pair that lies in the windows of ten epochs -- the old epochs' lags are a row or two long, their windows all sit in the one or
+// two generations behind the front, where nearly every particle is still its own ancestor -- is fetched ten times (run list ->
+// posterior scan and record range -> records: three dependent rounds of loads each time), and that fetching is what a row's
+// counting costs (profiles/round3/count_wgs.md: about eight times the extend role's workgroup-time).  Here the unit of work is
+// the pair itself: 256 tasks of one generation, their weights and record ranges fetched once and held in registers while the
+// epochs whose windows meet that generation take their turns (the records are read again per epoch, from the cache).  A step
+// has a fixed number of count workgroups (PipeLaunch::ncw) that deal the units out among themselves in a fixed order -- every
+// workgroup builds the same small table of the step's generations (their epoch masks and task counts) -- so the sums are
+// grouped the same way in every run (bit-identical output), though not as count_body groups them.
+#define PF_CU_ECMAX 8           // most epochs of a generation's mask that one unit takes
+struct CuLds {
+    int glo[PF_EMAX], ghi[PF_EMAX];
+    double T[PF_EMAX + 1], wa[PF_EMAX], wb[PF_EMAX];
+    int rf[PF_EMAX];
+    unsigned long long mask[PF_BS];            // one generation per thread and tile: epochs whose window meets it
+    int nt[PF_BS];                             // its tasks (ancestor runs, or the live particles)
+    int uoff[PF_BS + 1];                       // exclusive prefix sum of its units
+    int wsum[PF_BS / 64];
+    // the unit in hand: its tasks' weights, slots and first records, the prefix sum of their record counts
+    int roff[PF_BS + 1];
+    double rw[PF_BS];
+    int ra[PF_BS];
+    unsigned rk0[PF_BS];
+    // its epochs and their shares of the local map's LDS bins
+    int ce[PF_CU_ECMAX], boff[PF_CU_ECMAX], bn[PF_CU_ECMAX];
+    long long bb0[PF_CU_ECMAX];
+    int bins_used;
+    double red[PF_BS / 64][PF_CU_ECMAX][6];
+};
+static_assert(sizeof(CuLds) <= PF_COUNT_LDS_BYTES, "CuLds must fit the count roles' LDS");
+
+template <int NM, bool EXACT, class KA>
+__device__ __forceinline__ void count_units_body(const KA& A, const CountSrc& Q, const Ctrl::RowInfo& r, int wg, int nwg) {
+    constexpr int NI = NM - 1;
+    using AC = AccT<1>;
+    CuLds& Z = *(CuLds*)count_lds();
+    double* const s_lbins = count_bins();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long Np = A.Np;
+    const int n = EXACT ? NM : A.n, E = A.E, G = Q.G;
+    const double inv = Q.inv;
+    const int first = r.first;
+    const int ec = A.cu_ec > 0 ? (A.cu_ec < PF_CU_ECMAX ? A.cu_ec : PF_CU_ECMAX) : 4;
+    if (tid < PF_EMAX) {
+        const bool mv = tid >= first && tid < E;
+        Z.glo[tid] = mv ? r.g_lo[tid] : 1;
+        Z.ghi[tid] = mv ? r.g_hi[tid] : 0;
+        Z.T[tid] = tid < E ? A.T[tid] : PF_INF;
+        Z.wa[tid] = mv ? r.wa[tid] : 0.0;
+        Z.wb[tid] = mv ? r.wb[tid] : 0.0;
+        Z.rf[tid] = tid < E ? A.recflags[tid] : 0;
+        if (tid == 0) Z.T[PF_EMAX] = PF_INF;
+    }
+    __syncthreads();
+    int gmin = 0x7fffffff, gmax = -1;
+    for (int e = first; e < E; ++e) {
+        const int a = Z.glo[e], b = Z.ghi[e];
+        if (b >= a) { gmin = a < gmin ? a : gmin; gmax = b > gmax ? b : gmax; }
+    }
+    if (gmax < gmin) return;
+    const bool lmap = A.lmap_opp != nullptr;
+    long long ubase = 0;
+    for (int thi = gmax; thi >= gmin; thi -= PF_BS) {
+        const int tlo = thi - PF_BS + 1 > gmin ? thi - PF_BS + 1 : gmin;
+        const int ntile = thi - tlo + 1;
+        __syncthreads();
+        {
+            const int g = thi - tid;
+            unsigned long long m = 0;
+            int nt = 0;
+            if (tid < ntile) {
+                for (int e = first; e < E; ++e)
+                    if (Z.glo[e] <= g && g <= Z.ghi[e]) m |= 1ull << e;
+                if (m) nt = g == G ? (int)Np : Q.lists.nruns[g % A.Gcap];
+                if (nt < 0 || nt > (int)Np) nt = 0;          // an overflowed ledger ring (a reported error) aliases generations
+            }
+            // units of the generation: (block of PF_BS tasks) x (chunk of `ec` epochs of its mask)
+            const int nu = ((nt + PF_BS - 1) / PF_BS) * ((__popcll(m) + ec - 1) / ec);
+            int incl = nu;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                int o = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += o;
+            }
+            if (lane == 63) Z.wsum[wave] = incl;
+            __syncthreads();
+            int base = 0;
+            for (int w = 0; w < wave; ++w) base += Z.wsum[w];
+            Z.mask[tid] = m; Z.nt[tid] = nt; Z.uoff[tid] = base + incl - nu;
+            if (tid == PF_BS - 1) Z.uoff[PF_BS] = base + incl;
+        }
+        __syncthreads();
+        const int total = Z.uoff[PF_BS];
+        int u = (int)(((long long)wg - ubase) % nwg);
+        if (u < 0) u += nwg;
+        for (; u < total; u += nwg) {
+            int lo_i = 0, hi_i = PF_BS;             // generation of unit u: the last index with uoff[index] <= u
+            while (hi_i - lo_i > 1) {
+                const int mid = (lo_i + hi_i) >> 1;
+                if (Z.uoff[mid] <= u) lo_i = mid; else hi_i = mid;
+            }
+            const int g = thi - lo_i;
+            unsigned long long gm = Z.mask[lo_i];
+            const int ntk = Z.nt[lo_i];
+            const int nchunks = (__popcll(gm) + ec - 1) / ec;
+            const int chunk = (u - Z.uoff[lo_i]) % nchunks;
+            const long long task = (long long)((u - Z.uoff[lo_i]) / nchunks) * PF_BS + tid;
+            {
+                // the unit's chunk of the generation's epochs: set bits [chunk * ec, chunk * ec + ec) of the mask
+                for (int k = 0; k < chunk * ec; ++k) gm &= gm - 1;
+                unsigned long long keep = 0, t = gm;
+                for (int k = 0; k < ec && t; ++k) { keep |= t & (0ull - t); t &= t - 1; }
+                gm = keep;
+            }
+            const int nce = __popcll(gm);
+            const bool valid = task < ntk, live = g == G;
+            // rounds 1 and 2: the task's weight and its range of records
+            double w = 0.0;
+            long long a = 0;
+            unsigned k0 = 0, k1 = 0;
+            bool ok = false;
+            if (valid && live) {
+                a = task;
+                w = Q.w[a] * inv;
+                k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
+                k1 = Q.widx[a];
+                ok = w != 0.0;
+                if (ok && k1 - k0 > A.cap) { if (!A.ctrl->err) A.ctrl->err = ERR_LOG_OVERFLOW; k1 = k0; }
+            } else if (valid) {
+                const int* rst = Q.lists.st + (size_t)(g % A.Gcap) * Np;
+                const int* ran = Q.lists.anc + (size_t)(g % A.Gcap) * Np;
+                const int q0 = rst[task];
+                const int q1 = task + 1 < ntk ? rst[task + 1] : (int)Np;
+                a = ran[task];
+                if (!(q1 <= q0 || q1 > (int)Np || q0 < 0 || a < 0 || a >= Np)) {
+                    const double hi = Q.offp[(q1 - 1) >> 6] + Q.scanp[q1 - 1];
+                    const double lo = q0 > 0 ? Q.offp[(q0 - 1) >> 6] + Q.scanp[q0 - 1] : 0.0;
+                    k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
+                    k1 = A.gstart[(size_t)((g + 1) % A.Gcap) * Np + a];
+                    const unsigned wl = Q.widx_live[a];
+                    w = (hi - lo) * inv;
+                    ok = w > 0.0;
+                    if (ok && (wl - k0 > A.cap || k1 - k0 > A.cap)) { if (!A.ctrl->err) A.ctrl->err = ERR_LOG_OVERFLOW; ok = false; }
+                }
+            }
+            // the records of the unit's tasks, flattened: one record per thread and pass (a live particle's open stretch is
+            // its first), so that no thread waits for the task with the most records
+            const int nrec = ok ? (int)(k1 - k0) + (live ? 1 : 0) : 0;
+            {
+                int incl = nrec;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    int o = __shfl_up(incl, d, 64);
+                    if (lane >= d) incl += o;
+                }
+                __syncthreads();                       // (the tables of the previous unit are no longer read)
+                if (lane == 63) Z.wsum[wave] = incl;
+                __syncthreads();
+                int base = 0;
+                for (int v = 0; v < wave; ++v) base += Z.wsum[v];
+                Z.roff[tid] = base + incl - nrec; Z.rw[tid] = w; Z.ra[tid] = (int)a; Z.rk0[tid] = k0;
+                if (tid == PF_BS - 1) Z.roff[PF_BS] = base + incl;
+                if (tid < PF_CU_ECMAX) {
+                    unsigned long long q = gm;
+                    for (int j = 0; j < tid && q; ++j) q &= q - 1;
+                    Z.ce[tid] = q ? __builtin_ctzll(q) : 0;
+                }
+                __syncthreads();
+                if (lmap && tid == 0) {
+                    // the LDS bins of the local map are shared out among the unit's epochs, oldest first (their windows are a
+                    // row or two wide); an epoch that finds no room adds to memory directly
+                    int used = 0;
+                    for (int j = nce - 1; j >= 0; --j) {
+                        const int e = Z.ce[j];
+                        const long long b0 = (long long)(Z.wa[e] / 100.0);
+                        const long long span = (long long)(Z.wb[e] / 100.0) - b0 + 4;
+                        const int want = span < 1 ? 1 : (span > PF_LBINS ? PF_LBINS : (int)span);
+                        const int got = used + want <= PF_LBINS ? want : 0;
+                        Z.bb0[j] = b0; Z.boff[j] = used; Z.bn[j] = got;
+                        used += got;
+                    }
+                    Z.bins_used = used;
+                }
+                if (lmap) {
+                    __syncthreads();
+                    for (int k = tid; k < Z.bins_used; k += PF_BS) s_lbins[k] = 0.0;
+                    __syncthreads();
+                }
+            }
+            const int R = Z.roff[PF_BS];
+            for (int rb = 0; rb < R; rb += PF_BS) {
+                const int j = rb + tid;
+                const bool have = j < R;
+                double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0, f4 = 0.0, wv = 0.0;
+                long long av = 0;
+                double S[NI];
+#pragma unroll
+                for (int q = 0; q < NI; ++q) S[q] = 0.0;
+                if (have) {
+                    int li = 0, hi2 = PF_BS;
+                    while (hi2 - li > 1) {
+                        const int mid = (li + hi2) >> 1;
+                        if (Z.roff[mid] <= j) li = mid; else hi2 = mid;
+                    }
+                    const int d = j - Z.roff[li];
+                    wv = Z.rw[li]; av = Z.ra[li];
+                    if (live && d == 0) {
+                        // the open stretch of a live particle: a stretch record that ends nowhere yet
+                        f0 = Q.xm[av]; f1 = PF_INF;
+                        f4 = __longlong_as_double((long long)make_meta(1, Q.ml[av], -1, n));
+#pragma unroll
+                        for (int q = 0; q < NI; ++q) S[q] = q < n - 1 ? Q.S[(size_t)q * Np + av] : 0.0;
+                    } else {
+                        const double* rec = rec_ptr(A, av, Z.rk0[li] + (unsigned)(d - (live ? 1 : 0)));
+                        f0 = rec[0]; f1 = rec[1]; f2 = rec[2]; f3 = rec[3]; f4 = rec[4];
+#pragma unroll
+                        for (int q = 0; q < NI; ++q) S[q] = q < n - 1 ? rec[5 + q] : 0.0;
+                    }
+                }
+#pragma unroll 1
+                for (int jj = 0; jj < nce; ++jj) {
+                    const int e = Z.ce[jj];
+                    Win W;
+                    W.e = e; W.rf = Z.rf[e]; W.T0 = Z.T[e]; W.T1 = e + 1 < E ? Z.T[e + 1] : PF_INF; W.a_e = Z.wa[e]; W.b_e = Z.wb[e];
+                    W.end_seq = (A.L == W.b_e);
+                    LMap L;
+                    L.lds = s_lbins + Z.boff[jj]; L.b0 = Z.bb0[jj]; L.nlds = Z.bn[jj]; L.gopp = A.lmap_opp; L.gcnt = A.lmap_cnt; L.nbins = A.lmap_bins;
+                    AC acc;
+#pragma unroll
+                    for (int k = 0; k < AC::NC; ++k) acc.v[k] = 0.0;
+                    if (have) record_contrib_one<NI, 1>(acc, A, W, L, wv, av, f0, f1, f2, f3, f4, S);
+#pragma unroll
+                    for (int k = 0; k < AC::NC; ++k) {
+                        const double t = wave_total_dpp(acc.v[k]);
+                        if (lane == 0) Z.red[wave][jj][k] = t;
+                    }
+                }
+                __syncthreads();
+                // this workgroup's accumulators of the unit's epochs (folded by k_count_fin): wavefronts in order
+                if (tid < nce * AC::NC) {
+                    const int jj = tid / AC::NC, k = tid % AC::NC;
+                    double t = Z.red[0][jj][k];
+                    for (int v = 1; v < PF_BS / 64; ++v) t += Z.red[v][jj][k];
+                    if (t != 0.0) A.partial[((size_t)Z.ce[jj] * A.nbx + wg) * AC::NC + k] += t;
+                }
+                __syncthreads();
+            }
+            if (lmap) {
+                for (int jj = nce - 1; jj >= 0; --jj) {
+                    const int nb_e = Z.bn[jj], off = Z.boff[jj];
+                    const long long b0 = Z.bb0[jj];
+                    for (int k = tid; k < nb_e; k += PF_BS) {
+                        const double v = s_lbins[off + k];
+                        const long long idx = b0 + k;
+                        if (v != 0.0 && idx < A.lmap_bins) atomicAdd(&A.lmap_opp[idx], v);
+                    }
+                }
+            }
+        }
+        ubase += total;
     }
 }
 
@@ -1960,6 +2261,7 @@ __device__ __forceinline__ void pipe_bookkeeping(const KA& A, const PipeLds& q, 
         int gr = c->g_lo[0];
         for (int e = 1; e < E; ++e) gr = c->g_lo[e] < gr ? c->g_lo[e] : gr;
         c->g_retain = gr;
+        c->g_safe = c->ri[(slot + PF_RING - 2) & (PF_RING - 1)].g_retain;      // (the entry of two rows ago, or what the seed of the call left there)
         c->delayed_opp += W.b[E - 1] - W.a[E - 1];
         if (BIASED) {
             long long npend = 0;      // update_delayed_weight_count (count.cpp:395-397)
@@ -1986,7 +2288,8 @@ __device__ __forceinline__ void pipe_bookkeeping(const KA& A, const PipeLds& q, 
             A.gen_x0[(G + 1) % A.Gcap] = PL.b_pos;
             c->n_resample = n_res + 1;
             c->lver ^= 1;                    // the ledger upkeep of this row (next launch) writes the other copy
-            if (G + 1 - gr >= A.Gcap - 1) c->err = ERR_GEN_OVERFLOW;
+            // an extend role that is a launch of its own is already writing offspring tables and log marks of up to PF_RING newer generations
+            if (G + 1 - gr >= A.Gcap - 1 - (PL.ahead ? PF_RING : 0)) c->err = ERR_GEN_OVERFLOW;
             if (A.rec_trees && G + 2 >= A.Gcap) c->err = ERR_GEN_OVERFLOW;      // -arg keeps every generation
         }
         c->gen_prev = c->gen; c->nres_prev = c->n_resample;
@@ -2023,7 +2326,7 @@ __device__ __forceinline__ void draw_role(const KA& A, int tb, int nT, int par) 
     }
 }
 
-template <int NM, bool BIASED, bool EXACT, bool TREES, int P = 1, class KA>
+template <int NM, bool BIASED, bool EXACT, bool TREES, int P = 1, bool BLC = false, class KA>
 __device__ __forceinline__ void pipe_roles(const KA& A, long long s, const PipeLaunch& PL, const Windows& Wb) {
     const int bx = (int)blockIdx.x;
     const int nb = PL.nb;
@@ -2055,11 +2358,39 @@ __device__ __forceinline__ void pipe_roles(const KA& A, long long s, const PipeL
         return;
     }
     const int idx = lb - PL.nL;
+    if constexpr (P == 1 && BLC) {
+        // (only in the launch of the bookkeeping / ledger / count roles of the split arrangement: in the one launch of k_sweep the
+        // body would raise the kernel's register count past the 168 that let three workgroups share a compute unit)
+        if (PL.units) {
+            // counting by generation: the workgroups of the step deal the (generation, 256 tasks) units out among themselves
+            if (idx >= PL.ncw || r.first >= A.E) return;
+            const DState st = state_slot(A, PL.lc_slot);
+            CountSrc Q;
+            Q.w = st.w_post; Q.S = st.S; Q.xm = st.x_mark; Q.ml = st.mark_limit;
+            Q.widx = A.rg_widx + (size_t)PL.lc_slot * A.Np;
+            Q.widx_live = A.rg_widx + (size_t)PL.live_slot * A.Np;
+            Q.scanp = A.rg_scanp + (size_t)PL.lc_slot * A.Np;
+            Q.offp = A.rg_coffp + (size_t)PL.lc_slot * A.nc;
+            Q.lists = run_lists(A, r.lver);
+            Q.inv = r.inv_T; Q.G = r.gen; Q.g_lo = 0; Q.g_hi = 0;
+            count_units_body<NM, EXACT>(A, Q, r, idx, PL.ncw);
+            return;
+        }
+    }
     // the columns of the oldest epochs first: their lags are the shortest, their windows sit right behind the front where
     // nearly every particle is still its own ancestor, and their workgroups are the long ones -- dispatched last they were
     // what a launch ended with
-    const int e = (A.flags & 512) ? r.first + idx / PL.ncw : A.E - 1 - idx / PL.ncw;
+    int e, cbx, cnb;
+    if (A.cw_off && !(A.flags & 512)) {
+        int j = 0;
+        while (j + 1 < A.E && A.cw_off[j + 1] <= idx) ++j;
+        e = A.E - 1 - j; cbx = idx - A.cw_off[j]; cnb = A.cw_off[j + 1] - A.cw_off[j];
+    } else {
+        e = (A.flags & 512) ? r.first + idx / PL.ncw : A.E - 1 - idx / PL.ncw;
+        cbx = idx % PL.ncw; cnb = PL.ncw;
+    }
     if (e >= A.E || e < r.first) return;
+    if (A.flags & (1 << 22)) return;          // probe: the count workgroups do nothing at all
     const DState st = state_slot(A, PL.lc_slot);
     CountSrc Q;
     Q.w = st.w_post; Q.S = st.S; Q.xm = st.x_mark; Q.ml = st.mark_limit;
@@ -2069,7 +2400,7 @@ __device__ __forceinline__ void pipe_roles(const KA& A, long long s, const PipeL
     Q.offp = A.rg_coffp + (size_t)PL.lc_slot * A.nc;
     Q.lists = run_lists(A, r.lver);
     Q.inv = r.inv_T; Q.G = r.gen; Q.g_lo = r.g_lo[e]; Q.g_hi = r.g_hi[e];
-    count_body<NM, P, EXACT>(A, Q, e, r.wa[e], r.wb[e], idx % PL.ncw, PL.ncw);
+    count_body<NM, P, EXACT>(A, Q, e, r.wa[e], r.wb[e], cbx, cnb);
 }
 
 template <int NM, bool BIASED, bool EXACT, bool TREES>
@@ -2112,7 +2443,7 @@ __device__ __forceinline__ void sweep_windows(const KA& A, Ctrl* c, double pos, 
 }
 
 template <int NM, bool BIASED, bool EXACT, bool TREES>
-__global__ __launch_bounds__(PF_BS) void k_sweep(const SweepChunk* tab_g, long long t, int nb) {
+__device__ __forceinline__ void sweep_kernel_body(const SweepChunk* tab_g, long long t, int nb) {
     SweepChunkC* tab = (SweepChunkC*)tab_g;
     SweepChunkC& ch = tab[blockIdx.y];
     KArgsC& A = ch.A;
@@ -2123,6 +2454,19 @@ __global__ __launch_bounds__(PF_BS) void k_sweep(const SweepChunk* tab_g, long l
     if (ch.split) PL.nL = -2;                              // extend and draw roles only: the other roles are k_sweep_blc's
     else if ((int)blockIdx.x == nb && PL.b_slot >= 0) sweep_windows(A, A.ctrl, PL.b_pos, W);
     pipe_roles<NM, BIASED, EXACT, TREES>(A, s, PL, W);
+}
+template <int NM, bool BIASED, bool EXACT, bool TREES>
+__global__ __launch_bounds__(PF_BS) void k_sweep(const SweepChunk* tab_g, long long t, int nb) {
+    sweep_kernel_body<NM, BIASED, EXACT, TREES>(tab_g, t, nb);
+}
+// The headline instance (at most four haplotypes, no focused sampling) with the occupancy stated: three workgroups per compute
+// unit, i.e. at most 168 registers a thread -- several chunks per GPU lose 15 % with two.  Left to itself
+// the register allocator aims at the occupancy the kernel's LDS allows: that gave 168 while the count roles' LDS was 8 KB
+// larger and 172-174 since round 4.  (The instances for more haplotypes or focused sampling need about 190 registers and would
+// spill to scratch memory under the same attribute; they stay as they are.)
+template <bool EXACT, bool TREES>
+__global__ __launch_bounds__(PF_BS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_sweep4(const SweepChunk* tab_g, long long t, int nb) {
+    sweep_kernel_body<4, false, EXACT, TREES>(tab_g, t, nb);
 }
 
 // The bookkeeping, ledger and count roles of a step as a launch of their own: what the structured models run on the counting
@@ -2140,7 +2484,7 @@ __global__ __launch_bounds__(PF_BS) void k_sweep_blc(const SweepChunk* tab_g, lo
     if (!sweep_plan(ch, s, 0, PL)) return;
     PL.nT = 0;                                             // the draw role rides with the extend launch
     if ((int)blockIdx.x == 0 && PL.b_slot >= 0) sweep_windows(A, A.ctrl, PL.b_pos, W);
-    pipe_roles<NM, BIASED, false, false, P>(A, s, PL, W);
+    pipe_roles<NM, BIASED, false, false, P, true>(A, s, PL, W);
 }
 
 // first step of a call: the seed of k_pipe_seed, and the chunk's window state
@@ -2767,7 +3111,9 @@ struct pf_handle {
     bool two_launch_rows = false; // PF_DEBUG_TWO_LAUNCH: the round-1 row pipeline (k_row + k_decide_ledger) instead of k_pipe
     bool pipe = false;            // the single-launch pipeline applies (one population, n <= 8; rings allocated)
     size_t smem_pipe = 0;
-    int ncw = 0;                  // count workgroups per epoch in the row pipeline (pf_params.count_wgs)
+    int ncw = 0;                  // count workgroups per epoch in the row pipeline (pf_params.count_wgs): the most a column gets
+    std::vector<int> cw_off;      // [E + 1] first count workgroup of the j-th column, oldest epoch first (KArgs::cw_off)
+    bool count_units = false;     // k_sweep / k_sweep_blc with one population: the counts by generation (count_units_body), ncw workgroups per step
     bool split_roles = false;     // PF_DEBUG_SPLIT_ROLES: one population too runs the extend role and the other roles as two launches on two streams
     bool pipe_mp = false;         // structured models on the row pipeline: extend launches on the filter stream, the other roles on the counting stream
     size_t smem_sweep_x = 0;
@@ -3008,6 +3354,7 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     KArgs& A = h->A;
     memset(&A, 0, sizeof(A));
     A.E = E; A.n = n; A.flags = m->flags | (h->no_spec_stage ? 256 : 0) | ((p->debug & PF_DEBUG_COUNT_YOUNG_FIRST) ? 512 : 0);
+    A.flags |= p->debug & (7 << 20);        // profiling probes of the count role (bits 20, 21: the sums are then wrong on purpose)
     A.L = m->loci_length; A.mu = m->mutation_rate; A.rho = m->recombination_rate;
     A.Np = Np;
     A.mcap = mcap;
@@ -3185,11 +3532,40 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     }
     // accumulators of the count workgroups per epoch (measured: four times as many count workgroups per epoch in the row
     // pipeline made a row 15 % slower -- the launch then holds 5 000 workgroups of 30 KB LDS each, four rounds of the chip)
+    // per-epoch accumulators: one per count workgroup of a column (count_body) or of a step (count_units_body, an experiment of
+    // round 4: by default four per 256 particles -- a unit is 256 tasks of one generation for four of its epochs)
     A.nbx = h->nblocks;
+    if (P == 1 && (p->debug & PF_DEBUG_COUNT_UNITS) && (p->debug & PF_DEBUG_SPLIT_ROLES))
+        A.nbx = p->count_wgs > 0 ? std::max(p->count_wgs, 1) : std::max(4 * h->nblocks, 16);
+    A.cu_ec = ((p->debug >> 16) & 15) ? ((p->debug >> 16) & 15) : 4;       // (bits 16-19 of debug: tuning experiments)
     // the row pipeline spreads an epoch's count tasks (the ancestor runs of the generations in its window: for the old epochs,
     // whose lag is a few rows, nearly one per particle) over this many workgroups; fewer is slower (C3 shape, one chunk: 40
     // workgroups 32.9 us per row, 16: 38.7, 8: 53.7, 4: 91.4, 2: 168 -- profiles/round3/count_wgs.md)
-    h->ncw = p->count_wgs > 0 ? std::min<int>(p->count_wgs, h->nblocks) : h->nblocks;
+    h->count_units = P == 1 && (p->debug & PF_DEBUG_COUNT_UNITS) && (p->debug & PF_DEBUG_SPLIT_ROLES) && !h->use_k_pipe && !(p->flags & 2);
+    if (h->count_units && h->pipe) h->ncw = A.nbx;     // workgroups per step
+    else h->ncw = p->count_wgs > 0 ? std::min<int>(p->count_wgs, h->nblocks) : h->nblocks;
+    {
+        // count workgroups per epoch column of the row pipeline: the tasks of an epoch are the live ancestors of the generations in its
+        // window, about Np / (1 + depth), depth = generations between window and front, i.e. in proportion to its lag: a column whose
+        // lag is a few rows long gets all h->ncw workgroups, the young epochs' columns, whose workgroups mostly found nothing to do
+        // and left after their prologue, as few as two.  (What a workgroup finds it strides over: any number is correct.)
+        h->cw_off.assign(E + 1, 0);
+        for (int j = 0; j < E; ++j) {
+            const double lag = m->lags[E - 1 - j];
+            int w = (int)std::ceil((double)h->ncw * std::min(1.0, 2500.0 / std::max(lag, 1.0)));
+            w = std::max(std::min(2, h->ncw), std::min(w, h->ncw));
+            // (only when the caller set count_wgs, i.e. runs several chunks side by side and wants fewer workgroups: a single chunk
+            // leaves most of the chip idle, and there every column is shortest with all the workgroups it can get)
+            if ((p->debug & PF_DEBUG_COUNT_YOUNG_FIRST) || p->count_wgs <= 0) w = h->ncw;
+            h->cw_off[j + 1] = h->cw_off[j] + w;
+        }
+        int* dcw = nullptr;
+        if (h->pipe || h->pipe_mp) {
+            rc |= dalloc(h, &dcw, E + 1);
+            if (!rc) { hipMemcpyAsync(dcw, h->cw_off.data(), (size_t)(E + 1) * 4, hipMemcpyHostToDevice, h->stream); hipStreamSynchronize(h->stream); }
+            A.cw_off = (p->debug & PF_DEBUG_COUNT_YOUNG_FIRST) ? nullptr : dcw;
+        }
+    }
     rc |= dalloc(h, &A.totals, (size_t)A.ncol * E);
     rc |= dalloc(h, &A.partial, (size_t)E * A.nbx * A.ncol);
     A.max_trace_events = h->max_trace_events;
@@ -3227,6 +3603,10 @@ pf_handle* pf_create(const pf_model* m, const pf_params* p, int device) {
     }
     if ((p->gen_cap > 0 && p->gen_cap < 4) || (p->log_cap > 0 && p->log_cap < 4)) {
         g_err = "pf_create: log_cap and gen_cap must be at least 4";
+        return nullptr;
+    }
+    if (p->gen_cap > 0 && p->gen_cap < PF_RING + 4 && (m->n_pops > 1 || (p->debug & PF_DEBUG_SPLIT_ROLES))) {
+        g_err = "pf_create: gen_cap must be at least 20 when the extend role runs ahead of the counts (structured models, PF_DEBUG_SPLIT_ROLES)";
         return nullptr;
     }
     return create_impl(m, p, device, p->log_cap > 0 ? p->log_cap : (trees ? 131072 : 16384),
@@ -3666,7 +4046,7 @@ static int run_pipeline(pf_handle* h, long long s_begin, long long s_end) {
         PL.nL = PL.lc_slot >= 0 ? nL_full : 0;
         PL.ncw = h->ncw;
         PL.nT = 0; PL.row.draws = 0;               // k_pipe keeps no draw table
-        const int ncount_wg = (PL.lc_slot >= 0 && W2.first < E) ? PL.ncw * (E - W2.first) : 0;
+        const int ncount_wg = (PL.lc_slot >= 0 && W2.first < E) ? h->cw_off[E - W2.first] : 0;
         if (ncount_wg > 0) h->fin_pending = true;
         const bool t = extend && timing_on(h, s);
         {
@@ -3702,15 +4082,21 @@ template <int NM, bool BIASED>
 static void launch_sweep(pf_handle* h, const dim3& grid, long long t) {
     const dim3 blk(PF_BS);
     const size_t lds = h->smem_pipe;
-    if (h->A.rec_trees) hipLaunchKernelGGL((k_sweep<NM, BIASED, false, true>), grid, blk, lds, h->stream, h->d_sweep, t, h->nblocks);
-    else if (h->n == NM) hipLaunchKernelGGL((k_sweep<NM, BIASED, true, false>), grid, blk, lds, h->stream, h->d_sweep, t, h->nblocks);
-    else hipLaunchKernelGGL((k_sweep<NM, BIASED, false, false>), grid, blk, lds, h->stream, h->d_sweep, t, h->nblocks);
+    if constexpr (NM == 4 && !BIASED) {
+        if (h->A.rec_trees) hipLaunchKernelGGL((k_sweep4<false, true>), grid, blk, lds, h->stream, h->d_sweep, t, h->nblocks);
+        else if (h->n == NM) hipLaunchKernelGGL((k_sweep4<true, false>), grid, blk, lds, h->stream, h->d_sweep, t, h->nblocks);
+        else hipLaunchKernelGGL((k_sweep4<false, false>), grid, blk, lds, h->stream, h->d_sweep, t, h->nblocks);
+    } else {
+        if (h->A.rec_trees) hipLaunchKernelGGL((k_sweep<NM, BIASED, false, true>), grid, blk, lds, h->stream, h->d_sweep, t, h->nblocks);
+        else if (h->n == NM) hipLaunchKernelGGL((k_sweep<NM, BIASED, true, false>), grid, blk, lds, h->stream, h->d_sweep, t, h->nblocks);
+        else hipLaunchKernelGGL((k_sweep<NM, BIASED, false, false>), grid, blk, lds, h->stream, h->d_sweep, t, h->nblocks);
+    }
 }
 
 static bool sweep_compatible(const pf_handle* a, const pf_handle* b) {
     const bool ba = a->A.n_bias > 0 || a->A.g_K > 0, bb = b->A.n_bias > 0 || b->A.g_K > 0;
     return a->device == b->device && a->Np == b->Np && a->n == b->n && a->E == b->E && a->P == b->P && ba == bb &&
-           a->A.rec_trees == b->A.rec_trees && a->ncw == b->ncw && a->smem_pipe == b->smem_pipe && a->no_count == b->no_count &&
+           a->A.rec_trees == b->A.rec_trees && a->ncw == b->ncw && a->cw_off == b->cw_off && a->count_units == b->count_units && a->smem_pipe == b->smem_pipe && a->no_count == b->no_count &&
            (a->A.dt_tab != nullptr) == (b->A.dt_tab != nullptr);
 }
 
@@ -3744,6 +4130,7 @@ static long long sweep_table(pf_handle* const* hs, int nh, long long s_begin, lo
         ch.nblk = g->nblocks;
         ch.nT = (g->A.dt_tab && g->P == 1) ? g->nblocks : 0;
         ch.split = (g->P == 1 && g->split_roles && !g->A.rec_trees) ? 1 : 0;
+        ch.units = g->count_units ? 1 : 0;
         if (last >= s_begin) steps = std::max(steps, last - s_begin + 3);
     }
     *failed = false;
@@ -3784,7 +4171,8 @@ static int run_sweep(pf_handle* const* hs, int nh, long long s_begin, long long 
         int columns = 0;
         for (int k = 0; k < nh; ++k)
             if (s >= s_begin + 2 && s - 2 <= h->h_sweep[k].s_last && !hs[k]->no_count) columns = std::max(columns, E - W2[k].first);
-        const dim3 grid((unsigned)(nb + 1 + h->h_sweep[0].nT + nL_full + h->ncw * columns), (unsigned)nh);
+        const int ncount = h->count_units ? (columns > 0 ? h->ncw : 0) : h->cw_off[columns];
+        const dim3 grid((unsigned)(nb + 1 + h->h_sweep[0].nT + nL_full + ncount), (unsigned)nh);
         const bool tm_on = timing_on(h, s);
         {
             Timed tm(h, 0, tm_on);
@@ -3873,7 +4261,8 @@ static int run_sweep_mp(pf_handle* h, long long s_begin, long long s_end) {
         if (check_launch("k_sweep (extend role)")) return -1;
         hipStreamWaitEvent(h->cstream, t >= 1 ? h->ev_x[(size_t)((t - 1) & 15)] : seeded, 0);
         const int columns = (s >= s_begin + 2 && s - 2 <= last && !h->no_count) ? E - W2.first : 0;
-        const dim3 grid((unsigned)(1 + nL_full + h->ncw * columns), 1u), blk(PF_BS);
+        const int ncount = h->count_units ? (columns > 0 ? h->ncw : 0) : h->cw_off[columns];
+        const dim3 grid((unsigned)(1 + nL_full + ncount), 1u), blk(PF_BS);
         hipEvent_t done = h->ev_blc[(size_t)(t & 15)];
 #define PF_LAUNCH_BLC(NMV, PV, BV) hipExtLaunchKernelGGL((k_sweep_blc<NMV, PV, BV>), grid, blk, h->smem_pipe, h->cstream, nullptr, done, 0, h->d_sweep, t)
         if (h->P == 1) { if (h->n <= 4) { if (biased) PF_LAUNCH_BLC(4, 1, true); else PF_LAUNCH_BLC(4, 1, false); } else { if (biased) PF_LAUNCH_BLC(8, 1, true); else PF_LAUNCH_BLC(8, 1, false); } }
@@ -3897,21 +4286,30 @@ static int run_sweep_mp(pf_handle* h, long long s_begin, long long s_end) {
     return 0;
 }
 
-int pf_run_many(pf_handle* const* handles, int32_t n_handles, int64_t s_begin, int64_t s_end) {
-    if (n_handles < 1 || !handles || !handles[0]) { g_err = "pf_run_many: no handles"; return -1; }
+// why pf_run_many would refuse these handles (null: it would not)
+static const char* run_many_refusal(pf_handle* const* handles, int32_t n_handles) {
+    if (n_handles < 1 || !handles || !handles[0]) return "pf_run_many: no handles";
     pf_handle* h = handles[0];
-    HIPCHK(hipSetDevice(h->device));
     for (int k = 0; k < n_handles; ++k) {
         pf_handle* g = handles[k];
-        if (!g) { g_err = "pf_run_many: null handle"; return -1; }
-        if (s_begin < 0) { g_err = "segment range out of bounds"; return -1; }        // a chunk with fewer rows sits the call out
-        if (!(extend_can_fuse(g) && g->pipe && !g->two_launch_rows)) {
-            g_err = "pf_run_many: the chunks must run on the single-launch row pipeline (one population, at most 8 haplotypes, no look-ahead)";
-            return -1;
-        }
-        if (!sweep_compatible(h, g)) { g_err = "pf_run_many: the chunks must share device, particle count, haplotypes, epochs and options"; return -1; }
-        for (int j = 0; j < k; ++j) if (handles[j] == g) { g_err = "pf_run_many: a handle appears twice"; return -1; }
+        if (!g) return "pf_run_many: null handle";
+        if (!(extend_can_fuse(g) && g->pipe && !g->two_launch_rows))
+            return "pf_run_many: the chunks must run on the single-launch row pipeline (one population, at most 8 haplotypes, no look-ahead)";
+        if (!sweep_compatible(h, g)) return "pf_run_many: the chunks must share device, particle count, haplotypes, epochs and options";
+        for (int j = 0; j < k; ++j) if (handles[j] == g) return "pf_run_many: a handle appears twice";
     }
+    return nullptr;
+}
+
+int pf_can_run_many(pf_handle* const* handles, int32_t n_handles) {
+    return run_many_refusal(handles, n_handles) == nullptr ? 1 : 0;
+}
+
+int pf_run_many(pf_handle* const* handles, int32_t n_handles, int64_t s_begin, int64_t s_end) {
+    if (const char* why = run_many_refusal(handles, n_handles)) { g_err = why; return -1; }
+    pf_handle* h = handles[0];
+    HIPCHK(hipSetDevice(h->device));
+    if (s_begin < 0) { g_err = "segment range out of bounds"; return -1; }        // a chunk with fewer rows sits the call out
     return run_sweep(handles, n_handles, s_begin, s_end);
 }
 

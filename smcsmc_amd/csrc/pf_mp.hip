@@ -982,6 +982,12 @@ __device__ __forceinline__ void extend_mpr_body(const KA& A, long long s, int fu
         if constexpr (PIPE) {
             A.rg_widx[(size_t)cur * A.Np + p] = widx;
             if (!do_extend) A.widx[p] = widx;              // the state goes back to the general kernels
+            {
+                // this launch runs up to PF_RING - 2 rows ahead of the counts: the writer itself checks that it has not overwritten a
+                // record that a pending count can still ask for (Ctrl::g_safe: the oldest generation those counts reach)
+                const unsigned kold = A.gstart[(size_t)(A.ctrl->g_safe % A.Gcap) * A.Np + p];
+                if (widx - kold > A.cap && !A.ctrl->err) A.ctrl->err = ERR_LOG_OVERFLOW;
+            }
         } else {
             A.widx[p] = widx;
         }

@@ -167,6 +167,7 @@ struct PipeRow {
     int slot_out;          // slot to write
     double pos_prev;       // end of the previous row
     int draws;             // the draw table is kept up by this launch sequence (k_sweep): 1 + parity of the row, 0: no table
+    int ahead;             // the extend role is a launch of its own and runs up to PF_RING - 2 rows ahead of the other roles
 };
 
 
@@ -181,8 +182,10 @@ struct PipeLaunch {
     int lc_slot;           // ring slot of the row whose ledger upkeep and counts are due (-1: none)
     int live_slot;         // newest complete slot of the per-slot record counters (ring-overwrite check)
     int nL;                // ledger workgroups
-    int ncw;               // count workgroups per epoch
+    int ncw;               // count workgroups per epoch -- or, with `units`, of the step
     int nT;                // workgroups that keep up the draw table (k_sweep only)
+    int units;             // the counts are dealt out by generation (count_units_body) instead of one column per epoch
+    int ahead;             // as PipeRow::ahead: the rings need PF_RING entries of headroom
 };
 
 
@@ -197,6 +200,7 @@ struct SweepChunk {
     int nblk;                      // particle blocks of 256
     int nT;                        // draw-table workgroups per step (0: no table)
     int split;                     // the extend role (with the draw role) and the other roles are separate launches (PF_DEBUG_SPLIT_ROLES)
+    int units;                     // count workgroups take units of one generation for all its epochs (ncw = workgroups per step)
 };
 typedef const __attribute__((address_space(4))) SweepChunk SweepChunkC;
 
@@ -221,6 +225,7 @@ __device__ __forceinline__ bool sweep_plan(SweepChunkC& ch, long long s, int nb,
     // only a step that completes a row needs its end; on the second flush step row s - 1 = s_last + 1 may lie past the table
     PL.row.pos_prev = (PL.row.complete && s > s_begin) ? sweep_seg_pos(ch.A, s - 1) : 0.0;
     PL.row.draws = ch.nT > 0 ? 1 + (int)(s & 1) : 0;
+    PL.ahead = PL.row.ahead = (ch.split || ch.A.P > 1) ? 1 : 0;
     PL.nT = extend ? ch.nT : 0;
     PL.b_slot = have_b ? (int)((s - 1) & (PF_RING - 1)) : -1;
     PL.b_row = s - 1;
@@ -230,6 +235,7 @@ __device__ __forceinline__ bool sweep_plan(SweepChunkC& ch, long long s, int nb,
     PL.live_slot = (int)((s - 1) & (PF_RING - 1));
     PL.nL = PL.lc_slot >= 0 ? ch.nL_full : 0;
     PL.ncw = ch.ncw;
+    PL.units = ch.units;
     return true;
 }
 

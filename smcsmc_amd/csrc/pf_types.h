@@ -59,6 +59,8 @@ struct Ctrl {
     int gen;               // current generation (number of resampling events so far)
     int first_epoch;       // first epoch updated by the current count step (E = none)
     int g_retain;          // oldest generation whose run list is still maintained
+    int g_safe;            // g_retain as of two rows before the last one booked: no count that is running or still to run asks for an older
+                           // generation (what an extend role that runs ahead of the counts checks its log writes against)
     int g_lo[PF_EMAX];     // generation containing counted_to[e]
     int g_hi[PF_EMAX];     // generation containing update_to[e] of the current count step
     int err;               // sticky error code
@@ -219,6 +221,10 @@ struct KArgs {
     double* totals;                // [6][E]
     double* partial;               // [E][nbx][6]
     int nbx;
+    int cu_ec;                     // count_units_body: epochs of a generation's mask per unit
+    const int* cw_off;             // row pipeline: [E + 1] first count workgroup of the j-th column, columns in the order oldest epoch first
+                                   // (the old epochs' windows hold nearly every particle, the young ones' a few ancestors: their columns
+                                   // are given fewer workgroups); null: PipeLaunch::ncw workgroups for every column
     // segments
     const double* seg_start;
     const double* seg_len;

@@ -92,9 +92,9 @@ class PackedLookahead:
 EXPORTS = [
     "pf_last_error", "pf_device_count", "pf_create", "pf_destroy", "pf_init_prior", "pf_load_segments", "pf_load_lookahead",
     "pf_terminal_branch_quantiles",
-    "pf_update_segment", "pf_count", "pf_resample", "pf_run", "pf_run_many", "pf_finish", "pf_sync",
+    "pf_update_segment", "pf_count", "pf_resample", "pf_run", "pf_run_many", "pf_can_run_many", "pf_finish", "pf_sync",
     "pf_num_segments_done", "pf_logl", "pf_get_counts", "pf_get_trace", "pf_get_resample_events",
-    "pf_get_particles", "pf_get_migrations", "pf_get_local_recomb", "pf_sample_tree_events", "pf_sample_tree_events_pops", "pf_get_kernel_time", "pf_set_timing", "pf_get_stats", "pf_get_delay_stats", "pf_debug_stamps", "pf_test_search_lut", "pf_simulate_sites",
+    "pf_get_particles", "pf_get_migrations", "pf_get_local_recomb", "pf_sample_tree_events", "pf_sample_tree_events_pops", "pf_get_kernel_time", "pf_set_timing", "pf_get_stats", "pf_get_delay_stats", "pf_probe_handoff", "pf_debug_stamps", "pf_test_search_lut", "pf_simulate_sites",
     "pf_median_survival", "pf_test_math", "pf_test_div", "pf_test_uniform", "pf_test_reduce", "pf_test_systematic",
 ]
 
@@ -124,6 +124,7 @@ def load_library(path=None):
     L.pf_resample.argtypes = [vp, C.c_int64]
     L.pf_run.argtypes = [vp, C.c_int64, C.c_int64]
     L.pf_run_many.argtypes = [vp, C.c_int32, C.c_int64, C.c_int64]
+    L.pf_can_run_many.argtypes = [vp, C.c_int32]
     L.pf_finish.argtypes = [vp]
     L.pf_sync.argtypes = [vp]
     L.pf_sample_tree_events.restype = C.c_int64
@@ -144,6 +145,7 @@ def load_library(path=None):
     L.pf_set_timing.argtypes = [vp, C.c_int]
     L.pf_get_stats.argtypes = [vp, vp, vp, vp]
     L.pf_get_delay_stats.argtypes = [vp, vp, vp]
+    L.pf_probe_handoff.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, vp, vp, C.c_int32]
     L.pf_median_survival.argtypes = [C.POINTER(_Model), C.c_uint64, C.c_int32, C.c_int64, vp, vp, C.c_int]
     L.pf_test_math.argtypes = [vp, C.c_int64, vp, vp, vp, C.c_int]
     L.pf_test_div.argtypes = [vp, vp, C.c_int64, vp, C.c_int]
@@ -247,6 +249,16 @@ def unpack_counts(out, E, P=1):
 
 
 KERNEL_CLASSES = ("extend", "decide", "count", "resample")
+
+
+def probe_handoff(mode, rows=2000, nw=157, spin_us=0.0, device=0):
+    """microseconds per row of the row hand-off probe (pf_probe_handoff): mode 0 = a kernel boundary per row, 1 = a resident grid"""
+    L = load_library()
+    us = C.c_double(); cs = C.c_double()
+    rc = L.pf_probe_handoff(int(mode), int(rows), int(nw), int(round(spin_us * 100.0)), C.byref(us), C.byref(cs), int(device))
+    if rc != 0:
+        raise PfError("pf_probe_handoff failed (%d)" % rc)
+    return us.value, cs.value
 
 
 class ParticleFilter:

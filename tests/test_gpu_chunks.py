@@ -45,6 +45,42 @@ def test_chunk_statistics_do_not_depend_on_the_ranks(hiplib, tmp_path):
     assert abs(d[("Recomb", -1, -1, -1)][1] / single[("Recomb", -1, -1, -1)][1] - 1) < 0.1
 
 
+def test_chunks_leave_their_local_recombination_maps(hiplib, tmp_path):
+    """The reference writes <prefix>.recomb.gz in every chunk process (smcsmc.cpp:376-383); -chunks K leaves one map per chunk,
+    <prefix>.chunkN.recomb.gz, with the chunk's own loci, whichever way the chunks are spread over ranks."""
+    import gzip
+    _run(tmp_path, "m", ["-chunks", "2", "-ranks", "1"])
+    rows = []
+    for c in range(2):
+        path = tmp_path / ("m.chunk%d.recomb.gz" % c)
+        assert path.exists(), "no local recombination map for chunk %d" % c
+        lines = gzip.open(path, "rt").read().splitlines()
+        assert lines[0].split()[:4] == ["iter", "locus", "size", "opp_per_nt"]
+        body = [ln.split() for ln in lines[1:]]
+        assert len(body) == L // 2 // 100
+        assert float(body[0][1]) == 1 + c * (L // 2)                 # first locus of the chunk (1-based start position)
+        assert sum(float(r[3]) for r in body) > 0
+        rows.append(body)
+    # the same chunks filtered one after the other by two ranks (no lockstep launch) leave the same maps
+    _run(tmp_path, "m2", ["-chunks", "2", "-ranks", "2", "-reduce", "host"])
+    for c in range(2):
+        other = [ln.split() for ln in gzip.open(tmp_path / ("m2.chunk%d.recomb.gz" % c), "rt").read().splitlines()[1:]]
+        a = np.array([[float(v) for v in r_[3:]] for r_ in other]); b = np.array([[float(v) for v in r_[3:]] for r_ in rows[c]])
+        np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-12)      # (five significant digits in the file; sums of atomics)
+
+
+def test_rccl_exchange_between_two_devices(hiplib, tmp_path):
+    """-reduce rccl with two ranks on two devices: the branch no one-GPU box can run.  Switches itself on where a second device
+    is visible (the driver's multi-GPU node) and must then give the .out of the host exchange, byte for byte."""
+    from smcsmc_amd import pf
+    if pf.load_library().pf_device_count() < 2:
+        pytest.skip("one device: RCCL between ranks needs two")
+    host, _ = _run(tmp_path, "h2", ["-chunks", "4", "-ranks", "2", "-reduce", "host"])
+    rccl, log = _run(tmp_path, "n2", ["-chunks", "4", "-ranks", "2", "-devices", "2", "-reduce", "rccl"])
+    assert "exchanged by rccl" in log and "2 device(s)" in log
+    assert rccl == host
+
+
 def test_chunked_em_iterations(hiplib, tmp_path):
     """-EM with several chunks: the M-step works on the summed statistics, every iteration re-filters all chunks."""
     text, _ = _run(tmp_path, "em", ["-chunks", "2", "-ranks", "2", "-reduce", "host", "-EM", "1"])

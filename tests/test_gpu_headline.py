@@ -130,14 +130,20 @@ def test_rings_wrap_many_times(oracle, hiplib, n, E, Np, P, debug):
     assert st["records"] / Np > 10 * 64 * (0.5 if P > 1 else 1.0), "event log must wrap many times (%.0f records per slot)" % (st["records"] / Np)
 
 
-@pytest.mark.parametrize("log_cap,gen_cap,what", [(8, 4096, "event log ring overflow"), (4096, 4, "generation ledger overflow")])
-def test_ring_too_small_is_a_reported_error(hiplib, log_cap, gen_cap, what):
-    """A ring that cannot hold what the lags keep alive must stop the run with an error, never overwrite silently."""
+@pytest.mark.parametrize("P,log_cap,gen_cap,what", [(1, 8, 4096, "event log ring overflow"), (1, 4096, 4, "generation ledger overflow"),
+                                                    (2, 16, 4096, "event log ring overflow"), (2, 4096, 24, "generation ledger overflow"),
+                                                    (2, 4096, 8, "gen_cap must be at least 20")])
+def test_ring_too_small_is_a_reported_error(hiplib, P, log_cap, gen_cap, what):
+    """A ring that cannot hold what the lags keep alive must stop the run with an error, never overwrite silently -- also where
+    the extend launches run up to fourteen rows ahead of the bookkeeping and the counts (structured models on the row pipeline):
+    there the generation ledger keeps sixteen entries of headroom and the extend role checks its own writes to the event log."""
     from smcsmc_amd import ParticleFilter
     from smcsmc_amd.pf import PfError
     model = cases.make_model(n=4, E=8, L=3.0e5, lag=60000.0)
     segs = cases.make_segments(model, seed=12, max_seg_len=5000)
-    g = ParticleFilter(model, 400, seed=3, log_cap=log_cap, gen_cap=gen_cap)
-    g.init_prior(0.0); g.load_segments(segs)
+    if P > 1:
+        model = cases.make_structured(model, P=P, split_epoch=5, mig=1.0)
     with pytest.raises(PfError, match=what):
+        g = ParticleFilter(model, 400, seed=3, log_cap=log_cap, gen_cap=gen_cap)
+        g.init_prior(0.0); g.load_segments(segs)
         g.run(); g.finish()
