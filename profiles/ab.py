@@ -25,7 +25,10 @@ def main():
     for rnd in range(args.rounds):
         for v in variants:
             extra = ["--debug", v] if v.lstrip("-").isdigit() else v.split()
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + rest + extra, capture_output=True, text=True)
+            tree = ROOT
+            if extra and extra[0].startswith("@"):            # "@scratch/r3tree ..." = the bench.py (and library) of another checkout
+                tree = os.path.join(ROOT, extra[0][1:]); extra = extra[1:]
+            r = subprocess.run([sys.executable, os.path.join(tree, "bench.py")] + rest + extra, capture_output=True, text=True, cwd=tree)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if not line:
                 print("%-40s FAILED %s" % (v, r.stderr[-300:].replace("\n", " | ")), flush=True)

@@ -43,25 +43,32 @@ def main():
         if files:
             res[counter] = pmc_summary(files[0], out + "_pmc_%s.csv" % counter)
     if len(res) == 2:
-        # dominant kernel = largest total duration in the stats file
-        dom = None
-        if stats:
-            with open(stats[0]) as f:
-                dom = next(csv.DictReader(f))["Name"]
-        dom = dom or max(res["WRITE_SIZE"], key=lambda k: res["WRITE_SIZE"][k][1])
-        fr, wr = res["FETCH_SIZE"].get(dom), res["WRITE_SIZE"].get(dom)
-        if fr and wr:
-            json.dump({
-                "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes), profiles/collect_round3.sh",
-                "kernel": dom, "dispatches": fr[0], "fetch_size_kb_avg_raw": fr[1], "write_size_kb_avg": wr[1], "fetch_correction": 2.0,
+        # one file per row kernel (everything whose name starts with k_sweep / k_pipe / k_extend / k_row), named after it; `shape` and
+        # the note of the counter run (argv[3], argv[4]) let bench.py pick the file of its own workload AND kernel
+        shape = json.loads(sys.argv[3]) if len(sys.argv) > 3 else None
+        run_note = sys.argv[4] if len(sys.argv) > 4 else ""
+        for name in res["WRITE_SIZE"]:
+            short = name.replace("void ", "").split("<")[0].split("(")[0]
+            if not short.startswith(("k_sweep", "k_pipe", "k_extend", "k_row")) or short == "k_sweep_seed":
+                continue
+            fr, wr = res["FETCH_SIZE"].get(name), res["WRITE_SIZE"].get(name)
+            if not (fr and wr):
+                continue
+            doc = {
+                "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes), profiles/collect_round4.sh",
+                "kernel": name, "dispatches": fr[0], "fetch_size_kb_avg_raw": fr[1], "write_size_kb_avg": wr[1], "fetch_correction": 2.0,
                 "note": "gfx950: FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced streaming reads "
                         "(MI355X_MICROARCH.md, HBM); the loads here are 8 B per lane or scattered 64-B records, for which the "
                         "counter is uncalibrated: the corrected figure (x2) is an upper bound, the raw one a lower bound. "
                         "WRITE_SIZE is exact." + ("  The launch also carries the bookkeeping, ledger and count workgroups."
-                                                  if ("k_pipe" in dom or "k_sweep" in dom) else ""),
+                                                  if short in ("k_pipe", "k_sweep", "k_sweep4") else ""),
+                "counter_run": run_note,
                 "traffic_bytes_per_launch": 1024.0 * (2.0 * fr[1] + wr[1]),
                 "traffic_bytes_per_launch_lower": 1024.0 * (fr[1] + wr[1]),
-            }, open(out + "_pmc.json", "w"), indent=1)
+            }
+            if shape:
+                doc["shape"] = shape
+            json.dump(doc, open(out + "_pmc_%s.json" % short, "w"), indent=1)
     # the raw traces stay on the box
     for d in glob.glob(src + "_stats") + glob.glob(src + "_fetch") + glob.glob(src + "_write"):
         shutil.rmtree(d, ignore_errors=True)

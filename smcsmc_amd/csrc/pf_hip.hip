@@ -46,7 +46,8 @@ __global__ __launch_bounds__(PF_BS) void k_init(KArgs A, double initial_position
         c->cur_pos = initial_position;
         c->logl = 0; c->inv_T = 1; c->T = 1; c->flag = 0; c->cur = 0; c->gen = 0; c->n_resample = 0; c->lver = 0;
         c->first_epoch = A.E; c->err = 0; c->delayed_opp = 0; c->delayed_count = 0; c->count_active = 0; c->end_seq = 0;
-        c->g_retain = 0; c->pending_fin = 0; c->nbx_used = A.nbx; c->gen_prev = 0; c->nres_prev = 0;
+        c->g_retain = 0; c->g_safe = 0; c->delay_peak = 0; c->n_delay_evict = 0; c->pending_fin = 0;
+        for (int k = 0; k < PF_RING; ++k) c->ri[k].g_retain = 0;      // (what Ctrl::g_safe is read from in the first rows of a sweep) c->nbx_used = A.nbx; c->gen_prev = 0; c->nres_prev = 0;
         for (int e = 0; e < A.E; ++e) { c->counted_to[e] = 0; c->update_to[e] = 0; c->g_lo[e] = 0; c->g_hi[e] = 0; }
         A.gen_x0[0] = 0.0;
     }
@@ -1288,7 +1289,7 @@ struct Win { int e, rf; double T0, T1, a_e, b_e; bool end_seq; };
 
 // local recombination map (record_local_recomb_events, count.cpp:559-613): per workgroup the differential
 // opportunity of its window is collected in LDS bins and flushed with one global atomic per touched bin
-#define PF_LBINS 1024
+#define PF_LBINS 2048
 struct LMap {
     double* lds;          // [PF_LBINS] bins of this workgroup, bin 0 = interval b0
     int nlds;             // bins in use: the window of the step spans few of them (the rest of a step's additions, if any, go to memory)
@@ -1300,7 +1301,9 @@ struct LMap {
 __device__ __forceinline__ void lmap_add(const LMap& L, long long idx, double v) {
     if (idx < 0 || idx >= L.nbins) return;
     long long k = idx - L.b0;
-    if (k >= 0 && k < L.nlds) atomicAdd(&L.lds[k], v);
+    // the bins are LDS: said in the pointer's type, so that the addition is a ds_add_f64 and not a flat atomic that finds out per lane
+    typedef __attribute__((address_space(3))) double lds_double;
+    if (k >= 0 && k < L.nlds) __hip_atomic_fetch_add((lds_double*)L.lds + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else atomicAdd(&L.gopp[idx], v);
 }
 // constant opportunity density over [x_lo, x_hi): the differential encoding of count.cpp:578-588
@@ -1476,10 +1479,11 @@ __device__ __forceinline__ double* count_bins() {
     return bins;
 }
 
-// LDS of the count roles: a workgroup runs one of the two bodies
+// LDS of a count role: one buffer per body (only the launch of the split arrangement carries both bodies)
 #define PF_COUNT_LDS_BYTES 14336
+template <int BYTES>
 __device__ __forceinline__ char* count_lds() {
-    __shared__ __attribute__((aligned(16))) char buf[PF_COUNT_LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) char buf[BYTES];
     return buf;
 }
 
@@ -1516,9 +1520,8 @@ template <int NM, int P, bool EXACT = false, class KA>
 __device__ __forceinline__ void count_body(const KA& A, const CountSrc& Q, int e, double win_a, double win_b, int bx, int nbxg) {
     constexpr int NI = NM - 1;
     using AC = AccT<P>;
-    // LDS from the count roles' common buffer (count_units_body is the other tenant)
-    static_assert(sizeof(AC) * (PF_BS / 64) + sizeof(int) * (PF_CNT_TILE + 1 + PF_BS / 64) + 16 <= PF_COUNT_LDS_BYTES, "count_body's LDS");
-    char* const cl = count_lds();
+    constexpr int LDS_BYTES = (int)(((sizeof(AC) * (PF_BS / 64) + 15) & ~(size_t)15) + sizeof(int) * (PF_CNT_TILE + 1 + PF_BS / 64) + 16);
+    char* const cl = count_lds<LDS_BYTES>();
     AC* const red = (AC*)cl;
     int* const s_off = (int*)(cl + ((sizeof(AC) * (PF_BS / 64) + 15) & ~(size_t)15));
     int* const s_wsum = s_off + PF_CNT_TILE + 1;
@@ -1752,7 +1755,7 @@ template <int NM, bool EXACT, class KA>
 __device__ __forceinline__ void count_units_body(const KA& A, const CountSrc& Q, const Ctrl::RowInfo& r, int wg, int nwg) {
     constexpr int NI = NM - 1;
     using AC = AccT<1>;
-    CuLds& Z = *(CuLds*)count_lds();
+    CuLds& Z = *(CuLds*)count_lds<PF_COUNT_LDS_BYTES>();
     double* const s_lbins = count_bins();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long Np = A.Np;
@@ -2382,8 +2385,8 @@ __device__ __forceinline__ void pipe_roles(const KA& A, long long s, const PipeL
     // what a launch ended with
     int e, cbx, cnb;
     if (A.cw_off && !(A.flags & 512)) {
-        int j = 0;
-        while (j + 1 < A.E && A.cw_off[j + 1] <= idx) ++j;
+        int j = 0, hi = A.E;                       // the column of workgroup idx: last j with cw_off[j] <= idx
+        while (hi - j > 1) { const int mid = (j + hi) >> 1; if (A.cw_off[mid] <= idx) j = mid; else hi = mid; }
         e = A.E - 1 - j; cbx = idx - A.cw_off[j]; cnb = A.cw_off[j + 1] - A.cw_off[j];
     } else {
         e = (A.flags & 512) ? r.first + idx / PL.ncw : A.E - 1 - idx / PL.ncw;
@@ -3563,7 +3566,8 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
         if (h->pipe || h->pipe_mp) {
             rc |= dalloc(h, &dcw, E + 1);
             if (!rc) { hipMemcpyAsync(dcw, h->cw_off.data(), (size_t)(E + 1) * 4, hipMemcpyHostToDevice, h->stream); hipStreamSynchronize(h->stream); }
-            A.cw_off = (p->debug & PF_DEBUG_COUNT_YOUNG_FIRST) ? nullptr : dcw;
+            // (with every column at full width the kernels compute column and workgroup from the index: no table)
+            A.cw_off = ((p->debug & PF_DEBUG_COUNT_YOUNG_FIRST) || p->count_wgs <= 0) ? nullptr : dcw;
         }
     }
     rc |= dalloc(h, &A.totals, (size_t)A.ncol * E);

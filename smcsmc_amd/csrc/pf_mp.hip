@@ -89,7 +89,8 @@ __global__ __launch_bounds__(PF_BS) void k_init_mp(KArgs A, double initial_posit
         c->cur_pos = initial_position;
         c->logl = 0; c->inv_T = 1; c->T = 1; c->flag = 0; c->cur = 0; c->gen = 0; c->n_resample = 0; c->lver = 0;
         c->first_epoch = A.E; c->err = 0; c->delayed_opp = 0; c->delayed_count = 0; c->count_active = 0; c->end_seq = 0;
-        c->g_retain = 0; c->pending_fin = 0; c->nbx_used = A.nbx; c->gen_prev = 0; c->nres_prev = 0;
+        c->g_retain = 0; c->g_safe = 0; c->delay_peak = 0; c->n_delay_evict = 0; c->pending_fin = 0;
+        for (int k = 0; k < PF_RING; ++k) c->ri[k].g_retain = 0;      // (what Ctrl::g_safe is read from in the first rows of a sweep) c->nbx_used = A.nbx; c->gen_prev = 0; c->nres_prev = 0;
         for (int e = 0; e < A.E; ++e) { c->counted_to[e] = 0; c->update_to[e] = 0; c->g_lo[e] = 0; c->g_hi[e] = 0; }
         A.gen_x0[0] = 0.0;
     }

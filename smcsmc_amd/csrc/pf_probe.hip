@@ -70,13 +70,51 @@ __global__ __launch_bounds__(256) void k_handoff_resident(double* part /* [2][nw
     if (gw < nw && lane == 0) out[gw] = acc;
 }
 
+// the same with the hand-off done per workgroup: one arrival and one poller per workgroup (the other wavefronts wait at the
+// workgroup barrier), the partials fetched once per workgroup into LDS
+__global__ __launch_bounds__(256) void k_handoff_resident_wg(double* part, unsigned* arrive, int nw, int rows, long long spin, double* out, int* err) {
+    __shared__ double s_part[4096];
+    __shared__ int s_bad;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nwg = (int)gridDim.x, np = nw * NPART;
+    double acc = 0.0;
+    if (threadIdx.x == 0) s_bad = 0;
+    for (int r = 0; r < rows; ++r) {
+        double* mine = part + (size_t)(r & 1) * np;
+        spin_100mhz(spin);
+        if (gw < nw && lane < NPART) __hip_atomic_store(&mine[gw * NPART + lane], acc * 1e-3 + (double)(gw + lane + r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(&arrive[r], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            int guard = 0;
+            while (__hip_atomic_load(&arrive[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nwg) {
+                if (++guard > 4000000) { *err = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) s_bad = 1;
+        }
+        __syncthreads();
+        if (s_bad) break;
+        for (int k = threadIdx.x; k < np && k < 4096; k += 256) s_part[k] = __hip_atomic_load(&mine[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        double a2 = 0.0;
+        for (int k = lane; k < np && k < 4096; k += 64) a2 += s_part[k];
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) a2 += __shfl_xor(a2, m, 64);
+        acc = a2;
+        __syncthreads();
+    }
+    if (gw < nw && lane == 0) out[gw] = acc;
+}
+
 }  // namespace
 
-// mode 0: `rows` launches of k_handoff_launch back to back on one stream; mode 1: one launch of the resident grid.
+// mode 0: `rows` launches of k_handoff_launch back to back on one stream; mode 1: one launch of the resident grid, every wavefront
+// arriving and polling for itself; mode 2: the resident grid with one arrival and one poller per workgroup.
 // nw wavefronts in workgroups of four; spin_ticks of 10 ns of stand-in work per wavefront and row.  Returns microseconds per row
 // (HIP events around the whole sequence) in *us_per_row and a checksum (the two modes compute the same numbers).
 extern "C" int pf_probe_handoff(int32_t mode, int32_t rows, int32_t nw, int64_t spin_ticks, double* us_per_row, double* checksum, int32_t device) {
-    if (rows < 1 || nw < 1 || nw > 4096) return -1;
+    if (rows < 1 || nw < 1 || nw > 4096 || (mode == 2 && nw * NPART > 4096)) return -1;
     if (hipSetDevice(device) != hipSuccess) return -1;
     const int nwg = (nw + 3) / 4;
     double *part = nullptr, *out = nullptr;
@@ -101,8 +139,10 @@ extern "C" int pf_probe_handoff(int32_t mode, int32_t rows, int32_t nw, int64_t 
             double* next = part + (size_t)(r & 1) * nw * NPART;
             hipLaunchKernelGGL(k_handoff_launch, dim3(nwg), dim3(256), 0, st, prev, next, nw, (long long)spin_ticks, out, r);
         }
-    } else {
+    } else if (mode == 1) {
         hipLaunchKernelGGL(k_handoff_resident, dim3(nwg), dim3(256), 0, st, part, arrive, nw, rows, (long long)spin_ticks, out, err);
+    } else {
+        hipLaunchKernelGGL(k_handoff_resident_wg, dim3(nwg), dim3(256), 0, st, part, arrive, nw, rows, (long long)spin_ticks, out, err);
     }
     hipEventRecord(e1, st);
     if (mode == 0)          // (untimed) the reduction of the last row's partials, which the resident grid has already done

@@ -72,3 +72,44 @@ def test_the_reference_bands_of_these_classes_are_not_the_exact_values():
     ex = GOLD["TestConstPopSize"]
     outside = [b for b in ex["bands"] if not (b["min"] <= (ex["exact"]["rho"] if b["type"] == "Recomb" else ex["exact"]["ne"][b["epoch"]]) <= b["max"])]
     assert {(b["type"], b["epoch"]) for b in outside} >= {("Coal", 1), ("Coal", 2), ("Recomb", None)}
+
+
+def test_forty_replicates_recover_the_truth(hiplib):
+    """Forty independent 10 Mb data sets of two samples from the numpy simulator (smcsmc_amd/simulate.py: coalescent with
+    recombination, independent of the device code), each filtered once at the true parameters (Np = 4 000, lag of four survival
+    distances).  At the true parameters the expected sufficient statistics are those of the model, so the pooled ratios
+    sum(opportunity) / (2 sum(count)) and sum(recombinations) / sum(opportunity) must sit on the truth: within 2.5 jackknife
+    standard errors for every epoch and for rho.  (What the exact E-step says about ONE data set is the other tests' subject;
+    this one checks the estimator against the truth itself.)"""
+    from smcsmc_amd import ParticleFilter, pf, simulate, segments as segmod
+    ct = np.array([0.0, 400.0, 10000.0, 20000.0, 40000.0, 60000.0])
+    ne = np.full(6, 1.0e4)
+    L, mu, rho = 1.0e7, 2.5e-8, 1.0e-8
+    model = dict(change_times=ct, pop_sizes=ne, nsam=2, loci_length=L, mutation_rate=mu, recombination_rate=rho, lags=np.ones(6))
+    med, _ = pf.median_survival(model, seed=1, min_events=200, max_trees=1000000)
+    model["lags"] = med * 4.0
+    R = 40
+    cc, co, rc, ro = [], [], [], []
+    for rep in range(R):
+        seg = simulate.simulate_seg(2, L, mu, rho, ct, ne, seed=1000 + rep)
+        S = segmod.Segments.from_sites(seg["start"], seg["length"], seg["alleles"], 2, L, max_segment_length=int(2.0 / (rho * 4 * 1.0e4)))
+        segs = S.pack(model["lags"])
+        g = ParticleFilter(model, 4000, seed=rep + 1, max_trace_events=0)
+        g.init_prior(segs["start"][0]); g.load_segments(segs); g.run(); g.finish()
+        c = g.counts()
+        cc.append(c["coal_count"]); co.append(c["coal_opp"]); rc.append(c["rec_count"].sum()); ro.append(c["rec_opp"].sum())
+        g.close()
+    cc, co, rc, ro = np.array(cc), np.array(co), np.array(rc), np.array(ro)
+
+    def pooled_with_jackknife(num, den, scale):
+        est = scale * num.sum(0) / den.sum(0)
+        loo = np.array([scale * (num.sum(0) - num[i]) / (den.sum(0) - den[i]) for i in range(R)])
+        se = np.sqrt((R - 1) / R * ((loo - loo.mean(0)) ** 2).sum(0))
+        return est, se
+    ne_hat, ne_se = pooled_with_jackknife(co, cc, 0.5)
+    rho_hat, rho_se = pooled_with_jackknife(rc[:, None], ro[:, None], 1.0)
+    z = (ne_hat - ne) / ne_se
+    assert np.abs(z).max() < 2.5, (ne_hat, ne_se, z)
+    assert np.all(ne_se[1:] / ne[1:] < 0.01), ne_se                    # forty times 10 Mb pin every epoch with data to better than 1 %
+    assert abs(rho_hat[0] - rho) / rho_se[0] < 2.5, (rho_hat, rho_se)
+    assert rho_se[0] / rho < 0.005
