@@ -13,8 +13,9 @@
  *   pf_update_segment    ParticleContainer::update_state_to_data (particleContainer.cpp:441-466)
  *   pf_count             CountModel::extract_and_update_count (count.cpp:355-415)
  *   pf_resample          ParticleContainer::resample (particleContainer.cpp:247-311)
- *   pf_run               the do-while of pfARG_core (smcsmc.cpp:324-360) over a segment range,
- *                        enqueued without host round trips
+ *   pf_run               the do-while of pfARG_core (smcsmc.cpp:324-360) over a segment range: its rows are enqueued without
+ *                        a host round trip per row (the call itself waits once, for the launches of the previous call that
+ *                        still read the chunk table it is about to rewrite: bin/smcsmc calls it every 1000 rows)
  *   pf_run_many          the same loop for the chunks the front-end starts side by side, one process each
  *                        (smcsmc/model.py:1094-1098): one launch per row covers all of them
  *   pf_finish            final normalize_probability + lag-free flush (smcsmc.cpp:371-373)

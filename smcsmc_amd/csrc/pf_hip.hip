@@ -4228,9 +4228,17 @@ static int run_sweep_mp(pf_handle* h, long long s_begin, long long s_end) {
     const int nL_full = nb + std::max(16, std::min(PF_LEDGER_BLOCKS, 192));
     if (h->ev_cnt) { hipStreamWaitEvent(h->stream, h->ev_cnt, 0); h->ev_cnt = nullptr; }
     if (h->ev_x.empty()) {
-        h->ev_x.resize(16); h->ev_blc.resize(16);
-        for (auto& e : h->ev_x) if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) { g_err = "hipEventCreate failed"; return -1; }
-        for (auto& e : h->ev_blc) if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) { g_err = "hipEventCreate failed"; return -1; }
+        // all thirty-two or none: a vector left half filled would pass for complete on the next call, and launches with null
+        // completion events lose the ordering between the two streams without a word
+        std::vector<hipEvent_t> ev(32, nullptr);
+        bool ok = true;
+        for (auto& e : ev) if (ok && hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) { e = nullptr; ok = false; }
+        if (!ok) {
+            for (auto e : ev) if (e) hipEventDestroy(e);
+            g_err = "hipEventCreate failed";
+            return -1;
+        }
+        h->ev_x.assign(ev.begin(), ev.begin() + 16); h->ev_blc.assign(ev.begin() + 16, ev.end());
     }
     pf_handle* one[1] = {h};
     bool failed = false;
