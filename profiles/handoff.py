@@ -23,6 +23,8 @@ def main():
     for spin in (0.0, 5.0, 10.0, 20.0):
         res = [min(pf.probe_handoff(mode, args.rows, args.nw, spin)[0] for _ in range(3)) for mode in (0, 1, 2)]
         print("| %.0f us | %.2f | %.2f | %.2f |" % (spin, res[0], res[1], res[2]), flush=True)
+    cs = [pf.probe_handoff(mode, 500, args.nw, 0.0)[1] for mode in (0, 1, 2)]
+    print("checksums of the three forms after 500 rows (the same numbers must come out): %r %r %r -> %s" % (cs[0], cs[1], cs[2], "equal" if cs[0] == cs[1] == cs[2] else "DIFFERENT"))
     for nw in (40, 157, 628):
         res = [min(pf.probe_handoff(mode, args.rows, nw, 0.0)[0] for _ in range(3)) for mode in (0, 1, 2)]
         print("| no work, %d wavefronts | %.2f | %.2f | %.2f |" % (nw, res[0], res[1], res[2]), flush=True)

@@ -50,9 +50,47 @@ def exact(m, packed, K):
                 rec_count=res["rec_count"].tolist(), rec_opp=res["rec_opp"].tolist(), ne=ne_hat.tolist(), rho=float(rho_hat))
 
 
+REPLICATES = dict(n=40, first_seed=1000, L=1.0e7, mu=2.5e-8, rho=1.0e-8, change_times=[0.0, 400.0, 10000.0, 20000.0, 40000.0, 60000.0], ne=1.0e4, K=250)
+
+
+def replicate_rows(rep):
+    """data set `rep` of the replicate test: two samples, 10 Mb, from the numpy simulator (smcsmc_amd/simulate.py), packed as a .seg file is"""
+    from smcsmc_amd import simulate
+    R = REPLICATES
+    ct, ne = np.array(R["change_times"]), np.full(len(R["change_times"]), R["ne"])
+    seg = simulate.simulate_seg(2, R["L"], R["mu"], R["rho"], ct, ne, seed=R["first_seed"] + rep)
+    S = segmod.Segments.from_sites(seg["start"], seg["length"], seg["alleles"], 2, R["L"], max_segment_length=int(2.0 / (R["rho"] * 4 * R["ne"])))
+    return S
+
+
+def replicates():
+    """the exact E-step summed over the forty simulated data sets of tests/test_gpu_exact_hmm.py::test_forty_replicates...: what the
+    filter must reproduce there.  (It is NOT the truth: the reference's emission -- no mutation over the whole row, then the site --
+    books the site's base twice, which costs the deep epochs 0.7-0.9 % on infinite-sites data; the exact E-step shows that offset
+    as the filter does.)"""
+    R = REPLICATES
+    ct, ne = np.array(R["change_times"]), np.full(len(R["change_times"]), R["ne"])
+    h = exact_hmm2.ExactHMM2(ct, ne, R["mu"], R["rho"], K=R["K"])
+    tot = {k: np.zeros(len(ct)) for k in ("coal_count", "coal_opp", "rec_count", "rec_opp")}
+    logl = 0.0
+    for rep in range(R["n"]):
+        res = h.run(replicate_rows(rep).pack(np.full(len(ct), 1e99)), seq_len=R["L"])
+        for k in tot:
+            tot[k] += res[k]
+        logl += res["logl"]
+        print("replicate", rep, " ".join("%.0f" % v for v in tot["coal_opp"] / (2 * tot["coal_count"])), flush=True)
+    return dict(R, pooled={k: v.tolist() for k, v in tot.items()}, pooled_ne=(tot["coal_opp"] / (2 * tot["coal_count"])).tolist(),
+                pooled_rho=float(tot["rec_count"].sum() / tot["rec_opp"].sum()), logl_sum=logl)
+
+
 def main():
     K = int(sys.argv[1]) if len(sys.argv) > 1 else 600
     out = {"generator": "tests/golden/make_exact_hmm2.py", "method": "tests/exact_hmm2.py", "classes": {}}
+    if "--replicates-only" in sys.argv:
+        out = json.load(open(os.path.join(ROOT, "tests/golden/exact_hmm2.json")))
+        out["replicates"] = replicates()
+        json.dump(out, open(os.path.join(ROOT, "tests/golden/exact_hmm2.json"), "w"), indent=1)
+        return
     for name in CLASSES:
         c, m, packed = case_inputs(name)
         fine, coarse = exact(m, packed, K), exact(m, packed, K // 2)
@@ -62,6 +100,7 @@ def main():
                                     bands=[dict(type=t["type"], epoch=t.get("epoch"), min=t["min"], max=t["max"]) for t in c["targets"]])
         print(name, "logl %.3f" % fine["logl"], " ".join("%.1f" % v for v in fine["ne"]), "rho %.5e" % fine["rho"],
               "| K/2:", " ".join("%.1f" % v for v in coarse["ne"]), "%.5e" % coarse["rho"], flush=True)
+    out["replicates"] = replicates()
     with open(os.path.join(ROOT, "tests/golden/exact_hmm2.json"), "w") as f:
         json.dump(out, f, indent=1)
 

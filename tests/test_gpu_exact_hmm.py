@@ -74,42 +74,41 @@ def test_the_reference_bands_of_these_classes_are_not_the_exact_values():
     assert {(b["type"], b["epoch"]) for b in outside} >= {("Coal", 1), ("Coal", 2), ("Recomb", None)}
 
 
-def test_forty_replicates_recover_the_truth(hiplib):
-    """Forty independent 10 Mb data sets of two samples from the numpy simulator (smcsmc_amd/simulate.py: coalescent with
-    recombination, independent of the device code), each filtered once at the true parameters (Np = 4 000, lag of four survival
-    distances).  At the true parameters the expected sufficient statistics are those of the model, so the pooled ratios
-    sum(opportunity) / (2 sum(count)) and sum(recombinations) / sum(opportunity) must sit on the truth: within 2.5 jackknife
-    standard errors for every epoch and for rho.  (What the exact E-step says about ONE data set is the other tests' subject;
-    this one checks the estimator against the truth itself.)"""
-    from smcsmc_amd import ParticleFilter, pf, simulate, segments as segmod
-    ct = np.array([0.0, 400.0, 10000.0, 20000.0, 40000.0, 60000.0])
-    ne = np.full(6, 1.0e4)
-    L, mu, rho = 1.0e7, 2.5e-8, 1.0e-8
-    model = dict(change_times=ct, pop_sizes=ne, nsam=2, loci_length=L, mutation_rate=mu, recombination_rate=rho, lags=np.ones(6))
+def test_forty_replicates_equal_the_exact_e_step_and_sit_near_the_truth(hiplib):
+    """Forty independent 10 Mb data sets of two samples from the numpy simulator (smcsmc_amd/simulate.py, independent of the device
+    code), each filtered once at the true parameters (Np = 16 000, lag of four survival distances), the sufficient statistics summed
+    over the data sets.  Two things are held:
+    (1) the pooled ratios equal those of the EXACT E-step summed over the same forty data sets (tests/golden/exact_hmm2.json,
+        "replicates") to 0.3 % for every epoch with data and 0.1 % for rho -- forty times the evidence of the single-file tests;
+    (2) they sit within 1.2 % of the truth.  Not closer, and the exact E-step says why: the reference's emission (no mutation over
+        the whole row, then the site likelihood: the site's base is booked twice, and the two-state site model allows back
+        mutation) is an approximation of order mu x T, which on infinite-sites data costs the epochs beyond 40 000 generations
+        0.7 - 0.9 % -- in the exact E-step and in the filter alike (with the standard error of the forty data sets at 0.2 %, a
+        test of the filter against the truth alone fails at five standard errors, at Np = 4 000 and at Np = 16 000)."""
+    from smcsmc_amd import ParticleFilter, pf
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_exact_hmm2 as mk
+    R = json.load(open(os.path.join(ROOT, "tests/golden/exact_hmm2.json")))["replicates"]
+    assert (R["n"], R["first_seed"]) == (mk.REPLICATES["n"], mk.REPLICATES["first_seed"])
+    ct = np.array(R["change_times"]); E = len(ct)
+    ne = np.full(E, R["ne"])
+    model = dict(change_times=ct, pop_sizes=ne, nsam=2, loci_length=R["L"], mutation_rate=R["mu"], recombination_rate=R["rho"], lags=np.ones(E))
     med, _ = pf.median_survival(model, seed=1, min_events=200, max_trees=1000000)
     model["lags"] = med * 4.0
-    R = 40
-    cc, co, rc, ro = [], [], [], []
-    for rep in range(R):
-        seg = simulate.simulate_seg(2, L, mu, rho, ct, ne, seed=1000 + rep)
-        S = segmod.Segments.from_sites(seg["start"], seg["length"], seg["alleles"], 2, L, max_segment_length=int(2.0 / (rho * 4 * 1.0e4)))
-        segs = S.pack(model["lags"])
-        g = ParticleFilter(model, 4000, seed=rep + 1, max_trace_events=0)
+    tot = {k: np.zeros(E) for k in ("coal_count", "coal_opp", "rec_count", "rec_opp")}
+    for rep in range(R["n"]):
+        segs = mk.replicate_rows(rep).pack(model["lags"])
+        g = ParticleFilter(model, 16000, seed=rep + 1, max_trace_events=0)
         g.init_prior(segs["start"][0]); g.load_segments(segs); g.run(); g.finish()
         c = g.counts()
-        cc.append(c["coal_count"]); co.append(c["coal_opp"]); rc.append(c["rec_count"].sum()); ro.append(c["rec_opp"].sum())
+        for k in tot:
+            tot[k] += c[k]
         g.close()
-    cc, co, rc, ro = np.array(cc), np.array(co), np.array(rc), np.array(ro)
-
-    def pooled_with_jackknife(num, den, scale):
-        est = scale * num.sum(0) / den.sum(0)
-        loo = np.array([scale * (num.sum(0) - num[i]) / (den.sum(0) - den[i]) for i in range(R)])
-        se = np.sqrt((R - 1) / R * ((loo - loo.mean(0)) ** 2).sum(0))
-        return est, se
-    ne_hat, ne_se = pooled_with_jackknife(co, cc, 0.5)
-    rho_hat, rho_se = pooled_with_jackknife(rc[:, None], ro[:, None], 1.0)
-    z = (ne_hat - ne) / ne_se
-    assert np.abs(z).max() < 2.5, (ne_hat, ne_se, z)
-    assert np.all(ne_se[1:] / ne[1:] < 0.01), ne_se                    # forty times 10 Mb pin every epoch with data to better than 1 %
-    assert abs(rho_hat[0] - rho) / rho_se[0] < 2.5, (rho_hat, rho_se)
-    assert rho_se[0] / rho < 0.005
+    ne_hat = tot["coal_opp"] / (2 * tot["coal_count"])
+    rho_hat = tot["rec_count"].sum() / tot["rec_opp"].sum()
+    exact_ne, exact_rho = np.array(R["pooled_ne"]), R["pooled_rho"]
+    np.testing.assert_allclose(ne_hat[1:], exact_ne[1:], rtol=3e-3)
+    assert abs(ne_hat[0] / exact_ne[0] - 1) < 0.05                       # (forty events in all: the filter's own noise)
+    assert abs(rho_hat / exact_rho - 1) < 1e-3
+    assert np.abs(ne_hat[1:] / ne[1:] - 1).max() < 1.2e-2 and abs(rho_hat / R["rho"] - 1) < 5e-3
+    assert np.abs(exact_ne[1:] / ne[1:] - 1).max() < 1.2e-2             # the exact E-step carries the same offset from the truth
