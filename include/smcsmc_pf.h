@@ -126,6 +126,10 @@ typedef struct pf_params {
                                   * column of workgroups per epoch -- an experiment of round 4, measured slower;
                                   * the sums are grouped differently and agree to rounding */
 
+#define PF_DEBUG_FLAG_HANDOFF 8192 /* one population: a row as two launches (extend + draw roles; bookkeeping + ledger + counts) that no longer wait
+                                  * for each other's END: the extend launches alternate between two streams and hand the row over through
+                                  * arrival counters in memory, the other launches wait the same way (run_sweep_flags; same bits) */
+
 #define PF_DEBUG_CU_MASK 1024     /* with PF_DEBUG_SPLIT_ROLES: the two streams on disjoint sets of compute units (experiment) */
 
 typedef struct pf_segments {

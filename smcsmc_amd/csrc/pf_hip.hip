@@ -2445,18 +2445,29 @@ __device__ __forceinline__ void sweep_windows(const KA& A, Ctrl* c, double pos, 
     __syncthreads();
 }
 
-template <int NM, bool BIASED, bool EXACT, bool TREES>
+template <int NM, bool BIASED, bool EXACT, bool TREES, bool HANDOFF = false>
 __device__ __forceinline__ void sweep_kernel_body(const SweepChunk* tab_g, long long t, int nb) {
     SweepChunkC* tab = (SweepChunkC*)tab_g;
     SweepChunkC& ch = tab[blockIdx.y];
     KArgsC& A = ch.A;
     const long long s = ch.s_begin + t;
     __shared__ Windows W;           // written and read by the bookkeeping workgroup only
+    bool ok = true;
+    if constexpr (HANDOFF) {
+        // this launch was enqueued without waiting for the one of step t - 1 to end: its workgroups wait for that launch's workgroups
+        // to have arrived (state, scans, partials and draw table of row s - 1 are then visible), and -- ring reuse -- for the
+        // bookkeeping / ledger / count launch of step t - 14 to have ended
+        Ctrl* c = A.ctrl;
+        if (t >= PF_RING - 2) ok = sweep_wait_ge(c, (const unsigned*)&c->blc_step, (unsigned)(t - (PF_RING - 3)));      // (nothing is read from that launch)
+        if (ok && t > 0) { ok = sweep_wait_ge(c, &c->xt_done[(t - 1) & (PF_RING - 1)], (unsigned)((t - 1) / PF_RING + 1) * (unsigned)ch.xt_wgs); sweep_acquire(); }
+    }
     PipeLaunch PL;
-    if (!sweep_plan(ch, s, nb, PL)) return;
-    if (ch.split) PL.nL = -2;                              // extend and draw roles only: the other roles are k_sweep_blc's
-    else if ((int)blockIdx.x == nb && PL.b_slot >= 0) sweep_windows(A, A.ctrl, PL.b_pos, W);
-    pipe_roles<NM, BIASED, EXACT, TREES>(A, s, PL, W);
+    if (ok && sweep_plan(ch, s, nb, PL)) {
+        if (ch.split) PL.nL = -2;                          // extend and draw roles only: the other roles are k_sweep_blc's
+        else if ((int)blockIdx.x == nb && PL.b_slot >= 0) sweep_windows(A, A.ctrl, PL.b_pos, W);
+        pipe_roles<NM, BIASED, EXACT, TREES>(A, s, PL, W);
+    }
+    if constexpr (HANDOFF) sweep_arrive(&A.ctrl->xt_done[t & (PF_RING - 1)]);
 }
 template <int NM, bool BIASED, bool EXACT, bool TREES>
 __global__ __launch_bounds__(PF_BS) void k_sweep(const SweepChunk* tab_g, long long t, int nb) {
@@ -2471,6 +2482,12 @@ template <bool EXACT, bool TREES>
 __global__ __launch_bounds__(PF_BS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_sweep4(const SweepChunk* tab_g, long long t, int nb) {
     sweep_kernel_body<4, false, EXACT, TREES>(tab_g, t, nb);
 }
+// the extend / draw launch of run_sweep_flags: the same body behind a wait for the previous step's arrivals (a kernel of its own:
+// the few values the wait keeps alive would tip k_sweep4 into scratch memory)
+template <bool EXACT>
+__global__ __launch_bounds__(PF_BS) void k_sweep4h(const SweepChunk* tab_g, long long t, int nb) {
+    sweep_kernel_body<4, false, EXACT, false, true>(tab_g, t, nb);
+}
 
 // The bookkeeping, ledger and count roles of a step as a launch of their own: what the structured models run on the counting
 // stream beside their extend launch (k_sweep_xmp, pf_mp.hip).  The extend workgroups of those models carry their trees'
@@ -2483,11 +2500,26 @@ __global__ __launch_bounds__(PF_BS) void k_sweep_blc(const SweepChunk* tab_g, lo
     KArgsC& A = ch.A;
     const long long s = ch.s_begin + t;
     __shared__ Windows W;
+    Ctrl* c = A.ctrl;
     PipeLaunch PL;
-    if (!sweep_plan(ch, s, 0, PL)) return;
-    PL.nT = 0;                                             // the draw role rides with the extend launch
-    if ((int)blockIdx.x == 0 && PL.b_slot >= 0) sweep_windows(A, A.ctrl, PL.b_pos, W);
-    pipe_roles<NM, BIASED, false, false, P, true>(A, s, PL, W);
+    if (sweep_plan(ch, s, 0, PL)) {
+        PL.nT = 0;                                         // the draw role rides with the extend launch
+        if ((int)blockIdx.x == 0 && PL.b_slot >= 0) sweep_windows(A, c, PL.b_pos, W);
+        pipe_roles<NM, BIASED, false, false, P, true>(A, s, PL, W);
+    }
+    if (ch.handoff) {
+        // run_sweep_flags: the extend launch of step t + 14 overwrites ring slots this launch read; it polls Ctrl::blc_step, which the
+        // last workgroup of this launch to finish advances (launches of this kind run one after the other; nothing they WRITE is read
+        // by an extend launch, so no release is needed -- a release per workgroup would write the L2 back a thousand times a step)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned before = __hip_atomic_fetch_add(&c->blc_arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (before + 1 == gridDim.x) {
+                __hip_atomic_store(&c->blc_arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&c->blc_step, (int)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 // first step of a call: the seed of k_pipe_seed, and the chunk's window state
@@ -2505,6 +2537,8 @@ __global__ void k_sweep_seed(const SweepChunk* tab_g) {
         c->xr[slot].n_res = c->n_resample; c->xr[slot].gen = c->gen; c->xr[slot].flag = 0;
     }
     if ((int)threadIdx.x < A.E) c->counted_to[threadIdx.x] = ch.counted_to[threadIdx.x];
+    if ((int)threadIdx.x < PF_RING) c->xt_done[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { c->blc_arrive = 0; c->blc_step = 0; }
     if (ch.nT > 0) {
         // the draw table starts every call empty, from the counters the slots have now
         const size_t par = (size_t)((ch.s_begin + 1) & 1);          // parity of row s_begin - 1
@@ -3116,6 +3150,10 @@ struct pf_handle {
     size_t smem_pipe = 0;
     int ncw = 0;                  // count workgroups per epoch in the row pipeline (pf_params.count_wgs): the most a column gets
     std::vector<int> cw_off;      // [E + 1] first count workgroup of the j-th column, oldest epoch first (KArgs::cw_off)
+    bool flag_handoff = false;    // PF_DEBUG_FLAG_HANDOFF: one population, rows as extend / draw launches that alternate between two streams and
+                                  // bookkeeping / ledger / count launches on the counting stream, ordered by counters in memory instead of events
+    hipStream_t stream2 = nullptr;
+    bool sweep_handoff = false;   // (argument of sweep_table: the table it builds is for run_sweep_flags)
     bool count_units = false;     // k_sweep / k_sweep_blc with one population: the counts by generation (count_units_body), ncw workgroups per step
     bool split_roles = false;     // PF_DEBUG_SPLIT_ROLES: one population too runs the extend role and the other roles as two launches on two streams
     bool pipe_mp = false;         // structured models on the row pipeline: extend launches on the filter stream, the other roles on the counting stream
@@ -3351,6 +3389,9 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     h->use_k_pipe = (p->debug & PF_DEBUG_K_PIPE) != 0;
     h->no_spec_stage = (p->debug & PF_DEBUG_NO_SPEC_STAGE) != 0;
     h->split_roles = (p->debug & PF_DEBUG_SPLIT_ROLES) != 0;
+    // (instantiated for the headline shape only: at most four haplotypes, no focused sampling or guide, no tree dump)
+    h->flag_handoff = (p->debug & PF_DEBUG_FLAG_HANDOFF) != 0 && P == 1 && n <= 4 && m->n_bias_heights == 0 && m->n_rate_segments == 0 && !(p->flags & 2);
+    if (h->flag_handoff && hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) { delete h; return fail("hipStreamCreate failed"); }
     h->h_lags.assign(m->lags, m->lags + E);
     h->h_counted_to.assign(E, 0.0);
     h->h_L = m->loci_length;
@@ -3628,6 +3669,7 @@ void pf_destroy(pf_handle* h) {
     for (auto e : h->ev_x) if (e) hipEventDestroy(e);
     for (auto e : h->ev_blc) if (e) hipEventDestroy(e);
     if (h->cstream) hipStreamDestroy(h->cstream);
+    if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
     for (auto& sp : h->spans) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
     for (auto e : h->ev_pool) hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -4135,6 +4177,9 @@ static long long sweep_table(pf_handle* const* hs, int nh, long long s_begin, lo
         ch.nT = (g->A.dt_tab && g->P == 1) ? g->nblocks : 0;
         ch.split = (g->P == 1 && g->split_roles && !g->A.rec_trees) ? 1 : 0;
         ch.units = g->count_units ? 1 : 0;
+        ch.handoff = h->sweep_handoff ? 1 : 0;
+        ch.xt_wgs = h->sweep_handoff ? g->nblocks + (ch.nT > 0 ? 1 + ch.nT : 0) : 0;
+        if (h->sweep_handoff) ch.split = 1;
         if (last >= s_begin) steps = std::max(steps, last - s_begin + 3);
     }
     *failed = false;
@@ -4298,6 +4343,83 @@ static int run_sweep_mp(pf_handle* h, long long s_begin, long long s_end) {
     return 0;
 }
 
+// One population, rows handed over through memory (PF_DEBUG_FLAG_HANDOFF).  A row is two launches, as in the split arrangement of
+// run_sweep_mp -- k_sweep with the extend and draw roles, k_sweep_blc with bookkeeping, ledger and counts -- but no launch waits for
+// another launch to END: the extend / draw launches alternate between two streams, so that step t + 1 is dispatched while step t
+// still runs, and its workgroups wait in the kernel for the arrivals of step t's workgroups (Ctrl::xt_done; sweep_wait_ge); the
+// launches of the other roles follow one another on the counting stream and wait the same way for the extend launch they read
+// from; ring reuse (the extend launch of step t overwrites what the counts of step t - 14 read) is a wait on Ctrl::blc_step.  What
+// a row pays for the hand-off is then a release, an arrival and a poll (3.8 us for 157 wavefronts, pf_probe_handoff) instead of a
+// kernel boundary (5.4 us), and the count workgroups no longer share the launch of the extend workgroups.
+static int run_sweep_flags(pf_handle* h, long long s_begin, long long s_end) {
+    if (s_begin >= s_end) return 0;
+    const int nb = h->nblocks, E = h->E;
+    const bool biased = h->A.n_bias > 0 || h->A.g_K > 0;
+    const int nL_full = nb + std::max(16, std::min(PF_LEDGER_BLOCKS, 192));
+    if (h->ev_cnt) { hipStreamWaitEvent(h->stream, h->ev_cnt, 0); h->ev_cnt = nullptr; }
+    pf_handle* one[1] = {h};
+    bool failed = false;
+    // (sweep_table uploads the chunk table and runs the seed on h->stream; the hand-off fields are set in the host copy first)
+    h->sweep_handoff = true;
+    const long long steps = sweep_table(one, 1, s_begin, s_end, nL_full, &failed);
+    h->sweep_handoff = false;
+    if (failed) return -1;
+    if (steps == 0) return 0;
+    if (h->ev_x.empty()) {
+        std::vector<hipEvent_t> ev(32, nullptr);
+        bool ok = true;
+        for (auto& e : ev) if (ok && hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) { e = nullptr; ok = false; }
+        if (!ok) { for (auto e : ev) if (e) hipEventDestroy(e); g_err = "hipEventCreate failed"; return -1; }
+        h->ev_x.assign(ev.begin(), ev.begin() + 16); h->ev_blc.assign(ev.begin() + 16, ev.end());
+    }
+    hipEvent_t seeded = next_sync_event(h);
+    hipEventRecord(seeded, h->stream);
+    hipStreamWaitEvent(h->stream2, seeded, 0);
+    hipStreamWaitEvent(h->cstream, seeded, 0);
+    const int nT = h->h_sweep[0].nT;
+    const dim3 gx((unsigned)(nb + (nT > 0 ? 1 + nT : 0)), 1u), bx(PF_BS);
+    Windows W1 = no_windows(h), W2 = W1;
+    const long long last = h->h_sweep[0].s_last;
+    for (long long t = 0; t < steps; ++t) {
+        const long long s = s_begin + t;
+        hipStream_t xs = (t & 1) ? h->stream2 : h->stream;
+        hipEvent_t xdone = h->ev_x[(size_t)(t & 15)];
+        {
+            Timed tm(h, 0, timing_on(h, s) && !(t & 1));
+#define PF_LAUNCH_XF(KERN) hipExtLaunchKernelGGL((KERN), gx, bx, h->smem_pipe, xs, nullptr, xdone, 0, h->d_sweep, t, nb)
+            if (h->n == 4) PF_LAUNCH_XF((k_sweep4h<true>)); else PF_LAUNCH_XF((k_sweep4h<false>));
+#undef PF_LAUNCH_XF
+        }
+        if (check_launch("k_sweep (extend role, flag hand-off)")) return -1;
+        // the other roles' launch of step t reads what the extend launch of step t - 1 wrote: ordered by that launch's completion
+        // signal on the counting stream (a queue-level wait: nothing spins; this stream is not the critical one)
+        if (t >= 1) hipStreamWaitEvent(h->cstream, h->ev_x[(size_t)((t - 1) & 15)], 0);
+        const int columns = (s >= s_begin + 2 && s - 2 <= last && !h->no_count) ? E - W2.first : 0;
+        const int ncount = h->cw_off[columns];
+        const dim3 grid((unsigned)(1 + nL_full + ncount), 1u), blk(PF_BS);
+#define PF_LAUNCH_BLCF(NMV, BV) hipLaunchKernelGGL((k_sweep_blc<NMV, 1, BV>), grid, blk, h->smem_pipe, h->cstream, h->d_sweep, t)
+        if (h->n <= 4) { if (biased) PF_LAUNCH_BLCF(4, true); else PF_LAUNCH_BLCF(4, false); } else { if (biased) PF_LAUNCH_BLCF(8, true); else PF_LAUNCH_BLCF(8, false); }
+#undef PF_LAUNCH_BLCF
+        if (check_launch("k_sweep_blc (flag hand-off)")) return -1;
+        if ((t & 1023) == 1023) trim_spans(h);
+        W2 = W1;
+        if (s <= last) {
+            W1 = host_windows(h, seg_pos(h, s), false);
+            h->step_windows = W1;
+            if (W1.first < E && !h->no_count) h->fin_pending = true;
+        } else {
+            W1 = no_windows(h);
+        }
+    }
+    h->k_launches[0] -= 2;                                      // flush steps are not rows
+    // what follows on the filter stream waits for all three
+    hipEvent_t e2 = next_sync_event(h), ec = next_sync_event(h);
+    hipEventRecord(e2, h->stream2); hipEventRecord(ec, h->cstream);
+    hipStreamWaitEvent(h->stream, e2, 0); hipStreamWaitEvent(h->stream, ec, 0);
+    if (last >= s_begin) h->seg_done = last + 1;
+    return 0;
+}
+
 // why pf_run_many would refuse these handles (null: it would not)
 static const char* run_many_refusal(pf_handle* const* handles, int32_t n_handles) {
     if (n_handles < 1 || !handles || !handles[0]) return "pf_run_many: no handles";
@@ -4331,6 +4453,7 @@ int pf_run(pf_handle* h, int64_t s_begin, int64_t s_end) {
     if (extend_can_fuse(h)) {
         if (!h->pipe || h->two_launch_rows) return run_single_stream(h, s_begin, s_end);
         if (h->use_k_pipe) return run_pipeline(h, s_begin, s_end);
+        if (h->flag_handoff) return run_sweep_flags(h, s_begin, s_end);
         if (h->split_roles && !h->A.rec_trees) return run_sweep_mp(h, s_begin, s_end);
         pf_handle* one[1] = {h};
         return run_sweep(one, 1, s_begin, s_end);

@@ -201,8 +201,43 @@ struct SweepChunk {
     int nT;                        // draw-table workgroups per step (0: no table)
     int split;                     // the extend role (with the draw role) and the other roles are separate launches (PF_DEBUG_SPLIT_ROLES)
     int units;                     // count workgroups take units of one generation for all its epochs (ncw = workgroups per step)
+    int handoff;                   // launches hand over through Ctrl::xt_done / blc_step instead of through kernel boundaries (run_sweep_flags)
+    int xt_wgs;                    // workgroups of an extend / draw launch (what a slot of xt_done grows by per step)
 };
 typedef const __attribute__((address_space(4))) SweepChunk SweepChunkC;
+
+// Waiting for another launch inside a kernel (all threads of the workgroup call it): thread 0 polls `*ctr` until it reaches `target`
+// (or until somebody has reported an error: then everybody leaves at once), the workgroup barrier holds the others, and an acquire
+// at agent scope -- vector caches and the scalar cache -- makes what the other launch released visible to the loads that follow.
+// A workgroup that waits longer than any launch can take reports ERR_HANDOFF instead of hanging the device.
+__device__ __forceinline__ bool sweep_wait_ge(Ctrl* c, const unsigned* ctr, unsigned target) {
+    __shared__ int s_wait_bad;
+    if (threadIdx.x == 0) {
+        int bad = 0;
+        long long guard = 0;
+        // (relaxed polls: an acquiring load would invalidate the caches on every trip, for every workgroup that waits)
+        while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            if (__hip_atomic_load(&c->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { bad = 1; break; }
+            if (++guard > 30000000LL) { bad = 1; __hip_atomic_store(&c->err, (int)ERR_HANDOFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        s_wait_bad = bad;
+    }
+    __syncthreads();
+    const int bad_all = s_wait_bad;
+    __syncthreads();                                   // (the flag may be written again by the next wait)
+    return bad_all == 0;
+}
+// what another launch released becomes visible to the loads that follow: vector caches and the scalar cache
+__device__ __forceinline__ void sweep_acquire() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_s_dcache_inv();
+}
+// the workgroup's stores of this launch released, its arrival counted
+__device__ __forceinline__ void sweep_arrive(unsigned* ctr) {
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 template <class KA>
 __device__ __forceinline__ double sweep_seg_pos(const KA& A, long long s) {       // seg_pos() of the host

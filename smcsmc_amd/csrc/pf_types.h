@@ -92,6 +92,12 @@ struct Ctrl {
     // what the extend role itself notes about the row it completes (slot r & (PF_RING - 1)): the structured models' extend launches run
     // on their own stream and do not wait for the bookkeeping role, which derives the same numbers on the counting stream
     struct ExtendNote { long long n_res; int gen; int flag; } xr[PF_RING];
+    // Hand-off between launches through memory (PF_DEBUG_FLAG_HANDOFF, run_sweep_flags): the extend / draw launch of step t is enqueued
+    // without waiting for the launch of step t - 1 to end; its workgroups wait here for the arrivals of that launch's workgroups.
+    // Counters only grow during a pf_run call (slot t & (PF_RING - 1) is at (t / PF_RING + 1) x workgroups-per-launch when step t is done).
+    unsigned xt_done[PF_RING];   // arrivals of the extend / draw launches
+    unsigned blc_arrive;         // arrivals of the bookkeeping / ledger / count launch in flight (they run one after the other)
+    int blc_step;                // steps whose bookkeeping / ledger / count launch has ended
     double last1[PF_RING];       // pilot scan value at the last particle of the row in ring slot k (= oracle incl[N-1] minus chunk offset)
 };
 
@@ -278,7 +284,7 @@ struct Windows {
 };
 
 enum { ERR_LOG_OVERFLOW = 1, ERR_GEN_OVERFLOW = 2, ERR_ZERO_PROB = 3, ERR_COUNT_MISMATCH = 4, ERR_MIG_OVERFLOW = 5,
-       ERR_MP_INTERNAL = 6, ERR_NO_COALESCENCE = 7, ERR_DELAY_OVERFLOW = 8 };
+       ERR_MP_INTERNAL = 6, ERR_NO_COALESCENCE = 7, ERR_DELAY_OVERFLOW = 8, ERR_HANDOFF = 9 };
 
 // record meta word: type | lim_start+1 << 8 | lim_event+1 << 16 | n_eff << 24 | descendants << 32 (samples below the
 // branch cut by the recombination that ends the stretch, bit i = sample i; descendants.hpp:22-33) | descendants of the
