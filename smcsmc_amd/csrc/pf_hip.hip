@@ -1297,6 +1297,7 @@ struct LMap {
     double* gopp;         // global differential opportunity (null: map not recorded)
     double* gcnt;         // global counts [(n+2)][nbins]
     long long nbins;
+    int ncnt;             // bins whose (n+2) count rows are collected in LDS too, behind the nlds opportunity bins (0: the counts go to memory)
 };
 __device__ __forceinline__ void lmap_add(const LMap& L, long long idx, double v) {
     if (idx < 0 || idx >= L.nbins) return;
@@ -1306,24 +1307,37 @@ __device__ __forceinline__ void lmap_add(const LMap& L, long long idx, double v)
     if (k >= 0 && k < L.nlds) __hip_atomic_fetch_add((lds_double*)L.lds + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else atomicAdd(&L.gopp[idx], v);
 }
-// constant opportunity density over [x_lo, x_hi): the differential encoding of count.cpp:578-588
+// constant opportunity density over [x_lo, x_hi): the differential encoding of count.cpp:578-588.  When the stretch spans more than one
+// interval the two additions at its left end depend on (x_lo, density) only and the two at its right end on (x_hi, density) only.
+__device__ __forceinline__ void lmap_left(const LMap& L, double x_lo, double dens) {
+    const double iv = 100.0;
+    const long long first = (long long)(x_lo / iv);
+    const double fi = (double)(first + 1) * iv - x_lo;
+    lmap_add(L, first, fi * dens);
+    lmap_add(L, first + 1, (iv - fi) * dens);
+}
+__device__ __forceinline__ void lmap_right(const LMap& L, double x_hi, double dens) {
+    const double iv = 100.0;
+    const long long last = (long long)(1 + x_hi / iv);
+    const double li = x_hi - (double)(last - 1) * iv;
+    lmap_add(L, last - 1, (li - iv) * dens);
+    lmap_add(L, last, -(li * dens));
+}
 __device__ __forceinline__ void lmap_opportunity(const LMap& L, double x_lo, double x_hi, double weight, double opp) {
     const double iv = 100.0;
     long long first = (long long)(x_lo / iv);
     long long last = (long long)(1 + x_hi / iv);
-    double top = (double)(first + 1) * iv;
-    double first_interval = (top < x_hi ? top : x_hi) - x_lo;
-    double bot = (double)(last - 1) * iv;
-    double last_interval = x_hi - (bot > x_lo ? bot : x_lo);
     double dens = weight * opp / (x_hi - x_lo);
     if (first == last - 1) {
+        double top = (double)(first + 1) * iv;
+        double first_interval = (top < x_hi ? top : x_hi) - x_lo;
         lmap_add(L, first, first_interval * dens);
         lmap_add(L, first + 1, -(first_interval * dens));
     } else {
-        lmap_add(L, first, first_interval * dens);
-        lmap_add(L, first + 1, (iv - first_interval) * dens);
-        lmap_add(L, last - 1, (last_interval - iv) * dens);
-        lmap_add(L, last, -(last_interval * dens));
+        // (keeping the densities of the ends that coincide with the window's -- most of them -- in two registers per lane and adding them
+        // once per wavefront was measured: slower, 3.29e4 -> 3.20e4 segments/s for one chunk, the registers cost more than the conflicts)
+        lmap_left(L, x_lo, dens);
+        lmap_right(L, x_hi, dens);
     }
 }
 // a recombination event at event_base, height h, below which the samples `desc` hang (count.cpp:590-612)
@@ -1331,6 +1345,18 @@ __device__ __forceinline__ void lmap_event(const LMap& L, int n, double event_ba
     long long idx = (long long)(event_base / 100.0);
     if (idx < 0 || idx >= L.nbins) return;
     const int nd = __popc(desc);
+    const long long k = idx - L.b0;
+    if (k >= 0 && k < L.ncnt) {
+        // the workgroup's own rows of the counts: a row's events all fall into the few intervals of its epoch's window, and every one
+        // of them used to be n + 2 additions on memory, to the same handful of addresses as everybody else's
+        typedef __attribute__((address_space(3))) double lds_double;
+        lds_double* base = (lds_double*)L.lds + L.nlds + k;
+        for (int i = 0; i < n; ++i)
+            if ((desc >> i) & 1u) __hip_atomic_fetch_add(base + (size_t)i * L.ncnt, weight / nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(base + (size_t)n * L.ncnt, weight * h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(base + (size_t)(n + 1) * L.ncnt, weight * dlog(h + 1.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+    }
     for (int i = 0; i < n; ++i)
         if ((desc >> i) & 1u) atomicAdd(&L.gcnt[(size_t)i * L.nbins + idx], weight / nd);
     atomicAdd(&L.gcnt[(size_t)n * L.nbins + idx], weight * h);
@@ -1540,6 +1566,7 @@ __device__ __forceinline__ void count_body(const KA& A, const CountSrc& Q, int e
     {
         const long long span = (long long)(W.b_e / 100.0) - L.b0 + 4;
         L.nlds = span < 1 ? 1 : (span > PF_LBINS ? PF_LBINS : (int)span);
+        L.ncnt = (A.n + 3) * L.nlds <= PF_LBINS ? L.nlds : 0;       // room for the n + 2 count rows of the same intervals
     }
     bool bins_ready = false;
     const int g_lo = Q.g_lo, g_hi = Q.g_hi;
@@ -1602,7 +1629,7 @@ __device__ __forceinline__ void count_body(const KA& A, const CountSrc& Q, int e
         if (tile_hi == g_hi && tile_lo == g_lo && (long long)bx * PF_BS >= T) return;
         if (A.flags & (1 << 20)) return;          // probe: what the workgroups cost before their first task
         if (L.gopp && !bins_ready) {
-            for (int k = threadIdx.x; k < L.nlds; k += PF_BS) s_lbins[k] = 0.0;
+            for (int k = threadIdx.x; k < L.nlds + (A.n + 2) * L.ncnt; k += PF_BS) s_lbins[k] = 0.0;
             __syncthreads();
             bins_ready = true;
         }
@@ -1704,6 +1731,11 @@ __device__ __forceinline__ void count_body(const KA& A, const CountSrc& Q, int e
             double v = s_lbins[k];
             long long idx = L.b0 + k;
             if (v != 0.0 && idx < L.nbins) atomicAdd(&L.gopp[idx], v);
+        }
+        for (int k = threadIdx.x; k < (A.n + 2) * L.ncnt; k += PF_BS) {
+            const double v = s_lbins[L.nlds + k];
+            const long long idx = L.b0 + k % L.ncnt;
+            if (v != 0.0 && idx < L.nbins) atomicAdd(&L.gcnt[(size_t)(k / L.ncnt) * L.nbins + idx], v);
         }
     }
 #pragma unroll
@@ -1946,7 +1978,7 @@ __device__ __forceinline__ void count_units_body(const KA& A, const CountSrc& Q,
                     W.e = e; W.rf = Z.rf[e]; W.T0 = Z.T[e]; W.T1 = e + 1 < E ? Z.T[e + 1] : PF_INF; W.a_e = Z.wa[e]; W.b_e = Z.wb[e];
                     W.end_seq = (A.L == W.b_e);
                     LMap L;
-                    L.lds = s_lbins + Z.boff[jj]; L.b0 = Z.bb0[jj]; L.nlds = Z.bn[jj]; L.gopp = A.lmap_opp; L.gcnt = A.lmap_cnt; L.nbins = A.lmap_bins;
+                    L.lds = s_lbins + Z.boff[jj]; L.b0 = Z.bb0[jj]; L.nlds = Z.bn[jj]; L.gopp = A.lmap_opp; L.gcnt = A.lmap_cnt; L.nbins = A.lmap_bins; L.ncnt = 0;
                     AC acc;
 #pragma unroll
                     for (int k = 0; k < AC::NC; ++k) acc.v[k] = 0.0;
