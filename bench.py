@@ -232,6 +232,8 @@ def main():
                          "1 = the headline single-chunk configuration")
     ap.add_argument("--count-wgs", type=int, default=0, help="pf_params.count_wgs: count workgroups per epoch in the row pipeline (0 = default: one per "
                     "particle block; 24 with six or more chunks per GPU, where the chip holds a fraction of the count workgroups at a time)")
+    ap.add_argument("--count-workers", type=int, default=-1, help="pf_params.count_workers: with several chunks per GPU, workgroups per chunk and step that take the "
+                    "ledger and count work off a queue (0 = every work item a workgroup of the launch; default: 0 for one chunk)")
     ap.add_argument("--chunk-threads", action="store_true",
                     help="with --chunks-per-gpu: one host thread and stream per chunk (rounds 1 and 2) instead of pf_run_many")
     args = ap.parse_args()
@@ -265,7 +267,8 @@ def main():
         model, segs = build_workload(args, seed=args.seed + rank * C + k)     # independent chunks
         f = ParticleFilter(model, args.np, ess_fraction=0.5, seed=args.seed + 1000 * (rank * C + k), max_trace_events=0,
                            device=dev, local_recomb=not args.no_local_recomb, debug=args.debug,
-                           count_wgs=args.count_wgs or (24 if (args.chunks_per_gpu >= 6 and not (args.debug & 2048)) else 0))
+                           count_wgs=args.count_wgs or (24 if (args.chunks_per_gpu >= 6 and not (args.debug & 2048)) else 0),
+                           count_workers=max(0, args.count_workers))
         f.load_segments(segs)
         chunks.append((f, segs))
     pf, segs = chunks[0]

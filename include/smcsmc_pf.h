@@ -103,6 +103,11 @@ typedef struct pf_params {
                                   * delay_cap entries per particle in device memory.  One factor too many is a reported error
                                   * ("delayed-factor store overflow"), unless flags bit2 is set: then the earliest pending factor is
                                   * applied ahead of its position to make room, and pf_get_delay_stats says how often that happened. */
+    int32_t count_workers;       /* row pipeline: > 0 = the ledger and count work of a step is dealt out at run time among this many workgroups
+                                  * per chunk (a counter in device memory; every item still writes its own accumulators: the sums are those of
+                                  * count_workers = 0, where every item is a workgroup of its own in the launch).  For several chunks per GPU
+                                  * (pf_run_many), where the launch of a step is several thousand workgroups otherwise. */
+    int32_t reserved4;
 } pf_params;
 #define PF_DEBUG_FORCE_LDS 1     /* run the LDS-tree kernels whatever nsam is */
 #define PF_DEBUG_NO_FUSE   2     /* complete every row with the stand-alone k_resample (two-stream pipeline) */
@@ -129,6 +134,9 @@ typedef struct pf_params {
 #define PF_DEBUG_FLAG_HANDOFF 8192 /* one population: a row as two launches (extend + draw roles; bookkeeping + ledger + counts) that no longer wait
                                   * for each other's END: the extend launches alternate between two streams and hand the row over through
                                   * arrival counters in memory, the other launches wait the same way (run_sweep_flags; same bits) */
+
+#define PF_DEBUG_CHUNK_FASTEST (1 << 23) /* pf_run_many: the grid of a step as (chunks, 1, workgroups per chunk) -- every chunk's extend workgroups
+                                  * are handed out before any chunk's count workgroups -- instead of (workgroups per chunk, chunks); A/B, same bits */
 
 #define PF_DEBUG_CU_MASK 1024     /* with PF_DEBUG_SPLIT_ROLES: the two streams on disjoint sets of compute units (experiment) */
 
@@ -256,6 +264,13 @@ int pf_test_search_lut(const double* tab, int32_t n, uint8_t* lut, int32_t* kbas
  * release stores, an arrival counter per row, polling, coherent loads), with spin_ticks x 10 ns of stand-in work per wavefront
  * and row and the same reduction of all wavefronts' five partials either way.  Microseconds per row in *us_per_row. */
 int pf_probe_handoff(int32_t mode, int32_t rows, int32_t nw, int64_t spin_ticks, double* us_per_row, double* checksum, int32_t device);
+/* measurement aid: time stamps of every workgroup of the row kernel (k_sweep4t, pf_hip.hip; at most four haplotypes, no focused sampling)
+ * for steps [first_step, first_step + n_steps) of the following pf_run / pf_run_many calls led by `h`.  pf_get_wg_trace copies four
+ * 64-bit words per workgroup slot and traced step -- start, end (100 MHz clock; 0 0: the step's grid did not use the slot),
+ * HW_ID | XCC_ID << 32, index within the chunk | chunk << 32 -- returns the number of words there are and fills
+ * info = {steps, slots per step}.  n_steps = 0 switches the trace off. */
+int pf_set_wg_trace(pf_handle* h, int64_t first_step, int32_t n_steps);
+int64_t pf_get_wg_trace(pf_handle* h, uint64_t* out, int64_t cap_words, int32_t* info);
 /* the delayed-factor store (adjustWeightsWithDelay, particle.hpp:185-209): factors applied ahead of their position because the
  * store was full (only with pf_params.flags bit2; otherwise that is an error) and the most factors any particle ever had pending */
 int pf_get_delay_stats(pf_handle* h, int64_t* n_forced, int32_t* peak_pending);

@@ -193,6 +193,17 @@ __device__ __forceinline__ void philox_pair(unsigned long long seed, unsigned sl
     u1 = ((double)b1 + 0.5) * 1.1102230246251565e-16;
 }
 
+// The index of a workgroup within its chunk.  The row kernels of the sweep (k_sweep*, k_sweep_blc) have one of two grids: (workgroups
+// per chunk, chunks) -- the dispatcher hands workgroups out x fastest: all of chunk 0, then all of chunk 1 ... -- or, with
+// PF_DEBUG_CHUNK_FASTEST, (chunks, 1, workgroups per chunk): the first workgroups of EVERY chunk (the extend role, whose chain of
+// dependent loads is the critical path of a step) before any chunk's ledger and count workgroups.  Every other kernel has a grid of one
+// dimension, or (workgroups, epochs): the index is blockIdx.x in all of them but the chunk-fastest form.
+__device__ __forceinline__ int pf_bx() { return (int)(gridDim.z > 1 ? blockIdx.z : blockIdx.x); }
+// ... and the chunk of a workgroup of those kernels.  Consecutive workgroups go to consecutive XCDs: in the chunk-fastest form with
+// chunk = blockIdx.x each of eight chunks would have an XCD to itself, and a step would last as long as the chunk with the most count
+// work on that row (measured: 117 us a step against 104 us); rotated by the workgroup's index every chunk visits all XCDs in turn.
+__device__ __forceinline__ int pf_chunk() { return (int)(gridDim.z > 1 ? (blockIdx.x + blockIdx.z) % gridDim.x : blockIdx.y); }
+
 // ------------------------------------------------------------------ wavefront (64-lane) primitives
 // xor-butterfly sum: every lane ends with the same pairwise-tree total (matches oracle tree64).
 __device__ __forceinline__ double wave_tree_sum(double v) {

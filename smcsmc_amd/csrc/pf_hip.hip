@@ -350,13 +350,13 @@ __device__ __forceinline__ void pf_acc_trip(unsigned long long* a) { a[5] += 1; 
 #endif
 #ifdef PF_STAMPS
 #define PF_STAMP(k) do { if (A.stamps && (threadIdx.x & 63) == 0 && s < A.stamp_rows)                                   \
-        A.stamps[((size_t)s * A.nc + (size_t)(((long long)blockIdx.x * PF_BS + threadIdx.x) >> 6)) * PF_STAMP_W + (k)] = wall_clock64(); } while (0)
+        A.stamps[((size_t)s * A.nc + (size_t)(((long long)pf_bx() * PF_BS + threadIdx.x) >> 6)) * PF_STAMP_W + (k)] = wall_clock64(); } while (0)
 #define PF_TICK(var) unsigned long long var = wall_clock64()
 #define PF_ACC(slot, t0, t1) pf_acc[slot] += (t1) - (t0)
 #define PF_ACC_DECL unsigned long long pf_acc[6] = {0, 0, 0, 0, 0, 0}
 #define PF_ACC_STORE do { if (A.stamps && (threadIdx.x & 63) == 0 && s < A.stamp_rows)                                  \
         for (int k_ = 0; k_ < 6; ++k_)                                                                                  \
-            A.stamps[((size_t)s * A.nc + (size_t)(((long long)blockIdx.x * PF_BS + threadIdx.x) >> 6)) * PF_STAMP_W + 9 + k_] = pf_acc[k_]; } while (0)
+            A.stamps[((size_t)s * A.nc + (size_t)(((long long)pf_bx() * PF_BS + threadIdx.x) >> 6)) * PF_STAMP_W + 9 + k_] = pf_acc[k_]; } while (0)
 #else
 #define PF_STAMP(k) do {} while (0)
 #define PF_TICK(var) do {} while (0)
@@ -391,7 +391,7 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
     double* sBS = sBH + (PF_BIAS_MAX + 2);
     const Ctrl* c = A.ctrl;
     const int n = EXACT ? NM : A.n;
-    const long long p = (long long)blockIdx.x * PF_BS + threadIdx.x;
+    const long long p = (long long)pf_bx() * PF_BS + threadIdx.x;
     const bool active = p < A.Np;
     const int lane = threadIdx.x & 63;
     // PIPE: everything the prologue and the particle itself need from memory is requested first, in one round trip: the
@@ -420,7 +420,7 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
             // of this workgroup's own wavefronts and six on either side are requested now, with everything else the prologue
             // reads, instead of in a round trip of their own once the search knows the range; a range outside this window
             // is staged the old way.
-            spec_lo = (int)blockIdx.x * (PF_BS / 64) - (PF_PIPE_STAGE - PF_BS / 64) / 2;
+            spec_lo = pf_bx() * (PF_BS / 64) - (PF_PIPE_STAGE - PF_BS / 64) / 2;
             if (spec_lo > A.nc - PF_PIPE_STAGE) spec_lo = A.nc - PF_PIPE_STAGE;
             if (spec_lo < 0) spec_lo = 0;
             if (A.flags & 256) spec_lo = -0x40000000;              // PF_DEBUG_NO_SPEC_STAGE (A/B): never covers the range
@@ -489,7 +489,7 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
             PF_STAMP(2);
             inv = d.inv; S1v = d.S1;
             gather = d.flag != 0;
-            if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (pf_bx() == 0 && threadIdx.x == 0) {
                 Ctrl* cw = A.ctrl;
                 cw->xr[row_slot].n_res = n_res; cw->xr[row_slot].gen = G_end; cw->xr[row_slot].flag = d.flag;
             }
@@ -563,7 +563,7 @@ __device__ __forceinline__ void extend_reg_body(const KA& A, long long s, int fu
                 if (threadIdx.x == 0) {
                     int tot = 0;
                     for (int w = 0; w < PF_BS / 64; ++w) tot += q.wint[2 * (PF_BS / 64) + w];
-                    A.rg_blkcnt[(size_t)row_slot * gridDim_particles(A) * A.blk_gran + blockIdx.x] = tot;
+                    A.rg_blkcnt[(size_t)row_slot * gridDim_particles(A) * A.blk_gran + pf_bx()] = tot;
                 }
                 if (active) {
                     const double coff_p = pipe_chunk_offset(q, pch);
@@ -1086,7 +1086,7 @@ __device__ __forceinline__ void decide_body(const KA& A, long long s, int mode, 
     __shared__ double pm[4096];           // exclusive prefix max over chunks of the pilot prefix sums
     Ctrl* c = A.ctrl;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = PF_BS / 64;
-    if ((int)blockIdx.x == nblocks) {
+    if (pf_bx() == nblocks) {
         window_generations(A, c, W, tid);
         return;
     }
@@ -1094,7 +1094,7 @@ __device__ __forceinline__ void decide_body(const KA& A, long long s, int mode, 
     const int nc = (int)((Np + 63) / 64);
     const int ng = (nc + 63) / 64;
     const double last_scan1 = A.scan1[Np - 1];
-    const long long i_own = (long long)blockIdx.x * PF_BS + tid;
+    const long long i_own = (long long)pf_bx() * PF_BS + tid;
     const double own_scan1m = (i_own > 0 && i_own < Np) ? A.scan1m[i_own - 1] : 0.0;
     const double next_scan1m = (i_own + 1 < Np) ? A.scan1m[i_own] : 0.0;
     // generation / event counters as published by the previous k_resample: workgroup 0 advances the live ones
@@ -1112,7 +1112,7 @@ __device__ __forceinline__ void decide_body(const KA& A, long long s, int mode, 
         double rs = wave_tree_sum(vs);
         double sc = wave_hs_scan(vl, lane);
         double scq = wave_hs_scan(vq, lane);
-        if (ch < nc) { l2s[ch] = sc; if (blockIdx.x == 0) A.l2scanp[ch] = scq; }
+        if (ch < nc) { l2s[ch] = sc; if (pf_bx() == 0) A.l2scanp[ch] = scq; }
         if (lane == 63) { l2_post[g] = rp; l2_sq[g] = rs; l2_tot[g] = sc; l2_totp[g] = scq; }
     }
     __syncthreads();
@@ -1131,7 +1131,7 @@ __device__ __forceinline__ void decide_body(const KA& A, long long s, int mode, 
         double off = (ch % 64 == 0) ? 0.0 : l2s[ch - 1];
         return run + off;
     };
-    if (blockIdx.x == 0) {
+    if (pf_bx() == 0) {
         for (int ch = tid; ch < nc; ch += PF_BS) {
             A.chunk_off[ch] = chunk_offset(ch);
             double runp = 0.0;
@@ -1149,7 +1149,7 @@ __device__ __forceinline__ void decide_body(const KA& A, long long s, int mode, 
         pos = seg_end < A.L ? seg_end : A.L;
     }
     const double u = flag ? philox_uniform(A.seed, 0xFFFFFFFFu, 1, n_res) : 0.0;
-    if (blockIdx.x == 0 && tid == 0) {
+    if (pf_bx() == 0 && tid == 0) {
         if (!(T > 0.0) && !c->err) c->err = ERR_ZERO_PROB;       // the first error is the one reported
         double logl = c->logl + dlog(T);
         c->logl = logl;
@@ -1229,8 +1229,8 @@ __device__ __forceinline__ void decide_body(const KA& A, long long s, int mode, 
     if (tid == 0) {
         int tot = 0;
         for (int w = 0; w < nwaves; ++w) tot += wred[w];
-        A.blkcnt2[A.sp][blockIdx.x] = tot;
-        if (blockIdx.x == 0) {
+        A.blkcnt2[A.sp][pf_bx()] = tot;
+        if (pf_bx() == 0) {
             // toggle buffers / open the next generation
             int ev = (int)n_res;
             if (ev < A.max_trace_events) A.ev_seg[ev] = (int)s;
@@ -2307,6 +2307,7 @@ __device__ __forceinline__ void pipe_bookkeeping(const KA& A, const PipeLds& q, 
         c->count_active = W.first < E;
         if (W.first < E) c->pending_fin = 1;
         c->nbx_used = A.nbx;
+        c->wq[PL.b_slot] = 0;                 // the next step deals out the ledger and count work of this row (pipe_roles)
         if (!(d.T > 0.0) && !c->err) c->err = ERR_ZERO_PROB;
         double logl = c->logl + dlog(d.T);
         c->logl = logl;
@@ -2361,57 +2362,18 @@ __device__ __forceinline__ void draw_role(const KA& A, int tb, int nT, int par) 
     }
 }
 
-template <int NM, bool BIASED, bool EXACT, bool TREES, int P = 1, bool BLC = false, class KA>
-__device__ __forceinline__ void pipe_roles(const KA& A, long long s, const PipeLaunch& PL, const Windows& Wb) {
-    const int bx = (int)blockIdx.x;
-    const int nb = PL.nb;
-    if (bx < nb) {
-        if constexpr (P == 1) { if (PL.row.extend || PL.row.complete) extend_reg_body<NM, BIASED, EXACT, TREES, true>(A, s, 0, PL.row); }
-        return;
-    }
-    if (bx == nb) {
-        if (PL.b_slot < 0 || PL.nL < -1) return;           // nL = -2: the extend launch of a split step
-        extern __shared__ double smem[];
-        PipeLds q = pipe_carve(smem + (2 * PF_EPAD + A.E + 2 * PF_BIAS_MAX + 3), A.nc);
-        pipe_bookkeeping<BIASED>(A, q, PL, Wb);
-        return;
-    }
-    if (bx - (nb + 1) < PL.nT) {
-        if constexpr (P == 1) draw_role(A, bx - (nb + 1), PL.nT, PL.row.draws - 1);
-        return;
-    }
-    if (PL.lc_slot < 0 || PL.nL < -1) return;
-    const Ctrl* c = A.ctrl;
-    const Ctrl::RowInfo& r = c->ri[PL.lc_slot];
-    const int lb = bx - (nb + 1) - PL.nT;
-    if (lb < PL.nL) {
-        if (!r.flag) return;
-        const RunLists src = run_lists(A, r.lver), dst = run_lists(A, r.lver ^ 1);
-        const int nblk = PL.nblk;              // particle blocks of 256 (the extend workgroups of the one-population kernels)
-        if (lb < nblk) ledger_new_list(A, dst, A.rg_blkcnt + (size_t)PL.lc_slot * nblk * A.blk_gran, nblk, lb, r.gen, A.blk_gran);
-        else ledger_update(A, lb - nblk, PL.nL - nblk, r.gen, r.g_retain, src, dst);
-        return;
-    }
-    const int idx = lb - PL.nL;
-    if constexpr (P == 1 && BLC) {
-        // (only in the launch of the bookkeeping / ledger / count roles of the split arrangement: in the one launch of k_sweep the
-        // body would raise the kernel's register count past the 168 that let three workgroups share a compute unit)
-        if (PL.units) {
-            // counting by generation: the workgroups of the step deal the (generation, 256 tasks) units out among themselves
-            if (idx >= PL.ncw || r.first >= A.E) return;
-            const DState st = state_slot(A, PL.lc_slot);
-            CountSrc Q;
-            Q.w = st.w_post; Q.S = st.S; Q.xm = st.x_mark; Q.ml = st.mark_limit;
-            Q.widx = A.rg_widx + (size_t)PL.lc_slot * A.Np;
-            Q.widx_live = A.rg_widx + (size_t)PL.live_slot * A.Np;
-            Q.scanp = A.rg_scanp + (size_t)PL.lc_slot * A.Np;
-            Q.offp = A.rg_coffp + (size_t)PL.lc_slot * A.nc;
-            Q.lists = run_lists(A, r.lver);
-            Q.inv = r.inv_T; Q.G = r.gen; Q.g_lo = 0; Q.g_hi = 0;
-            count_units_body<NM, EXACT>(A, Q, r, idx, PL.ncw);
-            return;
-        }
-    }
+// one block of the ledger upkeep of the row in ring slot PL.lc_slot (a resampling row): the new run list, or a share of the old ones
+template <class KA>
+__device__ __forceinline__ void pipe_ledger_item(const KA& A, const PipeLaunch& PL, const Ctrl::RowInfo& r, int lb) {
+    const RunLists src = run_lists(A, r.lver), dst = run_lists(A, r.lver ^ 1);
+    const int nblk = PL.nblk;              // particle blocks of 256 (the extend workgroups of the one-population kernels)
+    if (lb < nblk) ledger_new_list(A, dst, A.rg_blkcnt + (size_t)PL.lc_slot * nblk * A.blk_gran, nblk, lb, r.gen, A.blk_gran);
+    else ledger_update(A, lb - nblk, PL.nL - nblk, r.gen, r.g_retain, src, dst);
+}
+
+// count work item idx of that row: part cbx of cnb of the column of epoch e
+template <int NM, bool EXACT, int P, class KA>
+__device__ __forceinline__ void pipe_count_item(const KA& A, const PipeLaunch& PL, const Ctrl::RowInfo& r, int idx) {
     // the columns of the oldest epochs first: their lags are the shortest, their windows sit right behind the front where
     // nearly every particle is still its own ancestor, and their workgroups are the long ones -- dispatched last they were
     // what a launch ended with
@@ -2438,13 +2400,90 @@ __device__ __forceinline__ void pipe_roles(const KA& A, long long s, const PipeL
     count_body<NM, P, EXACT>(A, Q, e, r.wa[e], r.wb[e], cbx, cnb);
 }
 
+template <int NM, bool BIASED, bool EXACT, bool TREES, int P = 1, bool BLC = false, bool QUEUE = false, class KA>
+__device__ __forceinline__ void pipe_roles(const KA& A, long long s, const PipeLaunch& PL, const Windows& Wb) {
+    const int bx = pf_bx();
+    const int nb = PL.nb;
+    if (bx < nb) {
+        if constexpr (P == 1) { if (PL.row.extend || PL.row.complete) extend_reg_body<NM, BIASED, EXACT, TREES, true>(A, s, 0, PL.row); }
+        return;
+    }
+    if (bx == nb) {
+        if (PL.b_slot < 0 || PL.nL < -1) return;           // nL = -2: the extend launch of a split step
+        extern __shared__ double smem[];
+        PipeLds q = pipe_carve(smem + (2 * PF_EPAD + A.E + 2 * PF_BIAS_MAX + 3), A.nc);
+        pipe_bookkeeping<BIASED>(A, q, PL, Wb);
+        return;
+    }
+    if (bx - (nb + 1) < PL.nT) {
+        if constexpr (P == 1) draw_role(A, bx - (nb + 1), PL.nT, PL.row.draws - 1);
+        return;
+    }
+    if (PL.lc_slot < 0 || PL.nL < -1) return;
+    const Ctrl* c = A.ctrl;
+    const Ctrl::RowInfo& r = c->ri[PL.lc_slot];
+    const int lb = bx - (nb + 1) - PL.nT;
+    if constexpr (P == 1 && BLC) {
+        // (only in the launch of the bookkeeping / ledger / count roles of the split arrangement: in the one launch of k_sweep the
+        // body would raise the kernel's register count past the 168 that let three workgroups share a compute unit)
+        if (PL.units && PL.workers == 0) {
+            // counting by generation: the workgroups of the step deal the (generation, 256 tasks) units out among themselves
+            const int idx = lb - PL.nL;
+            if (idx < 0) { if (r.flag) pipe_ledger_item(A, PL, r, lb); return; }
+            if (idx >= PL.ncw || r.first >= A.E) return;
+            const DState st = state_slot(A, PL.lc_slot);
+            CountSrc Q;
+            Q.w = st.w_post; Q.S = st.S; Q.xm = st.x_mark; Q.ml = st.mark_limit;
+            Q.widx = A.rg_widx + (size_t)PL.lc_slot * A.Np;
+            Q.widx_live = A.rg_widx + (size_t)PL.live_slot * A.Np;
+            Q.scanp = A.rg_scanp + (size_t)PL.lc_slot * A.Np;
+            Q.offp = A.rg_coffp + (size_t)PL.lc_slot * A.nc;
+            Q.lists = run_lists(A, r.lver);
+            Q.inv = r.inv_T; Q.G = r.gen; Q.g_lo = 0; Q.g_hi = 0;
+            count_units_body<NM, EXACT>(A, Q, r, idx, PL.ncw);
+            return;
+        }
+    }
+    // The ledger and count work of the step: items -- a ledger block of a resampling row, or part cbx of the count column of an
+    // epoch.  Without pf_params.count_workers every item is a workgroup of this launch (ledger blocks first, then the columns,
+    // oldest epoch first).
+    if constexpr (!QUEUE) {
+        if (lb < PL.nL) { if (r.flag) pipe_ledger_item(A, PL, r, lb); }
+        else pipe_count_item<NM, EXACT, P>(A, PL, r, lb - PL.nL);
+    } else {
+        // With it, `workers` workgroups take the items -- the columns first, then the ledger's blocks -- off a counter until none is
+        // left: an item writes the same accumulators whoever runs it, the sums do not change.  What that saves several chunks per
+        // GPU: the 232 ledger workgroups per chunk and step that find no resampling and leave (2 us of a slot each), the prologue
+        // of 260 count workgroups, and the dispatcher's strict order -- workgroup i + 1 is not placed before workgroup i, so one
+        // full XCD holds up the other seven while long count workgroups run (profiles/round4/wg_trace.md).  A kernel instance of
+        // its own (k_sweep4q): in the static form the count body is the last thing a workgroup does and nothing is live across it;
+        // what this loop needs after an item comes back from LDS.
+        __shared__ int s_wk[8];
+        if (lb >= PL.workers) return;
+        if (threadIdx.x == 0) { s_wk[0] = PL.lc_slot; s_wk[1] = PL.live_slot; s_wk[2] = PL.nL; s_wk[3] = PL.nblk; s_wk[4] = PL.ncw; }
+        for (;;) {
+            __syncthreads();
+            if (threadIdx.x == 0) s_wk[6] = (int)__hip_atomic_fetch_add(&A.ctrl->wq[s_wk[0]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            PipeLaunch Q2;
+            Q2.lc_slot = s_wk[0]; Q2.live_slot = s_wk[1]; Q2.nL = s_wk[2]; Q2.nblk = s_wk[3]; Q2.ncw = s_wk[4];
+            const int it = s_wk[6];
+            const Ctrl::RowInfo& r2 = A.ctrl->ri[Q2.lc_slot];
+            const int ncnt = r2.first < A.E ? (A.cw_off ? A.cw_off[A.E - r2.first] : (A.E - r2.first) * Q2.ncw) : 0;
+            if (it >= ncnt + (r2.flag ? Q2.nL : 0)) return;                  // (every workgroup gets here: the counter only grows)
+            if (it < ncnt) pipe_count_item<NM, EXACT, P>(A, Q2, r2, it);
+            else pipe_ledger_item(A, Q2, r2, it - ncnt);
+        }
+    }
+}
+
 template <int NM, bool BIASED, bool EXACT, bool TREES>
 __global__ __launch_bounds__(PF_BS) void k_pipe(KArgs A, long long s, PipeLaunch PL, Windows Wb) {
     pipe_roles<NM, BIASED, EXACT, TREES>(A, s, PL, Wb);
 }
 
 // ------------------------------------------------------------------ k_sweep: several chunks per launch
-// The same four roles as k_pipe, for C independent chunks at once: blockIdx.y is the chunk, each with its own argument
+// The same four roles as k_pipe, for C independent chunks at once: blockIdx.x is the chunk (pf_bx(), pf_device.h), each with its own argument
 // block in device memory (SweepChunk::A, read through the constant address space: every field is a scalar load where it
 // is used, nothing of the block is a kernel argument any more), its own Ctrl, rings and event log.  All chunks step in
 // lockstep: launch t handles row s = s_begin + t of every chunk that still has one (then its two flush steps).  What
@@ -2477,14 +2516,31 @@ __device__ __forceinline__ void sweep_windows(const KA& A, Ctrl* c, double pos, 
     __syncthreads();
 }
 
-template <int NM, bool BIASED, bool EXACT, bool TREES, bool HANDOFF = false>
+// where a workgroup of a traced step (pf_set_wg_trace) leaves its four words: start and end on the 100 MHz clock, HW_ID | XCC_ID << 32,
+// index within the chunk | chunk << 32
+__device__ __forceinline__ unsigned long long* wg_trace_slot(SweepChunkC& ch, long long t) {
+    if (!ch.trace || t < ch.trace_t0 || t >= ch.trace_t0 + ch.trace_n) return nullptr;
+    const size_t lin = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+    return ch.trace + ((size_t)(t - ch.trace_t0) * (size_t)ch.trace_stride + lin) * 4;
+}
+
+template <int NM, bool BIASED, bool EXACT, bool TREES, bool HANDOFF = false, bool TRACE = false, bool QUEUE = false>
 __device__ __forceinline__ void sweep_kernel_body(const SweepChunk* tab_g, long long t, int nb) {
     SweepChunkC* tab = (SweepChunkC*)tab_g;
-    SweepChunkC& ch = tab[blockIdx.y];
+    SweepChunkC& ch = tab[pf_chunk()];
     KArgsC& A = ch.A;
     const long long s = ch.s_begin + t;
     __shared__ Windows W;           // written and read by the bookkeeping workgroup only
     bool ok = true;
+    if constexpr (TRACE) {
+        if (threadIdx.x == 0) {
+            if (unsigned long long* w = wg_trace_slot(ch, t)) {
+                w[0] = wall_clock64();
+                w[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+                w[3] = (unsigned long long)(unsigned)pf_bx() | ((unsigned long long)(unsigned)pf_chunk() << 32);
+            }
+        }
+    }
     if constexpr (HANDOFF) {
         // this launch was enqueued without waiting for the one of step t - 1 to end: its workgroups wait for that launch's workgroups
         // to have arrived (state, scans, partials and draw table of row s - 1 are then visible), and -- ring reuse -- for the
@@ -2496,10 +2552,14 @@ __device__ __forceinline__ void sweep_kernel_body(const SweepChunk* tab_g, long 
     PipeLaunch PL;
     if (ok && sweep_plan(ch, s, nb, PL)) {
         if (ch.split) PL.nL = -2;                          // extend and draw roles only: the other roles are k_sweep_blc's
-        else if ((int)blockIdx.x == nb && PL.b_slot >= 0) sweep_windows(A, A.ctrl, PL.b_pos, W);
-        pipe_roles<NM, BIASED, EXACT, TREES>(A, s, PL, W);
+        else if (pf_bx() == nb && PL.b_slot >= 0) sweep_windows(A, A.ctrl, PL.b_pos, W);
+        pipe_roles<NM, BIASED, EXACT, TREES, 1, false, QUEUE>(A, s, PL, W);
     }
     if constexpr (HANDOFF) sweep_arrive(&A.ctrl->xt_done[t & (PF_RING - 1)]);
+    if constexpr (TRACE) {
+        __syncthreads();
+        if (threadIdx.x == 0) if (unsigned long long* w = wg_trace_slot(ch, t)) w[1] = wall_clock64();
+    }
 }
 template <int NM, bool BIASED, bool EXACT, bool TREES>
 __global__ __launch_bounds__(PF_BS) void k_sweep(const SweepChunk* tab_g, long long t, int nb) {
@@ -2521,6 +2581,17 @@ __global__ __launch_bounds__(PF_BS) void k_sweep4h(const SweepChunk* tab_g, long
     sweep_kernel_body<4, false, EXACT, false, true>(tab_g, t, nb);
 }
 
+// the headline instance with the ledger and count work of a step taken off a queue (pf_params.count_workers; the traced form too)
+template <bool EXACT, bool TRACE>
+__global__ __launch_bounds__(PF_BS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_sweep4q(const SweepChunk* tab_g, long long t, int nb) {
+    sweep_kernel_body<4, false, EXACT, false, false, TRACE, true>(tab_g, t, nb);
+}
+// the headline instance with a time stamp at either end of every workgroup (pf_set_wg_trace: where do the slots of a step go?)
+template <bool EXACT>
+__global__ __launch_bounds__(PF_BS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_sweep4t(const SweepChunk* tab_g, long long t, int nb) {
+    sweep_kernel_body<4, false, EXACT, false, false, true>(tab_g, t, nb);
+}
+
 // The bookkeeping, ledger and count roles of a step as a launch of their own: what the structured models run on the counting
 // stream beside their extend launch (k_sweep_xmp, pf_mp.hip).  The extend workgroups of those models carry their trees'
 // migration events in LDS (61 KB per 64 particles at the default capacity); in one launch every count workgroup would be
@@ -2528,7 +2599,7 @@ __global__ __launch_bounds__(PF_BS) void k_sweep4h(const SweepChunk* tab_g, long
 template <int NM, int P, bool BIASED>
 __global__ __launch_bounds__(PF_BS) void k_sweep_blc(const SweepChunk* tab_g, long long t) {
     SweepChunkC* tab = (SweepChunkC*)tab_g;
-    SweepChunkC& ch = tab[blockIdx.y];
+    SweepChunkC& ch = tab[pf_chunk()];
     KArgsC& A = ch.A;
     const long long s = ch.s_begin + t;
     __shared__ Windows W;
@@ -2536,7 +2607,7 @@ __global__ __launch_bounds__(PF_BS) void k_sweep_blc(const SweepChunk* tab_g, lo
     PipeLaunch PL;
     if (sweep_plan(ch, s, 0, PL)) {
         PL.nT = 0;                                         // the draw role rides with the extend launch
-        if ((int)blockIdx.x == 0 && PL.b_slot >= 0) sweep_windows(A, c, PL.b_pos, W);
+        if (pf_bx() == 0 && PL.b_slot >= 0) sweep_windows(A, c, PL.b_pos, W);
         pipe_roles<NM, BIASED, false, false, P, true>(A, s, PL, W);
     }
     if (ch.handoff) {
@@ -2546,7 +2617,7 @@ __global__ __launch_bounds__(PF_BS) void k_sweep_blc(const SweepChunk* tab_g, lo
         __syncthreads();
         if (threadIdx.x == 0) {
             const unsigned before = __hip_atomic_fetch_add(&c->blc_arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (before + 1 == gridDim.x) {
+            if (before + 1 == gridDim.x * gridDim.z) {          // (one chunk: either grid form)
                 __hip_atomic_store(&c->blc_arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&c->blc_step, (int)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -2569,7 +2640,7 @@ __global__ void k_sweep_seed(const SweepChunk* tab_g) {
         c->xr[slot].n_res = c->n_resample; c->xr[slot].gen = c->gen; c->xr[slot].flag = 0;
     }
     if ((int)threadIdx.x < A.E) c->counted_to[threadIdx.x] = ch.counted_to[threadIdx.x];
-    if ((int)threadIdx.x < PF_RING) c->xt_done[threadIdx.x] = 0;
+    if ((int)threadIdx.x < PF_RING) { c->xt_done[threadIdx.x] = 0; c->wq[threadIdx.x] = 0; }
     if (threadIdx.x == 0) { c->blc_arrive = 0; c->blc_step = 0; }
     if (ch.nT > 0) {
         // the draw table starts every call empty, from the counters the slots have now
@@ -3181,11 +3252,17 @@ struct pf_handle {
     bool pipe = false;            // the single-launch pipeline applies (one population, n <= 8; rings allocated)
     size_t smem_pipe = 0;
     int ncw = 0;                  // count workgroups per epoch in the row pipeline (pf_params.count_wgs): the most a column gets
+    int ledger_wgs = 192;         // workgroups per step that re-base the older generations' run lists after a resampling (beside one per particle block)
+    int workers = 0;              // pf_params.count_workers: workgroups per step that take the ledger and count items off a queue (0: one workgroup per item)
     std::vector<int> cw_off;      // [E + 1] first count workgroup of the j-th column, oldest epoch first (KArgs::cw_off)
     bool flag_handoff = false;    // PF_DEBUG_FLAG_HANDOFF: one population, rows as extend / draw launches that alternate between two streams and
                                   // bookkeeping / ledger / count launches on the counting stream, ordered by counters in memory instead of events
     hipStream_t stream2 = nullptr;
     bool sweep_handoff = false;   // (argument of sweep_table: the table it builds is for run_sweep_flags)
+    bool chunk_fastest = false;   // PF_DEBUG_CHUNK_FASTEST: the sweep's grid as (chunks, 1, workgroups per chunk)
+    unsigned long long* d_trace = nullptr;   // pf_set_wg_trace (leader of a pf_run_many call): four words per workgroup and step
+    size_t trace_words = 0;
+    int trace_t0 = 0, trace_n = 0, trace_stride = 0, trace_grid[3] = {0, 0, 0};
     bool count_units = false;     // k_sweep / k_sweep_blc with one population: the counts by generation (count_units_body), ncw workgroups per step
     bool split_roles = false;     // PF_DEBUG_SPLIT_ROLES: one population too runs the extend role and the other roles as two launches on two streams
     bool pipe_mp = false;         // structured models on the row pipeline: extend launches on the filter stream, the other roles on the counting stream
@@ -3421,6 +3498,11 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     h->use_k_pipe = (p->debug & PF_DEBUG_K_PIPE) != 0;
     h->no_spec_stage = (p->debug & PF_DEBUG_NO_SPEC_STAGE) != 0;
     h->split_roles = (p->debug & PF_DEBUG_SPLIT_ROLES) != 0;
+    h->chunk_fastest = (p->debug & PF_DEBUG_CHUNK_FASTEST) != 0;
+    // (several chunks per GPU -- the caller set count_wgs -- : on the rows that do not resample, nine in ten, these workgroups find nothing to do and
+    // leave after 2 us of a slot each; with 32 instead of 192 eight chunks gain 3 %, one chunk is the same either way: 28.7 us per row)
+    h->ledger_wgs = p->count_wgs > 0 ? 32 : std::max(16, std::min(PF_LEDGER_BLOCKS, 192));
+    if (!(p->debug & PF_DEBUG_COUNT_UNITS) && ((p->debug >> 16) & 15)) h->ledger_wgs = 16 * ((p->debug >> 16) & 15);       // (bits 16-19 of debug: tuning experiments)
     // (instantiated for the headline shape only: at most four haplotypes, no focused sampling or guide, no tree dump)
     h->flag_handoff = (p->debug & PF_DEBUG_FLAG_HANDOFF) != 0 && P == 1 && n <= 4 && m->n_bias_heights == 0 && m->n_rate_segments == 0 && !(p->flags & 2);
     if (h->flag_handoff && hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) { delete h; return fail("hipStreamCreate failed"); }
@@ -3620,6 +3702,9 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     h->count_units = P == 1 && (p->debug & PF_DEBUG_COUNT_UNITS) && (p->debug & PF_DEBUG_SPLIT_ROLES) && !h->use_k_pipe && !(p->flags & 2);
     if (h->count_units && h->pipe) h->ncw = A.nbx;     // workgroups per step
     else h->ncw = p->count_wgs > 0 ? std::min<int>(p->count_wgs, h->nblocks) : h->nblocks;
+    // (the queue has one kernel instance so far: one population, at most four haplotypes, no focused sampling, no -arg, single launch per step)
+    h->workers = (h->pipe && !h->use_k_pipe && !h->count_units && P == 1 && n <= 4 && !(m->n_bias_heights > 0 || m->n_rate_segments > 0) && !(p->flags & 2) &&
+                  !(p->debug & (PF_DEBUG_SPLIT_ROLES | PF_DEBUG_FLAG_HANDOFF))) ? std::max(0, std::min(p->count_workers, 4096)) : 0;
     {
         // count workgroups per epoch column of the row pipeline: the tasks of an epoch are the live ancestors of the generations in its
         // window, about Np / (1 + depth), depth = generations between window and front, i.e. in proportion to its lag: a column whose
@@ -3629,6 +3714,7 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
         for (int j = 0; j < E; ++j) {
             const double lag = m->lags[E - 1 - j];
             int w = (int)std::ceil((double)h->ncw * std::min(1.0, 2500.0 / std::max(lag, 1.0)));
+            // (a higher minimum -- 4, 8, 12, 15 -- changes nothing: the long count workgroups of a step are not those of narrow columns)
             w = std::max(std::min(2, h->ncw), std::min(w, h->ncw));
             // (only when the caller set count_wgs, i.e. runs several chunks side by side and wants fewer workgroups: a single chunk
             // leaves most of the chip idle, and there every column is shortest with all the workgroups it can get)
@@ -3697,6 +3783,7 @@ void pf_destroy(pf_handle* h) {
     if (h->cstream) hipStreamSynchronize(h->cstream);
     for (void* p : h->allocs) hipFree(p);
     if (h->d_sweep) hipFree(h->d_sweep);
+    if (h->d_trace) hipFree(h->d_trace);
     for (auto e : h->sync_ev) if (e) hipEventDestroy(e);
     for (auto e : h->ev_x) if (e) hipEventDestroy(e);
     for (auto e : h->ev_blc) if (e) hipEventDestroy(e);
@@ -4097,7 +4184,7 @@ static int run_pipeline(pf_handle* h, long long s_begin, long long s_end) {
     hipLaunchKernelGGL(k_pipe_seed, dim3(1), dim3(1), 0, h->stream, h->A, (int)((s_begin + PF_RING - 1) & (PF_RING - 1)));
     Windows W1 = no_windows(h), W2 = no_windows(h);      // windows of rows s-1 and s-2
     long long last = s_begin - 1;                        // last row extended so far
-    const int nL_full = nb + std::max(16, std::min(PF_LEDGER_BLOCKS, 192));
+    const int nL_full = nb + h->ledger_wgs;
     auto dispatch = [&](long long s, const PipeLaunch& PL, int ncount_wg, const Windows& Wb) {
         if (h->n <= 4 && biased) launch_pipe<4, true>(h, s, PL, ncount_wg, Wb);
         else if (h->n <= 4) launch_pipe<4, false>(h, s, PL, ncount_wg, Wb);
@@ -4161,6 +4248,17 @@ static void launch_sweep(pf_handle* h, const dim3& grid, long long t) {
     const dim3 blk(PF_BS);
     const size_t lds = h->smem_pipe;
     if constexpr (NM == 4 && !BIASED) {
+        const bool traced = h->d_trace && t >= h->trace_t0 && t < h->trace_t0 + h->trace_n;
+        if (h->h_sweep[0].workers > 0) {
+            if (h->n == NM) { if (traced) hipLaunchKernelGGL((k_sweep4q<true, true>), grid, blk, lds, h->stream, h->d_sweep, t, h->nblocks); else hipLaunchKernelGGL((k_sweep4q<true, false>), grid, blk, lds, h->stream, h->d_sweep, t, h->nblocks); }
+            else { if (traced) hipLaunchKernelGGL((k_sweep4q<false, true>), grid, blk, lds, h->stream, h->d_sweep, t, h->nblocks); else hipLaunchKernelGGL((k_sweep4q<false, false>), grid, blk, lds, h->stream, h->d_sweep, t, h->nblocks); }
+            return;
+        }
+        if (h->d_trace && !h->A.rec_trees && t >= h->trace_t0 && t < h->trace_t0 + h->trace_n) {
+            if (h->n == NM) hipLaunchKernelGGL((k_sweep4t<true>), grid, blk, lds, h->stream, h->d_sweep, t, h->nblocks);
+            else hipLaunchKernelGGL((k_sweep4t<false>), grid, blk, lds, h->stream, h->d_sweep, t, h->nblocks);
+            return;
+        }
         if (h->A.rec_trees) hipLaunchKernelGGL((k_sweep4<false, true>), grid, blk, lds, h->stream, h->d_sweep, t, h->nblocks);
         else if (h->n == NM) hipLaunchKernelGGL((k_sweep4<true, false>), grid, blk, lds, h->stream, h->d_sweep, t, h->nblocks);
         else hipLaunchKernelGGL((k_sweep4<false, false>), grid, blk, lds, h->stream, h->d_sweep, t, h->nblocks);
@@ -4174,7 +4272,7 @@ static void launch_sweep(pf_handle* h, const dim3& grid, long long t) {
 static bool sweep_compatible(const pf_handle* a, const pf_handle* b) {
     const bool ba = a->A.n_bias > 0 || a->A.g_K > 0, bb = b->A.n_bias > 0 || b->A.g_K > 0;
     return a->device == b->device && a->Np == b->Np && a->n == b->n && a->E == b->E && a->P == b->P && ba == bb &&
-           a->A.rec_trees == b->A.rec_trees && a->ncw == b->ncw && a->cw_off == b->cw_off && a->count_units == b->count_units && a->smem_pipe == b->smem_pipe && a->no_count == b->no_count &&
+           a->A.rec_trees == b->A.rec_trees && a->ncw == b->ncw && a->workers == b->workers && a->ledger_wgs == b->ledger_wgs && a->cw_off == b->cw_off && a->count_units == b->count_units && a->smem_pipe == b->smem_pipe && a->no_count == b->no_count &&
            (a->A.dt_tab != nullptr) == (b->A.dt_tab != nullptr);
 }
 
@@ -4209,9 +4307,11 @@ static long long sweep_table(pf_handle* const* hs, int nh, long long s_begin, lo
         ch.nT = (g->A.dt_tab && g->P == 1) ? g->nblocks : 0;
         ch.split = (g->P == 1 && g->split_roles && !g->A.rec_trees) ? 1 : 0;
         ch.units = g->count_units ? 1 : 0;
+        ch.workers = g->count_units ? 0 : g->workers;
         ch.handoff = h->sweep_handoff ? 1 : 0;
         ch.xt_wgs = h->sweep_handoff ? g->nblocks + (ch.nT > 0 ? 1 + ch.nT : 0) : 0;
         if (h->sweep_handoff) ch.split = 1;
+        ch.trace = h->d_trace; ch.trace_t0 = h->trace_t0; ch.trace_n = h->d_trace ? h->trace_n : 0; ch.trace_stride = h->trace_stride;
         if (last >= s_begin) steps = std::max(steps, last - s_begin + 3);
     }
     *failed = false;
@@ -4228,7 +4328,7 @@ static int run_sweep(pf_handle* const* hs, int nh, long long s_begin, long long 
     if (s_begin >= s_end) return 0;
     const int nb = h->nblocks, E = h->E;
     const bool biased = h->A.n_bias > 0 || h->A.g_K > 0;
-    const int nL_full = nb + std::max(16, std::min(PF_LEDGER_BLOCKS, 192));
+    const int nL_full = nb + h->ledger_wgs;
     // the other handles' streams (anything they still have in flight) come first, then the table
     for (int k = 0; k < nh; ++k) {
         pf_handle* g = hs[k];
@@ -4238,6 +4338,14 @@ static int run_sweep(pf_handle* const* hs, int nh, long long s_begin, long long 
             hipEventRecord(ev, g->stream);
             hipStreamWaitEvent(h->stream, ev, 0);
         }
+    }
+    if (h->trace_n > 0 && !h->d_trace) {
+        // pf_set_wg_trace: room for the largest grid a step of these chunks can have
+        const int nT = (h->A.dt_tab && h->P == 1) ? nb : 0;
+        h->trace_stride = nh * (nb + 1 + nT + nL_full + (h->count_units ? h->ncw : h->cw_off[E]));
+        h->trace_words = (size_t)h->trace_n * (size_t)h->trace_stride * 4;
+        if (hipMalloc((void**)&h->d_trace, h->trace_words * 8) != hipSuccess) { h->d_trace = nullptr; g_err = "hipMalloc of the workgroup trace failed"; return -1; }
+        hipMemsetAsync(h->d_trace, 0, h->trace_words * 8, h->stream);
     }
     bool failed = false;
     const long long steps = sweep_table(hs, nh, s_begin, s_end, nL_full, &failed);
@@ -4253,7 +4361,10 @@ static int run_sweep(pf_handle* const* hs, int nh, long long s_begin, long long 
         for (int k = 0; k < nh; ++k)
             if (s >= s_begin + 2 && s - 2 <= h->h_sweep[k].s_last && !hs[k]->no_count) columns = std::max(columns, E - W2[k].first);
         const int ncount = h->count_units ? (columns > 0 ? h->ncw : 0) : h->cw_off[columns];
-        const dim3 grid((unsigned)(nb + 1 + h->h_sweep[0].nT + nL_full + ncount), (unsigned)nh);
+        bool any_lc = false;
+        for (int k = 0; k < nh; ++k) any_lc = any_lc || (s >= s_begin + 2 && s - 2 <= h->h_sweep[k].s_last && !hs[k]->no_count);
+        const unsigned per_chunk = (unsigned)(nb + 1 + h->h_sweep[0].nT + (h->h_sweep[0].workers > 0 ? (any_lc ? h->h_sweep[0].workers : 0) : nL_full + ncount));
+        const dim3 grid = h->chunk_fastest ? dim3((unsigned)nh, 1u, per_chunk) : dim3(per_chunk, (unsigned)nh, 1u);      // pf_bx() / pf_chunk(), pf_device.h
         const bool tm_on = timing_on(h, s);
         {
             Timed tm(h, 0, tm_on);
@@ -4302,7 +4413,7 @@ static int run_sweep_mp(pf_handle* h, long long s_begin, long long s_end) {
     if (s_begin >= s_end) return 0;
     const int nb = h->nblocks, E = h->E;
     const bool biased = h->A.n_bias > 0 || h->A.g_K > 0;
-    const int nL_full = nb + std::max(16, std::min(PF_LEDGER_BLOCKS, 192));
+    const int nL_full = nb + h->ledger_wgs;
     if (h->ev_cnt) { hipStreamWaitEvent(h->stream, h->ev_cnt, 0); h->ev_cnt = nullptr; }
     if (h->ev_x.empty()) {
         // all thirty-two or none: a vector left half filled would pass for complete on the next call, and launches with null
@@ -4351,7 +4462,7 @@ static int run_sweep_mp(pf_handle* h, long long s_begin, long long s_end) {
         hipStreamWaitEvent(h->cstream, t >= 1 ? h->ev_x[(size_t)((t - 1) & 15)] : seeded, 0);
         const int columns = (s >= s_begin + 2 && s - 2 <= last && !h->no_count) ? E - W2.first : 0;
         const int ncount = h->count_units ? (columns > 0 ? h->ncw : 0) : h->cw_off[columns];
-        const dim3 grid((unsigned)(1 + nL_full + ncount), 1u), blk(PF_BS);
+        const dim3 grid((unsigned)(1 + (h->h_sweep[0].workers > 0 ? ((s >= s_begin + 2 && s - 2 <= last && !h->no_count) ? h->h_sweep[0].workers : 0) : nL_full + ncount)), 1u), blk(PF_BS);
         hipEvent_t done = h->ev_blc[(size_t)(t & 15)];
 #define PF_LAUNCH_BLC(NMV, PV, BV) hipExtLaunchKernelGGL((k_sweep_blc<NMV, PV, BV>), grid, blk, h->smem_pipe, h->cstream, nullptr, done, 0, h->d_sweep, t)
         if (h->P == 1) { if (h->n <= 4) { if (biased) PF_LAUNCH_BLC(4, 1, true); else PF_LAUNCH_BLC(4, 1, false); } else { if (biased) PF_LAUNCH_BLC(8, 1, true); else PF_LAUNCH_BLC(8, 1, false); } }
@@ -4387,7 +4498,7 @@ static int run_sweep_flags(pf_handle* h, long long s_begin, long long s_end) {
     if (s_begin >= s_end) return 0;
     const int nb = h->nblocks, E = h->E;
     const bool biased = h->A.n_bias > 0 || h->A.g_K > 0;
-    const int nL_full = nb + std::max(16, std::min(PF_LEDGER_BLOCKS, 192));
+    const int nL_full = nb + h->ledger_wgs;
     if (h->ev_cnt) { hipStreamWaitEvent(h->stream, h->ev_cnt, 0); h->ev_cnt = nullptr; }
     pf_handle* one[1] = {h};
     bool failed = false;
@@ -4428,7 +4539,7 @@ static int run_sweep_flags(pf_handle* h, long long s_begin, long long s_end) {
         if (t >= 1) hipStreamWaitEvent(h->cstream, h->ev_x[(size_t)((t - 1) & 15)], 0);
         const int columns = (s >= s_begin + 2 && s - 2 <= last && !h->no_count) ? E - W2.first : 0;
         const int ncount = h->cw_off[columns];
-        const dim3 grid((unsigned)(1 + nL_full + ncount), 1u), blk(PF_BS);
+        const dim3 grid((unsigned)(1 + (h->h_sweep[0].workers > 0 ? ((s >= s_begin + 2 && s - 2 <= last && !h->no_count) ? h->h_sweep[0].workers : 0) : nL_full + ncount)), 1u), blk(PF_BS);
 #define PF_LAUNCH_BLCF(NMV, BV) hipLaunchKernelGGL((k_sweep_blc<NMV, 1, BV>), grid, blk, h->smem_pipe, h->cstream, h->d_sweep, t)
         if (h->n <= 4) { if (biased) PF_LAUNCH_BLCF(4, true); else PF_LAUNCH_BLCF(4, false); } else { if (biased) PF_LAUNCH_BLCF(8, true); else PF_LAUNCH_BLCF(8, false); }
 #undef PF_LAUNCH_BLCF
@@ -4901,6 +5012,30 @@ int pf_get_kernel_time(pf_handle* h, int k, double* ms, int64_t* launches) {
     if (ms) *ms = mean * (double)h->k_launches[k];
     if (launches) *launches = h->k_launches[k];
     return 0;
+}
+
+// Measurement aid: steps [first_step, first_step + n_steps) of the next pf_run / pf_run_many calls led by this handle run the traced
+// instance of the row kernel (k_sweep4t: at most four haplotypes, no focused sampling; other shapes ignore the request).
+int pf_set_wg_trace(pf_handle* h, int64_t first_step, int32_t n_steps) {
+    HIPCHK(hipSetDevice(h->device));
+    if (pf_sync(h)) return -1;
+    if (h->d_trace) { hipFree(h->d_trace); h->d_trace = nullptr; }
+    h->trace_t0 = (int)std::max<int64_t>(0, first_step);
+    h->trace_n = std::max(0, n_steps);
+    h->trace_stride = 0; h->trace_words = 0;
+    return 0;
+}
+
+// The trace: four 64-bit words per workgroup slot of every traced step -- start and end (100 MHz clock; 0 0: slot not used by that step's
+// grid), HW_ID | XCC_ID << 32, index within the chunk | chunk << 32.  Returns the number of words (0: nothing traced yet); copies at most
+// cap_words of them; info = {steps, workgroup slots per step}.
+int64_t pf_get_wg_trace(pf_handle* h, uint64_t* out, int64_t cap_words, int32_t* info) {
+    if (hipSetDevice(h->device) != hipSuccess || pf_sync(h)) return -1;
+    if (info) { info[0] = h->d_trace ? h->trace_n : 0; info[1] = h->trace_stride; }
+    if (!h->d_trace) return 0;
+    const size_t nw = std::min<size_t>(h->trace_words, (size_t)std::max<int64_t>(0, cap_words));
+    if (out && nw && hipMemcpy(out, h->d_trace, nw * 8, hipMemcpyDeviceToHost) != hipSuccess) { g_err = "copy of the workgroup trace failed"; return -1; }
+    return (int64_t)h->trace_words;
 }
 
 int pf_get_delay_stats(pf_handle* h, int64_t* n_forced, int32_t* peak_pending) {

@@ -186,6 +186,7 @@ struct PipeLaunch {
     int nT;                // workgroups that keep up the draw table (k_sweep only)
     int units;             // the counts are dealt out by generation (count_units_body) instead of one column per epoch
     int ahead;             // as PipeRow::ahead: the rings need PF_RING entries of headroom
+    int workers;           // > 0: the ledger and count work of the step is dealt out among this many workgroups (Ctrl::wq)
 };
 
 
@@ -203,6 +204,9 @@ struct SweepChunk {
     int units;                     // count workgroups take units of one generation for all its epochs (ncw = workgroups per step)
     int handoff;                   // launches hand over through Ctrl::xt_done / blc_step instead of through kernel boundaries (run_sweep_flags)
     int xt_wgs;                    // workgroups of an extend / draw launch (what a slot of xt_done grows by per step)
+    unsigned long long* trace;     // pf_set_wg_trace: four words per workgroup of steps [trace_t0, trace_t0 + trace_n) (k_sweep4t only)
+    int trace_t0, trace_n, trace_stride;
+    int workers;                   // pf_params.count_workers (PipeLaunch::workers)
 };
 typedef const __attribute__((address_space(4))) SweepChunk SweepChunkC;
 
@@ -271,6 +275,7 @@ __device__ __forceinline__ bool sweep_plan(SweepChunkC& ch, long long s, int nb,
     PL.nL = PL.lc_slot >= 0 ? ch.nL_full : 0;
     PL.ncw = ch.ncw;
     PL.units = ch.units;
+    PL.workers = ch.workers;
     return true;
 }
 

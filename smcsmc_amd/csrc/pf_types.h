@@ -98,6 +98,8 @@ struct Ctrl {
     unsigned xt_done[PF_RING];   // arrivals of the extend / draw launches
     unsigned blc_arrive;         // arrivals of the bookkeeping / ledger / count launch in flight (they run one after the other)
     int blc_step;                // steps whose bookkeeping / ledger / count launch has ended
+    unsigned wq[PF_RING];        // pf_params.count_workers: next ledger / count work item of the row in that ring slot (zeroed by the bookkeeping of
+                                 // the step before the one whose workers use it)
     double last1[PF_RING];       // pilot scan value at the last particle of the row in ring slot k (= oracle incl[N-1] minus chunk offset)
 };
 

@@ -49,7 +49,8 @@ class _Params(C.Structure):
     _fields_ = [("np", C.c_int64), ("ess_fraction", C.c_double), ("seed", C.c_uint64),
                 ("max_trace_events", C.c_int32), ("flags", C.c_int32),
                 ("log_cap", C.c_int64), ("gen_cap", C.c_int64), ("piece_cap", C.c_int64),
-                ("debug", C.c_int32), ("mig_cap", C.c_int32), ("count_wgs", C.c_int32), ("delay_cap", C.c_int32)]
+                ("debug", C.c_int32), ("mig_cap", C.c_int32), ("count_wgs", C.c_int32), ("delay_cap", C.c_int32),
+                ("count_workers", C.c_int32), ("reserved4", C.c_int32)]
 
 
 DEBUG_FORCE_LDS, DEBUG_NO_FUSE, DEBUG_NO_COUNT, DEBUG_TWO_LAUNCH = 1, 2, 4, 8
@@ -94,7 +95,7 @@ EXPORTS = [
     "pf_terminal_branch_quantiles",
     "pf_update_segment", "pf_count", "pf_resample", "pf_run", "pf_run_many", "pf_can_run_many", "pf_finish", "pf_sync",
     "pf_num_segments_done", "pf_logl", "pf_get_counts", "pf_get_trace", "pf_get_resample_events",
-    "pf_get_particles", "pf_get_migrations", "pf_get_local_recomb", "pf_sample_tree_events", "pf_sample_tree_events_pops", "pf_get_kernel_time", "pf_set_timing", "pf_get_stats", "pf_get_delay_stats", "pf_probe_handoff", "pf_debug_stamps", "pf_test_search_lut", "pf_simulate_sites",
+    "pf_get_particles", "pf_get_migrations", "pf_get_local_recomb", "pf_sample_tree_events", "pf_sample_tree_events_pops", "pf_get_kernel_time", "pf_set_timing", "pf_get_stats", "pf_get_delay_stats", "pf_probe_handoff", "pf_set_wg_trace", "pf_get_wg_trace", "pf_debug_stamps", "pf_test_search_lut", "pf_simulate_sites",
     "pf_median_survival", "pf_test_math", "pf_test_div", "pf_test_uniform", "pf_test_reduce", "pf_test_systematic",
 ]
 
@@ -146,6 +147,9 @@ def load_library(path=None):
     L.pf_get_stats.argtypes = [vp, vp, vp, vp]
     L.pf_get_delay_stats.argtypes = [vp, vp, vp]
     L.pf_probe_handoff.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, vp, vp, C.c_int32]
+    L.pf_set_wg_trace.argtypes = [vp, C.c_int64, C.c_int32]
+    L.pf_get_wg_trace.argtypes = [vp, vp, C.c_int64, vp]
+    L.pf_get_wg_trace.restype = C.c_int64
     L.pf_median_survival.argtypes = [C.POINTER(_Model), C.c_uint64, C.c_int32, C.c_int64, vp, vp, C.c_int]
     L.pf_test_math.argtypes = [vp, C.c_int64, vp, vp, vp, C.c_int]
     L.pf_test_div.argtypes = [vp, vp, C.c_int64, vp, C.c_int]
@@ -264,7 +268,7 @@ def probe_handoff(mode, rows=2000, nw=157, spin_us=0.0, device=0):
 class ParticleFilter:
     def __init__(self, model, np_particles, ess_fraction=0.5, seed=1, max_trace_events=64, device=0, local_recomb=False,
                  record_trees=False, log_cap=0, gen_cap=0, piece_cap=0, debug=0, mig_cap=0, count_wgs=0, delay_cap=0,
-                 delay_evict=False):
+                 delay_evict=False, count_workers=0):
         self.L = load_library()
         m = model
         self._ct = np.ascontiguousarray(m["change_times"], dtype=np.float64)
@@ -284,7 +288,7 @@ class ParticleFilter:
         self.loci_length = float(m["loci_length"])
         self._params = _Params(self.Np, float(ess_fraction), int(seed), self.max_trace_events,
                                (1 if local_recomb else 0) | (2 if record_trees else 0) | (4 if delay_evict else 0),
-                               int(log_cap), int(gen_cap), int(piece_cap), int(debug), int(mig_cap), int(count_wgs), int(delay_cap))
+                               int(log_cap), int(gen_cap), int(piece_cap), int(debug), int(mig_cap), int(count_wgs), int(delay_cap), int(count_workers), 0)
         self.mig_cap = int(mig_cap) if mig_cap else 96
         self.h = self.L.pf_create(C.byref(self._model), C.byref(self._params), int(device))
         if not self.h:
@@ -439,6 +443,21 @@ class ParticleFilter:
         a = C.c_int64(); b = C.c_int64(); c = C.c_int64()
         self._chk(self.L.pf_get_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return {"records": a.value, "state_bytes_per_particle": b.value, "resamples": c.value}
+
+    def set_wg_trace(self, first_step, n_steps):
+        """measurement aid (pf_set_wg_trace): time stamps of every workgroup of the row kernel over a range of steps"""
+        self._chk(self.L.pf_set_wg_trace(self.h, int(first_step), int(n_steps)))
+
+    def wg_trace(self):
+        """[steps, slots, 4] uint64: start, end (10 ns ticks; 0 0 = slot unused), HW_ID | XCC_ID << 32, index in chunk | chunk << 32"""
+        info = (C.c_int32 * 2)()
+        n = self.L.pf_get_wg_trace(self.h, None, 0, info)
+        if n < 0:
+            self._chk(-1)
+        out = np.zeros(max(n, 0), dtype=np.uint64)
+        if n > 0:
+            self._chk(0 if self.L.pf_get_wg_trace(self.h, out.ctypes.data_as(C.c_void_p), n, info) >= 0 else -1)
+        return out.reshape(info[0], info[1], 4) if n > 0 else out.reshape(0, 0, 4)
 
     def delay_stats(self):
         """delayed-factor store: factors applied ahead of their position to make room (only with delay_evict; otherwise a full

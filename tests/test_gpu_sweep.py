@@ -156,6 +156,36 @@ def test_chunks_in_one_launch_equal_their_own_runs(hiplib):
         _same(f, g)
 
 
+@pytest.mark.parametrize("workers,count_wgs", [(7, 3), (40, 0), (1, 2)])
+def test_count_workers_change_nothing(hiplib, workers, count_wgs):
+    """pf_params.count_workers: the ledger and count work of a step taken off a queue by a fixed number of workgroups instead of one
+    workgroup per item in the launch -- every item writes its own accumulators, so the bits are those of the static form, for one chunk
+    and for chunks that run in one launch (and end at different rows)."""
+    model = cases.make_model(n=4, E=12, L=2e5)
+    chunks = []
+    for k in range(3):
+        m = dict(model, loci_length=float(model["loci_length"] * (0.6 + 0.2 * k)))
+        chunks.append((m, cases.make_segments(m, seed=30 + k, max_seg_len=4000)))
+    static = [_run_alone(m, sg, 1100, 5 + k, 0, count_wgs=count_wgs, local_recomb=True) for k, (m, sg) in enumerate(chunks)]
+    alone = _run_alone(chunks[0][0], chunks[0][1], 1100, 5, 0, count_wgs=count_wgs, count_workers=workers, local_recomb=True, step=53)
+    _same(alone, static[0])
+    many = []
+    for k, (m, sg) in enumerate(chunks):
+        f = ParticleFilter(m, 1100, seed=5 + k, count_wgs=count_wgs, count_workers=workers, local_recomb=True)
+        f.init_prior(0.0); f.load_segments(sg)
+        many.append(f)
+    nmax = max(f.n_segs for f in many)
+    for s0 in range(0, nmax, 211):
+        ParticleFilter.run_many(many, s0, min(nmax, s0 + 211))
+    for f, g in zip(many, static):
+        f.finish()
+        _same(f, g)
+        for key in ("opp_diff", "counts"):              # (added with atomics in either form: equal to rounding, bins that cancel to nothing included)
+            ref = g.local_recomb()[key]
+            np.testing.assert_allclose(f.local_recomb()[key], ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max())
+    assert sum(int(f.trace()["resampled"].sum()) for f in many) > 10        # the ledger items were there to be taken
+
+
 def test_run_many_rejects_chunks_of_different_shape(hiplib):
     from smcsmc_amd import PfError
     m1 = cases.make_model(n=4, E=8, L=5e4)
