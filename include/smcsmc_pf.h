@@ -135,9 +135,6 @@ typedef struct pf_params {
                                   * for each other's END: the extend launches alternate between two streams and hand the row over through
                                   * arrival counters in memory, the other launches wait the same way (run_sweep_flags; same bits) */
 
-#define PF_DEBUG_CHUNK_FASTEST (1 << 23) /* pf_run_many: the grid of a step as (chunks, 1, workgroups per chunk) -- every chunk's extend workgroups
-                                  * are handed out before any chunk's count workgroups -- instead of (workgroups per chunk, chunks); A/B, same bits */
-
 #define PF_DEBUG_CU_MASK 1024     /* with PF_DEBUG_SPLIT_ROLES: the two streams on disjoint sets of compute units (experiment) */
 
 typedef struct pf_segments {

@@ -193,16 +193,14 @@ __device__ __forceinline__ void philox_pair(unsigned long long seed, unsigned sl
     u1 = ((double)b1 + 0.5) * 1.1102230246251565e-16;
 }
 
-// The index of a workgroup within its chunk.  The row kernels of the sweep (k_sweep*, k_sweep_blc) have one of two grids: (workgroups
-// per chunk, chunks) -- the dispatcher hands workgroups out x fastest: all of chunk 0, then all of chunk 1 ... -- or, with
-// PF_DEBUG_CHUNK_FASTEST, (chunks, 1, workgroups per chunk): the first workgroups of EVERY chunk (the extend role, whose chain of
-// dependent loads is the critical path of a step) before any chunk's ledger and count workgroups.  Every other kernel has a grid of one
-// dimension, or (workgroups, epochs): the index is blockIdx.x in all of them but the chunk-fastest form.
-__device__ __forceinline__ int pf_bx() { return (int)(gridDim.z > 1 ? blockIdx.z : blockIdx.x); }
-// ... and the chunk of a workgroup of those kernels.  Consecutive workgroups go to consecutive XCDs: in the chunk-fastest form with
-// chunk = blockIdx.x each of eight chunks would have an XCD to itself, and a step would last as long as the chunk with the most count
-// work on that row (measured: 117 us a step against 104 us); rotated by the workgroup's index every chunk visits all XCDs in turn.
-__device__ __forceinline__ int pf_chunk() { return (int)(gridDim.z > 1 ? (blockIdx.x + blockIdx.z) % gridDim.x : blockIdx.y); }
+// The index of a workgroup within its chunk, and its chunk: the row kernels of the sweep (k_sweep*, k_sweep_blc) are launched with the grid
+// (workgroups per chunk, chunks), every other kernel with a grid of one dimension or (workgroups, epochs).  The dispatcher hands
+// workgroups out x fastest: one chunk after the other.  Other orders were built on these two functions and measured in round 4
+// (profiles/round4/wg_trace.md: one workgroup per chunk in turn, with and without a rotation over the XCDs; slabs of 24 ... 162
+// workgroups per chunk, e.g. every chunk's extend role before any chunk's counts): all slower with counting, and the index arithmetic
+// alone cost one chunk 1 %.
+__device__ __forceinline__ int pf_bx() { return (int)blockIdx.x; }
+__device__ __forceinline__ int pf_chunk() { return (int)blockIdx.y; }
 
 // ------------------------------------------------------------------ wavefront (64-lane) primitives
 // xor-butterfly sum: every lane ends with the same pairwise-tree total (matches oracle tree64).

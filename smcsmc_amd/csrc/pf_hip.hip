@@ -2461,18 +2461,25 @@ __device__ __forceinline__ void pipe_roles(const KA& A, long long s, const PipeL
         __shared__ int s_wk[8];
         if (lb >= PL.workers) return;
         if (threadIdx.x == 0) { s_wk[0] = PL.lc_slot; s_wk[1] = PL.live_slot; s_wk[2] = PL.nL; s_wk[3] = PL.nblk; s_wk[4] = PL.ncw; }
+        const KA* Ap = &A;
         for (;;) {
+            // (the argument block behind a pointer the compiler cannot see through: otherwise it loads every field the item bodies use once,
+            // before the loop, keeps them all in registers across the items and spills vector registers to scratch memory to do so)
+            asm volatile("" : "+s"(Ap));
+            const KA& A2 = *Ap;
             __syncthreads();
-            if (threadIdx.x == 0) s_wk[6] = (int)__hip_atomic_fetch_add(&A.ctrl->wq[s_wk[0]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0) s_wk[6] = (int)__hip_atomic_fetch_add(&A2.ctrl->wq[s_wk[0]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             PipeLaunch Q2;
             Q2.lc_slot = s_wk[0]; Q2.live_slot = s_wk[1]; Q2.nL = s_wk[2]; Q2.nblk = s_wk[3]; Q2.ncw = s_wk[4];
             const int it = s_wk[6];
-            const Ctrl::RowInfo& r2 = A.ctrl->ri[Q2.lc_slot];
-            const int ncnt = r2.first < A.E ? (A.cw_off ? A.cw_off[A.E - r2.first] : (A.E - r2.first) * Q2.ncw) : 0;
+            const Ctrl::RowInfo& r2 = A2.ctrl->ri[Q2.lc_slot];
+            const int ncnt = r2.first < A2.E ? (A2.cw_off ? A2.cw_off[A2.E - r2.first] : (A2.E - r2.first) * Q2.ncw) : 0;
             if (it >= ncnt + (r2.flag ? Q2.nL : 0)) return;                  // (every workgroup gets here: the counter only grows)
-            if (it < ncnt) pipe_count_item<NM, EXACT, P>(A, Q2, r2, it);
-            else pipe_ledger_item(A, Q2, r2, it - ncnt);
+            // (inlined: as real calls the item bodies save and restore 124 registers per item in scratch memory -- 5.7e4 segments/s
+            // against 8.0e4 for eight chunks with 264 workers each, and 9.4e4 without the queue)
+            if (it < ncnt) pipe_count_item<NM, EXACT, P>(A2, Q2, r2, it);
+            else pipe_ledger_item(A2, Q2, r2, it - ncnt);
         }
     }
 }
@@ -2617,7 +2624,7 @@ __global__ __launch_bounds__(PF_BS) void k_sweep_blc(const SweepChunk* tab_g, lo
         __syncthreads();
         if (threadIdx.x == 0) {
             const unsigned before = __hip_atomic_fetch_add(&c->blc_arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (before + 1 == gridDim.x * gridDim.z) {          // (one chunk: either grid form)
+            if (before + 1 == gridDim.x) {
                 __hip_atomic_store(&c->blc_arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&c->blc_step, (int)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -3259,7 +3266,6 @@ struct pf_handle {
                                   // bookkeeping / ledger / count launches on the counting stream, ordered by counters in memory instead of events
     hipStream_t stream2 = nullptr;
     bool sweep_handoff = false;   // (argument of sweep_table: the table it builds is for run_sweep_flags)
-    bool chunk_fastest = false;   // PF_DEBUG_CHUNK_FASTEST: the sweep's grid as (chunks, 1, workgroups per chunk)
     unsigned long long* d_trace = nullptr;   // pf_set_wg_trace (leader of a pf_run_many call): four words per workgroup and step
     size_t trace_words = 0;
     int trace_t0 = 0, trace_n = 0, trace_stride = 0, trace_grid[3] = {0, 0, 0};
@@ -3498,11 +3504,9 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     h->use_k_pipe = (p->debug & PF_DEBUG_K_PIPE) != 0;
     h->no_spec_stage = (p->debug & PF_DEBUG_NO_SPEC_STAGE) != 0;
     h->split_roles = (p->debug & PF_DEBUG_SPLIT_ROLES) != 0;
-    h->chunk_fastest = (p->debug & PF_DEBUG_CHUNK_FASTEST) != 0;
     // (several chunks per GPU -- the caller set count_wgs -- : on the rows that do not resample, nine in ten, these workgroups find nothing to do and
     // leave after 2 us of a slot each; with 32 instead of 192 eight chunks gain 3 %, one chunk is the same either way: 28.7 us per row)
     h->ledger_wgs = p->count_wgs > 0 ? 32 : std::max(16, std::min(PF_LEDGER_BLOCKS, 192));
-    if (!(p->debug & PF_DEBUG_COUNT_UNITS) && ((p->debug >> 16) & 15)) h->ledger_wgs = 16 * ((p->debug >> 16) & 15);       // (bits 16-19 of debug: tuning experiments)
     // (instantiated for the headline shape only: at most four haplotypes, no focused sampling or guide, no tree dump)
     h->flag_handoff = (p->debug & PF_DEBUG_FLAG_HANDOFF) != 0 && P == 1 && n <= 4 && m->n_bias_heights == 0 && m->n_rate_segments == 0 && !(p->flags & 2);
     if (h->flag_handoff && hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) { delete h; return fail("hipStreamCreate failed"); }
@@ -4364,7 +4368,7 @@ static int run_sweep(pf_handle* const* hs, int nh, long long s_begin, long long 
         bool any_lc = false;
         for (int k = 0; k < nh; ++k) any_lc = any_lc || (s >= s_begin + 2 && s - 2 <= h->h_sweep[k].s_last && !hs[k]->no_count);
         const unsigned per_chunk = (unsigned)(nb + 1 + h->h_sweep[0].nT + (h->h_sweep[0].workers > 0 ? (any_lc ? h->h_sweep[0].workers : 0) : nL_full + ncount));
-        const dim3 grid = h->chunk_fastest ? dim3((unsigned)nh, 1u, per_chunk) : dim3(per_chunk, (unsigned)nh, 1u);      // pf_bx() / pf_chunk(), pf_device.h
+        const dim3 grid(per_chunk, (unsigned)nh);          // (pf_bx() / pf_chunk(), pf_device.h)
         const bool tm_on = timing_on(h, s);
         {
             Timed tm(h, 0, tm_on);
