@@ -127,6 +127,7 @@ struct ChunkJob {
     std::vector<double>* survival_out = nullptr;       // receives them when they were calibrated here
     std::vector<double>* packed_out = nullptr;         // PF_COUNTS_LEN2 doubles, raw sums (no pseudo-counts)
     uint64_t seed_offset = 0;                          // + chunk index, the rule of smcsmc_amd/em.py
+    int count_wgs = 0;                                 // pf_params.count_wgs (0: the library's default)
 };
 
 // One chunk's filter between its creation and the collection of its results: pfARG_core (smcsmc.cpp:278-401) in three
@@ -263,6 +264,7 @@ static void open_filter(ChunkFilter& F, PfParam& P, const HostModel& M0, int dev
     pp.flags = 1;          // the local recombination map is always recorded (smcsmc.cpp:376-383)
     pp.mig_cap = P.mig_cap;
     pp.delay_cap = P.delay_cap;
+    pp.count_wgs = job ? job->count_wgs : P.count_wgs;
     if (P.delay_evict) pp.flags |= 4;
     if (P.record_trees) {
         if (NP > 1 && M.nsam > 8) throw Unsupported("-arg with more than one population and more than 8 samples");
@@ -616,6 +618,11 @@ static void run_chunks(ChunkPlan& C, PfParam& P, const HostModel& M0) {
                                             ".chunk" + std::to_string(c) + ".recomb.gz";
                 if (P.em_iteration == 0) remove(params[k].recomb_map_path.c_str());
                 jobs[k].survival = &survival; jobs[k].survival_out = &survival; jobs[k].packed_out = &packed[k]; jobs[k].seed_offset = (uint64_t)c;
+                // Six or more chunks side by side on a device: 24 count workgroups per epoch column instead of one per 256 particles,
+                // and the library trims its ledger workgroups (8 chunks of the C3 shape: 9.4e4 segments/s against 8.0e4,
+                // profiles/round4/wg_trace.md).  The sums of a chunk are grouped by workgroup: a run that must give the same bits
+                // whatever the number of ranks pins the width with -count_wgs.
+                jobs[k].count_wgs = P.count_wgs > 0 ? P.count_wgs : ((lockstep && my_chunks.size() >= 6) ? 24 : 0);
             }
             // Side by side in groups: as many of the rank's chunks as the device has memory for are opened together (every
             // filter holds its own rings: the event log alone is Np x 16 384 records by default) and go through one launch per

@@ -303,6 +303,8 @@ const std::vector<DriverOption>& driver_options() {
          [](PfParam& p, const std::string& v) { p.mig_cap = convert<int>("-migcap", v); if (p.mig_cap < 1) throw OutOfRange("-migcap", v); }},
         // not reference flags: room for pending delayed importance factors per particle (the reference's heap is unbounded,
         // particle.hpp:248), and what happens when it runs out
+        {"-count_wgs", "INT", "Inference tuning", "Workgroups per epoch that share the lagged counting of a row (part of what makes two runs bit-identical) [ one per 256 particles; 24 with six or more chunks per device ]",
+         [](PfParam& p, const std::string& v) { p.count_wgs = convert<int>("-count_wgs", v); if (p.count_wgs < 1) throw OutOfRange("-count_wgs", v); }},
         {"-delaycap", "INT", "Inference tuning", "Delayed importance factors a particle may have pending; one too many stops the run [ 128 ]",
          [](PfParam& p, const std::string& v) { p.delay_cap = convert<int>("-delaycap", v); if (p.delay_cap < 1) throw OutOfRange("-delaycap", v); }},
         {"-delay_evict", "", "Inference tuning", "A full store of delayed factors applies its earliest factor early instead of stopping (counted in the log)",
