@@ -234,10 +234,15 @@ def main():
                     "particle block; 24 with six or more chunks per GPU, where the chip holds a fraction of the count workgroups at a time)")
     ap.add_argument("--count-workers", type=int, default=-1, help="pf_params.count_workers: with several chunks per GPU, workgroups per chunk and step that take the "
                     "ledger and count work off a queue (0 = every work item a workgroup of the launch; default: 0 for one chunk)")
+    ap.add_argument("--log-cap", type=int, default=-1, help="pf_params.log_cap: event-log records per particle slot (0 = the library's default, 16384; default here: 4096 "
+                    "for one population -- the C3 workload needs between 1024 and 2048, too small a ring is a reported error -- because the 10 GB of the default ring "
+                    "cost 2.4 %% in address translation: 3.27e4 -> 3.35e4 segments/s)")
     ap.add_argument("--chunk-threads", action="store_true",
                     help="with --chunks-per-gpu: one host thread and stream per chunk (rounds 1 and 2) instead of pf_run_many")
     args = ap.parse_args()
 
+    if args.log_cap < 0:
+        args.log_cap = 4096 if args.pops == 1 else 0
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -268,7 +273,7 @@ def main():
         f = ParticleFilter(model, args.np, ess_fraction=0.5, seed=args.seed + 1000 * (rank * C + k), max_trace_events=0,
                            device=dev, local_recomb=not args.no_local_recomb, debug=args.debug,
                            count_wgs=args.count_wgs or (24 if (args.chunks_per_gpu >= 6 and not (args.debug & 2048)) else 0),
-                           count_workers=max(0, args.count_workers))
+                           count_workers=max(0, args.count_workers), log_cap=args.log_cap)
         f.load_segments(segs)
         chunks.append((f, segs))
     pf, segs = chunks[0]
@@ -389,7 +394,7 @@ def main():
                                       args.length / 1e6, args.np, args.epochs),
                        "populations": args.pops, "local_recombination_map": not args.no_local_recomb,
                        "segments_per_chunk": n_segments, "nsam": args.nsam, "np": args.np,
-                       "sequence_length": args.length, "epochs": args.epochs,
+                       "sequence_length": args.length, "epochs": args.epochs, "event_log_records_per_particle": args.log_cap or 16384,
                        "count_workgroups_per_epoch": args.count_wgs or (24 if (args.chunks_per_gpu >= 6 and not (args.debug & 2048)) else "one per particle block"),
                        "parallelism": "%d chunk(s) per gpu%s x %d gpu(s)" % (C, (", one launch per row for all of them" if many else ", one host thread and stream each") if C > 1 else "", world), "log_likelihood_sum": logl_sum},
             "roofline": {"bound": "hbm", "kernel": ("k_pipe" if args.debug & 16 else "k_sweep") + " (one launch per row: extend workgroups; bookkeeping, ledger and counts ride along)" if args.pops == 1 and args.nsam <= 8 and not (args.debug & 8) else ("k_row" if args.pops == 1 and args.nsam <= 8 else (("k_sweep_xmp (extend role of the row pipeline; bookkeeping, ledger and counts as k_sweep_blc on a second stream)" if not (args.debug & 16) else "k_extend_mpr (register tree, completes the previous row while loading)") if args.nsam <= 8 and not (args.debug & 3) else "k_extend_mp") if args.pops > 1 else "k_extend"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -264,6 +264,7 @@ static void open_filter(ChunkFilter& F, PfParam& P, const HostModel& M0, int dev
     pp.flags = 1;          // the local recombination map is always recorded (smcsmc.cpp:376-383)
     pp.mig_cap = P.mig_cap;
     pp.delay_cap = P.delay_cap;
+    pp.log_cap = P.log_cap;
     pp.count_wgs = job ? job->count_wgs : P.count_wgs;
     if (P.delay_evict) pp.flags |= 4;
     if (P.record_trees) {

@@ -1459,12 +1459,28 @@ template <int NI, int P, class KA>
 __device__ __forceinline__ void records_contrib(AccT<P>& acc, const KA& A, const Win& W, const LMap& L, double w, long long a,
                                                 unsigned k0, unsigned k1) {
     const int n = A.n;
-    for (unsigned k = k0; k != k1; ++k) {
+    // A slot appends its records in the order of their positions.  Those that end before the window were consumed by earlier windows
+    // (record_contrib_one's first test), those that start at or behind its end add nothing yet: on a row that lies thirty rows behind
+    // the last resampling a live particle has twenty records of which the window of an old epoch meets one, and the lane with the most
+    // records is what its wavefront waits for.  So the first record that can matter is looked for with three probes at a time
+    // (independent loads: a round trip narrows the range to a quarter), and the walk stops at the first record past the window.
+    unsigned lo = k0, len = k1 - k0;
+    while (len > 4) {
+        const unsigned q = len >> 2;
+        const double xa = rec_ptr(A, a, lo + q)[1], xb = rec_ptr(A, a, lo + 2 * q)[1], xc = rec_ptr(A, a, lo + 3 * q)[1];
+        // (x1 does not decrease along the records: the first one with x1 >= a_e lies behind every probe that is still below a_e)
+        if (xc < W.a_e) { lo += 3 * q + 1; len -= 3 * q + 1; }
+        else if (xb < W.a_e) { lo += 2 * q + 1; len = q; }
+        else if (xa < W.a_e) { lo += q + 1; len = q; }
+        else len = q;
+    }
+    for (unsigned k = lo; k != k1; ++k) {
         const double* rec = rec_ptr(A, a, k);
         double f0 = rec[0], f1 = rec[1], f2 = rec[2], f3 = rec[3], f4 = rec[4];
         double S[NI];
 #pragma unroll
         for (int r = 0; r < NI; ++r) S[r] = r < n - 1 ? rec[5 + r] : 0.0;
+        if (f0 >= W.b_e && !W.end_seq) break;           // this record and all behind it start past the window
         record_contrib_one<NI, P>(acc, A, W, L, w, a, f0, f1, f2, f3, f4, S);
     }
 }
