@@ -1556,6 +1556,18 @@ __device__ __forceinline__ void count_run(AccT<P>& acc, const KA& A, const Count
     records_contrib<NI, P>(acc, A, W, L, w, a, k0, k1);
 }
 
+// LDS of the flattened record walk of count_body: the weight, slot and first record of the task each thread found in a trip, and the
+// exclusive prefix sum of the tasks' record counts
+struct FlatTask { double w; int a; unsigned k0; };
+__device__ __forceinline__ FlatTask* count_flat_tasks() {
+    __shared__ FlatTask ft[PF_BS];
+    return ft;
+}
+__device__ __forceinline__ int* count_flat_prefix() {
+    __shared__ int pre[PF_BS + 1];
+    return pre;
+}
+
 // The body of k_count for the workgroup (bx, by) of a column of nbxg workgroups; `sp` = parity of the step whose
 // weights and snapshot it reads.  Called from k_count and from the count workgroups of k_row.
 template <int NM, int P, bool EXACT = false, class KA>
@@ -1649,95 +1661,100 @@ __device__ __forceinline__ void count_body(const KA& A, const CountSrc& Q, int e
             __syncthreads();
             bins_ready = true;
         }
-        for (long long tb = gtid; tb < T; tb += (long long)PF_CNT_BATCH * nthreads) {
-            int tg[PF_CNT_BATCH], tnr[PF_CNT_BATCH];
-            long long ti[PF_CNT_BATCH];
-            bool tval[PF_CNT_BATCH], tlive[PF_CNT_BATCH];
-#pragma unroll
-            for (int u = 0; u < PF_CNT_BATCH; ++u) {
-                const long long t = tb + (long long)u * nthreads;
-                tval[u] = t < T;
-                // generation of task t: last idx with s_off[idx] <= t
-                int lo_i = 0, hi_i = ntile;
-                while (tval[u] && hi_i - lo_i > 1) {
-                    int mid = (lo_i + hi_i) >> 1;
-                    if ((long long)s_off[mid] <= t) lo_i = mid; else hi_i = mid;
-                }
-                tg[u] = tile_hi - lo_i;
-                ti[u] = t - s_off[lo_i];
-                tnr[u] = s_off[lo_i + 1] - s_off[lo_i];
-                tlive[u] = tval[u] && tg[u] == G;
+        // A trip of the workgroup: one task per thread -- its weight and its records found in two rounds of loads -- then the RECORDS of
+        // the 256 tasks dealt out over the threads, one record per thread and pass.  A task's records used to be walked by the thread
+        // that owned the task, a load and a wait each, and a wavefront lasted as long as its lane with the most records: on the rows
+        // where many epochs catch up the count role ended ten microseconds after the extend role (profiles/round4/wg_trace.md).  The
+        // sums are grouped differently than before round 4 (by the thread that evaluates a record, not by the task's owner), in the
+        // same way in every run.
+        FlatTask* const s_ft = count_flat_tasks();
+        int* const s_fpre = count_flat_prefix();
+        for (long long base = (long long)bx * PF_BS; base < T; base += nthreads) {          // (the same trips for every thread: barriers inside)
+            const long long t = base + threadIdx.x;
+            const bool tval = t < T;
+            // generation of task t: last idx with s_off[idx] <= t
+            int lo_i = 0, hi_i = ntile;
+            while (tval && hi_i - lo_i > 1) {
+                int mid = (lo_i + hi_i) >> 1;
+                if ((long long)s_off[mid] <= t) lo_i = mid; else hi_i = mid;
             }
+            const int tg = tile_hi - lo_i;
+            const long long ti = t - s_off[lo_i];
+            const int tnr = s_off[lo_i + 1] - s_off[lo_i];
+            const bool tlive = tval && tg == G;
             // round 1: the run (slots [q0, q1) of the row descend from slot a of generation g)
-            int q0[PF_CNT_BATCH], q1[PF_CNT_BATCH];
-            long long aa[PF_CNT_BATCH];
-#pragma unroll
-            for (int u = 0; u < PF_CNT_BATCH; ++u) {
-                q0[u] = 0; q1[u] = 0; aa[u] = -1;
-                if (tval[u] && !tlive[u]) {
-                    const int* rst = Q.lists.st + (size_t)(tg[u] % A.Gcap) * Np;
-                    const int* ran = Q.lists.anc + (size_t)(tg[u] % A.Gcap) * Np;
-                    q0[u] = rst[ti[u]];
-                    q1[u] = ti[u] + 1 < tnr[u] ? rst[ti[u] + 1] : (int)Np;
-                    aa[u] = ran[ti[u]];
-                }
+            int q0 = 0, q1 = 0;
+            long long aa = -1;
+            if (tval && !tlive) {
+                const int* rst = Q.lists.st + (size_t)(tg % A.Gcap) * Np;
+                const int* ran = Q.lists.anc + (size_t)(tg % A.Gcap) * Np;
+                q0 = rst[ti];
+                q1 = ti + 1 < tnr ? rst[ti + 1] : (int)Np;
+                aa = ran[ti];
             }
-            // round 2: posterior mass of the run's slots (difference of the inclusive posterior scan) and the ancestor's records
-            // of that generation.  A ledger ring that has overflowed (reported by the bookkeeping, ERR_GEN_OVERFLOW) aliases
-            // generations: whatever is read then must stay inside the arrays until the host sees the error.
-            bool tok[PF_CNT_BATCH];
-            double mhi[PF_CNT_BATCH], mlo[PF_CNT_BATCH];
-            unsigned rk0[PF_CNT_BATCH], rk1[PF_CNT_BATCH], rwl[PF_CNT_BATCH];
+            // round 2: posterior mass of the run's slots (difference of the inclusive posterior scan) and the ancestor's records of that
+            // generation; for a live particle its own weight, its open stretch and the records it wrote this generation.  A ledger ring
+            // that has overflowed (reported by the bookkeeping, ERR_GEN_OVERFLOW) aliases generations: whatever is read then must stay
+            // inside the arrays until the host sees the error.
+            double w = 0.0;
+            long long a_t = 0;
+            unsigned k0 = 0, nrec = 0;
+            if (tlive) {
+                const long long a = ti;
+                w = Q.w[a] * inv;
+                double S[NI];
 #pragma unroll
-            for (int u = 0; u < PF_CNT_BATCH; ++u) {
-                tok[u] = tval[u] && !tlive[u] && !(q1[u] <= q0[u] || q1[u] > (int)Np || q0[u] < 0 || aa[u] < 0 || aa[u] >= Np);
-                mhi[u] = 0.0; mlo[u] = 0.0; rk0[u] = 0; rk1[u] = 0; rwl[u] = 0;
-                if (tok[u]) {
-                    mhi[u] = Q.offp[(q1[u] - 1) >> 6] + Q.scanp[q1[u] - 1];
-                    mlo[u] = q0[u] > 0 ? Q.offp[(q0[u] - 1) >> 6] + Q.scanp[q0[u] - 1] : 0.0;
-                    rk0[u] = A.gstart[(size_t)(tg[u] % A.Gcap) * Np + aa[u]];
-                    rk1[u] = A.gstart[(size_t)((tg[u] + 1) % A.Gcap) * Np + aa[u]];
-                    rwl[u] = Q.widx_live[aa[u]];
-                }
-            }
-            if (A.flags & (1 << 21)) continue;        // probe: rounds 1 and 2 only
-            // round 3, task by task.  One copy of the record loop for the four tasks: the task's values are picked with selects
-            // (the arrays live in registers and cannot be indexed at run time).
-#pragma unroll 1
-            for (int u = 0; u < PF_CNT_BATCH; ++u) {
-                bool live_u = false, ok_u = false;
-                int g_u = 0;
-                long long i_u = 0, a_u = 0;
-                double hi_u = 0.0, lo_u = 0.0;
-                unsigned k0_u = 0, k1_u = 0, wl_u = 0;
-#pragma unroll
-                for (int v = 0; v < PF_CNT_BATCH; ++v)
-                    if (v == u) {
-                        live_u = tlive[v]; ok_u = tok[v]; g_u = tg[v]; i_u = ti[v]; a_u = aa[v];
-                        hi_u = mhi[v]; lo_u = mlo[v]; k0_u = rk0[v]; k1_u = rk1[v]; wl_u = rwl[v];
-                    }
-                if (live_u) {
-                    // live particle: its own weight, its open stretch, the records it wrote this generation
-                    const long long a = i_u;
-                    double w = Q.w[a] * inv;
-                    double S[NI];
-#pragma unroll
-                    for (int r = 0; r < NI; ++r) S[r] = r < n - 1 ? Q.S[(size_t)r * Np + a] : 0.0;
-                    double xm = Q.xm[a];
-                    int ml = Q.ml[a];
-                    unsigned k0 = A.gstart[(size_t)(g_u % A.Gcap) * Np + a];
-                    unsigned k1 = Q.widx[a];
-                    if (w == 0.0) continue;
+                for (int r = 0; r < NI; ++r) S[r] = r < n - 1 ? Q.S[(size_t)r * Np + a] : 0.0;
+                const double xm = Q.xm[a];
+                const int ml = Q.ml[a];
+                const unsigned g0 = A.gstart[(size_t)(tg % A.Gcap) * Np + a];
+                const unsigned g1 = Q.widx[a];
+                if (!(A.flags & (1 << 21)) && w != 0.0) {
                     stretch_contrib<NI, P>(acc, A, W, L, w, xm, PF_INF, S, ml);
-                    if (k1 - k0 > A.cap) { if (!A.ctrl->err) A.ctrl->err = ERR_LOG_OVERFLOW; continue; }
-                    records_contrib<NI, P>(acc, A, W, L, w, a, k0, k1);
-                } else if (ok_u) {
-                    const double w = (hi_u - lo_u) * inv;
-                    if (!(w > 0.0)) continue;
-                    if (wl_u - k0_u > A.cap || k1_u - k0_u > A.cap) { if (!A.ctrl->err) A.ctrl->err = ERR_LOG_OVERFLOW; continue; }
-                    records_contrib<NI, P>(acc, A, W, L, w, a_u, k0_u, k1_u);
+                    if (g1 - g0 > A.cap) { if (!A.ctrl->err) A.ctrl->err = ERR_LOG_OVERFLOW; }
+                    else { a_t = a; k0 = g0; nrec = g1 - g0; }
+                }
+            } else if (tval && !(q1 <= q0 || q1 > (int)Np || q0 < 0 || aa < 0 || aa >= Np)) {
+                const double mhi = Q.offp[(q1 - 1) >> 6] + Q.scanp[q1 - 1];
+                const double mlo = q0 > 0 ? Q.offp[(q0 - 1) >> 6] + Q.scanp[q0 - 1] : 0.0;
+                const unsigned rk0 = A.gstart[(size_t)(tg % A.Gcap) * Np + aa];
+                const unsigned rk1 = A.gstart[(size_t)((tg + 1) % A.Gcap) * Np + aa];
+                const unsigned rwl = Q.widx_live[aa];
+                w = (mhi - mlo) * inv;
+                if (!(A.flags & (1 << 21)) && w > 0.0) {
+                    if (rwl - rk0 > A.cap || rk1 - rk0 > A.cap) { if (!A.ctrl->err) A.ctrl->err = ERR_LOG_OVERFLOW; }
+                    else { a_t = aa; k0 = rk0; nrec = rk1 - rk0; }
                 }
             }
+            // the records of the trip's tasks, numbered through: exclusive prefix sum of the record counts over the workgroup
+            int incl_r = (int)nrec;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl_r, d, 64);
+                if (lane >= d) incl_r += o;
+            }
+            if (lane == 63) s_wsum[threadIdx.x >> 6] = incl_r;
+            __syncthreads();
+            int base_r = 0;
+            for (int wv = 0; wv < (int)(threadIdx.x >> 6); ++wv) base_r += s_wsum[wv];
+            s_fpre[threadIdx.x] = base_r + incl_r - (int)nrec;
+            if (threadIdx.x == PF_BS - 1) s_fpre[PF_BS] = base_r + incl_r;
+            s_ft[threadIdx.x].w = w; s_ft[threadIdx.x].a = (int)a_t; s_ft[threadIdx.x].k0 = k0;
+            __syncthreads();
+            const int nrec_all = s_fpre[PF_BS];
+            for (int r = (int)threadIdx.x; r < nrec_all; r += PF_BS) {
+                int lo_j = 0, hi_j = PF_BS;                  // the task of record r: last j with s_fpre[j] <= r (its own count is not zero)
+                while (hi_j - lo_j > 1) { const int mid = (lo_j + hi_j) >> 1; if (s_fpre[mid] <= r) lo_j = mid; else hi_j = mid; }
+                const double w_r = s_ft[lo_j].w;
+                const long long a_r = s_ft[lo_j].a;
+                const double* rec = rec_ptr(A, a_r, s_ft[lo_j].k0 + (unsigned)(r - s_fpre[lo_j]));
+                double f0 = rec[0], f1 = rec[1], f2 = rec[2], f3 = rec[3], f4 = rec[4];
+                double S[NI];
+#pragma unroll
+                for (int q = 0; q < NI; ++q) S[q] = q < n - 1 ? rec[5 + q] : 0.0;
+                record_contrib_one<NI, P>(acc, A, W, L, w_r, a_r, f0, f1, f2, f3, f4, S);
+            }
+            __syncthreads();                                 // (the next trip, or the next tile's staging, writes the arrays again)
         }
     }
     // deterministic workgroup reduction: butterfly per wavefront, then wavefronts in order
