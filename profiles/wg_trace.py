@@ -59,7 +59,7 @@ def main():
     if a.raw:
         np.savez_compressed(a.raw, trace=tr, nb=(a.np + 255) // 256, chunks=a.chunks, count_wgs=cw, count_workers=a.count_workers, debug=a.debug)
     nb = (a.np + 255) // 256
-    nL = nb + 192
+    nL = nb + (32 if cw > 0 else 192)          # ledger workgroups per step (pf_hip.hip: 32 beside the particle blocks when the caller sets count_wgs)
     bounds = [("extend", 0, nb), ("bookkeeping", nb, nb + 1), ("draw table", nb + 1, 2 * nb + 1), ("ledger", 2 * nb + 1, 2 * nb + 1 + nL), ("counts", 2 * nb + 1 + nL, 1 << 30)]
     if a.count_workers > 0:
         bounds = bounds[:3] + [("workers", 2 * nb + 1, 1 << 30)]
