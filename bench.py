@@ -223,7 +223,7 @@ def main():
                     help="synthetic data from the numpy simulator (round-1 inputs) instead of the device-side simulator")
     ap.add_argument("--uncalibrated-lags", action="store_true",
                     help="the reference's uncalibrated lags 4/(rho*top_t) instead of the calibrated default of the binary")
-    ap.add_argument("--debug", type=int, default=0, help="pf_params.debug bits (include/smcsmc_pf.h): 4 no counting, 8 two launches per row, 16 the round-2 row paths, 32 no speculative staging, 64 extend role and the other roles as two launches")
+    ap.add_argument("--debug", type=int, default=0, help="pf_params.debug bits (include/smcsmc_pf.h): 4 no counting, 8 two launches per row, 16 the round-2 row paths, 32 no speculative staging, 64 extend role and the other roles as two launches (round 3 form), 8388608 every role of a step in one launch (rounds 3-4)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a single-GPU box: every rank uses device 0 and the collectives go through gloo "
                          "on host tensors (RCCL refuses two ranks on one device); the numbers it prints are not a scaling result")
@@ -265,6 +265,9 @@ def main():
 
     import threading
     C = max(1, args.chunks_per_gpu)
+    # six or more chunks per GPU: count_wgs set (to the most a column can have) makes the library taper the columns of the young epochs and trim its
+    # ledger workgroups -- 8 chunks 1.09e5 -> 1.17e5 segments/s, 12 chunks 1.11e5 -> 1.29e5; fewer chunks are faster without (4: 8.95e4 against 8.55e4)
+    many_wgs = (args.np + 255) // 256
     dev = local_rank if (world > 1 and not args.rehearse_on_one_gpu) else 0
     args.device = dev
     chunks = []
@@ -272,7 +275,7 @@ def main():
         model, segs = build_workload(args, seed=args.seed + rank * C + k)     # independent chunks
         f = ParticleFilter(model, args.np, ess_fraction=0.5, seed=args.seed + 1000 * (rank * C + k), max_trace_events=0,
                            device=dev, local_recomb=not args.no_local_recomb, debug=args.debug,
-                           count_wgs=args.count_wgs or (24 if (args.chunks_per_gpu >= 6 and not (args.debug & 2048)) else 0),
+                           count_wgs=max(0, args.count_wgs) or (many_wgs if (args.chunks_per_gpu >= 6 and args.count_wgs == 0) else 0),
                            count_workers=max(0, args.count_workers), log_cap=args.log_cap)
         f.load_segments(segs)
         chunks.append((f, segs))
@@ -395,9 +398,9 @@ def main():
                        "populations": args.pops, "local_recombination_map": not args.no_local_recomb,
                        "segments_per_chunk": n_segments, "nsam": args.nsam, "np": args.np,
                        "sequence_length": args.length, "epochs": args.epochs, "event_log_records_per_particle": args.log_cap or 16384,
-                       "count_workgroups_per_epoch": args.count_wgs or (24 if (args.chunks_per_gpu >= 6 and not (args.debug & 2048)) else "one per particle block"),
+                       "count_workgroups_per_epoch": ("one per particle block, tapered for the young epochs" if (args.chunks_per_gpu >= 6 and args.count_wgs == 0) else (args.count_wgs if args.count_wgs > 0 else "one per particle block")),
                        "parallelism": "%d chunk(s) per gpu%s x %d gpu(s)" % (C, (", one launch per row for all of them" if many else ", one host thread and stream each") if C > 1 else "", world), "log_likelihood_sum": logl_sum},
-            "roofline": {"bound": "hbm", "kernel": ("k_pipe" if args.debug & 16 else "k_sweep") + " (one launch per row: extend workgroups; bookkeeping, ledger and counts ride along)" if args.pops == 1 and args.nsam <= 8 and not (args.debug & 8) else ("k_row" if args.pops == 1 and args.nsam <= 8 else (("k_sweep_xmp (extend role of the row pipeline; bookkeeping, ledger and counts as k_sweep_blc on a second stream)" if not (args.debug & 16) else "k_extend_mpr (register tree, completes the previous row while loading)") if args.nsam <= 8 and not (args.debug & 3) else "k_extend_mp") if args.pops > 1 else "k_extend"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": ("k_pipe (one launch per row: extend workgroups; bookkeeping, ledger and counts ride along)" if args.debug & 16 else ("k_sweep4 (one launch per row: the extend, bookkeeping and draw roles; ledger and counts as k_sweep_blc4 on a second stream)" if args.nsam <= 4 and not (args.debug & (1 << 23)) else "k_sweep (one launch per row: extend workgroups; bookkeeping, ledger and counts ride along)")) if args.pops == 1 and args.nsam <= 8 and not (args.debug & 8) else ("k_row" if args.pops == 1 and args.nsam <= 8 else (("k_sweep_xmp (extend role of the row pipeline; bookkeeping, ledger and counts as k_sweep_blc on a second stream)" if not (args.debug & 16) else "k_extend_mpr (register tree, completes the previous row while loading)") if args.nsam <= 8 and not (args.debug & 3) else "k_extend_mp") if args.pops > 1 else "k_extend"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_launch": alg_bytes,
                          "alg_bytes_model": "2 x %d B of state per particle (read and written once per row) x Np + %.2f records of %d B appended per row (DESIGN.md section 2)" % (state_bytes, rec_per_seg, rec_bytes),

@@ -97,7 +97,7 @@ typedef struct pf_params {
                                   * any tree is a reported error ("too many migration events on one local tree"). */
     int32_t count_wgs;           /* row pipeline: workgroups per epoch that share the lagged counting of a row (0 = one
                                   * per 256 particles, which is also the most).  The sums are grouped by workgroup, so the value is part
-                                  * of what makes two runs bit-identical.  (With PF_DEBUG_COUNT_UNITS: workgroups per step.) */
+                                  * of what makes two runs bit-identical. */
     int32_t delay_cap;           /* focused sampling / guide: delayed importance factors a particle may have pending (0 = 128).  The
                                   * reference keeps them in an unbounded heap (particle.hpp:59-101, 248); here the store is a column of
                                   * delay_cap entries per particle in device memory.  One factor too many is a reported error
@@ -126,14 +126,14 @@ typedef struct pf_params {
 
 #define PF_DEBUG_COUNT_YOUNG_FIRST 512 /* row pipeline: count workgroups in ascending epoch order, as before round 3 (A/B) */
 
-#define PF_DEBUG_COUNT_UNITS 2048 /* with PF_DEBUG_SPLIT_ROLES, one population: the lagged counts dealt out by generation (256 tasks of one
-                                  * generation for up to four of the epochs whose windows meet it; count_units_body) instead of one
-                                  * column of workgroups per epoch -- an experiment of round 4, measured slower;
-                                  * the sums are grouped differently and agree to rounding */
-
 #define PF_DEBUG_FLAG_HANDOFF 8192 /* one population: a row as two launches (extend + draw roles; bookkeeping + ledger + counts) that no longer wait
                                   * for each other's END: the extend launches alternate between two streams and hand the row over through
                                   * arrival counters in memory, the other launches wait the same way (run_sweep_flags; same bits) */
+
+#define PF_DEBUG_ONE_LAUNCH (1 << 23) /* one population, at most four haplotypes, no focused sampling: every role of a step in ONE launch (k_sweep4 with the
+                                  * ledger and count workgroups riding along: the form of rounds 3 and 4) instead of two -- the extend, bookkeeping
+                                  * and draw roles; the ledger and count roles on the counting stream, four workgroups to a compute unit
+                                  * (run_sweep_split).  A/B, same bits */
 
 #define PF_DEBUG_CU_MASK 1024     /* with PF_DEBUG_SPLIT_ROLES: the two streams on disjoint sets of compute units (experiment) */
 

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--raw", default="", help="save the raw trace (npz) for analysis elsewhere")
     a = ap.parse_args()
+    a.debug |= 1 << 23          # PF_DEBUG_ONE_LAUNCH: the trace is of the form in which every role of a step is one launch (k_sweep4t / k_sweep4q)
     from smcsmc_amd import ParticleFilter
     wl = argparse.Namespace(np=a.np, nsam=a.nsam, length=a.length, epochs=a.epochs, seed=1, pops=1, uncalibrated_lags=False, host_data=False, device=0)
     cw = a.count_wgs if a.count_wgs >= 0 else (24 if a.chunks >= 6 else 0)

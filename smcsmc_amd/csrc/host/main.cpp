@@ -619,11 +619,11 @@ static void run_chunks(ChunkPlan& C, PfParam& P, const HostModel& M0) {
                                             ".chunk" + std::to_string(c) + ".recomb.gz";
                 if (P.em_iteration == 0) remove(params[k].recomb_map_path.c_str());
                 jobs[k].survival = &survival; jobs[k].survival_out = &survival; jobs[k].packed_out = &packed[k]; jobs[k].seed_offset = (uint64_t)c;
-                // Six or more chunks side by side on a device: 24 count workgroups per epoch column instead of one per 256 particles,
-                // and the library trims its ledger workgroups (8 chunks of the C3 shape: 9.4e4 segments/s against 8.0e4,
-                // profiles/round4/wg_trace.md).  The sums of a chunk are grouped by workgroup: a run that must give the same bits
+                // Six or more chunks side by side on a device: count_wgs set (to the most a column can have, one per 256 particles) makes
+                // the library taper the columns of the young epochs and trim its ledger workgroups (8 chunks of the C3 shape: 1.17e5
+                // segments/s against 1.09e5, 12 chunks 1.29e5 against 1.11e5; profiles/round4/wg_trace.md).  The sums of a chunk are grouped by workgroup: a run that must give the same bits
                 // whatever the number of ranks pins the width with -count_wgs.
-                jobs[k].count_wgs = P.count_wgs > 0 ? P.count_wgs : ((lockstep && my_chunks.size() >= 6) ? 24 : 0);
+                jobs[k].count_wgs = P.count_wgs > 0 ? P.count_wgs : ((lockstep && my_chunks.size() >= 6) ? (int)((P.particles + 255) / 256) : 0);
             }
             // Side by side in groups: as many of the rank's chunks as the device has memory for are opened together (every
             // filter holds its own rings: the event log alone is Np x 16 384 records by default) and go through one launch per

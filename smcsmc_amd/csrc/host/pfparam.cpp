@@ -305,7 +305,7 @@ const std::vector<DriverOption>& driver_options() {
         // particle.hpp:248), and what happens when it runs out
         {"-log_cap", "INT", "Inference tuning", "Event-log records kept per particle (a ring; one too few for the lags in force stops the run with a message) [ 16384 ]",
          [](PfParam& p, const std::string& v) { p.log_cap = convert<long long>("-log_cap", v); if (p.log_cap < 4) throw OutOfRange("-log_cap", v); }},
-        {"-count_wgs", "INT", "Inference tuning", "Workgroups per epoch that share the lagged counting of a row (part of what makes two runs bit-identical) [ one per 256 particles; 24 with six or more chunks per device ]",
+        {"-count_wgs", "INT", "Inference tuning", "Workgroups per epoch that share the lagged counting of a row (part of what makes two runs bit-identical) [ one per 256 particles; with six or more chunks per device fewer for the young epochs ]",
          [](PfParam& p, const std::string& v) { p.count_wgs = convert<int>("-count_wgs", v); if (p.count_wgs < 1) throw OutOfRange("-count_wgs", v); }},
         {"-delaycap", "INT", "Inference tuning", "Delayed importance factors a particle may have pending; one too many stops the run [ 128 ]",
          [](PfParam& p, const std::string& v) { p.delay_cap = convert<int>("-delaycap", v); if (p.delay_cap < 1) throw OutOfRange("-delaycap", v); }},

@@ -210,7 +210,7 @@ class PfParam {
     int mig_cap = 0;                                 // -migcap: pf_params.mig_cap (0 = the library's default)
     int delay_cap = 0;                               // -delaycap: pf_params.delay_cap (0 = the library's default)
     long long log_cap = 0;                           // -log_cap: pf_params.log_cap (0 = the library's default; -arg sizes its own)
-    int count_wgs = 0;                               // -count_wgs: pf_params.count_wgs (0 = chosen here: the library's default, or 24 with six or more chunks per device)
+    int count_wgs = 0;                               // -count_wgs: pf_params.count_wgs (0 = chosen here: the library's default, or tapered columns with six or more chunks per device)
     bool delay_evict = false;                        // -delay_evict: pf_params.flags bit 2
     std::string reduce_transport;                    // "rccl" / "host" / "" = choose
     double segment_cap() const;                      // rows longer than this many bases are cut (pfparam.cpp:364)

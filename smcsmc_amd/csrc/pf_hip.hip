@@ -1783,270 +1783,10 @@ __device__ __forceinline__ void count_body(const KA& A, const CountSrc& Q, int e
     }
 }
 
-// ------------------------------------------------------------------ counting by generation (round 4)
-// count_body gives every epoch a column of workgroups that walks the (generation, ancestor run) pairs of the epoch's window: a
-// pair that lies in the windows of ten epochs -- the old epochs' lags are a row or two long, their windows all sit in the one or
-// two generations behind the front, where nearly every particle is still its own ancestor -- is fetched ten times (run list ->
-// posterior scan and record range -> records: three dependent rounds of loads each time), and that fetching is what a row's
-// counting costs (profiles/round3/count_wgs.md: about eight times the extend role's workgroup-time).  Here the unit of work is
-// the pair itself: 256 tasks of one generation, their weights and record ranges fetched once and held in registers while the
-// epochs whose windows meet that generation take their turns (the records are read again per epoch, from the cache).  A step
-// has a fixed number of count workgroups (PipeLaunch::ncw) that deal the units out among themselves in a fixed order -- every
-// workgroup builds the same small table of the step's generations (their epoch masks and task counts) -- so the sums are
-// grouped the same way in every run (bit-identical output), though not as count_body groups them.
-#define PF_CU_ECMAX 8           // most epochs of a generation's mask that one unit takes
-struct CuLds {
-    int glo[PF_EMAX], ghi[PF_EMAX];
-    double T[PF_EMAX + 1], wa[PF_EMAX], wb[PF_EMAX];
-    int rf[PF_EMAX];
-    unsigned long long mask[PF_BS];            // one generation per thread and tile: epochs whose window meets it
-    int nt[PF_BS];                             // its tasks (ancestor runs, or the live particles)
-    int uoff[PF_BS + 1];                       // exclusive prefix sum of its units
-    int wsum[PF_BS / 64];
-    // the unit in hand: its tasks' weights, slots and first records, the prefix sum of their record counts
-    int roff[PF_BS + 1];
-    double rw[PF_BS];
-    int ra[PF_BS];
-    unsigned rk0[PF_BS];
-    // its epochs and their shares of the local map's LDS bins
-    int ce[PF_CU_ECMAX], boff[PF_CU_ECMAX], bn[PF_CU_ECMAX];
-    long long bb0[PF_CU_ECMAX];
-    int bins_used;
-    double red[PF_BS / 64][PF_CU_ECMAX][6];
-};
-static_assert(sizeof(CuLds) <= PF_COUNT_LDS_BYTES, "CuLds must fit the count roles' LDS");
-
-template <int NM, bool EXACT, class KA>
-__device__ __forceinline__ void count_units_body(const KA& A, const CountSrc& Q, const Ctrl::RowInfo& r, int wg, int nwg) {
-    constexpr int NI = NM - 1;
-    using AC = AccT<1>;
-    CuLds& Z = *(CuLds*)count_lds<PF_COUNT_LDS_BYTES>();
-    double* const s_lbins = count_bins();
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long Np = A.Np;
-    const int n = EXACT ? NM : A.n, E = A.E, G = Q.G;
-    const double inv = Q.inv;
-    const int first = r.first;
-    const int ec = A.cu_ec > 0 ? (A.cu_ec < PF_CU_ECMAX ? A.cu_ec : PF_CU_ECMAX) : 4;
-    if (tid < PF_EMAX) {
-        const bool mv = tid >= first && tid < E;
-        Z.glo[tid] = mv ? r.g_lo[tid] : 1;
-        Z.ghi[tid] = mv ? r.g_hi[tid] : 0;
-        Z.T[tid] = tid < E ? A.T[tid] : PF_INF;
-        Z.wa[tid] = mv ? r.wa[tid] : 0.0;
-        Z.wb[tid] = mv ? r.wb[tid] : 0.0;
-        Z.rf[tid] = tid < E ? A.recflags[tid] : 0;
-        if (tid == 0) Z.T[PF_EMAX] = PF_INF;
-    }
-    __syncthreads();
-    int gmin = 0x7fffffff, gmax = -1;
-    for (int e = first; e < E; ++e) {
-        const int a = Z.glo[e], b = Z.ghi[e];
-        if (b >= a) { gmin = a < gmin ? a : gmin; gmax = b > gmax ? b : gmax; }
-    }
-    if (gmax < gmin) return;
-    const bool lmap = A.lmap_opp != nullptr;
-    long long ubase = 0;
-    for (int thi = gmax; thi >= gmin; thi -= PF_BS) {
-        const int tlo = thi - PF_BS + 1 > gmin ? thi - PF_BS + 1 : gmin;
-        const int ntile = thi - tlo + 1;
-        __syncthreads();
-        {
-            const int g = thi - tid;
-            unsigned long long m = 0;
-            int nt = 0;
-            if (tid < ntile) {
-                for (int e = first; e < E; ++e)
-                    if (Z.glo[e] <= g && g <= Z.ghi[e]) m |= 1ull << e;
-                if (m) nt = g == G ? (int)Np : Q.lists.nruns[g % A.Gcap];
-                if (nt < 0 || nt > (int)Np) nt = 0;          // an overflowed ledger ring (a reported error) aliases generations
-            }
-            // units of the generation: (block of PF_BS tasks) x (chunk of `ec` epochs of its mask)
-            const int nu = ((nt + PF_BS - 1) / PF_BS) * ((__popcll(m) + ec - 1) / ec);
-            int incl = nu;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                int o = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += o;
-            }
-            if (lane == 63) Z.wsum[wave] = incl;
-            __syncthreads();
-            int base = 0;
-            for (int w = 0; w < wave; ++w) base += Z.wsum[w];
-            Z.mask[tid] = m; Z.nt[tid] = nt; Z.uoff[tid] = base + incl - nu;
-            if (tid == PF_BS - 1) Z.uoff[PF_BS] = base + incl;
-        }
-        __syncthreads();
-        const int total = Z.uoff[PF_BS];
-        int u = (int)(((long long)wg - ubase) % nwg);
-        if (u < 0) u += nwg;
-        for (; u < total; u += nwg) {
-            int lo_i = 0, hi_i = PF_BS;             // generation of unit u: the last index with uoff[index] <= u
-            while (hi_i - lo_i > 1) {
-                const int mid = (lo_i + hi_i) >> 1;
-                if (Z.uoff[mid] <= u) lo_i = mid; else hi_i = mid;
-            }
-            const int g = thi - lo_i;
-            unsigned long long gm = Z.mask[lo_i];
-            const int ntk = Z.nt[lo_i];
-            const int nchunks = (__popcll(gm) + ec - 1) / ec;
-            const int chunk = (u - Z.uoff[lo_i]) % nchunks;
-            const long long task = (long long)((u - Z.uoff[lo_i]) / nchunks) * PF_BS + tid;
-            {
-                // the unit's chunk of the generation's epochs: set bits [chunk * ec, chunk * ec + ec) of the mask
-                for (int k = 0; k < chunk * ec; ++k) gm &= gm - 1;
-                unsigned long long keep = 0, t = gm;
-                for (int k = 0; k < ec && t; ++k) { keep |= t & (0ull - t); t &= t - 1; }
-                gm = keep;
-            }
-            const int nce = __popcll(gm);
-            const bool valid = task < ntk, live = g == G;
-            // rounds 1 and 2: the task's weight and its range of records
-            double w = 0.0;
-            long long a = 0;
-            unsigned k0 = 0, k1 = 0;
-            bool ok = false;
-            if (valid && live) {
-                a = task;
-                w = Q.w[a] * inv;
-                k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
-                k1 = Q.widx[a];
-                ok = w != 0.0;
-                if (ok && k1 - k0 > A.cap) { if (!A.ctrl->err) A.ctrl->err = ERR_LOG_OVERFLOW; k1 = k0; }
-            } else if (valid) {
-                const int* rst = Q.lists.st + (size_t)(g % A.Gcap) * Np;
-                const int* ran = Q.lists.anc + (size_t)(g % A.Gcap) * Np;
-                const int q0 = rst[task];
-                const int q1 = task + 1 < ntk ? rst[task + 1] : (int)Np;
-                a = ran[task];
-                if (!(q1 <= q0 || q1 > (int)Np || q0 < 0 || a < 0 || a >= Np)) {
-                    const double hi = Q.offp[(q1 - 1) >> 6] + Q.scanp[q1 - 1];
-                    const double lo = q0 > 0 ? Q.offp[(q0 - 1) >> 6] + Q.scanp[q0 - 1] : 0.0;
-                    k0 = A.gstart[(size_t)(g % A.Gcap) * Np + a];
-                    k1 = A.gstart[(size_t)((g + 1) % A.Gcap) * Np + a];
-                    const unsigned wl = Q.widx_live[a];
-                    w = (hi - lo) * inv;
-                    ok = w > 0.0;
-                    if (ok && (wl - k0 > A.cap || k1 - k0 > A.cap)) { if (!A.ctrl->err) A.ctrl->err = ERR_LOG_OVERFLOW; ok = false; }
-                }
-            }
-            // the records of the unit's tasks, flattened: one record per thread and pass (a live particle's open stretch is
-            // its first), so that no thread waits for the task with the most records
-            const int nrec = ok ? (int)(k1 - k0) + (live ? 1 : 0) : 0;
-            {
-                int incl = nrec;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    int o = __shfl_up(incl, d, 64);
-                    if (lane >= d) incl += o;
-                }
-                __syncthreads();                       // (the tables of the previous unit are no longer read)
-                if (lane == 63) Z.wsum[wave] = incl;
-                __syncthreads();
-                int base = 0;
-                for (int v = 0; v < wave; ++v) base += Z.wsum[v];
-                Z.roff[tid] = base + incl - nrec; Z.rw[tid] = w; Z.ra[tid] = (int)a; Z.rk0[tid] = k0;
-                if (tid == PF_BS - 1) Z.roff[PF_BS] = base + incl;
-                if (tid < PF_CU_ECMAX) {
-                    unsigned long long q = gm;
-                    for (int j = 0; j < tid && q; ++j) q &= q - 1;
-                    Z.ce[tid] = q ? __builtin_ctzll(q) : 0;
-                }
-                __syncthreads();
-                if (lmap && tid == 0) {
-                    // the LDS bins of the local map are shared out among the unit's epochs, oldest first (their windows are a
-                    // row or two wide); an epoch that finds no room adds to memory directly
-                    int used = 0;
-                    for (int j = nce - 1; j >= 0; --j) {
-                        const int e = Z.ce[j];
-                        const long long b0 = (long long)(Z.wa[e] / 100.0);
-                        const long long span = (long long)(Z.wb[e] / 100.0) - b0 + 4;
-                        const int want = span < 1 ? 1 : (span > PF_LBINS ? PF_LBINS : (int)span);
-                        const int got = used + want <= PF_LBINS ? want : 0;
-                        Z.bb0[j] = b0; Z.boff[j] = used; Z.bn[j] = got;
-                        used += got;
-                    }
-                    Z.bins_used = used;
-                }
-                if (lmap) {
-                    __syncthreads();
-                    for (int k = tid; k < Z.bins_used; k += PF_BS) s_lbins[k] = 0.0;
-                    __syncthreads();
-                }
-            }
-            const int R = Z.roff[PF_BS];
-            for (int rb = 0; rb < R; rb += PF_BS) {
-                const int j = rb + tid;
-                const bool have = j < R;
-                double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0, f4 = 0.0, wv = 0.0;
-                long long av = 0;
-                double S[NI];
-#pragma unroll
-                for (int q = 0; q < NI; ++q) S[q] = 0.0;
-                if (have) {
-                    int li = 0, hi2 = PF_BS;
-                    while (hi2 - li > 1) {
-                        const int mid = (li + hi2) >> 1;
-                        if (Z.roff[mid] <= j) li = mid; else hi2 = mid;
-                    }
-                    const int d = j - Z.roff[li];
-                    wv = Z.rw[li]; av = Z.ra[li];
-                    if (live && d == 0) {
-                        // the open stretch of a live particle: a stretch record that ends nowhere yet
-                        f0 = Q.xm[av]; f1 = PF_INF;
-                        f4 = __longlong_as_double((long long)make_meta(1, Q.ml[av], -1, n));
-#pragma unroll
-                        for (int q = 0; q < NI; ++q) S[q] = q < n - 1 ? Q.S[(size_t)q * Np + av] : 0.0;
-                    } else {
-                        const double* rec = rec_ptr(A, av, Z.rk0[li] + (unsigned)(d - (live ? 1 : 0)));
-                        f0 = rec[0]; f1 = rec[1]; f2 = rec[2]; f3 = rec[3]; f4 = rec[4];
-#pragma unroll
-                        for (int q = 0; q < NI; ++q) S[q] = q < n - 1 ? rec[5 + q] : 0.0;
-                    }
-                }
-#pragma unroll 1
-                for (int jj = 0; jj < nce; ++jj) {
-                    const int e = Z.ce[jj];
-                    Win W;
-                    W.e = e; W.rf = Z.rf[e]; W.T0 = Z.T[e]; W.T1 = e + 1 < E ? Z.T[e + 1] : PF_INF; W.a_e = Z.wa[e]; W.b_e = Z.wb[e];
-                    W.end_seq = (A.L == W.b_e);
-                    LMap L;
-                    L.lds = s_lbins + Z.boff[jj]; L.b0 = Z.bb0[jj]; L.nlds = Z.bn[jj]; L.gopp = A.lmap_opp; L.gcnt = A.lmap_cnt; L.nbins = A.lmap_bins; L.ncnt = 0;
-                    AC acc;
-#pragma unroll
-                    for (int k = 0; k < AC::NC; ++k) acc.v[k] = 0.0;
-                    if (have) record_contrib_one<NI, 1>(acc, A, W, L, wv, av, f0, f1, f2, f3, f4, S);
-#pragma unroll
-                    for (int k = 0; k < AC::NC; ++k) {
-                        const double t = wave_total_dpp(acc.v[k]);
-                        if (lane == 0) Z.red[wave][jj][k] = t;
-                    }
-                }
-                __syncthreads();
-                // this workgroup's accumulators of the unit's epochs (folded by k_count_fin): wavefronts in order
-                if (tid < nce * AC::NC) {
-                    const int jj = tid / AC::NC, k = tid % AC::NC;
-                    double t = Z.red[0][jj][k];
-                    for (int v = 1; v < PF_BS / 64; ++v) t += Z.red[v][jj][k];
-                    if (t != 0.0) A.partial[((size_t)Z.ce[jj] * A.nbx + wg) * AC::NC + k] += t;
-                }
-                __syncthreads();
-            }
-            if (lmap) {
-                for (int jj = nce - 1; jj >= 0; --jj) {
-                    const int nb_e = Z.bn[jj], off = Z.boff[jj];
-                    const long long b0 = Z.bb0[jj];
-                    for (int k = tid; k < nb_e; k += PF_BS) {
-                        const double v = s_lbins[off + k];
-                        const long long idx = b0 + k;
-                        if (v != 0.0 && idx < A.lmap_bins) atomicAdd(&A.lmap_opp[idx], v);
-                    }
-                }
-            }
-        }
-        ubase += total;
-    }
-}
+// (Round 4 also built the counting by generation -- units of 256 tasks of one generation, their weights and record ranges fetched once
+// for all the epochs whose windows meet that generation, records flattened over the workgroup: count_units_body, commit 9818bcc and
+// before.  It was slower in every regime (profiles/round4/count_rebuild.md); the part of it that paid, the flattened record walk, is in
+// count_body now, and the rest was taken out.)
 
 template <int NM, int P>
 __global__ __launch_bounds__(PF_BS) void k_count(KArgs A, int e0, Windows Wn) {
@@ -2329,7 +2069,9 @@ __device__ __forceinline__ void pipe_bookkeeping(const KA& A, const PipeLds& q, 
         int gr = c->g_lo[0];
         for (int e = 1; e < E; ++e) gr = c->g_lo[e] < gr ? c->g_lo[e] : gr;
         c->g_retain = gr;
-        c->g_safe = c->ri[(slot + PF_RING - 2) & (PF_RING - 1)].g_retain;      // (the entry of two rows ago, or what the seed of the call left there)
+        // (the entry of two rows ago, or what the seed of the call left there; where the bookkeeping itself runs ahead of the counts with the
+        // extend role -- run_sweep_split -- the oldest entry of the ring: the counts in flight are at most fifteen rows behind this one)
+        c->g_safe = c->ri[(slot + PF_RING - (PL.nL == -3 ? PF_RING - 1 : 2)) & (PF_RING - 1)].g_retain;
         c->delayed_opp += W.b[E - 1] - W.a[E - 1];
         if (BIASED) {
             long long npend = 0;      // update_delayed_weight_count (count.cpp:395-397)
@@ -2442,7 +2184,7 @@ __device__ __forceinline__ void pipe_roles(const KA& A, long long s, const PipeL
         return;
     }
     if (bx == nb) {
-        if (PL.b_slot < 0 || PL.nL < -1) return;           // nL = -2: the extend launch of a split step
+        if (PL.b_slot < 0 || PL.nL == -2) return;          // nL = -2: the extend launch of a split step (-3: one that keeps the bookkeeping)
         extern __shared__ double smem[];
         PipeLds q = pipe_carve(smem + (2 * PF_EPAD + A.E + 2 * PF_BIAS_MAX + 3), A.nc);
         pipe_bookkeeping<BIASED>(A, q, PL, Wb);
@@ -2456,27 +2198,6 @@ __device__ __forceinline__ void pipe_roles(const KA& A, long long s, const PipeL
     const Ctrl* c = A.ctrl;
     const Ctrl::RowInfo& r = c->ri[PL.lc_slot];
     const int lb = bx - (nb + 1) - PL.nT;
-    if constexpr (P == 1 && BLC) {
-        // (only in the launch of the bookkeeping / ledger / count roles of the split arrangement: in the one launch of k_sweep the
-        // body would raise the kernel's register count past the 168 that let three workgroups share a compute unit)
-        if (PL.units && PL.workers == 0) {
-            // counting by generation: the workgroups of the step deal the (generation, 256 tasks) units out among themselves
-            const int idx = lb - PL.nL;
-            if (idx < 0) { if (r.flag) pipe_ledger_item(A, PL, r, lb); return; }
-            if (idx >= PL.ncw || r.first >= A.E) return;
-            const DState st = state_slot(A, PL.lc_slot);
-            CountSrc Q;
-            Q.w = st.w_post; Q.S = st.S; Q.xm = st.x_mark; Q.ml = st.mark_limit;
-            Q.widx = A.rg_widx + (size_t)PL.lc_slot * A.Np;
-            Q.widx_live = A.rg_widx + (size_t)PL.live_slot * A.Np;
-            Q.scanp = A.rg_scanp + (size_t)PL.lc_slot * A.Np;
-            Q.offp = A.rg_coffp + (size_t)PL.lc_slot * A.nc;
-            Q.lists = run_lists(A, r.lver);
-            Q.inv = r.inv_T; Q.G = r.gen; Q.g_lo = 0; Q.g_hi = 0;
-            count_units_body<NM, EXACT>(A, Q, r, idx, PL.ncw);
-            return;
-        }
-    }
     // The ledger and count work of the step: items -- a ledger block of a resampling row, or part cbx of the count column of an
     // epoch.  Without pf_params.count_workers every item is a workgroup of this launch (ledger blocks first, then the columns,
     // oldest epoch first).
@@ -2591,8 +2312,11 @@ __device__ __forceinline__ void sweep_kernel_body(const SweepChunk* tab_g, long 
     }
     PipeLaunch PL;
     if (ok && sweep_plan(ch, s, nb, PL)) {
-        if (ch.split) PL.nL = -2;                          // extend and draw roles only: the other roles are k_sweep_blc's
-        else if (pf_bx() == nb && PL.b_slot >= 0) sweep_windows(A, A.ctrl, PL.b_pos, W);
+        if (ch.split == 1) PL.nL = -2;                     // extend and draw roles only: the other roles are k_sweep_blc's
+        else {
+            if (ch.split == 2) PL.nL = -3;                 // ... the bookkeeping too: only ledger and counts are k_sweep_blc's (run_sweep_split)
+            if (pf_bx() == nb && PL.b_slot >= 0) sweep_windows(A, A.ctrl, PL.b_pos, W);
+        }
         pipe_roles<NM, BIASED, EXACT, TREES, 1, false, QUEUE>(A, s, PL, W);
     }
     if constexpr (HANDOFF) sweep_arrive(&A.ctrl->xt_done[t & (PF_RING - 1)]);
@@ -2636,8 +2360,8 @@ __global__ __launch_bounds__(PF_BS) __attribute__((amdgpu_waves_per_eu(3, 3))) v
 // stream beside their extend launch (k_sweep_xmp, pf_mp.hip).  The extend workgroups of those models carry their trees'
 // migration events in LDS (61 KB per 64 particles at the default capacity); in one launch every count workgroup would be
 // given the same allocation and one would fit a CU.
-template <int NM, int P, bool BIASED>
-__global__ __launch_bounds__(PF_BS) void k_sweep_blc(const SweepChunk* tab_g, long long t) {
+template <int NM, int P, bool BIASED, bool EXACT = false>
+__device__ __forceinline__ void sweep_blc_body(const SweepChunk* tab_g, long long t) {
     SweepChunkC* tab = (SweepChunkC*)tab_g;
     SweepChunkC& ch = tab[pf_chunk()];
     KArgsC& A = ch.A;
@@ -2647,8 +2371,9 @@ __global__ __launch_bounds__(PF_BS) void k_sweep_blc(const SweepChunk* tab_g, lo
     PipeLaunch PL;
     if (sweep_plan(ch, s, 0, PL)) {
         PL.nT = 0;                                         // the draw role rides with the extend launch
+        if (ch.split == 2) PL.b_slot = -1;                 // ... and so does the bookkeeping (run_sweep_split)
         if (pf_bx() == 0 && PL.b_slot >= 0) sweep_windows(A, c, PL.b_pos, W);
-        pipe_roles<NM, BIASED, false, false, P, true>(A, s, PL, W);
+        pipe_roles<NM, BIASED, EXACT, false, P, true>(A, s, PL, W);
     }
     if (ch.handoff) {
         // run_sweep_flags: the extend launch of step t + 14 overwrites ring slots this launch read; it polls Ctrl::blc_step, which the
@@ -2663,6 +2388,17 @@ __global__ __launch_bounds__(PF_BS) void k_sweep_blc(const SweepChunk* tab_g, lo
             }
         }
     }
+}
+
+template <int NM, int P, bool BIASED>
+__global__ __launch_bounds__(PF_BS) void k_sweep_blc(const SweepChunk* tab_g, long long t) {
+    sweep_blc_body<NM, P, BIASED>(tab_g, t);
+}
+// the ledger and count roles of several chunks beside their extend launches (run_sweep_split): at most four haplotypes, no focused
+// sampling, and no dynamic LDS -- four workgroups to a compute unit (128 registers, 36.6 KB)
+template <bool EXACT>
+__global__ __launch_bounds__(PF_BS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_sweep_blc4(const SweepChunk* tab_g, long long t) {
+    sweep_blc_body<4, 1, false, EXACT>(tab_g, t);
 }
 
 // first step of a call: the seed of k_pipe_seed, and the chunk's window state
@@ -3299,10 +3035,11 @@ struct pf_handle {
                                   // bookkeeping / ledger / count launches on the counting stream, ordered by counters in memory instead of events
     hipStream_t stream2 = nullptr;
     bool sweep_handoff = false;   // (argument of sweep_table: the table it builds is for run_sweep_flags)
+    bool sweep_split2 = false;    // (argument of sweep_table: ... for run_sweep_split)
+    bool split_many = false;      // a step as two launches (run_sweep_split; not with PF_DEBUG_ONE_LAUNCH)
     unsigned long long* d_trace = nullptr;   // pf_set_wg_trace (leader of a pf_run_many call): four words per workgroup and step
     size_t trace_words = 0;
     int trace_t0 = 0, trace_n = 0, trace_stride = 0, trace_grid[3] = {0, 0, 0};
-    bool count_units = false;     // k_sweep / k_sweep_blc with one population: the counts by generation (count_units_body), ncw workgroups per step
     bool split_roles = false;     // PF_DEBUG_SPLIT_ROLES: one population too runs the extend role and the other roles as two launches on two streams
     bool pipe_mp = false;         // structured models on the row pipeline: extend launches on the filter stream, the other roles on the counting stream
     size_t smem_sweep_x = 0;
@@ -3537,6 +3274,9 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     h->use_k_pipe = (p->debug & PF_DEBUG_K_PIPE) != 0;
     h->no_spec_stage = (p->debug & PF_DEBUG_NO_SPEC_STAGE) != 0;
     h->split_roles = (p->debug & PF_DEBUG_SPLIT_ROLES) != 0;
+    // one population, at most four haplotypes, no focused sampling, no -arg: a step is two launches (run_sweep_split) unless the switch says one
+    h->split_many = !(p->debug & PF_DEBUG_ONE_LAUNCH) && P == 1 && n <= 4 && m->n_bias_heights == 0 && m->n_rate_segments == 0 && !(p->flags & 2) &&
+                    !(p->debug & (PF_DEBUG_SPLIT_ROLES | PF_DEBUG_FLAG_HANDOFF | PF_DEBUG_K_PIPE | PF_DEBUG_TWO_LAUNCH | PF_DEBUG_NO_FUSE));
     // (several chunks per GPU -- the caller set count_wgs -- : on the rows that do not resample, nine in ten, these workgroups find nothing to do and
     // leave after 2 us of a slot each; with 32 instead of 192 eight chunks gain 3 %, one chunk is the same either way: 28.7 us per row)
     h->ledger_wgs = p->count_wgs > 0 ? 32 : std::max(16, std::min(PF_LEDGER_BLOCKS, 192));
@@ -3727,20 +3467,14 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     }
     // accumulators of the count workgroups per epoch (measured: four times as many count workgroups per epoch in the row
     // pipeline made a row 15 % slower -- the launch then holds 5 000 workgroups of 30 KB LDS each, four rounds of the chip)
-    // per-epoch accumulators: one per count workgroup of a column (count_body) or of a step (count_units_body, an experiment of
-    // round 4: by default four per 256 particles -- a unit is 256 tasks of one generation for four of its epochs)
+    // per-epoch accumulators: one per count workgroup of a column (count_body)
     A.nbx = h->nblocks;
-    if (P == 1 && (p->debug & PF_DEBUG_COUNT_UNITS) && (p->debug & PF_DEBUG_SPLIT_ROLES))
-        A.nbx = p->count_wgs > 0 ? std::max(p->count_wgs, 1) : std::max(4 * h->nblocks, 16);
-    A.cu_ec = ((p->debug >> 16) & 15) ? ((p->debug >> 16) & 15) : 4;       // (bits 16-19 of debug: tuning experiments)
     // the row pipeline spreads an epoch's count tasks (the ancestor runs of the generations in its window: for the old epochs,
     // whose lag is a few rows, nearly one per particle) over this many workgroups; fewer is slower (C3 shape, one chunk: 40
     // workgroups 32.9 us per row, 16: 38.7, 8: 53.7, 4: 91.4, 2: 168 -- profiles/round3/count_wgs.md)
-    h->count_units = P == 1 && (p->debug & PF_DEBUG_COUNT_UNITS) && (p->debug & PF_DEBUG_SPLIT_ROLES) && !h->use_k_pipe && !(p->flags & 2);
-    if (h->count_units && h->pipe) h->ncw = A.nbx;     // workgroups per step
-    else h->ncw = p->count_wgs > 0 ? std::min<int>(p->count_wgs, h->nblocks) : h->nblocks;
+    h->ncw = p->count_wgs > 0 ? std::min<int>(p->count_wgs, h->nblocks) : h->nblocks;
     // (the queue has one kernel instance so far: one population, at most four haplotypes, no focused sampling, no -arg, single launch per step)
-    h->workers = (h->pipe && !h->use_k_pipe && !h->count_units && P == 1 && n <= 4 && !(m->n_bias_heights > 0 || m->n_rate_segments > 0) && !(p->flags & 2) &&
+    h->workers = (h->pipe && !h->use_k_pipe && P == 1 && n <= 4 && !(m->n_bias_heights > 0 || m->n_rate_segments > 0) && !(p->flags & 2) &&
                   !(p->debug & (PF_DEBUG_SPLIT_ROLES | PF_DEBUG_FLAG_HANDOFF))) ? std::max(0, std::min(p->count_workers, 4096)) : 0;
     {
         // count workgroups per epoch column of the row pipeline: the tasks of an epoch are the live ancestors of the generations in its
@@ -4309,7 +4043,7 @@ static void launch_sweep(pf_handle* h, const dim3& grid, long long t) {
 static bool sweep_compatible(const pf_handle* a, const pf_handle* b) {
     const bool ba = a->A.n_bias > 0 || a->A.g_K > 0, bb = b->A.n_bias > 0 || b->A.g_K > 0;
     return a->device == b->device && a->Np == b->Np && a->n == b->n && a->E == b->E && a->P == b->P && ba == bb &&
-           a->A.rec_trees == b->A.rec_trees && a->ncw == b->ncw && a->workers == b->workers && a->ledger_wgs == b->ledger_wgs && a->cw_off == b->cw_off && a->count_units == b->count_units && a->smem_pipe == b->smem_pipe && a->no_count == b->no_count &&
+           a->A.rec_trees == b->A.rec_trees && a->ncw == b->ncw && a->workers == b->workers && a->ledger_wgs == b->ledger_wgs && a->split_many == b->split_many && a->cw_off == b->cw_off && a->smem_pipe == b->smem_pipe && a->no_count == b->no_count &&
            (a->A.dt_tab != nullptr) == (b->A.dt_tab != nullptr);
 }
 
@@ -4343,11 +4077,11 @@ static long long sweep_table(pf_handle* const* hs, int nh, long long s_begin, lo
         ch.nblk = g->nblocks;
         ch.nT = (g->A.dt_tab && g->P == 1) ? g->nblocks : 0;
         ch.split = (g->P == 1 && g->split_roles && !g->A.rec_trees) ? 1 : 0;
-        ch.units = g->count_units ? 1 : 0;
-        ch.workers = g->count_units ? 0 : g->workers;
+        ch.workers = g->workers;
         ch.handoff = h->sweep_handoff ? 1 : 0;
         ch.xt_wgs = h->sweep_handoff ? g->nblocks + (ch.nT > 0 ? 1 + ch.nT : 0) : 0;
         if (h->sweep_handoff) ch.split = 1;
+        if (h->sweep_split2) ch.split = 2;
         ch.trace = h->d_trace; ch.trace_t0 = h->trace_t0; ch.trace_n = h->d_trace ? h->trace_n : 0; ch.trace_stride = h->trace_stride;
         if (last >= s_begin) steps = std::max(steps, last - s_begin + 3);
     }
@@ -4379,7 +4113,7 @@ static int run_sweep(pf_handle* const* hs, int nh, long long s_begin, long long 
     if (h->trace_n > 0 && !h->d_trace) {
         // pf_set_wg_trace: room for the largest grid a step of these chunks can have
         const int nT = (h->A.dt_tab && h->P == 1) ? nb : 0;
-        h->trace_stride = nh * (nb + 1 + nT + nL_full + (h->count_units ? h->ncw : h->cw_off[E]));
+        h->trace_stride = nh * (nb + 1 + nT + nL_full + h->cw_off[E]);
         h->trace_words = (size_t)h->trace_n * (size_t)h->trace_stride * 4;
         if (hipMalloc((void**)&h->d_trace, h->trace_words * 8) != hipSuccess) { h->d_trace = nullptr; g_err = "hipMalloc of the workgroup trace failed"; return -1; }
         hipMemsetAsync(h->d_trace, 0, h->trace_words * 8, h->stream);
@@ -4397,7 +4131,7 @@ static int run_sweep(pf_handle* const* hs, int nh, long long s_begin, long long 
         int columns = 0;
         for (int k = 0; k < nh; ++k)
             if (s >= s_begin + 2 && s - 2 <= h->h_sweep[k].s_last && !hs[k]->no_count) columns = std::max(columns, E - W2[k].first);
-        const int ncount = h->count_units ? (columns > 0 ? h->ncw : 0) : h->cw_off[columns];
+        const int ncount = h->cw_off[columns];
         bool any_lc = false;
         for (int k = 0; k < nh; ++k) any_lc = any_lc || (s >= s_begin + 2 && s - 2 <= h->h_sweep[k].s_last && !hs[k]->no_count);
         const unsigned per_chunk = (unsigned)(nb + 1 + h->h_sweep[0].nT + (h->h_sweep[0].workers > 0 ? (any_lc ? h->h_sweep[0].workers : 0) : nL_full + ncount));
@@ -4430,6 +4164,94 @@ static int run_sweep(pf_handle* const* hs, int nh, long long s_begin, long long 
         const long long last = h->h_sweep[k].s_last;
         if (last >= s_begin) g->seg_done = last + 1;
         if (k > 0) {                                            // the chunk's own stream continues after the sweep
+            hipEvent_t ev = next_sync_event(h);
+            hipEventRecord(ev, h->stream);
+            hipStreamWaitEvent(g->stream, ev, 0);
+        }
+    }
+    return 0;
+}
+
+// One or several chunks in lockstep as TWO launches per step (the default for one population, at most four haplotypes, no focused sampling;
+// PF_DEBUG_ONE_LAUNCH = run_sweep): the extend, bookkeeping and draw roles of all chunks
+// (k_sweep4, one launch after the other on the leader's stream: the chain of dependent loads that is the critical path of a step) and
+// their ledger and count roles (k_sweep_blc, on the counting stream, behind the extend launch of the step before by its completion
+// signal and paced by the sixteen-slot ring as in run_sweep_mp).  The second launch needs no dynamic LDS -- that is the bookkeeping
+// role's -- and fewer registers than the extend role: four of its workgroups share a compute unit where the single launch has room for
+// three, and its tail no longer holds up the next row's extend role.  Same bits as run_sweep.
+static int run_sweep_split(pf_handle* const* hs, int nh, long long s_begin, long long s_end) {
+    pf_handle* h = hs[0];
+    if (s_begin >= s_end) return 0;
+    const int nb = h->nblocks, E = h->E;
+    const int nL_full = nb + h->ledger_wgs;
+    for (int k = 0; k < nh; ++k) {
+        pf_handle* g = hs[k];
+        if (g->ev_cnt) { hipStreamWaitEvent(h->stream, g->ev_cnt, 0); g->ev_cnt = nullptr; }
+        if (k > 0) {
+            hipEvent_t ev = next_sync_event(g);
+            hipEventRecord(ev, g->stream);
+            hipStreamWaitEvent(h->stream, ev, 0);
+        }
+    }
+    if (h->ev_x.empty()) {
+        std::vector<hipEvent_t> ev(32, nullptr);
+        bool ok = true;
+        for (auto& e : ev) if (ok && hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) { e = nullptr; ok = false; }
+        if (!ok) { for (auto e : ev) if (e) hipEventDestroy(e); g_err = "hipEventCreate failed"; return -1; }
+        h->ev_x.assign(ev.begin(), ev.begin() + 16); h->ev_blc.assign(ev.begin() + 16, ev.end());
+    }
+    bool failed = false;
+    h->sweep_split2 = true;
+    const long long steps = sweep_table(hs, nh, s_begin, s_end, nL_full, &failed);
+    h->sweep_split2 = false;
+    if (failed) return -1;
+    if (steps == 0) return 0;
+    hipEvent_t seeded = next_sync_event(h);
+    hipEventRecord(seeded, h->stream);
+    const int nT = h->h_sweep[0].nT;
+    const dim3 gx((unsigned)(nb + 1 + nT), (unsigned)nh), blk(PF_BS);
+    std::vector<Windows> W1((size_t)nh), W2((size_t)nh);
+    for (int k = 0; k < nh; ++k) { W1[k] = no_windows(hs[k]); W2[k] = W1[k]; }
+    for (long long t = 0; t < steps; ++t) {
+        const long long s = s_begin + t;
+        static_assert(PF_RING == 16, "the wait schedule below is written for sixteen ring slots");
+        if (t >= 8 && (t & 7) == 0) hipStreamWaitEvent(h->stream, h->ev_blc[(size_t)((t - 7) & 15)], 0);      // ring slot reuse, as in run_sweep_mp
+        {
+            Timed tm(h, 0, timing_on(h, s));
+            hipEvent_t xdone = h->ev_x[(size_t)(t & 15)];
+            if (h->n == 4) hipExtLaunchKernelGGL((k_sweep4<true, false>), gx, blk, h->smem_pipe, h->stream, nullptr, xdone, 0, h->d_sweep, t, nb);
+            else hipExtLaunchKernelGGL((k_sweep4<false, false>), gx, blk, h->smem_pipe, h->stream, nullptr, xdone, 0, h->d_sweep, t, nb);
+        }
+        if (check_launch("k_sweep4 (extend, bookkeeping and draw roles)")) return -1;
+        hipStreamWaitEvent(h->cstream, t >= 1 ? h->ev_x[(size_t)((t - 1) & 15)] : seeded, 0);
+        int columns = 0;
+        for (int k = 0; k < nh; ++k)
+            if (s >= s_begin + 2 && s - 2 <= h->h_sweep[k].s_last && !hs[k]->no_count) columns = std::max(columns, E - W2[k].first);
+        const dim3 grid((unsigned)(1 + nL_full + h->cw_off[columns]), (unsigned)nh);
+        if (h->n == 4) hipExtLaunchKernelGGL((k_sweep_blc4<true>), grid, blk, 0, h->cstream, nullptr, h->ev_blc[(size_t)(t & 15)], 0, h->d_sweep, t);
+        else hipExtLaunchKernelGGL((k_sweep_blc4<false>), grid, blk, 0, h->cstream, nullptr, h->ev_blc[(size_t)(t & 15)], 0, h->d_sweep, t);
+        if (check_launch("k_sweep_blc (ledger and count roles)")) return -1;
+        if ((t & 1023) == 1023) trim_spans(h);
+        for (int k = 0; k < nh; ++k) {
+            pf_handle* g = hs[k];
+            W2[k] = W1[k];
+            if (s <= h->h_sweep[k].s_last) {
+                W1[k] = host_windows(g, seg_pos(g, s), false);
+                g->step_windows = W1[k];
+                if (W1[k].first < E && !g->no_count) g->fin_pending = true;
+            } else {
+                W1[k] = no_windows(g);
+            }
+        }
+    }
+    h->k_launches[0] -= 2;                                      // flush steps are not rows
+    // what follows on any chunk's stream waits for the last launch of the other roles
+    hipStreamWaitEvent(h->stream, h->ev_blc[(size_t)((steps - 1) & 15)], 0);
+    for (int k = 0; k < nh; ++k) {
+        pf_handle* g = hs[k];
+        const long long last = h->h_sweep[k].s_last;
+        if (last >= s_begin) g->seg_done = last + 1;
+        if (k > 0) {
             hipEvent_t ev = next_sync_event(h);
             hipEventRecord(ev, h->stream);
             hipStreamWaitEvent(g->stream, ev, 0);
@@ -4498,7 +4320,7 @@ static int run_sweep_mp(pf_handle* h, long long s_begin, long long s_end) {
         if (check_launch("k_sweep (extend role)")) return -1;
         hipStreamWaitEvent(h->cstream, t >= 1 ? h->ev_x[(size_t)((t - 1) & 15)] : seeded, 0);
         const int columns = (s >= s_begin + 2 && s - 2 <= last && !h->no_count) ? E - W2.first : 0;
-        const int ncount = h->count_units ? (columns > 0 ? h->ncw : 0) : h->cw_off[columns];
+        const int ncount = h->cw_off[columns];
         const dim3 grid((unsigned)(1 + (h->h_sweep[0].workers > 0 ? ((s >= s_begin + 2 && s - 2 <= last && !h->no_count) ? h->h_sweep[0].workers : 0) : nL_full + ncount)), 1u), blk(PF_BS);
         hipEvent_t done = h->ev_blc[(size_t)(t & 15)];
 #define PF_LAUNCH_BLC(NMV, PV, BV) hipExtLaunchKernelGGL((k_sweep_blc<NMV, PV, BV>), grid, blk, h->smem_pipe, h->cstream, nullptr, done, 0, h->d_sweep, t)
@@ -4624,6 +4446,7 @@ int pf_run_many(pf_handle* const* handles, int32_t n_handles, int64_t s_begin, i
     pf_handle* h = handles[0];
     HIPCHK(hipSetDevice(h->device));
     if (s_begin < 0) { g_err = "segment range out of bounds"; return -1; }        // a chunk with fewer rows sits the call out
+    if (h->split_many && !h->A.rec_trees && h->workers == 0) return run_sweep_split(handles, n_handles, s_begin, s_end);
     return run_sweep(handles, n_handles, s_begin, s_end);
 }
 
@@ -4636,6 +4459,7 @@ int pf_run(pf_handle* h, int64_t s_begin, int64_t s_end) {
         if (h->flag_handoff) return run_sweep_flags(h, s_begin, s_end);
         if (h->split_roles && !h->A.rec_trees) return run_sweep_mp(h, s_begin, s_end);
         pf_handle* one[1] = {h};
+        if (h->split_many && !h->A.rec_trees && h->workers == 0) return run_sweep_split(one, 1, s_begin, s_end);
         return run_sweep(one, 1, s_begin, s_end);
     }
     if (h->pipe_mp && h->A.apf == 0 && !h->force_lds && !h->no_fuse) return run_sweep_mp(h, s_begin, s_end);

@@ -182,9 +182,8 @@ struct PipeLaunch {
     int lc_slot;           // ring slot of the row whose ledger upkeep and counts are due (-1: none)
     int live_slot;         // newest complete slot of the per-slot record counters (ring-overwrite check)
     int nL;                // ledger workgroups
-    int ncw;               // count workgroups per epoch -- or, with `units`, of the step
+    int ncw;               // count workgroups per epoch
     int nT;                // workgroups that keep up the draw table (k_sweep only)
-    int units;             // the counts are dealt out by generation (count_units_body) instead of one column per epoch
     int ahead;             // as PipeRow::ahead: the rings need PF_RING entries of headroom
     int workers;           // > 0: the ledger and count work of the step is dealt out among this many workgroups (Ctrl::wq)
 };
@@ -201,7 +200,6 @@ struct SweepChunk {
     int nblk;                      // particle blocks of 256
     int nT;                        // draw-table workgroups per step (0: no table)
     int split;                     // the extend role (with the draw role) and the other roles are separate launches (PF_DEBUG_SPLIT_ROLES)
-    int units;                     // count workgroups take units of one generation for all its epochs (ncw = workgroups per step)
     int handoff;                   // launches hand over through Ctrl::xt_done / blc_step instead of through kernel boundaries (run_sweep_flags)
     int xt_wgs;                    // workgroups of an extend / draw launch (what a slot of xt_done grows by per step)
     unsigned long long* trace;     // pf_set_wg_trace: four words per workgroup of steps [trace_t0, trace_t0 + trace_n) (k_sweep4t only)
@@ -274,7 +272,6 @@ __device__ __forceinline__ bool sweep_plan(SweepChunkC& ch, long long s, int nb,
     PL.live_slot = (int)((s - 1) & (PF_RING - 1));
     PL.nL = PL.lc_slot >= 0 ? ch.nL_full : 0;
     PL.ncw = ch.ncw;
-    PL.units = ch.units;
     PL.workers = ch.workers;
     return true;
 }

@@ -229,7 +229,6 @@ struct KArgs {
     double* totals;                // [6][E]
     double* partial;               // [E][nbx][6]
     int nbx;
-    int cu_ec;                     // count_units_body: epochs of a generation's mask per unit
     const int* cw_off;             // row pipeline: [E + 1] first count workgroup of the j-th column, columns in the order oldest epoch first
                                    // (the old epochs' windows hold nearly every particle, the young ones' a few ancestors: their columns
                                    // are given fewer workgroups); null: PipeLaunch::ncw workgroups for every column

@@ -46,15 +46,15 @@ def test_chunk_statistics_do_not_depend_on_the_ranks(hiplib, tmp_path):
 
 
 def test_six_chunks_on_a_device_take_the_narrow_count_columns(hiplib, tmp_path):
-    """With six or more chunks per device the host asks for 24 count workgroups per epoch column (pf_params.count_wgs; the sums are
-    grouped by workgroup): the same bytes as asking for them with -count_wgs, and the same statistics to rounding as the wide
-    columns give.  A width pinned with -count_wgs gives the same bytes for any number of ranks."""
+    """With six or more chunks per device the host sets pf_params.count_wgs (one per 256 particles: the library then tapers the columns of
+    the young epochs; the sums are grouped by workgroup): the same bytes as asking for that with -count_wgs, and the same statistics to
+    rounding as other widths give.  A width pinned with -count_wgs gives the same bytes for any number of ranks."""
     auto, _ = _run(tmp_path, "auto", ["-chunks", "6", "-ranks", "1"])
-    pinned, _ = _run(tmp_path, "pin", ["-chunks", "6", "-ranks", "1", "-count_wgs", "24"])
+    pinned, _ = _run(tmp_path, "pin", ["-chunks", "6", "-ranks", "1", "-count_wgs", "2"])
     assert auto == pinned
-    spread, _ = _run(tmp_path, "spread", ["-chunks", "6", "-ranks", "3", "-reduce", "host", "-count_wgs", "24"])
+    spread, _ = _run(tmp_path, "spread", ["-chunks", "6", "-ranks", "3", "-reduce", "host", "-count_wgs", "2"])
     assert spread == pinned
-    wide = _rows(_run(tmp_path, "wide", ["-chunks", "6", "-ranks", "1", "-count_wgs", "2"])[0])
+    wide = _rows(_run(tmp_path, "wide", ["-chunks", "6", "-ranks", "1", "-count_wgs", "1"])[0])
     for key, (count, opp) in _rows(auto).items():
         assert count == pytest.approx(wide[key][0], rel=1e-6, abs=1e-9) and opp == pytest.approx(wide[key][1], rel=1e-6, abs=1e-9), key
 

@@ -28,7 +28,6 @@ def _run_alone(model, segs, Np, seed, debug, step=None, **kw):
     return f
 
 
-COUNT_UNITS = 2048 + 64   # PF_DEBUG_COUNT_UNITS with PF_DEBUG_SPLIT_ROLES: the counts dealt out by generation (round-4 experiment)
 
 
 def _same(a, b, counts_rtol=None):
@@ -62,12 +61,6 @@ def test_sweep_equals_k_pipe_and_oracle(oracle, hiplib, n, Np, biased):
     a = _run_alone(model, segs, Np, 5, 0, local_recomb=True)               # k_sweep, one chunk
     b = _run_alone(model, segs, Np, 5, K_PIPE, local_recomb=True)          # k_pipe
     _same(a, b)
-    if not biased:
-        c = _run_alone(model, segs, Np, 5, COUNT_UNITS, local_recomb=True)     # the counts by generation: the same terms, grouped differently
-        _same(c, a, counts_rtol=1e-10)
-        lc = c.local_recomb()
-        for k in lc:
-            np.testing.assert_allclose(lc[k], a.local_recomb()[k], rtol=1e-9, atol=1e-9 * max(1e-300, float(np.abs(lc[k]).max())))
     la, lb = a.local_recomb(), b.local_recomb()
     for k in la:                                                            # atomics: same terms, any order
         np.testing.assert_allclose(la[k], lb[k], rtol=1e-9, atol=1e-9 * max(1e-300, float(np.abs(lb[k]).max())))
@@ -110,7 +103,7 @@ def test_draw_table_changes_nothing(oracle, hiplib, n, biased, mu, rho, step):
         np.testing.assert_allclose(cg[k], co[k], rtol=1e-9, atol=1e-300)
 
 
-@pytest.mark.parametrize("debug", [64, 64 + 1024, 512, 256, 8192], ids=["split-roles", "split-roles-cu-masks", "count-young-first", "four-way-search", "flag-handoff"])
+@pytest.mark.parametrize("debug", [64, 64 + 1024, 512, 256, 8192, 1 << 23], ids=["split-roles", "split-roles-cu-masks", "count-young-first", "four-way-search", "flag-handoff", "one-launch"])
 def test_launch_arrangements_change_nothing(hiplib, debug):
     """The A/B switches of the row pipeline -- the extend role and the other roles as two launches on two streams (with the
     draw role riding with the extend launch), the two streams on disjoint compute units, the count columns in ascending
@@ -118,7 +111,7 @@ def test_launch_arrangements_change_nothing(hiplib, debug):
     model = cases.make_model(n=4, E=12, L=1.5e5)
     segs = cases.make_segments(model, seed=9, max_seg_len=3500)
     a = _run_alone(model, segs, 1100, 4, 0)
-    b = _run_alone(model, segs, 1100, 4, debug, step=(41 if debug in (64, 8192) else None))
+    b = _run_alone(model, segs, 1100, 4, debug, step=(41 if debug in (64, 8192, 1 << 23) else None))
     _same(a, b)
 
 
@@ -184,6 +177,33 @@ def test_count_workers_change_nothing(hiplib, workers, count_wgs):
             ref = g.local_recomb()[key]
             np.testing.assert_allclose(f.local_recomb()[key], ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max())
     assert sum(int(f.trace()["resampled"].sum()) for f in many) > 10        # the ledger items were there to be taken
+
+
+def test_chunks_as_two_launches_per_step_equal_their_own_single_launch_runs(hiplib):
+    """The default for the headline shape: the extend, bookkeeping and draw roles of all chunks as one launch per step, their ledger and
+    count roles as a second launch on the counting stream (four workgroups to a compute unit), paced by the sixteen-slot ring.  Every
+    chunk is bit-identical to its own run with everything in ONE launch (PF_DEBUG_ONE_LAUNCH), in several calls, with chunks that end
+    at different rows."""
+    model = cases.make_model(n=4, E=12, L=2e5)
+    chunks = []
+    for k in range(4):
+        m = dict(model, loci_length=float(model["loci_length"] * (0.55 + 0.15 * k)))
+        chunks.append((m, cases.make_segments(m, seed=40 + k, max_seg_len=4000)))
+    alone = [_run_alone(m, sg, 1100, 9 + k, 1 << 23, count_wgs=3, local_recomb=True) for k, (m, sg) in enumerate(chunks)]
+    many = []
+    for k, (m, sg) in enumerate(chunks):
+        f = ParticleFilter(m, 1100, seed=9 + k, count_wgs=3, local_recomb=True)
+        f.init_prior(0.0); f.load_segments(sg)
+        many.append(f)
+    nmax = max(f.n_segs for f in many)
+    for s0 in range(0, nmax, 173):
+        ParticleFilter.run_many(many, s0, min(nmax, s0 + 173))
+    for f, g in zip(many, alone):
+        f.finish()
+        _same(f, g)
+        for key in ("opp_diff", "counts"):
+            ref = g.local_recomb()[key]
+            np.testing.assert_allclose(f.local_recomb()[key], ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max())
 
 
 def test_run_many_rejects_chunks_of_different_shape(hiplib):
