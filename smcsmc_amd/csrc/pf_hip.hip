@@ -2175,24 +2175,30 @@ __device__ __forceinline__ void pipe_count_item(const KA& A, const PipeLaunch& P
     count_body<NM, P, EXACT>(A, Q, e, r.wa[e], r.wb[e], cbx, cnb);
 }
 
-template <int NM, bool BIASED, bool EXACT, bool TREES, int P = 1, bool BLC = false, bool QUEUE = false, class KA>
+template <int NM, bool BIASED, bool EXACT, bool TREES, int P = 1, bool BLC = false, bool QUEUE = false, bool LEAN = false, class KA>
 __device__ __forceinline__ void pipe_roles(const KA& A, long long s, const PipeLaunch& PL, const Windows& Wb) {
     const int bx = pf_bx();
     const int nb = PL.nb;
-    if (bx < nb) {
-        if constexpr (P == 1) { if (PL.row.extend || PL.row.complete) extend_reg_body<NM, BIASED, EXACT, TREES, true>(A, s, 0, PL.row); }
-        return;
-    }
-    if (bx == nb) {
-        if (PL.b_slot < 0 || PL.nL == -2) return;          // nL = -2: the extend launch of a split step (-3: one that keeps the bookkeeping)
-        extern __shared__ double smem[];
-        PipeLds q = pipe_carve(smem + (2 * PF_EPAD + A.E + 2 * PF_BIAS_MAX + 3), A.nc);
-        pipe_bookkeeping<BIASED>(A, q, PL, Wb);
-        return;
-    }
-    if (bx - (nb + 1) < PL.nT) {
-        if constexpr (P == 1) draw_role(A, bx - (nb + 1), PL.nT, PL.row.draws - 1);
-        return;
+    // (LEAN: the launch of the ledger and count roles alone -- run_sweep_split -- is compiled without the other three: their registers and LDS
+    // are what would keep it from four workgroups per compute unit)
+    if constexpr (!LEAN) {
+        if (bx < nb) {
+            if constexpr (P == 1) { if (PL.row.extend || PL.row.complete) extend_reg_body<NM, BIASED, EXACT, TREES, true>(A, s, 0, PL.row); }
+            return;
+        }
+        if (bx == nb) {
+            if (PL.b_slot < 0 || PL.nL == -2) return;          // nL = -2: the extend launch of a split step (-3: one that keeps the bookkeeping)
+            extern __shared__ double smem[];
+            PipeLds q = pipe_carve(smem + (2 * PF_EPAD + A.E + 2 * PF_BIAS_MAX + 3), A.nc);
+            pipe_bookkeeping<BIASED>(A, q, PL, Wb);
+            return;
+        }
+        if (bx - (nb + 1) < PL.nT) {
+            if constexpr (P == 1) draw_role(A, bx - (nb + 1), PL.nT, PL.row.draws - 1);
+            return;
+        }
+    } else {
+        if (bx <= nb) return;
     }
     if (PL.lc_slot < 0 || PL.nL < -1) return;
     const Ctrl* c = A.ctrl;
@@ -2360,7 +2366,7 @@ __global__ __launch_bounds__(PF_BS) __attribute__((amdgpu_waves_per_eu(3, 3))) v
 // stream beside their extend launch (k_sweep_xmp, pf_mp.hip).  The extend workgroups of those models carry their trees'
 // migration events in LDS (61 KB per 64 particles at the default capacity); in one launch every count workgroup would be
 // given the same allocation and one would fit a CU.
-template <int NM, int P, bool BIASED, bool EXACT = false>
+template <int NM, int P, bool BIASED, bool EXACT = false, bool LEAN = false>
 __device__ __forceinline__ void sweep_blc_body(const SweepChunk* tab_g, long long t) {
     SweepChunkC* tab = (SweepChunkC*)tab_g;
     SweepChunkC& ch = tab[pf_chunk()];
@@ -2373,7 +2379,7 @@ __device__ __forceinline__ void sweep_blc_body(const SweepChunk* tab_g, long lon
         PL.nT = 0;                                         // the draw role rides with the extend launch
         if (ch.split == 2) PL.b_slot = -1;                 // ... and so does the bookkeeping (run_sweep_split)
         if (pf_bx() == 0 && PL.b_slot >= 0) sweep_windows(A, c, PL.b_pos, W);
-        pipe_roles<NM, BIASED, EXACT, false, P, true>(A, s, PL, W);
+        pipe_roles<NM, BIASED, EXACT, false, P, true, false, LEAN>(A, s, PL, W);
     }
     if (ch.handoff) {
         // run_sweep_flags: the extend launch of step t + 14 overwrites ring slots this launch read; it polls Ctrl::blc_step, which the
@@ -2398,7 +2404,7 @@ __global__ __launch_bounds__(PF_BS) void k_sweep_blc(const SweepChunk* tab_g, lo
 // sampling, and no dynamic LDS -- four workgroups to a compute unit (128 registers, 36.6 KB)
 template <bool EXACT>
 __global__ __launch_bounds__(PF_BS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_sweep_blc4(const SweepChunk* tab_g, long long t) {
-    sweep_blc_body<4, 1, false, EXACT>(tab_g, t);
+    sweep_blc_body<4, 1, false, EXACT, true>(tab_g, t);
 }
 
 // first step of a call: the seed of k_pipe_seed, and the chunk's window state
