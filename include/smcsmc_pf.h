@@ -217,8 +217,9 @@ int pf_resample(pf_handle* h, int64_t s);
 /* the hot loop over segments [s_begin, s_end): update -> count -> resample per segment */
 int pf_run(pf_handle* h, int64_t s_begin, int64_t s_end);
 /* the same loop for several chunks at once: rows [s_begin, s_end) of n_handles independent filters (one per chromosome
- * chunk; same device, particle count, haplotypes, epochs and options) step in lockstep through one kernel launch per row
- * whose grid covers all of them.  The reference starts one process per chunk, all at once (smcsmc/model.py:1094-1098);
+ * chunk; same device, particle count, haplotypes, epochs and options) step in lockstep through the same kernel launches, whose
+ * grids cover all of them (two per row for at most four haplotypes without focused sampling -- the extend roles; the ledger and
+ * count roles on the counting stream -- one otherwise).  The reference starts one process per chunk, all at once (smcsmc/model.py:1094-1098);
  * every chunk's results are bit-identical to its own pf_run.  A chunk that runs out of rows simply stops. */
 int pf_run_many(pf_handle* const* handles, int32_t n_handles, int64_t s_begin, int64_t s_end);
 /* 1 when pf_run_many would take these handles, 0 when the caller has to run them one after the other with pf_run (the row
@@ -265,7 +266,8 @@ int pf_probe_handoff(int32_t mode, int32_t rows, int32_t nw, int64_t spin_ticks,
  * for steps [first_step, first_step + n_steps) of the following pf_run / pf_run_many calls led by `h`.  pf_get_wg_trace copies four
  * 64-bit words per workgroup slot and traced step -- start, end (100 MHz clock; 0 0: the step's grid did not use the slot),
  * HW_ID | XCC_ID << 32, index within the chunk | chunk << 32 -- returns the number of words there are and fills
- * info = {steps, slots per step}.  n_steps = 0 switches the trace off. */
+ * info = {steps, slots per step}.  n_steps = 0 switches the trace off.  Only the form in which every role of a step is ONE launch is
+ * traced (create the handles with PF_DEBUG_ONE_LAUNCH). */
 int pf_set_wg_trace(pf_handle* h, int64_t first_step, int32_t n_steps);
 int64_t pf_get_wg_trace(pf_handle* h, uint64_t* out, int64_t cap_words, int32_t* info);
 /* the delayed-factor store (adjustWeightsWithDelay, particle.hpp:185-209): factors applied ahead of their position because the
