@@ -2366,7 +2366,7 @@ __global__ __launch_bounds__(PF_BS) __attribute__((amdgpu_waves_per_eu(3, 3))) v
 // stream beside their extend launch (k_sweep_xmp, pf_mp.hip).  The extend workgroups of those models carry their trees'
 // migration events in LDS (61 KB per 64 particles at the default capacity); in one launch every count workgroup would be
 // given the same allocation and one would fit a CU.
-template <int NM, int P, bool BIASED, bool EXACT = false, bool LEAN = false>
+template <int NM, int P, bool BIASED, bool EXACT = false, bool LEAN = false, bool QUEUE = false>
 __device__ __forceinline__ void sweep_blc_body(const SweepChunk* tab_g, long long t) {
     SweepChunkC* tab = (SweepChunkC*)tab_g;
     SweepChunkC& ch = tab[pf_chunk()];
@@ -2379,7 +2379,7 @@ __device__ __forceinline__ void sweep_blc_body(const SweepChunk* tab_g, long lon
         PL.nT = 0;                                         // the draw role rides with the extend launch
         if (ch.split == 2) PL.b_slot = -1;                 // ... and so does the bookkeeping (run_sweep_split)
         if (pf_bx() == 0 && PL.b_slot >= 0) sweep_windows(A, c, PL.b_pos, W);
-        pipe_roles<NM, BIASED, EXACT, false, P, true, false, LEAN>(A, s, PL, W);
+        pipe_roles<NM, BIASED, EXACT, false, P, true, QUEUE, LEAN>(A, s, PL, W);
     }
     if (ch.handoff) {
         // run_sweep_flags: the extend launch of step t + 14 overwrites ring slots this launch read; it polls Ctrl::blc_step, which the
@@ -2405,6 +2405,11 @@ __global__ __launch_bounds__(PF_BS) void k_sweep_blc(const SweepChunk* tab_g, lo
 template <bool EXACT>
 __global__ __launch_bounds__(PF_BS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_sweep_blc4(const SweepChunk* tab_g, long long t) {
     sweep_blc_body<4, 1, false, EXACT, true>(tab_g, t);
+}
+// ... with the ledger and count items of a step taken off a queue by a fixed number of workgroups (pf_params.count_workers)
+template <bool EXACT>
+__global__ __launch_bounds__(PF_BS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_sweep_blc4q(const SweepChunk* tab_g, long long t) {
+    sweep_blc_body<4, 1, false, EXACT, true, true>(tab_g, t);
 }
 
 // first step of a call: the seed of k_pipe_seed, and the chunk's window state
@@ -4233,9 +4238,18 @@ static int run_sweep_split(pf_handle* const* hs, int nh, long long s_begin, long
         int columns = 0;
         for (int k = 0; k < nh; ++k)
             if (s >= s_begin + 2 && s - 2 <= h->h_sweep[k].s_last && !hs[k]->no_count) columns = std::max(columns, E - W2[k].first);
-        const dim3 grid((unsigned)(1 + nL_full + h->cw_off[columns]), (unsigned)nh);
-        if (h->n == 4) hipExtLaunchKernelGGL((k_sweep_blc4<true>), grid, blk, 0, h->cstream, nullptr, h->ev_blc[(size_t)(t & 15)], 0, h->d_sweep, t);
-        else hipExtLaunchKernelGGL((k_sweep_blc4<false>), grid, blk, 0, h->cstream, nullptr, h->ev_blc[(size_t)(t & 15)], 0, h->d_sweep, t);
+        bool any_lc = false;
+        for (int k = 0; k < nh; ++k) any_lc = any_lc || (s >= s_begin + 2 && s - 2 <= h->h_sweep[k].s_last && !hs[k]->no_count);
+        const int W = h->h_sweep[0].workers;
+        const dim3 grid((unsigned)(1 + (W > 0 ? (any_lc ? W : 0) : nL_full + h->cw_off[columns])), (unsigned)nh);
+        hipEvent_t bdone = h->ev_blc[(size_t)(t & 15)];
+        if (W > 0) {
+            if (h->n == 4) hipExtLaunchKernelGGL((k_sweep_blc4q<true>), grid, blk, 0, h->cstream, nullptr, bdone, 0, h->d_sweep, t);
+            else hipExtLaunchKernelGGL((k_sweep_blc4q<false>), grid, blk, 0, h->cstream, nullptr, bdone, 0, h->d_sweep, t);
+        } else {
+            if (h->n == 4) hipExtLaunchKernelGGL((k_sweep_blc4<true>), grid, blk, 0, h->cstream, nullptr, bdone, 0, h->d_sweep, t);
+            else hipExtLaunchKernelGGL((k_sweep_blc4<false>), grid, blk, 0, h->cstream, nullptr, bdone, 0, h->d_sweep, t);
+        }
         if (check_launch("k_sweep_blc (ledger and count roles)")) return -1;
         if ((t & 1023) == 1023) trim_spans(h);
         for (int k = 0; k < nh; ++k) {
@@ -4452,7 +4466,7 @@ int pf_run_many(pf_handle* const* handles, int32_t n_handles, int64_t s_begin, i
     pf_handle* h = handles[0];
     HIPCHK(hipSetDevice(h->device));
     if (s_begin < 0) { g_err = "segment range out of bounds"; return -1; }        // a chunk with fewer rows sits the call out
-    if (h->split_many && !h->A.rec_trees && h->workers == 0) return run_sweep_split(handles, n_handles, s_begin, s_end);
+    if (h->split_many && !h->A.rec_trees) return run_sweep_split(handles, n_handles, s_begin, s_end);
     return run_sweep(handles, n_handles, s_begin, s_end);
 }
 
@@ -4465,7 +4479,7 @@ int pf_run(pf_handle* h, int64_t s_begin, int64_t s_end) {
         if (h->flag_handoff) return run_sweep_flags(h, s_begin, s_end);
         if (h->split_roles && !h->A.rec_trees) return run_sweep_mp(h, s_begin, s_end);
         pf_handle* one[1] = {h};
-        if (h->split_many && !h->A.rec_trees && h->workers == 0) return run_sweep_split(one, 1, s_begin, s_end);
+        if (h->split_many && !h->A.rec_trees) return run_sweep_split(one, 1, s_begin, s_end);
         return run_sweep(one, 1, s_begin, s_end);
     }
     if (h->pipe_mp && h->A.apf == 0 && !h->force_lds && !h->no_fuse) return run_sweep_mp(h, s_begin, s_end);
