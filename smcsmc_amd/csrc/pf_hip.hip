@@ -3048,6 +3048,7 @@ struct pf_handle {
     bool sweep_handoff = false;   // (argument of sweep_table: the table it builds is for run_sweep_flags)
     bool sweep_split2 = false;    // (argument of sweep_table: ... for run_sweep_split)
     bool split_many = false;      // a step as two launches (run_sweep_split; not with PF_DEBUG_ONE_LAUNCH)
+    int split_batch = 0;          // ... the second launches enqueued in batches of this many steps behind one completion signal (0: chosen by the runner)
     unsigned long long* d_trace = nullptr;   // pf_set_wg_trace (leader of a pf_run_many call): four words per workgroup and step
     size_t trace_words = 0;
     int trace_t0 = 0, trace_n = 0, trace_stride = 0, trace_grid[3] = {0, 0, 0};
@@ -3285,6 +3286,7 @@ static pf_handle* create_impl(const pf_model* m, const pf_params* p, int device,
     h->use_k_pipe = (p->debug & PF_DEBUG_K_PIPE) != 0;
     h->no_spec_stage = (p->debug & PF_DEBUG_NO_SPEC_STAGE) != 0;
     h->split_roles = (p->debug & PF_DEBUG_SPLIT_ROLES) != 0;
+    h->split_batch = (p->debug >> 16) & 15;       // (bits 16-19 of debug: tuning experiments; 0 = four with several chunks, one with one)
     // one population, at most four haplotypes, no focused sampling, no -arg: a step is two launches (run_sweep_split) unless the switch says one
     h->split_many = !(p->debug & PF_DEBUG_ONE_LAUNCH) && P == 1 && n <= 4 && m->n_bias_heights == 0 && m->n_rate_segments == 0 && !(p->flags & 2) &&
                     !(p->debug & (PF_DEBUG_SPLIT_ROLES | PF_DEBUG_FLAG_HANDOFF | PF_DEBUG_K_PIPE | PF_DEBUG_TWO_LAUNCH | PF_DEBUG_NO_FUSE));
@@ -4223,34 +4225,52 @@ static int run_sweep_split(pf_handle* const* hs, int nh, long long s_begin, long
     const dim3 gx((unsigned)(nb + 1 + nT), (unsigned)nh), blk(PF_BS);
     std::vector<Windows> W1((size_t)nh), W2((size_t)nh);
     for (int k = 0; k < nh; ++k) { W1[k] = no_windows(hs[k]); W2[k] = W1[k]; }
+    // (at most four: the second launch of step t - 7 must be enqueued when step t waits for it.  Several chunks: eight 20 Mb chunks 1.205e5 ->
+    // 1.248e5 segments/s with two, 1.272e5 with four; one chunk is the same with any)
+    const long long batch = std::max(1, std::min(4, h->split_batch > 0 ? h->split_batch : (nh > 1 ? 4 : 1)));
+    std::vector<unsigned> pending_grid((size_t)batch, 1u);
+    hipStreamWaitEvent(h->cstream, seeded, 0);
     for (long long t = 0; t < steps; ++t) {
         const long long s = s_begin + t;
         static_assert(PF_RING == 16, "the wait schedule below is written for sixteen ring slots");
         if (t >= 8 && (t & 7) == 0) hipStreamWaitEvent(h->stream, h->ev_blc[(size_t)((t - 7) & 15)], 0);      // ring slot reuse, as in run_sweep_mp
+        // The second launches follow in batches of `batch` steps: only the last extend launch of a batch carries a completion signal, and the
+        // batch's second launches wait for that one (each needs the extend launch of the step before it: complete by then).
+        const bool batch_end = ((t + 1) % batch) == 0 || t == steps - 1;
         {
             Timed tm(h, 0, timing_on(h, s));
             hipEvent_t xdone = h->ev_x[(size_t)(t & 15)];
-            if (h->n == 4) hipExtLaunchKernelGGL((k_sweep4<true, false>), gx, blk, h->smem_pipe, h->stream, nullptr, xdone, 0, h->d_sweep, t, nb);
-            else hipExtLaunchKernelGGL((k_sweep4<false, false>), gx, blk, h->smem_pipe, h->stream, nullptr, xdone, 0, h->d_sweep, t, nb);
+            if (batch_end) {
+                if (h->n == 4) hipExtLaunchKernelGGL((k_sweep4<true, false>), gx, blk, h->smem_pipe, h->stream, nullptr, xdone, 0, h->d_sweep, t, nb);
+                else hipExtLaunchKernelGGL((k_sweep4<false, false>), gx, blk, h->smem_pipe, h->stream, nullptr, xdone, 0, h->d_sweep, t, nb);
+            } else {
+                if (h->n == 4) hipLaunchKernelGGL((k_sweep4<true, false>), gx, blk, h->smem_pipe, h->stream, h->d_sweep, t, nb);
+                else hipLaunchKernelGGL((k_sweep4<false, false>), gx, blk, h->smem_pipe, h->stream, h->d_sweep, t, nb);
+            }
         }
         if (check_launch("k_sweep4 (extend, bookkeeping and draw roles)")) return -1;
-        hipStreamWaitEvent(h->cstream, t >= 1 ? h->ev_x[(size_t)((t - 1) & 15)] : seeded, 0);
         int columns = 0;
         for (int k = 0; k < nh; ++k)
             if (s >= s_begin + 2 && s - 2 <= h->h_sweep[k].s_last && !hs[k]->no_count) columns = std::max(columns, E - W2[k].first);
         bool any_lc = false;
         for (int k = 0; k < nh; ++k) any_lc = any_lc || (s >= s_begin + 2 && s - 2 <= h->h_sweep[k].s_last && !hs[k]->no_count);
         const int W = h->h_sweep[0].workers;
-        const dim3 grid((unsigned)(1 + (W > 0 ? (any_lc ? W : 0) : nL_full + h->cw_off[columns])), (unsigned)nh);
-        hipEvent_t bdone = h->ev_blc[(size_t)(t & 15)];
-        if (W > 0) {
-            if (h->n == 4) hipExtLaunchKernelGGL((k_sweep_blc4q<true>), grid, blk, 0, h->cstream, nullptr, bdone, 0, h->d_sweep, t);
-            else hipExtLaunchKernelGGL((k_sweep_blc4q<false>), grid, blk, 0, h->cstream, nullptr, bdone, 0, h->d_sweep, t);
-        } else {
-            if (h->n == 4) hipExtLaunchKernelGGL((k_sweep_blc4<true>), grid, blk, 0, h->cstream, nullptr, bdone, 0, h->d_sweep, t);
-            else hipExtLaunchKernelGGL((k_sweep_blc4<false>), grid, blk, 0, h->cstream, nullptr, bdone, 0, h->d_sweep, t);
+        pending_grid[(size_t)(t % batch)] = (unsigned)(1 + (W > 0 ? (any_lc ? W : 0) : nL_full + h->cw_off[columns]));
+        if (batch_end) {
+            hipStreamWaitEvent(h->cstream, h->ev_x[(size_t)(t & 15)], 0);
+            for (long long u = t - (t % batch); u <= t; ++u) {
+                const dim3 grid(pending_grid[(size_t)(u % batch)], (unsigned)nh);
+                hipEvent_t bdone = h->ev_blc[(size_t)(u & 15)];
+                if (W > 0) {
+                    if (h->n == 4) hipExtLaunchKernelGGL((k_sweep_blc4q<true>), grid, blk, 0, h->cstream, nullptr, bdone, 0, h->d_sweep, u);
+                    else hipExtLaunchKernelGGL((k_sweep_blc4q<false>), grid, blk, 0, h->cstream, nullptr, bdone, 0, h->d_sweep, u);
+                } else {
+                    if (h->n == 4) hipExtLaunchKernelGGL((k_sweep_blc4<true>), grid, blk, 0, h->cstream, nullptr, bdone, 0, h->d_sweep, u);
+                    else hipExtLaunchKernelGGL((k_sweep_blc4<false>), grid, blk, 0, h->cstream, nullptr, bdone, 0, h->d_sweep, u);
+                }
+            }
+            if (check_launch("k_sweep_blc (ledger and count roles)")) return -1;
         }
-        if (check_launch("k_sweep_blc (ledger and count roles)")) return -1;
         if ((t & 1023) == 1023) trim_spans(h);
         for (int k = 0; k < nh; ++k) {
             pf_handle* g = hs[k];

@@ -103,7 +103,7 @@ def test_draw_table_changes_nothing(oracle, hiplib, n, biased, mu, rho, step):
         np.testing.assert_allclose(cg[k], co[k], rtol=1e-9, atol=1e-300)
 
 
-@pytest.mark.parametrize("debug", [64, 64 + 1024, 512, 256, 8192, 1 << 23], ids=["split-roles", "split-roles-cu-masks", "count-young-first", "four-way-search", "flag-handoff", "one-launch"])
+@pytest.mark.parametrize("debug", [64, 64 + 1024, 512, 256, 8192, 1 << 23, 4 << 16], ids=["split-roles", "split-roles-cu-masks", "count-young-first", "four-way-search", "flag-handoff", "one-launch", "second-launches-in-fours"])
 def test_launch_arrangements_change_nothing(hiplib, debug):
     """The A/B switches of the row pipeline -- the extend role and the other roles as two launches on two streams (with the
     draw role riding with the extend launch), the two streams on disjoint compute units, the count columns in ascending
@@ -111,7 +111,7 @@ def test_launch_arrangements_change_nothing(hiplib, debug):
     model = cases.make_model(n=4, E=12, L=1.5e5)
     segs = cases.make_segments(model, seed=9, max_seg_len=3500)
     a = _run_alone(model, segs, 1100, 4, 0)
-    b = _run_alone(model, segs, 1100, 4, debug, step=(41 if debug in (64, 8192, 1 << 23) else None))
+    b = _run_alone(model, segs, 1100, 4, debug, step=(41 if debug in (64, 8192, 1 << 23, 4 << 16) else None))
     _same(a, b)
 
 
