@@ -11,8 +11,9 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JS
     smcsmc/model.py:563-662), then one RCCL all-gather of the packed CountModel buffers summed
     in rank order (deterministic), the functional equivalent of smcsmc/model.py:1176-1184.
   * value = (segments processed by all ranks over K steps) / (max over ranks of the timed wall time).
-Extra objects: "roofline" for the dominant kernel (k_extend) and "cpu_baseline" (the CPU oracle,
-kind "port": the reference binary cannot be built here) timed on a bounded sample on rank 0.
+Extra objects: "roofline" for the dominant kernel (the row kernel of the extend role: k_sweep4 for the default workload, one launch per
+row on the filter stream; the ledger and count roles run beside it as k_sweep_blc4 on the counting stream) and "cpu_baseline" (the CPU
+oracle, kind "port": the reference binary cannot be built here) timed on a bounded sample on rank 0.
 """
 import argparse
 import json
