@@ -400,7 +400,7 @@ def main():
                        "segments_per_chunk": n_segments, "nsam": args.nsam, "np": args.np,
                        "sequence_length": args.length, "epochs": args.epochs, "event_log_records_per_particle": args.log_cap or 16384,
                        "count_workgroups_per_epoch": ("one per particle block, tapered for the young epochs" if (args.chunks_per_gpu >= 6 and args.count_wgs == 0) else (args.count_wgs if args.count_wgs > 0 else "one per particle block")),
-                       "parallelism": "%d chunk(s) per gpu%s x %d gpu(s)" % (C, (", one launch per row for all of them" if many else ", one host thread and stream each") if C > 1 else "", world), "log_likelihood_sum": logl_sum},
+                       "parallelism": "%d chunk(s) per gpu%s x %d gpu(s)" % (C, ((", two launches per row for all of them" if (args.nsam <= 4 and not (args.debug & (1 << 23))) else ", one launch per row for all of them") if many else ", one host thread and stream each") if C > 1 else "", world), "log_likelihood_sum": logl_sum},
             "roofline": {"bound": "hbm", "kernel": ("k_pipe (one launch per row: extend workgroups; bookkeeping, ledger and counts ride along)" if args.debug & 16 else ("k_sweep4 (one launch per row: the extend, bookkeeping and draw roles; ledger and counts as k_sweep_blc4 on a second stream)" if args.nsam <= 4 and not (args.debug & (1 << 23)) else "k_sweep (one launch per row: extend workgroups; bookkeeping, ledger and counts ride along)")) if args.pops == 1 and args.nsam <= 8 and not (args.debug & 8) else ("k_row" if args.pops == 1 and args.nsam <= 8 else (("k_sweep_xmp (extend role of the row pipeline; bookkeeping, ledger and counts as k_sweep_blc on a second stream)" if not (args.debug & 16) else "k_extend_mpr (register tree, completes the previous row while loading)") if args.nsam <= 8 and not (args.debug & 3) else "k_extend_mp") if args.pops > 1 else "k_extend"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_launch": alg_bytes,
